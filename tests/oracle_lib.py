@@ -1,0 +1,188 @@
+"""ctypes wrapper around oracle/libpsac_oracle.so (the CPU restatement of psac).
+
+Test infrastructure: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg only -- never from psac_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "libpsac_oracle.so")
+
+
+class Trace(C.Structure):
+    _fields_ = [("h", C.c_uint64), ("unfinished_buckets", C.c_uint64),
+                ("unfinished_elements", C.c_uint64), ("phase", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def build():
+    src = os.path.join(ROOT, "oracle", "psac_ref.cpp")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libpsac_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.psac_ref_fnv64_u64.restype = C.c_uint64
+        _lib.psac_ref_fnv64_u32.restype = C.c_uint64
+        _lib.psac_ref_range_min_u32.restype = C.c_uint32
+        _lib.psac_ref_range_min_u64.restype = C.c_uint64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dt(bits):
+    return np.uint32 if bits == 32 else np.uint64
+
+
+def as_text(x):
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), dtype=np.uint8).copy()
+    if isinstance(x, str):
+        return np.frombuffer(x.encode("latin-1"), dtype=np.uint8).copy()
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def construct(text, bits=32, fast=True, k=0, lcp=True):
+    """psac's suffix_array<>::construct at p=1.  Returns dict(SA, ISA, LCP, trace, k, l)."""
+    t = as_text(text)
+    n = t.size
+    dt = _dt(bits)
+    SA = np.zeros(n, dt); ISA = np.zeros(n, dt)
+    LCP = np.zeros(n, dt) if lcp else None
+    tr = (Trace * 256)()
+    trn = C.c_uint32(0); ku = C.c_uint32(0); lu = C.c_uint32(0)
+    f = getattr(lib(), "psac_ref_construct_u%d" % bits)
+    rc = f(_p(t), C.c_uint64(n), C.c_int(1 if fast else 0), C.c_uint(k), _p(SA), _p(ISA),
+           _p(LCP) if lcp else None, tr, C.c_uint32(256), C.byref(trn), C.byref(ku), C.byref(lu))
+    if rc != 0:
+        raise RuntimeError("oracle construct failed rc=%d" % rc)
+    trace = [(tr[i].h, tr[i].unfinished_buckets, tr[i].unfinished_elements, tr[i].phase)
+             for i in range(min(trn.value, 256))]
+    return dict(SA=SA, ISA=ISA, LCP=LCP, trace=trace, k=ku.value, l=lu.value)
+
+
+def kasai(text, SA, ISA):
+    t = as_text(text)
+    bits = SA.dtype.itemsize * 8
+    out = np.zeros(t.size, SA.dtype)
+    getattr(lib(), "psac_ref_kasai_u%d" % bits)(_p(t), C.c_uint64(t.size), _p(np.ascontiguousarray(SA)),
+                                                 _p(np.ascontiguousarray(ISA)), _p(out))
+    return out
+
+
+def check_sa(text, SA, ISA):
+    t = as_text(text)
+    bits = SA.dtype.itemsize * 8
+    return getattr(lib(), "psac_ref_check_sa_u%d" % bits)(_p(t), C.c_uint64(t.size),
+                                                          _p(np.ascontiguousarray(SA)),
+                                                          _p(np.ascontiguousarray(ISA)))
+
+
+def naive_sa(text, bits=32):
+    t = as_text(text)
+    out = np.zeros(t.size, _dt(bits))
+    getattr(lib(), "psac_ref_naive_sa_u%d" % bits)(_p(t), C.c_uint64(t.size), _p(out))
+    return out
+
+
+def kmers(text, k, bits=32):
+    t = as_text(text)
+    out = np.zeros(t.size, _dt(bits))
+    getattr(lib(), "psac_ref_kmers_u%d" % bits)(_p(t), C.c_uint64(t.size), C.c_uint(k), _p(out))
+    return out
+
+
+def alphabet(text):
+    t = as_text(text)
+    code = np.zeros(256, np.uint16)
+    s = C.c_uint32(0); b = C.c_uint32(0)
+    lib().psac_ref_alphabet(_p(t), C.c_uint64(t.size), _p(code), C.byref(s), C.byref(b))
+    return code, s.value, b.value
+
+
+def optimal_k(word_bits, l, n, k=0):
+    return lib().psac_ref_optimal_k(C.c_uint(word_bits), C.c_uint(l), C.c_uint64(n), C.c_uint(k))
+
+
+def rebucket(b1, b2):
+    bits = b1.dtype.itemsize * 8
+    v1 = np.ascontiguousarray(b1).copy(); v2 = np.ascontiguousarray(b2)
+    ub = C.c_uint64(0); ue = C.c_uint64(0)
+    getattr(lib(), "psac_ref_rebucket_u%d" % bits)(_p(v1), _p(v2), C.c_uint64(v1.size), C.byref(ub), C.byref(ue))
+    return v1, ub.value, ue.value
+
+
+def lcp_bitwise(x, y, bits, k, l):
+    ct = C.c_uint32 if bits == 32 else C.c_uint64
+    return getattr(lib(), "psac_ref_lcp_bitwise_u%d" % bits)(ct(x), ct(y), C.c_uint(k), C.c_uint(l))
+
+
+def leading_zeros(x, bits):
+    ct = C.c_uint32 if bits == 32 else C.c_uint64
+    return getattr(lib(), "psac_ref_leading_zeros_u%d" % bits)(ct(x))
+
+
+def trailing_zeros(x, bits):
+    ct = C.c_uint32 if bits == 32 else C.c_uint64
+    return getattr(lib(), "psac_ref_trailing_zeros_u%d" % bits)(ct(x))
+
+
+def floorlog2(x):
+    return lib().psac_ref_floorlog2(C.c_uint64(x))
+
+
+def ceillog2(x):
+    return lib().psac_ref_ceillog2(C.c_uint64(x))
+
+
+def rand_dna(n, seed):
+    out = np.zeros(n, np.uint8)
+    lib().psac_ref_rand_dna(C.c_uint64(n), C.c_int(seed), _p(out))
+    return out
+
+
+def ansv(values, left, kind, nonsv):
+    """kind: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq (ansv_common.hpp:20-22)."""
+    v = np.ascontiguousarray(values)
+    bits = v.dtype.itemsize * 8
+    out = np.zeros(v.size, np.uint64)
+    getattr(lib(), "psac_ref_ansv_u%d" % bits)(_p(v), C.c_uint64(v.size), C.c_int(1 if left else 0),
+                                               C.c_int(kind), C.c_uint64(nonsv), _p(out))
+    return out
+
+
+def ansv_seq(values, left, nonsv):
+    v = np.ascontiguousarray(values)
+    bits = v.dtype.itemsize * 8
+    out = np.zeros(v.size, np.uint64)
+    getattr(lib(), "psac_ref_ansv_seq_u%d" % bits)(_p(v), C.c_uint64(v.size), C.c_int(1 if left else 0),
+                                                   C.c_uint64(nonsv), _p(out))
+    return out
+
+
+def range_min(values, l, r):
+    v = np.ascontiguousarray(values)
+    bits = v.dtype.itemsize * 8
+    return getattr(lib(), "psac_ref_range_min_u%d" % bits)(_p(v), C.c_uint64(v.size), C.c_uint64(l), C.c_uint64(r))
+
+
+def fnv(arr):
+    a = np.ascontiguousarray(arr)
+    if a.dtype == np.uint32:
+        return lib().psac_ref_fnv64_u32(_p(a), C.c_uint64(a.size))
+    a = a.astype(np.uint64)
+    return lib().psac_ref_fnv64_u64(_p(a), C.c_uint64(a.size))

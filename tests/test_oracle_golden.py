@@ -1,0 +1,174 @@
+"""Pins the CPU oracle (oracle/psac_ref.cpp) against the reference's own
+known-answer vectors and the checksums captured from the reference
+(tests/golden/reference_kat.json; provenance inside)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "reference_kat.json")))
+
+
+def make_input(row):
+    g = row["gen"]
+    if g == "literal":
+        return O.as_text(row["arg"])
+    if g == "rand_dna":
+        return O.rand_dna(row["n"], row["seed"])
+    if g == "cyclic":
+        return inputs.cyclic(row["n"], row["arg"])
+    if g == "tandem_rand_dna":
+        return inputs.tandem(row["n"], row["period"], O.rand_dna(row["period"], row["seed"]))
+    if g == "splitmix_mod127p1":
+        return inputs.bytes_mod127p1(row["n"], row["seed"])
+    if g == "splitmix_dna":
+        return inputs.dna(row["n"], row["seed"])
+    if g == "splitmix_ascii128":
+        return inputs.ascii128(row["n"], row["seed"])
+    raise KeyError(g)
+
+
+def test_mississippi_exact():
+    m = KAT["mississippi"]
+    for bits in (32, 64):
+        for fast in (True, False):
+            r = O.construct(m["text"], bits=bits, fast=fast)
+            assert r["SA"].tolist() == m["SA"]
+            assert r["ISA"].tolist() == m["ISA"]
+            assert r["LCP"].tolist() == m["LCP"]
+
+
+def test_int_alphabet_mississippi_order():
+    # test/test_psac.cpp:277-304 uses an int alphabet; the byte engine sees the
+    # same order after densifying the symbols.
+    m = KAT["int_alphabet_mississippi"]
+    sym = sorted(set(m["text"]))
+    dense = bytes(1 + sym.index(c) for c in m["text"])
+    assert O.construct(dense, bits=32)["SA"].tolist() == m["SA"]
+
+
+def test_bitops_kats():
+    b = KAT["bitops"]
+    for x, bits, exp in b["trailing_zeros"]:
+        assert O.trailing_zeros(int(x, 16), bits) == exp
+    for x, bits, exp in b["leading_zeros"]:
+        assert O.leading_zeros(int(x, 16), bits) == exp
+    for x, y, bits, k, l, exp in b["lcp_bitwise"]:
+        assert O.lcp_bitwise(int(x, 16), int(y, 16), bits, k, l) == exp
+    for x, exp in b["floorlog2"]:
+        assert O.floorlog2(int(x, 16)) == exp
+    for x, exp in b["ceillog2"]:
+        assert O.ceillog2(int(x, 16)) == exp
+
+
+def test_bitops_random_against_naive():
+    # test/test_bitops.cpp:36-48, 62-74: 100000 random words vs bit loops (10000 here)
+    rng = np.random.default_rng(5)
+    for x in rng.integers(1, 2**63, size=10000, dtype=np.uint64).tolist():
+        assert O.leading_zeros(x, 64) == 64 - x.bit_length()
+        assert O.trailing_zeros(x, 64) == (x & -x).bit_length() - 1
+
+
+@pytest.mark.parametrize("row", KAT["checksums"], ids=[r["name"] for r in KAT["checksums"]])
+def test_reference_checksums(row):
+    text = make_input(row)
+    assert text.size == row["n"]
+    bits = 64 if row["name"] in ("rand_dna_66763_23", "ascii128_1M_42", "bytes127_1M_42") else 32
+    r = O.construct(text, bits=bits)
+    assert "%016x" % O.fnv(r["SA"]) == row["sa"]
+    assert "%016x" % O.fnv(r["ISA"]) == row["isa"]
+    assert "%016x" % O.fnv(r["LCP"]) == row["lcp"]
+    assert int(r["LCP"].max()) == row["max_lcp"]
+    assert int(r["LCP"].astype(np.uint64).sum()) == row["sum_lcp"]
+    # independent checks: order property + Kasai (check_suffix_array.hpp:56-88, lcp.hpp:46-77)
+    assert O.check_sa(text, r["SA"], r["ISA"]) == 0
+    assert np.array_equal(O.kasai(text, r["SA"], r["ISA"]), r["LCP"])
+
+
+def test_tandem_round_trace():
+    t = KAT["tandem_trace"]
+    row = [r for r in KAT["checksums"] if r["name"] == "tandem_1M_1024_3"][0]
+    text = make_input(row)
+    r = O.construct(text, bits=32)
+    assert r["k"] == t["k"]
+    doubling = [x for x in r["trace"] if x[3] == 0]
+    assert len(doubling) == t["rounds"]
+    n = t["n"]
+    for i, (h, ub, ue, _) in enumerate(doubling):
+        assert h == t["k"] << i
+        if i < t["rounds"] - 1:
+            assert ub == 1024 and ue == n - 2 * h + 1
+        else:
+            assert ub == 0 and ue == 0
+
+
+@pytest.mark.parametrize("bits,fast,k", [(32, True, 0), (32, True, 3), (32, False, 2), (64, True, 0), (64, True, 3)])
+def test_variants_agree_with_naive(bits, fast, k):
+    # test/test_psac.cpp:131-176 (RandAll) and :250-274 (Lcp1): default k, k=3 (forces
+    # bucket chasing), fast=false with k=2.
+    text = O.rand_dna(20011, 7)
+    r = O.construct(text, bits=bits, fast=fast, k=k)
+    assert np.array_equal(r["SA"], O.naive_sa(text, bits))
+    assert O.check_sa(text, r["SA"], r["ISA"]) == 0
+    assert np.array_equal(O.kasai(text, r["SA"], r["ISA"]), r["LCP"])
+
+
+def test_repeats_dictionary_words():
+    # test/test_psac.cpp:178-224 (RepeatsAll): concatenated dictionary words
+    words = ["helloworld", "blahlablah", "ellow", "worldblah", "rld", "hello"]
+    rng = np.random.default_rng(3)
+    s = "".join(words[i] for i in rng.integers(0, len(words), 3000))
+    for k in (0, 3):
+        r = O.construct(s, bits=64, k=k)
+        assert np.array_equal(r["SA"], O.naive_sa(s, 64))
+        assert np.array_equal(O.kasai(s, r["SA"], r["ISA"]), r["LCP"])
+
+
+def test_small_strings():
+    # test/test_psac.cpp:226-248 (n = 9) plus the degenerate sizes
+    for n in (2, 3, 4, 5, 9, 17):
+        text = O.rand_dna(n, 13)
+        r = O.construct(text, bits=32)
+        assert np.array_equal(r["SA"], O.naive_sa(text, 32)), n
+        assert np.array_equal(O.kasai(text, r["SA"], r["ISA"]), r["LCP"]), n
+    r = O.construct(b"A", bits=32)
+    assert r["SA"].tolist() == [0] and r["ISA"].tolist() == [0] and r["LCP"].tolist() == [0]
+    for s in (b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", b"ABABABABABABABABABABABABABA", b"\x00\x00\x01\x00\x00"):
+        r = O.construct(s, bits=32)
+        assert np.array_equal(r["SA"], O.naive_sa(s, 32))
+        assert np.array_equal(O.kasai(s, r["SA"], r["ISA"]), r["LCP"])
+
+
+def test_ansv_definitions():
+    # test/test_ansv.cpp:255-268 sizes; brute-force definitions
+    rng = np.random.default_rng(11)
+    for n in (8, 137, 1000):
+        v = rng.integers(0, 20, n).astype(np.uint32)
+        NO = 2**64 - 1
+        for left in (True, False):
+            sm = O.ansv(v, left, 0, NO); eq = O.ansv(v, left, 1, NO); fe = O.ansv(v, left, 2, NO)
+            assert np.array_equal(sm, O.ansv_seq(v, left, NO))
+            for i in range(n):
+                rng_idx = range(i - 1, -1, -1) if left else range(i + 1, n)
+                e_sm = e_eq = NO
+                for j in rng_idx:
+                    if e_eq == NO and v[j] <= v[i]:
+                        e_eq = j
+                    if v[j] < v[i]:
+                        e_sm = j
+                        break
+                assert sm[i] == e_sm and eq[i] == e_eq
+                e_fe = e_eq
+                if e_eq != NO:
+                    step = -1 if left else 1
+                    j = e_eq + step
+                    while 0 <= j < n and v[j] >= v[e_eq]:
+                        if v[j] == v[e_eq]:
+                            e_fe = j
+                        j += step
+                assert fe[i] == e_fe
