@@ -1,0 +1,142 @@
+/* psacx.h -- C ABI of the MI355X-native suffix-array / ISA / LCP engine.
+ *
+ * This is the drop-in boundary for the SA+LCP path of patflick/psac.  Each
+ * entry point names the reference interface (file:line under /root/reference)
+ * it stands in for.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PSACX_E* code;
+ *     psacx_strerror() turns a code into text.  Nothing throws across the ABI
+ *     (the reference throws std::runtime_error, suffix_array.hpp:226-227; the
+ *     C++ mirror in include/suffix_array.hpp re-throws from these codes).
+ *   - a psacx_ctx owns one HIP device, one stream and a reusable HBM
+ *     workspace.  It is not re-entrant; use one ctx per host thread / per GPU.
+ *   - "_dev" entry points take DEVICE pointers (text resident in HBM, results
+ *     left in HBM); the plain ones take HOST pointers and stage over PCIe.
+ *   - index type: _u32 needs n <= 2^32 - 2 (idxsort.hpp:39), _u64 needs n < 2^62.
+ */
+#ifndef PSACX_H
+#define PSACX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psacx_ctx psacx_ctx;
+
+enum {
+    PSACX_OK = 0,
+    PSACX_EINVAL = -1,     /* bad argument (null pointer, n == 0, k too large ...) */
+    PSACX_ERANGE = -2,     /* n does not fit the index type */
+    PSACX_ENOMEM = -3,     /* HBM workspace allocation failed */
+    PSACX_EHIP = -4,       /* a HIP runtime call failed (psacx_last_hip_error) */
+    PSACX_EDEVICE = -5,    /* a kernel reported an internal error (look-back timeout) */
+    PSACX_ENOGPU = -6      /* no usable HIP device */
+};
+
+/* flags for psacx_construct_* */
+enum {
+    PSACX_LCP = 1u,        /* also build the LCP array (template flag _CONSTRUCT_LCP,
+                              suffix_array.hpp:170) */
+    PSACX_NO_FAST = 2u,    /* fast_resolval = false (suffix_array.hpp:470): keep sorting
+                              every suffix each round instead of only unresolved buckets */
+    PSACX_PROFILE = 4u     /* bracket every kernel class with HIP events (psacx_get_stats) */
+};
+
+#define PSACX_MAX_ROUNDS 72
+
+typedef struct psacx_round {
+    uint64_t h;                    /* prefix length already sorted when the round started */
+    uint64_t active;               /* suffixes that took part in this round's sort */
+    uint64_t unfinished_buckets;   /* as printed by suffix_array.hpp:416 / :961 */
+    uint64_t unfinished_elements;
+    uint32_t sort_passes;          /* radix passes executed */
+    uint32_t sort_passes_skipped;  /* digits found constant by the histogram */
+} psacx_round;
+
+typedef struct psacx_stats {
+    uint32_t sigma;                /* alphabet.hpp:147-155 */
+    uint32_t bits_per_char;        /* alphabet.hpp:154 */
+    uint32_t k;                    /* kmer.hpp:26-40 */
+    uint32_t n_rounds;
+    psacx_round rounds[PSACX_MAX_ROUNDS];
+    /* event timers, milliseconds, filled when PSACX_PROFILE was set */
+    double ms_total;               /* whole construct call, device side */
+    double ms_alphabet, ms_kmer, ms_sort_hist, ms_sort_scatter, ms_rebucket, ms_isa_scatter,
+           ms_gather, ms_compact, ms_rmq_build, ms_finalize;
+    uint64_t scatter_launches;     /* number of radix scatter-pass kernels launched */
+    uint64_t scatter_records;      /* records moved by them (sum over launches) */
+    uint64_t scatter_bytes;        /* algorithmic bytes: 2 * 3w per record */
+    uint64_t hist_bytes;           /* algorithmic bytes of the histogram kernels: 2w per record */
+    uint64_t workspace_bytes;      /* HBM held by the ctx */
+} psacx_stats;
+
+/* life cycle ------------------------------------------------------------- */
+
+/* Replaces suffix_array(const mxx::comm&) (suffix_array.hpp:174): binds the
+ * engine to HIP device `device` (>= 0).  `stream` may be NULL (the ctx makes
+ * its own) or an existing hipStream_t passed as void*. */
+int psacx_create(psacx_ctx** out, int device, void* stream);
+void psacx_destroy(psacx_ctx* ctx);
+const char* psacx_strerror(int code);
+/* text of the last HIP error seen by this ctx ("" if none) */
+const char* psacx_last_hip_error(const psacx_ctx* ctx);
+/* release the cached HBM workspace (it is re-grown on the next call) */
+int psacx_trim(psacx_ctx* ctx);
+
+/* construction ------------------------------------------------------------
+ * Replace suffix_array<char,index_t,LCP>::construct(begin, end, fast_resolval, k)
+ * (suffix_array.hpp:469-486 -> :365-466) for one rank holding the whole text.
+ *   text  n bytes (any byte values; the alphabet is detected, alphabet.hpp:213-218)
+ *   k     0 = auto (kmer.hpp:26-40), else upper bound on the k-mer length
+ *   SA    out, n entries: local_SA        (suffix_array.hpp:204)
+ *   ISA   out, n entries: local_B, 0-based inverse SA (suffix_array.hpp:206, :460-464)
+ *   LCP   out, n entries or NULL: local_LCP (suffix_array.hpp:209); LCP[0] = 0
+ */
+int psacx_construct_u32(psacx_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t k,
+                        uint32_t flags, uint32_t* SA, uint32_t* ISA, uint32_t* LCP);
+int psacx_construct_u64(psacx_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t k,
+                        uint32_t flags, uint64_t* SA, uint64_t* ISA, uint64_t* LCP);
+int psacx_construct_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k,
+                            uint32_t flags, uint32_t* d_SA, uint32_t* d_ISA, uint32_t* d_LCP);
+int psacx_construct_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k,
+                            uint32_t flags, uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP);
+
+/* statistics of the last construct call on this ctx (iteration log of
+ * suffix_array.hpp:416, section timers of suffix_array.hpp:52-63) */
+int psacx_get_stats(const psacx_ctx* ctx, psacx_stats* out);
+
+/* the rank-pair sort on its own -------------------------------------------
+ * Replaces idxsort_vectors(vec1, vec2, comm) (idxsort.hpp:23-83) at one rank:
+ * sorts records (b1[i], b2[i], i) by (b1, b2); on return b1/b2 hold the sorted
+ * keys and idx the permutation.  Device pointers, n entries each.  key_bits =
+ * number of significant low bits in each key word (0 = all). */
+int psacx_pair_sort_dev_u32(psacx_ctx* ctx, uint32_t* d_b1, uint32_t* d_b2, uint32_t* d_idx,
+                            uint64_t n, uint32_t key_bits);
+int psacx_pair_sort_dev_u64(psacx_ctx* ctx, uint64_t* d_b1, uint64_t* d_b2, uint64_t* d_idx,
+                            uint64_t n, uint32_t key_bits);
+
+/* all nearest smaller values ----------------------------------------------
+ * Replaces ansv<T,left_type,right_type,global_indexing>(in, left, right, comm)
+ * (ansv.hpp:2042-2051) at one rank.  type: 0 nearest_sm, 1 nearest_eq,
+ * 2 furthest_eq (ansv_common.hpp:20-22).  Results are global indices, `nonsv`
+ * where no such element exists.  Host pointers. */
+int psacx_ansv_u32(psacx_ctx* ctx, const uint32_t* in, uint64_t n, int left_type, int right_type,
+                   uint64_t nonsv, uint64_t* left_nsv, uint64_t* right_nsv);
+int psacx_ansv_u64(psacx_ctx* ctx, const uint64_t* in, uint64_t n, int left_type, int right_type,
+                   uint64_t nonsv, uint64_t* left_nsv, uint64_t* right_nsv);
+
+/* device memory helpers for hosts without their own HIP bindings ------------ */
+int psacx_dev_alloc(psacx_ctx* ctx, void** out, uint64_t bytes);
+int psacx_dev_free(psacx_ctx* ctx, void* p);
+int psacx_copy_h2d(psacx_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int psacx_copy_d2h(psacx_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int psacx_sync(psacx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSACX_H */

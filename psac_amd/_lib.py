@@ -1,0 +1,87 @@
+"""Loads libpsacx.so (the HIP engine) and declares the C-ABI of include/psacx.h.
+
+There is no CPU fallback: if the library is missing or no GPU is present the
+calls raise.  When PyTorch is used in the same process it must own the HIP
+runtime, so torch is imported before the library whenever it is installed
+(both resolve libamdhip64.so.7 to one copy).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpsacx.so")
+
+PSACX_LCP = 1
+PSACX_NO_FAST = 2
+PSACX_PROFILE = 4
+PSACX_MAX_ROUNDS = 72
+
+EXPORTS = [
+    "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim",
+    "psacx_construct_u32", "psacx_construct_u64", "psacx_construct_dev_u32", "psacx_construct_dev_u64",
+    "psacx_get_stats", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
+    "psacx_ansv_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
+]
+
+
+class Round(C.Structure):
+    _fields_ = [("h", C.c_uint64), ("active", C.c_uint64), ("unfinished_buckets", C.c_uint64),
+                ("unfinished_elements", C.c_uint64), ("sort_passes", C.c_uint32),
+                ("sort_passes_skipped", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sigma", C.c_uint32), ("bits_per_char", C.c_uint32), ("k", C.c_uint32),
+                ("n_rounds", C.c_uint32), ("rounds", Round * PSACX_MAX_ROUNDS),
+                ("ms_total", C.c_double), ("ms_alphabet", C.c_double), ("ms_kmer", C.c_double),
+                ("ms_sort_hist", C.c_double), ("ms_sort_scatter", C.c_double), ("ms_rebucket", C.c_double),
+                ("ms_isa_scatter", C.c_double), ("ms_gather", C.c_double), ("ms_compact", C.c_double),
+                ("ms_rmq_build", C.c_double), ("ms_finalize", C.c_double),
+                ("scatter_launches", C.c_uint64), ("scatter_records", C.c_uint64),
+                ("scatter_bytes", C.c_uint64), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+
+
+class PsacxError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "psacx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Returns the ctypes handle of libpsacx.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libpsacx.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                          % LIB_PATH)
+    try:                       # let torch's bundled HIP runtime load first if torch is around
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    lib.psacx_create.argtypes = [C.POINTER(vp), i32, vp]
+    lib.psacx_destroy.argtypes = [vp]
+    lib.psacx_destroy.restype = None
+    lib.psacx_strerror.argtypes = [i32]
+    lib.psacx_strerror.restype = C.c_char_p
+    lib.psacx_last_hip_error.argtypes = [vp]
+    lib.psacx_last_hip_error.restype = C.c_char_p
+    lib.psacx_trim.argtypes = [vp]
+    for suf in ("u32", "u64"):
+        for name in ("psacx_construct_", "psacx_construct_dev_"):
+            getattr(lib, name + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
+        getattr(lib, "psacx_pair_sort_dev_" + suf).argtypes = [vp, vp, vp, vp, u64, u32]
+        getattr(lib, "psacx_ansv_" + suf).argtypes = [vp, vp, u64, i32, i32, u64, vp, vp]
+    lib.psacx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.psacx_dev_alloc.argtypes = [vp, C.POINTER(vp), u64]
+    lib.psacx_dev_free.argtypes = [vp, vp]
+    lib.psacx_copy_h2d.argtypes = [vp, vp, vp, u64]
+    lib.psacx_copy_d2h.argtypes = [vp, vp, vp, u64]
+    lib.psacx_sync.argtypes = [vp]
+    _lib = lib
+    return lib

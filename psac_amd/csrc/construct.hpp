@@ -1,0 +1,350 @@
+// construct.hpp -- the prefix-doubling loop on one MI355X.
+//
+// Shape of the reference loop: /root/reference/include/suffix_array.hpp:365-466
+// (k-mer bucketing, then per round shift -> rank-pair sort -> LCP -> rebucket ->
+// SA->ISA) and its sparse tail :1032-1285.  On the GPU both phases are one
+// routine: after the first full (B1,B2) sort only suffixes that still share a
+// bucket are gathered, sorted by (bucket, rank of the suffix h further) and
+// written back in place, so the work per round follows the number of
+// unresolved suffixes.  The final SA / ISA / LCP are identical to the
+// reference's because they are uniquely determined by the text.
+#pragma once
+#include "engine.hpp"
+
+namespace psacx {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+template <typename T> struct Work {
+    T *bsa;
+    SortBufs<T> x, y;
+    T *pos_a, *pos_b;
+    Pyramid<T> pyr;
+    unsigned long long* d_hist256;     // char histogram
+    unsigned long long* d_counters;    // [2] active / unfinished buckets
+    char* d_scan_desc;                 // counter (256 B) + uint64 descriptors
+    size_t scan_desc_bytes;
+    SortScratch sc;
+};
+
+template <typename T>
+size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
+    w.bsa = a.take<T>(n);
+    w.x.k1 = a.take<T>(n); w.x.k2 = a.take<T>(n); w.x.v = a.take<T>(n);
+    w.y.k1 = a.take<T>(n); w.y.k2 = a.take<T>(n); w.y.v = a.take<T>(n);
+    w.pos_a = a.take<T>(n); w.pos_b = a.take<T>(n);
+    w.pyr.nlev = 0;
+    for (int i = 0; i < PYR_MAX; ++i) { w.pyr.lvl[i] = nullptr; w.pyr.len[i] = 0; }
+    if (with_lcp) {
+        w.pyr.lvl[0] = d_lcp; w.pyr.len[0] = n; w.pyr.nlev = 1;
+        uint64_t len = n;
+        while (len > 128 && w.pyr.nlev < PYR_MAX) {
+            len = (len + 63) / 64;
+            w.pyr.lvl[w.pyr.nlev] = a.take<T>(len);
+            w.pyr.len[w.pyr.nlev] = len;
+            w.pyr.nlev++;
+        }
+    }
+    w.d_hist256 = a.take<unsigned long long>(256);
+    w.d_counters = a.take<unsigned long long>(2);
+    w.scan_desc_bytes = 256 + ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t);
+    w.d_scan_desc = a.take<char>(w.scan_desc_bytes);
+    w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+    w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+    w.sc.desc_bytes = sort_desc_bytes(n);
+    w.sc.d_desc = a.take<char>(w.sc.desc_bytes);
+    w.sc.d_err = a.take<unsigned>(64);
+    return a.off;
+}
+
+inline int ensure_pinned(psacx_ctx* c, size_t bytes) {
+    if (c->pinned_bytes >= bytes) return PSACX_OK;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinned_bytes = 0;
+    PSACX_HIP(c, hipHostMalloc((void**)&c->pinned, bytes, hipHostMallocDefault));
+    c->pinned_bytes = bytes;
+    return PSACX_OK;
+}
+
+// alphabet.hpp:147-164 on the host from the device histogram
+inline void build_alphabet(const unsigned long long* hist, CodeTable& tab, uint32_t& sigma, uint32_t& bits) {
+    uint16_t next = 1;
+    for (int ch = 0; ch < 256; ++ch) tab.c[ch] = hist[ch] ? next++ : (uint16_t)0;
+    sigma = next - 1u;
+    uint32_t v = sigma + 1u, b = 0;
+    while ((1u << b) < v) ++b;          // ceil(log2(sigma + 1))
+    bits = b;
+}
+
+// kmer.hpp:26-40 for a single rank
+inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k) {
+    const uint32_t max_k = word_bits / l;
+    if (k == 0 || k > max_k) k = max_k;
+    if ((uint64_t)k >= n) { k = (uint32_t)n; if (k > 1) --k; }
+    return k;
+}
+
+template <typename T>
+int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
+                uint64_t* active, uint64_t* unf_buckets) {
+    unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(c->pinned);   // [2]
+    {
+        ProfScope ps(c, TC_COMPACT);
+        const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+        PSACX_HIP(c, hipMemsetAsync(w.d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+        PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
+                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out,
+                           reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
+                           reinterpret_cast<unsigned*>(w.d_scan_desc), w.d_counters, w.sc.d_err);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    *active = h_cnt[0];
+    *unf_buckets = h_cnt[1];
+    return PSACX_OK;
+}
+
+template <typename T, bool WITH_LCP>
+int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_req, uint32_t flags,
+                  T* d_sa, T* d_isa, T* d_lcp) {
+    const bool no_fast = (flags & PSACX_NO_FAST) != 0;
+    psacx_stats& st = c->stats;
+    PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
+
+    if (n == 1) {
+        PSACX_HIP(c, hipMemsetAsync(d_sa, 0, sizeof(T), c->stream));
+        PSACX_HIP(c, hipMemsetAsync(d_isa, 0, sizeof(T), c->stream));
+        if (WITH_LCP) PSACX_HIP(c, hipMemsetAsync(d_lcp, 0, sizeof(T), c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        st.sigma = 1; st.bits_per_char = 1; st.k = 1;
+        return PSACX_OK;
+    }
+
+    // workspace
+    Work<T> w;
+    { Arena dry(nullptr); carve<T>(dry, w, n, WITH_LCP, d_lcp); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+    Arena ar(c->slab);
+    carve<T>(ar, w, n, WITH_LCP, d_lcp);
+    st.workspace_bytes = c->slab_bytes;
+    w.sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+    w.sc.h_base = w.sc.h_hist + (size_t)MAX_PASSES * RADIX;
+    PSACX_HIP(c, hipMemsetAsync(w.sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
+
+    ProfScope* total = new ProfScope(c, TC_TOTAL);
+    struct TotalGuard { ProfScope*& p; ~TotalGuard() { delete p; p = nullptr; } } tg{total};
+
+    // ---- alphabet (alphabet.hpp:213-218) and k (kmer.hpp:26-40)
+    CodeTable tab;
+    {
+        ProfScope ps(c, TC_ALPHABET);
+        PSACX_HIP(c, hipMemsetAsync(w.d_hist256, 0, 256 * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL((char_hist_kernel<256>), dim3(grid_for(c, n / 16 + 1, 256, 8)), dim3(256), 0, c->stream,
+                           d_text, n, w.d_hist256);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    unsigned long long* h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+    PSACX_HIP(c, hipMemcpyAsync(h_hist, w.d_hist256, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    build_alphabet(h_hist, tab, st.sigma, st.bits_per_char);
+    const uint32_t l = st.bits_per_char;
+    const uint32_t k = choose_k((uint32_t)sizeof(T) * 8, l, n, k_req);
+    st.k = k;
+
+    // ---- initial (B1,B2) = (k-mer at i, k-mer at i+k)  (kmer.hpp:119-177, shifting.hpp:33-122)
+    {
+        ProfScope ps(c, TC_KMER);
+        constexpr int KB = 256, KI = 8;
+        const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
+        hipLaunchKernelGGL((kmer_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n,
+                           tab, k, l, w.x.k1, w.x.k2);
+        PSACX_HIP(c, hipGetLastError());
+    }
+
+    // ---- first rank-pair sort (idxsort.hpp:23-83); payload = text position -> SA
+    psacx_round* r0 = &st.rounds[0];
+    std::memset(r0, 0, sizeof(*r0));
+    SortBufs<T> sorted;
+    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, k * l, d_sa, &sorted, r0));
+
+    // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
+    {
+        ProfScope ps(c, TC_REBUCKET);
+        const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
+                           dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, n, k, l, w.bsa, d_lcp,
+                           reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
+                           reinterpret_cast<unsigned*>(w.d_scan_desc), w.sc.d_err);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    // ---- SA -> ISA (bulk_permute.hpp:14-73)
+    {
+        ProfScope ps(c, TC_ISA_SCATTER);
+        hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa,
+                           w.bsa, n, d_isa);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    if (WITH_LCP) {
+        ProfScope ps(c, TC_RMQ_BUILD);
+        for (int L = 1; L < w.pyr.nlev; ++L) {
+            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, w.pyr.len[L] * 64, 256, 8)), dim3(256), 0,
+                               c->stream, w.pyr.lvl[L - 1], w.pyr.len[L - 1], w.pyr.lvl[L], w.pyr.len[L]);
+            PSACX_HIP(c, hipGetLastError());
+        }
+    }
+
+    // ---- which suffixes still share a bucket (suffix_array.hpp:925-965)
+    uint64_t active = 0, unf_b = 0;
+    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b));
+    r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;
+    st.n_rounds = 1;
+
+    T* pos = w.pos_a;
+    T* pos_next = w.pos_b;
+    const unsigned id_bits = bits_for(n);
+    for (uint64_t h = 2ull * k; unf_b > 0 && h < n; h <<= 1) {
+        const uint64_t cnt = no_fast ? n : active;
+        const T* plist = no_fast ? nullptr : pos;
+        psacx_round* rr = st.n_rounds < PSACX_MAX_ROUNDS ? &st.rounds[st.n_rounds] : nullptr;
+        if (rr) std::memset(rr, 0, sizeof(*rr));
+        {
+            ProfScope ps(c, TC_GATHER);
+            hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(grid_for(c, cnt, 256, 16)), dim3(256), 0, c->stream,
+                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, nullptr, &sorted, rr));
+        T* ids = (sorted.k1 == w.x.k1) ? w.y.k1 : w.x.k1;     // the set not holding the result is free
+        {
+            ProfScope ps(c, TC_REBUCKET);
+            const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+            PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
+            hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
+                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
+                               d_sa, w.bsa, d_isa, w.pyr, ids, reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
+                               reinterpret_cast<unsigned*>(w.d_scan_desc), w.sc.d_err);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        uint64_t nactive = 0;
+        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, pos_next, &nactive, &unf_b));
+        if (rr) {
+            rr->h = h; rr->active = cnt; rr->unfinished_buckets = unf_b; rr->unfinished_elements = nactive;
+            st.n_rounds++;
+        }
+        active = nactive;
+        std::swap(pos, pos_next);
+    }
+
+    // ---- 1-based bucket ids -> 0-based ISA (suffix_array.hpp:460-464)
+    {
+        ProfScope ps(c, TC_FINALIZE);
+        hipLaunchKernelGGL((isa_finalize_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_isa, n);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    delete total; total = nullptr;
+
+    unsigned h_err = 0;
+    PSACX_HIP(c, hipMemcpyAsync(c->pinned, w.sc.d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    h_err = *reinterpret_cast<unsigned*>(c->pinned);
+    if (h_err) return PSACX_EDEVICE;
+    return PSACX_OK;
+}
+
+template <typename T>
+int construct_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t flags, T* d_sa,
+                       T* d_isa, T* d_lcp) {
+    if (!c || !d_text || !d_sa || !d_isa || n == 0) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !d_lcp) return PSACX_EINVAL;
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    if (sizeof(T) == 8 && n >= (1ull << 62)) return PSACX_ERANGE;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    c->profile = (flags & PSACX_PROFILE) != 0;
+    c->ev_used = 0;
+    int rc;
+    if (flags & PSACX_LCP) rc = construct_dev<T, true>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp);
+    else rc = construct_dev<T, false>(c, d_text, n, k, flags, d_sa, d_isa, (T*)nullptr);
+    if (rc == PSACX_OK && c->profile) prof_collect(c);
+    return rc;
+}
+
+// host-pointer form: stage over PCIe, run, copy back
+template <typename T>
+int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp) {
+    if (!c || !text || !sa || !isa || n == 0) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    uint8_t* d_text = nullptr; T *d_sa = nullptr, *d_isa = nullptr, *d_lcp = nullptr;
+    auto cleanup = [&]() {
+        if (d_text) (void)hipFree(d_text); if (d_sa) (void)hipFree(d_sa);
+        if (d_isa) (void)hipFree(d_isa); if (d_lcp) (void)hipFree(d_lcp);
+    };
+    hipError_t e = hipMalloc((void**)&d_text, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sa, n * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_isa, n * sizeof(T));
+    if (e == hipSuccess && (flags & PSACX_LCP)) e = hipMalloc((void**)&d_lcp, n * sizeof(T));
+    if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(io): ") + hipGetErrorString(e); (void)hipGetLastError(); cleanup(); return PSACX_ENOMEM; }
+    int rc = PSACX_OK;
+    e = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); cleanup(); return PSACX_EHIP; }
+    rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp);
+    if (rc == PSACX_OK) {
+        e = hipMemcpyAsync(sa, d_sa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(isa, d_isa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && d_lcp) e = hipMemcpyAsync(lcp, d_lcp, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); rc = PSACX_EHIP; }
+    }
+    cleanup();
+    return rc;
+}
+
+// stand-alone rank-pair sort (idxsort.hpp:23-83): sorts in place, idx receives the permutation
+template <typename T>
+int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t key_bits) {
+    if (!c || !d_b1 || !d_b2 || !d_idx || n == 0) return PSACX_EINVAL;
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
+    Arena dry(nullptr);
+    auto layout = [&](Arena& a, SortBufs<T>& alt, SortScratch& sc, T*& vtmp) {
+        alt.k1 = a.take<T>(n); alt.k2 = a.take<T>(n); alt.v = a.take<T>(n); vtmp = a.take<T>(n);
+        sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+        sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+        sc.desc_bytes = sort_desc_bytes(n);
+        sc.d_desc = a.take<char>(sc.desc_bytes);
+        sc.d_err = a.take<unsigned>(64);
+    };
+    SortBufs<T> alt; SortScratch sc; T* vtmp;
+    layout(dry, alt, sc, vtmp);
+    PSACX_TRY(ensure_slab(c, dry.off + 4096));
+    Arena ar(c->slab);
+    layout(ar, alt, sc, vtmp);
+    sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+    sc.h_base = sc.h_hist + (size_t)MAX_PASSES * RADIX;
+    PSACX_HIP(c, hipMemsetAsync(sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    c->profile = true; c->ev_used = 0;
+    SortBufs<T> in{d_b1, d_b2, vtmp}, res;
+    psacx_round rs; std::memset(&rs, 0, sizeof(rs));
+    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, true, key_bits, nullptr, &res, &rs));
+    if (res.k1 != d_b1) {
+        PSACX_HIP(c, hipMemcpyAsync(d_b1, res.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        PSACX_HIP(c, hipMemcpyAsync(d_b2, res.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    }
+    PSACX_HIP(c, hipMemcpyAsync(d_idx, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    PSACX_HIP(c, hipMemcpyAsync(c->pinned, sc.d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.rounds[0] = rs; c->stats.n_rounds = 1;
+    prof_collect(c);
+    if (*reinterpret_cast<unsigned*>(c->pinned)) return PSACX_EDEVICE;
+    return PSACX_OK;
+}
+
+} // namespace psacx

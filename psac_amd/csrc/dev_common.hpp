@@ -1,0 +1,194 @@
+// dev_common.hpp -- shared device helpers for the psacx HIP engine (gfx950, wave64).
+//
+// Everything here is written for CDNA4 only: 64-lane wavefronts, __ballot()
+// returning a 64-bit mask, per-XCD L2s that are not coherent with each other
+// (inter-workgroup words go through relaxed agent-scope atomics, i.e. sc1
+// accesses that bypass the per-CU L1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psacx {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ unsigned lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+template <typename T> __device__ __forceinline__ T shfl(T v, int src);
+template <> __device__ __forceinline__ uint32_t shfl<uint32_t>(uint32_t v, int src) {
+    return (uint32_t)__shfl((int)v, src, WAVE);
+}
+template <> __device__ __forceinline__ uint64_t shfl<uint64_t>(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, WAVE);
+    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T shfl_up(T v, int d);
+template <> __device__ __forceinline__ uint32_t shfl_up<uint32_t>(uint32_t v, int d) {
+    return (uint32_t)__shfl_up((int)v, d, WAVE);
+}
+template <> __device__ __forceinline__ uint64_t shfl_up<uint64_t>(uint64_t v, int d) {
+    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, WAVE);
+    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T shfl_xor(T v, int m);
+template <> __device__ __forceinline__ uint32_t shfl_xor<uint32_t>(uint32_t v, int m) {
+    return (uint32_t)__shfl_xor((int)v, m, WAVE);
+}
+template <> __device__ __forceinline__ uint64_t shfl_xor<uint64_t>(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, WAVE);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct OpSum {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
+};
+struct OpMax {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; }
+};
+struct OpMin {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? a : b; }
+};
+
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = op(v, shfl_xor<T>(v, m));
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave (identity never needed)
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_scan_inclusive(T v, Op op) {
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        T o = shfl_up<T>(v, d);
+        if (lane >= (unsigned)d) v = op(o, v);
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread.  `smem` needs BLOCK/64 + 1
+// entries of T.  Returns the exclusive prefix; *total gets the block aggregate.
+template <int BLOCK, typename T, typename Op>
+__device__ __forceinline__ T block_scan_exclusive(T v, Op op, T identity, T* smem, T* total) {
+    constexpr int NW = BLOCK / WAVE;
+    const unsigned lane = lane_id();
+    const unsigned wave = threadIdx.x / WAVE;
+    T inc = wave_scan_inclusive<T>(v, op);
+    if (lane == WAVE - 1) smem[wave] = inc;
+    __syncthreads();
+    T wprefix = identity;
+    T tot = identity;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        T s = smem[w];
+        if ((unsigned)w < wave) wprefix = op(wprefix, s);
+        tot = op(tot, s);
+    }
+    T prev = shfl_up<T>(inc, 1);
+    T excl = (lane == 0) ? wprefix : op(wprefix, prev);
+    *total = tot;
+    __syncthreads();   // smem reusable afterwards
+    return excl;
+}
+
+template <int BLOCK, typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T* smem) {
+    constexpr int NW = BLOCK / WAVE;
+    v = wave_reduce<T>(v, op);
+    if (lane_id() == 0) smem[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    T r = smem[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = op(r, smem[w]);
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Decoupled look-back descriptors.  One naturally aligned word carries
+// {status, value}; it is written by ONE relaxed agent-scope store and read by
+// relaxed agent-scope loads, so no fence is needed (the data is the flag).
+// Status 0 = not yet published (arrays are zeroed by hipMemsetAsync before
+// every launch), 1 = tile aggregate, 2 = inclusive prefix.
+// ---------------------------------------------------------------------------
+template <typename D> struct Desc;
+template <> struct Desc<uint64_t> {
+    static constexpr int SHIFT = 62;
+    static constexpr uint64_t MASK = (1ull << 62) - 1ull;
+};
+template <> struct Desc<uint32_t> {
+    static constexpr int SHIFT = 30;
+    static constexpr uint32_t MASK = (1u << 30) - 1u;
+};
+
+template <typename D> __device__ __forceinline__ void desc_store(D* p, unsigned status, D value) {
+    __hip_atomic_store(p, (D)(((D)status << Desc<D>::SHIFT) | (value & Desc<D>::MASK)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename D> __device__ __forceinline__ D desc_load(const D* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A spin that can never hang the GPU: after SPIN_LIMIT polls the kernel raises
+// the error word and carries on with garbage; the host turns it into
+// PSACX_EDEVICE.
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+template <typename D>
+__device__ __forceinline__ D desc_wait(const D* p, unsigned* err) {
+    D d = desc_load<D>(p);
+    unsigned spins = 0;
+    while ((d >> Desc<D>::SHIFT) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        d = desc_load<D>(p);
+        if (++spins > SPIN_LIMIT) { atomicOr(err, 1u); break; }
+    }
+    return d;
+}
+
+// Exclusive prefix of `aggregate` over all earlier tiles, computed by the 64
+// lanes of ONE wave (call from wave 0 with a wave-uniform aggregate).  Publishes
+// this tile's aggregate first and its inclusive prefix at the end.
+template <typename Op>
+__device__ __forceinline__ uint64_t lookback_wave(uint64_t* desc, unsigned tile, uint64_t aggregate,
+                                                  Op op, uint64_t identity, unsigned* err) {
+    const unsigned lane = lane_id();
+    if (tile == 0) {
+        if (lane == 0) desc_store<uint64_t>(desc, 2u, aggregate);
+        return identity;
+    }
+    if (lane == 0) desc_store<uint64_t>(desc + tile, 1u, aggregate);
+    uint64_t excl = identity;
+    long long base = (long long)tile - 1;
+    while (true) {
+        long long t = base - (long long)lane;
+        uint64_t d = (2ull << 62) | (identity & Desc<uint64_t>::MASK);   // before tile 0: inclusive identity
+        if (t >= 0) d = desc_wait<uint64_t>(desc + t, err);
+        const bool inc = (d >> 62) == 2u;
+        const uint64_t incmask = __ballot(inc);
+        const unsigned first = incmask ? (unsigned)__builtin_ctzll(incmask) : 64u;
+        uint64_t v = (lane <= first) ? (d & Desc<uint64_t>::MASK) : identity;
+        excl = op(excl, wave_reduce<uint64_t>(v, op));
+        if (incmask) break;
+        base -= WAVE;
+    }
+    if (lane == 0) desc_store<uint64_t>(desc + tile, 2u, op(excl, aggregate));
+    return excl;
+}
+
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ unsigned clz_t(T x);
+template <> __device__ __forceinline__ unsigned clz_t<uint32_t>(uint32_t x) { return x ? __clz((int)x) : 32u; }
+template <> __device__ __forceinline__ unsigned clz_t<uint64_t>(uint64_t x) { return x ? __clzll((long long)x) : 64u; }
+
+} // namespace psacx

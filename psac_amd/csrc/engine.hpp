@@ -1,0 +1,282 @@
+// engine.hpp -- host side of the psacx engine: context, HBM workspace, the
+// rank-pair sorter driver and the prefix-doubling loop.  Compiled by hipcc into
+// libpsacx.so; the only public surface is include/psacx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/psacx.h"
+#include "radix.hpp"
+#include "sa_kernels.hpp"
+
+namespace psacx {
+
+enum TimerCat {
+    TC_ALPHABET = 0, TC_KMER, TC_SORT_HIST, TC_SORT_SCATTER, TC_REBUCKET, TC_ISA_SCATTER,
+    TC_GATHER, TC_COMPACT, TC_RMQ_BUILD, TC_FINALIZE, TC_TOTAL, TC_COUNT
+};
+
+} // namespace psacx
+
+struct psacx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char* slab = nullptr;
+    size_t slab_bytes = 0;
+    char* pinned = nullptr;          // host-pinned scratch (histograms, counters)
+    size_t pinned_bytes = 0;
+    std::string hip_err;
+    psacx_stats stats;
+    bool profile = false;
+    struct Ev { hipEvent_t a, b; int cat; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    int n_cu = 256;
+};
+
+namespace psacx {
+
+#define PSACX_HIP(ctx, call)                                                              \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            (ctx)->hip_err = std::string(#call) + ": " + hipGetErrorString(e__);          \
+            return PSACX_EHIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define PSACX_TRY(expr)                                                                   \
+    do { int rc__ = (expr); if (rc__ != PSACX_OK) return rc__; } while (0)
+
+struct ProfScope {
+    psacx_ctx* c; size_t idx; bool on;
+    ProfScope(psacx_ctx* ctx, int cat) : c(ctx), idx(0), on(ctx->profile) {
+        if (!on) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            psacx_ctx::Ev e; e.cat = cat;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+            c->ev_pool.push_back(e);
+        }
+        idx = c->ev_used++;
+        c->ev_pool[idx].cat = cat;
+        (void)hipEventRecord(c->ev_pool[idx].a, c->stream);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(c->ev_pool[idx].b, c->stream); }
+};
+
+inline void prof_collect(psacx_ctx* c) {
+    double acc[TC_COUNT];
+    for (int i = 0; i < TC_COUNT; ++i) acc[i] = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) acc[c->ev_pool[i].cat] += ms;
+    }
+    psacx_stats& s = c->stats;
+    s.ms_alphabet = acc[TC_ALPHABET]; s.ms_kmer = acc[TC_KMER]; s.ms_sort_hist = acc[TC_SORT_HIST];
+    s.ms_sort_scatter = acc[TC_SORT_SCATTER]; s.ms_rebucket = acc[TC_REBUCKET];
+    s.ms_isa_scatter = acc[TC_ISA_SCATTER]; s.ms_gather = acc[TC_GATHER]; s.ms_compact = acc[TC_COMPACT];
+    s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
+}
+
+// bump allocator over the ctx slab; a first pass with base == nullptr sizes it
+struct Arena {
+    char* base; size_t off;
+    explicit Arena(char* b) : base(b), off(0) {}
+    template <typename U> U* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        U* p = base ? reinterpret_cast<U*>(base + off) : nullptr;
+        off += count * sizeof(U);
+        return p;
+    }
+};
+
+inline int ensure_slab(psacx_ctx* c, size_t bytes) {
+    if (c->slab_bytes >= bytes) return PSACX_OK;
+    if (c->slab) { (void)hipFree(c->slab); c->slab = nullptr; c->slab_bytes = 0; }
+    hipError_t e = hipMalloc((void**)&c->slab, bytes);
+    if (e != hipSuccess) {
+        c->hip_err = std::string("hipMalloc(workspace): ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return PSACX_ENOMEM;
+    }
+    c->slab_bytes = bytes;
+    return PSACX_OK;
+}
+
+inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8) {
+    uint64_t want = (work_items + block - 1) / block;
+    uint64_t cap = (uint64_t)c->n_cu * per_cu;
+    if (want < 1) want = 1;
+    return (int)std::min<uint64_t>(want, cap);
+}
+
+inline unsigned bits_for(uint64_t max_value) {      // bits needed to hold values 0..max_value
+    unsigned b = 0;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b ? b : 1;
+}
+
+// ----------------------------------------------------------------------------
+// Rank-pair sorter
+// ----------------------------------------------------------------------------
+template <typename T> struct SortBufs { T* k1; T* k2; T* v; };
+
+struct SortScratch {
+    unsigned long long* d_hist;    // [MAX_PASSES][RADIX]
+    unsigned long long* d_base;    // [MAX_PASSES][RADIX]
+    char* d_desc;                  // counter (256 B) + descriptors
+    size_t desc_bytes;
+    unsigned* d_err;
+    unsigned long long* h_hist;    // pinned
+    unsigned long long* h_base;    // pinned
+};
+
+constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
+
+inline size_t sort_desc_bytes(uint64_t n) {
+    return 256 + ((n + SORT_TILE_MIN - 1) / SORT_TILE_MIN + 1) * RADIX * sizeof(uint64_t);
+}
+
+template <typename T, typename D, int BLOCK, int ITEMS>
+inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out,
+                           T* ko_out, T* v_out, uint64_t n, int shift, const unsigned long long* base,
+                           char* desc, unsigned* err) {
+    constexpr int TILE = BLOCK * ITEMS;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    hipLaunchKernelGGL((radix_scatter_kernel<T, D, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
+                       c->stream, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base,
+                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err);
+}
+
+template <typename T> struct ScatterCfg;
+template <> struct ScatterCfg<uint32_t> { static constexpr int DEF = 1; };
+template <> struct ScatterCfg<uint64_t> { static constexpr int DEF = 0; };
+
+inline int sort_cfg_env() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PSACX_SORT_CFG"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
+template <typename T, typename D>
+inline uint64_t dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in,
+                                 T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
+                                 const unsigned long long* base, char* desc, unsigned* err) {
+    // returns the tile size used
+    switch (cfg) {
+        case 0: launch_scatter<T, D, 256, 8>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 8;
+        case 2: launch_scatter<T, D, 512, 8>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 512 * 8;
+        case 3: launch_scatter<T, D, 512, 16>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 512 * 16;
+        case 4: launch_scatter<T, D, 256, 12>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 12;
+        case 1:
+        default: launch_scatter<T, D, 256, 16>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 16;
+    }
+}
+
+inline uint64_t cfg_tile(int cfg) {
+    switch (cfg) { case 0: return 2048; case 2: return 4096; case 3: return 8192; case 4: return 3072; default: return 4096; }
+}
+
+// Sorts `n` records by (k1, k2).  With `iota` the payload read by the first pass
+// is the record index (in.v is only used as scratch).  The sorted arrays end up in
+// *res (the `in` or the `alt` set); when final_v is given the payload of the last
+// executed pass is written there instead and res->v == final_v.
+template <typename T>
+int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
+              unsigned key_bits, T* final_v, SortBufs<T>* res, psacx_round* rs) {
+    if (key_bits == 0 || key_bits > sizeof(T) * 8) key_bits = sizeof(T) * 8;
+    const PassPlan plan = make_plan((int)key_bits);
+    HistArgs ha;
+    ha.n_pass = plan.n_pass;
+    for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
+
+    {
+        ProfScope ps(c, TC_SORT_HIST);
+        PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
+        const int grid = grid_for(c, n, 256, 8);
+        hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n,
+                           ha, sc.d_hist);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    PSACX_HIP(c, hipMemcpyAsync(sc.h_hist, sc.d_hist, sizeof(unsigned long long) * plan.n_pass * RADIX,
+                                hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    c->stats.hist_bytes += 2ull * sizeof(T) * n;
+
+    bool skip[MAX_PASSES];
+    int n_exec = 0;
+    for (int p = 0; p < plan.n_pass; ++p) {
+        const unsigned long long* h = sc.h_hist + (size_t)p * RADIX;
+        unsigned long long run = 0;
+        skip[p] = false;
+        for (int d = 0; d < RADIX; ++d) {
+            if (h[d] == n) skip[p] = true;
+            sc.h_base[(size_t)p * RADIX + d] = run;
+            run += h[d];
+        }
+        if (!skip[p]) ++n_exec;
+    }
+    if (rs) { rs->sort_passes = (uint32_t)n_exec; rs->sort_passes_skipped = (uint32_t)(plan.n_pass - n_exec); }
+    if (n_exec) {
+        PSACX_HIP(c, hipMemcpyAsync(sc.d_base, sc.h_base, sizeof(unsigned long long) * plan.n_pass * RADIX,
+                                    hipMemcpyHostToDevice, c->stream));
+    }
+
+    int cfg = sort_cfg_env();
+    if (cfg < 0) cfg = ScatterCfg<T>::DEF;
+    const bool small_desc = n < (1ull << 30);
+    SortBufs<T> cur = in, oth = alt;
+    int done = 0;
+    for (int p = 0; p < plan.n_pass; ++p) {
+        if (skip[p]) continue;
+        const bool first = (done == 0);
+        ++done;
+        const bool last = (done == n_exec);
+        const T* kd_in = plan.word[p] ? cur.k2 : cur.k1;
+        const T* ko_in = plan.word[p] ? cur.k1 : cur.k2;
+        const T* v_in = (first && iota) ? nullptr : cur.v;
+        T* kd_out = plan.word[p] ? oth.k2 : oth.k1;
+        T* ko_out = plan.word[p] ? oth.k1 : oth.k2;
+        T* v_out = (last && final_v) ? final_v : oth.v;
+        const uint64_t tile = cfg_tile(cfg);
+        const uint64_t ntiles = (n + tile - 1) / tile;
+        const size_t dbytes = 256 + ntiles * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t));
+        PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, dbytes, c->stream));
+        {
+            ProfScope ps(c, TC_SORT_SCATTER);
+            const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
+            if (small_desc)
+                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err);
+            else
+                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        c->stats.scatter_launches += 1;
+        c->stats.scatter_records += n;
+        c->stats.scatter_bytes += 6ull * sizeof(T) * n;
+        std::swap(cur, oth);
+        cur.v = v_out;
+    }
+    if (n_exec == 0) {
+        // every digit constant: the input order is already sorted
+        T* dst = final_v ? final_v : cur.v;
+        if (iota) {
+            hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n);
+            PSACX_HIP(c, hipGetLastError());
+        } else if (dst != cur.v) {
+            PSACX_HIP(c, hipMemcpyAsync(dst, cur.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        }
+        cur.v = dst;
+    }
+    *res = cur;
+    return PSACX_OK;
+}
+
+} // namespace psacx

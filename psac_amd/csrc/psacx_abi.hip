@@ -1,0 +1,141 @@
+// psacx_abi.hip -- extern "C" surface of libpsacx.so (include/psacx.h).
+#include "engine.hpp"
+
+namespace psacx {
+int construct_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int construct_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
+int construct_host_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int construct_host_u64(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
+int pair_sort_dev_u32(psacx_ctx*, uint32_t*, uint32_t*, uint32_t*, uint64_t, uint32_t);
+int pair_sort_dev_u64(psacx_ctx*, uint64_t*, uint64_t*, uint64_t*, uint64_t, uint32_t);
+int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
+int ansv_host_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
+}
+
+using namespace psacx;
+
+extern "C" {
+
+int psacx_create(psacx_ctx** out, int device, void* stream) {
+    if (!out || device < 0) return PSACX_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return PSACX_ENOGPU; }
+    if (device >= count) return PSACX_EINVAL;
+    psacx_ctx* c = new psacx_ctx();
+    c->device = device;
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    if (hipSetDevice(device) != hipSuccess) { delete c; return PSACX_EHIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
+    if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSACX_EHIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return PSACX_OK;
+}
+
+void psacx_destroy(psacx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->slab) (void)hipFree(c->slab);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* psacx_strerror(int code) {
+    switch (code) {
+        case PSACX_OK: return "ok";
+        case PSACX_EINVAL: return "invalid argument";
+        case PSACX_ERANGE: return "input too long for the index type";
+        case PSACX_ENOMEM: return "out of device memory";
+        case PSACX_EHIP: return "HIP runtime error";
+        case PSACX_EDEVICE: return "device-side failure (look-back timeout)";
+        case PSACX_ENOGPU: return "no HIP device available";
+        default: return "unknown error";
+    }
+}
+
+const char* psacx_last_hip_error(const psacx_ctx* c) { return c ? c->hip_err.c_str() : ""; }
+
+int psacx_trim(psacx_ctx* c) {
+    if (!c) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->slab) { PSACX_HIP(c, hipFree(c->slab)); c->slab = nullptr; c->slab_bytes = 0; }
+    return PSACX_OK;
+}
+
+int psacx_construct_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_host_u32(c, t, n, k, f, sa, isa, lcp);
+}
+int psacx_construct_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+    return construct_host_u64(c, t, n, k, f, sa, isa, lcp);
+}
+int psacx_construct_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_dev_u32(c, t, n, k, f, sa, isa, lcp);
+}
+int psacx_construct_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+    return construct_dev_u64(c, t, n, k, f, sa, isa, lcp);
+}
+
+int psacx_get_stats(const psacx_ctx* c, psacx_stats* out) {
+    if (!c || !out) return PSACX_EINVAL;
+    *out = c->stats;
+    return PSACX_OK;
+}
+
+int psacx_pair_sort_dev_u32(psacx_ctx* c, uint32_t* b1, uint32_t* b2, uint32_t* idx, uint64_t n, uint32_t bits) {
+    return pair_sort_dev_u32(c, b1, b2, idx, n, bits);
+}
+int psacx_pair_sort_dev_u64(psacx_ctx* c, uint64_t* b1, uint64_t* b2, uint64_t* idx, uint64_t n, uint32_t bits) {
+    return pair_sort_dev_u64(c, b1, b2, idx, n, bits);
+}
+
+int psacx_ansv_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_host_u32(c, in, n, lt, rt, nonsv, l, r);
+}
+int psacx_ansv_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_host_u64(c, in, n, lt, rt, nonsv, l, r);
+}
+
+int psacx_dev_alloc(psacx_ctx* c, void** out, uint64_t bytes) {
+    if (!c || !out) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) { c->hip_err = std::string("hipMalloc: ") + hipGetErrorString(e); (void)hipGetLastError(); return PSACX_ENOMEM; }
+    return PSACX_OK;
+}
+int psacx_dev_free(psacx_ctx* c, void* p) {
+    if (!c) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_HIP(c, hipFree(p));
+    return PSACX_OK;
+}
+int psacx_copy_h2d(psacx_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+int psacx_copy_d2h(psacx_ctx* c, void* dst, const void* src, uint64_t bytes) {
+    if (!c) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+int psacx_sync(psacx_ctx* c) {
+    if (!c) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,13 @@
+// 32-bit index instantiation of the engine (n <= 2^32 - 2).
+#include "construct.hpp"
+namespace psacx {
+int construct_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_dispatch<uint32_t>(c, t, n, k, f, sa, isa, lcp);
+}
+int construct_host_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_host<uint32_t>(c, t, n, k, f, sa, isa, lcp);
+}
+int pair_sort_dev_u32(psacx_ctx* c, uint32_t* b1, uint32_t* b2, uint32_t* idx, uint64_t n, uint32_t bits) {
+    return pair_sort_dev<uint32_t>(c, b1, b2, idx, n, bits);
+}
+}

@@ -1,0 +1,402 @@
+// sa_kernels.hpp -- the non-sort kernels of the prefix-doubling loop.
+//
+// Reference loops each kernel stands in for (paths under /root/reference/include):
+//   char_hist_kernel        alphabet.hpp:49-59        256-bin byte histogram
+//   kmer_pairs_kernel       kmer.hpp:119-177 + shifting.hpp:33-122 (B2[i] = B[i+k])
+//   rebucket_first_kernel   suffix_array.hpp:1353-1396 (k-mer LCP) + bucketing.hpp:57-123, 21-53
+//   isa_scatter_kernel      bulk_permute.hpp:14-73     ISA[SA[i]] = B[i]
+//   compact_active_kernel   suffix_array.hpp:925-965   get_active
+//   gather_keys_kernel      suffix_array.hpp:972-996   sparse_get_b2 (B2 = ISA[SA+h])
+//   rebucket_refine_kernel  suffix_array.hpp:1092-1157 + :1444-1508 (new ids, LCP = h + range min)
+//   pyramid_level_kernel    rmq.hpp:87-179 / par_rmq.hpp:199-332 (range-minimum structure)
+//   isa_finalize_kernel     suffix_array.hpp:460-464   ISA -= 1
+#pragma once
+#include "dev_common.hpp"
+
+namespace psacx {
+
+struct CodeTable { uint16_t c[256]; };   // codes 1..sigma (sigma may be 256)
+
+// ------------------------------------------------------------------ K1
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void char_hist_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                          unsigned long long* __restrict__ hist) {
+    __shared__ unsigned lh[4][256];
+    for (int i = threadIdx.x; i < 1024; i += BLOCK) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t nvec = ((uintptr_t)text % 16 == 0) ? n / 16 : 0;
+    const uint4* tv = reinterpret_cast<const uint4*>(text);
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    unsigned* my = lh[threadIdx.x & 3];
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) {
+        const uint4 v = tv[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            atomicAdd(&my[w[q] & 255u], 1u);
+            atomicAdd(&my[(w[q] >> 8) & 255u], 1u);
+            atomicAdd(&my[(w[q] >> 16) & 255u], 1u);
+            atomicAdd(&my[w[q] >> 24], 1u);
+        }
+    }
+    for (uint64_t i = nvec * 16 + (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride)
+        atomicAdd(&my[text[i]], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += BLOCK) {
+        const unsigned c = lh[0][i] + lh[1][i] + lh[2][i] + lh[3][i];
+        if (c) atomicAdd(&hist[i], (unsigned long long)c);
+    }
+}
+
+// ------------------------------------------------------------------ K2 (+K3 for round 1)
+// B1[i] = k-mer starting at i, B2[i] = k-mer starting at i+k, codes of l bits,
+// first character most significant, zero past the end of the text.
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void kmer_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                           CodeTable tab, unsigned k, unsigned l,
+                                                           T* __restrict__ B1, T* __restrict__ B2) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int HALO = 2 * 64;             // 2k <= 128 always (k <= 64 / l)
+    __shared__ uint16_t codes[TILE + HALO];
+    __shared__ uint16_t ctab[256];
+    if (threadIdx.x < 256) ctab[threadIdx.x] = tab.c[threadIdx.x];
+    if (BLOCK < 256) for (int i = threadIdx.x + BLOCK; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const unsigned need = TILE + 2 * k;
+    for (unsigned i = threadIdx.x; i < need; i += BLOCK) {
+        const uint64_t g = base + i;
+        codes[i] = g < n ? ctab[text[g]] : (uint16_t)0;
+    }
+    __syncthreads();
+    const T mask = (k * l >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (k * l)) - 1);
+    const unsigned q = threadIdx.x * ITEMS;
+    T c1 = 0, c2 = 0;
+    for (unsigned j = 0; j + 1 < k; ++j) {
+        c1 = (T)(c1 << l) | (T)codes[q + j];
+        c2 = (T)(c2 << l) | (T)codes[q + k + j];
+    }
+    T o1[ITEMS], o2[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        c1 = ((T)(c1 << l) | (T)codes[q + j + k - 1]) & mask;
+        c2 = ((T)(c2 << l) | (T)codes[q + j + 2 * k - 1]) & mask;
+        o1[j] = c1; o2[j] = c2;
+    }
+    const uint64_t e0 = base + q;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (e0 + j < n) { B1[e0 + j] = o1[j]; B2[e0 + j] = o2[j]; }
+    }
+}
+
+// number of equal leading characters of two k-mers (bitops.hpp:170-183)
+template <typename T>
+__device__ __forceinline__ unsigned kmer_lcp(T x, T y, unsigned k, unsigned l) {
+    if (x == y) return k;
+    const unsigned lz = clz_t<T>((T)(x ^ y));
+    return (lz - (unsigned)(sizeof(T) * 8 - k * l)) / l;
+}
+
+// ------------------------------------------------------------------ K6 + K7, first round
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
+__global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
+    const T* __restrict__ S1, const T* __restrict__ S2, uint64_t n, unsigned k, unsigned l,
+    T* __restrict__ Bsa, T* __restrict__ LCP, uint64_t* __restrict__ desc,
+    unsigned* __restrict__ tile_counter, unsigned* __restrict__ err) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ T scan_tmp[BLOCK / WAVE + 1];
+    __shared__ uint64_t s_excl;
+    __shared__ unsigned s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
+
+    T a1[ITEMS], a2[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        a1[j] = e < n ? S1[e] : 0;
+        a2[j] = e < n ? S2[e] : 0;
+    }
+    T p1 = 0, p2 = 0;
+    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; }
+
+    T id[ITEMS];
+    T lc[ITEMS];
+    T run = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        const bool head = (e == 0) || a1[j] != p1 || a2[j] != p2;
+        id[j] = (e < n && head) ? (T)(e + 1) : (T)0;
+        if (WITH_LCP) {
+            T v = (T)n;
+            if (head) {
+                if (e == 0) v = 0;
+                else {
+                    unsigned c = kmer_lcp<T>(p1, a1[j], k, l);
+                    if (c == k) c += kmer_lcp<T>(p2, a2[j], k, l);
+                    v = (T)c;
+                }
+            }
+            lc[j] = v;
+        }
+        p1 = a1[j]; p2 = a2[j];
+        if (id[j] > run) run = id[j];
+    }
+    T agg;
+    T excl = block_scan_exclusive<BLOCK, T>(run, OpMax(), (T)0, scan_tmp, &agg);
+    if (threadIdx.x < WAVE) {
+        const uint64_t te = lookback_wave(desc, tile, (uint64_t)agg, OpMax(), 0ull, err);
+        if (threadIdx.x == 0) s_excl = te;
+    }
+    __syncthreads();
+    T carry = (T)s_excl;
+    if (excl > carry) carry = excl;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        if (id[j] == 0) id[j] = carry; else carry = id[j];
+        if (e < n) {
+            Bsa[e] = id[j];
+            if (WITH_LCP) LCP[e] = lc[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K8
+template <typename T>
+__global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict__ Bsa, uint64_t n,
+                                   T* __restrict__ ISA) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        ISA[SA[i]] = Bsa[i];
+}
+
+// ------------------------------------------------------------------ K12
+// ids: bucket ids of `cnt` consecutive list entries (SA order).  An entry is
+// still active when it shares its id with a neighbour.  pos_in == nullptr means
+// list entry j sits at SA position j.  counters[0] += active entries,
+// counters[1] += buckets with more than one member.
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void compact_active_kernel(
+    const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
+    uint64_t* __restrict__ desc, unsigned* __restrict__ tile_counter,
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ err) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint64_t scan_tmp[BLOCK / WAVE + 1];
+    __shared__ uint64_t s_excl;
+    __shared__ unsigned s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
+
+    T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]
+#pragma unroll
+    for (int j = 0; j < ITEMS + 2; ++j) {
+        const uint64_t e = e0 + j;     // index + 1
+        v[j] = (e >= 1 && e - 1 < cnt) ? ids[e - 1] : (T)0;   // ids are >= 1, 0 never matches
+    }
+    unsigned act = 0, nact = 0, nub = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool in = (e0 + j) < cnt;
+        const bool eqp = in && v[j + 1] == v[j];
+        const bool eqn = in && v[j + 1] == v[j + 2];
+        if (eqp || eqn) { act |= 1u << j; ++nact; }
+        if (!eqp && eqn) ++nub;
+    }
+    uint64_t agg;
+    uint64_t excl = block_scan_exclusive<BLOCK, uint64_t>((uint64_t)nact, OpSum(), 0ull, scan_tmp, &agg);
+    if (threadIdx.x < WAVE) {
+        const uint64_t te = lookback_wave(desc, tile, agg, OpSum(), 0ull, err);
+        if (threadIdx.x == 0) s_excl = te;
+    }
+    // per-block reduction of the bucket count, one atomic per wave
+    const unsigned wub = wave_reduce<uint32_t>(nub, OpSum());
+    if (lane_id() == 0 && wub) atomicAdd(&counters[1], (unsigned long long)wub);
+    if (threadIdx.x == 0 && agg) atomicAdd(&counters[0], (unsigned long long)agg);
+    __syncthreads();
+    uint64_t o = s_excl + excl;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (act & (1u << j)) {
+            const uint64_t e = e0 + j;
+            pos_out[o++] = pos_in ? pos_in[e] : (T)e;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sparse B2 fetch
+template <typename T>
+__global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ SA,
+                                   const T* __restrict__ Bsa, const T* __restrict__ ISA, uint64_t n,
+                                   uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const uint64_t p = pos ? (uint64_t)pos[j] : j;
+        const T sa = SA[p];
+        const uint64_t q = (uint64_t)sa + h;
+        K1[j] = Bsa[p];
+        K2[j] = q < n ? ISA[q] : (T)0;
+        V[j] = sa;
+    }
+}
+
+// ------------------------------------------------------------------ range minimum pyramid
+// lvl[0] is the LCP array itself, lvl[L][i] = min(lvl[L-1][64 i .. 64 i + 63]).
+constexpr int PYR_MAX = 8;
+template <typename T> struct Pyramid {
+    T* lvl[PYR_MAX];
+    uint64_t len[PYR_MAX];
+    int nlev;
+};
+
+template <typename T>
+__global__ void pyramid_level_kernel(const T* __restrict__ in, uint64_t len_in, T* __restrict__ out,
+                                     uint64_t len_out) {
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
+    const unsigned lane = lane_id();
+    for (uint64_t c = wave_id; c < len_out; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        T v = i < len_in ? in[i] : ~(T)0;
+        v = wave_reduce<T>(v, OpMin());
+        if (lane == 0) out[c] = v;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T pyramid_min(const Pyramid<T>& P, uint64_t l, uint64_t r) {
+    T m = ~(T)0;
+    for (int L = 0; L < P.nlev; ++L) {
+        const T* a = P.lvl[L];
+        if (r - l <= 128 || L == P.nlev - 1) {
+            for (uint64_t i = l; i < r; ++i) { const T x = a[i]; m = x < m ? x : m; }
+            return m;
+        }
+        const uint64_t lb = (l + 63) >> 6, rb = r >> 6;
+        for (uint64_t i = l; i < (lb << 6); ++i) { const T x = a[i]; m = x < m ? x : m; }
+        for (uint64_t i = (rb << 6); i < r; ++i) { const T x = a[i]; m = x < m ? x : m; }
+        l = lb; r = rb;
+        if (l >= r) return m;
+    }
+    return m;
+}
+
+template <typename T> __device__ __forceinline__ void atomic_min_t(T* p, T v);
+template <> __device__ __forceinline__ void atomic_min_t<uint32_t>(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+template <> __device__ __forceinline__ void atomic_min_t<uint64_t>(uint64_t* p, uint64_t v) {
+    atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+
+template <typename T>
+__device__ __forceinline__ void pyramid_set(const Pyramid<T>& P, uint64_t p, T v) {
+    P.lvl[0][p] = v;
+    uint64_t q = p;
+    for (int L = 1; L < P.nlev; ++L) {
+        q >>= 6;
+        atomic_min_t<T>(&P.lvl[L][q], v);
+    }
+}
+
+// ------------------------------------------------------------------ K13 + K9-K11, later rounds
+// Sorted active records (K1 = old bucket id, K2 = id of the suffix h further,
+// V = suffix start) and their SA positions pos[] (ascending).  Writes back the
+// refined order and ids, and the LCP of every freshly split boundary.
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
+__global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
+    const T* __restrict__ K1, const T* __restrict__ K2, const T* __restrict__ V,
+    const T* __restrict__ pos, uint64_t cnt, uint64_t n, uint64_t h, T* __restrict__ SA,
+    T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
+    uint64_t* __restrict__ desc, unsigned* __restrict__ tile_counter, unsigned* __restrict__ err) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ T scan_tmp[BLOCK / WAVE + 1];
+    __shared__ uint64_t s_excl;
+    __shared__ unsigned s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
+
+    T a1[ITEMS], a2[ITEMS], ps[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        a1[j] = e < cnt ? K1[e] : 0;
+        a2[j] = e < cnt ? K2[e] : 0;
+        ps[j] = e < cnt ? (pos ? pos[e] : (T)e) : 0;
+    }
+    T p1 = 0, p2 = 0;
+    if (e0 > 0 && e0 - 1 < cnt) { p1 = K1[e0 - 1]; p2 = K2[e0 - 1]; }
+
+    T id[ITEMS];
+    T run = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        const bool in = e < cnt;
+        const bool same1 = (e > 0) && a1[j] == p1;
+        const bool head = !same1 || a2[j] != p2 || a2[j] == 0;
+        id[j] = (in && head) ? (T)(ps[j] + 1) : (T)0;
+        if (WITH_LCP && in && same1 && head) {
+            // boundary that appeared inside an old bucket (suffix_array.hpp:1457-1476)
+            const uint64_t at = (uint64_t)ps[j];
+            if (p2 == 0 || a2[j] == 0) {
+                if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);
+            } else {
+                const T lo = p2 < a2[j] ? p2 : a2[j];
+                const T hi = p2 < a2[j] ? a2[j] : p2;
+                const T m = pyramid_min<T>(pyr, (uint64_t)lo, (uint64_t)hi);
+                pyramid_set<T>(pyr, at, (T)(h + m));
+            }
+        }
+        p1 = a1[j]; p2 = a2[j];
+        if (id[j] > run) run = id[j];
+    }
+    T agg;
+    T excl = block_scan_exclusive<BLOCK, T>(run, OpMax(), (T)0, scan_tmp, &agg);
+    if (threadIdx.x < WAVE) {
+        const uint64_t te = lookback_wave(desc, tile, (uint64_t)agg, OpMax(), 0ull, err);
+        if (threadIdx.x == 0) s_excl = te;
+    }
+    __syncthreads();
+    T carry = (T)s_excl;
+    if (excl > carry) carry = excl;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t e = e0 + j;
+        if (id[j] == 0) id[j] = carry; else carry = id[j];
+        if (e < cnt) {
+            const T sa = V[e];
+            SA[ps[j]] = sa;
+            Bsa[ps[j]] = id[j];
+            ISA[sa] = id[j];
+            ids_out[e] = id[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K14
+template <typename T>
+__global__ void isa_finalize_kernel(T* __restrict__ ISA, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ISA[i] -= 1;
+}
+
+template <typename T>
+__global__ void fill_kernel(T* __restrict__ a, uint64_t n, T v) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
+}
+
+template <typename T>
+__global__ void iota_kernel(T* __restrict__ a, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = (T)i;
+}
+
+} // namespace psacx

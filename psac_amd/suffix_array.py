@@ -1,0 +1,158 @@
+"""Python mirror of the reference's suffix_array<> interface for one rank / one GPU."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import PSACX_LCP, PSACX_NO_FAST, PSACX_PROFILE, PsacxError, Stats
+
+NEAREST_SM, NEAREST_EQ, FURTHEST_EQ = 0, 1, 2      # ansv_common.hpp:20-22
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """One HIP device + stream + reusable HBM workspace (psacx_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.psacx_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise PsacxError(rc, self._lib.psacx_strerror(rc).decode())
+        self.handle = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self._lib.psacx_strerror(rc).decode()
+            detail = self._lib.psacx_last_hip_error(self.handle).decode()
+            raise PsacxError(rc, msg + (" [" + detail + "]" if detail else ""))
+
+    def stats(self):
+        s = Stats()
+        self.check(self._lib.psacx_get_stats(self.handle, C.byref(s)))
+        return s
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.psacx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # raw device memory (for callers without their own HIP bindings)
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self._lib.psacx_dev_alloc(self.handle, C.byref(p), nbytes))
+        return p.value
+
+    def free(self, p):
+        self.check(self._lib.psacx_dev_free(self.handle, C.c_void_p(p)))
+
+    def h2d(self, dptr, arr):
+        a = np.ascontiguousarray(arr)
+        self.check(self._lib.psacx_copy_h2d(self.handle, C.c_void_p(dptr), _ptr(a), a.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self.check(self._lib.psacx_copy_d2h(self.handle, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
+
+
+class SuffixArray(object):
+    """suffix_array<char, index_t, LCP> for a whole text held by one rank.
+
+    Fields follow the reference (suffix_array.hpp:180-212): n, local_size,
+    local_SA, local_B (0-based inverse suffix array after construct()),
+    local_LCP (empty unless lcp=True).  `log` receives the reference's stderr
+    lines ("Alphabet: ...", "iteration h: unfinished buckets = ...").
+    """
+
+    def __init__(self, index_bits=64, lcp=False, ctx=None, log=None):
+        if index_bits not in (32, 64):
+            raise ValueError("index_bits must be 32 or 64")
+        self.index_bits = index_bits
+        self.lcp = bool(lcp)
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.dtype = np.uint32 if index_bits == 32 else np.uint64
+        self.log = log
+        self.n = 0
+        self.local_size = 0
+        self.p = 1
+        self.local_SA = np.zeros(0, self.dtype)
+        self.local_B = np.zeros(0, self.dtype)
+        self.local_LCP = np.zeros(0, self.dtype)
+        self.k = 0
+        self.sigma = 0
+        self.bits_per_char = 0
+        self.rounds = []
+
+    def _flags(self, fast_resolval, profile):
+        f = 0
+        if self.lcp:
+            f |= PSACX_LCP
+        if not fast_resolval:
+            f |= PSACX_NO_FAST
+        if profile:
+            f |= PSACX_PROFILE
+        return f
+
+    def _after(self):
+        s = self.ctx.stats()
+        self.k, self.sigma, self.bits_per_char = s.k, s.sigma, s.bits_per_char
+        self.rounds = [(r.h, r.unfinished_buckets, r.unfinished_elements, r.active, r.sort_passes,
+                        r.sort_passes_skipped) for r in s.rounds[:s.n_rounds]]
+        if self.log is not None:
+            for r in self.rounds:
+                self.log.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % r[:3])
+        return s
+
+    def construct(self, text, fast_resolval=True, k=0, profile=False):
+        """suffix_array::construct(begin, end, fast_resolval, k) (suffix_array.hpp:469-486)."""
+        if isinstance(text, str):
+            text = text.encode("latin-1")
+        t = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) \
+            else np.ascontiguousarray(text, dtype=np.uint8)
+        n = int(t.size)
+        if n == 0:
+            raise ValueError("empty input")
+        if self.index_bits == 32 and n > 0xFFFFFFFE:
+            raise PsacxError(-2, "input too long for the index type")
+        self.n = self.local_size = n
+        self.local_SA = np.empty(n, self.dtype)
+        self.local_B = np.empty(n, self.dtype)
+        self.local_LCP = np.empty(n, self.dtype) if self.lcp else np.zeros(0, self.dtype)
+        fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
+        rc = fn(self.ctx.handle, _ptr(t), n, int(k), self._flags(fast_resolval, profile), _ptr(self.local_SA),
+                _ptr(self.local_B), _ptr(self.local_LCP) if self.lcp else None)
+        self.ctx.check(rc)
+        return self._after()
+
+    def construct_device(self, d_text, n, d_sa, d_isa, d_lcp=None, fast_resolval=True, k=0, profile=False):
+        """Same with every buffer already resident in HBM (raw device addresses)."""
+        fn = getattr(self.ctx._lib, "psacx_construct_dev_u%d" % self.index_bits)
+        rc = fn(self.ctx.handle, C.c_void_p(d_text), int(n), int(k), self._flags(fast_resolval, profile),
+                C.c_void_p(d_sa), C.c_void_p(d_isa), C.c_void_p(d_lcp) if d_lcp else None)
+        self.ctx.check(rc)
+        self.n = self.local_size = int(n)
+        return self._after()
+
+
+def ansv(values, left_type=NEAREST_SM, right_type=NEAREST_SM, nonsv=0, ctx=None):
+    """ansv<T,left_type,right_type>(in, left_nsv, right_nsv, comm) (ansv.hpp:2042-2051), one rank."""
+    v = np.ascontiguousarray(values)
+    if v.dtype not in (np.uint32, np.uint64):
+        raise TypeError("ansv needs uint32 or uint64 input")
+    ctx = ctx if ctx is not None else Context(0)
+    left = np.empty(v.size, np.uint64)
+    right = np.empty(v.size, np.uint64)
+    fn = getattr(ctx._lib, "psacx_ansv_u%d" % (v.dtype.itemsize * 8))
+    ctx.check(fn(ctx.handle, _ptr(v), v.size, int(left_type), int(right_type), int(nonsv), _ptr(left), _ptr(right)))
+    return left, right

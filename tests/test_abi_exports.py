@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every
+symbol include/psacx.h declares; no compute call is made (there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "psacx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(psacx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from psac_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_strerror_and_no_gpu_behaviour():
+    import ctypes as C
+    from psac_amd import _lib
+    lib = _lib.load()
+    assert lib.psacx_strerror(0) == b"ok"
+    assert lib.psacx_strerror(-2) == b"input too long for the index type"
+    assert lib.psacx_create(None, 0, None) == -1
+    import torch
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert lib.psacx_create(C.byref(h), 0, None) == -6      # PSACX_ENOGPU: fails loudly, no CPU fallback
+
+
+def test_product_does_not_touch_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "psac_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if "oracle" in txt.lower() and f not in ("_lib.py",):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
