@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- SA+LCP construction throughput of the HIP engine on MI355X.
+
+One "step" = one full suffix-array + inverse-SA + LCP construction of the
+synthetic text, text already resident in HBM, results left in HBM.
+
+N = 1 workload (BASELINE.json configs[1]): 256 MiB random DNA (sigma = 4,
+splitmix64 seed 1), uint32 indices, SA + LCP.
+
+Prints ONE JSON line (rank 0): metric MChars/s, plus
+  roofline     -- the dominant kernel (the radix scatter pass of the rank-pair
+                  sort): algorithmic bytes (6w per record per pass)
+                  / HIP-event time of those launches inside the timed region
+  cpu_baseline -- the CPU oracle (a port of psac's algorithm, 1 thread) timed on
+                  this box's host on a bounded sample of the same kind of text.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 28, help="characters per GPU")
+    ap.add_argument("--index", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--alphabet", default="dna", choices=("dna", "ascii128", "tandem"))
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="characters for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-lcp", action="store_true")
+    return ap.parse_args()
+
+
+def make_text(kind, n, seed):
+    import inputs
+    if kind == "dna":
+        return inputs.dna(n, seed)
+    if kind == "ascii128":
+        return inputs.ascii128(n, seed)
+    return inputs.tandem(n, 1024, inputs.dna(1024, seed))
+
+
+def cpu_baseline(kind, sample, seed, bits):
+    """psac's algorithm restated on the CPU (oracle/psac_ref.cpp), one thread."""
+    import oracle_lib as O
+    text = make_text(kind, sample, seed)
+    t0 = time.perf_counter()
+    O.construct(text, bits=bits, lcp=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample / dt / 1e6, 3), "unit": "MChars/s", "cores": 1, "kind": "port",
+            "sample": "%d chars of the same generator (%s, seed %d), SA+LCP, uint%d, %.1f s"
+                      % (sample, kind, seed, bits, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import psac_amd
+
+    n = a.n
+    bits = a.index
+    w = bits // 8
+    ctx = psac_amd.Context(local_rank)
+    text = make_text(a.alphabet, n, a.seed + rank)
+    d_text = ctx.alloc(n)
+    ctx.h2d(d_text, text)
+    d_sa = ctx.alloc(n * w); d_isa = ctx.alloc(n * w); d_lcp = ctx.alloc(n * w)
+    sa = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=ctx)
+
+    def step(profile):
+        return sa.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp, profile=profile)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.check(ctx._lib.psacx_sync(ctx.handle))
+
+    for _ in range(a.warmup):
+        step(False)
+    barrier()
+    scat_ms = 0.0; scat_bytes = 0; scat_launches = 0; hist_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        s = step(True)
+        scat_ms += s.ms_sort_scatter; scat_bytes += s.scatter_bytes; scat_launches += s.scatter_launches
+        hist_ms += s.ms_sort_hist
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity on the result of the last step (cheap device->host spot check)
+    head = np.empty(4, np.uint32 if bits == 32 else np.uint64)
+    ctx.d2h(head, d_lcp if not a.no_lcp else d_sa)
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * n * a.steps / dt / 1e6
+        achieved = scat_bytes / (scat_ms * 1e-3) / 1e9 if scat_ms > 0 else 0.0
+        s_last = s
+        out = {
+            "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
+            "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u%d" % bits, "data": "synthetic",
+            "config": {"workload": "%d MiB random %s (splitmix64 seed %d), uint%d indices, SA+%s on %d x MI355X"
+                                   % (n >> 20, a.alphabet, a.seed, bits, "ISA" if a.no_lcp else "ISA+LCP", world),
+                       "n_per_gpu": n, "k": int(s_last.k), "bits_per_char": int(s_last.bits_per_char),
+                       "rounds": int(s_last.n_rounds),
+                       "parallelism": "1 process per GPU" if world == 1 else "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel (one 8-bit digit pass of the (B1,B2,idx) sort)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "avg_launch_ms": round(scat_ms / max(scat_launches, 1), 4),
+                         "launches_per_step": scat_launches // max(a.steps, 1),
+                         "bytes_per_record_per_pass": 6 * w, "traffic": None},
+            "phase_ms_last_step": {"total": round(s_last.ms_total, 3), "alphabet": round(s_last.ms_alphabet, 3),
+                                   "kmer": round(s_last.ms_kmer, 3), "sort_hist": round(s_last.ms_sort_hist, 3),
+                                   "sort_scatter": round(s_last.ms_sort_scatter, 3),
+                                   "rebucket": round(s_last.ms_rebucket, 3), "isa_scatter": round(s_last.ms_isa_scatter, 3),
+                                   "gather": round(s_last.ms_gather, 3), "compact": round(s_last.ms_compact, 3),
+                                   "rmq_build": round(s_last.ms_rmq_build, 3), "finalize": round(s_last.ms_finalize, 3)},
+        }
+        if a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)
+        print(json.dumps(out))
+    for p in (d_text, d_sa, d_isa, d_lcp):
+        ctx.free(p)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
