@@ -56,6 +56,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
     w.sc.desc_bytes = sort_desc_bytes(n);
     w.sc.d_desc = a.take<char>(w.sc.desc_bytes);
     w.sc.d_err = a.take<unsigned>(64);
+    w.sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     return a.off;
 }
 
@@ -239,12 +240,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         std::swap(pos, pos_next);
     }
 
-    // ---- 1-based bucket ids -> 0-based ISA (suffix_array.hpp:460-464)
-    {
-        ProfScope ps(c, TC_FINALIZE);
-        hipLaunchKernelGGL((isa_finalize_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_isa, n);
-        PSACX_HIP(c, hipGetLastError());
-    }
+    // ISA already holds 0-based ranks (the -1 of suffix_array.hpp:460-464 is applied on every write)
     delete total; total = nullptr;
 
     unsigned h_err = 0;
@@ -320,6 +316,7 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
         sc.desc_bytes = sort_desc_bytes(n);
         sc.d_desc = a.take<char>(sc.desc_bytes);
         sc.d_err = a.take<unsigned>(64);
+        sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     };
     SortBufs<T> alt; SortScratch sc; T* vtmp;
     layout(dry, alt, sc, vtmp);

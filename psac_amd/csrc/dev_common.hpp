@@ -187,6 +187,56 @@ __device__ __forceinline__ uint64_t lookback_wave(uint64_t* desc, unsigned tile,
 }
 
 // ---------------------------------------------------------------------------
+// ITEMS consecutive elements per thread, moved as 16-byte vectors when the run is
+// complete and the address is 16-byte aligned (always true for workspace arrays
+// and tile-aligned offsets), element-wise with bounds checks otherwise.
+template <typename T, int ITEMS>
+__device__ __forceinline__ void load_run(const T* __restrict__ p, uint64_t e0, uint64_t n, T (&out)[ITEMS], T fill) {
+    constexpr int PER = 16 / sizeof(T);
+    static_assert(ITEMS % PER == 0, "ITEMS must cover whole 16-byte vectors");
+    const T* q = p + e0;
+    if (e0 + ITEMS <= n && (reinterpret_cast<uintptr_t>(q) & 15u) == 0) {
+        const uint4* v = reinterpret_cast<const uint4*>(q);
+#pragma unroll
+        for (int i = 0; i < ITEMS / PER; ++i) {
+            const uint4 x = v[i];
+            if constexpr (sizeof(T) == 4) {
+                out[i * 4 + 0] = (T)x.x; out[i * 4 + 1] = (T)x.y; out[i * 4 + 2] = (T)x.z; out[i * 4 + 3] = (T)x.w;
+            } else {
+                out[i * 2 + 0] = (T)(((uint64_t)x.y << 32) | x.x);
+                out[i * 2 + 1] = (T)(((uint64_t)x.w << 32) | x.z);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) out[i] = (e0 + i < n) ? q[i] : fill;
+    }
+}
+
+template <typename T, int ITEMS>
+__device__ __forceinline__ void store_run(T* __restrict__ p, uint64_t e0, uint64_t n, const T (&in)[ITEMS]) {
+    constexpr int PER = 16 / sizeof(T);
+    T* q = p + e0;
+    if (e0 + ITEMS <= n && (reinterpret_cast<uintptr_t>(q) & 15u) == 0) {
+        uint4* v = reinterpret_cast<uint4*>(q);
+#pragma unroll
+        for (int i = 0; i < ITEMS / PER; ++i) {
+            uint4 x;
+            if constexpr (sizeof(T) == 4) {
+                x.x = (uint32_t)in[i * 4 + 0]; x.y = (uint32_t)in[i * 4 + 1];
+                x.z = (uint32_t)in[i * 4 + 2]; x.w = (uint32_t)in[i * 4 + 3];
+            } else {
+                const uint64_t a = (uint64_t)in[i * 2 + 0], b = (uint64_t)in[i * 2 + 1];
+                x.x = (uint32_t)a; x.y = (uint32_t)(a >> 32); x.z = (uint32_t)b; x.w = (uint32_t)(b >> 32);
+            }
+            v[i] = x;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) if (e0 + i < n) q[i] = in[i];
+    }
+}
+
 template <typename T> __device__ __forceinline__ unsigned clz_t(T x);
 template <> __device__ __forceinline__ unsigned clz_t<uint32_t>(uint32_t x) { return x ? __clz((int)x) : 32u; }
 template <> __device__ __forceinline__ unsigned clz_t<uint64_t>(uint64_t x) { return x ? __clzll((long long)x) : 64u; }

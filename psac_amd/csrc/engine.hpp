@@ -136,6 +136,7 @@ struct SortScratch {
     unsigned* d_err;
     unsigned long long* h_hist;    // pinned
     unsigned long long* h_base;    // pinned
+    unsigned long long* d_dbg;     // phase stamps of sampled tiles (PSACX_SORT_DEBUG), may be null
 };
 
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
@@ -147,12 +148,12 @@ inline size_t sort_desc_bytes(uint64_t n) {
 template <typename T, typename D, int BLOCK, int ITEMS>
 inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out,
                            T* ko_out, T* v_out, uint64_t n, int shift, const unsigned long long* base,
-                           char* desc, unsigned* err) {
+                           char* desc, unsigned* err, unsigned long long* dbg) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     hipLaunchKernelGGL((radix_scatter_kernel<T, D, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
                        c->stream, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base,
-                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err);
+                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err, dbg);
 }
 
 template <typename T> struct ScatterCfg;
@@ -165,23 +166,33 @@ inline int sort_cfg_env() {
     return v;
 }
 
-template <typename T, typename D>
-inline uint64_t dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in,
-                                 T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
-                                 const unsigned long long* base, char* desc, unsigned* err) {
-    // returns the tile size used
-    switch (cfg) {
-        case 0: launch_scatter<T, D, 256, 8>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 8;
-        case 2: launch_scatter<T, D, 512, 8>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 512 * 8;
-        case 3: launch_scatter<T, D, 512, 16>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 512 * 16;
-        case 4: launch_scatter<T, D, 256, 12>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 12;
-        case 1:
-        default: launch_scatter<T, D, 256, 16>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err); return 256 * 16;
-    }
-}
+struct ScatterShape { int block, items; };
+// scatter configurations selectable with PSACX_SORT_CFG (tuning aid)
+static const ScatterShape kShapes[] = {{256, 8}, {256, 16}, {512, 8}, {512, 16}, {256, 12}, {1024, 4}, {1024, 8}, {512, 12}};
+constexpr int N_SHAPES = 8;
 
 inline uint64_t cfg_tile(int cfg) {
-    switch (cfg) { case 0: return 2048; case 2: return 4096; case 3: return 8192; case 4: return 3072; default: return 4096; }
+    if (cfg < 0 || cfg >= N_SHAPES) cfg = 1;
+    return (uint64_t)kShapes[cfg].block * kShapes[cfg].items;
+}
+
+template <typename T, typename D>
+inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in,
+                             T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
+                             const unsigned long long* base, char* desc, unsigned* err, unsigned long long* dbg) {
+#define PSACX_SC(B, I) launch_scatter<T, D, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, dbg)
+    switch (cfg) {
+        case 0: PSACX_SC(256, 8); break;
+        case 2: PSACX_SC(512, 8); break;
+        case 3: PSACX_SC(512, 16); break;
+        case 4: PSACX_SC(256, 12); break;
+        case 5: PSACX_SC(1024, 4); break;
+        case 6: PSACX_SC(1024, 8); break;
+        case 7: PSACX_SC(512, 12); break;
+        case 1:
+        default: PSACX_SC(256, 16); break;
+    }
+#undef PSACX_SC
 }
 
 // Sorts `n` records by (k1, k2).  With `iota` the payload read by the first pass
@@ -253,10 +264,21 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             ProfScope ps(c, TC_SORT_SCATTER);
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             if (small_desc)
-                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err);
+                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg);
             else
-                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err);
+                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg);
             PSACX_HIP(c, hipGetLastError());
+        }
+        if (sc.d_dbg && ntiles >= 64) {
+            // tuning aid: average shader-clock span of each phase over the sampled tiles
+            const size_t ns = (size_t)(ntiles / 64);
+            std::vector<unsigned long long> h(ns * 8);
+            PSACX_HIP(c, hipMemcpyAsync(h.data(), sc.d_dbg, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < ns; ++i) for (int q = 0; q < 6; ++q) acc[q] += (double)(h[i * 8 + q + 1] - h[i * 8 + q]);
+            fprintf(stderr, "[psacx sort dbg] pass %d n=%llu tiles=%llu cycles/tile: load+rank %.0f scan %.0f lookback %.0f key %.0f key2 %.0f val %.0f\n",
+                    p, (unsigned long long)n, (unsigned long long)ntiles, acc[0] / ns, acc[1] / ns, acc[2] / ns, acc[3] / ns, acc[4] / ns, acc[5] / ns);
         }
         c->stats.scatter_launches += 1;
         c->stats.scatter_records += n;

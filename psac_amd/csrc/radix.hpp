@@ -84,48 +84,62 @@ __device__ __forceinline__ uint64_t match_any8(unsigned d, bool valid) {
 // T: record word type.  D: look-back descriptor word (uint32_t when n < 2^30).
 // kd_*: the key word that carries this pass's digit; ko_*: the other key word;
 // v_in may be null, in which case the payload is the record's global index.
-template <typename T, typename D, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
+// dbg (optional): every 64th tile stores shader-clock stamps of its phases.
+template <typename T, int TILE, int NW> struct ScatterShared {
+    T stage[TILE];
+    uint8_t sdig[TILE];          // digit of the record at each tile-sorted position
+    unsigned wcnt[NW * RADIX];   // per-wave digit counters -> per-wave exclusive bases
+    unsigned bstart[RADIX];      // tile-local start of each digit
+    T goff[RADIX];               // global offset of digit run minus bstart (wraps)
+    unsigned scan_tmp[NW + 1];
+    unsigned s_tile;
+};
+
+// FULL: the tile holds exactly TILE records, so no bounds guards are compiled in.
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL>
+__device__ __forceinline__ void radix_scatter_tile(
+    ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
-    T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
-    const unsigned long long* __restrict__ digit_base, D* __restrict__ desc,
-    unsigned* __restrict__ tile_counter, unsigned* __restrict__ err) {
+    T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
+    const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
+    unsigned long long* __restrict__ dbg) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
-    static_assert(BLOCK >= RADIX, "one thread per digit needed");
-
-    __shared__ T stage[TILE];
-    __shared__ unsigned wcnt[NW * RADIX];   // per-wave digit counters -> per-wave exclusive bases
-    __shared__ unsigned bstart[RADIX];      // tile-local start of each digit
-    __shared__ T goff[RADIX];               // global offset of digit run minus bstart (wraps)
-    __shared__ unsigned scan_tmp[NW + 1];
-    __shared__ unsigned s_tile;
+    T* const stage = sh.stage;
+    uint8_t* const sdig = sh.sdig;
+    unsigned* const wcnt = sh.wcnt;
+    unsigned* const bstart = sh.bstart;
+    T* const goff = sh.goff;
+    unsigned* const scan_tmp = sh.scan_tmp;
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = lane_id();
     const unsigned wave = tid / WAVE;
-
-    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
-    for (int i = tid; i < NW * RADIX; i += BLOCK) wcnt[i] = 0;
-    __syncthreads();
-    const unsigned tile = s_tile;
+    const bool stamp = dbg != nullptr && (tile & 63u) == 0 && tid == 0;
+    unsigned long long* mydbg = dbg + (size_t)(tile >> 6) * 8;
+    if (stamp) mydbg[0] = __builtin_amdgcn_s_memtime();
     const uint64_t base = (uint64_t)tile * TILE;
-    const uint64_t remain = n - base;
-    const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
 
     // wave-striped load: record (wave, i, lane) = base + wave*64*ITEMS + i*64 + lane
+    const T* __restrict__ pkd = kd_in + base;
+    const T* __restrict__ pko = ko_in + base;
+    const T* __restrict__ pv = v_in ? v_in + base : nullptr;
     T kd[ITEMS], ko[ITEMS], vv[ITEMS];
     const unsigned wbase = wave * (WAVE * ITEMS) + lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
-        if (loc < count) {
-            kd[i] = kd_in[base + loc];
-            ko[i] = ko_in[base + loc];
-            vv[i] = v_in ? v_in[base + loc] : (T)(base + loc);
-        } else {
-            kd[i] = 0; ko[i] = 0; vv[i] = 0;
-        }
+        kd[i] = (FULL || loc < count) ? pkd[loc] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = wbase + i * WAVE;
+        ko[i] = (FULL || loc < count) ? pko[loc] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = wbase + i * WAVE;
+        vv[i] = pv ? ((FULL || loc < count) ? pv[loc] : (T)0) : (T)(base + loc);
     }
 
     // rank inside the wave, round by round (keeps the sort stable)
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const bool valid = (wbase + i * WAVE) < count;
+        const bool valid = FULL || (wbase + i * WAVE) < count;
         const unsigned d = (unsigned)(kd[i] >> shift) & (RADIX - 1);
         const uint64_t m = match_any8(d, valid);
         unsigned prior = 0;
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
         rank[i] = prior + (unsigned)__builtin_popcountll(m & lt);
     }
     __syncthreads();
+    if (stamp) mydbg[1] = __builtin_amdgcn_s_memtime();
 
     // per digit: exclusive bases over waves, tile total, look-back
     unsigned tot = 0;
@@ -157,73 +172,98 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
             wcnt[w * RADIX + tid] = tot;
             tot += c;
         }
+        // publish the tile aggregate as early as possible
+        desc_store<D>(desc + (uint64_t)tile * RADIX + tid, tile == 0 ? 2u : 1u, (D)tot);
     }
     unsigned tile_total;
     unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tid < RADIX ? tot : 0u, OpSum(), 0u, scan_tmp, &tile_total);
+    if (stamp) mydbg[2] = __builtin_amdgcn_s_memtime();
     if (tid < RADIX) {
         bstart[tid] = bs;
-        D* my = desc + (uint64_t)tile * RADIX + tid;
         uint64_t excl = 0;
-        if (tile == 0) {
-            desc_store<D>(my, 2u, (D)tot);
-        } else {
-            desc_store<D>(my, 1u, (D)tot);
+        if (tile != 0) {
             long long t = (long long)tile - 1;
+            const D* dp = desc + tid;
+            // two predecessors per step: the second load is speculative and hides one round trip
             while (t >= 0) {
-                const D dsc = desc_wait<D>(desc + (uint64_t)t * RADIX + tid, err);
-                excl += (uint64_t)(dsc & Desc<D>::MASK);
-                if ((dsc >> Desc<D>::SHIFT) == 2u) break;
-                --t;
+                D d0 = desc_load<D>(dp + (uint64_t)t * RADIX);
+                D d1 = t > 0 ? desc_load<D>(dp + (uint64_t)(t - 1) * RADIX) : (D)0;
+                if ((d0 >> Desc<D>::SHIFT) == 0) d0 = desc_wait<D>(dp + (uint64_t)t * RADIX, err);
+                excl += (uint64_t)(d0 & Desc<D>::MASK);
+                if ((d0 >> Desc<D>::SHIFT) == 2u) break;
+                if (t == 0) break;
+                if ((d1 >> Desc<D>::SHIFT) == 0) d1 = desc_wait<D>(dp + (uint64_t)(t - 1) * RADIX, err);
+                excl += (uint64_t)(d1 & Desc<D>::MASK);
+                if ((d1 >> Desc<D>::SHIFT) == 2u) break;
+                t -= 2;
             }
-            desc_store<D>(my, 2u, (D)(excl + tot));
+            desc_store<D>(desc + (uint64_t)tile * RADIX + tid, 2u, (D)(excl + tot));
         }
         goff[tid] = (T)((uint64_t)digit_base[tid] + excl - (uint64_t)bs);
     }
     __syncthreads();
+    if (stamp) mydbg[3] = __builtin_amdgcn_s_memtime();
 
-    // final tile-local position of every record
+    // final tile-local position of every record; stage the digit word and the digit
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = (unsigned)(kd[i] >> shift) & (RADIX - 1);
         rank[i] += bstart[d] + mycnt[d];
+        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; sdig[rank[i]] = (uint8_t)d; }
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (FULL || p < count) kd_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+    }
+    __syncthreads();
+    if (stamp) mydbg[4] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = ko[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+    }
+    __syncthreads();
+    if (stamp) mydbg[5] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = vv[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (FULL || p < count) v_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+    }
+    if (stamp) mydbg[6] = __builtin_amdgcn_s_memtime();
+}
 
-    // move the three words through LDS one after the other
-    T dest[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if ((wbase + i * WAVE) < count) stage[rank[i]] = kd[i];
+template <typename T, typename D, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
+    const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
+    T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
+    const unsigned long long* __restrict__ digit_base, D* __restrict__ desc,
+    unsigned* __restrict__ tile_counter, unsigned* __restrict__ err,
+    unsigned long long* __restrict__ dbg) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int NW = BLOCK / WAVE;
+    static_assert(BLOCK >= RADIX, "one thread per digit needed");
+    __shared__ ScatterShared<T, TILE, NW> sh;
+    if (threadIdx.x == 0) sh.s_tile = atomicAdd(tile_counter, 1u);
+    for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned p = tid + j * BLOCK;
-        if (p < count) {
-            const T x = stage[p];
-            const unsigned d = (unsigned)(x >> shift) & (RADIX - 1);
-            dest[j] = (T)(goff[d] + (T)p);
-            kd_out[dest[j]] = x;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if ((wbase + i * WAVE) < count) stage[rank[i]] = ko[i];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned p = tid + j * BLOCK;
-        if (p < count) ko_out[dest[j]] = stage[p];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if ((wbase + i * WAVE) < count) stage[rank[i]] = vv[i];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned p = tid + j * BLOCK;
-        if (p < count) v_out[dest[j]] = stage[p];
-    }
+    const unsigned tile = sh.s_tile;
+    const uint64_t remain = n - (uint64_t)tile * TILE;
+    if (remain >= (uint64_t)TILE)
+        radix_scatter_tile<T, D, BLOCK, ITEMS, true>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out, ko_out,
+                                                     v_out, shift, digit_base, desc, err, dbg);
+    else
+        radix_scatter_tile<T, D, BLOCK, ITEMS, false>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out, ko_out,
+                                                      v_out, shift, digit_base, desc, err, dbg);
 }
 
 } // namespace psacx

@@ -84,10 +84,8 @@ __global__ __launch_bounds__(BLOCK) void kmer_pairs_kernel(const uint8_t* __rest
         o1[j] = c1; o2[j] = c2;
     }
     const uint64_t e0 = base + q;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (e0 + j < n) { B1[e0 + j] = o1[j]; B2[e0 + j] = o2[j]; }
-    }
+    store_run<T, ITEMS>(B1, e0, n, o1);
+    store_run<T, ITEMS>(B2, e0, n, o2);
 }
 
 // number of equal leading characters of two k-mers (bitops.hpp:170-183)
@@ -114,12 +112,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T a1[ITEMS], a2[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint64_t e = e0 + j;
-        a1[j] = e < n ? S1[e] : 0;
-        a2[j] = e < n ? S2[e] : 0;
-    }
+    load_run<T, ITEMS>(S1, e0, n, a1, (T)0);
+    load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; }
 
@@ -157,13 +151,10 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     if (excl > carry) carry = excl;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const uint64_t e = e0 + j;
         if (id[j] == 0) id[j] = carry; else carry = id[j];
-        if (e < n) {
-            Bsa[e] = id[j];
-            if (WITH_LCP) LCP[e] = lc[j];
-        }
     }
+    store_run<T, ITEMS>(Bsa, e0, n, id);
+    if (WITH_LCP) store_run<T, ITEMS>(LCP, e0, n, lc);
 }
 
 // ------------------------------------------------------------------ K8
@@ -172,7 +163,7 @@ __global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict
                                    T* __restrict__ ISA) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        ISA[SA[i]] = Bsa[i];
+        ISA[SA[i]] = Bsa[i] - 1;      // ISA holds 0-based ranks throughout (suffix_array.hpp:460-464)
 }
 
 // ------------------------------------------------------------------ K12
@@ -194,11 +185,14 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const unsigned tile = s_tile;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
-    T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]
+    T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]; ids are >= 1, so 0 never matches
+    {
+        T mid[ITEMS];
+        load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
 #pragma unroll
-    for (int j = 0; j < ITEMS + 2; ++j) {
-        const uint64_t e = e0 + j;     // index + 1
-        v[j] = (e >= 1 && e - 1 < cnt) ? ids[e - 1] : (T)0;   // ids are >= 1, 0 never matches
+        for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j];
+        v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (T)0;
+        v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (T)0;
     }
     unsigned act = 0, nact = 0, nub = 0;
 #pragma unroll
@@ -241,7 +235,7 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
         const T sa = SA[p];
         const uint64_t q = (uint64_t)sa + h;
         K1[j] = Bsa[p];
-        K2[j] = q < n ? ISA[q] : (T)0;
+        K2[j] = q < n ? (T)(ISA[q] + 1) : (T)0;   // 1-based bucket id, 0 = past the end
         V[j] = sa;
     }
 }
@@ -323,12 +317,12 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
+    load_run<T, ITEMS>(K1, e0, cnt, a1, (T)0);
+    load_run<T, ITEMS>(K2, e0, cnt, a2, (T)0);
+    if (pos) load_run<T, ITEMS>(pos, e0, cnt, ps, (T)0);
+    else {
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint64_t e = e0 + j;
-        a1[j] = e < cnt ? K1[e] : 0;
-        a2[j] = e < cnt ? K2[e] : 0;
-        ps[j] = e < cnt ? (pos ? pos[e] : (T)e) : 0;
+        for (int j = 0; j < ITEMS; ++j) ps[j] = (T)(e0 + j);
     }
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) { p1 = K1[e0 - 1]; p2 = K2[e0 - 1]; }
@@ -374,7 +368,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             const T sa = V[e];
             SA[ps[j]] = sa;
             Bsa[ps[j]] = id[j];
-            ISA[sa] = id[j];
+            ISA[sa] = id[j] - 1;
             ids_out[e] = id[j];
         }
     }
