@@ -13,8 +13,8 @@
 
 namespace psacx {
 
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 template <typename T> struct Work {
@@ -23,9 +23,10 @@ template <typename T> struct Work {
     T *pos_a, *pos_b;
     Pyramid<T> pyr;
     unsigned long long* d_hist256;     // char histogram
-    unsigned long long* d_counters;    // [2] active / unfinished buckets
-    char* d_scan_desc;                 // counter (256 B) + uint64 descriptors
-    size_t scan_desc_bytes;
+    uint64_t* d_carry;                 // per scan tile: id of the last head (then its exclusive max-scan)
+    uint64_t* d_nact;                  // per scan tile: active positions (then exclusive sum-scan)
+    uint64_t* d_nunf;                  // per scan tile: buckets with > 1 member
+    uint64_t* d_totals;                // [0] active, [1] unfinished buckets
     SortScratch sc;
 };
 
@@ -48,9 +49,11 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
         }
     }
     w.d_hist256 = a.take<unsigned long long>(256);
-    w.d_counters = a.take<unsigned long long>(2);
-    w.scan_desc_bytes = 256 + ((n + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(uint64_t);
-    w.d_scan_desc = a.take<char>(w.scan_desc_bytes);
+    const uint64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+    w.d_carry = a.take<uint64_t>(nt);
+    w.d_nact = a.take<uint64_t>(nt);
+    w.d_nunf = a.take<uint64_t>(nt);
+    w.d_totals = a.take<uint64_t>(4);
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.desc_bytes = sort_desc_bytes(n);
@@ -87,25 +90,43 @@ inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k)
     return k;
 }
 
+// per-tile carries of the prefix-max: last head of every tile, then an exclusive max-scan
+template <typename T, bool REFINE>
+int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt) {
+    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((last_head_kernel<T, REFINE>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
+                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry);
+    PSACX_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
+                       (uint64_t)0, (uint64_t*)nullptr);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
+// totals of the per-tile activity counts, then the compacted list of still-active positions
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
                 uint64_t* active, uint64_t* unf_buckets) {
-    unsigned long long* h_cnt = reinterpret_cast<unsigned long long*>(c->pinned);   // [2]
+    uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
+    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     {
         ProfScope ps(c, TC_COMPACT);
-        const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-        PSACX_HIP(c, hipMemsetAsync(w.d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
-        PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
-        hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out,
-                           reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
-                           reinterpret_cast<unsigned*>(w.d_scan_desc), w.d_counters, w.sc.d_err);
+        hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, w.d_nact, ntiles, OpSum(),
+                           (uint64_t)0, w.d_totals);
+        hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, w.d_nunf, ntiles, OpSum(),
+                           (uint64_t)0, w.d_totals + 1);
         PSACX_HIP(c, hipGetLastError());
     }
-    PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *active = h_cnt[0];
     *unf_buckets = h_cnt[1];
+    if (*active > 0) {
+        ProfScope ps(c, TC_COMPACT);
+        hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
+                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact);
+        PSACX_HIP(c, hipGetLastError());
+    }
     return PSACX_OK;
 }
 
@@ -175,11 +196,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-        PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
+        PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n)));
         hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                            dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, n, k, l, w.bsa, d_lcp,
-                           reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
-                           reinterpret_cast<unsigned*>(w.d_scan_desc), w.sc.d_err);
+                           w.d_carry, w.d_nact, w.d_nunf);
         PSACX_HIP(c, hipGetLastError());
     }
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
@@ -223,11 +243,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-            PSACX_HIP(c, hipMemsetAsync(w.d_scan_desc, 0, 256 + ntiles * sizeof(uint64_t), c->stream));
+            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt)));
             hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
-                               d_sa, w.bsa, d_isa, w.pyr, ids, reinterpret_cast<uint64_t*>(w.d_scan_desc + 256),
-                               reinterpret_cast<unsigned*>(w.d_scan_desc), w.sc.d_err);
+                               d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf);
             PSACX_HIP(c, hipGetLastError());
         }
         uint64_t nactive = 0;

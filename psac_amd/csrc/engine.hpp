@@ -211,7 +211,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     {
         ProfScope ps(c, TC_SORT_HIST);
         PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
-        const int grid = grid_for(c, n, 256, 8);
+        const int grid = grid_for(c, (n + 3) / 4, 256, 8);
         hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n,
                            ha, sc.d_hist);
         PSACX_HIP(c, hipGetLastError());

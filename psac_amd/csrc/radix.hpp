@@ -48,18 +48,24 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const T* __restrict__
                                                            const T* __restrict__ k2, uint64_t n,
                                                            HistArgs a,
                                                            unsigned long long* __restrict__ hist) {
+    constexpr int PER = 16 / sizeof(T);
     __shared__ unsigned lh[MAX_PASSES * RADIX];
     for (int i = threadIdx.x; i < a.n_pass * RADIX; i += BLOCK) lh[i] = 0;
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const T a1 = k1[i];
-        const T a2 = k2[i];
-#pragma unroll 4
-        for (int p = 0; p < a.n_pass; ++p) {
-            const T w = a.word[p] ? a2 : a1;
-            const unsigned d = (unsigned)(w >> a.shift[p]) & (RADIX - 1);
-            atomicAdd(&lh[p * RADIX + d], 1u);
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK * PER;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * PER; e0 < n; e0 += stride) {
+        T x1[PER], x2[PER];
+        load_run<T, PER>(k1, e0, n, x1, (T)0);
+        load_run<T, PER>(k2, e0, n, x2, (T)0);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (e0 + j < n) {
+                for (int p = 0; p < a.n_pass; ++p) {
+                    const T w = a.word[p] ? x2[j] : x1[j];
+                    const unsigned d = (unsigned)(w >> a.shift[p]) & (RADIX - 1);
+                    atomicAdd(&lh[p * RADIX + d], 1u);
+                }
+            }
         }
     }
     __syncthreads();

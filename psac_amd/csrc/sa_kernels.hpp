@@ -96,19 +96,87 @@ __device__ __forceinline__ unsigned kmer_lcp(T x, T y, unsigned k, unsigned l) {
     return (lz - (unsigned)(sizeof(T) * 8 - k * l)) / l;
 }
 
+// ------------------------------------------------------------------ tile carries for the prefix-max
+// Bucket ids are a prefix maximum over "head" positions (bucketing.hpp:21-53).  It is
+// evaluated in three launches without any inter-workgroup waiting:
+//   1. last_head_kernel: per tile, the id of its last head (found by a backward
+//      search that normally stops within the last 64 records),
+//   2. tile_scan_kernel: exclusive scan of those per-tile values,
+//   3. rebucket_*_kernel: every tile recomputes its heads and fills from its carry.
+// REFINE = false: heads of the first round, pair (S1,S2) differs from its predecessor.
+// REFINE = true : heads inside old buckets, (K1,K2) differs or K2 == 0; id = pos + 1.
+template <typename T, bool REFINE>
+__global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__ A2,
+                                 const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
+                                 uint64_t ntiles, uint64_t* __restrict__ agg) {
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const unsigned lane = lane_id();
+    if (wave_id >= ntiles) return;
+    const uint64_t lo = wave_id * tile_size;
+    uint64_t hi = lo + tile_size;
+    if (hi > cnt) hi = cnt;
+    uint64_t found = 0;
+    // walk backwards in windows of 64 records [w0, w0 + 64)
+    for (uint64_t wend = hi; wend > lo; ) {
+        const uint64_t w0 = wend >= lo + WAVE ? wend - WAVE : lo;
+        const uint64_t e = w0 + lane;
+        bool head = false;
+        if (e < wend) {
+            if (e == 0) head = true;
+            else {
+                const T x1 = A1[e], y1 = A1[e - 1], x2 = A2[e], y2 = A2[e - 1];
+                head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
+            }
+        }
+        const uint64_t m = __ballot(head);
+        if (m) {
+            const uint64_t at = w0 + (63u - (unsigned)__builtin_clzll(m));
+            found = REFINE ? (uint64_t)(pos ? pos[at] : (T)at) + 1 : at + 1;
+            break;
+        }
+        wend = w0;
+    }
+    if (lane == 0) agg[wave_id] = found;
+}
+
+// Exclusive scan of `len` uint64 values by one workgroup (len is the number of tiles, at
+// most a few tens of thousands).  total[0] receives the reduction of everything.
+template <int BLOCK, typename Op>
+__global__ __launch_bounds__(BLOCK) void tile_scan_kernel(uint64_t* __restrict__ a, uint64_t len, Op op,
+                                                          uint64_t identity, uint64_t* __restrict__ total) {
+    constexpr int PER = 4;
+    __shared__ uint64_t tmp[BLOCK / WAVE + 1];
+    uint64_t carry = identity;
+    for (uint64_t base = 0; base < len; base += (uint64_t)BLOCK * PER) {
+        const uint64_t e0 = base + (uint64_t)threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t run = identity;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { v[j] = (e0 + j < len) ? a[e0 + j] : identity; run = op(run, v[j]); }
+        uint64_t tot;
+        uint64_t ex = block_scan_exclusive<BLOCK, uint64_t>(run, op, identity, tmp, &tot);
+        ex = op(carry, ex);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { if (e0 + j < len) a[e0 + j] = ex; ex = op(ex, v[j]); }
+        carry = op(carry, tot);
+    }
+    if (threadIdx.x == 0 && total) total[0] = carry;
+}
+
 // ------------------------------------------------------------------ K6 + K7, first round
+// Sorted (S1,S2): writes the bucket id of every position, the LCP of the 2k-mers at
+// every bucket boundary (suffix_array.hpp:1353-1396; sentinel n elsewhere) and, per
+// tile, how many positions stay active (share their bucket) and how many buckets
+// hold more than one suffix (bucketing.hpp:98-118).
 template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, uint64_t n, unsigned k, unsigned l,
-    T* __restrict__ Bsa, T* __restrict__ LCP, uint64_t* __restrict__ desc,
-    unsigned* __restrict__ tile_counter, unsigned* __restrict__ err) {
+    T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
+    uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
-    __shared__ uint64_t s_excl;
-    __shared__ unsigned s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
-    __syncthreads();
-    const unsigned tile = s_tile;
+    __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
+    const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T a1[ITEMS], a2[ITEMS];
@@ -116,14 +184,19 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; }
+    // head flag of the first record after this run (for the activity test)
+    bool next_head = true;
+    if (e0 + ITEMS < n) next_head = (S1[e0 + ITEMS] != a1[ITEMS - 1]) || (S2[e0 + ITEMS] != a2[ITEMS - 1]);
 
     T id[ITEMS];
     T lc[ITEMS];
+    unsigned heads = 0;
     T run = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
         const bool head = (e == 0) || a1[j] != p1 || a2[j] != p2;
+        if (head || e >= n) heads |= 1u << j;
         id[j] = (e < n && head) ? (T)(e + 1) : (T)0;
         if (WITH_LCP) {
             T v = (T)n;
@@ -140,14 +213,23 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         p1 = a1[j]; p2 = a2[j];
         if (id[j] > run) run = id[j];
     }
+    if (next_head) heads |= 1u << ITEMS;
+    // activity: not a head, or a head followed by a non-head
+    unsigned nact = 0, nub = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (e0 + j < n) {
+            const bool h = (heads >> j) & 1u, hn = (heads >> (j + 1)) & 1u;
+            if (!h || !hn) ++nact;
+            if (h && !hn) ++nub;
+        }
+    }
     T agg;
     T excl = block_scan_exclusive<BLOCK, T>(run, OpMax(), (T)0, scan_tmp, &agg);
-    if (threadIdx.x < WAVE) {
-        const uint64_t te = lookback_wave(desc, tile, (uint64_t)agg, OpMax(), 0ull, err);
-        if (threadIdx.x == 0) s_excl = te;
-    }
-    __syncthreads();
-    T carry = (T)s_excl;
+    const unsigned tact = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
+    const unsigned tub = block_reduce<BLOCK, unsigned>(nub, OpSum(), red_tmp);
+    if (threadIdx.x == 0) { n_active[tile] = tact; n_unf[tile] = tub; }
+    T carry = (T)carry_in[tile];
     if (excl > carry) carry = excl;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -168,21 +250,16 @@ __global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict
 
 // ------------------------------------------------------------------ K12
 // ids: bucket ids of `cnt` consecutive list entries (SA order).  An entry is
-// still active when it shares its id with a neighbour.  pos_in == nullptr means
-// list entry j sits at SA position j.  counters[0] += active entries,
-// counters[1] += buckets with more than one member.
+// still active when it shares its id with a neighbour (suffix_array.hpp:925-965).
+// pos_in == nullptr means list entry j sits at SA position j.  offset[tile] is the
+// exclusive scan of the per-tile active counts the rebucket kernels produced.
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
-    uint64_t* __restrict__ desc, unsigned* __restrict__ tile_counter,
-    unsigned long long* __restrict__ counters, unsigned* __restrict__ err) {
+    const uint64_t* __restrict__ offset) {
     constexpr int TILE = BLOCK * ITEMS;
-    __shared__ uint64_t scan_tmp[BLOCK / WAVE + 1];
-    __shared__ uint64_t s_excl;
-    __shared__ unsigned s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
-    __syncthreads();
-    const unsigned tile = s_tile;
+    __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
+    const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]; ids are >= 1, so 0 never matches
@@ -194,33 +271,21 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
         v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (T)0;
         v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (T)0;
     }
-    unsigned act = 0, nact = 0, nub = 0;
+    unsigned act = 0, nact = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool in = (e0 + j) < cnt;
-        const bool eqp = in && v[j + 1] == v[j];
-        const bool eqn = in && v[j + 1] == v[j + 2];
-        if (eqp || eqn) { act |= 1u << j; ++nact; }
-        if (!eqp && eqn) ++nub;
+        if (in && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) { act |= 1u << j; ++nact; }
     }
-    uint64_t agg;
-    uint64_t excl = block_scan_exclusive<BLOCK, uint64_t>((uint64_t)nact, OpSum(), 0ull, scan_tmp, &agg);
-    if (threadIdx.x < WAVE) {
-        const uint64_t te = lookback_wave(desc, tile, agg, OpSum(), 0ull, err);
-        if (threadIdx.x == 0) s_excl = te;
-    }
-    // per-block reduction of the bucket count, one atomic per wave
-    const unsigned wub = wave_reduce<uint32_t>(nub, OpSum());
-    if (lane_id() == 0 && wub) atomicAdd(&counters[1], (unsigned long long)wub);
-    if (threadIdx.x == 0 && agg) atomicAdd(&counters[0], (unsigned long long)agg);
-    __syncthreads();
-    uint64_t o = s_excl + excl;
+    unsigned agg;
+    const unsigned excl = block_scan_exclusive<BLOCK, unsigned>(nact, OpSum(), 0u, scan_tmp, &agg);
+    if (agg == 0) return;
+    uint64_t o = offset[tile] + excl;
+    T ps[ITEMS];
+    if (pos_in) load_run<T, ITEMS>(pos_in, e0, cnt, ps, (T)0);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if (act & (1u << j)) {
-            const uint64_t e = e0 + j;
-            pos_out[o++] = pos_in ? pos_in[e] : (T)e;
-        }
+        if (act & (1u << j)) pos_out[o++] = pos_in ? ps[j] : (T)(e0 + j);
     }
 }
 
@@ -300,20 +365,18 @@ __device__ __forceinline__ void pyramid_set(const Pyramid<T>& P, uint64_t p, T v
 // ------------------------------------------------------------------ K13 + K9-K11, later rounds
 // Sorted active records (K1 = old bucket id, K2 = id of the suffix h further,
 // V = suffix start) and their SA positions pos[] (ascending).  Writes back the
-// refined order and ids, and the LCP of every freshly split boundary.
+// refined order and ids, the LCP of every freshly split boundary, and the per-tile
+// activity counts for the next round.
 template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
 __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const T* __restrict__ K1, const T* __restrict__ K2, const T* __restrict__ V,
     const T* __restrict__ pos, uint64_t cnt, uint64_t n, uint64_t h, T* __restrict__ SA,
     T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
-    uint64_t* __restrict__ desc, unsigned* __restrict__ tile_counter, unsigned* __restrict__ err) {
+    const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
-    __shared__ uint64_t s_excl;
-    __shared__ unsigned s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
-    __syncthreads();
-    const unsigned tile = s_tile;
+    __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
+    const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
@@ -326,8 +389,14 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) { p1 = K1[e0 - 1]; p2 = K2[e0 - 1]; }
+    bool next_head = true;
+    if (e0 + ITEMS < cnt) {
+        const T q1 = K1[e0 + ITEMS], q2 = K2[e0 + ITEMS];
+        next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
+    }
 
     T id[ITEMS];
+    unsigned heads = 0;
     T run = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -335,6 +404,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         const bool in = e < cnt;
         const bool same1 = (e > 0) && a1[j] == p1;
         const bool head = !same1 || a2[j] != p2 || a2[j] == 0;
+        if (head || !in) heads |= 1u << j;
         id[j] = (in && head) ? (T)(ps[j] + 1) : (T)0;
         if (WITH_LCP && in && same1 && head) {
             // boundary that appeared inside an old bucket (suffix_array.hpp:1457-1476)
@@ -351,27 +421,36 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         p1 = a1[j]; p2 = a2[j];
         if (id[j] > run) run = id[j];
     }
+    if (next_head) heads |= 1u << ITEMS;
+    unsigned nact = 0, nub = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (e0 + j < cnt) {
+            const bool hd = (heads >> j) & 1u, hn = (heads >> (j + 1)) & 1u;
+            if (!hd || !hn) ++nact;
+            if (hd && !hn) ++nub;
+        }
+    }
     T agg;
     T excl = block_scan_exclusive<BLOCK, T>(run, OpMax(), (T)0, scan_tmp, &agg);
-    if (threadIdx.x < WAVE) {
-        const uint64_t te = lookback_wave(desc, tile, (uint64_t)agg, OpMax(), 0ull, err);
-        if (threadIdx.x == 0) s_excl = te;
-    }
-    __syncthreads();
-    T carry = (T)s_excl;
+    const unsigned tact = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
+    const unsigned tub = block_reduce<BLOCK, unsigned>(nub, OpSum(), red_tmp);
+    if (threadIdx.x == 0) { n_active[tile] = tact; n_unf[tile] = tub; }
+    T carry = (T)carry_in[tile];
     if (excl > carry) carry = excl;
+    T sa[ITEMS];
+    load_run<T, ITEMS>(V, e0, cnt, sa, (T)0);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
         if (id[j] == 0) id[j] = carry; else carry = id[j];
         if (e < cnt) {
-            const T sa = V[e];
-            SA[ps[j]] = sa;
+            SA[ps[j]] = sa[j];
             Bsa[ps[j]] = id[j];
-            ISA[sa] = id[j] - 1;
-            ids_out[e] = id[j];
+            ISA[sa[j]] = id[j] - 1;
         }
     }
+    store_run<T, ITEMS>(ids_out, e0, cnt, id);
 }
 
 // ------------------------------------------------------------------ K14
