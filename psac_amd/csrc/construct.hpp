@@ -73,13 +73,19 @@ inline int ensure_pinned(psacx_ctx* c, size_t bytes) {
 }
 
 // alphabet.hpp:147-164 on the host from the device histogram
-inline void build_alphabet(const unsigned long long* hist, CodeTable& tab, uint32_t& sigma, uint32_t& bits) {
-    uint16_t next = 1;
+// tab gets codes 0..sigma-1 in byte order (the packed sort key needs no end-marker code);
+// bits is psac's bits_per_char = ceil(log2(sigma + 1)), bits_packed = max(1, ceil(log2(sigma))).
+inline void build_alphabet(const unsigned long long* hist, CodeTable& tab, uint32_t& sigma, uint32_t& bits,
+                           uint32_t& bits_packed) {
+    uint16_t next = 0;
     for (int ch = 0; ch < 256; ++ch) tab.c[ch] = hist[ch] ? next++ : (uint16_t)0;
-    sigma = next - 1u;
-    uint32_t v = sigma + 1u, b = 0;
-    while ((1u << b) < v) ++b;          // ceil(log2(sigma + 1))
+    sigma = next;
+    uint32_t b = 0;
+    while ((1u << b) < sigma + 1u) ++b;          // ceil(log2(sigma + 1))
     bits = b;
+    b = 0;
+    while ((1u << b) < sigma) ++b;               // ceil(log2(sigma))
+    bits_packed = b ? b : 1;
 }
 
 // kmer.hpp:26-40 for a single rank
@@ -92,10 +98,11 @@ inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k)
 
 // per-tile carries of the prefix-max: last head of every tile, then an exclusive max-scan
 template <typename T, bool REFINE>
-int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt) {
+int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
+                KeyShape ks) {
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL((last_head_kernel<T, REFINE>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
-                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry);
+                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks);
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
                        (uint64_t)0, (uint64_t*)nullptr);
@@ -171,18 +178,26 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     unsigned long long* h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
     PSACX_HIP(c, hipMemcpyAsync(h_hist, w.d_hist256, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
-    build_alphabet(h_hist, tab, st.sigma, st.bits_per_char);
+    uint32_t lc = 1;
+    build_alphabet(h_hist, tab, st.sigma, st.bits_per_char, lc);
     const uint32_t l = st.bits_per_char;
     const uint32_t k = choose_k((uint32_t)sizeof(T) * 8, l, n, k_req);
     st.k = k;
+    // the 2k-character window of the first round, packed with lc bits per character
+    KeyShape ks;
+    ks.lc = lc;
+    ks.c1 = std::min<uint32_t>(2 * k, (uint32_t)(sizeof(T) * 8) / lc);
+    ks.c2 = 2 * k - ks.c1;
+    ks.spec = std::min<uint64_t>(2ull * k - 1, n);
 
-    // ---- initial (B1,B2) = (k-mer at i, k-mer at i+k)  (kmer.hpp:119-177, shifting.hpp:33-122)
+    // ---- first-round keys: the 2k-character window at every position, packed (kmer.hpp:119-177,
+    //      shifting.hpp:33-122; see key_pairs_kernel for the packing)
     {
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
-        hipLaunchKernelGGL((kmer_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n,
-                           tab, k, l, w.x.k1, w.x.k2);
+        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n,
+                           tab, ks, w.x.k1, w.x.k2);
         PSACX_HIP(c, hipGetLastError());
     }
 
@@ -190,15 +205,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     psacx_round* r0 = &st.rounds[0];
     std::memset(r0, 0, sizeof(*r0));
     SortBufs<T> sorted;
-    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, k * l, d_sa, &sorted, r0));
+    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, d_sa, &sorted, r0, ks.spec, n));
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-        PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n)));
+        PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
         hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, n, k, l, w.bsa, d_lcp,
+                           dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
                            w.d_carry, w.d_nact, w.d_nunf);
         PSACX_HIP(c, hipGetLastError());
     }
@@ -238,12 +253,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v);
             PSACX_HIP(c, hipGetLastError());
         }
-        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, nullptr, &sorted, rr));
+        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr));
         T* ids = (sorted.k1 == w.x.k1) ? w.y.k1 : w.x.k1;     // the set not holding the result is free
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt)));
+            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, KeyShape())));
             hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
                                d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf);
@@ -349,7 +364,7 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
     c->profile = true; c->ev_used = 0;
     SortBufs<T> in{d_b1, d_b2, vtmp}, res;
     psacx_round rs; std::memset(&rs, 0, sizeof(rs));
-    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, true, key_bits, nullptr, &res, &rs));
+    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, true, key_bits ? key_bits : (uint32_t)sizeof(T) * 8, key_bits ? key_bits : (uint32_t)sizeof(T) * 8, nullptr, &res, &rs));
     if (res.k1 != d_b1) {
         PSACX_HIP(c, hipMemcpyAsync(d_b1, res.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         PSACX_HIP(c, hipMemcpyAsync(d_b2, res.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

@@ -148,12 +148,12 @@ inline size_t sort_desc_bytes(uint64_t n) {
 template <typename T, typename D, int BLOCK, int ITEMS>
 inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out,
                            T* ko_out, T* v_out, uint64_t n, int shift, const unsigned long long* base,
-                           char* desc, unsigned* err, unsigned long long* dbg) {
+                           char* desc, unsigned* err, unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     hipLaunchKernelGGL((radix_scatter_kernel<T, D, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
                        c->stream, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base,
-                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err, dbg);
+                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err, dbg, spec, spec_n);
 }
 
 template <typename T> struct ScatterCfg;
@@ -179,8 +179,9 @@ inline uint64_t cfg_tile(int cfg) {
 template <typename T, typename D>
 inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in,
                              T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
-                             const unsigned long long* base, char* desc, unsigned* err, unsigned long long* dbg) {
-#define PSACX_SC(B, I) launch_scatter<T, D, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, dbg)
+                             const unsigned long long* base, char* desc, unsigned* err, unsigned long long* dbg,
+                             uint64_t spec, uint64_t spec_n) {
+#define PSACX_SC(B, I) launch_scatter<T, D, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, dbg, spec, spec_n)
     switch (cfg) {
         case 0: PSACX_SC(256, 8); break;
         case 2: PSACX_SC(512, 8); break;
@@ -195,15 +196,18 @@ inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_
 #undef PSACX_SC
 }
 
-// Sorts `n` records by (k1, k2).  With `iota` the payload read by the first pass
-// is the record index (in.v is only used as scratch).  The sorted arrays end up in
+// Sorts `n` records by (k1, k2); bits1/bits2 = significant low bits of each word.
+// With `iota` the payload read by the first pass is the record index, or, when spec_n is
+// set, the suffix start the first-round record stands for (in.v is only scratch).  The sorted arrays end up in
 // *res (the `in` or the `alt` set); when final_v is given the payload of the last
 // executed pass is written there instead and res->v == final_v.
 template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
-              unsigned key_bits, T* final_v, SortBufs<T>* res, psacx_round* rs) {
-    if (key_bits == 0 || key_bits > sizeof(T) * 8) key_bits = sizeof(T) * 8;
-    const PassPlan plan = make_plan((int)key_bits);
+              unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
+              uint64_t spec = 0, uint64_t spec_n = 0) {
+    if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
+    if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
+    const PassPlan plan = make_plan((int)bits1, (int)bits2);
     HistArgs ha;
     ha.n_pass = plan.n_pass;
     for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
@@ -264,9 +268,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             ProfScope ps(c, TC_SORT_SCATTER);
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             if (small_desc)
-                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg);
+                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
             else
-                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg);
+                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
         }
         if (sc.d_dbg && ntiles >= 64) {
@@ -290,7 +294,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         // every digit constant: the input order is already sorted
         T* dst = final_v ? final_v : cur.v;
         if (iota) {
-            hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n);
+            hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
         } else if (dst != cur.v) {
             PSACX_HIP(c, hipMemcpyAsync(dst, cur.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

@@ -27,12 +27,14 @@ struct PassPlan {
     int shift[MAX_PASSES];
 };
 
-inline PassPlan make_plan(int key_bits) {
+// bits1 / bits2: significant low bits of key word 1 (major) and key word 2 (minor)
+inline PassPlan make_plan(int bits1, int bits2) {
     PassPlan p;
-    int per = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
     p.n_pass = 0;
-    for (int w = 1; w >= 0; --w)
+    for (int w = 1; w >= 0; --w) {
+        const int per = ((w ? bits2 : bits1) + RADIX_BITS - 1) / RADIX_BITS;
         for (int i = 0; i < per; ++i) { p.word[p.n_pass] = w; p.shift[p.n_pass] = i * RADIX_BITS; p.n_pass++; }
+    }
     return p;
 }
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
-    unsigned long long* __restrict__ dbg) {
+    unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     T* const stage = sh.stage;
@@ -145,7 +147,12 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
-        vv[i] = pv ? ((FULL || loc < count) ? pv[loc] : (T)0) : (T)(base + loc);
+        if (pv) vv[i] = (FULL || loc < count) ? pv[loc] : (T)0;
+        else {
+            // implicit payload: the record index, or the suffix the first-round record stands for
+            const uint64_t g = base + loc;
+            vv[i] = (T)(spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g);
+        }
     }
 
     // rank inside the wave, round by round (keeps the sort stable)
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc,
     unsigned* __restrict__ tile_counter, unsigned* __restrict__ err,
-    unsigned long long* __restrict__ dbg) {
+    unsigned long long* __restrict__ dbg, uint64_t spec, uint64_t spec_n) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
@@ -266,10 +273,10 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, D, BLOCK, ITEMS, true>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out, ko_out,
-                                                     v_out, shift, digit_base, desc, err, dbg);
+                                                     v_out, shift, digit_base, desc, err, dbg, spec, spec_n);
     else
         radix_scatter_tile<T, D, BLOCK, ITEMS, false>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out, ko_out,
-                                                      v_out, shift, digit_base, desc, err, dbg);
+                                                      v_out, shift, digit_base, desc, err, dbg, spec, spec_n);
 }
 
 } // namespace psacx

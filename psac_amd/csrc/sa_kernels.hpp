@@ -2,7 +2,7 @@
 //
 // Reference loops each kernel stands in for (paths under /root/reference/include):
 //   char_hist_kernel        alphabet.hpp:49-59        256-bin byte histogram
-//   kmer_pairs_kernel       kmer.hpp:119-177 + shifting.hpp:33-122 (B2[i] = B[i+k])
+//   key_pairs_kernel        kmer.hpp:119-177 + shifting.hpp:33-122 (the (B1,B2) window of round 1, packed)
 //   rebucket_first_kernel   suffix_array.hpp:1353-1396 (k-mer LCP) + bucketing.hpp:57-123, 21-53
 //   isa_scatter_kernel      bulk_permute.hpp:14-73     ISA[SA[i]] = B[i]
 //   compact_active_kernel   suffix_array.hpp:925-965   get_active
@@ -49,51 +49,87 @@ __global__ __launch_bounds__(BLOCK) void char_hist_kernel(const uint8_t* __restr
 }
 
 // ------------------------------------------------------------------ K2 (+K3 for round 1)
-// B1[i] = k-mer starting at i, B2[i] = k-mer starting at i+k, codes of l bits,
-// first character most significant, zero past the end of the text.
+// First-round sort keys.  psac sorts by (B1,B2) = (k-mer at i, k-mer at i+k) with
+// l = ceil(log2(sigma+1)) bits per character, code 0 being the end marker
+// (kmer.hpp:119-177, shifting.hpp:33-122).  The same 2k-character window is packed
+// here with lc = ceil(log2(sigma)) bits per character (codes 0..sigma-1, no code for
+// the end marker): word 1 holds the first c1 characters, word 2 the remaining c2.
+// That shortens the radix key (DNA, 32-bit words: 60 -> 40 bits).  The end marker is
+// recovered from the record ORDER instead: the `spec` suffixes shorter than 2k
+// characters come first in the input, shortest first, so the stable LSD sort leaves
+// them in front of every suffix with the same packed key, in the order psac's
+// zero-padded k-mers would give; rebucket_first_kernel caps their LCP by their length.
+struct KeyShape {
+    unsigned lc;        // bits per character in the packed key
+    unsigned c1, c2;    // characters in word 1 / word 2, c1 + c2 = 2k
+    uint64_t spec;      // number of suffixes shorter than 2k (= min(2k - 1, n))
+};
+
+// record j  <->  suffix start: the `spec` short suffixes first (shortest first), then 0, 1, 2, ...
+__device__ __forceinline__ uint64_t record_suffix(uint64_t j, uint64_t spec, uint64_t n) {
+    return j < spec ? n - 1 - j : j - spec;
+}
+
 template <typename T, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void kmer_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                           CodeTable tab, unsigned k, unsigned l,
-                                                           T* __restrict__ B1, T* __restrict__ B2) {
+__global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                          CodeTable tab, KeyShape ks,
+                                                          T* __restrict__ C1, T* __restrict__ C2) {
     constexpr int TILE = BLOCK * ITEMS;
-    constexpr int HALO = 2 * 64;             // 2k <= 128 always (k <= 64 / l)
+    constexpr int HALO = 2 * 64 + 8;             // 2k <= 128 always
     __shared__ uint16_t codes[TILE + HALO];
     __shared__ uint16_t ctab[256];
-    if (threadIdx.x < 256) ctab[threadIdx.x] = tab.c[threadIdx.x];
-    if (BLOCK < 256) for (int i = threadIdx.x + BLOCK; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    const unsigned need = TILE + 2 * k;
+    const unsigned two_k = ks.c1 + ks.c2;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;                 // first record of the tile
+    const uint64_t i_lo = (base > ks.spec ? base : ks.spec) - ks.spec; // first regular suffix of the tile
+    const unsigned need = TILE + two_k;
     for (unsigned i = threadIdx.x; i < need; i += BLOCK) {
-        const uint64_t g = base + i;
+        const uint64_t g = i_lo + i;
         codes[i] = g < n ? ctab[text[g]] : (uint16_t)0;
     }
     __syncthreads();
-    const T mask = (k * l >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (k * l)) - 1);
-    const unsigned q = threadIdx.x * ITEMS;
-    T c1 = 0, c2 = 0;
-    for (unsigned j = 0; j + 1 < k; ++j) {
-        c1 = (T)(c1 << l) | (T)codes[q + j];
-        c2 = (T)(c2 << l) | (T)codes[q + k + j];
-    }
+    const unsigned lc = ks.lc;
+    const T mask1 = (ks.c1 * lc >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (ks.c1 * lc)) - 1);
+    const T mask2 = (ks.c2 * lc >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (ks.c2 * lc)) - 1);
+    const uint64_t j0 = base + (uint64_t)threadIdx.x * ITEMS;
     T o1[ITEMS], o2[ITEMS];
+    if (j0 >= ks.spec) {
+        // ITEMS consecutive regular suffixes: rolling pack out of LDS
+        const unsigned q = (unsigned)(j0 - ks.spec - i_lo);
+        T w1 = 0, w2 = 0;
+        for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[q + t];
+        for (unsigned t = 0; t + 1 < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)codes[q + ks.c1 + t];
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        c1 = ((T)(c1 << l) | (T)codes[q + j + k - 1]) & mask;
-        c2 = ((T)(c2 << l) | (T)codes[q + j + 2 * k - 1]) & mask;
-        o1[j] = c1; o2[j] = c2;
+        for (int j = 0; j < ITEMS; ++j) {
+            w1 = ((T)(w1 << lc) | (T)codes[q + j + ks.c1 - 1]) & mask1;
+            if (ks.c2) w2 = ((T)(w2 << lc) | (T)codes[q + j + two_k - 1]) & mask2;
+            o1[j] = w1; o2[j] = w2;
+        }
+    } else {
+        // the few threads whose records include short suffixes: pack each record from the text
+#pragma unroll 1
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t rec = j0 + j;
+            T w1 = 0, w2 = 0;
+            if (rec < n) {
+                const uint64_t i = record_suffix(rec, ks.spec, n);
+                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i + t < n) ? tab.c[text[i + t]] : 0);
+                for (unsigned t = 0; t < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)((i + ks.c1 + t < n) ? tab.c[text[i + ks.c1 + t]] : 0);
+            }
+            o1[j] = w1; o2[j] = w2;
+        }
     }
-    const uint64_t e0 = base + q;
-    store_run<T, ITEMS>(B1, e0, n, o1);
-    store_run<T, ITEMS>(B2, e0, n, o2);
+    store_run<T, ITEMS>(C1, j0, n, o1);
+    store_run<T, ITEMS>(C2, j0, n, o2);
 }
 
-// number of equal leading characters of two k-mers (bitops.hpp:170-183)
+// characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
 template <typename T>
-__device__ __forceinline__ unsigned kmer_lcp(T x, T y, unsigned k, unsigned l) {
-    if (x == y) return k;
-    const unsigned lz = clz_t<T>((T)(x ^ y));
-    return (lz - (unsigned)(sizeof(T) * 8 - k * l)) / l;
+__device__ __forceinline__ unsigned window_lcp(T x1, T x2, T y1, T y2, const KeyShape& ks) {
+    if (x1 != y1) return (clz_t<T>((T)(x1 ^ y1)) - (unsigned)(sizeof(T) * 8 - ks.c1 * ks.lc)) / ks.lc;
+    if (x2 != y2) return ks.c1 + (clz_t<T>((T)(x2 ^ y2)) - (unsigned)(sizeof(T) * 8 - ks.c2 * ks.lc)) / ks.lc;
+    return ks.c1 + ks.c2;
 }
 
 // ------------------------------------------------------------------ tile carries for the prefix-max
@@ -103,12 +139,14 @@ __device__ __forceinline__ unsigned kmer_lcp(T x, T y, unsigned k, unsigned l) {
 //      search that normally stops within the last 64 records),
 //   2. tile_scan_kernel: exclusive scan of those per-tile values,
 //   3. rebucket_*_kernel: every tile recomputes its heads and fills from its carry.
-// REFINE = false: heads of the first round, pair (S1,S2) differs from its predecessor.
+// REFINE = false: heads of the first round, the 2k-character windows differ (packed pair
+//                 differs, or one of the two suffixes is shorter than 2k).
 // REFINE = true : heads inside old buckets, (K1,K2) differs or K2 == 0; id = pos + 1.
 template <typename T, bool REFINE>
 __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__ A2,
                                  const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
-                                 uint64_t ntiles, uint64_t* __restrict__ agg) {
+                                 uint64_t ntiles, uint64_t* __restrict__ agg, const T* __restrict__ SA,
+                                 KeyShape ks) {
     const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const unsigned lane = lane_id();
     if (wave_id >= ntiles) return;
@@ -126,6 +164,11 @@ __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__
             else {
                 const T x1 = A1[e], y1 = A1[e - 1], x2 = A2[e], y2 = A2[e - 1];
                 head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
+                if (!REFINE && !head) {
+                    // equal packed windows: still a boundary if either suffix is shorter than 2k
+                    const uint64_t two_k = ks.c1 + ks.c2;
+                    head = (cnt - (uint64_t)SA[e] < two_k) || (cnt - (uint64_t)SA[e - 1] < two_k);
+                }
             }
         }
         const uint64_t m = __ballot(head);
@@ -170,7 +213,7 @@ __global__ __launch_bounds__(BLOCK) void tile_scan_kernel(uint64_t* __restrict__
 // hold more than one suffix (bucketing.hpp:98-118).
 template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
-    const T* __restrict__ S1, const T* __restrict__ S2, uint64_t n, unsigned k, unsigned l,
+    const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf) {
     constexpr int TILE = BLOCK * ITEMS;
@@ -178,15 +221,23 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
     const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
+    const unsigned two_k = ks.c1 + ks.c2;
 
-    T a1[ITEMS], a2[ITEMS];
+    T a1[ITEMS], a2[ITEMS], sa[ITEMS];
     load_run<T, ITEMS>(S1, e0, n, a1, (T)0);
     load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
-    T p1 = 0, p2 = 0;
-    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; }
+    load_run<T, ITEMS>(SA, e0, n, sa, (T)0);
+    T p1 = 0, p2 = 0, psa = 0;
+    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; psa = SA[e0 - 1]; }
     // head flag of the first record after this run (for the activity test)
     bool next_head = true;
-    if (e0 + ITEMS < n) next_head = (S1[e0 + ITEMS] != a1[ITEMS - 1]) || (S2[e0 + ITEMS] != a2[ITEMS - 1]);
+    if (e0 + ITEMS < n) {
+        const T q1 = S1[e0 + ITEMS], q2 = S2[e0 + ITEMS], qsa = SA[e0 + ITEMS];
+        uint64_t c = window_lcp<T>(a1[ITEMS - 1], a2[ITEMS - 1], q1, q2, ks);
+        const uint64_t la = n - (uint64_t)sa[ITEMS - 1], lb = n - (uint64_t)qsa;
+        c = c < la ? c : la; c = c < lb ? c : lb;
+        next_head = c < two_k;
+    }
 
     T id[ITEMS];
     T lc[ITEMS];
@@ -195,22 +246,15 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
-        const bool head = (e == 0) || a1[j] != p1 || a2[j] != p2;
+        // common characters of the two 2k windows, the end marker differing from everything
+        uint64_t c = window_lcp<T>(p1, p2, a1[j], a2[j], ks);
+        const uint64_t la = n - (uint64_t)psa, lb = n - (uint64_t)sa[j];
+        c = c < la ? c : la; c = c < lb ? c : lb;
+        const bool head = (e == 0) || c < two_k;
         if (head || e >= n) heads |= 1u << j;
         id[j] = (e < n && head) ? (T)(e + 1) : (T)0;
-        if (WITH_LCP) {
-            T v = (T)n;
-            if (head) {
-                if (e == 0) v = 0;
-                else {
-                    unsigned c = kmer_lcp<T>(p1, a1[j], k, l);
-                    if (c == k) c += kmer_lcp<T>(p2, a2[j], k, l);
-                    v = (T)c;
-                }
-            }
-            lc[j] = v;
-        }
-        p1 = a1[j]; p2 = a2[j];
+        if (WITH_LCP) lc[j] = head ? (e == 0 ? (T)0 : (T)c) : (T)n;
+        p1 = a1[j]; p2 = a2[j]; psa = sa[j];
         if (id[j] > run) run = id[j];
     }
     if (next_head) heads |= 1u << ITEMS;
@@ -466,10 +510,12 @@ __global__ void fill_kernel(T* __restrict__ a, uint64_t n, T v) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
 }
 
+// a[g] = g, or the suffix start record g stands for in the first round (spec_n != 0)
 template <typename T>
-__global__ void iota_kernel(T* __restrict__ a, uint64_t n) {
+__global__ void iota_kernel(T* __restrict__ a, uint64_t n, uint64_t spec, uint64_t spec_n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = (T)i;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        a[i] = (T)(spec_n ? record_suffix(i, spec, spec_n) : i);
 }
 
 } // namespace psacx
