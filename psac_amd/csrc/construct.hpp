@@ -27,6 +27,8 @@ template <typename T> struct Work {
     uint64_t* d_nact;                  // per scan tile: active positions (then exclusive sum-scan)
     uint64_t* d_nunf;                  // per scan tile: buckets with > 1 member
     uint64_t* d_totals;                // [0] active, [1] unfinished buckets
+    unsigned* d_cursors;               // fill cursors of the destination buckets (ISA inversion)
+    size_t n_cursors;
     SortScratch sc;
 };
 
@@ -54,6 +56,8 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
     w.d_nact = a.take<uint64_t>(nt);
     w.d_nunf = a.take<uint64_t>(nt);
     w.d_totals = a.take<uint64_t>(4);
+    w.n_cursors = (size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P;
+    w.d_cursors = a.take<unsigned>(w.n_cursors);
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.desc_bytes = sort_desc_bytes(n);
@@ -134,6 +138,39 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
                            dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact);
         PSACX_HIP(c, hipGetLastError());
     }
+    return PSACX_OK;
+}
+
+// ISA[SA[i]] = val[i] - 1 for a full permutation SA (bulk_permute.hpp:14-73).  Large inputs go
+// through destination-partition passes + an LDS window scatter (see partition_pairs_kernel);
+// t1/t2 are two scratch pair buffers of n entries each.
+template <typename T>
+int invert_permutation(psacx_ctx* c, Work<T>& w, const T* d_sa, const T* val, uint64_t n, T* d_isa,
+                       SortBufs<T> t1, SortBufs<T> t2) {
+    constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average
+    const unsigned idx_bits = bits_for(n - 1);
+    if (n < (1ull << 22) || idx_bits > INV_WINDOW_BITS + 24) {
+        hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa, val, n, d_isa);
+        PSACX_HIP(c, hipGetLastError());
+        return PSACX_OK;
+    }
+    const int levels = (int)((idx_bits - INV_WINDOW_BITS + 7) / 8);
+    const T* kin = d_sa; const T* vin = val;
+    SortBufs<T> bufs[2] = {t1, t2};
+    for (int lv = 0; lv < levels; ++lv) {
+        const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
+        const size_t ncur = (size_t)(n >> shift) + 1;
+        PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ncur * sizeof(unsigned), c->stream));
+        SortBufs<T> o = bufs[lv & 1];
+        const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
+        hipLaunchKernelGGL((partition_pairs_kernel<T, PB, PI>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, kin, vin,
+                           o.k1, o.k2, n, shift, w.d_cursors);
+        PSACX_HIP(c, hipGetLastError());
+        kin = o.k1; vin = o.k2;
+    }
+    const uint64_t nwin = (n + (1ull << INV_WINDOW_BITS) - 1) >> INV_WINDOW_BITS;
+    hipLaunchKernelGGL((window_scatter_kernel<T, 512>), dim3((unsigned)nwin), dim3(512), 0, c->stream, kin, vin, n, d_isa);
+    PSACX_HIP(c, hipGetLastError());
     return PSACX_OK;
 }
 
@@ -220,9 +257,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
     {
         ProfScope ps(c, TC_ISA_SCATTER);
-        hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa,
-                           w.bsa, n, d_isa);
-        PSACX_HIP(c, hipGetLastError());
+        PSACX_TRY(invert_permutation<T>(c, w, d_sa, w.bsa, n, d_isa, w.x, w.y));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);

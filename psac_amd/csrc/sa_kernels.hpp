@@ -15,6 +15,8 @@
 
 namespace psacx {
 
+constexpr int RADIX_P = 256;    // fan-out of one destination-partition pass
+
 struct CodeTable { uint16_t c[256]; };   // codes 1..sigma (sigma may be 256)
 
 // ------------------------------------------------------------------ K1
@@ -290,6 +292,104 @@ __global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         ISA[SA[i]] = Bsa[i] - 1;      // ISA holds 0-based ranks throughout (suffix_array.hpp:460-464)
+}
+
+// ------------------------------------------------------------------ K8, cache-friendly form
+// ISA[SA[i]] = val[i] - 1 is the inverse of a permutation; written directly it is n
+// random 4/8-byte stores (32 B of HBM traffic each).  Because SA is a permutation,
+// the destination range [g << s, (g + 1) << s) receives EXACTLY its own size in
+// records, so the pairs can be MSD-partitioned by destination with no histogram: each
+// tile reserves room in bucket g with one atomicAdd (order inside a bucket is
+// irrelevant), and after one or two such passes every bucket is a 4096-entry
+// window that one workgroup scatters inside LDS and writes out as full lines.
+constexpr int INV_WINDOW_BITS = 12;
+
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
+    const T* __restrict__ key_in, const T* __restrict__ val_in, T* __restrict__ key_out,
+    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ T stage[TILE];
+    __shared__ unsigned cnt[RADIX_P];
+    __shared__ unsigned bstart[RADIX_P];
+    __shared__ uint64_t gbase[RADIX_P];
+    __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
+    const unsigned tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
+    for (int i = tid; i < RADIX_P; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    T key[ITEMS], val[ITEMS];
+    unsigned slot[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        if (loc < count) { key[i] = key_in[base + loc]; val[i] = val_in[base + loc]; }
+        else { key[i] = 0; val[i] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        const unsigned d = (unsigned)(key[i] >> shift) & (RADIX_P - 1);
+        slot[i] = loc < count ? atomicAdd(&cnt[d], 1u) : 0u;
+    }
+    __syncthreads();
+    // all keys of a tile share the bits above shift + 8 (tiles never straddle a parent bucket)
+    const unsigned tot = tid < RADIX_P ? cnt[tid] : 0u;
+    unsigned total;
+    const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, scan_tmp, &total);
+    if (tid < RADIX_P) {
+        bstart[tid] = bs;
+        if (tot) {
+            const uint64_t parent = (uint64_t)(key_in[base] >> shift) >> 8;   // same for the whole tile
+            const uint64_t g = (parent << 8) | tid;
+            const unsigned at = atomicAdd(&cursors[g], tot);
+            gbase[tid] = (g << shift) + at - bs;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned d = (unsigned)(key[i] >> shift) & (RADIX_P - 1);
+        slot[i] += bstart[d];
+        if (tid + i * BLOCK < count) stage[slot[i]] = key[i];
+    }
+    __syncthreads();
+    uint64_t dest[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (p < count) {
+            const T x = stage[p];
+            dest[j] = gbase[(unsigned)(x >> shift) & (RADIX_P - 1)] + p;
+            key_out[dest[j]] = x;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (tid + i * BLOCK < count) stage[slot[i]] = val[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (p < count) val_out[dest[j]] = stage[p];
+    }
+}
+
+// one workgroup per window of 2^INV_WINDOW_BITS destinations
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const T* __restrict__ key, const T* __restrict__ val,
+                                                               uint64_t n, T* __restrict__ out) {
+    constexpr unsigned W = 1u << INV_WINDOW_BITS;
+    __shared__ T win[W];
+    const uint64_t base = (uint64_t)blockIdx.x * W;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (T)(val[base + p] - 1);
+    __syncthreads();
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = win[p];
 }
 
 // ------------------------------------------------------------------ K12

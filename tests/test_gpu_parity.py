@@ -150,6 +150,16 @@ def test_medium_dna_properties(ctx):
     assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
 
 
+def test_isa_inversion_partition_path(ctx):
+    # sizes >= 2^22 take the destination-partition path of the SA -> ISA inversion
+    # (bulk_permute.hpp:14-73); ragged sizes leave partial buckets / windows
+    for n, bits in (((1 << 22) + 12345, 32), ((1 << 22) + 4097, 64), ((1 << 23) - 1, 32)):
+        text = inputs.dna(n, 4)
+        sa = run(ctx, text, bits=bits)
+        assert O.check_sa(text, sa.local_SA, sa.local_B) == 0
+        assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
+
+
 def test_pair_sort_standalone(ctx):
     # idxsort.hpp:23-83: records (b1, b2, i) sorted by (b1, b2)
     import ctypes as C
