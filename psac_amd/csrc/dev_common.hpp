@@ -47,6 +47,31 @@ template <> __device__ __forceinline__ uint64_t shfl_xor<uint64_t>(uint64_t v, i
     return ((uint64_t)hi << 32) | lo;
 }
 
+// XCD (chiplet) this wave runs on, 0..7.  Used for speed only (which L2 a tile's writes
+// land in), never for correctness.
+__device__ __forceinline__ unsigned xcc_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
+// Hands out tile numbers so that `chunk` consecutive tiles are taken by workgroups of the
+// SAME XCD right after one another: their output runs share cache lines, and only one L2
+// can merge them into full-line write-backs.  Chunks are dealt round-robin to eight
+// queues (queue q owns chunks q, q+8, ...); a workgroup draws from the queue of its own
+// XCD and, once that is empty, from the others, so every tile is handed out exactly once
+// whatever the placement.  qcnt: eight zeroed counters.  Call from one thread.
+__device__ __forceinline__ unsigned claim_tile(unsigned* qcnt, unsigned ntiles, unsigned chunk) {
+    if (chunk == 0) return atomicAdd(qcnt, 1u);
+    const unsigned x = xcc_id();
+    for (unsigned r = 0; r < 8; ++r) {
+        const unsigned q = (x + r) & 7u;
+        const unsigned k = atomicAdd(&qcnt[q], 1u);
+        const unsigned long long tile = ((unsigned long long)(k / chunk) * 8u + q) * chunk + k % chunk;
+        if (tile < ntiles) return (unsigned)tile;
+    }
+    return ntiles;   // unreachable when the grid has exactly ntiles workgroups
+}
+
 struct OpSum {
     template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
 };

@@ -142,7 +142,21 @@ struct SortScratch {
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
 
 inline size_t sort_desc_bytes(uint64_t n) {
-    return 256 + ((n + SORT_TILE_MIN - 1) / SORT_TILE_MIN + 1) * RADIX * sizeof(uint64_t);
+    const uint64_t nt = (n + SORT_TILE_MIN - 1) / SORT_TILE_MIN + 1;
+    // look-back descriptors, or (three-kernel form) per-tile counters + per-slab totals
+    return 1024 + nt * RADIX * sizeof(uint64_t) + (nt / SLAB_TILES + 2) * RADIX * sizeof(uint64_t);
+}
+
+inline unsigned sort_chunk_env() {   // tiles per XCD-local chunk (0 = plain ticket order)
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PSACX_SORT_CHUNK"); v = e ? atoi(e) : -1; }
+    return (unsigned)v;
+}
+inline unsigned sort_chunk_for(uint64_t n, bool three) {
+    const unsigned e = sort_chunk_env();
+    if (e != (unsigned)-1) return e;
+    if (n < (1ull << 21)) return 0;          // few tiles: plain start order
+    return three ? 64u : 16u;
 }
 
 template <typename T, typename D, int BLOCK, int ITEMS>
@@ -153,11 +167,12 @@ inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     hipLaunchKernelGGL((radix_scatter_kernel<T, D, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
                        c->stream, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base,
-                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err, dbg, spec, spec_n);
+                       reinterpret_cast<D*>(desc + 256), reinterpret_cast<unsigned*>(desc), err, dbg, spec, spec_n,
+                       sort_chunk_for(n, false));
 }
 
 template <typename T> struct ScatterCfg;
-template <> struct ScatterCfg<uint32_t> { static constexpr int DEF = 1; };
+template <> struct ScatterCfg<uint32_t> { static constexpr int DEF = 7; };
 template <> struct ScatterCfg<uint64_t> { static constexpr int DEF = 0; };
 
 inline int sort_cfg_env() {
@@ -194,6 +209,49 @@ inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_
         default: PSACX_SC(256, 16); break;
     }
 #undef PSACX_SC
+}
+
+inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three kernels per pass
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PSACX_SORT_MODE"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
+template <typename T, int BLOCK, int ITEMS>
+inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
+                         uint64_t n, int shift, const unsigned long long* base, char* scratch,
+                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
+    constexpr int TILE = BLOCK * ITEMS;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
+    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
+                       shift, tile_hist);
+    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
+    hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs);
+    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                       ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                       getenv("PSACX_SORT_STATIC") ? (unsigned*)nullptr : reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true));
+}
+
+template <typename T>
+inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out,
+                           T* v_out, uint64_t n, int shift, const unsigned long long* base, char* scratch,
+                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
+#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n)
+    switch (cfg) {
+        case 0: PSACX_P3(256, 8); break;
+        case 2: PSACX_P3(512, 8); break;
+        case 3: PSACX_P3(512, 16); break;
+        case 4: PSACX_P3(256, 12); break;
+        case 5: PSACX_P3(1024, 4); break;
+        case 6: PSACX_P3(1024, 8); break;
+        case 7: PSACX_P3(512, 12); break;
+        case 1:
+        default: PSACX_P3(256, 16); break;
+    }
+#undef PSACX_P3
 }
 
 // Sorts `n` records by (k1, k2); bits1/bits2 = significant low bits of each word.
@@ -263,11 +321,16 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         const uint64_t tile = cfg_tile(cfg);
         const uint64_t ntiles = (n + tile - 1) / tile;
         const size_t dbytes = 256 + ntiles * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t));
-        PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, dbytes, c->stream));
+        // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
+        // single-sweep look-back form for small ones where launch count matters more
+        const bool three = sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21);
+        PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
         {
             ProfScope ps(c, TC_SORT_SCATTER);
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
-            if (small_desc)
+            if (three)
+                dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n);
+            else if (small_desc)
                 dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
             else
                 dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);

@@ -19,6 +19,7 @@ namespace psacx {
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int MAX_PASSES = 2 * (64 / RADIX_BITS);   // two 64-bit key words
+constexpr int SLAB_TILES = 64;                       // tiles per slab of the three-kernel offset scan
 
 // pass p < passes_lo reads key2 (low word), the rest read key1
 struct PassPlan {
@@ -104,13 +105,16 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 };
 
 // FULL: the tile holds exactly TILE records, so no bounds guards are compiled in.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL>
+// LB: global offsets by decoupled look-back over `desc`; otherwise they were
+// precomputed (tile_excl row of this tile + slab_excl row of its slab).
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
-    unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n) {
+    unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
+    const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     T* const stage = sh.stage;
@@ -155,7 +159,10 @@ __device__ __forceinline__ void radix_scatter_tile(
         }
     }
 
-    // rank inside the wave, round by round (keeps the sort stable)
+    // rank inside the wave, round by round (keeps the sort stable).  Every lane reads the
+    // wave's running count of its digit, then the lowest lane of each digit group adds the
+    // group size; LDS operations of one wave execute in program order, so the rounds chain
+    // through the counters without any explicit wait between them.
     unsigned rank[ITEMS];
     unsigned* mycnt = wcnt + wave * RADIX;
     const uint64_t lt = lanemask_lt();
@@ -164,13 +171,9 @@ __device__ __forceinline__ void radix_scatter_tile(
         const bool valid = FULL || (wbase + i * WAVE) < count;
         const unsigned d = (unsigned)(kd[i] >> shift) & (RADIX - 1);
         const uint64_t m = match_any8(d, valid);
-        unsigned prior = 0;
-        const unsigned leader = m ? (unsigned)__builtin_ctzll(m) : 0u;
-        if (valid && lane == leader) {
-            prior = mycnt[d];
-            mycnt[d] = prior + (unsigned)__builtin_popcountll(m);
-        }
-        prior = shfl<uint32_t>(prior, (int)leader);
+        const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (valid && (m & lt) == 0)
+            __hip_atomic_fetch_add(&mycnt[d], (unsigned)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         rank[i] = prior + (unsigned)__builtin_popcountll(m & lt);
     }
     __syncthreads();
@@ -186,7 +189,7 @@ __device__ __forceinline__ void radix_scatter_tile(
             tot += c;
         }
         // publish the tile aggregate as early as possible
-        desc_store<D>(desc + (uint64_t)tile * RADIX + tid, tile == 0 ? 2u : 1u, (D)tot);
+        if (LB) desc_store<D>(desc + (uint64_t)tile * RADIX + tid, tile == 0 ? 2u : 1u, (D)tot);
     }
     unsigned tile_total;
     unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tid < RADIX ? tot : 0u, OpSum(), 0u, scan_tmp, &tile_total);
@@ -194,7 +197,10 @@ __device__ __forceinline__ void radix_scatter_tile(
     if (tid < RADIX) {
         bstart[tid] = bs;
         uint64_t excl = 0;
-        if (tile != 0) {
+        if (!LB) {
+            excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] +
+                   (uint64_t)slab_excl[(uint64_t)(tile / SLAB_TILES) * RADIX + tid];
+        } else if (tile != 0) {
             long long t = (long long)tile - 1;
             const D* dp = desc + tid;
             // two predecessors per step: the second load is speculative and hides one round trip
@@ -261,22 +267,120 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc,
     unsigned* __restrict__ tile_counter, unsigned* __restrict__ err,
-    unsigned long long* __restrict__ dbg, uint64_t spec, uint64_t spec_n) {
+    unsigned long long* __restrict__ dbg, uint64_t spec, uint64_t spec_n, unsigned chunk) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
     __shared__ ScatterShared<T, TILE, NW> sh;
-    if (threadIdx.x == 0) sh.s_tile = atomicAdd(tile_counter, 1u);
+    if (threadIdx.x == 0) sh.s_tile = claim_tile(tile_counter, gridDim.x, chunk);
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
     __syncthreads();
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, D, BLOCK, ITEMS, true>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out, ko_out,
-                                                     v_out, shift, digit_base, desc, err, dbg, spec, spec_n);
+        radix_scatter_tile<T, D, BLOCK, ITEMS, true, true>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out, ko_out,
+                                                     v_out, shift, digit_base, desc, err, dbg, spec, spec_n, nullptr, nullptr);
     else
-        radix_scatter_tile<T, D, BLOCK, ITEMS, false>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out, ko_out,
-                                                      v_out, shift, digit_base, desc, err, dbg, spec, spec_n);
+        radix_scatter_tile<T, D, BLOCK, ITEMS, false, true>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out, ko_out,
+                                                      v_out, shift, digit_base, desc, err, dbg, spec, spec_n, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// Three-kernel form of a pass (no inter-workgroup waiting): per-tile digit
+// histograms -> exclusive scan over tiles (within slabs of SLAB_TILES tiles, then
+// over slabs) -> scatter with known offsets.  Costs one extra read of the digit
+// word (w bytes per record) and 1 KiB of counters per tile.
+// ---------------------------------------------------------------------------
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist_kernel(const T* __restrict__ kd_in, uint64_t n, int shift,
+                                                                unsigned* __restrict__ tile_hist) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int PER = 16 / sizeof(T);
+    static_assert(ITEMS % PER == 0, "ITEMS must cover whole vectors");
+    __shared__ unsigned lh[4][RADIX];
+    for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    unsigned* my = lh[(threadIdx.x / WAVE) & 3];
+#pragma unroll
+    for (int v = 0; v < ITEMS / PER; ++v) {
+        const uint64_t e0 = base + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
+        T x[PER];
+        load_run<T, PER>(kd_in, e0, n, x, (T)0);
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (e0 + j < n) atomicAdd(&my[(unsigned)(x[j] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX; d += BLOCK)
+        tile_hist[(uint64_t)blockIdx.x * RADIX + d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
+}
+
+// one workgroup per slab: in-place exclusive scan of its tiles' counts per digit, slab totals out
+template <int TAG>
+__global__ __launch_bounds__(RADIX) void radix_slab_scan_kernel(unsigned* __restrict__ tile_hist, uint64_t ntiles,
+                                                                unsigned long long* __restrict__ slab_tot) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * SLAB_TILES;
+    const unsigned d = threadIdx.x;
+    unsigned long long run = 0;
+    constexpr int B = 16;
+    for (int b0 = 0; b0 < SLAB_TILES; b0 += B) {
+        unsigned v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) v[j] = (t0 + b0 + j < ntiles) ? tile_hist[(t0 + b0 + j) * RADIX + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (t0 + b0 + j < ntiles) tile_hist[(t0 + b0 + j) * RADIX + d] = (unsigned)run;
+            run += v[j];
+        }
+    }
+    slab_tot[(uint64_t)blockIdx.x * RADIX + d] = run;
+}
+
+// one workgroup: exclusive scan of the slab totals per digit (in place)
+template <int TAG>
+__global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long long* __restrict__ slab_tot, uint64_t nslabs) {
+    const unsigned d = threadIdx.x;
+    unsigned long long run = 0;
+    constexpr int B = 16;
+    for (uint64_t b0 = 0; b0 < nslabs; b0 += B) {
+        unsigned long long v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) v[j] = (b0 + j < nslabs) ? slab_tot[(b0 + j) * RADIX + d] : 0ull;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (b0 + j < nslabs) slab_tot[(b0 + j) * RADIX + d] = run;
+            run += v[j];
+        }
+    }
+}
+
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_scatter3_kernel(
+    const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
+    T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
+    const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
+    const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
+    uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int NW = BLOCK / WAVE;
+    static_assert(BLOCK >= RADIX, "one thread per digit needed");
+    __shared__ ScatterShared<T, TILE, NW> sh;
+    // tiles are handed out in start order so that neighbouring runs of a digit are written
+    // close in time (they share cache lines); nothing ever waits on another workgroup
+    if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
+    for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
+    __syncthreads();
+    const unsigned tile = sh.s_tile;
+    const uint64_t remain = n - (uint64_t)tile * TILE;
+    if (remain >= (uint64_t)TILE)
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+                                                                   ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
+                                                                   spec, spec_n, tile_excl, slab_excl);
+    else
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+                                                                    ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
+                                                                    spec, spec_n, tile_excl, slab_excl);
 }
 
 } // namespace psacx
