@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per launch of the dominant kernel from the PMC counters of the committed profile
+# (profiles/): FETCH_SIZE doubled (the gfx950 correction for coalesced streams) + WRITE_SIZE.
+# None until a PMC run of the current kernel has been recorded there.
+TRAFFIC_PER_LAUNCH = None
 
 
 def parse():
@@ -98,12 +102,16 @@ def main():
     for _ in range(a.warmup):
         step(False)
     barrier()
-    scat_ms = 0.0; scat_bytes = 0; scat_launches = 0; hist_ms = 0.0
+    # dominant kernel: the scatter kernel of a radix pass.  Large sorts use
+    # radix_scatter3_kernel (index 1), small ones radix_scatter_kernel (index 0); the
+    # roofline is quoted on whichever moved more bytes in the timed region.
+    scat_ms = [0.0, 0.0]; scat_bytes = [0, 0]; scat_launches = [0, 0]
     t0 = time.perf_counter()
     for _ in range(a.steps):
         s = step(True)
-        scat_ms += s.ms_sort_scatter; scat_bytes += s.scatter_bytes; scat_launches += s.scatter_launches
-        hist_ms += s.ms_sort_hist
+        scat_ms[0] += s.ms_sort_scatter; scat_ms[1] += s.ms_sort_scatter3
+        for q in (0, 1):
+            scat_bytes[q] += s.scatter_bytes[q]; scat_launches[q] += s.scatter_launches[q]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -118,7 +126,9 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * n * a.steps / dt / 1e6
-        achieved = scat_bytes / (scat_ms * 1e-3) / 1e9 if scat_ms > 0 else 0.0
+        dom = 1 if scat_bytes[1] >= scat_bytes[0] else 0
+        kname = ("radix_scatter3_kernel" if dom else "radix_scatter_kernel")
+        achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
         s_last = s
         out = {
             "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
@@ -130,15 +140,17 @@ def main():
                        "n_per_gpu": n, "k": int(s_last.k), "bits_per_char": int(s_last.bits_per_char),
                        "rounds": int(s_last.n_rounds),
                        "parallelism": "1 process per GPU" if world == 1 else "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel (one 8-bit digit pass of the (B1,B2,idx) sort)",
+            "roofline": {"bound": "hbm", "kernel": kname + " (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "avg_launch_ms": round(scat_ms / max(scat_launches, 1), 4),
-                         "launches_per_step": scat_launches // max(a.steps, 1),
-                         "bytes_per_record_per_pass": 6 * w, "traffic": None},
+                         "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
+                         "launches_per_step": scat_launches[dom] // max(a.steps, 1),
+                         "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
+                         "bytes_per_record_per_pass": 6 * w, "traffic": TRAFFIC_PER_LAUNCH},
             "phase_ms_last_step": {"total": round(s_last.ms_total, 3), "alphabet": round(s_last.ms_alphabet, 3),
                                    "kmer": round(s_last.ms_kmer, 3), "sort_hist": round(s_last.ms_sort_hist, 3),
-                                   "sort_scatter": round(s_last.ms_sort_scatter, 3),
+                                   "sort_scatter": round(s_last.ms_sort_scatter + s_last.ms_sort_scatter3, 3),
+                                   "sort_tile_hist": round(s_last.ms_sort_tilehist, 3),
                                    "rebucket": round(s_last.ms_rebucket, 3), "isa_scatter": round(s_last.ms_isa_scatter, 3),
                                    "gather": round(s_last.ms_gather, 3), "compact": round(s_last.ms_compact, 3),
                                    "rmq_build": round(s_last.ms_rmq_build, 3), "finalize": round(s_last.ms_finalize, 3)},

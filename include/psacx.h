@@ -67,9 +67,14 @@ typedef struct psacx_stats {
     double ms_total;               /* whole construct call, device side */
     double ms_alphabet, ms_kmer, ms_sort_hist, ms_sort_scatter, ms_rebucket, ms_isa_scatter,
            ms_gather, ms_compact, ms_rmq_build, ms_finalize;
-    uint64_t scatter_launches;     /* number of radix scatter-pass kernels launched */
-    uint64_t scatter_records;      /* records moved by them (sum over launches) */
-    uint64_t scatter_bytes;        /* algorithmic bytes: 2 * 3w per record */
+    /* the radix scatter-pass kernel, counted per form: [0] = single-sweep look-back form
+       (radix_scatter_kernel, small inputs), [1] = three-kernel form (radix_scatter3_kernel,
+       large inputs; ms_sort_scatter3 times only that kernel, its per-tile histogram and
+       offset scans are in ms_sort_tilehist) */
+    double ms_sort_scatter3, ms_sort_tilehist;
+    uint64_t scatter_launches[2];  /* kernels launched */
+    uint64_t scatter_records[2];   /* records moved by them (sum over launches) */
+    uint64_t scatter_bytes[2];     /* algorithmic bytes: 2 * 3w per record */
     uint64_t hist_bytes;           /* algorithmic bytes of the histogram kernels: 2w per record */
     uint64_t workspace_bytes;      /* HBM held by the ctx */
 } psacx_stats;

@@ -18,7 +18,7 @@
 namespace psacx {
 
 enum TimerCat {
-    TC_ALPHABET = 0, TC_KMER, TC_SORT_HIST, TC_SORT_SCATTER, TC_REBUCKET, TC_ISA_SCATTER,
+    TC_ALPHABET = 0, TC_KMER, TC_SORT_HIST, TC_SORT_SCATTER, TC_SORT_SCATTER3, TC_SORT_TILEHIST, TC_REBUCKET, TC_ISA_SCATTER,
     TC_GATHER, TC_COMPACT, TC_RMQ_BUILD, TC_FINALIZE, TC_TOTAL, TC_COUNT
 };
 
@@ -80,7 +80,8 @@ inline void prof_collect(psacx_ctx* c) {
     }
     psacx_stats& s = c->stats;
     s.ms_alphabet = acc[TC_ALPHABET]; s.ms_kmer = acc[TC_KMER]; s.ms_sort_hist = acc[TC_SORT_HIST];
-    s.ms_sort_scatter = acc[TC_SORT_SCATTER]; s.ms_rebucket = acc[TC_REBUCKET];
+    s.ms_sort_scatter = acc[TC_SORT_SCATTER]; s.ms_sort_scatter3 = acc[TC_SORT_SCATTER3];
+    s.ms_sort_tilehist = acc[TC_SORT_TILEHIST]; s.ms_rebucket = acc[TC_REBUCKET];
     s.ms_isa_scatter = acc[TC_ISA_SCATTER]; s.ms_gather = acc[TC_GATHER]; s.ms_compact = acc[TC_COMPACT];
     s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
 }
@@ -226,10 +227,14 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
-                       shift, tile_hist);
-    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
-    hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs);
+    {
+        ProfScope ps(c, TC_SORT_TILEHIST);
+        hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
+                           shift, tile_hist);
+        hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
+        hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs);
+    }
+    ProfScope ps(c, TC_SORT_SCATTER3);
     hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                        ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
                        getenv("PSACX_SORT_STATIC") ? (unsigned*)nullptr : reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true));
@@ -325,12 +330,14 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         // single-sweep look-back form for small ones where launch count matters more
         const bool three = sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21);
         PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
-        {
+        if (three) {
+            const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
+            dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n);
+            PSACX_HIP(c, hipGetLastError());
+        } else {
             ProfScope ps(c, TC_SORT_SCATTER);
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
-            if (three)
-                dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n);
-            else if (small_desc)
+            if (small_desc)
                 dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
             else
                 dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
@@ -347,9 +354,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             fprintf(stderr, "[psacx sort dbg] pass %d n=%llu tiles=%llu cycles/tile: load+rank %.0f scan %.0f lookback %.0f key %.0f key2 %.0f val %.0f\n",
                     p, (unsigned long long)n, (unsigned long long)ntiles, acc[0] / ns, acc[1] / ns, acc[2] / ns, acc[3] / ns, acc[4] / ns, acc[5] / ns);
         }
-        c->stats.scatter_launches += 1;
-        c->stats.scatter_records += n;
-        c->stats.scatter_bytes += 6ull * sizeof(T) * n;
+        c->stats.scatter_launches[three ? 1 : 0] += 1;
+        c->stats.scatter_records[three ? 1 : 0] += n;
+        c->stats.scatter_bytes[three ? 1 : 0] += 6ull * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
     }

@@ -472,18 +472,32 @@ __global__ void pyramid_level_kernel(const T* __restrict__ in, uint64_t len_in, 
     }
 }
 
+// min over [l, r), l < r.  Each level contributes at most 63 leading and 63 trailing
+// entries; they are fetched as predicated, fully unrolled batches so that the loads of a
+// level are all in flight together instead of forming a dependent chain.
+template <typename T>
+__device__ __forceinline__ T pyramid_edge_min(const T* __restrict__ a, uint64_t lo, uint64_t hi, T m) {
+    // hi - lo <= 128
+#pragma unroll 1
+    for (uint64_t b = lo; b < hi; b += 16) {
+        T v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = (b + t < hi) ? a[b + t] : ~(T)0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m = v[t] < m ? v[t] : m;
+    }
+    return m;
+}
+
 template <typename T>
 __device__ __forceinline__ T pyramid_min(const Pyramid<T>& P, uint64_t l, uint64_t r) {
     T m = ~(T)0;
     for (int L = 0; L < P.nlev; ++L) {
         const T* a = P.lvl[L];
-        if (r - l <= 128 || L == P.nlev - 1) {
-            for (uint64_t i = l; i < r; ++i) { const T x = a[i]; m = x < m ? x : m; }
-            return m;
-        }
+        if (r - l <= 128 || L == P.nlev - 1) return pyramid_edge_min<T>(a, l, r, m);
         const uint64_t lb = (l + 63) >> 6, rb = r >> 6;
-        for (uint64_t i = l; i < (lb << 6); ++i) { const T x = a[i]; m = x < m ? x : m; }
-        for (uint64_t i = (rb << 6); i < r; ++i) { const T x = a[i]; m = x < m ? x : m; }
+        m = pyramid_edge_min<T>(a, l, lb << 6, m);
+        m = pyramid_edge_min<T>(a, rb << 6, r, m);
         l = lb; r = rb;
         if (l >= r) return m;
     }
@@ -502,6 +516,9 @@ __device__ __forceinline__ void pyramid_set(const Pyramid<T>& P, uint64_t p, T v
     uint64_t q = p;
     for (int L = 1; L < P.nlev; ++L) {
         q >>= 6;
+        // entries only ever decrease, so a (possibly stale) value <= v proves the atomic is a no-op;
+        // without this test every update of a round hammers the single top-level word
+        if (P.lvl[L][q] <= v) break;
         atomic_min_t<T>(&P.lvl[L][q], v);
     }
 }

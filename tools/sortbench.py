@@ -33,10 +33,12 @@ for r in range(reps):
     ctx.h2d(d1, b1); ctx.h2d(d2, b2)
     ctx.check(fn(ctx.handle, C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(di), n, k * l))
     s = ctx.stats()
-    per = s.ms_sort_scatter / max(s.scatter_launches, 1)
-    gbs = s.scatter_bytes / (s.ms_sort_scatter * 1e-3) / 1e9
-    print("cfg=%s n=2^%d u%d: hist %.3f ms, scatter %.3f ms over %d passes (%.3f ms/pass) -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s)"
-          % (os.environ.get("PSACX_SORT_CFG", "def"), logn, bits, s.ms_sort_hist, s.ms_sort_scatter, s.scatter_launches, per, gbs, gbs / 80.0))
+    q = 1 if s.scatter_bytes[1] else 0
+    ms = s.ms_sort_scatter3 if q else s.ms_sort_scatter
+    per = ms / max(s.scatter_launches[q], 1)
+    gbs = s.scatter_bytes[q] / (ms * 1e-3) / 1e9
+    print("cfg=%s n=2^%d u%d: hist %.3f ms, tile-hist %.3f ms, scatter %.3f ms over %d passes (%.3f ms/pass) -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s)"
+          % (os.environ.get("PSACX_SORT_CFG", "def"), logn, bits, s.ms_sort_hist, s.ms_sort_tilehist, ms, s.scatter_launches[q], per, gbs, gbs / 80.0))
 if logn <= 24:
     o1 = np.empty(n, dt); o2 = np.empty(n, dt); oi = np.empty(n, dt)
     ctx.d2h(o1, d1); ctx.d2h(o2, d2); ctx.d2h(oi, di)
