@@ -63,6 +63,8 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
     w.sc.desc_bytes = sort_desc_bytes(n);
     w.sc.d_desc = a.take<char>(w.sc.desc_bytes);
     w.sc.d_err = a.take<unsigned>(64);
+    w.sc.d_summary = a.take<unsigned long long>(8);
+    w.sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
     w.sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     return a.off;
 }
@@ -198,6 +200,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     st.workspace_bytes = c->slab_bytes;
     w.sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
     w.sc.h_base = w.sc.h_hist + (size_t)MAX_PASSES * RADIX;
+    w.sc.h_summary = reinterpret_cast<unsigned long long*>(c->pinned + 256);
     PSACX_HIP(c, hipMemsetAsync(w.sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
 
     ProfScope* total = new ProfScope(c, TC_TOTAL);
@@ -234,15 +237,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         constexpr int KB = 256, KI = 8;
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
         hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n,
-                           tab, ks, w.x.k1, w.x.k2);
+                           tab, ks, w.x.k1, w.x.k2, w.sc.d_partials);
         PSACX_HIP(c, hipGetLastError());
+        PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
     }
 
     // ---- first rank-pair sort (idxsort.hpp:23-83); payload = text position -> SA
     psacx_round* r0 = &st.rounds[0];
     std::memset(r0, 0, sizeof(*r0));
     SortBufs<T> sorted;
-    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, d_sa, &sorted, r0, ks.spec, n));
+    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, d_sa, &sorted, r0, ks.spec, n, /*summary_ready=*/true));
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     {
@@ -284,11 +288,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         if (rr) std::memset(rr, 0, sizeof(*rr));
         {
             ProfScope ps(c, TC_GATHER);
-            hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(grid_for(c, cnt, 256, 16)), dim3(256), 0, c->stream,
-                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v);
+            const int gg = grid_for(c, cnt, 256, 16);
+            hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
+                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v, w.sc.d_partials);
             PSACX_HIP(c, hipGetLastError());
+            PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
-        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr));
+        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr, 0, 0,
+                               /*summary_ready=*/true));
         T* ids = (sorted.k1 == w.x.k1) ? w.y.k1 : w.x.k1;     // the set not holding the result is free
         {
             ProfScope ps(c, TC_REBUCKET);
@@ -385,6 +392,8 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
         sc.desc_bytes = sort_desc_bytes(n);
         sc.d_desc = a.take<char>(sc.desc_bytes);
         sc.d_err = a.take<unsigned>(64);
+        sc.d_summary = a.take<unsigned long long>(8);
+        sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
         sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     };
     SortBufs<T> alt; SortScratch sc; T* vtmp;
@@ -394,6 +403,7 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
     layout(ar, alt, sc, vtmp);
     sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
     sc.h_base = sc.h_hist + (size_t)MAX_PASSES * RADIX;
+    sc.h_summary = reinterpret_cast<unsigned long long*>(c->pinned + 256);
     PSACX_HIP(c, hipMemsetAsync(sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
     std::memset(&c->stats, 0, sizeof(c->stats));
     c->profile = true; c->ev_used = 0;

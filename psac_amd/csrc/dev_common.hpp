@@ -37,6 +37,9 @@ template <> __device__ __forceinline__ uint64_t shfl_up<uint64_t>(uint64_t v, in
     uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, WAVE);
     return ((uint64_t)hi << 32) | lo;
 }
+template <> __device__ __forceinline__ unsigned long long shfl_up<unsigned long long>(unsigned long long v, int d) {
+    return (unsigned long long)shfl_up<uint64_t>((uint64_t)v, d);
+}
 template <typename T> __device__ __forceinline__ T shfl_xor(T v, int m);
 template <> __device__ __forceinline__ uint32_t shfl_xor<uint32_t>(uint32_t v, int m) {
     return (uint32_t)__shfl_xor((int)v, m, WAVE);
@@ -77,6 +80,12 @@ struct OpSum {
 };
 struct OpMax {
     template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; }
+};
+struct OpOr {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a | b; }
+};
+struct OpAnd {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a & b; }
 };
 struct OpMin {
     template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? a : b; }

@@ -138,6 +138,9 @@ struct SortScratch {
     unsigned long long* h_hist;    // pinned
     unsigned long long* h_base;    // pinned
     unsigned long long* d_dbg;     // phase stamps of sampled tiles (PSACX_SORT_DEBUG), may be null
+    unsigned long long* d_summary; // OR/AND of the keys (see key_summary_add), 4 words
+    unsigned long long* h_summary; // pinned, 4 words
+    unsigned long long* d_partials;// per-workgroup key summaries of the producer kernel
 };
 
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
@@ -232,7 +235,8 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
         hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
                            shift, tile_hist);
         hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
-        hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs);
+        hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs,
+                           const_cast<unsigned long long*>(base));
     }
     ProfScope ps(c, TC_SORT_SCATTER3);
     hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
@@ -259,6 +263,13 @@ inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in
 #undef PSACX_P3
 }
 
+// folds the per-workgroup key summaries a producer kernel left in sc.d_partials into sc.d_summary
+inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
+    hipLaunchKernelGGL(summary_reduce_kernel<0>, dim3(1), dim3(1024), 0, c->stream, sc.d_partials, nblocks, sc.d_summary);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
 // Sorts `n` records by (k1, k2); bits1/bits2 = significant low bits of each word.
 // With `iota` the payload read by the first pass is the record index, or, when spec_n is
 // set, the suffix start the first-round record stands for (in.v is only scratch).  The sorted arrays end up in
@@ -267,45 +278,65 @@ inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in
 template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
-              uint64_t spec = 0, uint64_t spec_n = 0) {
+              uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false) {
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
     const PassPlan plan = make_plan((int)bits1, (int)bits2);
-    HistArgs ha;
-    ha.n_pass = plan.n_pass;
-    for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
-
-    {
-        ProfScope ps(c, TC_SORT_HIST);
-        PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
-        const int grid = grid_for(c, (n + 3) / 4, 256, 8);
-        hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n,
-                           ha, sc.d_hist);
-        PSACX_HIP(c, hipGetLastError());
-    }
-    PSACX_HIP(c, hipMemcpyAsync(sc.h_hist, sc.d_hist, sizeof(unsigned long long) * plan.n_pass * RADIX,
-                                hipMemcpyDeviceToHost, c->stream));
-    PSACX_HIP(c, hipStreamSynchronize(c->stream));
-    c->stats.hist_bytes += 2ull * sizeof(T) * n;
-
+    // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
+    // single-sweep look-back form for small ones where launch count matters more
+    const bool three = sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21);
     bool skip[MAX_PASSES];
     int n_exec = 0;
-    for (int p = 0; p < plan.n_pass; ++p) {
-        const unsigned long long* h = sc.h_hist + (size_t)p * RADIX;
-        unsigned long long run = 0;
-        skip[p] = false;
-        for (int d = 0; d < RADIX; ++d) {
-            if (h[d] == n) skip[p] = true;
-            sc.h_base[(size_t)p * RADIX + d] = run;
-            run += h[d];
+    if (three) {
+        // constant digits from the OR/AND summary of the keys; digit starts come from each pass's own scan
+        if (!summary_ready) {
+            ProfScope ps(c, TC_SORT_HIST);
+            const int g = grid_for(c, n, 256, 8);
+            hipLaunchKernelGGL((key_summary_kernel<T>), dim3(g), dim3(256), 0, c->stream, in.k1, in.k2, n, sc.d_partials);
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_TRY(summary_finish(c, sc, (unsigned)g));
+            c->stats.hist_bytes += 2ull * sizeof(T) * n;
         }
-        if (!skip[p]) ++n_exec;
+        PSACX_HIP(c, hipMemcpyAsync(sc.h_summary, sc.d_summary, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        for (int p = 0; p < plan.n_pass; ++p) {
+            const unsigned long long diff = plan.word[p] ? (sc.h_summary[2] ^ sc.h_summary[3]) : (sc.h_summary[0] ^ sc.h_summary[1]);
+            skip[p] = ((diff >> plan.shift[p]) & (RADIX - 1)) == 0;
+            if (!skip[p]) ++n_exec;
+        }
+    } else {
+        HistArgs ha;
+        ha.n_pass = plan.n_pass;
+        for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
+        {
+            ProfScope ps(c, TC_SORT_HIST);
+            PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
+            const int grid = grid_for(c, (n + 3) / 4, 256, 8);
+            hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n,
+                               ha, sc.d_hist);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        PSACX_HIP(c, hipMemcpyAsync(sc.h_hist, sc.d_hist, sizeof(unsigned long long) * plan.n_pass * RADIX,
+                                    hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        c->stats.hist_bytes += 2ull * sizeof(T) * n;
+        for (int p = 0; p < plan.n_pass; ++p) {
+            const unsigned long long* h = sc.h_hist + (size_t)p * RADIX;
+            unsigned long long run = 0;
+            skip[p] = false;
+            for (int d = 0; d < RADIX; ++d) {
+                if (h[d] == n) skip[p] = true;
+                sc.h_base[(size_t)p * RADIX + d] = run;
+                run += h[d];
+            }
+            if (!skip[p]) ++n_exec;
+        }
+        if (n_exec) {
+            PSACX_HIP(c, hipMemcpyAsync(sc.d_base, sc.h_base, sizeof(unsigned long long) * plan.n_pass * RADIX,
+                                        hipMemcpyHostToDevice, c->stream));
+        }
     }
     if (rs) { rs->sort_passes = (uint32_t)n_exec; rs->sort_passes_skipped = (uint32_t)(plan.n_pass - n_exec); }
-    if (n_exec) {
-        PSACX_HIP(c, hipMemcpyAsync(sc.d_base, sc.h_base, sizeof(unsigned long long) * plan.n_pass * RADIX,
-                                    hipMemcpyHostToDevice, c->stream));
-    }
 
     int cfg = sort_cfg_env();
     if (cfg < 0) cfg = ScatterCfg<T>::DEF;
@@ -326,9 +357,6 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         const uint64_t tile = cfg_tile(cfg);
         const uint64_t ntiles = (n + tile - 1) / tile;
         const size_t dbytes = 256 + ntiles * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t));
-        // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
-        // single-sweep look-back form for small ones where launch count matters more
-        const bool three = sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21);
         PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
         if (three) {
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;

@@ -40,6 +40,20 @@ inline PassPlan make_plan(int bits1, int bits2) {
 }
 
 // --------------------------------------------------------------- histogram
+// One LDS counter update per lane, except when the whole wave agrees on the digit (sorted
+// bucket ids give long runs of equal high digits; 64 same-address LDS atomics serialise).
+__device__ __forceinline__ void wave_hist_add(unsigned* hist, unsigned d, bool valid) {
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;                                        // wave-uniform
+    const int first = __builtin_ctzll(vm);
+    const unsigned dv = (unsigned)__builtin_amdgcn_readlane((int)d, first);
+    if (__ballot(valid && d != dv) == 0) {                      // every valid lane holds digit dv
+        if ((int)lane_id() == first) atomicAdd(&hist[dv], (unsigned)__builtin_popcountll(vm));
+    } else if (valid) {
+        atomicAdd(&hist[d], 1u);
+    }
+}
+
 struct HistArgs {
     int n_pass;
     int word[MAX_PASSES];
@@ -62,12 +76,11 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const T* __restrict__
         load_run<T, PER>(k2, e0, n, x2, (T)0);
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            if (e0 + j < n) {
-                for (int p = 0; p < a.n_pass; ++p) {
-                    const T w = a.word[p] ? x2[j] : x1[j];
-                    const unsigned d = (unsigned)(w >> a.shift[p]) & (RADIX - 1);
-                    atomicAdd(&lh[p * RADIX + d], 1u);
-                }
+            const bool in = e0 + j < n;
+            for (int p = 0; p < a.n_pass; ++p) {
+                const T w = a.word[p] ? x2[j] : x1[j];
+                const unsigned d = (unsigned)(w >> a.shift[p]) & (RADIX - 1);
+                wave_hist_add(&lh[p * RADIX], d, in);
             }
         }
     }
@@ -308,8 +321,7 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist_kernel(const T* __restr
         T x[PER];
         load_run<T, PER>(kd_in, e0, n, x, (T)0);
 #pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (e0 + j < n) atomicAdd(&my[(unsigned)(x[j] >> shift) & (RADIX - 1)], 1u);
+        for (int j = 0; j < PER; ++j) wave_hist_add(my, (unsigned)(x[j] >> shift) & (RADIX - 1), e0 + j < n);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < RADIX; d += BLOCK)
@@ -338,8 +350,11 @@ __global__ __launch_bounds__(RADIX) void radix_slab_scan_kernel(unsigned* __rest
 }
 
 // one workgroup: exclusive scan of the slab totals per digit (in place)
+// also turns the per-digit totals into the global start of every digit (digit_base)
 template <int TAG>
-__global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long long* __restrict__ slab_tot, uint64_t nslabs) {
+__global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long long* __restrict__ slab_tot, uint64_t nslabs,
+                                                               unsigned long long* __restrict__ digit_base) {
+    __shared__ unsigned long long tmp[RADIX / WAVE + 1];
     const unsigned d = threadIdx.x;
     unsigned long long run = 0;
     constexpr int B = 16;
@@ -353,6 +368,9 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
             run += v[j];
         }
     }
+    unsigned long long total;
+    const unsigned long long start = block_scan_exclusive<RADIX, unsigned long long>(run, OpSum(), 0ull, tmp, &total);
+    digit_base[d] = start;
 }
 
 template <typename T, int BLOCK, int ITEMS>

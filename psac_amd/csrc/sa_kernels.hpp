@@ -17,7 +17,65 @@ namespace psacx {
 
 constexpr int RADIX_P = 256;    // fan-out of one destination-partition pass
 
-struct CodeTable { uint16_t c[256]; };   // codes 1..sigma (sigma may be 256)
+struct CodeTable { uint16_t c[256]; };
+
+// OR / AND over all sort keys, accumulated by the kernels that produce the keys: bits where
+// both agree are constant, so a radix digit made only of such bits needs no pass.
+// summary[0] = OR(k1), [1] = AND(k1), [2] = OR(k2), [3] = AND(k2).
+// Each workgroup stores its four partial words (no atomics: millions of waves updating four
+// addresses serialise, and a cached copy of those words never refreshes); summary_reduce_kernel
+// folds the partials afterwards.
+template <typename T>
+__device__ __forceinline__ void key_summary_add(unsigned long long* partials, T or1, T and1, T or2, T and2) {
+    __shared__ unsigned long long red[4][16];
+    or1 = wave_reduce<T>(or1, OpOr()); and1 = wave_reduce<T>(and1, OpAnd());
+    or2 = wave_reduce<T>(or2, OpOr()); and2 = wave_reduce<T>(and2, OpAnd());
+    const unsigned wave = threadIdx.x / WAVE, nw = (blockDim.x + WAVE - 1) / WAVE;
+    const unsigned long long hi = ~(unsigned long long)(T)~(T)0;
+    if (lane_id() == 0) {
+        red[0][wave] = (unsigned long long)or1; red[1][wave] = (unsigned long long)and1 | hi;
+        red[2][wave] = (unsigned long long)or2; red[3][wave] = (unsigned long long)and2 | hi;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long v = red[threadIdx.x][0];
+        for (unsigned w = 1; w < nw; ++w) v = (threadIdx.x & 1) ? (v & red[threadIdx.x][w]) : (v | red[threadIdx.x][w]);
+        partials[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+template <int TAG>
+__global__ void summary_reduce_kernel(const unsigned long long* __restrict__ partials, unsigned nblocks,
+                                      unsigned long long* __restrict__ summary) {
+    unsigned long long o1 = 0, a1 = ~0ull, o2 = 0, a2 = ~0ull;
+    for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        o1 |= partials[(size_t)b * 4]; a1 &= partials[(size_t)b * 4 + 1];
+        o2 |= partials[(size_t)b * 4 + 2]; a2 &= partials[(size_t)b * 4 + 3];
+    }
+    __shared__ unsigned long long red[4][16];
+    o1 = wave_reduce<uint64_t>(o1, OpOr()); a1 = wave_reduce<uint64_t>(a1, OpAnd());
+    o2 = wave_reduce<uint64_t>(o2, OpOr()); a2 = wave_reduce<uint64_t>(a2, OpAnd());
+    const unsigned wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    if (lane_id() == 0) { red[0][wave] = o1; red[1][wave] = a1; red[2][wave] = o2; red[3][wave] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long v = red[threadIdx.x][0];
+        for (unsigned w = 1; w < nw; ++w) v = (threadIdx.x & 1) ? (v & red[threadIdx.x][w]) : (v | red[threadIdx.x][w]);
+        summary[threadIdx.x] = v;
+    }
+}
+
+template <typename T>
+__global__ void key_summary_kernel(const T* __restrict__ k1, const T* __restrict__ k2, uint64_t n,
+                                   unsigned long long* __restrict__ summary) {
+    T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T x = k1[i], y = k2[i];
+        o1 |= x; a1 &= x; o2 |= y; a2 &= y;
+    }
+    key_summary_add<T>(summary, o1, a1, o2, a2);
+}   // codes 1..sigma (sigma may be 256)
 
 // ------------------------------------------------------------------ K1
 template <int BLOCK>
@@ -75,7 +133,8 @@ __device__ __forceinline__ uint64_t record_suffix(uint64_t j, uint64_t spec, uin
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                           CodeTable tab, KeyShape ks,
-                                                          T* __restrict__ C1, T* __restrict__ C2) {
+                                                          T* __restrict__ C1, T* __restrict__ C2,
+                                                          unsigned long long* __restrict__ summary) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int HALO = 2 * 64 + 8;             // 2k <= 128 always
     __shared__ uint16_t codes[TILE + HALO];
@@ -124,6 +183,11 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
     }
     store_run<T, ITEMS>(C1, j0, n, o1);
     store_run<T, ITEMS>(C2, j0, n, o2);
+    T so1 = 0, sa1 = ~(T)0, so2 = 0, sa2 = ~(T)0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (j0 + j < n) { so1 |= o1[j]; sa1 &= o1[j]; so2 |= o2[j]; sa2 &= o2[j]; }
+    key_summary_add<T>(summary, so1, sa1, so2, sa2);
 }
 
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
@@ -437,16 +501,20 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
 template <typename T>
 __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ SA,
                                    const T* __restrict__ Bsa, const T* __restrict__ ISA, uint64_t n,
-                                   uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V) {
+                                   uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V,
+                                   unsigned long long* __restrict__ summary) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
         const uint64_t p = pos ? (uint64_t)pos[j] : j;
         const T sa = SA[p];
         const uint64_t q = (uint64_t)sa + h;
-        K1[j] = Bsa[p];
-        K2[j] = q < n ? (T)(ISA[q] + 1) : (T)0;   // 1-based bucket id, 0 = past the end
-        V[j] = sa;
+        const T b1 = Bsa[p];
+        const T b2 = q < n ? (T)(ISA[q] + 1) : (T)0;   // 1-based bucket id, 0 = past the end
+        K1[j] = b1; K2[j] = b2; V[j] = sa;
+        o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2;
     }
+    key_summary_add<T>(summary, o1, a1, o2, a2);
 }
 
 // ------------------------------------------------------------------ range minimum pyramid
