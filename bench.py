@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch of the dominant kernel from the PMC counters of the committed profile
 # (profiles/): FETCH_SIZE doubled (the gfx950 correction for coalesced streams) + WRITE_SIZE.
-# None until a PMC run of the current kernel has been recorded there.
-TRAFFIC_PER_LAUNCH = None
+# Valid for the default workload only (2^28 uint32 records per launch).
+TRAFFIC_PER_LAUNCH = 6553287372      # profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
 
 
 def parse():
@@ -146,7 +146,8 @@ def main():
                          "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
                          "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                          "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
-                         "bytes_per_record_per_pass": 6 * w, "traffic": TRAFFIC_PER_LAUNCH},
+                         "bytes_per_record_per_pass": 6 * w,
+                         "traffic": TRAFFIC_PER_LAUNCH if (dom == 1 and n == (1 << 28) and bits == 32) else None},
             "phase_ms_last_step": {"total": round(s_last.ms_total, 3), "alphabet": round(s_last.ms_alphabet, 3),
                                    "kmer": round(s_last.ms_kmer, 3), "sort_hist": round(s_last.ms_sort_hist, 3),
                                    "sort_scatter": round(s_last.ms_sort_scatter + s_last.ms_sort_scatter3, 3),
