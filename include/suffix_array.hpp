@@ -1,0 +1,222 @@
+// suffix_array.hpp -- C++11 host mirror of psac's suffix_array<> class over libpsacx.so.
+//
+// Same class name, template parameters, public fields and construct() signatures as
+// /root/reference/include/suffix_array.hpp:170-228, :365-486, so that a caller such as
+// src/psac.cpp:117-128 compiles against this header unchanged apart from the communicator
+// type: the reference takes an mxx::comm (one MPI rank per text block); this engine runs one
+// process per GPU and takes a psacx::comm naming the HIP device.  All compute happens in the
+// HIP engine behind the C ABI of psacx.h; this header only moves data and re-throws errors
+// (std::runtime_error, as suffix_array.hpp:226-227 does).
+#ifndef PSACX_SUFFIX_ARRAY_HPP
+#define PSACX_SUFFIX_ARRAY_HPP
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <iterator>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "psacx.h"
+
+namespace psacx {
+
+// Stand-in for mxx::comm at one rank (Appendix A of SURVEY.md lists the surface psac uses).
+class comm {
+public:
+    explicit comm(int device = 0) : device_(device) {}
+    int rank() const { return 0; }
+    int size() const { return 1; }
+    bool is_first() const { return true; }
+    int device() const { return device_; }
+    comm copy() const { return comm(device_); }
+private:
+    int device_;
+};
+
+// mxx::blk_dist at one rank (suffix_array.hpp:194, bulk_permute.hpp:23)
+struct blk_dist {
+    std::size_t n;
+    blk_dist() : n(0) {}
+    explicit blk_dist(std::size_t n_) : n(n_) {}
+    std::size_t global_size() const { return n; }
+    std::size_t local_size() const { return n; }
+    std::size_t eprefix_size() const { return 0; }
+    std::size_t iprefix_size() const { return n; }
+    int rank_of(std::size_t) const { return 0; }
+};
+
+// the part of alphabet<char> callers read (alphabet.hpp:147-164, :224-262, :296-300)
+template <typename char_t> class alphabet {
+public:
+    alphabet() : m_sigma(0), m_bits(0) {}
+    unsigned int sigma() const { return m_sigma; }
+    unsigned int size() const { return m_sigma; }
+    unsigned int bits_per_char() const { return m_bits; }
+    template <typename word_type> unsigned int chars_per_word() const {
+        unsigned int b = sizeof(word_type) * 8;
+        if (std::is_signed<word_type>::value) --b;
+        return b / m_bits;
+    }
+    const std::vector<char_t>& unique_chars() const { return m_chars; }
+    void write(const std::string& filename) const {
+        std::ofstream f(filename.c_str(), std::ios::binary);
+        for (std::size_t i = 0; i < m_chars.size(); ++i) f.write(reinterpret_cast<const char*>(&m_chars[i]), sizeof(char_t));
+    }
+    void set(const std::vector<char_t>& chars) {
+        m_chars = chars; m_sigma = (unsigned int)chars.size();
+        m_bits = 0; while ((1u << m_bits) < m_sigma + 1u) ++m_bits;
+    }
+private:
+    std::vector<char_t> m_chars;
+    unsigned int m_sigma, m_bits;
+};
+
+template <typename char_t> std::ostream& operator<<(std::ostream& os, const alphabet<char_t>& a) {
+    os << "{sigma=" << a.sigma() << ", l=" << a.bits_per_char() << ", A=[";
+    for (std::size_t i = 0; i < a.unique_chars().size(); ++i) os << (i ? ", " : "") << a.unique_chars()[i];
+    return os << "]}";
+}
+
+inline void check(psacx_ctx* ctx, int rc) {
+    if (rc == PSACX_OK) return;
+    std::string msg = std::string("psacx: ") + psacx_strerror(rc);
+    const char* d = ctx ? psacx_last_hip_error(ctx) : "";
+    if (d && *d) msg += std::string(" [") + d + "]";
+    throw std::runtime_error(msg);
+}
+
+} // namespace psacx
+
+#ifndef PSACX_INFO
+#define PSACX_INFO(msg) { std::cerr << msg << std::endl; }
+#endif
+
+template <typename char_t, typename index_t = std::size_t, bool _CONSTRUCT_LCP = false, bool _CONSTRUCT_LC = false>
+class suffix_array {
+    static_assert(sizeof(index_t) == 4 || sizeof(index_t) == 8, "index_t must be a 32 or 64 bit unsigned integer");
+    static_assert(!_CONSTRUCT_LC, "left-branching characters (_CONSTRUCT_LC) are not built by this engine");
+public:
+    explicit suffix_array(const psacx::comm& _comm) : n(0), local_size(0), comm(_comm.copy()), p(1), verbose(true), ctx_(nullptr) {
+        psacx::check(nullptr, psacx_create(&ctx_, comm.device(), nullptr));
+    }
+    virtual ~suffix_array() { if (ctx_) psacx_destroy(ctx_); }
+    suffix_array(const suffix_array&) = delete;
+    suffix_array& operator=(const suffix_array&) = delete;
+
+    /// The global size of the input string and suffix array (suffix_array.hpp:180)
+    std::size_t n;
+    /// The local size (== n: one rank holds the whole text) (suffix_array.hpp:185)
+    std::size_t local_size;
+    psacx::comm comm;
+    int p;
+    psacx::blk_dist part;
+    using char_type = char_t;
+    using alphabet_type = psacx::alphabet<char_t>;
+    alphabet_type alpha;
+    /// The suffix array, the inverse suffix array (0-based) and the LCP array
+    /// (suffix_array.hpp:204-209); local_LCP stays empty unless _CONSTRUCT_LCP.
+    std::vector<index_t> local_SA;
+    std::vector<index_t> local_B;
+    std::vector<index_t> local_LCP;
+    std::vector<char_t> local_Lc;
+    bool verbose;                     // print the reference's stderr lines
+
+    void init_size(std::size_t lsize) {      // suffix_array.hpp:217-228
+        local_size = lsize; n = lsize; p = 1; part = psacx::blk_dist(n);
+    }
+
+    // suffix_array.hpp:469-486
+    template <typename Iterator>
+    void construct(Iterator begin, Iterator end, bool fast_resolval = true, unsigned int k = 0) {
+        init_size((std::size_t)std::distance(begin, end));
+        if (n == 0) throw std::runtime_error("psacx: empty input");
+        std::vector<uint8_t> bytes(n);
+        std::vector<char_t> chars;
+        densify(begin, end, bytes, chars);
+        local_SA.assign(n, 0); local_B.assign(n, 0);
+        if (_CONSTRUCT_LCP) local_LCP.assign(n, 0); else local_LCP.clear();
+        uint32_t flags = (_CONSTRUCT_LCP ? PSACX_LCP : 0u) | (fast_resolval ? 0u : PSACX_NO_FAST);
+        int rc = run(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr);
+        psacx::check(ctx_, rc);
+        psacx_stats st;
+        psacx::check(ctx_, psacx_get_stats(ctx_, &st));
+        alpha.set(chars);
+        if (verbose) {
+            PSACX_INFO("Alphabet: " << alpha);                       // suffix_array.hpp:481
+            for (uint32_t r = 0; r < st.n_rounds; ++r)                // suffix_array.hpp:416
+                PSACX_INFO("iteration " << st.rounds[r].h << ": unfinished buckets = " << st.rounds[r].unfinished_buckets
+                           << ", unfinished elements = " << st.rounds[r].unfinished_elements);
+        }
+    }
+
+    // suffix_array.hpp:232-242: raw little-endian arrays, no header
+    void write(const std::string& basename) const {
+        dump(basename + ".sa", local_SA);
+        if (_CONSTRUCT_LCP) dump(basename + ".lcp", local_LCP);
+        alpha.write(basename + ".alpha");
+    }
+    // suffix_array.hpp:245-265
+    void read(const std::string& basename) {
+        slurp(basename + ".sa", local_SA);
+        if (_CONSTRUCT_LCP) {
+            slurp(basename + ".lcp", local_LCP);
+            if (local_SA.size() != local_LCP.size()) throw std::runtime_error("SA and LCP have to have same size");
+        }
+        init_size(local_SA.size());
+    }
+
+    psacx_ctx* context() { return ctx_; }
+
+private:
+    psacx_ctx* ctx_;
+
+    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+        return psacx_construct_u32(ctx_, t, n, k, flags, sa, isa, lcp);
+    }
+    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+        return psacx_construct_u64(ctx_, t, n, k, flags, sa, isa, lcp);
+    }
+    template <typename U>
+    typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
+    run(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp) {
+        typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
+        return run(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
+    }
+
+    // bytes pass through; wider symbols (int alphabets, test/test_psac.cpp:277-304) are ranked
+    // to bytes, which keeps their order, as long as at most 256 distinct symbols occur
+    template <typename Iterator>
+    void densify(Iterator begin, Iterator end, std::vector<uint8_t>& bytes, std::vector<char_t>& chars) {
+        typedef typename std::make_unsigned<char_t>::type uchar_t;
+        std::vector<uchar_t> u; u.reserve(n);
+        for (Iterator it = begin; it != end; ++it) u.push_back((uchar_t)*it);
+        std::vector<uchar_t> uniq(u);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        if (uniq.size() > 256) throw std::runtime_error("psacx: more than 256 distinct symbols");
+        chars.clear();
+        for (std::size_t i = 0; i < uniq.size(); ++i) chars.push_back((char_t)uniq[i]);
+        if (sizeof(char_t) == 1) { for (std::size_t i = 0; i < n; ++i) bytes[i] = (uint8_t)u[i]; return; }
+        for (std::size_t i = 0; i < n; ++i)
+            bytes[i] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), u[i]) - uniq.begin());
+    }
+    template <typename V> static void dump(const std::string& fn, const std::vector<V>& v) {
+        std::ofstream f(fn.c_str(), std::ios::binary | std::ios::trunc);
+        f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(V)));
+        if (!f) throw std::runtime_error("cannot write " + fn);
+    }
+    template <typename V> static void slurp(const std::string& fn, std::vector<V>& v) {
+        std::ifstream f(fn.c_str(), std::ios::binary | std::ios::ate);
+        if (!f) throw std::runtime_error("cannot read " + fn);
+        std::size_t bytes = (std::size_t)f.tellg();
+        v.resize(bytes / sizeof(V));
+        f.seekg(0); f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(V)));
+    }
+};
+
+#endif // PSACX_SUFFIX_ARRAY_HPP

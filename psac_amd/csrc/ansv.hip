@@ -1,7 +1,131 @@
 // ansv.hip -- all nearest smaller values over an integer array (the LCP array).
-// Placeholder translation unit: the kernels land in a later commit of this round.
+//
+// Stands in for ansv<T,left_type,right_type,global_indexing>() (/root/reference/include/
+// ansv.hpp:2042-2051; sequential semantics ansv.hpp:48-65; tie rules ansv_common.hpp:20-22;
+// caller suffix_tree.hpp:43-63 with left = furthest_eq, right = nearest_sm).
+//
+// The reference walks a monotone stack per rank and exchanges unmatched prefix minima.  On the
+// GPU every element searches a 64-ary min-pyramid of the array instead: scan the rest of the
+// own 64-block, climb while no sibling block holds a small enough value, then descend into the
+// nearest block that does.  The expected work per element is a few cache lines because the
+// nearest smaller value of an LCP entry is almost always close by.
 #include "engine.hpp"
+
 namespace psacx {
-int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*) { return PSACX_EINVAL; }
-int ansv_host_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*) { return PSACX_EINVAL; }
+
+constexpr uint64_t NSV_NONE = ~0ull;
+
+// nearest j < i (LEFT) or j > i (!LEFT) with in[j] < v (strict) or in[j] <= v
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t nsv_search(const Pyramid<T>& P, uint64_t i, T v, bool strict) {
+    uint64_t pos = i, j = 0;
+    int L = 0;
+    bool found = false;
+    while (!found) {
+        const T* a = P.lvl[L];
+        const uint64_t len = P.len[L];
+        if (LEFT) {
+            const uint64_t gstart = pos & ~63ull;
+            for (uint64_t c = pos; c-- > gstart;) {
+                const T x = a[c];
+                if (strict ? x < v : x <= v) { j = c; found = true; break; }
+            }
+            if (!found && gstart == 0) return NSV_NONE;
+        } else {
+            uint64_t gend = (pos | 63ull) + 1;
+            if (gend > len) gend = len;
+            for (uint64_t c = pos + 1; c < gend; ++c) {
+                const T x = a[c];
+                if (strict ? x < v : x <= v) { j = c; found = true; break; }
+            }
+            if (!found && gend >= len) return NSV_NONE;
+        }
+        if (!found) { pos >>= 6; ++L; }     // the top level is a single group, so this never overruns
+    }
+    while (L > 0) {
+        const T* a = P.lvl[L - 1];
+        const uint64_t lo = j << 6;
+        uint64_t hi = lo + 64;
+        if (hi > P.len[L - 1]) hi = P.len[L - 1];
+        if (LEFT) {
+            for (uint64_t c = hi; c-- > lo;) { const T x = a[c]; if (strict ? x < v : x <= v) { j = c; break; } }
+        } else {
+            for (uint64_t c = lo; c < hi; ++c) { const T x = a[c]; if (strict ? x < v : x <= v) { j = c; break; } }
+        }
+        --L;
+    }
+    return j;
 }
+
+// type 0 nearest_sm, 1 nearest_eq, 2 furthest_eq
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t nsv_typed(const Pyramid<T>& P, uint64_t n, uint64_t i, int type) {
+    const T v = P.lvl[0][i];
+    if (type == 0) return nsv_search<T, LEFT>(P, i, v, true);
+    const uint64_t j = nsv_search<T, LEFT>(P, i, v, false);
+    if (type == 1 || j == NSV_NONE) return j;
+    // furthest_eq: the far end of the run of values equal to in[j] that nothing smaller interrupts
+    const T u = P.lvl[0][j];
+    const uint64_t s = nsv_search<T, LEFT>(P, j, u, true);         // first strictly smaller beyond j
+    if (LEFT) {
+        // leftmost element <= u in (s, j]: search rightwards from s (or from before index 0)
+        if (s == NSV_NONE) { if (P.lvl[0][0] <= u) return 0; return nsv_search<T, false>(P, 0, u, false); }
+        return nsv_search<T, false>(P, s, u, false);
+    } else {
+        if (s == NSV_NONE) { if (P.lvl[0][n - 1] <= u) return n - 1; return nsv_search<T, true>(P, n - 1, u, false); }
+        return nsv_search<T, true>(P, s, u, false);
+    }
+}
+
+template <typename T>
+__global__ void ansv_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type, uint64_t nonsv,
+                            uint64_t* __restrict__ left, uint64_t* __restrict__ right) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t l = nsv_typed<T, true>(P, n, i, left_type);
+        const uint64_t r = nsv_typed<T, false>(P, n, i, right_type);
+        left[i] = l == NSV_NONE ? nonsv : l;
+        right[i] = r == NSV_NONE ? nonsv : r;
+    }
+}
+
+template <typename T>
+int ansv_host(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* left, uint64_t* right) {
+    if (!c || !in || !left || !right || n == 0 || lt < 0 || lt > 2 || rt < 0 || rt > 2) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    Pyramid<T> P;
+    T* d_in = nullptr; uint64_t *d_l = nullptr, *d_r = nullptr;
+    auto layout = [&](Arena& a) {
+        d_in = a.take<T>(n); d_l = a.take<uint64_t>(n); d_r = a.take<uint64_t>(n);
+        P.lvl[0] = d_in; P.len[0] = n; P.nlev = 1;
+        uint64_t len = n;
+        while (len > 64 && P.nlev < PYR_MAX) {
+            len = (len + 63) / 64;
+            P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len; P.nlev++;
+        }
+    };
+    { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+    Arena ar(c->slab);
+    layout(ar);
+    PSACX_HIP(c, hipMemcpyAsync(d_in, in, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    for (int L = 1; L < P.nlev; ++L) {
+        hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
+                           P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL((ansv_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r);
+    PSACX_HIP(c, hipGetLastError());
+    PSACX_HIP(c, hipMemcpyAsync(left, d_l, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipMemcpyAsync(right, d_r, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+
+int ansv_host_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_host<uint32_t>(c, in, n, lt, rt, nonsv, l, r);
+}
+int ansv_host_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_host<uint64_t>(c, in, n, lt, rt, nonsv, l, r);
+}
+
+} // namespace psacx

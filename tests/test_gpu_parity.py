@@ -190,3 +190,55 @@ def test_errors(ctx):
     import ctypes as C
     rc = ctx._lib.psacx_construct_u32(ctx.handle, None, 5, 0, 0, None, None, None)
     assert rc == -1
+
+
+def test_ansv_all_type_combinations(ctx):
+    # test/test_ansv.cpp:232-252, 270-282: every (left_type, right_type) on rand() % 100 inputs,
+    # n in {13, 137, 1000, 26666}; plus an LCP array (suffix_tree.hpp:62 uses furthest_eq / nearest_sm)
+    import psac_amd
+    rng = np.random.default_rng(17)
+    NO = 2**64 - 1
+    cases = [rng.integers(0, 100, n).astype(np.uint32) for n in (1, 2, 13, 137, 1000, 26666)]
+    cases.append(rng.integers(0, 3, 70000).astype(np.uint64))
+    cases.append(np.zeros(5000, np.uint32))
+    cases.append(np.arange(5000, dtype=np.uint32))
+    cases.append(np.arange(5000, dtype=np.uint64)[::-1].copy())
+    text = O.rand_dna(200000, 5)
+    cases.append(O.construct(text, bits=32)["LCP"])
+    for v in cases:
+        for lt in (0, 1, 2):
+            for rt in (0, 1, 2):
+                if v.size > 30000 and (lt, rt) not in ((0, 0), (2, 0), (1, 2)):
+                    continue
+                left, right = psac_amd.ansv(v, lt, rt, nonsv=NO, ctx=ctx)
+                assert np.array_equal(left, O.ansv(v, True, lt, NO)), (v.size, lt, rt)
+                assert np.array_equal(right, O.ansv(v, False, rt, NO)), (v.size, lt, rt)
+
+
+def test_cli_and_cpp_header(ctx, tmp_path):
+    # psac CLI parity (src/psac.cpp:65-128): -f/-l/-c/-o, .sa64/.lcp64 as raw uint64, print64 listing
+    # of README.md:88-100
+    import subprocess
+    root = os.path.dirname(HERE)
+    psac = os.path.join(root, "psac_amd", "bin", "psac")
+    p64 = os.path.join(root, "psac_amd", "bin", "print64")
+    if not (os.path.exists(psac) and os.path.exists(p64)):
+        pytest.skip("CLI not built")
+    f = tmp_path / "miss.txt"
+    f.write_bytes(b"mississippi")
+    r = subprocess.run([psac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "PSAC time:" in r.stderr and "[SUCCESS]" in r.stderr
+    sa = np.fromfile(str(tmp_path / "out.sa64"), dtype=np.uint64)
+    lcp = np.fromfile(str(tmp_path / "out.lcp64"), dtype=np.uint64)
+    assert sa.tolist() == KAT["mississippi"]["SA"] and lcp.tolist() == KAT["mississippi"]["LCP"]
+    listing = subprocess.run([p64, str(tmp_path / "out.sa64")], capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in listing] == KAT["mississippi"]["SA"]
+    # random input through -r, checked by the CLI's own -c, then the -t path (ANSV over LCP)
+    r = subprocess.run([psac, "-r", "300000", "-s", "3", "-l", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr
+    r = subprocess.run([psac, "-r", "100000", "-t", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ANSV time:" in r.stderr, r.stderr
+    # argument errors exit non-zero like TCLAP (src/psac.cpp:147-150)
+    assert subprocess.run([psac], capture_output=True).returncode != 0
+    assert subprocess.run([psac, "-f", str(f), "-r", "5"], capture_output=True).returncode != 0
