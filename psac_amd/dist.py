@@ -1,0 +1,319 @@
+"""Block-distributed SA / ISA / LCP construction: one rank per GPU.
+
+The text is block-partitioned like psac's (suffix_array.hpp:183-194, mxx::blk_dist):
+rank r owns text / SA / ISA / LCP positions [off_r, off_r + m_r).  The loop is the
+single-GPU one (psac_amd/csrc/construct.hpp) with every global step made explicit:
+
+  psac step (reference)                         here
+  -------------------------------------------   ------------------------------------------
+  alphabet allreduce     alphabet.hpp:98        all_reduce of the 256-bin histogram
+  k-mer halo             kmer.hpp:142           first 2k characters sent to the left rank
+  mxx::sort of tuples    idxsort.hpp:60-62      dist_sort: local radix sort, sampled
+                                                splitters, all-to-all, local sort, exact
+                                                re-balance to the block sizes
+  right_shift of the last tuple                 all_gather of first / last records
+                         bucketing.hpp:77,100
+  exscan(max) of bucket ids bucketing.hpp:39    all_gather of per-rank last head ids
+  bulk_permute_inplace   bulk_permute.hpp:14    dist_put: partition by owner, all-to-all,
+                                                local scatter
+  sparse_get_b2/bulk_rma suffix_array.hpp:972   dist_take: queries to owners, answers back
+  bulk_rmq_v2            par_rmq.hpp:199-332    edge sub-queries to owners + all-gathered
+                                                per-rank minima for whole ranks in between
+
+All arithmetic on the arrays happens in a LocalOps object (HIP kernels on the GPU:
+psac_amd/dist_ops.py); this module only slices, concatenates and exchanges tensors.
+Written as a generator so that it runs unchanged under torch.distributed or under the
+in-process LoopbackWorld (psac_amd/comm.py).
+"""
+import torch
+
+SAMPLES_PER_RANK = 256
+
+
+def blk_sizes(n, P):
+    """mxx::blk_dist: the first n mod P ranks hold one element more."""
+    return [n // P + (1 if r < n % P else 0) for r in range(P)]
+
+
+def prefix(xs):
+    out, s = [], 0
+    for x in xs:
+        out.append(s)
+        s += x
+    return out
+
+
+def build_alphabet(hist):
+    """alphabet.hpp:147-164: codes 1..sigma in byte order, l = ceil(log2(sigma + 1))."""
+    codes, nxt = [0] * 256, 1
+    for ch in range(256):
+        if hist[ch]:
+            codes[ch] = nxt
+            nxt += 1
+    sigma = nxt - 1
+    l = 0
+    while (1 << l) < sigma + 1:
+        l += 1
+    return codes, sigma, l
+
+
+def choose_k(word_bits, l, min_local, P, k):
+    """kmer.hpp:26-40."""
+    max_k = word_bits // l
+    if k == 0 or k > max_k:
+        k = max_k
+    if k >= min_local:
+        k = min_local
+        if P == 1 and k > 1:
+            k -= 1
+    return k
+
+
+def bits_for(v):
+    return max(1, int(v).bit_length())
+
+
+# ---------------------------------------------------------------------------------------
+# distributed primitives
+# ---------------------------------------------------------------------------------------
+def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
+    """Globally sorts records by (K1, K2); rank r ends with exactly targets[r] records, the
+    concatenation over ranks being sorted (the contract psac needs from mxx::sort,
+    idxsort.hpp:67-79)."""
+    P, r = comm.size, comm.rank
+    S1, S2, SV = ops.pair_sort(K1, K2, V, bits1, bits2)
+    if P == 1:
+        return S1, S2, SV
+    c = int(S1.numel())
+    # regular samples of the locally sorted records, made unique by (rank, index)
+    pos = [(c * (2 * i + 1)) // (2 * SAMPLES_PER_RANK) for i in range(SAMPLES_PER_RANK)] if c else []
+    pos = sorted(set(pos))
+    keys = ops.sample(S1, S2, pos)
+    mine = [(k1, k2, r, p) for (k1, k2), p in zip(keys, pos)]
+    allsamp = yield from comm.all_gather_obj(mine)
+    flat = sorted(s for lst in allsamp for s in lst)
+    splitters = []
+    for d in range(1, P):
+        if flat:
+            splitters.append(flat[min(len(flat) - 1, (len(flat) * d) // P)])
+    # boundaries: records equal to a splitter key are divided by the splitter's (rank, index)
+    bounds = [0]
+    if splitters:
+        lb, ub = ops.pair_bounds(S1, S2, [s[0] for s in splitters], [s[1] for s in splitters])
+        for s, lo, hi in zip(splitters, lb, ub):
+            if r < s[2]:
+                b = hi
+            elif r > s[2]:
+                b = lo
+            else:
+                b = min(max(s[3], lo), hi)
+            bounds.append(max(b, bounds[-1]))
+    while len(bounds) < P:
+        bounds.append(bounds[-1])
+    bounds.append(c)
+    parts = []
+    for arr in (S1, S2, SV):
+        got = yield from comm.all_to_all_v([arr[bounds[d]:bounds[d + 1]] for d in range(P)])
+        parts.append(torch.cat(got) if got else arr[:0])
+    R1, R2, RV = ops.pair_sort(parts[0], parts[1], parts[2], bits1, bits2)
+    # exact re-balance: global index of my j-th record is G[r] + j
+    c2 = int(R1.numel())
+    counts = yield from comm.all_gather_obj(c2)
+    G, TP = prefix(counts), prefix(targets)
+    out = []
+    for arr in (R1, R2, RV):
+        chunks = []
+        for d in range(P):
+            lo = max(TP[d], G[r]) - G[r]
+            hi = min(TP[d] + targets[d], G[r] + c2) - G[r]
+            chunks.append(arr[lo:hi] if hi > lo else arr[:0])
+        got = yield from comm.all_to_all_v(chunks)
+        out.append(torch.cat(got) if got else arr[:0])
+    return out[0], out[1], out[2]
+
+
+def _route(comm, ops, gidx, payload, n):
+    """Stable partition of `gidx` (global positions) and one payload array by owner rank: one
+    radix pass over the owner word carries the two other words along."""
+    P = comm.size
+    own = ops.owners(gidx, n, P)
+    o, g, v = ops.pair_sort(own, gidx, payload, bits_for(P - 1), 0)
+    bounds = ops.key_bounds(o, list(range(P))) + [int(o.numel())]
+    return g, v, bounds
+
+
+def dist_put(comm, ops, block, off, gidx, vals, delta, n):
+    """block[gidx - off_owner] = vals + delta on the owner of each global position
+    (bulk_permute_inplace, bulk_permute.hpp:14-73)."""
+    P = comm.size
+    if P == 1:
+        ops.put(block, gidx, off, vals, delta)
+        return
+    g, v, bounds = _route(comm, ops, gidx, vals, n)
+    gi = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
+    vi = yield from comm.all_to_all_v([v[bounds[d]:bounds[d + 1]] for d in range(P)])
+    ops.put(block, torch.cat(gi), off, torch.cat(vi), delta)
+
+
+def dist_take(comm, ops, block, off, gidx, n):
+    """Returns block_owner[gidx - off_owner] for every global position in gidx, in the order of
+    gidx (bulk_rma, bulk_rma.hpp:13-135).  Positions >= n are clamped (callers mask them)."""
+    P = comm.size
+    if P == 1:
+        return ops.take(block, gidx, off, n)
+    idx = ops.iota(int(gidx.numel()), 0)
+    g, back, bounds = _route(comm, ops, gidx, idx, n)
+    q = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
+    lens = [int(t.numel()) for t in q]
+    ans = ops.take(block, torch.cat(q), off, n)
+    got = yield from comm.all_to_all_v(list(torch.split(ans, lens)))
+    res = ops.empty_like(gidx)
+    ops.put(res, back, 0, torch.cat(got), 0)          # undo the routing permutation
+    return res
+
+
+def _neighbours(comm, first, last, has):
+    """Last record of the nearest non-empty rank below and first record of the nearest one above."""
+    allrec = yield from comm.all_gather_obj((has, first, last))
+    r = comm.rank
+    prev = nxt = None
+    for s in range(r - 1, -1, -1):
+        if allrec[s][0]:
+            prev = allrec[s][2]
+            break
+    for s in range(r + 1, comm.size):
+        if allrec[s][0]:
+            nxt = allrec[s][1]
+            break
+    return prev, nxt
+
+
+def dist_range_min(comm, ops, lcp_block, off, sizes, lo, hi, n):
+    """min(LCP[lo .. hi)) over the block-distributed LCP array for every query
+    (bulk_rmq_v2, par_rmq.hpp:199-332): the part inside the first and the last rank is
+    answered by their owners, whole ranks in between from the all-gathered block minima."""
+    P = comm.size
+    if P == 1:
+        return ops.range_min(lcp_block, lo, hi, off)
+    mins = yield from comm.all_gather_obj(ops.block_min(lcp_block))
+    offs = prefix(sizes)
+    own1, lo1, hi1, own2, lo2, hi2, ra, rb = ops.rmq_split(lo, hi, offs, sizes)
+    answers = []
+    for own, a, b in ((own1, lo1, hi1), (own2, lo2, hi2)):
+        idx = ops.iota(int(a.numel()), 0)
+        # route by owner; carry the upper end and the original slot along
+        o, ga, gb = ops.pair_sort(own, a, b, bits_for(P - 1), 0)
+        _, _, back = ops.pair_sort(own, a, idx, bits_for(P - 1), 0)
+        bounds = ops.key_bounds(o, list(range(P))) + [int(o.numel())]
+        qa = yield from comm.all_to_all_v([ga[bounds[d]:bounds[d + 1]] for d in range(P)])
+        qb = yield from comm.all_to_all_v([gb[bounds[d]:bounds[d + 1]] for d in range(P)])
+        lens = [int(t.numel()) for t in qa]
+        res = ops.range_min(lcp_block, torch.cat(qa), torch.cat(qb), off)
+        got = yield from comm.all_to_all_v(list(torch.split(res, lens)))
+        ordered = ops.empty_like(a)
+        ops.put(ordered, back, 0, torch.cat(got), 0)
+        answers.append(ordered)
+    return ops.rmq_combine(answers[0], answers[1], ra, rb, mins)
+
+
+# ---------------------------------------------------------------------------------------
+# the construction
+# ---------------------------------------------------------------------------------------
+def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
+    """Generator.  text_block: uint8 tensor holding this rank's block of the text.
+    Returns dict(SA, ISA, LCP, k, l, sigma, rounds) with this rank's blocks."""
+    P, r = comm.size, comm.rank
+    m = int(text_block.numel())
+    sizes = yield from comm.all_gather_obj(m)
+    n = sum(sizes)
+    if sizes != blk_sizes(n, P):      # suffix_array.hpp:226-227
+        raise RuntimeError("The input string must be equally block decomposed accross all MPI processes.")
+    offs = prefix(sizes)
+    off = offs[r]
+    word_bits = ops.index_bits
+
+    hist = yield from comm.all_reduce_sum(ops.char_hist(text_block))
+    codes, sigma, l = build_alphabet([int(x) for x in hist.tolist()])
+    k = choose_k(word_bits, l, min(sizes), P, k_req)
+    two_k = 2 * k
+    if P > 1 and min(sizes) < two_k:
+        raise RuntimeError("text blocks shorter than 2k characters are not supported with more than one rank")
+    c1 = min(two_k, word_bits // l)
+    c2 = two_k - c1
+
+    # halo: the first 2k characters of the right neighbour (zeros past the end of the text)
+    if P > 1:
+        send = [text_block[:0]] * P
+        if r > 0:
+            send[r - 1] = text_block[:two_k]
+        got = yield from comm.all_to_all_v(send)
+        halo = got[r + 1] if r + 1 < P else text_block[:0]
+    else:
+        halo = text_block[:0]
+    K1, K2 = ops.make_keys(text_block, halo, m, two_k, codes, l, c1, c2)
+    V = ops.iota(m, off)
+    S1, S2, SA = yield from dist_sort(comm, ops, K1, K2, V, sizes, c1 * l, c2 * l)
+    del K1, K2, V
+
+    rounds = []
+    shape = (l, c1, c2)
+
+    def neighbours(a1, a2, a3):
+        has = int(a1.numel()) > 0
+        first = ops.record_at(a1, a2, a3, 0) if has else None
+        last = ops.record_at(a1, a2, a3, int(a1.numel()) - 1) if has else None
+        return (yield from _neighbours(comm, first, last, has))
+
+    prev, nxt = yield from neighbours(S1, S2, SA)
+    lh = ops.last_head_first(S1, S2, SA, prev, off, n, shape)
+    heads = yield from comm.all_gather_obj(lh)
+    base = max([0] + heads[:r])
+    Bsa, LCP, nact, nunf = ops.rebucket_first(S1, S2, SA, prev, nxt, off, n, shape, base, want_lcp)
+    del S1, S2
+    ISA = ops.empty_idx(m)
+    yield from dist_put(comm, ops, ISA, off, SA, Bsa, -1, n)
+
+    def boundary_ids(ids):
+        has = int(ids.numel()) > 0
+        first = ops.value_at(ids, 0) if has else None
+        last = ops.value_at(ids, int(ids.numel()) - 1) if has else None
+        return (yield from _neighbours(comm, first, last, has))
+
+    pid, nid = yield from boundary_ids(Bsa)
+    pos = ops.compact(Bsa, None, off, pid, nid)
+    tot = yield from comm.all_gather_obj((nact, nunf))
+    unf_e, unf_b = sum(t[0] for t in tot), sum(t[1] for t in tot)
+    rounds.append((k, unf_b, unf_e))
+    if log is not None and r == 0:
+        log.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % rounds[-1])
+
+    id_bits = bits_for(n)
+    h = two_k
+    while unf_b > 0 and h < n:
+        cnt = int(pos.numel())
+        counts = yield from comm.all_gather_obj(cnt)
+        # B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
+        sa_act = ops.take(SA, pos, off, n)
+        q = ops.add_scalar(sa_act, h)
+        ans = yield from dist_take(comm, ops, ISA, off, q, n)
+        K2 = ops.finish_b2(ans, q, n)
+        K1 = ops.take(Bsa, pos, off, n)
+        T1, T2, TV = yield from dist_sort(comm, ops, K1, K2, sa_act, counts, id_bits, id_bits)
+        prev, nxt = yield from neighbours(T1, T2, TV)
+        lh = ops.last_head_refine(T1, T2, pos, prev)
+        heads = yield from comm.all_gather_obj(lh)
+        base = max([0] + heads[:r])
+        out = ops.rebucket_refine(T1, T2, TV, pos, prev, nxt, base, h, n, SA, Bsa, off, want_lcp, LCP)
+        yield from dist_put(comm, ops, ISA, off, TV, out["ids"], -1, n)
+        if want_lcp:
+            mins = yield from dist_range_min(comm, ops, LCP, off, sizes, out["q_lo"], out["q_hi"], n)
+            ops.lcp_apply(LCP, out["q_at"], off, mins, h)
+        pid, nid = yield from boundary_ids(out["ids"])
+        pos = ops.compact(out["ids"], pos, off, pid, nid)
+        tot = yield from comm.all_gather_obj((out["nact"], out["nunf"]))
+        unf_e, unf_b = sum(t[0] for t in tot), sum(t[1] for t in tot)
+        rounds.append((h, unf_b, unf_e))
+        if log is not None and r == 0:
+            log.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % rounds[-1])
+        h *= 2
+    return dict(SA=SA, ISA=ISA, LCP=LCP if want_lcp else None, k=k, l=l, sigma=sigma, rounds=rounds, n=n, off=off)

