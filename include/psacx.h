@@ -83,7 +83,9 @@ typedef struct psacx_stats {
 
 /* Replaces suffix_array(const mxx::comm&) (suffix_array.hpp:174): binds the
  * engine to HIP device `device` (>= 0).  `stream` may be NULL (the ctx makes
- * its own) or an existing hipStream_t passed as void*. */
+ * its own), an existing hipStream_t passed as void*, or PSACX_STREAM_DEFAULT for
+ * the device's default (null) stream, e.g. when sharing PyTorch's current stream. */
+#define PSACX_STREAM_DEFAULT ((void*)(intptr_t)-1)
 int psacx_create(psacx_ctx** out, int device, void* stream);
 void psacx_destroy(psacx_ctx* ctx);
 const char* psacx_strerror(int code);

@@ -84,5 +84,32 @@ def load():
     lib.psacx_copy_h2d.argtypes = [vp, vp, vp, u64]
     lib.psacx_copy_d2h.argtypes = [vp, vp, vp, u64]
     lib.psacx_sync.argtypes = [vp]
+    # step-level ops of the distributed path (include/psacx_ops.h)
+    i64, u16p = C.c_int64, C.POINTER(C.c_uint16)
+    u64p = C.POINTER(C.c_uint64)
+    lib.psacx_op_char_hist.argtypes = [vp, vp, u64, vp]
+    sig = {
+        "make_keys": [vp, vp, u64, u64, u16p, u32, u32, u32, vp, vp],
+        "iota": [vp, vp, u64, u64],
+        "pair_sort": [vp, vp, vp, vp, u64, u32, u32],
+        "pair_bounds": [vp, vp, vp, u64, u64p, u64p, u32, i32, u64p, u64p],
+        "owners": [vp, vp, u64, u64, u32, vp],
+        "take": [vp, vp, vp, u64, u64, u64, vp],
+        "put": [vp, vp, vp, u64, u64, vp, i64],
+        "add_scalar": [vp, vp, u64, u64, vp],
+        "finish_b2": [vp, vp, vp, u64, u64, vp],
+        "last_head": [vp, i32, vp, vp, vp, u64, u64, u32, u32, u32, vp, u64p],
+        "rebucket_first": [vp, vp, vp, vp, u64, u64, u32, u32, u32, vp, vp, vp, u64p, u64p],
+        "rebucket_refine": [vp, vp, vp, vp, vp, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, u64p, u64p, u64p],
+        "compact": [vp, vp, vp, u64, u64, u64, u64, vp, u64p],
+        "block_min": [vp, vp, u64, u64p],
+        "range_min": [vp, vp, u64, vp, vp, u64, u64, vp],
+        "rmq_split": [vp, vp, vp, u64, u64, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "rmq_combine": [vp, vp, vp, vp, vp, u64, u64p, u32, vp],
+        "lcp_apply": [vp, vp, vp, u64, u64, vp, u64],
+    }
+    for name, args in sig.items():
+        for suf in ("u32", "u64"):
+            getattr(lib, "psacx_op_%s_%s" % (name, suf)).argtypes = args
     _lib = lib
     return lib

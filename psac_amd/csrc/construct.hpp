@@ -108,7 +108,7 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
                 KeyShape ks) {
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL((last_head_kernel<T, REFINE>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
-                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks);
+                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
                        (uint64_t)0, (uint64_t*)nullptr);
@@ -137,7 +137,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     if (*active > 0) {
         ProfScope ps(c, TC_COMPACT);
         hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact);
+                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0);
         PSACX_HIP(c, hipGetLastError());
     }
     return PSACX_OK;
@@ -236,7 +236,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
-        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n,
+        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                            tab, ks, w.x.k1, w.x.k2, w.sc.d_partials);
         PSACX_HIP(c, hipGetLastError());
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
@@ -255,7 +255,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
         hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                            dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                           w.d_carry, w.d_nact, w.d_nunf);
+                           w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
         PSACX_HIP(c, hipGetLastError());
     }
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
@@ -301,9 +301,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
             PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, KeyShape())));
-            hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
+            hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
-                               d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf);
+                               d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
+                               (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr);
             PSACX_HIP(c, hipGetLastError());
         }
         uint64_t nactive = 0;

@@ -28,7 +28,8 @@ int psacx_create(psacx_ctx** out, int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
-    if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+    if (stream == PSACX_STREAM_DEFAULT) { c->stream = nullptr; c->own_stream = false; }
+    else if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSACX_EHIP; }
         c->own_stream = true;

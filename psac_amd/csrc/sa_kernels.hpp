@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t record_suffix(uint64_t j, uint64_t spec, uin
 
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                          CodeTable tab, KeyShape ks,
+                                                          uint64_t n_text, CodeTable tab, KeyShape ks,
                                                           T* __restrict__ C1, T* __restrict__ C2,
                                                           unsigned long long* __restrict__ summary) {
     constexpr int TILE = BLOCK * ITEMS;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
     const unsigned need = TILE + two_k;
     for (unsigned i = threadIdx.x; i < need; i += BLOCK) {
         const uint64_t g = i_lo + i;
-        codes[i] = g < n ? ctab[text[g]] : (uint16_t)0;
+        codes[i] = g < n_text ? ctab[text[g]] : (uint16_t)0;   // n_text >= n: the block plus its halo
     }
     __syncthreads();
     const unsigned lc = ks.lc;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
             T w1 = 0, w2 = 0;
             if (rec < n) {
                 const uint64_t i = record_suffix(rec, ks.spec, n);
-                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i + t < n) ? tab.c[text[i + t]] : 0);
-                for (unsigned t = 0; t < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)((i + ks.c1 + t < n) ? tab.c[text[i + ks.c1 + t]] : 0);
+                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i + t < n_text) ? tab.c[text[i + t]] : 0);
+                for (unsigned t = 0; t < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)((i + ks.c1 + t < n_text) ? tab.c[text[i + ks.c1 + t]] : 0);
             }
             o1[j] = w1; o2[j] = w2;
         }
@@ -198,6 +198,17 @@ __device__ __forceinline__ unsigned window_lcp(T x1, T x2, T y1, T y2, const Key
     return ks.c1 + ks.c2;
 }
 
+// What a rank needs to know about the records just outside its block of the globally sorted
+// sequence (all zero on a single GPU).  psac gets the same with right_shift of the last tuple
+// (bucketing.hpp:77,100) and exscan(max) of the bucket ids (bucketing.hpp:39).
+template <typename T> struct Boundary {
+    uint64_t off;            // global SA position of local record 0
+    uint64_t base;           // id of the last bucket head on all lower ranks (0 = none)
+    int has_prev, has_next;
+    T prev1, prev2, prev3;   // last record (k1, k2, suffix) of the nearest non-empty lower rank
+    T next1, next2, next3;   // first record of the nearest non-empty higher rank
+};
+
 // ------------------------------------------------------------------ tile carries for the prefix-max
 // Bucket ids are a prefix maximum over "head" positions (bucketing.hpp:21-53).  It is
 // evaluated in three launches without any inter-workgroup waiting:
@@ -212,7 +223,7 @@ template <typename T, bool REFINE>
 __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__ A2,
                                  const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
                                  uint64_t ntiles, uint64_t* __restrict__ agg, const T* __restrict__ SA,
-                                 KeyShape ks) {
+                                 KeyShape ks, uint64_t n_global, Boundary<T> bd) {
     const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const unsigned lane = lane_id();
     if (wave_id >= ntiles) return;
@@ -226,21 +237,23 @@ __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__
         const uint64_t e = w0 + lane;
         bool head = false;
         if (e < wend) {
-            if (e == 0) head = true;
+            if (e == 0 && !bd.has_prev) head = true;
             else {
-                const T x1 = A1[e], y1 = A1[e - 1], x2 = A2[e], y2 = A2[e - 1];
+                const T x1 = A1[e], x2 = A2[e];
+                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = e ? A2[e - 1] : bd.prev2;
                 head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
                 if (!REFINE && !head) {
                     // equal packed windows: still a boundary if either suffix is shorter than 2k
                     const uint64_t two_k = ks.c1 + ks.c2;
-                    head = (cnt - (uint64_t)SA[e] < two_k) || (cnt - (uint64_t)SA[e - 1] < two_k);
+                    const T ysa = e ? SA[e - 1] : bd.prev3;
+                    head = (n_global - (uint64_t)SA[e] < two_k) || (n_global - (uint64_t)ysa < two_k);
                 }
             }
         }
         const uint64_t m = __ballot(head);
         if (m) {
             const uint64_t at = w0 + (63u - (unsigned)__builtin_clzll(m));
-            found = REFINE ? (uint64_t)(pos ? pos[at] : (T)at) + 1 : at + 1;
+            found = REFINE ? (uint64_t)(pos ? pos[at] : (T)at) + 1 : bd.off + at + 1;
             break;
         }
         wend = w0;
@@ -281,7 +294,8 @@ template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
-    uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf) {
+    uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd) {
+    // n: records in this block; ng: length of the whole text (LCP sentinel, suffix lengths)
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
@@ -295,12 +309,15 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     load_run<T, ITEMS>(SA, e0, n, sa, (T)0);
     T p1 = 0, p2 = 0, psa = 0;
     if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; psa = SA[e0 - 1]; }
+    else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; psa = bd.prev3; }
     // head flag of the first record after this run (for the activity test)
     bool next_head = true;
-    if (e0 + ITEMS < n) {
-        const T q1 = S1[e0 + ITEMS], q2 = S2[e0 + ITEMS], qsa = SA[e0 + ITEMS];
+    if (e0 + ITEMS <= n && (e0 + ITEMS < n || bd.has_next)) {
+        const bool in = e0 + ITEMS < n;
+        const T q1 = in ? S1[e0 + ITEMS] : bd.next1, q2 = in ? S2[e0 + ITEMS] : bd.next2;
+        const T qsa = in ? SA[e0 + ITEMS] : bd.next3;
         uint64_t c = window_lcp<T>(a1[ITEMS - 1], a2[ITEMS - 1], q1, q2, ks);
-        const uint64_t la = n - (uint64_t)sa[ITEMS - 1], lb = n - (uint64_t)qsa;
+        const uint64_t la = ng - (uint64_t)sa[ITEMS - 1], lb = ng - (uint64_t)qsa;
         c = c < la ? c : la; c = c < lb ? c : lb;
         next_head = c < two_k;
     }
@@ -314,16 +331,29 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         const uint64_t e = e0 + j;
         // common characters of the two 2k windows, the end marker differing from everything
         uint64_t c = window_lcp<T>(p1, p2, a1[j], a2[j], ks);
-        const uint64_t la = n - (uint64_t)psa, lb = n - (uint64_t)sa[j];
+        const uint64_t la = ng - (uint64_t)psa, lb = ng - (uint64_t)sa[j];
         c = c < la ? c : la; c = c < lb ? c : lb;
-        const bool head = (e == 0) || c < two_k;
+        const bool very_first = (e == 0) && !bd.has_prev;      // nothing sorts before this record
+        const bool head = very_first || c < two_k;
         if (head || e >= n) heads |= 1u << j;
-        id[j] = (e < n && head) ? (T)(e + 1) : (T)0;
-        if (WITH_LCP) lc[j] = head ? (e == 0 ? (T)0 : (T)c) : (T)n;
+        id[j] = (e < n && head) ? (T)(bd.off + e + 1) : (T)0;
+        if (WITH_LCP) lc[j] = head ? ((very_first && bd.off == 0) ? (T)0 : (T)c) : (T)ng;
         p1 = a1[j]; p2 = a2[j]; psa = sa[j];
         if (id[j] > run) run = id[j];
     }
     if (next_head) heads |= 1u << ITEMS;
+    if (e0 < n && e0 + ITEMS > n) {
+        // the block ends inside this run: the record after its last one lives on the next rank
+        const unsigned lastj = (unsigned)(n - 1 - e0);
+        bool nh = true;
+        if (bd.has_next) {
+            uint64_t c = window_lcp<T>(a1[lastj], a2[lastj], bd.next1, bd.next2, ks);
+            const uint64_t la = ng - (uint64_t)sa[lastj], lb = ng - (uint64_t)bd.next3;
+            c = c < la ? c : la; c = c < lb ? c : lb;
+            nh = c < two_k;
+        }
+        heads = nh ? (heads | (1u << (lastj + 1))) : (heads & ~(1u << (lastj + 1)));
+    }
     // activity: not a head, or a head followed by a non-head
     unsigned nact = 0, nub = 0;
 #pragma unroll
@@ -340,6 +370,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const unsigned tub = block_reduce<BLOCK, unsigned>(nub, OpSum(), red_tmp);
     if (threadIdx.x == 0) { n_active[tile] = tact; n_unf[tile] = tub; }
     T carry = (T)carry_in[tile];
+    if ((T)bd.base > carry) carry = (T)bd.base;
     if (excl > carry) carry = excl;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -464,7 +495,9 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const T* __restri
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
-    const uint64_t* __restrict__ offset) {
+    const uint64_t* __restrict__ offset, uint64_t pos_off, T prev_id, T next_id) {
+    // prev_id / next_id: bucket id of the list entry just before / after this block (0 = none);
+    // pos_off: SA position of entry 0 when pos_in is null
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
     const unsigned tile = blockIdx.x;
@@ -476,8 +509,9 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
         load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j];
-        v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (T)0;
-        v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (T)0;
+        v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
+        v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (e0 + ITEMS == cnt ? next_id : (T)0);
+        if (e0 < cnt && e0 + ITEMS > cnt) v[(unsigned)(cnt - e0) + 1] = next_id;   // block ends inside this run
     }
     unsigned act = 0, nact = 0;
 #pragma unroll
@@ -493,8 +527,34 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     if (pos_in) load_run<T, ITEMS>(pos_in, e0, cnt, ps, (T)0);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if (act & (1u << j)) pos_out[o++] = pos_in ? ps[j] : (T)(e0 + j);
+        if (act & (1u << j)) pos_out[o++] = pos_in ? ps[j] : (T)(pos_off + e0 + j);
     }
+}
+
+// per-tile number of active entries (same predicate as compact_active_kernel), for callers that
+// do not get the counts from a rebucket kernel
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict__ ids, uint64_t cnt, T prev_id, T next_id,
+                                                             uint64_t* __restrict__ n_active) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
+    const uint64_t e0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
+    T v[ITEMS + 2];
+    {
+        T mid[ITEMS];
+        load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j];
+        v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
+        v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (e0 + ITEMS == cnt ? next_id : (T)0);
+        if (e0 < cnt && e0 + ITEMS > cnt) v[(unsigned)(cnt - e0) + 1] = next_id;
+    }
+    unsigned nact = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) ++nact;
+    const unsigned t = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
+    if (threadIdx.x == 0) n_active[blockIdx.x] = t;
 }
 
 // ------------------------------------------------------------------ sparse B2 fetch
@@ -596,12 +656,17 @@ __device__ __forceinline__ void pyramid_set(const Pyramid<T>& P, uint64_t p, T v
 // V = suffix start) and their SA positions pos[] (ascending).  Writes back the
 // refined order and ids, the LCP of every freshly split boundary, and the per-tile
 // activity counts for the next round.
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
+// DIST: this rank holds only a block of SA / Bsa / LCP (positions bd.off ...).  ISA is not
+// written (the ids go to their owners afterwards), range minima are not evaluated here: every
+// new boundary that needs one is appended to q_at / q_lo / q_hi (q_count = running length).
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool DIST>
 __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const T* __restrict__ K1, const T* __restrict__ K2, const T* __restrict__ V,
     const T* __restrict__ pos, uint64_t cnt, uint64_t n, uint64_t h, T* __restrict__ SA,
     T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
-    const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf) {
+    const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf,
+    Boundary<T> bd, T* __restrict__ q_at, T* __restrict__ q_lo, T* __restrict__ q_hi,
+    unsigned long long* __restrict__ q_count) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
@@ -618,9 +683,11 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) { p1 = K1[e0 - 1]; p2 = K2[e0 - 1]; }
+    else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; }
     bool next_head = true;
-    if (e0 + ITEMS < cnt) {
-        const T q1 = K1[e0 + ITEMS], q2 = K2[e0 + ITEMS];
+    if (e0 + ITEMS <= cnt && (e0 + ITEMS < cnt || bd.has_next)) {
+        const bool in = e0 + ITEMS < cnt;
+        const T q1 = in ? K1[e0 + ITEMS] : bd.next1, q2 = in ? K2[e0 + ITEMS] : bd.next2;
         next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
     }
 
@@ -631,18 +698,22 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
         const bool in = e < cnt;
-        const bool same1 = (e > 0) && a1[j] == p1;
+        const bool same1 = (e > 0 || bd.has_prev) && a1[j] == p1;
         const bool head = !same1 || a2[j] != p2 || a2[j] == 0;
         if (head || !in) heads |= 1u << j;
         id[j] = (in && head) ? (T)(ps[j] + 1) : (T)0;
         if (WITH_LCP && in && same1 && head) {
             // boundary that appeared inside an old bucket (suffix_array.hpp:1457-1476)
-            const uint64_t at = (uint64_t)ps[j];
+            const uint64_t at = (uint64_t)ps[j] - bd.off;
+            const T lo = p2 < a2[j] ? p2 : a2[j];
+            const T hi = p2 < a2[j] ? a2[j] : p2;
             if (p2 == 0 || a2[j] == 0) {
-                if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);
+                if (DIST) { if (pyr.lvl[0][at] == (T)n) pyr.lvl[0][at] = (T)h; }
+                else if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);
+            } else if (DIST) {
+                const unsigned long long slot = atomicAdd(q_count, 1ull);
+                q_at[slot] = ps[j]; q_lo[slot] = lo; q_hi[slot] = hi;
             } else {
-                const T lo = p2 < a2[j] ? p2 : a2[j];
-                const T hi = p2 < a2[j] ? a2[j] : p2;
                 const T m = pyramid_min<T>(pyr, (uint64_t)lo, (uint64_t)hi);
                 pyramid_set<T>(pyr, at, (T)(h + m));
             }
@@ -651,6 +722,12 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         if (id[j] > run) run = id[j];
     }
     if (next_head) heads |= 1u << ITEMS;
+    if (e0 < cnt && e0 + ITEMS > cnt) {
+        const unsigned lastj = (unsigned)(cnt - 1 - e0);
+        bool nh = true;
+        if (bd.has_next) nh = (bd.next1 != a1[lastj]) || (bd.next2 != a2[lastj]) || bd.next2 == 0;
+        heads = nh ? (heads | (1u << (lastj + 1))) : (heads & ~(1u << (lastj + 1)));
+    }
     unsigned nact = 0, nub = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -666,6 +743,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const unsigned tub = block_reduce<BLOCK, unsigned>(nub, OpSum(), red_tmp);
     if (threadIdx.x == 0) { n_active[tile] = tact; n_unf[tile] = tub; }
     T carry = (T)carry_in[tile];
+    if ((T)bd.base > carry) carry = (T)bd.base;
     if (excl > carry) carry = excl;
     T sa[ITEMS];
     load_run<T, ITEMS>(V, e0, cnt, sa, (T)0);
@@ -674,9 +752,9 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         const uint64_t e = e0 + j;
         if (id[j] == 0) id[j] = carry; else carry = id[j];
         if (e < cnt) {
-            SA[ps[j]] = sa[j];
-            Bsa[ps[j]] = id[j];
-            ISA[sa[j]] = id[j] - 1;
+            SA[(uint64_t)ps[j] - bd.off] = sa[j];
+            Bsa[(uint64_t)ps[j] - bd.off] = id[j];
+            if (!DIST) ISA[sa[j]] = id[j] - 1;
         }
     }
     store_run<T, ITEMS>(ids_out, e0, cnt, id);

@@ -14,6 +14,29 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(psacx_[a-z0-9_]+)\s*\(", src)))
 
 
+def declared_op_symbols():
+    src = open(os.path.join(ROOT, "include", "psacx_ops.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(psacx_op_[a-z0-9_]+?)(?:_##S)?\s*\(", src))
+    out = set()
+    for n in names:
+        if n == "psacx_op_char_hist":
+            out.add(n)
+        else:
+            out.add(n + "_u32"); out.add(n + "_u64")
+    return sorted(out)
+
+
+def test_ops_header_symbols_are_exported():
+    from psac_amd import _lib, dist_ops
+    lib = _lib.load()
+    syms = declared_op_symbols()
+    assert len(syms) == 37
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(dist_ops.OP_EXPORTS) == syms
+
+
 def test_header_symbols_are_exported():
     from psac_amd import _lib
     lib = _lib.load()

@@ -242,3 +242,50 @@ def test_cli_and_cpp_header(ctx, tmp_path):
     # argument errors exit non-zero like TCLAP (src/psac.cpp:147-150)
     assert subprocess.run([psac], capture_output=True).returncode != 0
     assert subprocess.run([psac, "-f", str(f), "-r", "5"], capture_output=True).returncode != 0
+
+
+def _dist_loopback_gpu(text, P, bits, k=0):
+    import torch
+    from psac_amd import dist as D
+    from psac_amd.comm import LoopbackWorld
+    from psac_amd.dist_ops import HipOps
+    sizes = D.blk_sizes(text.size, P)
+    offs = D.prefix(sizes)
+    ops = [HipOps(bits, 0) for _ in range(P)]
+    blocks = [torch.from_numpy(text[o:o + s].copy()).cuda() for o, s in zip(offs, sizes)]
+
+    def fn(comm, op, blk):
+        return (yield from D.construct(comm, op, blk, want_lcp=True, k_req=k))
+    res = LoopbackWorld(P).run(fn, [(ops[r], blocks[r]) for r in range(P)])
+    udt = np.uint32 if bits == 32 else np.uint64
+    cat = lambda key: np.concatenate([r[key].cpu().numpy().view(udt) for r in res])
+    out = cat("SA"), cat("ISA"), cat("LCP"), res[0]["rounds"]
+    for o in ops:
+        o.close()
+    return out
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_distributed_ops_on_one_gpu(ctx, P):
+    # the block-distributed choreography with the HIP step ops, P virtual ranks sharing this GPU
+    for bits in (32, 64):
+        text = O.rand_dna(60011, 7)
+        sa, isa, lcp, _ = _dist_loopback_gpu(text, P, bits)
+        ref = O.construct(text, bits=bits)
+        assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+    unit = O.rand_dna(256, 3)
+    text = inputs.tandem(40000, 256, unit)
+    sa, isa, lcp, rounds = _dist_loopback_gpu(text, P, 32)
+    ref = O.construct(text, bits=32)
+    assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+    text = O.rand_dna(30011, 23)
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, P, 64, k=3)
+    assert np.array_equal(sa, O.naive_sa(text, 64))
+    assert np.array_equal(O.kasai(text, sa, isa), lcp)
+
+
+def test_distributed_ops_larger(ctx):
+    text = inputs.dna((1 << 22) + 1234, 9)
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, 3, 32)
+    assert O.check_sa(text, sa, isa) == 0
+    assert np.array_equal(O.kasai(text, sa, isa), lcp)
