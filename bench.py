@@ -66,18 +66,92 @@ def cpu_baseline(kind, sample, seed, bits):
                       % (sample, kind, seed, bits, dt)}
 
 
+def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism):
+    w = bits // 8
+    ms_per_step = dt / a.steps * 1e3
+    value = world * n * a.steps / dt / 1e6
+    dom = 1 if scat_bytes[1] >= scat_bytes[0] else 0
+    kname = ("radix_scatter3_kernel" if dom else "radix_scatter_kernel")
+    achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
+    out = {
+        "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
+        "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u%d" % bits, "data": "synthetic",
+        "config": {"workload": "%d MiB random %s per GPU (splitmix64 seed %d + rank), %d MiB in total, uint%d indices, "
+                               "SA+%s on %d x MI355X" % (n >> 20, a.alphabet, a.seed, (world * n) >> 20, bits,
+                                                         "ISA" if a.no_lcp else "ISA+LCP", world),
+                   "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism},
+        "roofline": {"bound": "hbm", "kernel": kname + " (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
+                     "launches_per_step": scat_launches[dom] // max(a.steps, 1),
+                     "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
+                     "bytes_per_record_per_pass": 6 * w,
+                     "traffic": TRAFFIC_PER_LAUNCH if (world == 1 and dom == 1 and n == (1 << 28) and bits == 32) else None},
+    }
+    if phases:
+        out["phase_ms_last_step"] = phases
+    return out
+
+
+def main_distributed(a, rank, world, local_rank):
+    """N > 1: the text is block-partitioned over the ranks (one block of --n characters per GPU);
+    sort shuffle, SA->ISA scatter, B2 fetch and range-min queries go through RCCL all-to-all."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from psac_amd import dist as D
+    from psac_amd.comm import TorchComm
+    from psac_amd.dist_ops import HipOps
+    n, bits = a.n, a.index
+    if world * n > 0xFFFFFFFE:
+        bits = 64
+    ops = HipOps(bits, local_rank)
+    comm = TorchComm()
+    text = torch.from_numpy(make_text(a.alphabet, n, a.seed + rank)).cuda()
+
+    def step():
+        return D.run(D.construct(comm, ops, text, want_lcp=not a.no_lcp))
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ops.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    s = ops.stats()
+    if rank == 0:
+        out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3], list(s.scatter_bytes),
+                     list(s.scatter_launches), None, res["k"], res["l"], len(res["rounds"]),
+                     "block-partitioned text, 1 rank per GPU, RCCL all-to-all (sort shuffle, ISA scatter, B2 fetch)")
+        print(json.dumps(out))
+    ops.close()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        return main_distributed(a, rank, world, local_rank)
     import numpy as np
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import psac_amd
 
     n = a.n
@@ -94,8 +168,6 @@ def main():
         return sa.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp, profile=profile)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
         ctx.check(ctx._lib.psacx_sync(ctx.handle))
 
@@ -114,56 +186,24 @@ def main():
             scat_bytes[q] += s.scatter_bytes[q]; scat_launches[q] += s.scatter_launches[q]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     # sanity on the result of the last step (cheap device->host spot check)
     head = np.empty(4, np.uint32 if bits == 32 else np.uint64)
     ctx.d2h(head, d_lcp if not a.no_lcp else d_sa)
 
-    if rank == 0:
-        ms_per_step = dt / a.steps * 1e3
-        value = world * n * a.steps / dt / 1e6
-        dom = 1 if scat_bytes[1] >= scat_bytes[0] else 0
-        kname = ("radix_scatter3_kernel" if dom else "radix_scatter_kernel")
-        achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
-        s_last = s
-        out = {
-            "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
-            "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u%d" % bits, "data": "synthetic",
-            "config": {"workload": "%d MiB random %s (splitmix64 seed %d), uint%d indices, SA+%s on %d x MI355X"
-                                   % (n >> 20, a.alphabet, a.seed, bits, "ISA" if a.no_lcp else "ISA+LCP", world),
-                       "n_per_gpu": n, "k": int(s_last.k), "bits_per_char": int(s_last.bits_per_char),
-                       "rounds": int(s_last.n_rounds),
-                       "parallelism": "1 process per GPU" if world == 1 else "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": kname + " (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
-                         "launches_per_step": scat_launches[dom] // max(a.steps, 1),
-                         "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
-                         "bytes_per_record_per_pass": 6 * w,
-                         "traffic": TRAFFIC_PER_LAUNCH if (dom == 1 and n == (1 << 28) and bits == 32) else None},
-            "phase_ms_last_step": {"total": round(s_last.ms_total, 3), "alphabet": round(s_last.ms_alphabet, 3),
-                                   "kmer": round(s_last.ms_kmer, 3), "sort_hist": round(s_last.ms_sort_hist, 3),
-                                   "sort_scatter": round(s_last.ms_sort_scatter + s_last.ms_sort_scatter3, 3),
-                                   "sort_tile_hist": round(s_last.ms_sort_tilehist, 3),
-                                   "rebucket": round(s_last.ms_rebucket, 3), "isa_scatter": round(s_last.ms_isa_scatter, 3),
-                                   "gather": round(s_last.ms_gather, 3), "compact": round(s_last.ms_compact, 3),
-                                   "rmq_build": round(s_last.ms_rmq_build, 3), "finalize": round(s_last.ms_finalize, 3)},
-        }
-        if a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)
-        print(json.dumps(out))
+    phases = {"total": round(s.ms_total, 3), "alphabet": round(s.ms_alphabet, 3), "kmer": round(s.ms_kmer, 3),
+              "sort_hist": round(s.ms_sort_hist, 3), "sort_scatter": round(s.ms_sort_scatter + s.ms_sort_scatter3, 3),
+              "sort_tile_hist": round(s.ms_sort_tilehist, 3), "rebucket": round(s.ms_rebucket, 3),
+              "isa_scatter": round(s.ms_isa_scatter, 3), "gather": round(s.ms_gather, 3), "compact": round(s.ms_compact, 3),
+              "rmq_build": round(s.ms_rmq_build, 3)}
+    out = report(a, 1, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, int(s.k), int(s.bits_per_char),
+                 int(s.n_rounds), "1 process per GPU")
+    if a.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)
+    print(json.dumps(out))
     for p in (d_text, d_sa, d_isa, d_lcp):
         ctx.free(p)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

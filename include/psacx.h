@@ -112,6 +112,11 @@ int psacx_construct_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, u
 int psacx_construct_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k,
                             uint32_t flags, uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP);
 
+/* psacx_profile(ctx, 1): zero the statistics and let the step-level ops of psacx_ops.h add their
+ * radix-pass event times and byte counts to them (psacx_get_stats reads the running totals);
+ * psacx_profile(ctx, 0) stops it. */
+int psacx_profile(psacx_ctx* ctx, int on);
+
 /* statistics of the last construct call on this ctx (iteration log of
  * suffix_array.hpp:416, section timers of suffix_array.hpp:52-63) */
 int psacx_get_stats(const psacx_ctx* ctx, psacx_stats* out);

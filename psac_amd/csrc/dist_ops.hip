@@ -202,7 +202,7 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, uint64_t n, uint32_t bits1, u
     sc.h_base = sc.h_hist + (size_t)MAX_PASSES * RADIX;
     sc.h_summary = reinterpret_cast<unsigned long long*>(c->pinned + 256);
     PSACX_HIP(c, hipMemsetAsync(sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
-    c->profile = false; c->ev_used = 0;
+    c->profile = c->profile_ops; c->ev_used = 0;
     SortBufs<T> in{k1, k2, v}, res;
     // a word with zero significant bits takes no pass
     PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, false, bits1, bits2, nullptr, &res, nullptr));
@@ -213,6 +213,7 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, uint64_t n, uint32_t bits1, u
     if (res.v != v) PSACX_HIP(c, hipMemcpyAsync(v, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
     PSACX_HIP(c, hipMemcpyAsync(c->pinned, sc.d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->profile) { prof_accumulate(c); c->profile = false; }
     if (*reinterpret_cast<unsigned*>(c->pinned)) return PSACX_EDEVICE;
     return PSACX_OK;
 }

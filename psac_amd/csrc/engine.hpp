@@ -35,6 +35,7 @@ struct psacx_ctx {
     std::string hip_err;
     psacx_stats stats;
     bool profile = false;
+    bool profile_ops = false;        // step-level ops accumulate into stats (psacx_profile)
     struct Ev { hipEvent_t a, b; int cat; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
@@ -70,6 +71,20 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) (void)hipEventRecord(c->ev_pool[idx].b, c->stream); }
 };
+
+// adds the elapsed time of this call's event pairs to the running totals (step-level ops)
+inline void prof_accumulate(psacx_ctx* c) {
+    double acc[TC_COUNT];
+    for (int i = 0; i < TC_COUNT; ++i) acc[i] = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) acc[c->ev_pool[i].cat] += ms;
+    }
+    psacx_stats& s = c->stats;
+    s.ms_sort_hist += acc[TC_SORT_HIST]; s.ms_sort_scatter += acc[TC_SORT_SCATTER];
+    s.ms_sort_scatter3 += acc[TC_SORT_SCATTER3]; s.ms_sort_tilehist += acc[TC_SORT_TILEHIST];
+    c->ev_used = 0;
+}
 
 inline void prof_collect(psacx_ctx* c) {
     double acc[TC_COUNT];

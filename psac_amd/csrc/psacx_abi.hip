@@ -85,6 +85,13 @@ int psacx_construct_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t
     return construct_dev_u64(c, t, n, k, f, sa, isa, lcp);
 }
 
+int psacx_profile(psacx_ctx* c, int on) {
+    if (!c) return PSACX_EINVAL;
+    c->profile_ops = on != 0;
+    if (on) std::memset(&c->stats, 0, sizeof(c->stats));
+    return PSACX_OK;
+}
+
 int psacx_get_stats(const psacx_ctx* c, psacx_stats* out) {
     if (!c || !out) return PSACX_EINVAL;
     *out = c->stats;

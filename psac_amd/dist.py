@@ -317,3 +317,13 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
             log.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % rounds[-1])
         h *= 2
     return dict(SA=SA, ISA=ISA, LCP=LCP if want_lcp else None, k=k, l=l, sigma=sigma, rounds=rounds, n=n, off=off)
+
+
+def run(gen):
+    """Drives a construct() generator to completion under a back-end whose collectives complete
+    immediately (TorchComm)."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value

@@ -225,6 +225,14 @@ class HipOps(object):
     def lcp_apply(self, LCP, at, off, mins, h):
         self._chk(self._f("lcp_apply")(self.ctx, self._p(LCP), self._p(at), int(at.numel()), int(off), self._p(mins), int(h)))
 
+    def profile(self, on):
+        self._chk(self.lib.psacx_profile(self.ctx, int(on)))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._chk(self.lib.psacx_get_stats(self.ctx, C.byref(st)))
+        return st
+
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.psacx_destroy(self.ctx)
