@@ -121,6 +121,17 @@ int psacx_profile(psacx_ctx* ctx, int on);
  * suffix_array.hpp:416, section timers of suffix_array.hpp:52-63) */
 int psacx_get_stats(const psacx_ctx* ctx, psacx_stats* out);
 
+/* verification on the device ---------------------------------------------------
+ * Replaces check_SA / check_lcp / d_check_sa (check_suffix_array.hpp:56-88, :106-126, :207-267)
+ * for buffers resident in HBM.  errors[0] = SA entries out of range or ISA[SA[i]] != i,
+ * errors[1] = suffix-order violations, errors[2] = LCP entries that differ from a direct
+ * character comparison (d_LCP may be NULL), errors[3] = LCP[0] != 0.  All zero = correct.
+ * The LCP check costs sum(LCP) character reads: use it on texts without long repeats. */
+int psacx_check_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const uint32_t* d_SA,
+                        const uint32_t* d_ISA, const uint32_t* d_LCP, uint64_t errors[4]);
+int psacx_check_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const uint64_t* d_SA,
+                        const uint64_t* d_ISA, const uint64_t* d_LCP, uint64_t errors[4]);
+
 /* the rank-pair sort on its own -------------------------------------------
  * Replaces idxsort_vectors(vec1, vec2, comm) (idxsort.hpp:23-83) at one rank:
  * sorts records (b1[i], b2[i], i) by (b1, b2); on return b1/b2 hold the sorted

@@ -8,6 +8,8 @@ int construct_host_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t,
 int construct_host_u64(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
 int pair_sort_dev_u32(psacx_ctx*, uint32_t*, uint32_t*, uint32_t*, uint64_t, uint32_t);
 int pair_sort_dev_u64(psacx_ctx*, uint64_t*, uint64_t*, uint64_t*, uint64_t, uint32_t);
+int check_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
+int check_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*);
 int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 int ansv_host_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 }
@@ -103,6 +105,13 @@ int psacx_pair_sort_dev_u32(psacx_ctx* c, uint32_t* b1, uint32_t* b2, uint32_t* 
 }
 int psacx_pair_sort_dev_u64(psacx_ctx* c, uint64_t* b1, uint64_t* b2, uint64_t* idx, uint64_t n, uint32_t bits) {
     return pair_sort_dev_u64(c, b1, b2, idx, n, bits);
+}
+
+int psacx_check_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32_t* sa, const uint32_t* isa, const uint32_t* lcp, uint64_t* e) {
+    return check_dev_u32(c, t, n, sa, isa, lcp, e);
+}
+int psacx_check_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* sa, const uint64_t* isa, const uint64_t* lcp, uint64_t* e) {
+    return check_dev_u64(c, t, n, sa, isa, lcp, e);
 }
 
 int psacx_ansv_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {

@@ -145,6 +145,16 @@ class SuffixArray(object):
         return self._after()
 
 
+def check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, index_bits):
+    """check_SA / check_lcp on buffers resident in HBM (check_suffix_array.hpp:56-126).  Returns the four
+    error counters of psacx_check_dev_*; all zero means correct."""
+    err = (C.c_uint64 * 4)()
+    fn = getattr(ctx._lib, "psacx_check_dev_u%d" % index_bits)
+    ctx.check(fn(ctx.handle, C.c_void_p(d_text), int(n), C.c_void_p(d_sa), C.c_void_p(d_isa),
+                 C.c_void_p(d_lcp) if d_lcp else None, err))
+    return list(err)
+
+
 def ansv(values, left_type=NEAREST_SM, right_type=NEAREST_SM, nonsv=0, ctx=None):
     """ansv<T,left_type,right_type>(in, left_nsv, right_nsv, comm) (ansv.hpp:2042-2051), one rank."""
     v = np.ascontiguousarray(values)

@@ -289,3 +289,38 @@ def test_distributed_ops_larger(ctx):
     sa, isa, lcp, _ = _dist_loopback_gpu(text, 3, 32)
     assert O.check_sa(text, sa, isa) == 0
     assert np.array_equal(O.kasai(text, sa, isa), lcp)
+
+
+def _device_run_and_check(ctx, text, bits, corrupt=False):
+    import psac_amd
+    n = int(text.size); w = bits // 8
+    d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+    d_sa, d_isa, d_lcp = ctx.alloc(n * w), ctx.alloc(n * w), ctx.alloc(n * w)
+    sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
+    sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+    if corrupt:
+        bad = np.array([5], np.uint32 if bits == 32 else np.uint64)
+        ctx.h2d(d_lcp + 1000 * w, bad + 77)
+    err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, bits)
+    for p in (d_text, d_sa, d_isa, d_lcp):
+        ctx.free(p)
+    return err
+
+
+def test_device_checker_detects_errors(ctx):
+    text = inputs.dna(1 << 20, 3)
+    assert _device_run_and_check(ctx, text, 32) == [0, 0, 0, 0]
+    err = _device_run_and_check(ctx, text, 32, corrupt=True)
+    assert err[2] == 1 and err[0] == 0 and err[1] == 0
+
+
+def test_full_size_config_c2(ctx):
+    # BASELINE.json configs[1] at full size: 256 MiB random DNA, uint32; verified on the device by the
+    # order property and direct LCP comparison (size-independent properties)
+    text = inputs.dna(1 << 28, 1)
+    assert _device_run_and_check(ctx, text, 32) == [0, 0, 0, 0]
+
+
+def test_large_uint64(ctx):
+    text = inputs.ascii128((1 << 26) + 3, 42)
+    assert _device_run_and_check(ctx, text, 64) == [0, 0, 0, 0]
