@@ -19,8 +19,11 @@ constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 template <typename T> struct Work {
     T *bsa;
-    SortBufs<T> x, y;
-    T *pos_a, *pos_b;
+    SortBufs<T> x, y;                  // record sets of the first sort (y may alias the output buffers)
+    SortBufs<T> ry;                    // second record set of the refinement rounds (cap_active records)
+    T *pos_a, *pos_b;                  // active position lists (cap_active entries)
+    uint64_t cap_active;
+    bool diet;                         // large-n layout: the output buffers double as sort scratch
     Pyramid<T> pyr;
     unsigned long long* d_hist256;     // char histogram
     uint64_t* d_carry;                 // per scan tile: id of the last head (then its exclusive max-scan)
@@ -32,12 +35,25 @@ template <typename T> struct Work {
     SortScratch sc;
 };
 
+// Normal layout: Bsa + two n-record sets + two n-entry position lists (9 n w bytes).
+// Diet layout (when that does not fit in HBM): the second record set of the first sort is the
+// output buffers themselves (ISA, LCP, SA are dead until the sort is over), and the refinement
+// rounds get `cap` records of room instead of n (4 n w + 5 cap w bytes).
 template <typename T>
-size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp) {
+size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool diet, uint64_t cap, T* d_sa, T* d_isa) {
+    w.diet = diet;
+    w.cap_active = diet ? cap : n;
     w.bsa = a.take<T>(n);
     w.x.k1 = a.take<T>(n); w.x.k2 = a.take<T>(n); w.x.v = a.take<T>(n);
-    w.y.k1 = a.take<T>(n); w.y.k2 = a.take<T>(n); w.y.v = a.take<T>(n);
-    w.pos_a = a.take<T>(n); w.pos_b = a.take<T>(n);
+    if (!diet) {
+        w.y.k1 = a.take<T>(n); w.y.k2 = a.take<T>(n); w.y.v = a.take<T>(n);
+        w.ry = w.y;
+        w.pos_a = a.take<T>(n); w.pos_b = a.take<T>(n);
+    } else {
+        w.y.k1 = d_isa; w.y.k2 = with_lcp ? d_lcp : a.take<T>(n); w.y.v = d_sa;
+        w.ry.k1 = a.take<T>(cap); w.ry.k2 = a.take<T>(cap); w.ry.v = a.take<T>(cap);
+        w.pos_a = a.take<T>(cap); w.pos_b = a.take<T>(cap);
+    }
     w.pyr.nlev = 0;
     for (int i = 0; i < PYR_MAX; ++i) { w.pyr.lvl[i] = nullptr; w.pyr.len[i] = 0; }
     if (with_lcp) {
@@ -119,7 +135,7 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
 // totals of the per-tile activity counts, then the compacted list of still-active positions
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
-                uint64_t* active, uint64_t* unf_buckets) {
+                uint64_t* active, uint64_t* unf_buckets, uint64_t capacity) {
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     {
@@ -134,7 +150,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *active = h_cnt[0];
     *unf_buckets = h_cnt[1];
-    if (*active > 0) {
+    if (*active > 0 && *active <= capacity) {
         ProfScope ps(c, TC_COMPACT);
         hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
                            dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0);
@@ -192,11 +208,38 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         return PSACX_OK;
     }
 
-    // workspace
+    // workspace: the 9 n w layout when it fits, otherwise the diet layout (see carve)
     Work<T> w;
-    { Arena dry(nullptr); carve<T>(dry, w, n, WITH_LCP, d_lcp); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+    bool diet = false;
+    uint64_t cap = n;
+    {
+        Arena dry(nullptr);
+        carve<T>(dry, w, n, WITH_LCP, d_lcp, false, n, d_sa, d_isa);
+        size_t need = dry.off + 4096;
+        size_t free_b = 0, total_b = 0;
+        PSACX_HIP(c, hipMemGetInfo(&free_b, &total_b));
+        const size_t margin = (size_t)512 << 20;
+        const size_t avail = free_b + c->slab_bytes > margin ? free_b + c->slab_bytes - margin : 0;
+        if (getenv("PSACX_FORCE_DIET") || (need > c->slab_bytes && need > avail)) {
+            Arena d0(nullptr);
+            carve<T>(d0, w, n, WITH_LCP, d_lcp, true, 0, d_sa, d_isa);
+            const size_t base = d0.off + 8192;
+            if (no_fast || base >= avail) {
+                c->hip_err = "workspace does not fit in HBM";
+                return PSACX_ENOMEM;
+            }
+            cap = std::min<uint64_t>(n, (avail - base) / (5 * sizeof(T)) > 4096 ? (avail - base) / (5 * sizeof(T)) - 4096 : 0);
+            if (const char* e = getenv("PSACX_DIET_CAP")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 10));
+            if (cap < 1024) { c->hip_err = "workspace does not fit in HBM"; return PSACX_ENOMEM; }
+            diet = true;
+            Arena d1(nullptr);
+            carve<T>(d1, w, n, WITH_LCP, d_lcp, true, cap, d_sa, d_isa);
+            need = d1.off + 4096;
+        }
+        PSACX_TRY(ensure_slab(c, need));
+    }
     Arena ar(c->slab);
-    carve<T>(ar, w, n, WITH_LCP, d_lcp);
+    carve<T>(ar, w, n, WITH_LCP, d_lcp, diet, cap, d_sa, d_isa);
     st.workspace_bytes = c->slab_bytes;
     w.sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
     w.sc.h_base = w.sc.h_hist + (size_t)MAX_PASSES * RADIX;
@@ -230,6 +273,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     ks.c2 = 2 * k - ks.c1;
     ks.spec = std::min<uint64_t>(2ull * k - 1, n);
 
+    // In the diet layout the sorted keys must end up in the workspace set x (the other set is the
+    // LCP / ISA output), so an odd number of passes starts from y.
+    const unsigned planned = (ks.c1 * lc + RADIX_BITS - 1) / RADIX_BITS + (ks.c2 * lc + RADIX_BITS - 1) / RADIX_BITS;
+    const bool start_y = w.diet && (planned & 1u);
+    SortBufs<T> first_in = start_y ? w.y : w.x, first_alt = start_y ? w.x : w.y;
+
     // ---- first-round keys: the 2k-character window at every position, packed (kmer.hpp:119-177,
     //      shifting.hpp:33-122; see key_pairs_kernel for the packing)
     {
@@ -237,7 +286,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         constexpr int KB = 256, KI = 8;
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
         hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
-                           tab, ks, w.x.k1, w.x.k2, w.sc.d_partials);
+                           tab, ks, first_in.k1, first_in.k2, w.sc.d_partials);
         PSACX_HIP(c, hipGetLastError());
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
     }
@@ -246,7 +295,18 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     psacx_round* r0 = &st.rounds[0];
     std::memset(r0, 0, sizeof(*r0));
     SortBufs<T> sorted;
-    PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, d_sa, &sorted, r0, ks.spec, n, /*summary_ready=*/true));
+    PSACX_TRY(pair_sort<T>(c, w.sc, first_in, first_alt, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, w.diet ? (T*)nullptr : d_sa,
+                           &sorted, r0, ks.spec, n, /*summary_ready=*/true));
+    if (w.diet) {
+        // keys into the workspace set if a skipped pass changed the parity; SA out of the scratch payload
+        if (sorted.k1 != w.x.k1) {
+            PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            PSACX_HIP(c, hipMemcpyAsync(w.x.k2, sorted.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            sorted.k1 = w.x.k1; sorted.k2 = w.x.k2;
+        }
+        if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        sorted.v = d_sa;
+    }
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     {
@@ -261,7 +321,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
     {
         ProfScope ps(c, TC_ISA_SCATTER);
-        PSACX_TRY(invert_permutation<T>(c, w, d_sa, w.bsa, n, d_isa, w.x, w.y));
+        SortBufs<T> t2 = w.y;
+        if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
+        PSACX_TRY(invert_permutation<T>(c, w, d_sa, w.bsa, n, d_isa, w.x, t2));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);
@@ -274,9 +336,13 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- which suffixes still share a bucket (suffix_array.hpp:925-965)
     uint64_t active = 0, unf_b = 0;
-    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b));
+    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active));
     r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;
     st.n_rounds = 1;
+    if (active > w.cap_active) {
+        c->hip_err = "too many unresolved suffixes for the reduced-memory layout";
+        return PSACX_ENOMEM;
+    }
 
     T* pos = w.pos_a;
     T* pos_next = w.pos_b;
@@ -294,9 +360,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipGetLastError());
             PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
-        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.y, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr, 0, 0,
+        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr, 0, 0,
                                /*summary_ready=*/true));
-        T* ids = (sorted.k1 == w.x.k1) ? w.y.k1 : w.x.k1;     // the set not holding the result is free
+        T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
@@ -308,7 +374,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipGetLastError());
         }
         uint64_t nactive = 0;
-        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, pos_next, &nactive, &unf_b));
+        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, pos_next, &nactive, &unf_b, w.cap_active));
         if (rr) {
             rr->h = h; rr->active = cnt; rr->unfinished_buckets = unf_b; rr->unfinished_elements = nactive;
             st.n_rounds++;

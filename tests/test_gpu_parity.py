@@ -324,3 +324,25 @@ def test_full_size_config_c2(ctx):
 def test_large_uint64(ctx):
     text = inputs.ascii128((1 << 26) + 3, 42)
     assert _device_run_and_check(ctx, text, 64) == [0, 0, 0, 0]
+
+
+def test_reduced_memory_layout(ctx, monkeypatch):
+    # the large-n layout (output buffers double as sort scratch), forced at a small size
+    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
+    for bits in (32, 64):
+        for text in (O.rand_dna(300007, 5), inputs.ascii128(200003, 3), inputs.dna((1 << 22) + 77, 8)):
+            got = run(ctx, text, bits=bits)
+            if text.size < (1 << 21):
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(got.local_SA, ref["SA"]) and np.array_equal(got.local_B, ref["ISA"])
+                assert np.array_equal(got.local_LCP, ref["LCP"])
+            else:
+                assert O.check_sa(text, got.local_SA, got.local_B) == 0
+                assert np.array_equal(O.kasai(text, got.local_SA, got.local_B), got.local_LCP)
+    # no-LCP variant and a capacity overflow that must fail loudly, not corrupt
+    got = run(ctx, O.rand_dna(100003, 9), bits=32, lcp=False)
+    assert np.array_equal(got.local_SA, O.construct(O.rand_dna(100003, 9), bits=32, lcp=False)["SA"])
+    monkeypatch.setenv("PSACX_DIET_CAP", "2000")
+    import psac_amd
+    with pytest.raises(psac_amd.PsacxError):
+        run(ctx, inputs.tandem(100000, 64, O.rand_dna(64, 1)), bits=32)
