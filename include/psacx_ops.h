@@ -35,9 +35,11 @@ int psacx_op_char_hist(psacx_ctx*, const uint8_t* text, uint64_t n, uint64_t* hi
                                const uint16_t* codes256, uint32_t l, uint32_t c1, uint32_t c2, T* k1,  \
                                T* k2);                                                                 \
     int psacx_op_iota_##S(psacx_ctx*, T* out, uint64_t m, uint64_t start);                             \
-    /* idxsort.hpp:23-83 on one rank: stable sort of (k1,k2,v) by the low bits1 / bits2 bits */        \
-    int psacx_op_pair_sort_##S(psacx_ctx*, T* k1, T* k2, T* v, uint64_t n, uint32_t bits1,             \
-                               uint32_t bits2);                                                        \
+    /* idxsort.hpp:23-83 on one rank: stable sort of (k1,k2,v) by the low bits1 / bits2 bits, radix    \
+       passes ping-pong between the records and the scratch set (a1,a2,av); *where = 0 if the sorted   \
+       records end in (k1,k2,v), 1 if in (a1,a2,av).  The input survives when at most one pass runs */ \
+    int psacx_op_pair_sort_##S(psacx_ctx*, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n,        \
+                               uint32_t bits1, uint32_t bits2, int32_t* where);                        \
     /* lower / upper bound of each query pair in the sorted (s1,s2); queries and results on the host */ \
     int psacx_op_pair_bounds_##S(psacx_ctx*, const T* s1, const T* s2, uint64_t n, const uint64_t* q1, \
                                  const uint64_t* q2, uint32_t nq, int use_second, uint64_t* lb,        \
@@ -49,6 +51,11 @@ int psacx_op_char_hist(psacx_ctx*, const uint8_t* text, uint64_t n, uint64_t* hi
                           uint64_t n, T* out);                                                         \
     int psacx_op_put_##S(psacx_ctx*, T* block, const T* gidx, uint64_t cnt, uint64_t off,              \
                          const T* vals, int64_t delta);                                                \
+    /* the same when gidx is a permutation of [off, off + cnt) (bulk_permute.hpp:14-73 for a whole    \
+       block): destination-partition passes + LDS window scatter instead of cnt random stores;        \
+       only delta = -1 is supported; s1..s4: scratch arrays of cnt entries */                          \
+    int psacx_op_put_perm_##S(psacx_ctx*, T* block, const T* gidx, uint64_t cnt, uint64_t off,         \
+                              const T* vals, T* s1, T* s2, T* s3, T* s4);                              \
     int psacx_op_add_scalar_##S(psacx_ctx*, const T* in, uint64_t cnt, uint64_t s, T* out);            \
     /* suffix_array.hpp:972-996: out = q < n ? ans + 1 : 0 */                                          \
     int psacx_op_finish_b2_##S(psacx_ctx*, const T* ans, const T* q, uint64_t cnt, uint64_t n, T* out); \

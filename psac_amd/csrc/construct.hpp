@@ -162,13 +162,14 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 // ISA[SA[i]] = val[i] - 1 for a full permutation SA (bulk_permute.hpp:14-73).  Large inputs go
 // through destination-partition passes + an LDS window scatter (see partition_pairs_kernel);
 // t1/t2 are two scratch pair buffers of n entries each.
+// koff: the keys are a permutation of [koff, koff + n) (a rank's block in the distributed path)
 template <typename T>
-int invert_permutation(psacx_ctx* c, Work<T>& w, const T* d_sa, const T* val, uint64_t n, T* d_isa,
-                       SortBufs<T> t1, SortBufs<T> t2) {
+int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
+                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0) {
     constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average
     const unsigned idx_bits = bits_for(n - 1);
     if (n < (1ull << 22) || idx_bits > INV_WINDOW_BITS + 24) {
-        hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa, val, n, d_isa);
+        hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa, val, n, d_isa, koff);
         PSACX_HIP(c, hipGetLastError());
         return PSACX_OK;
     }
@@ -178,11 +179,11 @@ int invert_permutation(psacx_ctx* c, Work<T>& w, const T* d_sa, const T* val, ui
     for (int lv = 0; lv < levels; ++lv) {
         const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
         const size_t ncur = (size_t)(n >> shift) + 1;
-        PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ncur * sizeof(unsigned), c->stream));
+        PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
         SortBufs<T> o = bufs[lv & 1];
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
         hipLaunchKernelGGL((partition_pairs_kernel<T, PB, PI>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, kin, vin,
-                           o.k1, o.k2, n, shift, w.d_cursors);
+                           o.k1, o.k2, n, shift, d_cursors, lv == 0 ? koff : (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
         kin = o.k1; vin = o.k2;
     }
@@ -323,7 +324,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         ProfScope ps(c, TC_ISA_SCATTER);
         SortBufs<T> t2 = w.y;
         if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
-        PSACX_TRY(invert_permutation<T>(c, w, d_sa, w.bsa, n, d_isa, w.x, t2));
+        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);

@@ -179,13 +179,14 @@ int op_make_keys(psacx_ctx* c, const uint8_t* text, uint64_t m, uint64_t text_le
 }
 
 template <typename T>
-int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, uint64_t n, uint32_t bits1, uint32_t bits2) {
+int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n, uint32_t bits1, uint32_t bits2,
+                 int32_t* where) {
     OP_PROLOGUE(c);
+    *where = 0;
     if (n < 2) return PSACX_OK;
     PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
-    SortBufs<T> alt; SortScratch sc;
+    SortScratch sc;
     auto layout = [&](Arena& a) {
-        alt.k1 = a.take<T>(n); alt.k2 = a.take<T>(n); alt.v = a.take<T>(n);
         sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
         sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
         sc.desc_bytes = sort_desc_bytes(n);
@@ -203,19 +204,27 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, uint64_t n, uint32_t bits1, u
     sc.h_summary = reinterpret_cast<unsigned long long*>(c->pinned + 256);
     PSACX_HIP(c, hipMemsetAsync(sc.d_err, 0, 64 * sizeof(unsigned), c->stream));
     c->profile = c->profile_ops; c->ev_used = 0;
-    SortBufs<T> in{k1, k2, v}, res;
+    SortBufs<T> in{k1, k2, v}, alt{a1, a2, av}, res;
     // a word with zero significant bits takes no pass
     PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, false, bits1, bits2, nullptr, &res, nullptr));
-    if (res.k1 != k1) {
-        PSACX_HIP(c, hipMemcpyAsync(k1, res.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        PSACX_HIP(c, hipMemcpyAsync(k2, res.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (res.v != v) PSACX_HIP(c, hipMemcpyAsync(v, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    *where = (res.k1 == k1) ? 0 : 1;
+    if (res.v != (*where ? av : v))       // cannot happen without final_v, kept as a guard
+        PSACX_HIP(c, hipMemcpyAsync(*where ? av : v, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
     PSACX_HIP(c, hipMemcpyAsync(c->pinned, sc.d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     if (c->profile) { prof_accumulate(c); c->profile = false; }
     if (*reinterpret_cast<unsigned*>(c->pinned)) return PSACX_EDEVICE;
     return PSACX_OK;
+}
+
+template <typename T>
+int op_put_perm(psacx_ctx* c, T* block, const T* gidx, uint64_t cnt, uint64_t off, const T* vals, T* s1, T* s2, T* s3, T* s4) {
+    OP_PROLOGUE(c);
+    if (cnt == 0) return PSACX_OK;
+    const size_t ncur = (size_t)(cnt >> INV_WINDOW_BITS) + 2 + RADIX_P;
+    PSACX_TRY(ensure_slab(c, ncur * sizeof(unsigned) + 8192));
+    SortBufs<T> t1{s1, s2, nullptr}, t2{s3, s4, nullptr};
+    return invert_permutation<T>(c, reinterpret_cast<unsigned*>(c->slab), gidx, vals, cnt, block, t1, t2, off);
 }
 
 template <typename T>
@@ -450,8 +459,13 @@ int psacx_op_char_hist(psacx_ctx* c, const uint8_t* text, uint64_t n, uint64_t* 
     int psacx_op_iota_##S(psacx_ctx* c, T* out, uint64_t m, uint64_t start) {                                  \
         OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (iota_from_kernel<T>), m, out, m, start); return PSACX_OK;            \
     }                                                                                                          \
-    int psacx_op_pair_sort_##S(psacx_ctx* c, T* k1, T* k2, T* v, uint64_t n, uint32_t b1, uint32_t b2) {       \
-        return op_pair_sort<T>(c, k1, k2, v, n, b1, b2);                                                        \
+    int psacx_op_pair_sort_##S(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n, uint32_t b1, \
+                               uint32_t b2, int32_t* where) {                                                  \
+        return op_pair_sort<T>(c, k1, k2, v, a1, a2, av, n, b1, b2, where);                                     \
+    }                                                                                                          \
+    int psacx_op_put_perm_##S(psacx_ctx* c, T* b, const T* g, uint64_t cnt, uint64_t off, const T* v, T* s1,   \
+                              T* s2, T* s3, T* s4) {                                                           \
+        return op_put_perm<T>(c, b, g, cnt, off, v, s1, s2, s3, s4);                                            \
     }                                                                                                          \
     int psacx_op_pair_bounds_##S(psacx_ctx* c, const T* s1, const T* s2, uint64_t n, const uint64_t* q1,       \
                                  const uint64_t* q2, uint32_t nq, int us, uint64_t* lb, uint64_t* ub) {        \

@@ -383,10 +383,10 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
 // ------------------------------------------------------------------ K8
 template <typename T>
 __global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict__ Bsa, uint64_t n,
-                                   T* __restrict__ ISA) {
+                                   T* __restrict__ ISA, uint64_t koff) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        ISA[SA[i]] = Bsa[i] - 1;      // ISA holds 0-based ranks throughout (suffix_array.hpp:460-464)
+        ISA[(uint64_t)SA[i] - koff] = Bsa[i] - 1;      // ISA holds 0-based ranks throughout (suffix_array.hpp:460-464)
 }
 
 // ------------------------------------------------------------------ K8, cache-friendly form
@@ -402,7 +402,8 @@ constexpr int INV_WINDOW_BITS = 12;
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     const T* __restrict__ key_in, const T* __restrict__ val_in, T* __restrict__ key_out,
-    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors) {
+    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
+    // koff is subtracted from every key on the way in (first level of a rank's block)
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T stage[TILE];
     __shared__ unsigned cnt[RADIX_P];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
-        if (loc < count) { key[i] = key_in[base + loc]; val[i] = val_in[base + loc]; }
+        if (loc < count) { key[i] = (T)((uint64_t)key_in[base + loc] - koff); val[i] = val_in[base + loc]; }
         else { key[i] = 0; val[i] = 0; }
     }
 #pragma unroll
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     if (tid < RADIX_P) {
         bstart[tid] = bs;
         if (tot) {
-            const uint64_t parent = (uint64_t)(key_in[base] >> shift) >> 8;   // same for the whole tile
+            const uint64_t parent = ((uint64_t)key_in[base] - koff) >> shift >> 8;   // same for the whole tile
             const uint64_t g = (parent << 8) | tid;
             const unsigned at = atomicAdd(&cursors[g], tot);
             gbase[tid] = (g << shift) + at - bs;

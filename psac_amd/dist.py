@@ -81,7 +81,7 @@ def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
     concatenation over ranks being sorted (the contract psac needs from mxx::sort,
     idxsort.hpp:67-79)."""
     P, r = comm.size, comm.rank
-    S1, S2, SV = ops.pair_sort(K1, K2, V, bits1, bits2)
+    S1, S2, SV = ops.pair_sort(K1, K2, V, bits1, bits2, destroy=True)
     if P == 1:
         return S1, S2, SV
     c = int(S1.numel())
@@ -115,7 +115,7 @@ def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
     for arr in (S1, S2, SV):
         got = yield from comm.all_to_all_v([arr[bounds[d]:bounds[d + 1]] for d in range(P)])
         parts.append(torch.cat(got) if got else arr[:0])
-    R1, R2, RV = ops.pair_sort(parts[0], parts[1], parts[2], bits1, bits2)
+    R1, R2, RV = ops.pair_sort(parts[0], parts[1], parts[2], bits1, bits2, destroy=True)
     # exact re-balance: global index of my j-th record is G[r] + j
     c2 = int(R1.numel())
     counts = yield from comm.all_gather_obj(c2)
@@ -142,17 +142,22 @@ def _route(comm, ops, gidx, payload, n):
     return g, v, bounds
 
 
-def dist_put(comm, ops, block, off, gidx, vals, delta, n):
+def dist_put(comm, ops, block, off, gidx, vals, delta, n, permutation=False):
     """block[gidx - off_owner] = vals + delta on the owner of each global position
-    (bulk_permute_inplace, bulk_permute.hpp:14-73)."""
+    (bulk_permute_inplace, bulk_permute.hpp:14-73).  permutation=True: every position of every
+    block is written exactly once (the SA -> ISA inversion of the first round, delta = -1)."""
     P = comm.size
     if P == 1:
-        ops.put(block, gidx, off, vals, delta)
-        return
-    g, v, bounds = _route(comm, ops, gidx, vals, n)
-    gi = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
-    vi = yield from comm.all_to_all_v([v[bounds[d]:bounds[d + 1]] for d in range(P)])
-    ops.put(block, torch.cat(gi), off, torch.cat(vi), delta)
+        gi, vi = gidx, vals
+    else:
+        g, v, bounds = _route(comm, ops, gidx, vals, n)
+        gi = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
+        vi = yield from comm.all_to_all_v([v[bounds[d]:bounds[d + 1]] for d in range(P)])
+        gi, vi = torch.cat(gi), torch.cat(vi)
+    if permutation and delta == -1:
+        ops.put_perm(block, gi, off, vi)
+    else:
+        ops.put(block, gi, off, vi, delta)
 
 
 def dist_take(comm, ops, block, off, gidx, n):
@@ -271,7 +276,7 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
     Bsa, LCP, nact, nunf = ops.rebucket_first(S1, S2, SA, prev, nxt, off, n, shape, base, want_lcp)
     del S1, S2
     ISA = ops.empty_idx(m)
-    yield from dist_put(comm, ops, ISA, off, SA, Bsa, -1, n)
+    yield from dist_put(comm, ops, ISA, off, SA, Bsa, -1, n, permutation=True)
 
     def boundary_ids(ids):
         has = int(ids.numel()) > 0

@@ -17,7 +17,7 @@ class Boundary(C.Structure):
                 ("prev", C.c_uint64 * 3), ("next", C.c_uint64 * 3)]
 
 
-OPS = ["make_keys", "iota", "pair_sort", "pair_bounds", "owners", "take", "put", "add_scalar", "finish_b2",
+OPS = ["make_keys", "iota", "pair_sort", "pair_bounds", "owners", "take", "put", "put_perm", "add_scalar", "finish_b2",
        "last_head", "rebucket_first", "rebucket_refine", "compact", "block_min", "range_min", "rmq_split",
        "rmq_combine", "lcp_apply"]
 OP_EXPORTS = ["psacx_op_char_hist"] + ["psacx_op_%s_%s" % (o, s) for o in OPS for s in ("u32", "u64")]
@@ -55,10 +55,10 @@ class HipOps(object):
         return C.c_void_p(t.data_ptr() if t is not None and t.numel() else (t.data_ptr() if t is not None else 0))
 
     def empty_idx(self, m):
-        return torch.zeros(int(m), dtype=self.tdt, device=self.device)
+        return torch.empty(int(m), dtype=self.tdt, device=self.device)
 
     def empty_like(self, t):
-        return torch.zeros_like(t)
+        return torch.empty_like(t)
 
     def _u(self, x):
         return int(x) & self.mask
@@ -105,10 +105,17 @@ class HipOps(object):
         return t
 
     # -- sorting -------------------------------------------------------------------------
-    def pair_sort(self, K1, K2, V, bits1, bits2):
-        a, b, v = K1.clone(), K2.clone(), V.clone()
-        self._chk(self._f("pair_sort")(self.ctx, self._p(a), self._p(b), self._p(v), int(a.numel()), int(bits1), int(bits2)))
-        return a, b, v
+    def pair_sort(self, K1, K2, V, bits1, bits2, destroy=False):
+        """Stable sort by (K1, K2).  The inputs survive unless destroy=True (several radix passes then
+        ping-pong through them instead of through copies)."""
+        planned = (bits1 + 7) // 8 + (bits2 + 7) // 8
+        if not destroy and planned > 1:
+            K1, K2, V = K1.clone(), K2.clone(), V.clone()
+        a, b, v = self.empty_like(K1), self.empty_like(K2), self.empty_like(V)
+        where = C.c_int32(0)
+        self._chk(self._f("pair_sort")(self.ctx, self._p(K1), self._p(K2), self._p(V), self._p(a), self._p(b), self._p(v),
+                                       int(K1.numel()), int(bits1), int(bits2), C.byref(where)))
+        return (a, b, v) if where.value else (K1, K2, V)
 
     def _bounds(self, S1, S2, q1, q2, use_second):
         nq = len(q1)
@@ -138,6 +145,12 @@ class HipOps(object):
 
     def put(self, block, gidx, off, vals, delta):
         self._chk(self._f("put")(self.ctx, self._p(block), self._p(gidx), int(gidx.numel()), int(off), self._p(vals), int(delta)))
+
+    def put_perm(self, block, gidx, off, vals):
+        """block[gidx - off] = vals - 1 where gidx is a permutation of the block's positions."""
+        s = [self.empty_like(gidx) for _ in range(4)]
+        self._chk(self._f("put_perm")(self.ctx, self._p(block), self._p(gidx), int(gidx.numel()), int(off), self._p(vals),
+                                      *[self._p(x) for x in s]))
 
     def add_scalar(self, t, s):
         out = self.empty_like(t)

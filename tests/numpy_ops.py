@@ -57,7 +57,10 @@ class NumpyOps(object):
         return self.t(k1), self.t(k2)
 
     # -- sorting -------------------------------------------------------------------------
-    def pair_sort(self, K1, K2, V, bits1, bits2):
+    def put_perm(self, block, gidx, off, vals):
+        self.put(block, gidx, off, vals, -1)
+
+    def pair_sort(self, K1, K2, V, bits1, bits2, destroy=False):
         a, b = self.u(K1).astype(np.uint64), self.u(K2).astype(np.uint64)
         m1 = np.uint64((1 << bits1) - 1) if bits1 < 64 else np.uint64(2**64 - 1)
         m2 = np.uint64((1 << bits2) - 1) if bits2 < 64 else np.uint64(2**64 - 1)
