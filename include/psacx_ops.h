@@ -40,6 +40,13 @@ int psacx_op_char_hist(psacx_ctx*, const uint8_t* text, uint64_t n, uint64_t* hi
        records end in (k1,k2,v), 1 if in (a1,a2,av).  The input survives when at most one pass runs */ \
     int psacx_op_pair_sort_##S(psacx_ctx*, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n,        \
                                uint32_t bits1, uint32_t bits2, int32_t* where);                        \
+    /* sample-sort shuffle (the splitter step of mxx::sort, idxsort.hpp:60-62): records are grouped,   \
+       stably, by the number of splitters (k1,k2,rank,index tuples, host arrays, at most 63) that do    \
+       not sort after them; result in (o1,o2,ov), class_start[0..nsplit+1] on the host */              \
+    int psacx_op_split_by_##S(psacx_ctx*, const T* k1, const T* k2, const T* v, uint64_t n,            \
+                              const uint64_t* sk1, const uint64_t* sk2, const uint64_t* srank,         \
+                              const uint64_t* sidx, uint32_t nsplit, uint64_t my_rank, T* o1, T* o2,   \
+                              T* ov, uint64_t* class_start);                                           \
     /* lower / upper bound of each query pair in the sorted (s1,s2); queries and results on the host */ \
     int psacx_op_pair_bounds_##S(psacx_ctx*, const T* s1, const T* s2, uint64_t n, const uint64_t* q1, \
                                  const uint64_t* q2, uint32_t nq, int use_second, uint64_t* lb,        \

@@ -96,6 +96,7 @@ def load():
         "iota": [vp, vp, u64, u64],
         "pair_sort": [vp, vp, vp, vp, vp, vp, vp, u64, u32, u32, C.POINTER(C.c_int32)],
         "put_perm": [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp],
+        "split_by": [vp, vp, vp, vp, u64, u64p, u64p, u64p, u64p, u32, u64, vp, vp, vp, u64p],
         "pair_bounds": [vp, vp, vp, u64, u64p, u64p, u32, i32, u64p, u64p],
         "owners": [vp, vp, u64, u64, u32, vp],
         "take": [vp, vp, vp, u64, u64, u64, vp],

@@ -218,6 +218,40 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t
 }
 
 template <typename T>
+int op_split_by(psacx_ctx* c, const T* k1, const T* k2, const T* v, uint64_t n, const uint64_t* sk1, const uint64_t* sk2,
+                const uint64_t* srank, const uint64_t* sidx, uint32_t nsplit, uint64_t my_rank, T* o1, T* o2, T* ov,
+                uint64_t* class_start) {
+    OP_PROLOGUE(c);
+    if (nsplit > 63) return PSACX_EINVAL;
+    for (uint32_t i = 0; i <= nsplit + 1; ++i) class_start[i] = 0;
+    if (n == 0) return PSACX_OK;
+    PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
+    SortScratch sc;
+    T* cls = nullptr;
+    auto layout = [&](Arena& a) {
+        cls = a.take<T>(n);
+        sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+        sc.desc_bytes = sort_desc_bytes(n);
+        sc.d_desc = a.take<char>(sc.desc_bytes);
+    };
+    { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+    Arena ar(c->slab);
+    layout(ar);
+    Splitters sp;
+    sp.n = nsplit;
+    for (uint32_t i = 0; i < nsplit; ++i) { sp.k1[i] = sk1[i]; sp.k2[i] = sk2[i]; sp.rank[i] = srank[i]; sp.idx[i] = sidx[i]; }
+    hipLaunchKernelGGL((classify_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, k1, k2, n, sp,
+                       (unsigned long long)my_rank, cls);
+    PSACX_HIP(c, hipGetLastError());
+    SortBufs<T> in{const_cast<T*>(k1), const_cast<T*>(k2), const_cast<T*>(v)}, out{o1, o2, ov};
+    unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+    PSACX_TRY(class_partition<T>(c, sc, in, out, cls, n, starts));
+    for (uint32_t i = 0; i <= nsplit; ++i) class_start[i] = starts[i];
+    class_start[nsplit + 1] = n;
+    return PSACX_OK;
+}
+
+template <typename T>
 int op_put_perm(psacx_ctx* c, T* block, const T* gidx, uint64_t cnt, uint64_t off, const T* vals, T* s1, T* s2, T* s3, T* s4) {
     OP_PROLOGUE(c);
     if (cnt == 0) return PSACX_OK;
@@ -462,6 +496,11 @@ int psacx_op_char_hist(psacx_ctx* c, const uint8_t* text, uint64_t n, uint64_t* 
     int psacx_op_pair_sort_##S(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n, uint32_t b1, \
                                uint32_t b2, int32_t* where) {                                                  \
         return op_pair_sort<T>(c, k1, k2, v, a1, a2, av, n, b1, b2, where);                                     \
+    }                                                                                                          \
+    int psacx_op_split_by_##S(psacx_ctx* c, const T* k1, const T* k2, const T* v, uint64_t n, const uint64_t* a, \
+                              const uint64_t* b, const uint64_t* r, const uint64_t* x, uint32_t ns, uint64_t me, \
+                              T* o1, T* o2, T* ov, uint64_t* cs) {                                            \
+        return op_split_by<T>(c, k1, k2, v, n, a, b, r, x, ns, me, o1, o2, ov, cs);                              \
     }                                                                                                          \
     int psacx_op_put_perm_##S(psacx_ctx* c, T* b, const T* g, uint64_t cnt, uint64_t off, const T* v, T* s1,   \
                               T* s2, T* s3, T* s4) {                                                           \

@@ -278,6 +278,31 @@ inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in
 #undef PSACX_P3
 }
 
+// One pass that groups records by an externally supplied 8-bit class (cls[i] < 256), stable.
+// Result in `out`; class_start_host[0..256] receives the start of every class (host array).
+template <typename T>
+int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> out, const T* cls, uint64_t n,
+                    unsigned long long* class_start_host) {
+    constexpr int BLOCK = 512, ITEMS = 12, TILE = BLOCK * ITEMS;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
+    char* scratch = sc.d_desc;
+    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
+    PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+    hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, cls, n, 0, tile_hist);
+    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
+    hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, sc.d_base);
+    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, in.k1, in.k2,
+                       in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot, (unsigned long long*)nullptr, (uint64_t)0,
+                       (uint64_t)0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), cls);
+    PSACX_HIP(c, hipGetLastError());
+    PSACX_HIP(c, hipMemcpyAsync(class_start_host, sc.d_base, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    class_start_host[RADIX] = n;
+    return PSACX_OK;
+}
+
 // folds the per-workgroup key summaries a producer kernel left in sc.d_partials into sc.d_summary
 inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
     hipLaunchKernelGGL(summary_reduce_kernel<0>, dim3(1), dim3(1024), 0, c->stream, sc.d_partials, nblocks, sc.d_summary);

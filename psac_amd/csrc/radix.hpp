@@ -120,14 +120,17 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 // FULL: the tile holds exactly TILE records, so no bounds guards are compiled in.
 // LB: global offsets by decoupled look-back over `desc`; otherwise they were
 // precomputed (tile_excl row of this tile + slab_excl row of its slab).
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB>
+// EXT: the 8-bit class of a record comes from a separate array (dsrc, not moved) instead of a key
+// digit: one such pass partitions records by an externally computed destination.
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
-    const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl) {
+    const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
+    const T* __restrict__ dsrc = nullptr) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     T* const stage = sh.stage;
@@ -150,7 +153,16 @@ __device__ __forceinline__ void radix_scatter_tile(
     const T* __restrict__ pko = ko_in + base;
     const T* __restrict__ pv = v_in ? v_in + base : nullptr;
     T kd[ITEMS], ko[ITEMS], vv[ITEMS];
+    unsigned char cls[EXT ? ITEMS : 1];
     const unsigned wbase = wave * (WAVE * ITEMS) + lane;
+    if (EXT) {
+        const T* __restrict__ pd = dsrc + base;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const unsigned loc = wbase + i * WAVE;
+            cls[EXT ? i : 0] = (FULL || loc < count) ? (unsigned char)pd[loc] : (unsigned char)0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
@@ -182,7 +194,7 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const bool valid = FULL || (wbase + i * WAVE) < count;
-        const unsigned d = (unsigned)(kd[i] >> shift) & (RADIX - 1);
+        const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         const uint64_t m = match_any8(d, valid);
         const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (valid && (m & lt) == 0)
@@ -239,7 +251,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     // final tile-local position of every record; stage the digit word and the digit
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const unsigned d = (unsigned)(kd[i] >> shift) & (RADIX - 1);
+        const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
         if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; sdig[rank[i]] = (uint8_t)d; }
     }
@@ -296,6 +308,31 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
     else
         radix_scatter_tile<T, D, BLOCK, ITEMS, false, true>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out, ko_out,
                                                       v_out, shift, digit_base, desc, err, dbg, spec, spec_n, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// Destination class of every record for a splitter-based shuffle (sample sort): the number of
+// splitters that do not sort after the record in the total order (k1, k2, rank, index).
+struct Splitters { unsigned n; unsigned long long k1[64], k2[64], rank[64], idx[64]; };
+
+template <typename T>
+__global__ void classify_kernel(const T* __restrict__ k1, const T* __restrict__ k2, uint64_t n, Splitters sp,
+                                unsigned long long my_rank, T* __restrict__ cls) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long a = k1[i], b = k2[i];
+        unsigned lo = 0, hi = sp.n;                       // first splitter that sorts after the record
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            bool after;                                    // splitter[mid] > record ?
+            if (sp.k1[mid] != a) after = sp.k1[mid] > a;
+            else if (sp.k2[mid] != b) after = sp.k2[mid] > b;
+            else if (sp.rank[mid] != my_rank) after = sp.rank[mid] > my_rank;
+            else after = sp.idx[mid] > i;
+            if (after) hi = mid; else lo = mid + 1;
+        }
+        cls[i] = (T)lo;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -373,13 +410,13 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false>
 __global__ __launch_bounds__(BLOCK) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
-    uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk) {
+    uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
@@ -392,13 +429,13 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter3_kernel(
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
-                                                                   ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                   spec, spec_n, tile_excl, slab_excl);
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+                                                                        ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
+                                                                        spec, spec_n, tile_excl, slab_excl, dsrc);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
-                                                                    ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                    spec, spec_n, tile_excl, slab_excl);
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
+                                                                         spec, spec_n, tile_excl, slab_excl, dsrc);
 }
 
 } // namespace psacx

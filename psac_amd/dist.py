@@ -79,42 +79,27 @@ def bits_for(v):
 def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
     """Globally sorts records by (K1, K2); rank r ends with exactly targets[r] records, the
     concatenation over ranks being sorted (the contract psac needs from mxx::sort,
-    idxsort.hpp:67-79)."""
+    idxsort.hpp:67-79).  Sample sort: sampled splitters -> one partition pass by destination ->
+    all-to-all -> one local radix sort -> exact re-balance to the target sizes."""
     P, r = comm.size, comm.rank
-    S1, S2, SV = ops.pair_sort(K1, K2, V, bits1, bits2, destroy=True)
     if P == 1:
-        return S1, S2, SV
-    c = int(S1.numel())
-    # regular samples of the locally sorted records, made unique by (rank, index)
-    pos = [(c * (2 * i + 1)) // (2 * SAMPLES_PER_RANK) for i in range(SAMPLES_PER_RANK)] if c else []
-    pos = sorted(set(pos))
-    keys = ops.sample(S1, S2, pos)
+        return ops.pair_sort(K1, K2, V, bits1, bits2, destroy=True)
+    c = int(K1.numel())
+    # regular samples of the local records, made unique by (rank, index) so that ties are divided
+    pos = sorted(set((c * (2 * i + 1)) // (2 * SAMPLES_PER_RANK) for i in range(SAMPLES_PER_RANK))) if c else []
+    keys = ops.sample(K1, K2, pos)
     mine = [(k1, k2, r, p) for (k1, k2), p in zip(keys, pos)]
     allsamp = yield from comm.all_gather_obj(mine)
     flat = sorted(s for lst in allsamp for s in lst)
-    splitters = []
-    for d in range(1, P):
-        if flat:
-            splitters.append(flat[min(len(flat) - 1, (len(flat) * d) // P)])
-    # boundaries: records equal to a splitter key are divided by the splitter's (rank, index)
-    bounds = [0]
-    if splitters:
-        lb, ub = ops.pair_bounds(S1, S2, [s[0] for s in splitters], [s[1] for s in splitters])
-        for s, lo, hi in zip(splitters, lb, ub):
-            if r < s[2]:
-                b = hi
-            elif r > s[2]:
-                b = lo
-            else:
-                b = min(max(s[3], lo), hi)
-            bounds.append(max(b, bounds[-1]))
-    while len(bounds) < P:
-        bounds.append(bounds[-1])
-    bounds.append(c)
+    splitters = [flat[min(len(flat) - 1, (len(flat) * d) // P)] for d in range(1, P)] if flat else []
+    splitters = sorted(set(splitters))
+    G1, G2, GV, bounds = ops.split_by(K1, K2, V, splitters, r)
+    bounds = list(bounds[:len(splitters) + 1]) + [c] * (P + 1 - (len(splitters) + 1))   # empty trailing groups
     parts = []
-    for arr in (S1, S2, SV):
+    for arr in (G1, G2, GV):
         got = yield from comm.all_to_all_v([arr[bounds[d]:bounds[d + 1]] for d in range(P)])
         parts.append(torch.cat(got) if got else arr[:0])
+    del G1, G2, GV
     R1, R2, RV = ops.pair_sort(parts[0], parts[1], parts[2], bits1, bits2, destroy=True)
     # exact re-balance: global index of my j-th record is G[r] + j
     c2 = int(R1.numel())

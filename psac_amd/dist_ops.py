@@ -17,7 +17,7 @@ class Boundary(C.Structure):
                 ("prev", C.c_uint64 * 3), ("next", C.c_uint64 * 3)]
 
 
-OPS = ["make_keys", "iota", "pair_sort", "pair_bounds", "owners", "take", "put", "put_perm", "add_scalar", "finish_b2",
+OPS = ["make_keys", "iota", "pair_sort", "split_by", "pair_bounds", "owners", "take", "put", "put_perm", "add_scalar", "finish_b2",
        "last_head", "rebucket_first", "rebucket_refine", "compact", "block_min", "range_min", "rmq_split",
        "rmq_combine", "lcp_apply"]
 OP_EXPORTS = ["psacx_op_char_hist"] + ["psacx_op_%s_%s" % (o, s) for o in OPS for s in ("u32", "u64")]
@@ -116,6 +116,17 @@ class HipOps(object):
         self._chk(self._f("pair_sort")(self.ctx, self._p(K1), self._p(K2), self._p(V), self._p(a), self._p(b), self._p(v),
                                        int(K1.numel()), int(bits1), int(bits2), C.byref(where)))
         return (a, b, v) if where.value else (K1, K2, V)
+
+    def split_by(self, K1, K2, V, splitters, my_rank):
+        """Groups the records by destination rank (see psacx_op_split_by); returns the three grouped arrays
+        and the list of group boundaries (len(splitters) + 2 entries)."""
+        ns = len(splitters)
+        cols = [(C.c_uint64 * max(ns, 1))(*[int(s[i]) for s in splitters]) for i in range(4)]
+        o1, o2, ov = self.empty_like(K1), self.empty_like(K2), self.empty_like(V)
+        cs = (C.c_uint64 * (ns + 2))()
+        self._chk(self._f("split_by")(self.ctx, self._p(K1), self._p(K2), self._p(V), int(K1.numel()), cols[0], cols[1], cols[2],
+                                      cols[3], ns, int(my_rank), self._p(o1), self._p(o2), self._p(ov), cs))
+        return o1, o2, ov, list(cs)
 
     def _bounds(self, S1, S2, q1, q2, use_second):
         nq = len(q1)

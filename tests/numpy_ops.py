@@ -67,6 +67,15 @@ class NumpyOps(object):
         order = np.lexsort((b & m2, a & m1))            # stable
         return self.t(self.u(K1)[order]), self.t(self.u(K2)[order]), self.t(self.u(V)[order])
 
+    def split_by(self, K1, K2, V, splitters, my_rank):
+        import bisect
+        a, b = self.u(K1).tolist(), self.u(K2).tolist()
+        sp = [tuple(int(x) for x in s) for s in splitters]
+        cls = np.array([bisect.bisect_right(sp, (a[i], b[i], my_rank, i)) for i in range(len(a))], np.int64)
+        order = np.argsort(cls, kind="stable")
+        starts = [int(np.searchsorted(cls[order], d, side="left")) for d in range(len(sp) + 1)] + [len(a)]
+        return self.t(self.u(K1)[order]), self.t(self.u(K2)[order]), self.t(self.u(V)[order]), starts
+
     def sample(self, S1, S2, positions):
         a, b = self.u(S1), self.u(S2)
         return [(int(a[p]), int(b[p])) for p in positions]
