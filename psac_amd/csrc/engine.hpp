@@ -203,7 +203,7 @@ inline int sort_cfg_env() {
 struct ScatterShape { int block, items; };
 // scatter configurations selectable with PSACX_SORT_CFG (tuning aid)
 static const ScatterShape kShapes[] = {{256, 8}, {256, 16}, {512, 8}, {512, 16}, {256, 12}, {1024, 4}, {1024, 8}, {512, 12}};
-constexpr int N_SHAPES = 8;
+constexpr int N_SHAPES = 8;   // (register caps through __launch_bounds__ were measured: spills cost 1.6-3x)
 
 inline uint64_t cfg_tile(int cfg) {
     if (cfg < 0 || cfg >= N_SHAPES) cfg = 1;
@@ -236,7 +236,7 @@ inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three k
     return v;
 }
 
-template <typename T, int BLOCK, int ITEMS>
+template <typename T, int BLOCK, int ITEMS, int MINW = 1>
 inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
                          uint64_t n, int shift, const unsigned long long* base, char* scratch,
                          unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
@@ -254,9 +254,9 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
                            const_cast<unsigned long long*>(base));
     }
     ProfScope ps(c, TC_SORT_SCATTER3);
-    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                        ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                       getenv("PSACX_SORT_STATIC") ? (unsigned*)nullptr : reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true));
+                       reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
 }
 
 template <typename T>
@@ -293,9 +293,10 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
     hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, cls, n, 0, tile_hist);
     hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, sc.d_base);
-    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, in.k1, in.k2,
-                       in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot, (unsigned long long*)nullptr, (uint64_t)0,
-                       (uint64_t)0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), cls);
+    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
+                       c->stream, in.k1, in.k2, in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot,
+                       (unsigned long long*)nullptr, (uint64_t)0, (uint64_t)0, reinterpret_cast<unsigned*>(scratch),
+                       sort_chunk_for(n, true), cls);
     PSACX_HIP(c, hipGetLastError());
     PSACX_HIP(c, hipMemcpyAsync(class_start_host, sc.d_base, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
