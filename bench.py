@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--index", type=int, default=32, choices=(32, 64))
     ap.add_argument("--alphabet", default="dna", choices=("dna", "ascii128", "tandem"))
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="characters for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 27, help="characters for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-lcp", action="store_true")
     return ap.parse_args()
 

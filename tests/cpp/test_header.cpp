@@ -1,0 +1,71 @@
+// Exercises include/suffix_array.hpp the way the reference's tests use its class
+// (test/test_psac.cpp: Mississippi :105, IntAlphabetMiss :277-304, FileIO :306-347).
+// Built and run by tests/test_gpu_parity.py::test_cpp_header_program on the GPU box.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/suffix_array.hpp"
+
+#define CHECK(x) do { if (!(x)) { std::cerr << "FAILED: " #x " at line " << __LINE__ << std::endl; return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    const std::vector<uint32_t> exp = {10, 7, 4, 1, 0, 9, 8, 6, 3, 5, 2};
+    {
+        std::string s = "mississippi";
+        suffix_array<char, uint32_t, false> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct(s.begin(), s.end());
+        CHECK(sa.local_SA == exp);
+        CHECK(sa.n == 11 && sa.local_size == 11 && sa.p == 1);
+        CHECK(sa.alpha.sigma() == 4 && sa.alpha.bits_per_char() == 3);
+        CHECK(sa.local_LCP.empty());
+        // repeated construct on the same object (test/test_psac.cpp:148-170)
+        sa.construct(s.begin(), s.end(), true, 3);
+        CHECK(sa.local_SA == exp);
+        sa.construct(s.begin(), s.end(), false, 2);
+        CHECK(sa.local_SA == exp);
+    }
+    {
+        // int alphabet: i = 3, m = 128, p = 66000, s = 12345678
+        std::vector<int> v = {128, 3, 12345678, 12345678, 3, 12345678, 12345678, 3, 66000, 66000, 3};
+        suffix_array<int, unsigned int, true> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct(v.begin(), v.end());
+        CHECK(sa.local_SA == exp);
+        const std::vector<unsigned int> lcp = {0, 1, 1, 4, 0, 0, 1, 0, 2, 1, 3};
+        CHECK(sa.local_LCP == lcp);
+    }
+    {
+        // write / read round trip (suffix_array.hpp:232-265): raw little-endian arrays
+        std::string s;
+        srand(7);
+        for (int i = 0; i < 50000; ++i) s.push_back("ACGT"[rand() % 4]);
+        suffix_array<char, uint64_t, true> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct(s.begin(), s.end());
+        sa.write(tmp + "/psacx_fileio");
+        suffix_array<char, uint64_t, true> sb((psacx::comm(0)));
+        sb.read(tmp + "/psacx_fileio");
+        CHECK(sb.local_SA == sa.local_SA);
+        CHECK(sb.local_LCP == sa.local_LCP);
+        CHECK(sb.n == 50000);
+        FILE* f = fopen((tmp + "/psacx_fileio.alpha").c_str(), "rb");
+        CHECK(f != nullptr);
+        char buf[8]; size_t got = fread(buf, 1, 8, f); fclose(f);
+        CHECK(got == 4 && std::string(buf, 4) == "ACGT");
+    }
+    {
+        // errors surface as std::runtime_error (suffix_array.hpp:226-227)
+        std::string empty;
+        suffix_array<char, uint32_t, true> sa((psacx::comm(0)));
+        bool threw = false;
+        try { sa.construct(empty.begin(), empty.end()); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    }
+    std::cout << "cpp header tests passed" << std::endl;
+    return 0;
+}

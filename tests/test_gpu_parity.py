@@ -346,3 +346,17 @@ def test_reduced_memory_layout(ctx, monkeypatch):
     import psac_amd
     with pytest.raises(psac_amd.PsacxError):
         run(ctx, inputs.tandem(100000, 64, O.rand_dna(64, 1)), bits=32)
+
+
+def test_cpp_header_program(ctx, tmp_path):
+    # include/suffix_array.hpp used from C++11 like the reference's class (tests/cpp/test_header.cpp)
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "test_header")
+    lib = os.path.join(root, "psac_amd", "lib")
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-o", exe, os.path.join(HERE, "cpp", "test_header.cpp"),
+           "-L" + lib, "-lpsacx", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "cpp header tests passed" in r.stdout, r.stdout + r.stderr
