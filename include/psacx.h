@@ -152,6 +152,16 @@ int psacx_ansv_u32(psacx_ctx* ctx, const uint32_t* in, uint64_t n, int left_type
 int psacx_ansv_u64(psacx_ctx* ctx, const uint64_t* in, uint64_t n, int left_type, int right_type,
                    uint64_t nonsv, uint64_t* left_nsv, uint64_t* right_nsv);
 
+/* suffix tree topology -------------------------------------------------------
+ * Replaces construct_suffix_tree(sa, begin, end, comm) (suffix_tree.hpp:413-499, parents by
+ * for_each_parent :43-223) at one rank.  nodes: n x (sigma + 1) table, row i = internal node of LCP
+ * index i, cell c = child through the character with alphabet code c (0 = end of text), leaves are
+ * n + i, 0 = no child.  Host pointers.  Call with nodes == NULL first to learn sigma. */
+int psacx_suffix_tree_u32(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const uint32_t* SA,
+                          const uint32_t* LCP, uint64_t* nodes, uint32_t* sigma);
+int psacx_suffix_tree_u64(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const uint64_t* SA,
+                          const uint64_t* LCP, uint64_t* nodes, uint32_t* sigma);
+
 /* device memory helpers for hosts without their own HIP bindings ------------ */
 int psacx_dev_alloc(psacx_ctx* ctx, void** out, uint64_t bytes);
 int psacx_dev_free(psacx_ctx* ctx, void* p);

@@ -219,4 +219,31 @@ private:
     }
 };
 
+// construct_suffix_tree(sa, begin, end, comm) of /root/reference/include/suffix_tree.hpp:413-438:
+// the (sigma + 1) * n node table (row i = internal node of LCP index i, cell c = child through the
+// character with alphabet code c, leaves are n + i, 0 = none).  The text must be bytes.
+template <typename Iterator, typename index_t>
+std::vector<std::size_t> construct_suffix_tree(suffix_array<char, index_t, true>& sa, Iterator str_begin, Iterator str_end,
+                                               const psacx::comm&) {
+    static_assert(sizeof(std::size_t) == 8, "size_t must be 64 bit");
+    std::vector<uint8_t> text(str_begin, str_end);
+    if (text.size() != sa.n) throw std::runtime_error("construct_suffix_tree: text does not match the suffix array");
+    uint32_t sigma = 0;
+    typedef typename std::conditional<sizeof(index_t) == 4, uint32_t, uint64_t>::type W;
+    const W* p_sa = reinterpret_cast<const W*>(sa.local_SA.data());
+    const W* p_lcp = reinterpret_cast<const W*>(sa.local_LCP.data());
+    struct Call {
+        static int run(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32_t* a, const uint32_t* l, uint64_t* o, uint32_t* s) {
+            return psacx_suffix_tree_u32(c, t, n, a, l, o, s);
+        }
+        static int run(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* a, const uint64_t* l, uint64_t* o, uint32_t* s) {
+            return psacx_suffix_tree_u64(c, t, n, a, l, o, s);
+        }
+    };
+    psacx::check(sa.context(), Call::run(sa.context(), text.data(), sa.n, (const W*)nullptr, (const W*)nullptr, nullptr, &sigma));
+    std::vector<std::size_t> nodes((std::size_t)(sigma + 1) * sa.n, 0);
+    psacx::check(sa.context(), Call::run(sa.context(), text.data(), sa.n, p_sa, p_lcp, reinterpret_cast<uint64_t*>(nodes.data()), &sigma));
+    return nodes;
+}
+
 #endif // PSACX_SUFFIX_ARRAY_HPP

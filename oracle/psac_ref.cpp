@@ -455,6 +455,58 @@ void ansv_typed(const T* in, uint64_t n, int left, int type, uint64_t nonsv, uin
     }
 }
 
+// include/suffix_tree.hpp:43-223 (for_each_parent) and :440-499 (construct_suffix_tree) at p = 1:
+// one table row of sigma+1 cells per LCP index (= internal node), cell c holding the child
+// reached through the character with alphabet code c (0 = end of text); leaves are n + i.
+template <typename T>
+void suffix_tree_nodes(const uint8_t* s, uint64_t n, const T* SA, const T* LCP, uint64_t* nodes /* n*(sigma+1), zeroed */,
+                       uint32_t* sigma_out) {
+    Alpha a = make_alpha(s, n);
+    const uint64_t row = (uint64_t)a.sigma + 1;
+    *sigma_out = a.sigma;
+    const uint64_t NONE = ~0ull;
+    std::vector<uint64_t> L(n), R(n);
+    ansv_typed<T>(LCP, n, 1, 2, NONE, L.data());     // left: furthest_eq  (suffix_tree.hpp:62)
+    ansv_typed<T>(LCP, n, 0, 0, NONE, R.data());     // right: nearest_sm
+    auto add = [&](uint64_t parent, uint64_t gidx, uint64_t sa_val, uint64_t lcp_val) {
+        const uint64_t ci = sa_val + lcp_val;                       // suffix_tree.hpp:461-468
+        const uint64_t c = ci < n ? a.code[s[ci]] : 0;
+        nodes[parent * row + c] = gidx;
+    };
+    // leaves (suffix_tree.hpp:72-143)
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t parent, lcp_val;
+        if (i == 0) {
+            lcp_val = n > 1 ? (uint64_t)LCP[1] : 0;
+            parent = lcp_val > 0 ? 1 : 0;
+        } else if (i == n - 1 || LCP[i] >= LCP[i + 1]) {
+            const uint64_t nsv = L[i];
+            lcp_val = nsv != NONE ? (uint64_t)LCP[nsv] : 0;
+            if (nsv != NONE && lcp_val == (uint64_t)LCP[i]) parent = nsv;
+            else { parent = i; lcp_val = LCP[i]; }
+        } else {
+            parent = i + 1; lcp_val = LCP[i + 1];
+        }
+        add(parent, n + i, SA[i], lcp_val);
+    }
+    // internal nodes (suffix_tree.hpp:146-222)
+    for (uint64_t i = 1; i < n; ++i) {
+        if (LCP[i] == 0) continue;
+        uint64_t parent, lcp_val;
+        const uint64_t ln = L[i], rn = R[i];
+        const uint64_t lv = LCP[ln];                                // exists: LCP[0] = 0
+        if (rn == NONE) {
+            if (lv == (uint64_t)LCP[i]) continue;
+            parent = ln; lcp_val = lv;
+        } else {
+            const uint64_t rv = LCP[rn];
+            if (lv >= rv) { if (lv == (uint64_t)LCP[i]) continue; parent = ln; lcp_val = lv; }
+            else { parent = rn; lcp_val = rv; }
+        }
+        add(parent, i, SA[i], lcp_val);
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ C ABI
@@ -516,6 +568,10 @@ struct psac_ref_trace { uint64_t h, unfinished_buckets, unfinished_elements; uin
                              uint64_t* out) {                                                      \
         ansv_typed<T>(in, n, left, type, nonsv, out);                                              \
     }                                                                                              \
+    void psac_ref_suffix_tree_##SUF(const uint8_t* text, uint64_t n, const T* SA, const T* LCP,       \
+                                    uint64_t* nodes, uint32_t* sigma) {                                \
+        suffix_tree_nodes<T>(text, n, SA, LCP, nodes, sigma);                                          \
+    }                                                                                                  \
     T psac_ref_range_min_##SUF(const T* v, uint64_t n, uint64_t l, uint64_t r) {                   \
         RangeMin<T> rm(v, n);                                                                      \
         return rm.query(l, r);                                                                     \

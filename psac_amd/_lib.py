@@ -20,7 +20,7 @@ EXPORTS = [
     "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim",
     "psacx_construct_u32", "psacx_construct_u64", "psacx_construct_dev_u32", "psacx_construct_dev_u64",
     "psacx_get_stats", "psacx_profile", "psacx_check_dev_u32", "psacx_check_dev_u64", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
-    "psacx_ansv_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
+    "psacx_ansv_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
 ]
 
 
@@ -80,6 +80,8 @@ def load():
         getattr(lib, "psacx_ansv_" + suf).argtypes = [vp, vp, u64, i32, i32, u64, vp, vp]
     lib.psacx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.psacx_profile.argtypes = [vp, i32]
+    lib.psacx_suffix_tree_u32.argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(C.c_uint32)]
+    lib.psacx_suffix_tree_u64.argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(C.c_uint32)]
     lib.psacx_check_dev_u32.argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.psacx_check_dev_u64.argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.psacx_dev_alloc.argtypes = [vp, C.POINTER(vp), u64]

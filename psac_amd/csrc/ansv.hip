@@ -121,6 +121,101 @@ int ansv_host(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t no
     return PSACX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Suffix-tree node table (/root/reference/include/suffix_tree.hpp:43-223 for_each_parent and
+// :440-499 construct_suffix_tree, one rank): one row of sigma + 1 cells per LCP index (= internal
+// node); cell c holds the child reached through the character with alphabet code c (0 = end of
+// text).  Leaves are numbered n + i.  Parents come from the ANSV of LCP: left = furthest_eq,
+// right = nearest_sm (suffix_tree.hpp:62).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void st_nodes_kernel(Pyramid<T> P, uint64_t n, const T* __restrict__ SA, const uint8_t* __restrict__ text,
+                                CodeTable tab, uint64_t row, unsigned long long* __restrict__ nodes) {
+    const T* __restrict__ LCP = P.lvl[0];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t sa = SA[i];
+        const uint64_t li = LCP[i];
+        // ---- the leaf n + i (suffix_tree.hpp:72-143)
+        uint64_t parent, lcp_val;
+        const uint64_t ln = i ? nsv_typed<T, true>(P, n, i, 2) : NSV_NONE;
+        if (i == 0) {
+            lcp_val = n > 1 ? (uint64_t)LCP[1] : 0;
+            parent = lcp_val > 0 ? 1 : 0;
+        } else if (i == n - 1 || li >= (uint64_t)LCP[i + 1]) {
+            lcp_val = ln != NSV_NONE ? (uint64_t)LCP[ln] : 0;
+            if (ln != NSV_NONE && lcp_val == li) parent = ln;
+            else { parent = i; lcp_val = li; }
+        } else {
+            parent = i + 1; lcp_val = LCP[i + 1];
+        }
+        uint64_t ci = sa + lcp_val;
+        nodes[parent * row + (ci < n ? tab.c[text[ci]] : 0)] = n + i;
+        // ---- the internal node i (suffix_tree.hpp:146-222)
+        if (i == 0 || li == 0) continue;
+        const uint64_t rn = nsv_typed<T, false>(P, n, i, 0);
+        const uint64_t lv = LCP[ln];                  // exists because LCP[0] = 0
+        if (rn == NSV_NONE) {
+            if (lv == li) continue;                   // duplicate of the node further left
+            parent = ln; lcp_val = lv;
+        } else {
+            const uint64_t rv = LCP[rn];
+            if (lv >= rv) { if (lv == li) continue; parent = ln; lcp_val = lv; }
+            else { parent = rn; lcp_val = rv; }
+        }
+        ci = sa + lcp_val;
+        nodes[parent * row + (ci < n ? tab.c[text[ci]] : 0)] = i;
+    }
+}
+
+template <typename T>
+int suffix_tree_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa, const T* lcp, uint64_t* nodes, uint32_t* sigma) {
+    if (!c || !text || !sigma || n == 0) return PSACX_EINVAL;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    // alphabet on the host (alphabet.hpp:147-164): codes 1..sigma in byte order
+    bool used[256] = {false};
+    for (uint64_t i = 0; i < n; ++i) used[text[i]] = true;
+    CodeTable tab;
+    uint16_t next = 1;
+    for (int ch = 0; ch < 256; ++ch) tab.c[ch] = used[ch] ? next++ : (uint16_t)0;
+    *sigma = next - 1u;
+    if (!nodes) return PSACX_OK;                      // size query
+    if (!sa || !lcp) return PSACX_EINVAL;
+    const uint64_t row = (uint64_t)*sigma + 1;
+    Pyramid<T> P;
+    T* d_lcp = nullptr; T* d_sa = nullptr; uint8_t* d_text = nullptr; unsigned long long* d_nodes = nullptr;
+    auto layout = [&](Arena& a) {
+        d_lcp = a.take<T>(n); d_sa = a.take<T>(n); d_text = a.take<uint8_t>(n); d_nodes = a.take<unsigned long long>(n * row);
+        P.lvl[0] = d_lcp; P.len[0] = n; P.nlev = 1;
+        uint64_t len = n;
+        while (len > 64 && P.nlev < PYR_MAX) { len = (len + 63) / 64; P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len; P.nlev++; }
+    };
+    { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+    Arena ar(c->slab);
+    layout(ar);
+    PSACX_HIP(c, hipMemcpyAsync(d_lcp, lcp, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    PSACX_HIP(c, hipMemcpyAsync(d_sa, sa, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    PSACX_HIP(c, hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream));
+    PSACX_HIP(c, hipMemsetAsync(d_nodes, 0, n * row * sizeof(unsigned long long), c->stream));
+    for (int L = 1; L < P.nlev; ++L) {
+        hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
+                           P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL((st_nodes_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, P, n, d_sa, d_text, tab, row, d_nodes);
+    PSACX_HIP(c, hipGetLastError());
+    PSACX_HIP(c, hipMemcpyAsync(nodes, d_nodes, n * row * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+
+int suffix_tree_host_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32_t* sa, const uint32_t* lcp, uint64_t* nodes, uint32_t* sg) {
+    return suffix_tree_host<uint32_t>(c, t, n, sa, lcp, nodes, sg);
+}
+int suffix_tree_host_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* sa, const uint64_t* lcp, uint64_t* nodes, uint32_t* sg) {
+    return suffix_tree_host<uint64_t>(c, t, n, sa, lcp, nodes, sg);
+}
+
 int ansv_host_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
     return ansv_host<uint32_t>(c, in, n, lt, rt, nonsv, l, r);
 }

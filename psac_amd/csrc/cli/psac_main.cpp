@@ -40,6 +40,22 @@ template <typename T> static void write_u64(const std::string& fn, const std::ve
     if (!f) { std::cerr << "error: cannot write " << fn << std::endl; exit(EXIT_FAILURE); }
 }
 
+// src/psac.cpp:96-114: SA + LCP, then the suffix-tree node table (ANSV over LCP inside)
+template <typename IT>
+static void tree_step(suffix_array<char, IT, true>& sa, const std::string& str, const std::string& out, int device, double ms) {
+    auto t1 = std::chrono::steady_clock::now();
+    std::vector<std::size_t> nodes = construct_suffix_tree(sa, str.begin(), str.end(), psacx::comm(device));
+    double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    std::size_t edges = 0;
+    for (std::size_t i = 0; i < nodes.size(); ++i) edges += nodes[i] != 0;
+    std::cerr << "ST time: " << ms2 << " ms" << std::endl;
+    std::cerr << "Total  : " << ms + ms2 << " ms" << std::endl;
+    std::cerr << "ST edges: " << edges << std::endl;
+    if (!out.empty()) std::cerr << "Error, output of ST not supported" << std::endl;
+}
+template <typename IT>
+static void tree_step(suffix_array<char, IT, false>&, const std::string&, const std::string&, int, double) {}
+
 template <typename IT, bool LCP>
 static int run(const std::string& str, const std::string& out, bool check, int device, bool tree) {
     suffix_array<char, IT, LCP> sa((psacx::comm(device)));
@@ -47,19 +63,7 @@ static int run(const std::string& str, const std::string& out, bool check, int d
     sa.construct(str.begin(), str.end(), true);
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << (tree ? "SA time: " : "PSAC time: ") << ms << " ms" << std::endl;
-    if (tree) {
-        // src/psac.cpp:96-114: the tree needs the nearest-smaller-value arrays of LCP
-        std::vector<uint64_t> l(sa.n), r(sa.n);
-        auto t1 = std::chrono::steady_clock::now();
-        int rc = sizeof(IT) == 4
-            ? psacx_ansv_u32(sa.context(), reinterpret_cast<const uint32_t*>(sa.local_LCP.data()), sa.n, 2, 0, ~0ull, l.data(), r.data())
-            : psacx_ansv_u64(sa.context(), reinterpret_cast<const uint64_t*>(sa.local_LCP.data()), sa.n, 2, 0, ~0ull, l.data(), r.data());
-        psacx::check(sa.context(), rc);
-        double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-        std::cerr << "ANSV time: " << ms2 << " ms" << std::endl;
-        std::cerr << "Total  : " << ms + ms2 << " ms" << std::endl;
-        if (!out.empty()) std::cerr << "Error, output of ST not supported" << std::endl;
-    }
+    if (tree) tree_step(sa, str, out, device, ms);
     if (check) {
         bool ok = psacx_cli::check_SA(str, sa.local_SA, sa.local_B);
         if (ok && LCP) ok = psacx_cli::check_lcp(str, sa.local_SA, sa.local_B, sa.local_LCP);

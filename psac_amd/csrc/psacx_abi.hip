@@ -10,6 +10,8 @@ int pair_sort_dev_u32(psacx_ctx*, uint32_t*, uint32_t*, uint32_t*, uint64_t, uin
 int pair_sort_dev_u64(psacx_ctx*, uint64_t*, uint64_t*, uint64_t*, uint64_t, uint32_t);
 int check_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int check_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*);
+int suffix_tree_host_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, const uint32_t*, uint64_t*, uint32_t*);
+int suffix_tree_host_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t*, uint32_t*);
 int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 int ansv_host_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 }
@@ -119,6 +121,13 @@ int psacx_ansv_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt,
 }
 int psacx_ansv_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
     return ansv_host_u64(c, in, n, lt, rt, nonsv, l, r);
+}
+
+int psacx_suffix_tree_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32_t* sa, const uint32_t* lcp, uint64_t* nodes, uint32_t* sg) {
+    return suffix_tree_host_u32(c, t, n, sa, lcp, nodes, sg);
+}
+int psacx_suffix_tree_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* sa, const uint64_t* lcp, uint64_t* nodes, uint32_t* sg) {
+    return suffix_tree_host_u64(c, t, n, sa, lcp, nodes, sg);
 }
 
 int psacx_dev_alloc(psacx_ctx* c, void** out, uint64_t bytes) {

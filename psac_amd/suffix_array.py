@@ -145,6 +145,22 @@ class SuffixArray(object):
         return self._after()
 
 
+def suffix_tree(text, SA, LCP, ctx=None):
+    """construct_suffix_tree(sa, begin, end, comm) (suffix_tree.hpp:413-499) at one rank: the
+    n x (sigma + 1) node table (see psacx_suffix_tree_* in include/psacx.h)."""
+    if isinstance(text, str):
+        text = text.encode("latin-1")
+    t = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+    sa, lcp = np.ascontiguousarray(SA), np.ascontiguousarray(LCP)
+    ctx = ctx if ctx is not None else Context(0)
+    fn = getattr(ctx._lib, "psacx_suffix_tree_u%d" % (sa.dtype.itemsize * 8))
+    sigma = C.c_uint32(0)
+    ctx.check(fn(ctx.handle, _ptr(t), t.size, None, None, None, C.byref(sigma)))
+    nodes = np.zeros(t.size * (sigma.value + 1), np.uint64)
+    ctx.check(fn(ctx.handle, _ptr(t), t.size, _ptr(sa), _ptr(lcp), _ptr(nodes), C.byref(sigma)))
+    return nodes.reshape(t.size, sigma.value + 1)
+
+
 def check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, index_bits):
     """check_SA / check_lcp on buffers resident in HBM (check_suffix_array.hpp:56-126).  Returns the four
     error counters of psacx_check_dev_*; all zero means correct."""

@@ -59,6 +59,18 @@ int main(int argc, char** argv) {
         CHECK(got == 4 && std::string(buf, 4) == "ACGT");
     }
     {
+        // suffix tree node table (test/test_suffixtree.cpp:68-83)
+        std::string s = "mississippi";
+        suffix_array<char, uint64_t, true> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct(s.begin(), s.end());
+        std::vector<std::size_t> nodes = construct_suffix_tree(sa, s.begin(), s.end(), psacx::comm(0));
+        const std::vector<std::size_t> solution = {0, 1, 15, 6, 9, 11, 0, 0, 12, 3, 0, 0, 0, 0, 0, 0, 0, 0, 13, 14, 0, 0, 0, 0, 0,
+                                                   0, 0, 0, 0, 0, 0, 16, 0, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 18, 19, 0, 8, 0, 0, 10,
+                                                   0, 0, 0, 20, 21};
+        CHECK(nodes == solution);
+    }
+    {
         // errors surface as std::runtime_error (suffix_array.hpp:226-227)
         std::string empty;
         suffix_array<char, uint32_t, true> sa((psacx::comm(0)));

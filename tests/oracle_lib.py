@@ -174,6 +174,18 @@ def ansv_seq(values, left, nonsv):
     return out
 
 
+def suffix_tree(text, SA, LCP):
+    """construct_suffix_tree at p=1 (suffix_tree.hpp:440-499): (n x (sigma+1)) node table."""
+    t = as_text(text)
+    bits = SA.dtype.itemsize * 8
+    code, sigma, _ = alphabet(t)
+    nodes = np.zeros(t.size * (sigma + 1), np.uint64)
+    sg = C.c_uint32(0)
+    getattr(lib(), "psac_ref_suffix_tree_u%d" % bits)(_p(t), C.c_uint64(t.size), _p(np.ascontiguousarray(SA)),
+                                                      _p(np.ascontiguousarray(LCP)), _p(nodes), C.byref(sg))
+    return nodes.reshape(t.size, sigma + 1)
+
+
 def range_min(values, l, r):
     v = np.ascontiguousarray(values)
     bits = v.dtype.itemsize * 8

@@ -41,7 +41,7 @@ def test_header_symbols_are_exported():
     from psac_amd import _lib
     lib = _lib.load()
     syms = declared_symbols()
-    assert len(syms) >= 22
+    assert len(syms) >= 24
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.EXPORTS) == syms

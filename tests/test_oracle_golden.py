@@ -172,3 +172,11 @@ def test_ansv_definitions():
                             e_fe = j
                         j += step
                 assert fe[i] == e_fe
+
+
+def test_suffix_tree_mississippi_table():
+    # test/test_suffixtree.cpp:68-83
+    m = KAT["mississippi"]
+    r = O.construct(m["text"], bits=64)
+    nodes = O.suffix_tree(m["text"], r["SA"], r["LCP"])
+    assert nodes.reshape(-1).tolist() == m["suffix_tree_nodes"]
