@@ -112,6 +112,22 @@ int psacx_construct_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, u
 int psacx_construct_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k,
                             uint32_t flags, uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP);
 
+/* suffix_array<char_t, index_t, true, true>::construct (suffix_array.hpp:170, :469-486): SA, ISA
+ * and LCP as above (PSACX_LCP is implied) plus the left-branching characters local_Lc
+ * (suffix_array.hpp:211-212; built at :1365-1383 and par_rmq.hpp:334-481; consumed by
+ * desa.hpp:408, tldt.hpp:437):
+ *   Lc    out, n bytes: Lc[i] = text[SA[i-1] + LCP[i]], 0 when that position is past the end
+ *         (alphabet.hpp:168 decodes the end marker to '\0') and for i = 0.
+ */
+int psacx_construct_lc_u32(psacx_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags,
+                           uint32_t* SA, uint32_t* ISA, uint32_t* LCP, uint8_t* Lc);
+int psacx_construct_lc_u64(psacx_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags,
+                           uint64_t* SA, uint64_t* ISA, uint64_t* LCP, uint8_t* Lc);
+int psacx_construct_lc_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t flags,
+                               uint32_t* d_SA, uint32_t* d_ISA, uint32_t* d_LCP, uint8_t* d_Lc);
+int psacx_construct_lc_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t flags,
+                               uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP, uint8_t* d_Lc);
+
 /* psacx_profile(ctx, 1): zero the statistics and let the step-level ops of psacx_ops.h add their
  * radix-pass event times and byte counts to them (psacx_get_stats reads the running totals);
  * psacx_profile(ctx, 0) stops it. */

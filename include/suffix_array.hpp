@@ -67,6 +67,16 @@ public:
         std::ofstream f(filename.c_str(), std::ios::binary);
         for (std::size_t i = 0; i < m_chars.size(); ++i) f.write(reinterpret_cast<const char*>(&m_chars[i]), sizeof(char_t));
     }
+    // alphabet.hpp:303-311, :328-331: the used characters, ascending
+    void read(const std::string& filename) {
+        std::ifstream f(filename.c_str(), std::ios::binary);
+        if (!f) throw std::runtime_error("cannot read " + filename);
+        std::vector<char_t> chars; char_t c;
+        while (f.read(reinterpret_cast<char*>(&c), sizeof(char_t))) chars.push_back(c);
+        set(chars);
+    }
+    bool operator==(const alphabet& o) const { return m_chars == o.m_chars; }     // alphabet.hpp:286-288
+    bool operator!=(const alphabet& o) const { return !(*this == o); }
     void set(const std::vector<char_t>& chars) {
         m_chars = chars; m_sigma = (unsigned int)chars.size();
         m_bits = 0; while ((1u << m_bits) < m_sigma + 1u) ++m_bits;
@@ -99,7 +109,7 @@ inline void check(psacx_ctx* ctx, int rc) {
 template <typename char_t, typename index_t = std::size_t, bool _CONSTRUCT_LCP = false, bool _CONSTRUCT_LC = false>
 class suffix_array {
     static_assert(sizeof(index_t) == 4 || sizeof(index_t) == 8, "index_t must be a 32 or 64 bit unsigned integer");
-    static_assert(!_CONSTRUCT_LC, "left-branching characters (_CONSTRUCT_LC) are not built by this engine");
+    static_assert(!_CONSTRUCT_LC || _CONSTRUCT_LCP, "_CONSTRUCT_LC needs _CONSTRUCT_LCP (the reference fills Lc inside its LCP code)");
 public:
     explicit suffix_array(const psacx::comm& _comm) : n(0), local_size(0), comm(_comm.copy()), p(1), verbose(true), ctx_(nullptr) {
         psacx::check(nullptr, psacx_create(&ctx_, comm.device(), nullptr));
@@ -123,6 +133,8 @@ public:
     std::vector<index_t> local_SA;
     std::vector<index_t> local_B;
     std::vector<index_t> local_LCP;
+    /// left-branching characters Lc[i] = S[SA[i-1] + LCP[i]] (suffix_array.hpp:211-212), '\0' past
+    /// the end; stays empty unless _CONSTRUCT_LC
     std::vector<char_t> local_Lc;
     bool verbose;                     // print the reference's stderr lines
 
@@ -141,8 +153,20 @@ public:
         local_SA.assign(n, 0); local_B.assign(n, 0);
         if (_CONSTRUCT_LCP) local_LCP.assign(n, 0); else local_LCP.clear();
         uint32_t flags = (_CONSTRUCT_LCP ? PSACX_LCP : 0u) | (fast_resolval ? 0u : PSACX_NO_FAST);
-        int rc = run(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr);
+        std::vector<uint8_t> lc;
+        if (_CONSTRUCT_LC) lc.assign(n, 0);
+        int rc = run(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr,
+                     _CONSTRUCT_LC ? lc.data() : nullptr);
         psacx::check(ctx_, rc);
+        local_Lc.clear();
+        if (_CONSTRUCT_LC) {
+            // positions past the end carry '\0' (alphabet.hpp:168); they are exactly those with SA[i-1] + LCP[i] == n
+            local_Lc.assign(n, (char_t)0);
+            for (std::size_t i = 1; i < n; ++i) {
+                if ((std::size_t)local_SA[i - 1] + (std::size_t)local_LCP[i] >= n) continue;
+                local_Lc[i] = sizeof(char_t) == 1 ? (char_t)lc[i] : chars[lc[i]];
+            }
+        }
         psacx_stats st;
         psacx::check(ctx_, psacx_get_stats(ctx_, &st));
         alpha.set(chars);
@@ -158,6 +182,7 @@ public:
     void write(const std::string& basename) const {
         dump(basename + ".sa", local_SA);
         if (_CONSTRUCT_LCP) dump(basename + ".lcp", local_LCP);
+        if (_CONSTRUCT_LC) dump(basename + ".lc", local_Lc);
         alpha.write(basename + ".alpha");
     }
     // suffix_array.hpp:245-265
@@ -167,6 +192,11 @@ public:
             slurp(basename + ".lcp", local_LCP);
             if (local_SA.size() != local_LCP.size()) throw std::runtime_error("SA and LCP have to have same size");
         }
+        if (_CONSTRUCT_LC) {
+            slurp(basename + ".lc", local_Lc);
+            if (local_SA.size() != local_Lc.size()) throw std::runtime_error("SA and Lc have to have same size");
+        }
+        alpha.read(basename + ".alpha");
         init_size(local_SA.size());
     }
 
@@ -175,17 +205,17 @@ public:
 private:
     psacx_ctx* ctx_;
 
-    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
-        return psacx_construct_u32(ctx_, t, n, k, flags, sa, isa, lcp);
+    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp, uint8_t* lc) {
+        return lc ? psacx_construct_lc_u32(ctx_, t, n, k, flags, sa, isa, lcp, lc) : psacx_construct_u32(ctx_, t, n, k, flags, sa, isa, lcp);
     }
-    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
-        return psacx_construct_u64(ctx_, t, n, k, flags, sa, isa, lcp);
+    int run(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
+        return lc ? psacx_construct_lc_u64(ctx_, t, n, k, flags, sa, isa, lcp, lc) : psacx_construct_u64(ctx_, t, n, k, flags, sa, isa, lcp);
     }
     template <typename U>
     typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
-    run(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp) {
+    run(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp, uint8_t* lc) {
         typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
-        return run(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
+        return run(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp), lc);
     }
 
     // bytes pass through; wider symbols (int alphabets, test/test_psac.cpp:277-304) are ranked

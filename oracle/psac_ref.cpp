@@ -162,44 +162,47 @@ void permute_to_isa(std::vector<T>& val, const std::vector<T>& idx) {
     val.swap(out);
 }
 
-// Range-minimum over the LCP array, value only (include/rmq.hpp:37-339 returns
-// the leftmost minimum; only its value feeds LCP, suffix_array.hpp:1504).
-// Blocks of 64 + sparse table over block minima.
+// Range-minimum over the LCP array returning the position of the LEFTMOST minimum
+// (include/rmq.hpp:37-339; the value feeds LCP, suffix_array.hpp:1504, the position picks
+// the left-branching character, par_rmq.hpp:426-431).  Blocks of 64 + sparse table of
+// leftmost-minimum positions over the blocks.
 template <typename T> struct RangeMin {
     const T* v; uint64_t n; uint64_t nb;
-    std::vector<std::vector<T> > tab;
+    std::vector<std::vector<uint64_t> > tab;
+    uint64_t better(uint64_t a, uint64_t b) const { return v[b] < v[a] ? b : a; }   // a lies left of b
     RangeMin(const T* v_, uint64_t n_) : v(v_), n(n_) {
         nb = (n + 63) / 64;
         tab.emplace_back(nb);
         for (uint64_t b = 0; b < nb; ++b) {
-            T m = v[b * 64];
+            uint64_t m = b * 64;
             uint64_t e = std::min<uint64_t>(n, b * 64 + 64);
-            for (uint64_t i = b * 64 + 1; i < e; ++i) m = std::min(m, v[i]);
+            for (uint64_t i = b * 64 + 1; i < e; ++i) m = better(m, i);
             tab[0][b] = m;
         }
-        // tab[j][b] = min over blocks [b, b + 2^j)
+        // tab[j][b] = leftmost minimum over blocks [b, b + 2^j)
         for (uint64_t span = 2; span <= nb; span <<= 1) {
-            const std::vector<T>& p = tab.back();
-            std::vector<T> c(nb - span + 1);
-            for (uint64_t b = 0; b + span <= nb; ++b) c[b] = std::min(p[b], p[b + span / 2]);
+            const std::vector<uint64_t>& p = tab.back();
+            std::vector<uint64_t> c(nb - span + 1);
+            for (uint64_t b = 0; b + span <= nb; ++b) c[b] = better(p[b], p[b + span / 2]);
             tab.push_back(std::move(c));
         }
     }
-    T query(uint64_t l, uint64_t r) const {   // min over [l, r), l < r
+    uint64_t argmin(uint64_t l, uint64_t r) const {   // leftmost minimum of [l, r), l < r
         uint64_t bl = (l + 63) / 64, br = r / 64;
-        T m = std::numeric_limits<T>::max();
+        uint64_t m = l;
         if (bl >= br) {
-            // may still contain one full block when bl + 1 == br... handled by scans
-            for (uint64_t i = l; i < r; ++i) m = std::min(m, v[i]);
+            for (uint64_t i = l + 1; i < r; ++i) m = better(m, i);
             return m;
         }
-        for (uint64_t i = l; i < bl * 64; ++i) m = std::min(m, v[i]);
-        for (uint64_t i = br * 64; i < r; ++i) m = std::min(m, v[i]);
+        for (uint64_t i = l + 1; i < bl * 64; ++i) m = better(m, i);
         uint64_t len = br - bl;
         unsigned lg = floor_log2(len);
-        m = std::min(m, std::min(tab[lg][bl], tab[lg][br - (1ull << lg)]));
+        if (l < bl * 64) m = better(m, tab[lg][bl]); else m = tab[lg][bl];
+        m = better(m, tab[lg][br - (1ull << lg)]);
+        for (uint64_t i = br * 64; i < r; ++i) m = better(m, i);
         return m;
     }
+    T query(uint64_t l, uint64_t r) const { return v[argmin(l, r)]; }
 };
 
 struct Trace {           // one line per refinement round
@@ -213,23 +216,61 @@ template <typename T>
 struct Engine {
     uint64_t n;
     std::vector<T> SA, B, LCP;
+    std::vector<uint8_t> Lc;   // left-branching characters (suffix_array.hpp:211-212), want_lc only
     std::vector<Trace> trace;
     Alpha alpha;
     unsigned k;
-    bool want_lcp;
+    bool want_lcp, want_lc;
+    Engine() : want_lcp(false), want_lc(false) {}
 
-    // include/suffix_array.hpp:1353-1396 (non-LC branch): LCP from the packed
-    // 2k-mers at each bucket boundary of the first sort; sentinel n elsewhere.
+    // include/kmer.hpp:66-69 + alphabet.hpp:166-171, :281-283: character i of a packed k-mer,
+    // decoded through the inverse mapping whose entry 0 is '\0'.
+    uint8_t kmer_char(T kmer, unsigned i) const {
+        const unsigned l = alpha.bits;
+        unsigned code = (unsigned)((kmer >> ((k - 1 - i) * l)) & (((T)1 << l) - 1));
+        if (code == 0) return 0;
+        for (int c = 0; c < 256; ++c) if (alpha.code[c] == code) return (uint8_t)c;
+        return 0;
+    }
+
+    // include/suffix_array.hpp:1353-1396 (both branches): LCP from the packed
+    // 2k-mers at each bucket boundary of the first sort; sentinel n elsewhere.  With
+    // _CONSTRUCT_LC the character of the LEFT k-mer at the mismatch is decoded (:1365-1383).
     void lcp_from_kmers(const std::vector<T>& B1, const std::vector<T>& B2) {
         LCP.assign(n, (T)n);
         LCP[0] = 0;
+        if (want_lc) Lc.assign(n, 0);
         const unsigned l = alpha.bits;
         for (uint64_t i = 1; i < n; ++i) {
             if (B1[i - 1] != B1[i] || B2[i - 1] != B2[i]) {
                 unsigned v = kmer_lcp<T>(B1[i - 1], B1[i], k, l);
-                if (v == k) v += kmer_lcp<T>(B2[i - 1], B2[i], k, l);
+                if (v == k) {
+                    unsigned v2 = kmer_lcp<T>(B2[i - 1], B2[i], k, l);
+                    v += v2;
+                    if (want_lc) Lc[i] = kmer_char(B2[i - 1], v2);
+                } else if (want_lc) {
+                    Lc[i] = kmer_char(B1[i - 1], v);
+                }
                 LCP[i] = (T)v;
             }
+        }
+    }
+
+    // include/par_rmq.hpp:199-332 (bulk_rmq_v2) / :334-481 (bulk_rmq_Lc) at p = 1, then the
+    // update loops suffix_array.hpp:1485-1505 and :1221-1230: value h + min, and the
+    // left-branching character stored at the leftmost minimum.
+    void answer_ranges(uint64_t h, const std::vector<std::pair<uint64_t, uint64_t> >& q,
+                       const std::vector<uint64_t>& where) {
+        if (q.empty()) return;
+        RangeMin<T> rm(LCP.data(), n);
+        std::vector<uint64_t> pos(q.size());
+        for (size_t j = 0; j < q.size(); ++j) pos[j] = rm.argmin(q[j].first, q[j].second);
+        std::vector<T> ans(q.size());
+        std::vector<uint8_t> ch(q.size(), 0);
+        for (size_t j = 0; j < q.size(); ++j) { ans[j] = LCP[pos[j]]; if (want_lc) ch[j] = Lc[pos[j]]; }
+        for (size_t j = 0; j < q.size(); ++j) {
+            LCP[where[j]] = (T)(h + ans[j]);
+            if (want_lc) Lc[where[j]] = ch[j];
         }
     }
 
@@ -243,11 +284,7 @@ struct Engine {
             if (x == 0 || y == 0) { if (LCP[i] == (T)n) LCP[i] = (T)h; }
             else if (x != y) { q.emplace_back(std::min(x, y), std::max(x, y)); where.push_back(i); }
         }
-        if (q.empty()) return;
-        RangeMin<T> rm(LCP.data(), n);
-        std::vector<T> ans(q.size());
-        for (size_t j = 0; j < q.size(); ++j) ans[j] = rm.query(q[j].first, q[j].second);
-        for (size_t j = 0; j < q.size(); ++j) LCP[where[j]] = (T)(h + ans[j]);
+        answer_ranges(h, q, where);
     }
 
     // include/suffix_array.hpp:925-965 at p = 1: positions (SA order) whose
@@ -312,12 +349,7 @@ struct Engine {
                     ++out;
                 }
             }
-            if (want_lcp && !q.empty()) {
-                RangeMin<T> rm(LCP.data(), n);
-                std::vector<T> ans(q.size());
-                for (size_t j = 0; j < q.size(); ++j) ans[j] = rm.query(q[j].first, q[j].second);
-                for (size_t j = 0; j < q.size(); ++j) LCP[where[j]] = (T)(h + ans[j]);
-            }
+            if (want_lcp) answer_ranges(h, q, where);
             // suffix_array.hpp:1263-1277: push new ids to text order
             for (size_t a = 0; a < act.size(); ++a) B[SA[act[a]]] = Bsa[act[a]];
             collect_active(Bsa, act, false, unres, unf);
@@ -327,8 +359,9 @@ struct Engine {
     }
 
     // include/suffix_array.hpp:469-486 then :365-466.
-    int construct(const uint8_t* s, uint64_t n_, bool fast, unsigned k_req, bool lcp) {
-        n = n_; want_lcp = lcp; trace.clear();
+    int construct(const uint8_t* s, uint64_t n_, bool fast, unsigned k_req, bool lcp, bool lc = false) {
+        n = n_; want_lcp = lcp; want_lc = lcp && lc; trace.clear(); Lc.clear();
+        if (want_lc) Lc.assign(n, 0);
         if (n == 0) return 1;
         alpha = make_alpha(s, n);
         k = pick_k((unsigned)sizeof(T) * 8, alpha.bits, n, k_req);
@@ -535,6 +568,18 @@ struct psac_ref_trace { uint64_t h, unfinished_buckets, unfinished_elements; uin
         }                                                                                          \
         if (k_used) *k_used = e.k;                                                                 \
         if (bits_used) *bits_used = e.alpha.bits;                                                  \
+        return 0;                                                                                  \
+    }                                                                                              \
+    /* suffix_array<char, T, true, true>::construct (suffix_array.hpp:170, :469-486) */             \
+    int psac_ref_construct_lc_##SUF(const uint8_t* text, uint64_t n, int fast, unsigned k, T* SA,  \
+                                    T* ISA, T* LCP, uint8_t* Lc) {                                 \
+        Engine<T> e;                                                                               \
+        int rc = e.construct(text, n, fast != 0, k, true, true);                                   \
+        if (rc) return rc;                                                                         \
+        std::memcpy(SA, e.SA.data(), n * sizeof(T));                                               \
+        std::memcpy(ISA, e.B.data(), n * sizeof(T));                                               \
+        std::memcpy(LCP, e.LCP.data(), n * sizeof(T));                                             \
+        std::memcpy(Lc, e.Lc.data(), n);                                                           \
         return 0;                                                                                  \
     }                                                                                              \
     void psac_ref_kmers_##SUF(const uint8_t* text, uint64_t n, unsigned k, T* out) {               \

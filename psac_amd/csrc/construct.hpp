@@ -397,9 +397,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
 template <typename T>
 int construct_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t flags, T* d_sa,
-                       T* d_isa, T* d_lcp) {
+                       T* d_isa, T* d_lcp, uint8_t* d_lc = nullptr) {
     if (!c || !d_text || !d_sa || !d_isa || n == 0) return PSACX_EINVAL;
     if ((flags & PSACX_LCP) && !d_lcp) return PSACX_EINVAL;
+    if (d_lc && !(flags & PSACX_LCP)) return PSACX_EINVAL;
     if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
     if (sizeof(T) == 8 && n >= (1ull << 62)) return PSACX_ERANGE;
     PSACX_HIP(c, hipSetDevice(c->device));
@@ -409,35 +410,43 @@ int construct_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t
     int rc;
     if (flags & PSACX_LCP) rc = construct_dev<T, true>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp);
     else rc = construct_dev<T, false>(c, d_text, n, k, flags, d_sa, d_isa, (T*)nullptr);
+    if (rc == PSACX_OK && d_lc) {
+        hipLaunchKernelGGL((left_chars_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_text, n, d_sa, d_lcp, d_lc);
+        PSACX_HIP(c, hipGetLastError());
+    }
     if (rc == PSACX_OK && c->profile) prof_collect(c);
     return rc;
 }
 
 // host-pointer form: stage over PCIe, run, copy back
 template <typename T>
-int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp) {
+int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp,
+                   uint8_t* lc = nullptr) {
     if (!c || !text || !sa || !isa || n == 0) return PSACX_EINVAL;
     if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    if (lc && !(flags & PSACX_LCP)) return PSACX_EINVAL;
     if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
     PSACX_HIP(c, hipSetDevice(c->device));
-    uint8_t* d_text = nullptr; T *d_sa = nullptr, *d_isa = nullptr, *d_lcp = nullptr;
+    uint8_t *d_text = nullptr, *d_lc = nullptr; T *d_sa = nullptr, *d_isa = nullptr, *d_lcp = nullptr;
     auto cleanup = [&]() {
         if (d_text) (void)hipFree(d_text); if (d_sa) (void)hipFree(d_sa);
-        if (d_isa) (void)hipFree(d_isa); if (d_lcp) (void)hipFree(d_lcp);
+        if (d_isa) (void)hipFree(d_isa); if (d_lcp) (void)hipFree(d_lcp); if (d_lc) (void)hipFree(d_lc);
     };
     hipError_t e = hipMalloc((void**)&d_text, n);
     if (e == hipSuccess) e = hipMalloc((void**)&d_sa, n * sizeof(T));
     if (e == hipSuccess) e = hipMalloc((void**)&d_isa, n * sizeof(T));
     if (e == hipSuccess && (flags & PSACX_LCP)) e = hipMalloc((void**)&d_lcp, n * sizeof(T));
+    if (e == hipSuccess && lc) e = hipMalloc((void**)&d_lc, n);
     if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(io): ") + hipGetErrorString(e); (void)hipGetLastError(); cleanup(); return PSACX_ENOMEM; }
     int rc = PSACX_OK;
     e = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); cleanup(); return PSACX_EHIP; }
-    rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp);
+    rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_lc);
     if (rc == PSACX_OK) {
         e = hipMemcpyAsync(sa, d_sa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(isa, d_isa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && d_lcp) e = hipMemcpyAsync(lcp, d_lcp, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && d_lc) e = hipMemcpyAsync(lc, d_lc, n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); rc = PSACX_EHIP; }
     }

@@ -7,6 +7,14 @@ int construct_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, ui
 int construct_host_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
     return construct_host<uint64_t>(c, t, n, k, f, sa, isa, lcp);
 }
+int construct_lc_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
+    if (!lc) return PSACX_EINVAL;
+    return construct_dispatch<uint64_t>(c, t, n, k, f | PSACX_LCP, sa, isa, lcp, lc);
+}
+int construct_lc_host_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
+    if (!lc) return PSACX_EINVAL;
+    return construct_host<uint64_t>(c, t, n, k, f | PSACX_LCP, sa, isa, lcp, lc);
+}
 int pair_sort_dev_u64(psacx_ctx* c, uint64_t* b1, uint64_t* b2, uint64_t* idx, uint64_t n, uint32_t bits) {
     return pair_sort_dev<uint64_t>(c, b1, b2, idx, n, bits);
 }

@@ -768,6 +768,26 @@ __global__ void isa_finalize_kernel(T* __restrict__ ISA, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ISA[i] -= 1;
 }
 
+// Left-branching characters (/root/reference/include/suffix_array.hpp:211-212, built there
+// by :1365-1383 in the first round and carried through the range minima, par_rmq.hpp:334-481):
+// Lc[i] = S[SA[i-1] + LCP[i]], the character of the left neighbour at the first mismatch, '\0'
+// when that position is past the end (alphabet.hpp:168) and at i = 0.  The reference's own
+// definition of the result is desa.hpp:262-264; with SA, LCP and the text resident in HBM the
+// direct gather costs one pass (2w + 1 bytes streamed, one random byte read per suffix).
+template <typename T>
+__global__ void left_chars_kernel(const uint8_t* __restrict__ text, uint64_t n, const T* __restrict__ SA,
+                                  const T* __restrict__ LCP, uint8_t* __restrict__ Lc) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t ch = 0;
+        if (i) {
+            const uint64_t p = (uint64_t)SA[i - 1] + (uint64_t)LCP[i];
+            if (p < n) ch = text[p];
+        }
+        Lc[i] = ch;
+    }
+}
+
 template <typename T>
 __global__ void fill_kernel(T* __restrict__ a, uint64_t n, T v) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -71,15 +71,17 @@ class SuffixArray(object):
 
     Fields follow the reference (suffix_array.hpp:180-212): n, local_size,
     local_SA, local_B (0-based inverse suffix array after construct()),
-    local_LCP (empty unless lcp=True).  `log` receives the reference's stderr
+    local_LCP (empty unless lcp=True), local_Lc (left-branching characters,
+    suffix_array.hpp:211-212, empty unless lc=True; lc implies lcp).  `log` receives the reference's stderr
     lines ("Alphabet: ...", "iteration h: unfinished buckets = ...").
     """
 
-    def __init__(self, index_bits=64, lcp=False, ctx=None, log=None):
+    def __init__(self, index_bits=64, lcp=False, ctx=None, log=None, lc=False):
         if index_bits not in (32, 64):
             raise ValueError("index_bits must be 32 or 64")
         self.index_bits = index_bits
-        self.lcp = bool(lcp)
+        self.lc = bool(lc)
+        self.lcp = bool(lcp) or self.lc
         self.ctx = ctx if ctx is not None else Context(0)
         self.dtype = np.uint32 if index_bits == 32 else np.uint64
         self.log = log
@@ -89,6 +91,7 @@ class SuffixArray(object):
         self.local_SA = np.zeros(0, self.dtype)
         self.local_B = np.zeros(0, self.dtype)
         self.local_LCP = np.zeros(0, self.dtype)
+        self.local_Lc = np.zeros(0, np.uint8)
         self.k = 0
         self.sigma = 0
         self.bits_per_char = 0
@@ -129,18 +132,27 @@ class SuffixArray(object):
         self.local_SA = np.empty(n, self.dtype)
         self.local_B = np.empty(n, self.dtype)
         self.local_LCP = np.empty(n, self.dtype) if self.lcp else np.zeros(0, self.dtype)
-        fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
-        rc = fn(self.ctx.handle, _ptr(t), n, int(k), self._flags(fast_resolval, profile), _ptr(self.local_SA),
-                _ptr(self.local_B), _ptr(self.local_LCP) if self.lcp else None)
-        self.ctx.check(rc)
+        self.local_Lc = np.empty(n, np.uint8) if self.lc else np.zeros(0, np.uint8)
+        args = [self.ctx.handle, _ptr(t), n, int(k), self._flags(fast_resolval, profile), _ptr(self.local_SA),
+                _ptr(self.local_B), _ptr(self.local_LCP) if self.lcp else None]
+        if self.lc:
+            fn = getattr(self.ctx._lib, "psacx_construct_lc_u%d" % self.index_bits)
+            args.append(_ptr(self.local_Lc))
+        else:
+            fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
+        self.ctx.check(fn(*args))
         return self._after()
 
-    def construct_device(self, d_text, n, d_sa, d_isa, d_lcp=None, fast_resolval=True, k=0, profile=False):
+    def construct_device(self, d_text, n, d_sa, d_isa, d_lcp=None, fast_resolval=True, k=0, profile=False, d_lc=None):
         """Same with every buffer already resident in HBM (raw device addresses)."""
-        fn = getattr(self.ctx._lib, "psacx_construct_dev_u%d" % self.index_bits)
-        rc = fn(self.ctx.handle, C.c_void_p(d_text), int(n), int(k), self._flags(fast_resolval, profile),
-                C.c_void_p(d_sa), C.c_void_p(d_isa), C.c_void_p(d_lcp) if d_lcp else None)
-        self.ctx.check(rc)
+        args = [self.ctx.handle, C.c_void_p(d_text), int(n), int(k), self._flags(fast_resolval, profile),
+                C.c_void_p(d_sa), C.c_void_p(d_isa), C.c_void_p(d_lcp) if d_lcp else None]
+        if d_lc:
+            fn = getattr(self.ctx._lib, "psacx_construct_lc_dev_u%d" % self.index_bits)
+            args.append(C.c_void_p(d_lc))
+        else:
+            fn = getattr(self.ctx._lib, "psacx_construct_dev_u%d" % self.index_bits)
+        self.ctx.check(fn(*args))
         self.n = self.local_size = int(n)
         return self._after()
 

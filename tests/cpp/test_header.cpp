@@ -59,6 +59,29 @@ int main(int argc, char** argv) {
         CHECK(got == 4 && std::string(buf, 4) == "ACGT");
     }
     {
+        // FileIO with left-branching characters (test/test_psac.cpp:306-347: suffix_array<char, size_t, true, true>)
+        std::string s = "mississippi";
+        suffix_array<char, size_t, true, true> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct(s.begin(), s.end());
+        const std::string lc("\0\0ppimippip", 11);
+        CHECK(std::string(sa.local_Lc.begin(), sa.local_Lc.end()) == lc);
+        sa.write(tmp + "/miss");
+        suffix_array<char, size_t, true, true> sa2((psacx::comm(0)));
+        sa2.read(tmp + "/miss");
+        CHECK(sa.local_SA == sa2.local_SA);
+        CHECK(sa.local_LCP == sa2.local_LCP);
+        CHECK(sa.local_Lc == sa2.local_Lc);
+        CHECK(sa.alpha == sa2.alpha);
+        // int symbols map back to the caller's values
+        std::vector<int> v = {128, 3, 12345678, 12345678, 3, 12345678, 12345678, 3, 66000, 66000, 3};
+        suffix_array<int, uint32_t, true, true> si((psacx::comm(0)));
+        si.verbose = false;
+        si.construct(v.begin(), v.end());
+        const std::vector<int> ilc = {0, 0, 66000, 66000, 3, 128, 3, 66000, 66000, 3, 66000};
+        CHECK(si.local_Lc == ilc);
+    }
+    {
         // suffix tree node table (test/test_suffixtree.cpp:68-83)
         std::string s = "mississippi";
         suffix_array<char, uint64_t, true> sa((psacx::comm(0)));

@@ -75,6 +75,31 @@ def construct(text, bits=32, fast=True, k=0, lcp=True):
     return dict(SA=SA, ISA=ISA, LCP=LCP, trace=trace, k=ku.value, l=lu.value)
 
 
+def construct_lc(text, bits=32, fast=True, k=0):
+    """suffix_array<char, T, true, true>::construct at p=1: dict(SA, ISA, LCP, Lc)."""
+    t = as_text(text)
+    n = t.size
+    dt = _dt(bits)
+    SA = np.zeros(n, dt); ISA = np.zeros(n, dt); LCP = np.zeros(n, dt); Lc = np.zeros(n, np.uint8)
+    f = getattr(lib(), "psac_ref_construct_lc_u%d" % bits)
+    rc = f(_p(t), C.c_uint64(n), C.c_int(1 if fast else 0), C.c_uint(k), _p(SA), _p(ISA), _p(LCP), _p(Lc))
+    if rc != 0:
+        raise RuntimeError("oracle construct_lc failed rc=%d" % rc)
+    return dict(SA=SA, ISA=ISA, LCP=LCP, Lc=Lc)
+
+
+def left_chars_by_definition(text, SA, LCP):
+    """desa.hpp:262-264: Lc[i] = S[SA[i-1] + LCP[i]] (0 past the end and at i = 0)."""
+    t = as_text(text)
+    n = t.size
+    out = np.zeros(n, np.uint8)
+    if n > 1:
+        p = SA[:-1].astype(np.int64) + LCP[1:].astype(np.int64)
+        ok = p < n
+        out[1:][ok] = t[p[ok]]
+    return out
+
+
 def kasai(text, SA, ISA):
     t = as_text(text)
     bits = SA.dtype.itemsize * 8

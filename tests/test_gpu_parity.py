@@ -375,3 +375,59 @@ def test_suffix_tree_nodes(ctx):
         sa = run(ctx, text, bits=bits)
         got = psac_amd.suffix_tree(text, sa.local_SA, sa.local_LCP, ctx=ctx)
         assert np.array_equal(got, O.suffix_tree(text, sa.local_SA, sa.local_LCP))
+
+
+def test_left_branching_chars(ctx):
+    # suffix_array<char, T, true, true> (suffix_array.hpp:170, :211-212, :1365-1383; par_rmq.hpp:334-481):
+    # the engine's Lc against the oracle's (carried through the leftmost range minima) and the definition
+    import psac_amd
+    cases = [(O.as_text("mississippi"), 64, True, 0), (O.rand_dna(130370, 7), 32, True, 0), (O.rand_dna(66763, 23), 64, False, 2),
+             (inputs.cyclic(39999, "abc"), 32, True, 0), (inputs.tandem(100000, 1024, inputs.dna(1024, 5)), 32, True, 0),
+             (inputs.ascii128(200000, 9), 64, True, 0), (O.as_text("aaaaaaaaaaaaaaaa"), 32, True, 0), (O.as_text("ab"), 32, True, 0),
+             (O.as_text("a"), 64, True, 0)]
+    for text, bits, fast, k in cases:
+        sa = psac_amd.SuffixArray(index_bits=bits, lc=True, ctx=ctx)
+        sa.construct(text, fast_resolval=fast, k=k)
+        if text.size > 1:
+            ref = O.construct_lc(text, bits=bits, fast=fast, k=k)
+            assert np.array_equal(sa.local_SA, ref["SA"]) and np.array_equal(sa.local_LCP, ref["LCP"])
+            assert np.array_equal(sa.local_Lc, ref["Lc"])
+        assert np.array_equal(sa.local_Lc, O.left_chars_by_definition(text, sa.local_SA, sa.local_LCP))
+    # 2^24 DNA: definition only (size-independent property)
+    text = inputs.dna(1 << 24, 1)
+    sa = psac_amd.SuffixArray(index_bits=32, lc=True, ctx=ctx)
+    sa.construct(text)
+    assert np.array_equal(sa.local_Lc, O.left_chars_by_definition(text, sa.local_SA, sa.local_LCP))
+    # Lc without LCP is refused
+    import ctypes as C
+    buf = np.zeros(16, np.uint32); lc = np.zeros(16, np.uint8); t = O.as_text("abracadabraabrac")
+    rc = ctx._lib.psacx_construct_lc_u32(ctx.handle, t.ctypes.data, 16, 0, 0, buf.ctypes.data, buf.ctypes.data, None, lc.ctypes.data)
+    assert rc == -1
+
+
+def test_benchmark_clis(tmp_path):
+    # src/benchmark.cpp:35-80 ("p;method;ms"), src/benchmark_k.cpp:35-67 ("p;method;k;ms"),
+    # src/benchmark_ansv.cpp ("n;p;method;ms"): same flags and CSV columns
+    import subprocess
+    root = os.path.dirname(HERE)
+    bdir = os.path.join(root, "psac_amd", "bin")
+    sac, bk, ba = (os.path.join(bdir, x) for x in ("benchmark_sac", "benchmark_k", "benchmark-ansv"))
+    if not all(os.path.exists(x) for x in (sac, bk, ba)):
+        pytest.skip("benchmark CLIs not built")
+    r = subprocess.run([sac, "-r", "200000", "-i", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split(";") for l in r.stdout.split()]
+    assert [x[1] for x in rows] == ["reg-nolcp", "reg-fast-nolcp", "reg-lcp", "reg-fast-lcp"] * 2
+    assert all(x[0] == "1" and float(x[2]) > 0 for x in rows)
+    f = tmp_path / "t.txt"
+    f.write_bytes(bytes(inputs.dna(50000, 3)))
+    r = subprocess.run([bk, "-f", str(f), "-k", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split(";") for l in r.stdout.split()]
+    assert [(x[0], x[1], x[2]) for x in rows] == [("1", "reg-fast-nolcp", "4"), ("1", "reg-nolcp", "4")]
+    for flag in ("-u", "-k", "-b"):
+        r = subprocess.run([ba, "-n", "100000", flag], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        x = r.stdout.split()[0].split(";")
+        assert x[0] == "100000" and x[1] == "1" and x[2] == "gansv-hip" and float(x[3]) > 0
+    assert subprocess.run([sac], capture_output=True).returncode != 0

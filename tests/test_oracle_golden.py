@@ -180,3 +180,22 @@ def test_suffix_tree_mississippi_table():
     r = O.construct(m["text"], bits=64)
     nodes = O.suffix_tree(m["text"], r["SA"], r["LCP"])
     assert nodes.reshape(-1).tolist() == m["suffix_tree_nodes"]
+
+
+def test_left_branching_chars():
+    # suffix_array<char, T, true, true>: Lc carried through the range minima (suffix_array.hpp:1365-1383,
+    # par_rmq.hpp:334-481) equals its definition Lc[i] = S[SA[i-1] + LCP[i]] (desa.hpp:262-264)
+    m = KAT["mississippi"]
+    r = O.construct_lc(m["text"], bits=64)
+    assert r["SA"].tolist() == m["SA"] and r["LCP"].tolist() == m["LCP"]
+    # by hand from SA = 10 7 4 1 0 9 8 6 3 5 2, LCP = 0 1 1 4 0 0 1 0 2 1 3: S[SA[i-1] + LCP[i]]
+    assert bytes(r["Lc"]) == b"\x00\x00ppimippip"
+    cases = [(O.rand_dna(5000, 3), 32, True, 0), (O.rand_dna(5000, 3), 64, False, 2), (inputs.cyclic(4000, "abc"), 32, True, 0),
+             (inputs.tandem(6000, 64, inputs.dna(64, 5)), 32, True, 0), (inputs.ascii128(7000, 9), 64, True, 0),
+             (inputs.bytes_mod127p1(3000, 4), 32, True, 3), (O.as_text("aaaaaaaaaaaaaaaa"), 32, True, 0),
+             (O.as_text("ab"), 32, True, 0)]
+    for text, bits, fast, k in cases:
+        r = O.construct_lc(text, bits=bits, fast=fast, k=k)
+        base = O.construct(text, bits=bits, fast=fast, k=k)
+        assert np.array_equal(r["SA"], base["SA"]) and np.array_equal(r["LCP"], base["LCP"])
+        assert np.array_equal(r["Lc"], O.left_chars_by_definition(text, r["SA"], r["LCP"]))
