@@ -128,6 +128,24 @@ int psacx_construct_lc_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n
 int psacx_construct_lc_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t flags,
                                uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP, uint8_t* d_Lc);
 
+/* Generalized suffix array of a set of strings: suffix_array<>::construct_ss(simple_dstringset&,
+ * alphabet) (suffix_array.hpp:267-363; string set stringset.hpp:33-81; k-mers kmer.hpp:269-355; shifts
+ * shifting.hpp:374-418; bucket rules bucketing.hpp:130-143; tests test/test_gsa.cpp).
+ *   text     the m strings back to back WITHOUT separators, n bytes in total
+ *   offsets  m + 1 ascending offsets, offsets[0] = 0, offsets[m] = n, no empty string
+ *   SA       every suffix of every string, positions counted in `text`; a suffix ends with its
+ *            string, an end sorts below every character, equal suffixes come in text order
+ *   ISA      inverse of SA;  LCP (with PSACX_LCP): common prefix inside the strings
+ */
+int psacx_construct_gsa_u32(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const uint64_t* offsets, uint64_t m,
+                            uint32_t k, uint32_t flags, uint32_t* SA, uint32_t* ISA, uint32_t* LCP);
+int psacx_construct_gsa_u64(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const uint64_t* offsets, uint64_t m,
+                            uint32_t k, uint32_t flags, uint64_t* SA, uint64_t* ISA, uint64_t* LCP);
+int psacx_construct_gsa_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const uint64_t* d_offsets, uint64_t m,
+                                uint32_t k, uint32_t flags, uint32_t* d_SA, uint32_t* d_ISA, uint32_t* d_LCP);
+int psacx_construct_gsa_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const uint64_t* d_offsets, uint64_t m,
+                                uint32_t k, uint32_t flags, uint64_t* d_SA, uint64_t* d_ISA, uint64_t* d_LCP);
+
 /* psacx_profile(ctx, 1): zero the statistics and let the step-level ops of psacx_ops.h add their
  * radix-pass event times and byte counts to them (psacx_get_stats reads the running totals);
  * psacx_profile(ctx, 0) stops it. */

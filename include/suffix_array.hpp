@@ -67,6 +67,29 @@ public:
         std::ofstream f(filename.c_str(), std::ios::binary);
         for (std::size_t i = 0; i < m_chars.size(); ++i) f.write(reinterpret_cast<const char*>(&m_chars[i]), sizeof(char_t));
     }
+    // alphabet.hpp:205-236: the characters that occur, ascending by unsigned value
+    template <typename Iterator>
+    static alphabet from_sequence(Iterator begin, Iterator end) {
+        typedef typename std::make_unsigned<char_t>::type uchar_t;
+        std::vector<uchar_t> u;
+        for (Iterator it = begin; it != end; ++it) u.push_back((uchar_t)*it);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        std::vector<char_t> chars;
+        for (std::size_t i = 0; i < u.size(); ++i) chars.push_back((char_t)u[i]);
+        alphabet a; a.set(chars); return a;
+    }
+    template <typename Iterator, typename Comm>
+    static alphabet from_sequence(Iterator begin, Iterator end, const Comm&) { return from_sequence(begin, end); }
+    static alphabet from_string(const std::basic_string<char_t>& str) { return from_sequence(str.begin(), str.end()); }
+    template <typename Comm>
+    static alphabet from_string(const std::basic_string<char_t>& str, const Comm&) { return from_sequence(str.begin(), str.end()); }
+    template <typename StringSet, typename Comm>
+    static alphabet from_stringset(const StringSet& ss, const Comm&) {
+        std::basic_string<char_t> all;
+        for (std::size_t s = 0; s < ss.sizes.size(); ++s) all.append(ss.str_begins[s], ss.str_begins[s] + ss.sizes[s]);
+        return from_string(all);
+    }
     // alphabet.hpp:303-311, :328-331: the used characters, ascending
     void read(const std::string& filename) {
         std::ifstream f(filename.c_str(), std::ios::binary);
@@ -101,6 +124,39 @@ inline void check(psacx_ctx* ctx, int rc) {
 }
 
 } // namespace psacx
+
+// simple_dstringset of /root/reference/include/stringset.hpp:33-151 on one rank: the strings of a
+// flat buffer, cut at runs of the separator; empty strings do not exist.
+class simple_dstringset {
+public:
+    bool first_split, last_split;              // never set on one rank (stringset.hpp:74-80)
+    std::vector<const char*> str_begins;
+    std::vector<std::size_t> sizes;
+    std::size_t sum_sizes;
+
+    template <typename Iterator>
+    simple_dstringset(Iterator begin, Iterator end, const psacx::comm&, char sep = '$')
+        : first_split(false), last_split(false), sum_sizes(0) {
+        Iterator it = begin;
+        while (it != end && *it == sep) ++it;
+        while (it != end) {
+            Iterator e = it;
+            while (e != end && *e != sep) ++e;
+            sizes.push_back((std::size_t)std::distance(it, e));
+            sum_sizes += sizes.back();
+            str_begins.push_back(&(*it));
+            it = e;
+            while (it != end && *it == sep) ++it;
+        }
+    }
+};
+
+// stringset.hpp:586-600: every string followed by the separator
+inline std::string flatten_strings(const std::vector<std::string>& strs, char sep = '$') {
+    std::string out;
+    for (std::size_t i = 0; i < strs.size(); ++i) { out += strs[i]; out.push_back(sep); }
+    return out;
+}
 
 #ifndef PSACX_INFO
 #define PSACX_INFO(msg) { std::cerr << msg << std::endl; }
@@ -178,6 +234,36 @@ public:
         }
     }
 
+    // suffix_array.hpp:267-363: generalized suffix array of a string set.  local_SA counts positions
+    // in the strings laid back to back without separators; equal suffixes come in that order.
+    void construct_ss(simple_dstringset& ss, const alphabet_type& a) {
+        static_assert(sizeof(char_t) == 1, "string sets hold bytes");
+        static_assert(!_CONSTRUCT_LC, "left-branching characters are not defined for string sets");
+        init_size(ss.sum_sizes);
+        if (n == 0) throw std::runtime_error("psacx: empty input");
+        std::vector<uint8_t> bytes; bytes.reserve(n);
+        std::vector<uint64_t> off(1, 0);
+        for (std::size_t s = 0; s < ss.sizes.size(); ++s) {
+            bytes.insert(bytes.end(), reinterpret_cast<const uint8_t*>(ss.str_begins[s]),
+                         reinterpret_cast<const uint8_t*>(ss.str_begins[s]) + ss.sizes[s]);
+            off.push_back(bytes.size());
+        }
+        local_SA.assign(n, 0); local_B.assign(n, 0);
+        if (_CONSTRUCT_LCP) local_LCP.assign(n, 0); else local_LCP.clear();
+        const uint32_t flags = _CONSTRUCT_LCP ? PSACX_LCP : 0u;
+        psacx::check(ctx_, run_gsa(bytes.data(), off.data(), (uint64_t)ss.sizes.size(), flags, local_SA.data(), local_B.data(),
+                                   _CONSTRUCT_LCP ? local_LCP.data() : nullptr));
+        psacx_stats st;
+        psacx::check(ctx_, psacx_get_stats(ctx_, &st));
+        alpha = a;
+        if (verbose) {
+            PSACX_INFO("Alphabet: " << alpha);                       // suffix_array.hpp:273-275
+            for (uint32_t r = 0; r < st.n_rounds; ++r)                // suffix_array.hpp:317
+                PSACX_INFO("iteration " << st.rounds[r].h << ": unfinished buckets = " << st.rounds[r].unfinished_buckets
+                           << ", unfinished elements = " << st.rounds[r].unfinished_elements);
+        }
+    }
+
     // suffix_array.hpp:232-242: raw little-endian arrays, no header
     void write(const std::string& basename) const {
         dump(basename + ".sa", local_SA);
@@ -210,6 +296,18 @@ private:
     }
     int run(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
         return lc ? psacx_construct_lc_u64(ctx_, t, n, k, flags, sa, isa, lcp, lc) : psacx_construct_u64(ctx_, t, n, k, flags, sa, isa, lcp);
+    }
+    int run_gsa(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+        return psacx_construct_gsa_u32(ctx_, t, n, off, m, 0, flags, sa, isa, lcp);
+    }
+    int run_gsa(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+        return psacx_construct_gsa_u64(ctx_, t, n, off, m, 0, flags, sa, isa, lcp);
+    }
+    template <typename U>
+    typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
+    run_gsa(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, U* sa, U* isa, U* lcp) {
+        typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
+        return run_gsa(t, off, m, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
     }
     template <typename U>
     typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type

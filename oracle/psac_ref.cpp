@@ -133,17 +133,36 @@ void pair_sort(std::vector<T>& B1, std::vector<T>& B2, std::vector<T>& SA) {
     SA.resize(n);
     for (uint64_t i = 0; i < n; ++i) { B1[i] = t[i].a; B2[i] = t[i].b; SA[i] = t[i].idx; }
 }
+// idxsort_vectors<T, T, true> (idxsort.hpp:23-83 with _STABLE): equal pairs keep their input order
+template <typename T>
+void pair_sort_stable(std::vector<T>& B1, std::vector<T>& B2, std::vector<T>& SA) {
+    const uint64_t n = B1.size();
+    std::vector<Tup<T> > t(n);
+    for (uint64_t i = 0; i < n; ++i) { t[i].a = B1[i]; t[i].b = B2[i]; t[i].idx = (T)i; }
+    std::stable_sort(t.begin(), t.end(), [](const Tup<T>& x, const Tup<T>& y) {
+        return x.a < y.a || (x.a == y.a && x.b < y.b);
+    });
+    SA.resize(n);
+    for (uint64_t i = 0; i < n; ++i) { B1[i] = t[i].a; B2[i] = t[i].b; SA[i] = t[i].idx; }
+}
 
 // include/bucketing.hpp:57-123 + :21-53 at p = 1.  In sorted order, a position
 // whose (B1,B2) differs from its predecessor becomes a bucket head with id
 // i+1 (1-based), the others 0; count buckets/elements still unresolved, then
 // inclusive prefix-max fills the zeros.
+// gsa_mask: bucketing.hpp:130-143 -- rebucket_gsa (mask = all ones: equal pairs stay together only
+// if B2 != 0) and rebucket_gsa_kmers (mask = last character of the k-mer: only if the 2k-mer holds
+// no end of string); 0 = the plain rule.
 template <typename T>
-void rebucket_pairs(std::vector<T>& B1, const std::vector<T>& B2, uint64_t& unf_b, uint64_t& unf_e) {
+void rebucket_pairs(std::vector<T>& B1, const std::vector<T>& B2, uint64_t& unf_b, uint64_t& unf_e, T gsa_mask = 0) {
     const uint64_t n = B1.size();
     std::vector<uint8_t> head(n);
     head[0] = 1;
-    for (uint64_t i = 1; i < n; ++i) head[i] = !(B1[i] == B1[i - 1] && B2[i] == B2[i - 1]);
+    for (uint64_t i = 1; i < n; ++i) {
+        bool same = B1[i] == B1[i - 1] && B2[i] == B2[i - 1];
+        if (gsa_mask && (B2[i - 1] & gsa_mask) == 0) same = false;
+        head[i] = !same;
+    }
     for (uint64_t i = 0; i < n; ++i) B1[i] = head[i] ? (T)(i + 1) : (T)0;
     unf_b = 0; unf_e = 0;
     for (uint64_t i = 1; i < n; ++i) {
@@ -256,6 +275,81 @@ struct Engine {
         }
     }
 
+    // ---- generalized suffix array: strings s_0 .. s_{m-1} back to back without separators
+    // (stringset.hpp:33-81), str_end[i] = end offset of the string holding position i.
+    std::vector<uint64_t> str_end;
+
+    // include/kmer.hpp:269-355 at p = 1: k-mers never run past the end of their string
+    void make_kmers_ss(const uint8_t* s, const uint64_t* off, uint64_t m) {
+        const unsigned l = alpha.bits;
+        for (uint64_t t = 0; t < m; ++t) {
+            for (uint64_t i = off[t]; i < off[t + 1]; ++i) {
+                T w = 0;
+                for (unsigned j = 0; j < k; ++j) {
+                    w = (T)(w << l);
+                    if (i + j < off[t + 1]) w |= (T)alpha.code[s[i + j]];
+                }
+                B[i] = w;
+            }
+        }
+    }
+    // include/shifting.hpp:374-418 at p = 1 (only inner sequences): B2[i] = B[i+h] inside the string
+    void shift_ss(uint64_t h, std::vector<T>& B2) const {
+        B2.assign(n, 0);
+        for (uint64_t i = 0; i < n; ++i) if (i + h < str_end[i]) B2[i] = B[i + h];
+    }
+    // include/suffix_array.hpp:1404-1442 (initial_kmer_lcp_gsa)
+    void lcp_from_kmers_gsa(const std::vector<T>& B1, const std::vector<T>& B2) {
+        LCP.assign(n, (T)n);
+        LCP[0] = 0;
+        const unsigned l = alpha.bits;
+        for (uint64_t i = 1; i < n; ++i) {
+            const T l1 = B1[i - 1], l2 = B2[i - 1], r1 = B1[i], r2 = B2[i];
+            if (l1 != r1) { LCP[i] = (T)kmer_lcp<T>(l1, r1, k, l); continue; }
+            unsigned v = k - trail_zeros<T>(l1) / l;
+            if (v == k) {
+                if (l2 != r2) { v += kmer_lcp<T>(l2, r2, k, l); LCP[i] = (T)v; }
+                else {
+                    if (l2 != 0) v += k - trail_zeros<T>(l2) / l;
+                    if (v < 2 * k) LCP[i] = (T)v;
+                }
+            } else LCP[i] = (T)v;
+        }
+    }
+    // include/suffix_array.hpp:267-363 (construct_ss): one k-mer round, then always the
+    // bucket-chasing tail (:333 "else if (true)"), whose B2 fetch stops at string ends (:998-1029).
+    int construct_ss(const uint8_t* s, uint64_t n_, const uint64_t* off, uint64_t m, unsigned k_req, bool lcp) {
+        n = n_; want_lcp = lcp; want_lc = false; trace.clear(); Lc.clear();
+        if (n == 0 || m == 0 || off[0] != 0 || off[m] != n) return 1;
+        for (uint64_t t = 0; t < m; ++t) if (off[t + 1] <= off[t]) return 1;
+        alpha = make_alpha(s, n);
+        k = pick_k((unsigned)sizeof(T) * 8, alpha.bits, n, k_req);
+        str_end.assign(n, 0);
+        for (uint64_t t = 0; t < m; ++t) for (uint64_t i = off[t]; i < off[t + 1]; ++i) str_end[i] = off[t + 1];
+        B.assign(n, 0); SA.assign(n, 0); LCP.clear();
+        if (lcp) LCP.assign(n, (T)n);
+        if (n == 1) { SA[0] = 0; B[0] = 0; if (lcp) LCP[0] = 0; return 0; }
+        make_kmers_ss(s, off, m);
+        std::vector<T> Bsa;
+        uint64_t unf_b = 1, unf_e = n;
+        const uint64_t h = k;
+        if (h < n) {
+            std::vector<T> B2;
+            shift_ss(h, B2);
+            pair_sort_stable(B, B2, SA);
+            if (lcp) lcp_from_kmers_gsa(B, B2);
+            const T last_char = (T)(((T)1 << alpha.bits) - 1);
+            rebucket_pairs(B, B2, unf_b, unf_e, last_char);
+            Trace t = {h, unf_b, unf_e, 0};
+            trace.push_back(t);
+            if (!((h << 1) >= n || unf_b == 0)) Bsa = B;
+            permute_to_isa(B, SA);
+        } else return 2;
+        if (unf_b > 0 && !Bsa.empty()) chase(Bsa, 2 * h);
+        for (uint64_t i = 0; i < n; ++i) B[i] -= 1;
+        return 0;
+    }
+
     // include/par_rmq.hpp:199-332 (bulk_rmq_v2) / :334-481 (bulk_rmq_Lc) at p = 1, then the
     // update loops suffix_array.hpp:1485-1505 and :1221-1230: value h + min, and the
     // left-branching character stored at the leftmost minimum.
@@ -315,7 +409,9 @@ struct Engine {
             std::vector<T> b2(act.size(), 0);
             for (size_t a = 0; a < act.size(); ++a) {
                 uint64_t p = (uint64_t)SA[act[a]] + h;
-                if (p < n) b2[a] = B[p];
+                // suffix_array.hpp:972-996; with a string set the suffix h further must start
+                // inside the same string (:998-1029)
+                if (p < (str_end.empty() ? n : str_end[SA[act[a]]])) b2[a] = B[p];
             }
             std::vector<std::pair<uint64_t, uint64_t> > q;
             std::vector<uint64_t> where;
@@ -360,7 +456,7 @@ struct Engine {
 
     // include/suffix_array.hpp:469-486 then :365-466.
     int construct(const uint8_t* s, uint64_t n_, bool fast, unsigned k_req, bool lcp, bool lc = false) {
-        n = n_; want_lcp = lcp; want_lc = lcp && lc; trace.clear(); Lc.clear();
+        n = n_; want_lcp = lcp; want_lc = lcp && lc; trace.clear(); Lc.clear(); str_end.clear();
         if (want_lc) Lc.assign(n, 0);
         if (n == 0) return 1;
         alpha = make_alpha(s, n);
@@ -580,6 +676,28 @@ struct psac_ref_trace { uint64_t h, unfinished_buckets, unfinished_elements; uin
         std::memcpy(ISA, e.B.data(), n * sizeof(T));                                               \
         std::memcpy(LCP, e.LCP.data(), n * sizeof(T));                                             \
         std::memcpy(Lc, e.Lc.data(), n);                                                           \
+        return 0;                                                                                  \
+    }                                                                                              \
+    /* suffix_array<char, T, LCP>::construct_ss (suffix_array.hpp:267-363): text = the strings back  \
+     * to back, off[0..m] their offsets */                                                         \
+    int psac_ref_construct_ss_##SUF(const uint8_t* text, uint64_t n, const uint64_t* off,          \
+                                    uint64_t m, unsigned k, T* SA, T* ISA, T* LCP,                 \
+                                    psac_ref_trace* tr, uint32_t tr_cap, uint32_t* tr_len) {       \
+        Engine<T> e;                                                                               \
+        int rc = e.construct_ss(text, n, off, m, k, LCP != nullptr);                               \
+        if (rc) return rc;                                                                         \
+        std::memcpy(SA, e.SA.data(), n * sizeof(T));                                               \
+        std::memcpy(ISA, e.B.data(), n * sizeof(T));                                               \
+        if (LCP) std::memcpy(LCP, e.LCP.data(), n * sizeof(T));                                    \
+        if (tr_len) {                                                                              \
+            uint32_t c = (uint32_t)std::min<size_t>(e.trace.size(), tr_cap);                       \
+            for (uint32_t i = 0; i < c && tr; ++i) {                                               \
+                tr[i].h = e.trace[i].h; tr[i].unfinished_buckets = e.trace[i].unf_b;               \
+                tr[i].unfinished_elements = e.trace[i].unf_e; tr[i].phase = e.trace[i].phase;      \
+                tr[i].pad = 0;                                                                     \
+            }                                                                                      \
+            *tr_len = (uint32_t)e.trace.size();                                                    \
+        }                                                                                          \
         return 0;                                                                                  \
     }                                                                                              \
     void psac_ref_kmers_##SUF(const uint8_t* text, uint64_t n, unsigned k, T* out) {               \

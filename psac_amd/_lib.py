@@ -19,6 +19,7 @@ PSACX_MAX_ROUNDS = 72
 EXPORTS = [
     "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim",
     "psacx_construct_u32", "psacx_construct_u64", "psacx_construct_dev_u32", "psacx_construct_dev_u64",
+    "psacx_construct_gsa_u32", "psacx_construct_gsa_u64", "psacx_construct_gsa_dev_u32", "psacx_construct_gsa_dev_u64",
     "psacx_construct_lc_u32", "psacx_construct_lc_u64", "psacx_construct_lc_dev_u32", "psacx_construct_lc_dev_u64",
     "psacx_get_stats", "psacx_profile", "psacx_check_dev_u32", "psacx_check_dev_u64", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
     "psacx_ansv_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
@@ -77,6 +78,8 @@ def load():
     for suf in ("u32", "u64"):
         for name in ("psacx_construct_", "psacx_construct_dev_"):
             getattr(lib, name + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
+        for name in ("psacx_construct_gsa_", "psacx_construct_gsa_dev_"):
+            getattr(lib, name + suf).argtypes = [vp, vp, u64, vp, u64, u32, u32, vp, vp, vp]
         for name in ("psacx_construct_lc_", "psacx_construct_lc_dev_"):
             getattr(lib, name + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp, vp]
         getattr(lib, "psacx_pair_sort_dev_" + suf).argtypes = [vp, vp, vp, vp, u64, u32]

@@ -119,11 +119,11 @@ inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k)
 }
 
 // per-tile carries of the prefix-max: last head of every tile, then an exclusive max-scan
-template <typename T, bool REFINE>
+template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
                 KeyShape ks) {
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL((last_head_kernel<T, REFINE>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
                        a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
@@ -193,9 +193,12 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     return PSACX_OK;
 }
 
+// d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
+// d_text holds the strings back to back, d_slen[i] the characters from i to the end of its string.
 template <typename T, bool WITH_LCP>
 int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_req, uint32_t flags,
-                  T* d_sa, T* d_isa, T* d_lcp) {
+                  T* d_sa, T* d_isa, T* d_lcp, const T* d_slen = nullptr) {
+    const bool gsa = d_slen != nullptr;
     const bool no_fast = (flags & PSACX_NO_FAST) != 0;
     psacx_stats& st = c->stats;
     PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
@@ -269,10 +272,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     st.k = k;
     // the 2k-character window of the first round, packed with lc bits per character
     KeyShape ks;
+    if (gsa) {
+        // string ends need their own code in the key: psac's codes 1..sigma with l bits, 0 = end
+        for (int ch = 0; ch < 256; ++ch) if (h_hist[ch]) tab.c[ch] = (uint16_t)(tab.c[ch] + 1);
+        lc = l;
+    }
     ks.lc = lc;
     ks.c1 = std::min<uint32_t>(2 * k, (uint32_t)(sizeof(T) * 8) / lc);
     ks.c2 = 2 * k - ks.c1;
-    ks.spec = std::min<uint64_t>(2ull * k - 1, n);
+    ks.spec = gsa ? 0 : std::min<uint64_t>(2ull * k - 1, n);
 
     // In the diet layout the sorted keys must end up in the workspace set x (the other set is the
     // LCP / ISA output), so an odd number of passes starts from y.
@@ -286,8 +294,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
-        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
-                           tab, ks, first_in.k1, first_in.k2, w.sc.d_partials);
+        if (gsa)
+            hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
+                               tab, ks, first_in.k1, first_in.k2, w.sc.d_partials, d_slen);
+        else
+            hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
+                               tab, ks, first_in.k1, first_in.k2, w.sc.d_partials, (const T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
     }
@@ -313,10 +325,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-        PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
-        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                           w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
+        if (gsa) {
+            PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
+            hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
+                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
+        } else {
+            PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
+            hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
+                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
+        }
         PSACX_HIP(c, hipGetLastError());
     }
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
@@ -357,7 +376,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_GATHER);
             const int gg = grid_for(c, cnt, 256, 16);
             hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
-                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v, w.sc.d_partials);
+                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v, w.sc.d_partials, d_slen);
             PSACX_HIP(c, hipGetLastError());
             PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
@@ -415,6 +434,69 @@ int construct_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t
         PSACX_HIP(c, hipGetLastError());
     }
     if (rc == PSACX_OK && c->profile) prof_collect(c);
+    return rc;
+}
+
+// Generalized suffix array (construct_ss, suffix_array.hpp:267-363): d_off[0..m] are the offsets of
+// the m strings inside d_text (device memory, ascending, d_off[0] = 0, d_off[m] = n).
+template <typename T>
+int construct_gsa_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, const uint64_t* d_off, uint64_t m, uint32_t k,
+                           uint32_t flags, T* d_sa, T* d_isa, T* d_lcp) {
+    if (!c || !d_text || !d_off || !d_sa || !d_isa || n == 0 || m == 0 || m > n) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !d_lcp) return PSACX_EINVAL;
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    if (sizeof(T) == 8 && n >= (1ull << 62)) return PSACX_ERANGE;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    c->profile = (flags & PSACX_PROFILE) != 0;
+    c->ev_used = 0;
+    T* d_slen = nullptr;
+    hipError_t e = hipMalloc((void**)&d_slen, n * sizeof(T));
+    if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(string lengths): ") + hipGetErrorString(e); (void)hipGetLastError(); return PSACX_ENOMEM; }
+    hipLaunchKernelGGL((string_len_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_off, m, n, d_slen);
+    int rc = hipGetLastError() == hipSuccess ? PSACX_OK : PSACX_EHIP;
+    if (rc == PSACX_OK) {
+        if (flags & PSACX_LCP) rc = construct_dev<T, true>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_slen);
+        else rc = construct_dev<T, false>(c, d_text, n, k, flags, d_sa, d_isa, (T*)nullptr, d_slen);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_slen);
+    if (rc == PSACX_OK && c->profile) prof_collect(c);
+    return rc;
+}
+
+template <typename T>
+int construct_gsa_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const uint64_t* off, uint64_t m, uint32_t k, uint32_t flags,
+                       T* sa, T* isa, T* lcp) {
+    if (!c || !text || !off || !sa || !isa || n == 0 || m == 0 || m > n) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    if (off[0] != 0 || off[m] != n) return PSACX_EINVAL;
+    for (uint64_t t = 0; t < m; ++t) if (off[t + 1] <= off[t]) return PSACX_EINVAL;     // empty strings are not part of a set (stringset.hpp:53-72)
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    uint8_t* d_text = nullptr; uint64_t* d_off = nullptr; T *d_sa = nullptr, *d_isa = nullptr, *d_lcp = nullptr;
+    auto cleanup = [&]() {
+        if (d_text) (void)hipFree(d_text); if (d_off) (void)hipFree(d_off); if (d_sa) (void)hipFree(d_sa);
+        if (d_isa) (void)hipFree(d_isa); if (d_lcp) (void)hipFree(d_lcp);
+    };
+    hipError_t e = hipMalloc((void**)&d_text, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (m + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sa, n * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_isa, n * sizeof(T));
+    if (e == hipSuccess && (flags & PSACX_LCP)) e = hipMalloc((void**)&d_lcp, n * sizeof(T));
+    if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(io): ") + hipGetErrorString(e); (void)hipGetLastError(); cleanup(); return PSACX_ENOMEM; }
+    e = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); cleanup(); return PSACX_EHIP; }
+    int rc = construct_gsa_dispatch<T>(c, d_text, n, d_off, m, k, flags, d_sa, d_isa, d_lcp);
+    if (rc == PSACX_OK) {
+        e = hipMemcpyAsync(sa, d_sa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(isa, d_isa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && d_lcp) e = hipMemcpyAsync(lcp, d_lcp, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); rc = PSACX_EHIP; }
+    }
+    cleanup();
     return rc;
 }
 

@@ -274,5 +274,8 @@ __device__ __forceinline__ void store_run(T* __restrict__ p, uint64_t e0, uint64
 template <typename T> __device__ __forceinline__ unsigned clz_t(T x);
 template <> __device__ __forceinline__ unsigned clz_t<uint32_t>(uint32_t x) { return x ? __clz((int)x) : 32u; }
 template <> __device__ __forceinline__ unsigned clz_t<uint64_t>(uint64_t x) { return x ? __clzll((long long)x) : 64u; }
+template <typename T> __device__ __forceinline__ unsigned ctz_t(T x);      // x != 0
+template <> __device__ __forceinline__ unsigned ctz_t<uint32_t>(uint32_t x) { return (unsigned)__ffs((int)x) - 1u; }
+template <> __device__ __forceinline__ unsigned ctz_t<uint64_t>(uint64_t x) { return (unsigned)__ffsll((long long)x) - 1u; }
 
 } // namespace psacx

@@ -5,6 +5,10 @@ namespace psacx {
 int construct_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
 int construct_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
 int construct_host_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int construct_gsa_host_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int construct_gsa_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int construct_gsa_host_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
+int construct_gsa_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*);
 int construct_lc_host_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint8_t*);
 int construct_lc_host_u64(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint8_t*);
 int construct_lc_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint8_t*);
@@ -104,6 +108,19 @@ int psacx_construct_lc_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, uint3
 }
 int psacx_construct_lc_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
     return construct_lc_dev_u64(c, t, n, k, f, sa, isa, lcp, lc);
+}
+
+int psacx_construct_gsa_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t m, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_gsa_host_u32(c, t, n, off, m, k, f, sa, isa, lcp);
+}
+int psacx_construct_gsa_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t m, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return construct_gsa_dev_u32(c, t, n, off, m, k, f, sa, isa, lcp);
+}
+int psacx_construct_gsa_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t m, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+    return construct_gsa_host_u64(c, t, n, off, m, k, f, sa, isa, lcp);
+}
+int psacx_construct_gsa_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t m, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+    return construct_gsa_dev_u64(c, t, n, off, m, k, f, sa, isa, lcp);
 }
 
 int psacx_profile(psacx_ctx* c, int on) {

@@ -130,11 +130,16 @@ __device__ __forceinline__ uint64_t record_suffix(uint64_t j, uint64_t spec, uin
     return j < spec ? n - 1 - j : j - spec;
 }
 
-template <typename T, int BLOCK, int ITEMS>
+//
+// GSA (string sets, kmer.hpp:269-355): the codes are psac's 1..sigma with lc = l bits, 0 is the
+// end marker, spec = 0, and every window is cut at the end of its string: slen[i] = characters
+// from position i to the end of the string holding it.
+template <typename T, int BLOCK, int ITEMS, bool GSA = false>
 __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                           uint64_t n_text, CodeTable tab, KeyShape ks,
                                                           T* __restrict__ C1, T* __restrict__ C2,
-                                                          unsigned long long* __restrict__ summary) {
+                                                          unsigned long long* __restrict__ summary,
+                                                          const T* __restrict__ slen = nullptr) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int HALO = 2 * 64 + 8;             // 2k <= 128 always
     __shared__ uint16_t codes[TILE + HALO];
@@ -167,6 +172,19 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
             if (ks.c2) w2 = ((T)(w2 << lc) | (T)codes[q + j + two_k - 1]) & mask2;
             o1[j] = w1; o2[j] = w2;
         }
+        if (GSA) {
+            T len[ITEMS];
+            load_run<T, ITEMS>(slen, j0, n, len, (T)1);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                // keep the first min(len, c1) characters of word 1 and the first min(len - c1, c2) of word 2
+                const unsigned k1 = len[j] < (T)ks.c1 ? (unsigned)len[j] : ks.c1;
+                const unsigned k2 = len[j] <= (T)ks.c1 ? 0u : (len[j] - (T)ks.c1 < (T)ks.c2 ? (unsigned)(len[j] - (T)ks.c1) : ks.c2);
+                const unsigned d1 = (ks.c1 - k1) * lc, d2 = (ks.c2 - k2) * lc;
+                o1[j] = d1 >= sizeof(T) * 8 ? (T)0 : (T)((T)(o1[j] >> d1) << d1);
+                o2[j] = d2 >= sizeof(T) * 8 ? (T)0 : (T)((T)(o2[j] >> d2) << d2);
+            }
+        }
     } else {
         // the few threads whose records include short suffixes: pack each record from the text
 #pragma unroll 1
@@ -198,6 +216,17 @@ __device__ __forceinline__ unsigned window_lcp(T x1, T x2, T y1, T y2, const Key
     return ks.c1 + ks.c2;
 }
 
+// Length of a suffix as far as the first round needs it (capped LCP, "shorter than 2k" test).
+// Plain text: n - start.  String sets: the packed window carries end markers (code 0), so the
+// length inside the window is 2k minus its trailing empty characters (suffix_array.hpp:1421,
+// bucketing.hpp:138-143); 2k means "at least 2k".
+template <bool GSA, typename T>
+__device__ __forceinline__ uint64_t first_round_len(uint64_t ng, T sa, T w1, T w2, const KeyShape& ks) {
+    if (!GSA) return ng - (uint64_t)sa;
+    if (ks.c2 && w2 != 0) return ks.c1 + ks.c2 - ctz_t<T>(w2) / ks.lc;
+    return w1 != 0 ? ks.c1 - ctz_t<T>(w1) / ks.lc : 0;
+}
+
 // What a rank needs to know about the records just outside its block of the globally sorted
 // sequence (all zero on a single GPU).  psac gets the same with right_shift of the last tuple
 // (bucketing.hpp:77,100) and exscan(max) of the bucket ids (bucketing.hpp:39).
@@ -219,7 +248,7 @@ template <typename T> struct Boundary {
 // REFINE = false: heads of the first round, the 2k-character windows differ (packed pair
 //                 differs, or one of the two suffixes is shorter than 2k).
 // REFINE = true : heads inside old buckets, (K1,K2) differs or K2 == 0; id = pos + 1.
-template <typename T, bool REFINE>
+template <typename T, bool REFINE, bool GSA = false>
 __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__ A2,
                                  const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
                                  uint64_t ntiles, uint64_t* __restrict__ agg, const T* __restrict__ SA,
@@ -245,8 +274,11 @@ __global__ void last_head_kernel(const T* __restrict__ A1, const T* __restrict__
                 if (!REFINE && !head) {
                     // equal packed windows: still a boundary if either suffix is shorter than 2k
                     const uint64_t two_k = ks.c1 + ks.c2;
-                    const T ysa = e ? SA[e - 1] : bd.prev3;
-                    head = (n_global - (uint64_t)SA[e] < two_k) || (n_global - (uint64_t)ysa < two_k);
+                    if (GSA) head = first_round_len<true, T>(n_global, (T)0, x1, x2, ks) < two_k;    // equal windows
+                    else {
+                        const T ysa = e ? SA[e - 1] : bd.prev3;
+                        head = (n_global - (uint64_t)SA[e] < two_k) || (n_global - (uint64_t)ysa < two_k);
+                    }
                 }
             }
         }
@@ -290,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void tile_scan_kernel(uint64_t* __restrict__
 // every bucket boundary (suffix_array.hpp:1353-1396; sentinel n elsewhere) and, per
 // tile, how many positions stay active (share their bucket) and how many buckets
 // hold more than one suffix (bucketing.hpp:98-118).
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP>
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
@@ -317,7 +349,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         const T q1 = in ? S1[e0 + ITEMS] : bd.next1, q2 = in ? S2[e0 + ITEMS] : bd.next2;
         const T qsa = in ? SA[e0 + ITEMS] : bd.next3;
         uint64_t c = window_lcp<T>(a1[ITEMS - 1], a2[ITEMS - 1], q1, q2, ks);
-        const uint64_t la = ng - (uint64_t)sa[ITEMS - 1], lb = ng - (uint64_t)qsa;
+        const uint64_t la = first_round_len<GSA, T>(ng, sa[ITEMS - 1], a1[ITEMS - 1], a2[ITEMS - 1], ks);
+        const uint64_t lb = first_round_len<GSA, T>(ng, qsa, q1, q2, ks);
         c = c < la ? c : la; c = c < lb ? c : lb;
         next_head = c < two_k;
     }
@@ -331,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         const uint64_t e = e0 + j;
         // common characters of the two 2k windows, the end marker differing from everything
         uint64_t c = window_lcp<T>(p1, p2, a1[j], a2[j], ks);
-        const uint64_t la = ng - (uint64_t)psa, lb = ng - (uint64_t)sa[j];
+        const uint64_t la = first_round_len<GSA, T>(ng, psa, p1, p2, ks), lb = first_round_len<GSA, T>(ng, sa[j], a1[j], a2[j], ks);
         c = c < la ? c : la; c = c < lb ? c : lb;
         const bool very_first = (e == 0) && !bd.has_prev;      // nothing sorts before this record
         const bool head = very_first || c < two_k;
@@ -348,7 +381,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         bool nh = true;
         if (bd.has_next) {
             uint64_t c = window_lcp<T>(a1[lastj], a2[lastj], bd.next1, bd.next2, ks);
-            const uint64_t la = ng - (uint64_t)sa[lastj], lb = ng - (uint64_t)bd.next3;
+            const uint64_t la = first_round_len<GSA, T>(ng, sa[lastj], a1[lastj], a2[lastj], ks);
+            const uint64_t lb = first_round_len<GSA, T>(ng, bd.next3, bd.next1, bd.next2, ks);
             c = c < la ? c : la; c = c < lb ? c : lb;
             nh = c < two_k;
         }
@@ -563,7 +597,7 @@ template <typename T>
 __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ SA,
                                    const T* __restrict__ Bsa, const T* __restrict__ ISA, uint64_t n,
                                    uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V,
-                                   unsigned long long* __restrict__ summary) {
+                                   unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
@@ -571,7 +605,9 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
         const T sa = SA[p];
         const uint64_t q = (uint64_t)sa + h;
         const T b1 = Bsa[p];
-        const T b2 = q < n ? (T)(ISA[q] + 1) : (T)0;   // 1-based bucket id, 0 = past the end
+        // 1-based bucket id, 0 = past the end of the text, or of the own string (suffix_array.hpp:1010-1016)
+        const bool inside = slen ? h < (uint64_t)slen[sa] : q < n;
+        const T b2 = inside ? (T)(ISA[q] + 1) : (T)0;
         K1[j] = b1; K2[j] = b2; V[j] = sa;
         o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2;
     }
@@ -766,6 +802,17 @@ template <typename T>
 __global__ void isa_finalize_kernel(T* __restrict__ ISA, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ISA[i] -= 1;
+}
+
+// slen[i] = off[t + 1] - i for the string t holding position i (off ascending, off[0] = 0, off[m] = n)
+template <typename T>
+__global__ void string_len_kernel(const uint64_t* __restrict__ off, uint64_t m, uint64_t n, T* __restrict__ slen) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t lo = 0, hi = m;                 // largest t with off[t] <= i
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+        slen[i] = (T)(off[lo + 1] - i);
+    }
 }
 
 // Left-branching characters (/root/reference/include/suffix_array.hpp:211-212, built there

@@ -66,6 +66,36 @@ class Context(object):
         self.check(self._lib.psacx_copy_d2h(self.handle, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
 
 
+def parse_stringset(strings, sep=None):
+    """simple_dstringset::parse (stringset.hpp:43-72) on one rank: returns (characters of all strings
+    back to back as uint8, uint64 offsets[m + 1]).  A flat buffer is cut at runs of `sep`; empty
+    strings do not exist in a set."""
+    if isinstance(strings, (list, tuple)):
+        parts = [np.frombuffer(x.encode("latin-1") if isinstance(x, str) else bytes(x), dtype=np.uint8) for x in strings]
+        parts = [p for p in parts if p.size]
+        off = np.zeros(len(parts) + 1, np.uint64)
+        if parts:
+            off[1:] = np.cumsum([p.size for p in parts])
+        return (np.concatenate(parts) if parts else np.zeros(0, np.uint8)), off
+    flat = strings
+    if isinstance(flat, str):
+        flat = flat.encode("latin-1")
+    flat = np.frombuffer(bytes(flat), dtype=np.uint8) if isinstance(flat, (bytes, bytearray)) \
+        else np.ascontiguousarray(flat, dtype=np.uint8)
+    s = ord('$') if sep is None else (ord(sep) if isinstance(sep, (str, bytes)) else int(sep))
+    keep = flat != s
+    text = np.ascontiguousarray(flat[keep])
+    # a string starts at every kept character whose predecessor is a separator (or the start)
+    prev_sep = np.ones(flat.size, bool)
+    prev_sep[1:] = ~keep[:-1]
+    starts_flat = np.nonzero(keep & prev_sep)[0]
+    kept_before = np.cumsum(keep) - keep            # kept characters before each flat position
+    off = np.zeros(starts_flat.size + 1, np.uint64)
+    off[:-1] = kept_before[starts_flat]
+    off[-1] = text.size
+    return text, off
+
+
 class SuffixArray(object):
     """suffix_array<char, index_t, LCP> for a whole text held by one rank.
 
@@ -141,6 +171,30 @@ class SuffixArray(object):
         else:
             fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
         self.ctx.check(fn(*args))
+        return self._after()
+
+    def construct_ss(self, strings, sep=None, k=0, profile=False):
+        """suffix_array::construct_ss(simple_dstringset&, alphabet) (suffix_array.hpp:267-363): the
+        generalized suffix array of a set of strings.  `strings` is a list of byte strings, or one
+        flat buffer cut at runs of `sep` (stringset.hpp:43-72, default '$' as stringset.hpp:147; gsac
+        passes '\\n', src/gsac.cpp:170).
+        Positions in local_SA count the characters of the strings back to back, separators left out."""
+        text, off = parse_stringset(strings, sep)
+        n = int(text.size)
+        if n == 0:
+            raise ValueError("empty input")
+        if self.index_bits == 32 and n > 0xFFFFFFFE:
+            raise PsacxError(-2, "input too long for the index type")
+        if self.lc:
+            raise ValueError("left-branching characters are not defined for string sets")
+        self.n = self.local_size = n
+        self.local_SA = np.empty(n, self.dtype)
+        self.local_B = np.empty(n, self.dtype)
+        self.local_LCP = np.empty(n, self.dtype) if self.lcp else np.zeros(0, self.dtype)
+        fn = getattr(self.ctx._lib, "psacx_construct_gsa_u%d" % self.index_bits)
+        self.ctx.check(fn(self.ctx.handle, _ptr(text), n, _ptr(off), int(off.size - 1), int(k), self._flags(True, profile),
+                          _ptr(self.local_SA), _ptr(self.local_B), _ptr(self.local_LCP) if self.lcp else None))
+        self.string_offsets = off
         return self._after()
 
     def construct_device(self, d_text, n, d_sa, d_isa, d_lcp=None, fast_resolval=True, k=0, profile=False, d_lc=None):

@@ -82,6 +82,21 @@ int main(int argc, char** argv) {
         CHECK(si.local_Lc == ilc);
     }
     {
+        // generalized suffix array (test/test_gsa.cpp:73-105, SimpleTiny)
+        std::vector<std::string> strs = {"abab", "baba"};
+        std::string flat = flatten_strings(strs);
+        simple_dstringset ss(flat.begin(), flat.end(), psacx::comm(0));
+        CHECK(ss.sizes.size() == 2 && ss.sum_sizes == 8);
+        psacx::alphabet<char> a = psacx::alphabet<char>::from_string("ab", psacx::comm(0));
+        suffix_array<char, uint64_t, true> sa((psacx::comm(0)));
+        sa.verbose = false;
+        sa.construct_ss(ss, a);
+        const std::vector<uint64_t> ex_gsa = {7, 2, 5, 0, 3, 6, 1, 4}, ex_lcp = {0, 1, 2, 3, 0, 1, 2, 3};
+        CHECK(sa.local_SA == ex_gsa);
+        CHECK(sa.local_LCP == ex_lcp);
+        CHECK(sa.alpha.sigma() == 2);
+    }
+    {
         // suffix tree node table (test/test_suffixtree.cpp:68-83)
         std::string s = "mississippi";
         suffix_array<char, uint64_t, true> sa((psacx::comm(0)));

@@ -88,6 +88,54 @@ def construct_lc(text, bits=32, fast=True, k=0):
     return dict(SA=SA, ISA=ISA, LCP=LCP, Lc=Lc)
 
 
+def flatten(strings):
+    """Strings back to back plus their offsets (what simple_dstringset holds, stringset.hpp:33-81)."""
+    parts = [as_text(x) for x in strings]
+    off = np.zeros(len(parts) + 1, np.uint64)
+    off[1:] = np.cumsum([p.size for p in parts])
+    return (np.concatenate(parts) if parts else np.zeros(0, np.uint8)), off
+
+
+def construct_ss(strings, bits=64, k=0, lcp=True):
+    """suffix_array<char, T, LCP>::construct_ss at p=1 (suffix_array.hpp:267-363)."""
+    t, off = flatten(strings)
+    n = t.size
+    dt = _dt(bits)
+    SA = np.zeros(n, dt); ISA = np.zeros(n, dt)
+    LCP = np.zeros(n, dt) if lcp else None
+    tr = (Trace * 256)()
+    trn = C.c_uint32(0)
+    f = getattr(lib(), "psac_ref_construct_ss_u%d" % bits)
+    rc = f(_p(t), C.c_uint64(n), _p(off), C.c_uint64(len(off) - 1), C.c_uint(k), _p(SA), _p(ISA),
+           _p(LCP) if lcp else None, tr, C.c_uint32(256), C.byref(trn))
+    if rc != 0:
+        raise RuntimeError("oracle construct_ss failed rc=%d" % rc)
+    trace = [(tr[i].h, tr[i].unfinished_buckets, tr[i].unfinished_elements, tr[i].phase)
+             for i in range(min(trn.value, 256))]
+    return dict(SA=SA, ISA=ISA, LCP=LCP, trace=trace, text=t, off=off)
+
+
+def gsa_by_definition(strings):
+    """Suffixes of every string (ended by a marker below all characters), ties by position; LCP
+    bounded by the string ends.  Quadratic; small inputs only."""
+    t, off = flatten(strings)
+    sufs = []
+    for s in range(len(off) - 1):
+        b, e = int(off[s]), int(off[s + 1])
+        for i in range(b, e):
+            sufs.append((bytes(t[i:e]), i))
+    sufs.sort()
+    SA = np.array([i for _, i in sufs], np.uint64)
+    LCP = np.zeros(len(sufs), np.uint64)
+    for j in range(1, len(sufs)):
+        a, b = sufs[j - 1][0], sufs[j][0]
+        c = 0
+        while c < len(a) and c < len(b) and a[c] == b[c]:
+            c += 1
+        LCP[j] = c
+    return SA, LCP
+
+
 def left_chars_by_definition(text, SA, LCP):
     """desa.hpp:262-264: Lc[i] = S[SA[i-1] + LCP[i]] (0 past the end and at i = 0)."""
     t = as_text(text)

@@ -431,3 +431,93 @@ def test_benchmark_clis(tmp_path):
         x = r.stdout.split()[0].split(";")
         assert x[0] == "100000" and x[1] == "1" and x[2] == "gansv-hip" and float(x[3]) > 0
     assert subprocess.run([sac], capture_output=True).returncode != 0
+
+
+def _gsa(ctx, strings, bits, lcp=True, k=0, sep=None):
+    import psac_amd
+    sa = psac_amd.SuffixArray(index_bits=bits, lcp=lcp, ctx=ctx)
+    sa.construct_ss(strings, sep=sep, k=k)
+    return sa
+
+
+def test_gsa_reference_vectors(ctx):
+    # test/test_gsa.cpp:73-105 (SimpleTiny) and :107-179 (IncRepeats*): the reference's expected arrays
+    from test_oracle_golden import GSA_REPEATS, repeat_inc_gsa, repeat_inc_glcp, repeat_inc_seq
+    for bits in (64, 32):
+        sa = _gsa(ctx, ["abab", "baba"], bits)
+        assert sa.local_SA.tolist() == [7, 2, 5, 0, 3, 6, 1, 4]
+        assert sa.local_LCP.tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+        for seq, reps in GSA_REPEATS:
+            sa = _gsa(ctx, repeat_inc_seq(seq, reps), bits)
+            assert sa.local_SA.tolist() == repeat_inc_gsa(len(seq), reps), (seq, reps, bits)
+            assert sa.local_LCP.tolist() == repeat_inc_glcp(len(seq), reps), (seq, reps, bits)
+            assert np.array_equal(sa.local_B[sa.local_SA.astype(np.int64)], np.arange(sa.n, dtype=sa.dtype))
+
+
+def test_gsa_against_oracle(ctx):
+    rng = np.random.RandomState(11)
+    sets = []
+    for sigma, m, lo, hi in ((4, 300, 1, 400), (2, 50, 1, 30), (1, 40, 1, 100), (26, 2000, 5, 60), (4, 1, 5000, 5001),
+                             (4, 3000, 1, 3), (90, 200, 100, 2000)):
+        sets.append([bytes(rng.randint(65, 65 + sigma, size=int(rng.randint(lo, hi))).astype(np.uint8)) for _ in range(m)])
+    # many copies of the same reads (deep ties) and reads that are prefixes of each other
+    base = bytes(inputs.dna(300, 4))
+    sets.append([base[:int(x)] for x in rng.randint(1, 300, size=500)])
+    sets.append([base] * 200)
+    for strings in sets:
+        for bits, k in ((32, 0), (64, 0), (32, 3)):
+            got = _gsa(ctx, strings, bits, k=k)
+            ref = O.construct_ss(strings, bits=bits, k=k)
+            assert np.array_equal(got.local_SA, ref["SA"]), (bits, k)
+            assert np.array_equal(got.local_B, ref["ISA"]), (bits, k)
+            assert np.array_equal(got.local_LCP, ref["LCP"]), (bits, k)
+        nol = _gsa(ctx, strings, 32, lcp=False)
+        assert np.array_equal(nol.local_SA, ref["SA"].astype(np.uint32))
+    # flat buffer with separator runs (stringset.hpp:43-72), the way gsac reads a file (src/gsac.cpp:169-170)
+    flat = b"\n\n" + b"\n".join(sets[0]) + b"\n\n\n" + b"\n".join(sets[3]) + b"\n"
+    got = _gsa(ctx, flat, 64, sep="\n")
+    ref = O.construct_ss(sets[0] + sets[3], bits=64)
+    assert np.array_equal(got.local_SA, ref["SA"]) and np.array_equal(got.local_LCP, ref["LCP"])
+
+
+def test_gsa_large_properties(ctx):
+    # 2^22 characters in ~40k reads: sortedness and LCP by direct comparison of neighbours on a sample,
+    # SA a permutation, ISA its inverse
+    rng = np.random.RandomState(3)
+    text = inputs.dna(1 << 22, 9)
+    cuts = np.unique(np.concatenate([[0, text.size], rng.randint(1, text.size, size=40000)]))
+    strings = [bytes(text[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    sa = _gsa(ctx, strings, 32)
+    n = text.size
+    SA = sa.local_SA.astype(np.int64)
+    assert np.array_equal(np.sort(SA), np.arange(n))
+    assert np.array_equal(sa.local_B[SA], np.arange(n, dtype=np.uint32))
+    ends = cuts[np.searchsorted(cuts, SA, side="right")]
+    for i in rng.randint(1, n, size=20000):
+        a = bytes(text[SA[i - 1]:ends[i - 1]]); b = bytes(text[SA[i]:ends[i]])
+        assert a < b or (a == b and SA[i - 1] < SA[i])
+        c = 0
+        while c < len(a) and c < len(b) and a[c] == b[c]:
+            c += 1
+        assert sa.local_LCP[i] == c
+
+
+def test_gsac_cli(tmp_path):
+    # src/gsac.cpp:139-204: gsac -f <file> [-l] [-c]; strings are the lines of the file
+    import subprocess
+    root = os.path.dirname(HERE)
+    gsac = os.path.join(root, "psac_amd", "bin", "gsac")
+    if not os.path.exists(gsac):
+        pytest.skip("gsac not built")
+    rng = np.random.RandomState(2)
+    strings = [bytes(rng.randint(65, 69, size=int(rng.randint(1, 200))).astype(np.uint8)) for _ in range(500)]
+    f = tmp_path / "reads.txt"
+    f.write_bytes(b"\n".join(strings) + b"\n")
+    r = subprocess.run([gsac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "g")], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS] GSA correct" in r.stdout and "PSAC time:" in r.stderr, r.stdout + r.stderr
+    ref = O.construct_ss(strings, bits=64)
+    assert np.array_equal(np.fromfile(str(tmp_path / "g.sa64"), dtype=np.uint64), ref["SA"])
+    assert np.array_equal(np.fromfile(str(tmp_path / "g.lcp64"), dtype=np.uint64), ref["LCP"])
+    r = subprocess.run([gsac, "-f", str(f), "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stdout
+    assert subprocess.run([gsac], capture_output=True).returncode != 0

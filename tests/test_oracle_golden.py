@@ -199,3 +199,69 @@ def test_left_branching_chars():
         base = O.construct(text, bits=bits, fast=fast, k=k)
         assert np.array_equal(r["SA"], base["SA"]) and np.array_equal(r["LCP"], base["LCP"])
         assert np.array_equal(r["Lc"], O.left_chars_by_definition(text, r["SA"], r["LCP"]))
+
+
+# ---- generalized suffix array (test/test_gsa.cpp)
+def repeat_inc_seq(seq, reps):                       # test/test_gsa.cpp:27-33
+    return [seq * (i + 1) for i in range(reps)]
+
+
+def repeat_inc_gsa(slen, reps):                      # test/test_gsa.cpp:35-52
+    m = reps * (reps + 1) // 2
+    gsa = [0] * (slen * m)
+    for i in range(slen):
+        o = i * m
+        for j in range(reps):
+            gsa[o] = i + slen * (j * (j + 1)) // 2
+            o += 1
+            for k in range(j + 2, reps + 1):
+                gsa[o] = gsa[o - 1] + k * slen
+                o += 1
+    return gsa
+
+
+def repeat_inc_glcp(slen, reps):                     # test/test_gsa.cpp:54-71
+    m = reps * (reps + 1) // 2
+    lcp = [0] * (slen * m)
+    for i in range(slen):
+        o = i * m
+        lcp[o] = 0
+        o += 1
+        for j in range(1, reps):
+            for _ in range(reps + 1 - j):
+                lcp[o] = j * slen - i
+                o += 1
+    return lcp
+
+
+GSA_REPEATS = [("ab", 3), ("abc", 3), ("a", 20), ("abc", 10), ("abcdef", 50)]   # test/test_gsa.cpp:156-179
+
+
+def test_gsa_simple_tiny():
+    # test/test_gsa.cpp:73-105
+    r = O.construct_ss(["abab", "baba"], bits=64)
+    assert r["SA"].tolist() == [7, 2, 5, 0, 3, 6, 1, 4]
+    assert r["LCP"].tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+
+
+@pytest.mark.parametrize("seq,reps", GSA_REPEATS)
+def test_gsa_inc_repeats(seq, reps):
+    # test/test_gsa.cpp:107-179: strings seq, seq^2, ..., seq^reps
+    for bits in (64, 32):
+        r = O.construct_ss(repeat_inc_seq(seq, reps), bits=bits)
+        assert r["SA"].tolist() == repeat_inc_gsa(len(seq), reps)
+        assert r["LCP"].tolist() == repeat_inc_glcp(len(seq), reps)
+        assert np.array_equal(r["ISA"][r["SA"].astype(np.int64)], np.arange(r["SA"].size, dtype=r["ISA"].dtype))
+
+
+def test_gsa_random_sets_against_definition():
+    rng = np.random.RandomState(5)
+    for trial in range(12):
+        m = int(rng.randint(1, 40))
+        sigma = int(rng.choice([1, 2, 4, 20]))
+        strings = [bytes(rng.randint(97, 97 + sigma, size=int(rng.randint(1, 60))).astype(np.uint8)) for _ in range(m)]
+        for bits, k in ((32, 0), (64, 0), (64, 2)):
+            r = O.construct_ss(strings, bits=bits, k=k)
+            SA, LCP = O.gsa_by_definition(strings)
+            assert np.array_equal(r["SA"].astype(np.uint64), SA), (trial, bits, k)
+            assert np.array_equal(r["LCP"].astype(np.uint64), LCP), (trial, bits, k)
