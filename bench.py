@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch of the dominant kernel from the PMC counters of the committed profile
 # (profiles/): FETCH_SIZE doubled (the gfx950 correction for coalesced streams) + WRITE_SIZE.
 # Valid for the default workload only (2^28 uint32 records per launch).
-TRAFFIC_PER_LAUNCH = 6553287372      # profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
+TRAFFIC_PER_LAUNCH = {1: 6553287372}   # three-word form, profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
 
 
 def parse():
@@ -70,8 +70,11 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
     w = bits // 8
     ms_per_step = dt / a.steps * 1e3
     value = world * n * a.steps / dt / 1e6
-    dom = 1 if scat_bytes[1] >= scat_bytes[0] else 0
-    kname = ("radix_scatter3_kernel" if dom else "radix_scatter_kernel")
+    dom = max(range(len(scat_bytes)), key=lambda q: scat_bytes[q])
+    kname = ("radix_scatter_kernel (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort, look-back form)",
+             "radix_scatter3_kernel (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
+             "radix_scatter3_kernel<two-word> (one 8-bit digit pass of the first round's (B1,idx) prefix sort)")[dom]
+    rec_words = 2 if dom == 2 else 3
     achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
@@ -82,14 +85,14 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                                "SA+%s on %d x MI355X" % (n >> 20, a.alphabet, a.seed, (world * n) >> 20, bits,
                                                          "ISA" if a.no_lcp else "ISA+LCP", world),
                    "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism},
-        "roofline": {"bound": "hbm", "kernel": kname + " (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
+        "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
                      "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                      "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
-                     "bytes_per_record_per_pass": 6 * w,
-                     "traffic": TRAFFIC_PER_LAUNCH if (world == 1 and dom == 1 and n == (1 << 28) and bits == 32) else None},
+                     "bytes_per_record_per_pass": 2 * rec_words * w,
+                     "traffic": TRAFFIC_PER_LAUNCH.get(dom) if (world == 1 and n == (1 << 28) and bits == 32) else None},
     }
     if phases:
         out["phase_ms_last_step"] = phases
@@ -137,7 +140,7 @@ def main_distributed(a, rank, world, local_rank):
     dt = float(t.item())
     s = ops.stats()
     if rank == 0:
-        out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3], list(s.scatter_bytes),
+        out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3, s.ms_sort_scatter2], list(s.scatter_bytes),
                      list(s.scatter_launches), None, res["k"], res["l"], len(res["rounds"]),
                      "block-partitioned text, 1 rank per GPU, RCCL all-to-all (sort shuffle, ISA scatter, B2 fetch)")
         print(json.dumps(out))
@@ -179,12 +182,12 @@ def main():
     # dominant kernel: the scatter kernel of a radix pass.  Large sorts use
     # radix_scatter3_kernel (index 1), small ones radix_scatter_kernel (index 0); the
     # roofline is quoted on whichever moved more bytes in the timed region.
-    scat_ms = [0.0, 0.0]; scat_bytes = [0, 0]; scat_launches = [0, 0]
+    scat_ms = [0.0, 0.0, 0.0]; scat_bytes = [0, 0, 0]; scat_launches = [0, 0, 0]
     t0 = time.perf_counter()
     for _ in range(a.steps):
         s = step(True)
-        scat_ms[0] += s.ms_sort_scatter; scat_ms[1] += s.ms_sort_scatter3
-        for q in (0, 1):
+        scat_ms[0] += s.ms_sort_scatter; scat_ms[1] += s.ms_sort_scatter3; scat_ms[2] += s.ms_sort_scatter2
+        for q in (0, 1, 2):
             scat_bytes[q] += s.scatter_bytes[q]; scat_launches[q] += s.scatter_launches[q]
     barrier()
     dt = time.perf_counter() - t0
@@ -194,7 +197,7 @@ def main():
     ctx.d2h(head, d_lcp if not a.no_lcp else d_sa)
 
     phases = {"total": round(s.ms_total, 3), "alphabet": round(s.ms_alphabet, 3), "kmer": round(s.ms_kmer, 3),
-              "sort_hist": round(s.ms_sort_hist, 3), "sort_scatter": round(s.ms_sort_scatter + s.ms_sort_scatter3, 3),
+              "sort_hist": round(s.ms_sort_hist, 3), "sort_scatter": round(s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, 3),
               "sort_tile_hist": round(s.ms_sort_tilehist, 3), "rebucket": round(s.ms_rebucket, 3),
               "isa_scatter": round(s.ms_isa_scatter, 3), "gather": round(s.ms_gather, 3), "compact": round(s.ms_compact, 3),
               "rmq_build": round(s.ms_rmq_build, 3)}

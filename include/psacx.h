@@ -70,11 +70,12 @@ typedef struct psacx_stats {
     /* the radix scatter-pass kernel, counted per form: [0] = single-sweep look-back form
        (radix_scatter_kernel, small inputs), [1] = three-kernel form (radix_scatter3_kernel,
        large inputs; ms_sort_scatter3 times only that kernel, its per-tile histogram and
-       offset scans are in ms_sort_tilehist) */
-    double ms_sort_scatter3, ms_sort_tilehist;
-    uint64_t scatter_launches[2];  /* kernels launched */
-    uint64_t scatter_records[2];   /* records moved by them (sum over launches) */
-    uint64_t scatter_bytes[2];     /* algorithmic bytes: 2 * 3w per record */
+       offset scans are in ms_sort_tilehist), [2] = three-kernel form over two-word records
+       (B1, idx): the prefix sort that opens the first round (ms_sort_scatter2) */
+    double ms_sort_scatter3, ms_sort_tilehist, ms_sort_scatter2;
+    uint64_t scatter_launches[3];  /* kernels launched */
+    uint64_t scatter_records[3];   /* records moved by them (sum over launches) */
+    uint64_t scatter_bytes[3];     /* algorithmic bytes: read + write of the record, 2 * 3w ([2]: 2 * 2w) per record */
     uint64_t hist_bytes;           /* algorithmic bytes of the histogram kernels: 2w per record */
     uint64_t workspace_bytes;      /* HBM held by the ctx */
 } psacx_stats;

@@ -39,9 +39,9 @@ class Stats(C.Structure):
                 ("ms_sort_hist", C.c_double), ("ms_sort_scatter", C.c_double), ("ms_rebucket", C.c_double),
                 ("ms_isa_scatter", C.c_double), ("ms_gather", C.c_double), ("ms_compact", C.c_double),
                 ("ms_rmq_build", C.c_double), ("ms_finalize", C.c_double),
-                ("ms_sort_scatter3", C.c_double), ("ms_sort_tilehist", C.c_double),
-                ("scatter_launches", C.c_uint64 * 2), ("scatter_records", C.c_uint64 * 2),
-                ("scatter_bytes", C.c_uint64 * 2), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+                ("ms_sort_scatter3", C.c_double), ("ms_sort_tilehist", C.c_double), ("ms_sort_scatter2", C.c_double),
+                ("scatter_launches", C.c_uint64 * 3), ("scatter_records", C.c_uint64 * 3),
+                ("scatter_bytes", C.c_uint64 * 3), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
 
 class PsacxError(RuntimeError):

@@ -135,7 +135,8 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
 // totals of the per-tile activity counts, then the compacted list of still-active positions
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
-                uint64_t* active, uint64_t* unf_buckets, uint64_t capacity) {
+                uint64_t* active, uint64_t* unf_buckets, uint64_t capacity, unsigned shift = 0,
+                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr) {
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     {
@@ -152,8 +153,14 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     *unf_buckets = h_cnt[1];
     if (*active > 0 && *active <= capacity) {
         ProfScope ps(c, TC_COMPACT);
-        hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0);
+        if (payload)
+            hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
+                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0, shift,
+                               payload, out_id, out_payload);
+        else
+            hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
+                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0, shift,
+                               (const T*)nullptr, (T*)nullptr, (T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
     }
     return PSACX_OK;
@@ -282,11 +289,27 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     ks.c2 = 2 * k - ks.c1;
     ks.spec = gsa ? 0 : std::min<uint64_t>(2ull * k - 1, n);
 
+    // ---- first rank-pair sort (idxsort.hpp:23-83); payload = text position -> SA.
+    // Two stages when the leading bits of word 1 already separate almost every suffix (random DNA,
+    // 32-bit words: 4^16 windows for 2^28 suffixes; 64-bit words: the top 40 bits for 2^32): stage 1
+    // sorts (word 1, suffix) pairs on those bits only -- two thirds of the bytes per pass and far
+    // fewer passes -- and stage 2 orders the suffixes that still tie by the full window.
+    const unsigned bits_w1 = ks.c1 * lc, bits_w2 = ks.c2 * lc;
+    unsigned lead = bits_for(n - 1) + 3;                      // leading bits stage 1 sorts on (ties: ~ n / 2^lead)
+    lead = (lead + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
+    const bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
+                           lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
+    const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
+
     // In the diet layout the sorted keys must end up in the workspace set x (the other set is the
     // LCP / ISA output), so an odd number of passes starts from y.
-    const unsigned planned = (ks.c1 * lc + RADIX_BITS - 1) / RADIX_BITS + (ks.c2 * lc + RADIX_BITS - 1) / RADIX_BITS;
+    const unsigned planned = two_stage ? lead / RADIX_BITS
+                                       : (bits_w1 + RADIX_BITS - 1) / RADIX_BITS + (bits_w2 + RADIX_BITS - 1) / RADIX_BITS;
     const bool start_y = w.diet && (planned & 1u);
     SortBufs<T> first_in = start_y ? w.y : w.x, first_alt = start_y ? w.x : w.y;
+    // word 2 of every record is sorted along in one stage; with two stages it is not kept at all
+    // (the few suffixes that need it read it from the text)
+    T* const k2rec = two_stage ? (T*)nullptr : first_in.k2;
 
     // ---- first-round keys: the 2k-character window at every position, packed (kmer.hpp:119-177,
     //      shifting.hpp:33-122; see key_pairs_kernel for the packing)
@@ -296,29 +319,101 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
         if (gsa)
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
-                               tab, ks, first_in.k1, first_in.k2, w.sc.d_partials, d_slen);
+                               tab, ks, first_in.k1, k2rec, w.sc.d_partials, d_slen);
         else
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
-                               tab, ks, first_in.k1, first_in.k2, w.sc.d_partials, (const T*)nullptr);
+                               tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
     }
 
-    // ---- first rank-pair sort (idxsort.hpp:23-83); payload = text position -> SA
     psacx_round* r0 = &st.rounds[0];
     std::memset(r0, 0, sizeof(*r0));
     SortBufs<T> sorted;
-    PSACX_TRY(pair_sort<T>(c, w.sc, first_in, first_alt, n, /*iota=*/true, ks.c1 * lc, ks.c2 * lc, w.diet ? (T*)nullptr : d_sa,
-                           &sorted, r0, ks.spec, n, /*summary_ready=*/true));
-    if (w.diet) {
-        // keys into the workspace set if a skipped pass changed the parity; SA out of the scratch payload
-        if (sorted.k1 != w.x.k1) {
-            PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-            PSACX_HIP(c, hipMemcpyAsync(w.x.k2, sorted.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-            sorted.k1 = w.x.k1; sorted.k2 = w.x.k2;
+    if (two_stage) {
+        SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
+        PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
+                               ks.spec, n, /*summary_ready=*/true, lo1));
+        if (w.diet) {
+            if (sorted.k1 != w.x.k1) {        // a skipped pass changed the parity
+                PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                sorted.k1 = w.x.k1;
+            }
+            if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         }
-        if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        sorted.v = d_sa;
+        T* const S1 = sorted.k1;
+        T* const S2 = w.diet ? w.x.k2 : first_alt.k2;        // word 2 in sorted order, filled for the ties only
+        T* const free_k1 = (S1 == w.x.k1) ? w.y.k1 : w.x.k1;
+        // stage 2, common case: all tie groups are tiny and get ordered in place
+        constexpr int TB = 256, TI = 16, TG = 8;
+        unsigned long long* d_big = reinterpret_cast<unsigned long long*>(w.d_totals + 2);
+        unsigned long long* h_big = reinterpret_cast<unsigned long long*>(c->pinned + 64);
+        {
+            ProfScope ps(c, TC_GATHER);
+            PSACX_HIP(c, hipMemsetAsync(d_big, 0, sizeof(unsigned long long), c->stream));
+            const uint64_t nb = (n + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
+            if (!getenv("PSACX_TIES_RADIX"))
+                hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, S1, d_sa, S2, n, lo1,
+                                   d_text, n, tab, ks, d_big);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        PSACX_HIP(c, hipMemcpyAsync(h_big, d_big, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        if (*h_big || getenv("PSACX_TIES_RADIX")) {
+            // some group is long (repetitive text): compact all ties and radix-sort them by the full window
+            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+            {
+                ProfScope ps(c, TC_COMPACT);
+                hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+                                   c->stream, S1, n, (T)0, (T)0, w.d_nact, lo1);
+                PSACX_HIP(c, hipGetLastError());
+                PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
+            }
+            // two record sets for the ties out of buffers that are idle until the rebucket step; the
+            // compaction already fills word 1 and the suffix of set a
+            SortBufs<T> a, b, s2;
+            if (w.diet) { a = w.ry; b.k1 = w.bsa; b.k2 = w.x.v; b.v = free_k1; }
+            else { a.k1 = free_k1; a.k2 = first_alt.v; a.v = first_in.v; b.k1 = w.bsa; b.k2 = w.pos_b; b.v = d_isa; }
+            uint64_t ties = 0, unused = 0;
+            PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &unused, w.cap_active, lo1, d_sa, a.k1, a.v));
+            if (ties > w.cap_active) {
+                c->hip_err = "too many unresolved suffixes for the reduced-memory layout";
+                return PSACX_ENOMEM;
+            }
+            if (ties) {
+                {
+                    ProfScope ps(c, TC_GATHER);
+                    const int gg = grid_for(c, ties, 256, 16);
+                    hipLaunchKernelGGL((gather_prefix_ties_kernel<T, 256>), dim3(gg), dim3(256), 0, c->stream, ties, a.k1, a.v,
+                                       d_text, n, tab, ks, a.k2, w.sc.d_partials);
+                    PSACX_HIP(c, hipGetLastError());
+                    PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
+                }
+                psacx_round r1;
+                std::memset(&r1, 0, sizeof(r1));
+                PSACX_TRY(pair_sort<T>(c, w.sc, a, b, ties, /*iota=*/false, bits_w1, bits_w2, nullptr, &s2, &r1, 0, 0,
+                                       /*summary_ready=*/true));
+                r0->sort_passes += r1.sort_passes; r0->sort_passes_skipped += r1.sort_passes_skipped;
+                ProfScope ps(c, TC_GATHER);
+                hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, ties, 256, 16)), dim3(256), 0, c->stream,
+                                   w.pos_a, ties, lo1 ? s2.k1 : (const T*)nullptr, s2.k2, s2.v, S1, S2, d_sa);
+                PSACX_HIP(c, hipGetLastError());
+            }
+        }
+        sorted.k2 = S2; sorted.v = d_sa;
+    } else {
+        PSACX_TRY(pair_sort<T>(c, w.sc, first_in, first_alt, n, /*iota=*/true, bits_w1, bits_w2, w.diet ? (T*)nullptr : d_sa,
+                               &sorted, r0, ks.spec, n, /*summary_ready=*/true));
+        if (w.diet) {
+            // keys into the workspace set if a skipped pass changed the parity; SA out of the scratch payload
+            if (sorted.k1 != w.x.k1) {
+                PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                PSACX_HIP(c, hipMemcpyAsync(w.x.k2, sorted.k2, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                sorted.k1 = w.x.k1; sorted.k2 = w.x.k2;
+            }
+            if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            sorted.v = d_sa;
+        }
     }
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)

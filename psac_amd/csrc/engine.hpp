@@ -18,7 +18,7 @@
 namespace psacx {
 
 enum TimerCat {
-    TC_ALPHABET = 0, TC_KMER, TC_SORT_HIST, TC_SORT_SCATTER, TC_SORT_SCATTER3, TC_SORT_TILEHIST, TC_REBUCKET, TC_ISA_SCATTER,
+    TC_ALPHABET = 0, TC_KMER, TC_SORT_HIST, TC_SORT_SCATTER, TC_SORT_SCATTER3, TC_SORT_SCATTER2, TC_SORT_TILEHIST, TC_REBUCKET, TC_ISA_SCATTER,
     TC_GATHER, TC_COMPACT, TC_RMQ_BUILD, TC_FINALIZE, TC_TOTAL, TC_COUNT
 };
 
@@ -83,6 +83,7 @@ inline void prof_accumulate(psacx_ctx* c) {
     psacx_stats& s = c->stats;
     s.ms_sort_hist += acc[TC_SORT_HIST]; s.ms_sort_scatter += acc[TC_SORT_SCATTER];
     s.ms_sort_scatter3 += acc[TC_SORT_SCATTER3]; s.ms_sort_tilehist += acc[TC_SORT_TILEHIST];
+    s.ms_sort_scatter2 += acc[TC_SORT_SCATTER2];
     c->ev_used = 0;
 }
 
@@ -97,6 +98,7 @@ inline void prof_collect(psacx_ctx* c) {
     s.ms_alphabet = acc[TC_ALPHABET]; s.ms_kmer = acc[TC_KMER]; s.ms_sort_hist = acc[TC_SORT_HIST];
     s.ms_sort_scatter = acc[TC_SORT_SCATTER]; s.ms_sort_scatter3 = acc[TC_SORT_SCATTER3];
     s.ms_sort_tilehist = acc[TC_SORT_TILEHIST]; s.ms_rebucket = acc[TC_REBUCKET];
+    s.ms_sort_scatter2 = acc[TC_SORT_SCATTER2];
     s.ms_isa_scatter = acc[TC_ISA_SCATTER]; s.ms_gather = acc[TC_GATHER]; s.ms_compact = acc[TC_COMPACT];
     s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
 }
@@ -253,10 +255,15 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
         hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs,
                            const_cast<unsigned long long*>(base));
     }
-    ProfScope ps(c, TC_SORT_SCATTER3);
-    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                       ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                       reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
+    ProfScope ps(c, ko_in ? TC_SORT_SCATTER3 : TC_SORT_SCATTER2);
+    if (ko_in)
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
+    else            // two-word records (k1, v): the prefix sort of the first round
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
 }
 
 template <typename T>
@@ -319,13 +326,16 @@ inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
 template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
-              uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false) {
+              uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0) {
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
-    const PassPlan plan = make_plan((int)bits1, (int)bits2);
+    if (!in.k2) bits2 = 0;
+    if (!in.k2 && !summary_ready) return PSACX_EINVAL;
+    const PassPlan plan = make_plan((int)bits1, (int)bits2, (int)lo1);
     // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
     // single-sweep look-back form for small ones where launch count matters more
-    const bool three = sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21);
+    // (records without a second key word exist only in the three-kernel form)
+    const bool three = !in.k2 || (sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21));
     bool skip[MAX_PASSES];
     int n_exec = 0;
     if (three) {
@@ -423,9 +433,10 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             fprintf(stderr, "[psacx sort dbg] pass %d n=%llu tiles=%llu cycles/tile: load+rank %.0f scan %.0f lookback %.0f key %.0f key2 %.0f val %.0f\n",
                     p, (unsigned long long)n, (unsigned long long)ntiles, acc[0] / ns, acc[1] / ns, acc[2] / ns, acc[3] / ns, acc[4] / ns, acc[5] / ns);
         }
-        c->stats.scatter_launches[three ? 1 : 0] += 1;
-        c->stats.scatter_records[three ? 1 : 0] += n;
-        c->stats.scatter_bytes[three ? 1 : 0] += 6ull * sizeof(T) * n;
+        const int form = !in.k2 ? 2 : (three ? 1 : 0);
+        c->stats.scatter_launches[form] += 1;
+        c->stats.scatter_records[form] += n;
+        c->stats.scatter_bytes[form] += (in.k2 ? 6ull : 4ull) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
     }

@@ -29,12 +29,14 @@ struct PassPlan {
 };
 
 // bits1 / bits2: significant low bits of key word 1 (major) and key word 2 (minor)
-inline PassPlan make_plan(int bits1, int bits2) {
+// lo1: the low lo1 bits of word 1 are not sorted on (prefix sort by the leading bits only)
+inline PassPlan make_plan(int bits1, int bits2, int lo1 = 0) {
     PassPlan p;
     p.n_pass = 0;
     for (int w = 1; w >= 0; --w) {
-        const int per = ((w ? bits2 : bits1) + RADIX_BITS - 1) / RADIX_BITS;
-        for (int i = 0; i < per; ++i) { p.word[p.n_pass] = w; p.shift[p.n_pass] = i * RADIX_BITS; p.n_pass++; }
+        const int lo = w ? 0 : lo1;
+        const int per = ((w ? bits2 : bits1) - lo + RADIX_BITS - 1) / RADIX_BITS;
+        for (int i = 0; i < per; ++i) { p.word[p.n_pass] = w; p.shift[p.n_pass] = lo + i * RADIX_BITS; p.n_pass++; }
     }
     return p;
 }
@@ -122,7 +124,8 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 // precomputed (tile_excl row of this tile + slab_excl row of its slab).
 // EXT: the 8-bit class of a record comes from a separate array (dsrc, not moved) instead of a key
 // digit: one such pass partitions records by an externally computed destination.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false>
+// NOKO: records of two words (digit word + payload); ko_in / ko_out are not touched.
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
@@ -157,7 +160,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     if (!LB && tid < RADIX)
         pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / SLAB_TILES) * RADIX + tid] +
                    (uint64_t)digit_base[tid];
-    T kd[ITEMS], ko[ITEMS], vv[ITEMS];
+    T kd[ITEMS], ko[NOKO ? 1 : ITEMS], vv[ITEMS];
     unsigned char cls[EXT ? ITEMS : 1];
     const unsigned wbase = wave * (WAVE * ITEMS) + lane;
     if (EXT) {
@@ -173,10 +176,12 @@ __device__ __forceinline__ void radix_scatter_tile(
         const unsigned loc = wbase + i * WAVE;
         kd[i] = (FULL || loc < count) ? pkd[loc] : (T)0;
     }
+    if (!NOKO) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const unsigned loc = wbase + i * WAVE;
-        ko[i] = (FULL || loc < count) ? pko[loc] : (T)0;
+        for (int i = 0; i < ITEMS; ++i) {
+            const unsigned loc = wbase + i * WAVE;
+            ko[NOKO ? 0 : i] = (FULL || loc < count) ? pko[loc] : (T)0;
+        }
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -267,16 +272,18 @@ __device__ __forceinline__ void radix_scatter_tile(
     }
     __syncthreads();
     if (stamp) mydbg[4] = __builtin_amdgcn_s_memtime();
+    if (!NOKO) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = ko[i];
-    __syncthreads();
+        for (int i = 0; i < ITEMS; ++i)
+            if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = ko[NOKO ? 0 : i];
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned p = tid + j * BLOCK;
-        if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned p = tid + j * BLOCK;
+            if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (stamp) mydbg[5] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
@@ -435,11 +442,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                         spec, spec_n, tile_excl, slab_excl, dsrc);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                          spec, spec_n, tile_excl, slab_excl, dsrc);
 }

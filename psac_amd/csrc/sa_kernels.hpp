@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
         }
     }
     store_run<T, ITEMS>(C1, j0, n, o1);
-    store_run<T, ITEMS>(C2, j0, n, o2);
+    if (C2) store_run<T, ITEMS>(C2, j0, n, o2);      // (not kept when the first round sorts on word 1 only)
     T so1 = 0, sa1 = ~(T)0, so2 = 0, sa2 = ~(T)0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
@@ -527,10 +527,13 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const T* __restri
 // still active when it shares its id with a neighbour (suffix_array.hpp:925-965).
 // pos_in == nullptr means list entry j sits at SA position j.  offset[tile] is the
 // exclusive scan of the per-tile active counts the rebucket kernels produced.
-template <typename T, int BLOCK, int ITEMS>
+// EMIT: also writes ids[e] and payload[e] of every active entry to out_id / out_payload (list order).
+template <typename T, int BLOCK, int ITEMS, bool EMIT = false>
 __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
-    const uint64_t* __restrict__ offset, uint64_t pos_off, T prev_id, T next_id) {
+    const uint64_t* __restrict__ offset, uint64_t pos_off, T prev_id, T next_id, unsigned shift = 0,
+    const T* __restrict__ payload = nullptr, T* __restrict__ out_id = nullptr, T* __restrict__ out_payload = nullptr) {
+    // shift: only the bits above `shift` of an id count (ties of a prefix sort by the leading bits)
     // prev_id / next_id: bucket id of the list entry just before / after this block (0 = none);
     // pos_off: SA position of entry 0 when pos_in is null
     constexpr int TILE = BLOCK * ITEMS;
@@ -539,14 +542,19 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
     T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]; ids are >= 1, so 0 never matches
+    T raw[EMIT ? ITEMS : 1];
     {
         T mid[ITEMS];
         load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j];
+        for (int j = 0; j < ITEMS; ++j) { v[j + 1] = mid[j]; if (EMIT) raw[EMIT ? j : 0] = mid[j]; }
         v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
         v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (e0 + ITEMS == cnt ? next_id : (T)0);
         if (e0 < cnt && e0 + ITEMS > cnt) v[(unsigned)(cnt - e0) + 1] = next_id;   // block ends inside this run
+        if (shift) {
+#pragma unroll
+            for (int j = 0; j < ITEMS + 2; ++j) v[j] >>= shift;
+        }
     }
     unsigned act = 0, nact = 0;
 #pragma unroll
@@ -560,9 +568,19 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     uint64_t o = offset[tile] + excl;
     T ps[ITEMS];
     if (pos_in) load_run<T, ITEMS>(pos_in, e0, cnt, ps, (T)0);
+    T pl[EMIT ? ITEMS : 1];
+    if (EMIT && nact) {
+        T tmp[ITEMS];
+        load_run<T, ITEMS>(payload, e0, cnt, tmp, (T)0);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) pl[EMIT ? j : 0] = tmp[j];
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if (act & (1u << j)) pos_out[o++] = pos_in ? ps[j] : (T)(pos_off + e0 + j);
+        if (act & (1u << j)) {
+            if (EMIT) { out_id[o] = raw[EMIT ? j : 0]; out_payload[o] = pl[EMIT ? j : 0]; }
+            pos_out[o++] = pos_in ? ps[j] : (T)(pos_off + e0 + j);
+        }
     }
 }
 
@@ -570,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
 // do not get the counts from a rebucket kernel
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict__ ids, uint64_t cnt, T prev_id, T next_id,
-                                                             uint64_t* __restrict__ n_active) {
+                                                             uint64_t* __restrict__ n_active, unsigned shift = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
     const uint64_t e0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
@@ -583,6 +601,10 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
         v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
         v[ITEMS + 1] = (e0 + ITEMS < cnt) ? ids[e0 + ITEMS] : (e0 + ITEMS == cnt ? next_id : (T)0);
         if (e0 < cnt && e0 + ITEMS > cnt) v[(unsigned)(cnt - e0) + 1] = next_id;
+        if (shift) {
+#pragma unroll
+            for (int j = 0; j < ITEMS + 2; ++j) v[j] >>= shift;
+        }
     }
     unsigned nact = 0;
 #pragma unroll
@@ -590,6 +612,134 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
         if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) ++nact;
     const unsigned t = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
     if (threadIdx.x == 0) n_active[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------ first round in two stages
+// When the first key word alone separates almost all suffixes (2^(c1 lc) >> n), the first sort
+// moves only (word 1, suffix) and the few suffixes that still tie on word 1 are ordered by the
+// full window afterwards.  K2rec holds word 2 in RECORD order (see record_suffix).
+// word 2 of the packed window of suffix `sa`, straight from the text (same packing as key_pairs_kernel)
+template <typename T>
+__device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
+                                          const KeyShape& ks, uint64_t sa) {
+    T w2 = 0;
+    for (unsigned t = 0; t < ks.c2; ++t) {
+        const uint64_t q = sa + ks.c1 + t;
+        w2 = (T)(w2 << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
+    }
+    return w2;
+}
+
+// Stage 2, common case: every group of suffixes that tie on the leading bits of word 1 is tiny.
+// The thread that owns the first member of a group of at most G loads the group, fetches word 2 of
+// each member from the text, orders the group by (word 1, word 2) with a stable odd-even
+// transposition network and writes it back in place (S2 is filled for tied positions only).
+// Groups longer than G are left alone and counted in big[0]; the caller then falls back to the
+// compaction + radix path for all ties.
+template <typename T, int BLOCK, int ITEMS, int G>
+__global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, T* __restrict__ SA, T* __restrict__ S2,
+                                                            uint64_t n, unsigned lo1, const uint8_t* __restrict__ text,
+                                                            uint64_t n_text, CodeTable tab, KeyShape ks,
+                                                            unsigned long long* __restrict__ big) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint16_t ctab[256];
+    __shared__ unsigned leaders[TILE / 2 + 1];     // tile-relative position of the first member of every group
+    __shared__ unsigned n_leaders;
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    if (threadIdx.x == 0) n_leaders = 0;
+    __syncthreads();
+    // pass 1 (streaming): find the groups that start in this tile
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t e0 = t0 + (uint64_t)threadIdx.x * ITEMS;
+    if (e0 < n) {
+        T v[ITEMS + 2];                 // leading bits of S1[e0-1 .. e0+ITEMS]
+        T mid[ITEMS];
+        load_run<T, ITEMS>(S1, e0, n, mid, (T)0);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j] >> lo1;
+        v[0] = e0 ? (T)(S1[e0 - 1] >> lo1) : (T)0;
+        v[ITEMS + 1] = e0 + ITEMS < n ? (T)(S1[e0 + ITEMS] >> lo1) : (T)0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t e = e0 + j;
+            const bool start = (e == 0) || v[j] != v[j + 1];
+            if (e + 1 < n && start && v[j + 2] == v[j + 1]) leaders[atomicAdd(&n_leaders, 1u)] = (unsigned)(e - t0);
+        }
+    }
+    __syncthreads();
+    // pass 2: one thread per group, all loads of a step issued together
+    const unsigned ng = n_leaders;
+    for (unsigned g = threadIdx.x; g < ng; g += BLOCK) {
+        const uint64_t e = t0 + leaders[g];
+        T k1[G + 1], sa[G];
+#pragma unroll
+        for (int i = 0; i <= G; ++i) k1[i] = e + i < n ? S1[e + i] : (T)0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) sa[i] = e + i < n ? SA[e + i] : (T)0;
+        const T key = k1[0] >> lo1;
+        unsigned len = 1;
+#pragma unroll
+        for (int i = 1; i <= G; ++i) if (len == (unsigned)i && e + i < n && (T)(k1[i] >> lo1) == key) len = i + 1;
+        if (len > (unsigned)G) { atomicAdd(big, 1ull); continue; }
+        T k2[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if ((unsigned)i < len) k2[i] = window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
+            else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
+        }
+        // adjacent exchanges of strictly descending neighbours only: stable
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+#pragma unroll
+            for (int i = r & 1; i + 1 < G; i += 2) {
+                const bool sw = k1[i] > k1[i + 1] || (k1[i] == k1[i + 1] && k2[i] > k2[i + 1]);
+                const T a1 = sw ? k1[i + 1] : k1[i], b1 = sw ? k1[i] : k1[i + 1];
+                const T a2 = sw ? k2[i + 1] : k2[i], b2 = sw ? k2[i] : k2[i + 1];
+                const T a3 = sw ? sa[i + 1] : sa[i], b3 = sw ? sa[i] : sa[i + 1];
+                k1[i] = a1; k1[i + 1] = b1; k2[i] = a2; k2[i + 1] = b2; sa[i] = a3; sa[i + 1] = b3;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if ((unsigned)i < len) {
+                if (lo1) S1[e + i] = k1[i];
+                S2[e + i] = k2[i]; SA[e + i] = sa[i];
+            }
+        }
+    }
+}
+
+// Stage 2, fallback: K1 / V are word 1 and suffix of the tied records (written by the compaction);
+// fetches word 2 from the text.
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt, const T* __restrict__ K1, const T* __restrict__ V,
+                                          const uint8_t* __restrict__ text, uint64_t n_text, CodeTable tab, KeyShape ks,
+                                          T* __restrict__ K2, unsigned long long* __restrict__ summary) {
+    __shared__ uint16_t ctab[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const T k1 = K1[j], k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        K2[j] = k2;
+        o1 |= k1; a1 &= k1; o2 |= k2; a2 &= k2;
+    }
+    key_summary_add<T>(summary, o1, a1, o2, a2);
+}
+
+// the tie groups are contiguous in SA order and pos[] ascends, so the sorted records go back in list order
+// (S1 is rewritten as well when stage 1 left the low bits of word 1 unsorted)
+template <typename T>
+__global__ void scatter_prefix_ties_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ K1s,
+                                           const T* __restrict__ K2s, const T* __restrict__ Vs, T* __restrict__ S1,
+                                           T* __restrict__ S2, T* __restrict__ SA) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const uint64_t p = pos[j];
+        if (K1s) S1[p] = K1s[j];
+        S2[p] = K2s[j]; SA[p] = Vs[j];
+    }
 }
 
 // ------------------------------------------------------------------ sparse B2 fetch

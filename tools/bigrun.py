@@ -30,14 +30,15 @@ for it in range(steps):
     t0 = time.time()
     s = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp, profile=True)
     dt = time.time() - t0
-    q = 1 if s.scatter_bytes[1] else 0
-    ms = s.ms_sort_scatter3 if q else s.ms_sort_scatter
+    q = max(range(3), key=lambda i: s.scatter_bytes[i])       # dominant form of the scatter kernel
+    ms = (s.ms_sort_scatter, s.ms_sort_scatter3, s.ms_sort_scatter2)[q]
     print(json.dumps({"n": n, "bits": bits, "kind": kind, "seconds": round(dt, 3), "MChars_per_s": round(n / dt / 1e6, 1),
                       "k": s.k, "rounds": [(r.h, r.unfinished_buckets, r.unfinished_elements, r.sort_passes) for r in s.rounds[:s.n_rounds]],
+                      "scatter_form": ("look-back", "three-word", "two-word")[q], "scatter_launches": s.scatter_launches[q],
                       "scatter_ms_per_pass": round(ms / max(1, s.scatter_launches[q]), 3),
                       "scatter_GBps": round(s.scatter_bytes[q] / (ms * 1e-3) / 1e9, 1) if ms else None,
                       "workspace_GiB": round(s.workspace_bytes / 2**30, 1),
-                      "phases_ms": {"keys": round(s.ms_kmer, 1), "scatter": round(ms, 1), "tilehist": round(s.ms_sort_tilehist, 1),
+                      "phases_ms": {"keys": round(s.ms_kmer, 1), "scatter": round(s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, 1), "tilehist": round(s.ms_sort_tilehist, 1),
                                     "rebucket": round(s.ms_rebucket, 1), "isa": round(s.ms_isa_scatter, 1), "compact": round(s.ms_compact, 1),
                                     "rmq": round(s.ms_rmq_build, 1), "gather": round(s.ms_gather, 1)}}), flush=True)
 t0 = time.time()
