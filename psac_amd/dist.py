@@ -95,25 +95,18 @@ def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
     splitters = sorted(set(splitters))
     G1, G2, GV, bounds = ops.split_by(K1, K2, V, splitters, r)
     bounds = list(bounds[:len(splitters) + 1]) + [c] * (P + 1 - (len(splitters) + 1))   # empty trailing groups
-    parts = []
-    for arr in (G1, G2, GV):
-        got = yield from comm.all_to_all_v([arr[bounds[d]:bounds[d + 1]] for d in range(P)])
-        parts.append(torch.cat(got) if got else arr[:0])
+    parts, _ = yield from comm.exchange([G1, G2, GV], bounds)
     del G1, G2, GV
     R1, R2, RV = ops.pair_sort(parts[0], parts[1], parts[2], bits1, bits2, destroy=True)
     # exact re-balance: global index of my j-th record is G[r] + j
     c2 = int(R1.numel())
     counts = yield from comm.all_gather_obj(c2)
     G, TP = prefix(counts), prefix(targets)
-    out = []
-    for arr in (R1, R2, RV):
-        chunks = []
-        for d in range(P):
-            lo = max(TP[d], G[r]) - G[r]
-            hi = min(TP[d] + targets[d], G[r] + c2) - G[r]
-            chunks.append(arr[lo:hi] if hi > lo else arr[:0])
-        got = yield from comm.all_to_all_v(chunks)
-        out.append(torch.cat(got) if got else arr[:0])
+    if counts == list(targets):
+        return R1, R2, RV                       # already balanced: nothing moves
+    # my records [cut[d], cut[d+1]) belong to rank d (contiguous ranges, ascending in d)
+    cut = [min(max(TP[d] - G[r], 0), c2) for d in range(P)] + [c2]
+    out, _ = yield from comm.exchange([R1, R2, RV], cut)
     return out[0], out[1], out[2]
 
 
@@ -136,9 +129,7 @@ def dist_put(comm, ops, block, off, gidx, vals, delta, n, permutation=False):
         gi, vi = gidx, vals
     else:
         g, v, bounds = _route(comm, ops, gidx, vals, n)
-        gi = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
-        vi = yield from comm.all_to_all_v([v[bounds[d]:bounds[d + 1]] for d in range(P)])
-        gi, vi = torch.cat(gi), torch.cat(vi)
+        (gi, vi), _ = yield from comm.exchange([g, v], bounds)
     if permutation and delta == -1:
         ops.put_perm(block, gi, off, vi)
     else:
@@ -153,12 +144,11 @@ def dist_take(comm, ops, block, off, gidx, n):
         return ops.take(block, gidx, off, n)
     idx = ops.iota(int(gidx.numel()), 0)
     g, back, bounds = _route(comm, ops, gidx, idx, n)
-    q = yield from comm.all_to_all_v([g[bounds[d]:bounds[d + 1]] for d in range(P)])
-    lens = [int(t.numel()) for t in q]
-    ans = ops.take(block, torch.cat(q), off, n)
-    got = yield from comm.all_to_all_v(list(torch.split(ans, lens)))
+    (q,), lens = yield from comm.exchange([g], bounds)
+    ans = ops.take(block, q, off, n)
+    (got,), _ = yield from comm.exchange([ans], prefix(lens) + [sum(lens)])
     res = ops.empty_like(gidx)
-    ops.put(res, back, 0, torch.cat(got), 0)          # undo the routing permutation
+    ops.put(res, back, 0, got, 0)          # undo the routing permutation
     return res
 
 
@@ -195,13 +185,11 @@ def dist_range_min(comm, ops, lcp_block, off, sizes, lo, hi, n):
         o, ga, gb = ops.pair_sort(own, a, b, bits_for(P - 1), 0)
         _, _, back = ops.pair_sort(own, a, idx, bits_for(P - 1), 0)
         bounds = ops.key_bounds(o, list(range(P))) + [int(o.numel())]
-        qa = yield from comm.all_to_all_v([ga[bounds[d]:bounds[d + 1]] for d in range(P)])
-        qb = yield from comm.all_to_all_v([gb[bounds[d]:bounds[d + 1]] for d in range(P)])
-        lens = [int(t.numel()) for t in qa]
-        res = ops.range_min(lcp_block, torch.cat(qa), torch.cat(qb), off)
-        got = yield from comm.all_to_all_v(list(torch.split(res, lens)))
+        (qa, qb), lens = yield from comm.exchange([ga, gb], bounds)
+        res = ops.range_min(lcp_block, qa, qb, off)
+        (got,), _ = yield from comm.exchange([res], prefix(lens) + [sum(lens)])
         ordered = ops.empty_like(a)
-        ops.put(ordered, back, 0, torch.cat(got), 0)
+        ops.put(ordered, back, 0, got, 0)
         answers.append(ordered)
     return ops.rmq_combine(answers[0], answers[1], ra, rb, mins)
 
@@ -228,7 +216,14 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
     two_k = 2 * k
     if P > 1 and min(sizes) < two_k:
         raise RuntimeError("text blocks shorter than 2k characters are not supported with more than one rank")
-    c1 = min(two_k, word_bits // l)
+    # The 2k-character window is packed without an end-marker code (codes 0..sigma-1, lc bits each;
+    # see key_pairs_kernel): 40 instead of 60 key bits for DNA and 32-bit words.  The suffixes
+    # shorter than 2k -- the last 2k - 1 positions of the text -- then tie with longer ones on the
+    # zero padding; they are moved to the very front of the record order (rank 0, shortest first),
+    # where the (rank, index) tie-break of the stable distributed sort leaves them first.
+    lc = max(1, (sigma - 1).bit_length())
+    pcodes = [c - 1 if c else 0 for c in codes]
+    c1 = min(two_k, word_bits // lc)
     c2 = two_k - c1
 
     # halo: the first 2k characters of the right neighbour (zeros past the end of the text)
@@ -240,13 +235,28 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
         halo = got[r + 1] if r + 1 < P else text_block[:0]
     else:
         halo = text_block[:0]
-    K1, K2 = ops.make_keys(text_block, halo, m, two_k, codes, l, c1, c2)
+    K1, K2 = ops.make_keys(text_block, halo, m, two_k, pcodes, lc, c1, c2)
     V = ops.iota(m, off)
-    S1, S2, SA = yield from dist_sort(comm, ops, K1, K2, V, sizes, c1 * l, c2 * l)
+    spec = min(two_k - 1, n)
+    mine = min(m, max(0, off + m - (n - spec)))          # short suffixes in this block (its tail)
+    tails = [torch.flip(a[m - mine:], [0]) for a in (K1, K2, V)]
+    if P > 1:
+        moved, rc = yield from comm.exchange(tails, [0] + [mine] * P)      # everything to rank 0
+        if r == 0:
+            cuts = prefix(rc) + [sum(rc)]
+            moved = [torch.cat([a[cuts[s]:cuts[s + 1]] for s in range(P - 1, -1, -1)]) for a in moved]
+    else:
+        moved = tails
+    keep = [a[:m - mine] for a in (K1, K2, V)]
+    if r == 0:
+        K1, K2, V = [torch.cat([mv, kp]) for mv, kp in zip(moved, keep)]
+    else:
+        K1, K2, V = keep
+    S1, S2, SA = yield from dist_sort(comm, ops, K1, K2, V, sizes, c1 * lc, c2 * lc)
     del K1, K2, V
 
     rounds = []
-    shape = (l, c1, c2)
+    shape = (lc, c1, c2)
 
     def neighbours(a1, a2, a3):
         has = int(a1.numel()) > 0
