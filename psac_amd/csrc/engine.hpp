@@ -436,7 +436,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         const int form = !in.k2 ? 2 : (three ? 1 : 0);
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
-        c->stats.scatter_bytes[form] += (in.k2 ? 6ull : 4ull) * sizeof(T) * n;
+        // words read + written per record; a pass that makes up its payload (iota) reads one word less
+        c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
     }
