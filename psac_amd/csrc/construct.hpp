@@ -13,8 +13,6 @@
 
 namespace psacx {
 
-constexpr unsigned CURSOR_PAD = 32;            // words between the fill cursors of a small partition level (128 B)
-constexpr size_t CURSOR_PAD_MAX = 1u << 16;    // levels with at most this many cursors are padded
 constexpr int SCAN_BLOCK = 1024;
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
@@ -74,7 +72,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.d_nact = a.take<uint64_t>(nt);
     w.d_nunf = a.take<uint64_t>(nt);
     w.d_totals = a.take<uint64_t>(4);
-    w.n_cursors = std::max<size_t>((size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P, (CURSOR_PAD_MAX + 1) * CURSOR_PAD);
+    w.n_cursors = (size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P;
     w.d_cursors = a.take<unsigned>(w.n_cursors);
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
@@ -175,7 +173,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
                        SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0) {
-    constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16 measured the same)
+    constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16, 32-bit destinations with staged class bytes, and cursors padded to their own cache lines all measured the same or worse)
     const unsigned idx_bits = bits_for(n - 1);
     if (n < (1ull << 22) || idx_bits > INV_WINDOW_BITS + 24) {
         hipLaunchKernelGGL((isa_scatter_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_sa, val, n, d_isa, koff);
@@ -188,12 +186,11 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     for (int lv = 0; lv < levels; ++lv) {
         const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
         const size_t ncur = (size_t)(n >> shift) + 1;
-        const unsigned stride = ncur <= CURSOR_PAD_MAX ? CURSOR_PAD : 1u;
-        PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * stride * sizeof(unsigned), c->stream));
+        PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
         SortBufs<T> o = bufs[lv & 1];
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
         hipLaunchKernelGGL((partition_pairs_kernel<T, PB, PI>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, kin, vin,
-                           o.k1, o.k2, n, shift, d_cursors, lv == 0 ? koff : (uint64_t)0, stride);
+                           o.k1, o.k2, n, shift, d_cursors, lv == 0 ? koff : (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
         kin = o.k1; vin = o.k2;
     }

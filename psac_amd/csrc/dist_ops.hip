@@ -255,7 +255,7 @@ template <typename T>
 int op_put_perm(psacx_ctx* c, T* block, const T* gidx, uint64_t cnt, uint64_t off, const T* vals, T* s1, T* s2, T* s3, T* s4) {
     OP_PROLOGUE(c);
     if (cnt == 0) return PSACX_OK;
-    const size_t ncur = std::max<size_t>((size_t)(cnt >> INV_WINDOW_BITS) + 2 + RADIX_P, (CURSOR_PAD_MAX + 1) * CURSOR_PAD);
+    const size_t ncur = (size_t)(cnt >> INV_WINDOW_BITS) + 2 + RADIX_P;
     PSACX_TRY(ensure_slab(c, ncur * sizeof(unsigned) + 8192));
     SortBufs<T> t1{s1, s2, nullptr}, t2{s3, s4, nullptr};
     return invert_permutation<T>(c, reinterpret_cast<unsigned*>(c->slab), gidx, vals, cnt, block, t1, t2, off);

@@ -436,17 +436,13 @@ constexpr int INV_WINDOW_BITS = 12;
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     const T* __restrict__ key_in, const T* __restrict__ val_in, T* __restrict__ key_out,
-    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff,
-    unsigned cur_stride = 1) {
+    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
     // koff is subtracted from every key on the way in (first level of a rank's block)
-    // cur_stride: distance between fill cursors in words (a level with few classes keeps every cursor
-    // in its own cache line: tens of thousands of tiles add to each of them)
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T stage[TILE];
-    __shared__ uint8_t sdig[TILE];      // destination class of the record staged at each tile position
     __shared__ unsigned cnt[RADIX_P];
     __shared__ unsigned bstart[RADIX_P];
-    __shared__ T gbase[RADIX_P];        // global start of the tile's run of each class minus bstart (wraps)
+    __shared__ uint64_t gbase[RADIX_P];
     __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
     const unsigned tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
@@ -459,12 +455,8 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
-        key[i] = loc < count ? (T)((uint64_t)key_in[base + loc] - koff) : (T)0;
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const unsigned loc = tid + i * BLOCK;
-        val[i] = loc < count ? val_in[base + loc] : (T)0;
+        if (loc < count) { key[i] = (T)((uint64_t)key_in[base + loc] - koff); val[i] = val_in[base + loc]; }
+        else { key[i] = 0; val[i] = 0; }
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -482,8 +474,8 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
         if (tot) {
             const uint64_t parent = ((uint64_t)key_in[base] - koff) >> shift >> 8;   // same for the whole tile
             const uint64_t g = (parent << 8) | tid;
-            const unsigned at = atomicAdd(&cursors[g * cur_stride], tot);
-            gbase[tid] = (T)((g << shift) + at - bs);
+            const unsigned at = atomicAdd(&cursors[g], tot);
+            gbase[tid] = (g << shift) + at - bs;
         }
     }
     __syncthreads();
@@ -491,13 +483,18 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = (unsigned)(key[i] >> shift) & (RADIX_P - 1);
         slot[i] += bstart[d];
-        if (tid + i * BLOCK < count) { stage[slot[i]] = key[i]; sdig[slot[i]] = (uint8_t)d; }
+        if (tid + i * BLOCK < count) stage[slot[i]] = key[i];
     }
     __syncthreads();
+    uint64_t dest[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
-        if (p < count) key_out[(T)(gbase[sdig[p]] + (T)p)] = stage[p];
+        if (p < count) {
+            const T x = stage[p];
+            dest[j] = gbase[(unsigned)(x >> shift) & (RADIX_P - 1)] + p;
+            key_out[dest[j]] = x;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -507,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
-        if (p < count) val_out[(T)(gbase[sdig[p]] + (T)p)] = stage[p];
+        if (p < count) val_out[dest[j]] = stage[p];
     }
 }
 
