@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=1 << 27, help="characters for the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-lcp", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time psacx_construct_* with host pointers (H2D of the text, D2H of SA/ISA/LCP); reported "
+                         "as an extra field, never as `value`")
     return ap.parse_args()
 
 
@@ -205,6 +208,15 @@ def main():
               "rmq_build": round(s.ms_rmq_build, 3)}
     out = report(a, 1, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, int(s.k), int(s.bits_per_char),
                  int(s.n_rounds), "1 process per GPU")
+    if a.host_path:
+        hs = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=ctx)
+        hs.construct(text)                       # first call pays for page faults of the result arrays
+        t1 = time.perf_counter()
+        hs.construct(text)
+        ht = time.perf_counter() - t1
+        out["host_pointer_path"] = {"ms": round(ht * 1e3, 1), "MChars_per_s": round(n / ht / 1e6, 1),
+                                    "note": "pageable host buffers: H2D %d MiB + D2H %d MiB over PCIe, device buffers allocated per call"
+                                            % (n >> 20, (n * w * (2 if a.no_lcp else 3)) >> 20)}
     if a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)
     print(json.dumps(out))

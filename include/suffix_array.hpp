@@ -321,15 +321,30 @@ private:
     template <typename Iterator>
     void densify(Iterator begin, Iterator end, std::vector<uint8_t>& bytes, std::vector<char_t>& chars) {
         typedef typename std::make_unsigned<char_t>::type uchar_t;
+        chars.clear();
+        if (sizeof(char_t) == 1) {
+            bool used[256] = {false};
+            std::size_t i = 0;
+            for (Iterator it = begin; it != end; ++it, ++i) { const uint8_t b = (uint8_t)(uchar_t)*it; bytes[i] = b; used[b] = true; }
+            for (int ch = 0; ch < 256; ++ch) if (used[ch]) chars.push_back((char_t)(uchar_t)ch);
+            return;
+        }
         std::vector<uchar_t> u; u.reserve(n);
         for (Iterator it = begin; it != end; ++it) u.push_back((uchar_t)*it);
-        std::vector<uchar_t> uniq(u);
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-        if (uniq.size() > 256) throw std::runtime_error("psacx: more than 256 distinct symbols");
-        chars.clear();
+        std::vector<uchar_t> uniq;                      // distinct symbols, ascending by unsigned value
+        {
+            std::vector<uchar_t> seen;
+            for (std::size_t i = 0; i < n; ++i) {
+                // symbols are few: a sorted vector probed by binary search
+                typename std::vector<uchar_t>::iterator at = std::lower_bound(seen.begin(), seen.end(), u[i]);
+                if (at == seen.end() || *at != u[i]) {
+                    seen.insert(at, u[i]);
+                    if (seen.size() > 256) throw std::runtime_error("psacx: more than 256 distinct symbols");
+                }
+            }
+            uniq.swap(seen);
+        }
         for (std::size_t i = 0; i < uniq.size(); ++i) chars.push_back((char_t)uniq[i]);
-        if (sizeof(char_t) == 1) { for (std::size_t i = 0; i < n; ++i) bytes[i] = (uint8_t)u[i]; return; }
         for (std::size_t i = 0; i < n; ++i)
             bytes[i] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), u[i]) - uniq.begin());
     }
