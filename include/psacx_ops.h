@@ -98,6 +98,12 @@ int psacx_op_char_hist(psacx_ctx*, const uint8_t* text, uint64_t n, uint64_t* hi
                                T* rb);                                                                 \
     int psacx_op_rmq_combine_##S(psacx_ctx*, const T* a1, const T* a2, const T* ra, const T* rb,       \
                                  uint64_t cnt, const uint64_t* rank_mins_host, uint32_t P, T* out);    \
+    /* one search step of the distributed ANSV (ansv.hpp:2042-2051 over a block-distributed array): for  \
+       every query the nearest element of this block strictly beyond global position start[j] (left != 0: \
+       towards lower positions) with value < thr[j] (strict != 0) or <= thr[j]; start may lie outside the  \
+       block.  idx = global position or all ones, val = its value. */                                      \
+    int psacx_op_nsv_from_##S(psacx_ctx*, const T* block, uint64_t m, uint64_t off, const int64_t* start,  \
+                              const T* thr, uint64_t cnt, int strict, int left, T* idx, T* val);           \
     /* suffix_array.hpp:1503-1505: block[at - off] = h + mins */                                       \
     int psacx_op_lcp_apply_##S(psacx_ctx*, T* block, const T* at, uint64_t cnt, uint64_t off,          \
                                const T* mins, uint64_t h);

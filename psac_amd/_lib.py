@@ -120,6 +120,7 @@ def load():
         "rmq_split": [vp, vp, vp, u64, u64, u32, vp, vp, vp, vp, vp, vp, vp, vp],
         "rmq_combine": [vp, vp, vp, vp, vp, u64, u64p, u32, vp],
         "lcp_apply": [vp, vp, vp, u64, u64, vp, u64],
+        "nsv_from": [vp, vp, u64, u64, vp, vp, u64, i32, i32, vp, vp],
     }
     for name, args in sig.items():
         for suf in ("u32", "u64"):

@@ -10,52 +10,9 @@
 // nearest block that does.  The expected work per element is a few cache lines because the
 // nearest smaller value of an LCP entry is almost always close by.
 #include "engine.hpp"
+#include "nsv.hpp"
 
 namespace psacx {
-
-constexpr uint64_t NSV_NONE = ~0ull;
-
-// nearest j < i (LEFT) or j > i (!LEFT) with in[j] < v (strict) or in[j] <= v
-template <typename T, bool LEFT>
-__device__ __forceinline__ uint64_t nsv_search(const Pyramid<T>& P, uint64_t i, T v, bool strict) {
-    uint64_t pos = i, j = 0;
-    int L = 0;
-    bool found = false;
-    while (!found) {
-        const T* a = P.lvl[L];
-        const uint64_t len = P.len[L];
-        if (LEFT) {
-            const uint64_t gstart = pos & ~63ull;
-            for (uint64_t c = pos; c-- > gstart;) {
-                const T x = a[c];
-                if (strict ? x < v : x <= v) { j = c; found = true; break; }
-            }
-            if (!found && gstart == 0) return NSV_NONE;
-        } else {
-            uint64_t gend = (pos | 63ull) + 1;
-            if (gend > len) gend = len;
-            for (uint64_t c = pos + 1; c < gend; ++c) {
-                const T x = a[c];
-                if (strict ? x < v : x <= v) { j = c; found = true; break; }
-            }
-            if (!found && gend >= len) return NSV_NONE;
-        }
-        if (!found) { pos >>= 6; ++L; }     // the top level is a single group, so this never overruns
-    }
-    while (L > 0) {
-        const T* a = P.lvl[L - 1];
-        const uint64_t lo = j << 6;
-        uint64_t hi = lo + 64;
-        if (hi > P.len[L - 1]) hi = P.len[L - 1];
-        if (LEFT) {
-            for (uint64_t c = hi; c-- > lo;) { const T x = a[c]; if (strict ? x < v : x <= v) { j = c; break; } }
-        } else {
-            for (uint64_t c = lo; c < hi; ++c) { const T x = a[c]; if (strict ? x < v : x <= v) { j = c; break; } }
-        }
-        --L;
-    }
-    return j;
-}
 
 // type 0 nearest_sm, 1 nearest_eq, 2 furthest_eq
 template <typename T, bool LEFT>

@@ -3,6 +3,7 @@
 // (psac_amd/dist.py over torch.distributed / RCCL).
 #include "../../include/psacx_ops.h"
 #include "construct.hpp"
+#include "nsv.hpp"
 
 namespace psacx {
 
@@ -464,6 +465,64 @@ int op_range_min(psacx_ctx* c, const T* block, uint64_t m, const T* lo, const T*
     return PSACX_OK;
 }
 
+// One step of the distributed ANSV (ansv.hpp:1304-1740 keeps per-rank stacks and merges them; here every
+// open query is a search in the block's min-pyramid): nearest element of this block strictly beyond the
+// global position start[j] (to the left or to the right) whose value is < thr[j] (strict) or <= thr[j].
+// start may lie outside the block (or be -1 / n): the search then begins at the block's edge.
+template <typename T>
+__global__ void nsv_from_kernel(Pyramid<T> P, uint64_t m, uint64_t off, const long long* __restrict__ start,
+                                const T* __restrict__ thr, uint64_t cnt, int strict, int left,
+                                T* __restrict__ out_idx, T* __restrict__ out_val) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const long long s = start[j] - (long long)off;          // block-relative, may be < 0 or >= m
+        const T v = thr[j];
+        uint64_t r = NSV_NONE;
+        if (m) {
+            if (left) {
+                if (s > 0) {
+                    if ((uint64_t)s >= m) {                        // from beyond the right edge: element m - 1 counts
+                        const T x = P.lvl[0][m - 1];
+                        r = (strict ? x < v : x <= v) ? m - 1 : (m > 1 ? nsv_search<T, true>(P, m - 1, v, strict != 0) : NSV_NONE);
+                    } else r = nsv_search<T, true>(P, (uint64_t)s, v, strict != 0);
+                }
+            } else {
+                if (s < (long long)m - 1) {
+                    if (s < 0) {                                   // from before the left edge: element 0 counts
+                        const T x = P.lvl[0][0];
+                        r = (strict ? x < v : x <= v) ? 0 : (m > 1 ? nsv_search<T, false>(P, 0, v, strict != 0) : NSV_NONE);
+                    } else r = nsv_search<T, false>(P, (uint64_t)s, v, strict != 0);
+                }
+            }
+        }
+        out_idx[j] = r == NSV_NONE ? ~(T)0 : (T)(off + r);
+        out_val[j] = r == NSV_NONE ? (T)0 : P.lvl[0][r];
+    }
+}
+
+template <typename T>
+int op_nsv_from(psacx_ctx* c, const T* block, uint64_t m, uint64_t off, const long long* start, const T* thr, uint64_t cnt,
+                int strict, int left, T* out_idx, T* out_val) {
+    OP_PROLOGUE(c);
+    if (cnt == 0) return PSACX_OK;
+    Pyramid<T> P;
+    std::memset(&P, 0, sizeof(P));
+    if (m) {
+        { Arena dry(nullptr); nsv_pyramid_layout<T>(dry, block, m, P); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
+        Arena ar(c->slab);
+        nsv_pyramid_layout<T>(ar, block, m, P);
+        for (int L = 1; L < P.nlev; ++L) {
+            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
+                               P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
+            PSACX_HIP(c, hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL((nsv_from_kernel<T>), dim3(grid_for(c, cnt, 256, 16)), dim3(256), 0, c->stream, P, m, off, start, thr, cnt,
+                       strict, left, out_idx, out_val);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
 #define SIMPLE_LAUNCH(c, kern, cnt, ...)                                                                     \
     do { if ((cnt) > 0) { hipLaunchKernelGGL(kern, dim3(grid_for(c, cnt, 256, 16)), dim3(256), 0, (c)->stream, __VA_ARGS__); \
                           PSACX_HIP(c, hipGetLastError()); } } while (0)
@@ -565,6 +624,10 @@ int psacx_op_char_hist(psacx_ctx* c, const uint8_t* text, uint64_t n, uint64_t* 
         RankMins rm; for (uint32_t i = 0; i < 64; ++i) rm.v[i] = i < P ? mins[i] : ~0ull;                      \
         SIMPLE_LAUNCH(c, (rmq_combine_kernel<T>), cnt, a1, a2, ra, rb, cnt, rm, out);                          \
         return PSACX_OK;                                                                                       \
+    }                                                                                                          \
+    int psacx_op_nsv_from_##S(psacx_ctx* c, const T* b, uint64_t m, uint64_t off, const int64_t* start,        \
+                              const T* thr, uint64_t cnt, int strict, int left, T* oi, T* ov) {                \
+        return op_nsv_from<T>(c, b, m, off, reinterpret_cast<const long long*>(start), thr, cnt, strict, left, oi, ov); \
     }                                                                                                          \
     int psacx_op_lcp_apply_##S(psacx_ctx* c, T* b, const T* at, uint64_t cnt, uint64_t off, const T* mins,     \
                                uint64_t h) {                                                                   \

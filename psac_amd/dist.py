@@ -195,6 +195,109 @@ def dist_range_min(comm, ops, lcp_block, off, sizes, lo, hi, n):
 
 
 # ---------------------------------------------------------------------------------------
+# all nearest smaller values over a block-distributed array
+# ---------------------------------------------------------------------------------------
+NEAREST_SM, NEAREST_EQ, FURTHEST_EQ = 0, 1, 2       # ansv_common.hpp:20-22
+
+
+def _as_i64(ops, t):
+    """Unsigned value of an index tensor as int64 (values stay below 2^62 on this path)."""
+    x = t.to(torch.int64)
+    return x & 0xFFFFFFFF if ops.index_bits == 32 else x
+
+
+def dist_search(comm, ops, block, off, sizes, mins, start, thr, strict, left):
+    """For every query the nearest element of the distributed array strictly beyond global position
+    start[j] (int64 tensor; -1 and n are allowed) whose value is < thr[j] (strict) or <= thr[j];
+    left: towards lower positions.  Returns (idx, val) index tensors, idx = all ones where no such
+    element exists.  Queries are answered by the block holding `start`, then by the nearest further
+    block whose minimum qualifies (its edge element search cannot fail)."""
+    P, r = comm.size, comm.rank
+    n = sum(sizes)
+    offs = prefix(sizes)
+    cnt = int(thr.numel())
+    none = -1
+    if P == 1:
+        return ops.nsv_from(block, start, thr, strict, left, off)
+    dev = thr.device
+    # block that holds the start position (clamped: -1 -> first block, n -> last block)
+    ends = torch.tensor([o + s for o, s in zip(offs, sizes)], dtype=torch.int64, device=dev)
+    own = torch.searchsorted(ends, start.clamp(0, max(n - 1, 0)), right=True).clamp(max=P - 1)
+    idx = ops.empty_like(thr); idx.fill_(none)
+    val = ops.empty_like(thr); val.zero_()
+    thr64 = _as_i64(ops, thr)
+
+    def ask(target, st):
+        """Sends query j to rank target[j] (>= 0) with start st[j]; returns (idx, val) in query order."""
+        sel = torch.nonzero(target >= 0).reshape(-1)
+        oi = ops.empty_like(thr); oi.fill_(none)
+        ov = ops.empty_like(thr); ov.zero_()
+        order = torch.argsort(target[sel], stable=True)
+        sel = sel[order]
+        tgt = target[sel]
+        bounds = torch.searchsorted(tgt, torch.arange(P + 1, dtype=torch.int64, device=dev)).tolist()
+        (qs, qt), lens = yield from comm.exchange([st[sel].contiguous(), thr[sel].contiguous()], bounds)
+        ri, rv = ops.nsv_from(block, qs, qt, strict, left, off)
+        (bi, bv), _ = yield from comm.exchange([ri, rv], prefix(lens) + [sum(lens)])
+        oi[sel] = bi; ov[sel] = bv
+        return oi, ov
+
+    # phase A: the block of the start position
+    i1, v1 = yield from ask(own.clone(), start)
+    idx, val = i1, v1
+    # phase B: the nearest block beyond it whose minimum qualifies
+    open_q = idx == none
+    target = torch.full((cnt,), -1, dtype=torch.int64, device=dev)
+    order = range(P - 2, -1, -1) if left else range(1, P)
+    for b in (order if left else order):
+        ok = (thr64 > mins[b]) if strict else (thr64 >= mins[b])
+        beyond = (own > b) if left else (own < b)
+        take = open_q & (target < 0) & ok & beyond & (sizes[b] > 0)
+        target[take] = b
+    edge = torch.full((cnt,), n if left else -1, dtype=torch.int64, device=dev)   # beyond the target's far edge
+    i2, v2 = yield from ask(target, edge)
+    got = target >= 0
+    idx[got] = i2[got]; val[got] = v2[got]
+    return idx, val
+
+
+def dist_ansv(comm, ops, block, left_type=NEAREST_SM, right_type=NEAREST_SM):
+    """ansv<T, left_type, right_type, global_indexing> (ansv.hpp:2042-2051) over a block-distributed
+    array: for every local element the global index of its nearest smaller value on each side
+    (type 0: strictly smaller; 1: smaller or equal; 2: the furthest element of the run of equal
+    values that nothing smaller interrupts, ansv_common.hpp:20-22); all ones where none exists.
+    Returns (left, right) index tensors."""
+    P, r = comm.size, comm.rank
+    m = int(block.numel())
+    sizes = yield from comm.all_gather_obj(m)
+    offs = prefix(sizes)
+    off = offs[r]
+    n = sum(sizes)
+    mins = yield from comm.all_gather_obj(ops.block_min(block) if m else (1 << 64) - 1)
+    none = -1
+    here = torch.arange(off, off + m, dtype=torch.int64, device=block.device)
+    out = []
+    for left, typ in ((True, left_type), (False, right_type)):
+        if typ == NEAREST_SM:
+            idx, _ = yield from dist_search(comm, ops, block, off, sizes, mins, here, block, True, left)
+        else:
+            j, u = yield from dist_search(comm, ops, block, off, sizes, mins, here, block, False, left)
+            idx = j
+            if typ == FURTHEST_EQ:
+                # first strictly smaller value beyond j, then back towards i: the first value <= in[j]
+                jj = _as_i64(ops, j)
+                found = j != none
+                start2 = torch.where(found, jj, torch.full_like(jj, n if left else -1))
+                s, _ = yield from dist_search(comm, ops, block, off, sizes, mins, start2, u, True, left)
+                ss = _as_i64(ops, s)
+                start3 = torch.where(s != none, ss, torch.full_like(ss, -1 if left else n))
+                f, _ = yield from dist_search(comm, ops, block, off, sizes, mins, start3, u, False, not left)
+                idx = torch.where(found, f, j)
+        out.append(idx)
+    return out[0], out[1]
+
+
+# ---------------------------------------------------------------------------------------
 # the construction
 # ---------------------------------------------------------------------------------------
 def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):

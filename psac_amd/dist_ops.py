@@ -19,7 +19,7 @@ class Boundary(C.Structure):
 
 OPS = ["make_keys", "iota", "pair_sort", "split_by", "pair_bounds", "owners", "take", "put", "put_perm", "add_scalar", "finish_b2",
        "last_head", "rebucket_first", "rebucket_refine", "compact", "block_min", "range_min", "rmq_split",
-       "rmq_combine", "lcp_apply"]
+       "rmq_combine", "lcp_apply", "nsv_from"]
 OP_EXPORTS = ["psacx_op_char_hist"] + ["psacx_op_%s_%s" % (o, s) for o in OPS for s in ("u32", "u64")]
 
 
@@ -245,6 +245,15 @@ class HipOps(object):
         self._chk(self._f("rmq_combine")(self.ctx, self._p(a1), self._p(a2), self._p(ra), self._p(rb), int(a1.numel()), M,
                                          len(mins), self._p(out)))
         return out
+
+    def nsv_from(self, block, start, thr, strict, left, off):
+        """Per query the nearest element of `block` strictly beyond global position start[j] (int64
+        tensor; left: towards lower positions) with value < thr[j] (strict) or <= thr[j].
+        Returns (idx, val): global position or all ones, and the value found."""
+        idx, val = self.empty_like(thr), self.empty_like(thr)
+        self._chk(self._f("nsv_from")(self.ctx, self._p(block), int(block.numel()), int(off), self._p(start), self._p(thr),
+                                      int(thr.numel()), int(bool(strict)), int(bool(left)), self._p(idx), self._p(val)))
+        return idx, val
 
     def lcp_apply(self, LCP, at, off, mins, h):
         self._chk(self._f("lcp_apply")(self.ctx, self._p(LCP), self._p(at), int(at.numel()), int(off), self._p(mins), int(h)))

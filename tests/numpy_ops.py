@@ -248,6 +248,21 @@ class NumpyOps(object):
                 out[i] = a[l[i]:r[i]].min()
         return self.t(out)
 
+    def nsv_from(self, block, start, thr, strict, left, off):
+        a = self.u(block).astype(np.uint64)
+        st = start.numpy().astype(np.int64) - off
+        th = self.u(thr).astype(np.uint64)
+        m = a.size
+        none = np.uint64(self.INF)
+        idx = np.full(th.size, none, np.uint64); val = np.zeros(th.size, np.uint64)
+        for j in range(th.size):
+            rng = range(min(int(st[j]), m) - 1, -1, -1) if left else range(max(int(st[j]), -1) + 1, m)
+            for e in rng:
+                if (a[e] < th[j]) if strict else (a[e] <= th[j]):
+                    idx[j] = off + e; val[j] = a[e]
+                    break
+        return self.t(idx), self.t(val)
+
     def rmq_split(self, lo, hi, offs, sizes):
         l, r = self.u(lo).astype(np.int64), self.u(hi).astype(np.int64)
         ends = np.array(offs) + np.array(sizes)

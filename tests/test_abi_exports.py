@@ -31,7 +31,7 @@ def test_ops_header_symbols_are_exported():
     from psac_amd import _lib, dist_ops
     lib = _lib.load()
     syms = declared_op_symbols()
-    assert len(syms) == 41
+    assert len(syms) == 43
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(dist_ops.OP_EXPORTS) == syms

@@ -77,6 +77,43 @@ def test_loopback_short_suffix_ties(P):
             check_against_oracle(text, P, bits)
 
 
+def _ansv_loopback(vals, P, bits, lt, rt, make_ops, to_tensor, to_numpy):
+    sizes = D.blk_sizes(vals.size, P)
+    offs = D.prefix(sizes)
+    blocks = [to_tensor(vals[o:o + s]) for o, s in zip(offs, sizes)]
+
+    def fn(comm, ops, blk):
+        return (yield from D.dist_ansv(comm, ops, blk, lt, rt))
+    res = LoopbackWorld(P).run(fn, [(make_ops(), b) for b in blocks])
+    return (np.concatenate([to_numpy(x[0]) for x in res]).astype(np.uint64),
+            np.concatenate([to_numpy(x[1]) for x in res]).astype(np.uint64))
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5])
+def test_loopback_distributed_ansv(P):
+    # ansv<T, left_type, right_type, global_indexing> (ansv.hpp:2042-2051) over blocks: all nine type pairs
+    # (ansv_common.hpp:20-22) against the sequential definition, on inputs with many ties and few ties
+    rng = np.random.RandomState(P)
+    for trial in range(6):
+        n = int(rng.randint(P, 400))
+        vals = rng.randint(0, int(rng.choice([2, 5, 1000])), size=n).astype(np.uint64)
+        for bits in (32, 64):
+            ops = NumpyOps(bits)
+            v = vals.astype(np.uint32 if bits == 32 else np.uint64)
+            none = (1 << bits) - 1
+            for lt in (0, 1, 2):
+                for rt in (0, 1, 2):
+                    L, R = _ansv_loopback(vals, P, bits, lt, rt, lambda: NumpyOps(bits), ops.t, ops.u)
+                    assert np.array_equal(L, O.ansv(v, True, lt, none)), (n, bits, lt)
+                    assert np.array_equal(R, O.ansv(v, False, rt, none)), (n, bits, rt)
+    # the LCP array of a text: the input psac feeds it (suffix_tree.hpp:62: left furthest_eq, right nearest_sm)
+    text = O.rand_dna(3000, 4)
+    r = O.construct(text, bits=64)
+    ops = NumpyOps(64)
+    L, R = _ansv_loopback(r["LCP"], P, 64, 2, 0, lambda: NumpyOps(64), ops.t, ops.u)
+    assert np.array_equal(L, O.ansv(r["LCP"], True, 2, (1 << 64) - 1)) and np.array_equal(R, O.ansv(r["LCP"], False, 0, (1 << 64) - 1))
+
+
 def test_loopback_round_log_matches_oracle():
     text = inputs.tandem(6000, 128, O.rand_dna(128, 5))
     info = check_against_oracle(text, 3, 32)

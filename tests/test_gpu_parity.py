@@ -521,3 +521,36 @@ def test_gsac_cli(tmp_path):
     r = subprocess.run([gsac, "-f", str(f), "-c"], capture_output=True, text=True)
     assert r.returncode == 0 and "[SUCCESS]" in r.stdout
     assert subprocess.run([gsac], capture_output=True).returncode != 0
+
+
+def test_distributed_ansv_on_gpu(ctx):
+    # the HIP search op (psacx_op_nsv_from_*) under the loopback world: P virtual ranks sharing this GPU
+    import torch
+    from psac_amd import dist as D
+    from psac_amd.comm import LoopbackWorld
+    from psac_amd.dist_ops import HipOps
+    rng = np.random.RandomState(8)
+    text = inputs.dna(200000, 6)
+    lcp = run(ctx, text, bits=32).local_LCP
+    cases = [(rng.randint(0, 4, size=5000).astype(np.uint64), 32), (rng.randint(0, 10**6, size=70000).astype(np.uint64), 64),
+             (lcp.astype(np.uint64), 32), (np.zeros(3000, np.uint64), 64), (np.arange(5000, dtype=np.uint64), 32)]
+    for vals, bits in cases:
+        v = vals.astype(np.uint32 if bits == 32 else np.uint64)
+        none = (1 << bits) - 1
+        for P in (1, 2, 4):
+            sizes = D.blk_sizes(vals.size, P)
+            offs = D.prefix(sizes)
+            ops = [HipOps(bits, 0) for _ in range(P)]
+            sdt = np.int32 if bits == 32 else np.int64
+            blocks = [torch.from_numpy(v[o:o + s].view(sdt).copy()).cuda() for o, s in zip(offs, sizes)]
+            for lt, rt in ((0, 0), (2, 0), (1, 2), (2, 1)):
+                def fn(comm, op, blk):
+                    return (yield from D.dist_ansv(comm, op, blk, lt, rt))
+                res = LoopbackWorld(P).run(fn, [(ops[r], blocks[r]) for r in range(P)])
+                udt = np.uint32 if bits == 32 else np.uint64
+                L = np.concatenate([x[0].cpu().numpy().view(udt) for x in res]).astype(np.uint64)
+                R = np.concatenate([x[1].cpu().numpy().view(udt) for x in res]).astype(np.uint64)
+                assert np.array_equal(L, O.ansv(v, True, lt, none)), (bits, P, lt)
+                assert np.array_equal(R, O.ansv(v, False, rt, none)), (bits, P, rt)
+            for o in ops:
+                o.close()
