@@ -1,0 +1,165 @@
+"""psac over one or several MI355X: `python -m psac_amd (-f <file> | -r <size>) [-s seed] [-o base] [-l] [-c]`.
+
+The command line of /root/reference/src/psac.cpp:56-153 for the block-distributed path: start it once
+per GPU with torchrun (`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1
+-m psac_amd ...`), the way the reference is started with `mpirun -np N psac ...`.
+
+* input: every rank reads its block of the file (mxx::file_block_decompose, src/psac.cpp:85), or draws
+  size / N random DNA characters with seed * rank (src/psac.cpp:88, alphabet.hpp:32-45, glibc rand);
+* output: `<base>.sa64` (and `.lcp64` with -l), raw little-endian uint64 in global order, every rank
+  writing its block (mxx::write_ordered, src/psac.cpp:123-128);
+* `-c`: the arrays are gathered on rank 0 and verified there by the device checker
+  (check_suffix_array.hpp:56-126); prints the reference's `[SUCCESS]` / `[ERROR]` lines.
+With a single process the single-GPU engine is used; `-t` (suffix tree) is only available in the C++
+`psac` binary.  Extra flag: `--index {32,64,auto}` (files stay uint64).
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def _rand_dna(size, seed):
+    """alphabet.hpp:32-45: srand(1337 * seed); "ACGT"[rand() % 4] with the C library's generator."""
+    libc = ctypes.CDLL(None)
+    libc.srand(ctypes.c_uint(1337 * seed))
+    out = np.empty(size, np.uint8)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rand = libc.rand
+    for i in range(size):
+        out[i] = lut[rand() & 3]
+    return out
+
+
+def _blk(n, P, r):
+    m = n // P + (1 if r < n % P else 0)
+    off = r * (n // P) + min(r, n % P)
+    return off, m
+
+
+def _write_block(path, arr_u64, off_elems, total_elems, rank, barrier):
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.truncate(total_elems * 8)
+    barrier()
+    with open(path, "r+b") as f:
+        f.seek(off_elems * 8)
+        f.write(arr_u64.tobytes())
+    barrier()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m psac_amd",
+                                 description="Parallel distributed suffix array and LCP construction (MI355X engine).")
+    g = ap.add_mutually_exclusive_group(required=True)
+    g.add_argument("-f", "--file")
+    g.add_argument("-r", "--random", type=int)
+    ap.add_argument("-o", "--outfile", default="")
+    ap.add_argument("-s", "--seed", type=int, default=0)
+    ap.add_argument("-l", "--lcp", action="store_true")
+    ap.add_argument("-c", "--check", action="store_true")
+    ap.add_argument("--index", default="auto", choices=("32", "64", "auto"))
+    a = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import psac_amd
+
+    if a.file:
+        n = os.path.getsize(a.file)
+        off, m = _blk(n, world, rank)
+        with open(a.file, "rb") as f:
+            f.seek(off)
+            text = np.frombuffer(f.read(m), np.uint8).copy()
+    else:
+        m = a.random // world                       # src/psac.cpp:88
+        n = m * world
+        off = rank * m
+        text = _rand_dna(m, a.seed * rank)
+    if n == 0:
+        sys.stderr.write("error: empty input\n")
+        return 1
+    bits = 32 if (a.index == "32" or (a.index == "auto" and n < 0xFFFFFFFE)) else 64
+    udt = np.uint32 if bits == 32 else np.uint64
+
+    single = world == 1 and not os.environ.get("PSACX_CLI_FORCE_DIST")
+    if single:
+        sa = psac_amd.SuffixArray(index_bits=bits, lcp=a.lcp, ctx=psac_amd.Context(local_rank), log=sys.stderr)
+        t0 = time.perf_counter()
+        sa.construct(text)
+        sys.stderr.write("PSAC time: %g ms\n" % ((time.perf_counter() - t0) * 1e3))
+        SA, ISA, LCP = sa.local_SA, sa.local_B, (sa.local_LCP if a.lcp else None)
+        barrier = lambda: None
+        gathered = (text, SA, ISA, LCP)
+    else:
+        import torch.distributed as dist
+        from psac_amd import dist as D
+        from psac_amd.comm import TorchComm
+        from psac_amd.dist_ops import HipOps
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm()
+        ops = HipOps(bits, local_rank)
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+        d_text = torch.from_numpy(text).cuda()
+        barrier()
+        t0 = time.perf_counter()
+        res = D.run(D.construct(comm, ops, d_text, want_lcp=a.lcp, log=sys.stderr))
+        barrier()
+        if rank == 0:
+            sys.stderr.write("PSAC time: %g ms\n" % ((time.perf_counter() - t0) * 1e3))
+        view = lambda t: t.cpu().numpy().view(udt)
+        SA, ISA = view(res["SA"]), view(res["ISA"])
+        LCP = view(res["LCP"]) if a.lcp else None
+        gathered = None
+        if a.check:
+            def gather(t):
+                parts = []
+                for src in range(world):
+                    buf = t if src == rank else torch.empty(_blk(n, world, src)[1], dtype=t.dtype, device=t.device)
+                    dist.broadcast(buf, src=src)
+                    parts.append(buf)
+                return torch.cat(parts).cpu().numpy()
+            gt = gather(d_text)
+            gsa, gisa = gather(res["SA"]).view(udt), gather(res["ISA"]).view(udt)
+            glcp = gather(res["LCP"]).view(udt) if a.lcp else None
+            gathered = (gt, gsa, gisa, glcp)
+
+    rc = 0
+    if a.check and rank == 0:
+        gt, gsa, gisa, glcp = gathered
+        ctx = psac_amd.Context(local_rank)
+        w = bits // 8
+        d_t, d_s, d_i = ctx.alloc(n), ctx.alloc(n * w), ctx.alloc(n * w)
+        d_l = ctx.alloc(n * w) if a.lcp else 0
+        ctx.h2d(d_t, gt); ctx.h2d(d_s, gsa); ctx.h2d(d_i, gisa)
+        if a.lcp:
+            ctx.h2d(d_l, glcp)
+        err = psac_amd.check_device(ctx, d_t, n, d_s, d_i, d_l, bits)
+        if any(err):
+            sys.stderr.write("[ERROR] Test unsuccessful\n")
+            rc = 1
+        else:
+            sys.stderr.write("[SUCCESS] Suffix Array%s are correct\n" % (" and LCP" if a.lcp else ""))
+    if a.outfile:
+        _write_block(a.outfile + ".sa64", SA.astype(np.uint64), off, n, rank, barrier)
+        if a.lcp:
+            _write_block(a.outfile + ".lcp64", LCP.astype(np.uint64), off, n, rank, barrier)
+    if not single:
+        import torch.distributed as dist
+        ops.close()
+        dist.destroy_process_group()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

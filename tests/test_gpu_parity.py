@@ -2,6 +2,7 @@
 oracle and the reference's golden vectors, bit-exact.  Run with -m gpu on an MI355X."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -554,3 +555,29 @@ def test_distributed_ansv_on_gpu(ctx):
                 assert np.array_equal(R, O.ansv(v, False, rt, none)), (bits, P, rt)
             for o in ops:
                 o.close()
+
+
+def test_python_cli_single_and_torchrun(tmp_path):
+    # `python -m psac_amd` = src/psac.cpp's command line for the block-distributed path; with one process it
+    # uses the single-GPU engine, under torchrun (here: one rank, RCCL) the distributed choreography
+    import subprocess
+    root = os.path.dirname(HERE)
+    text = inputs.dna(300000, 12)
+    f = tmp_path / "t.txt"
+    f.write_bytes(bytes(text))
+    ref = O.construct(text, bits=32)
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "psac_amd", "-f", str(f), "-l", "-c", "-o", str(tmp_path / "a")],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr and "PSAC time:" in r.stderr, r.stderr[-2000:]
+    assert np.array_equal(np.fromfile(str(tmp_path / "a.sa64"), np.uint64), ref["SA"].astype(np.uint64))
+    assert np.array_equal(np.fromfile(str(tmp_path / "a.lcp64"), np.uint64), ref["LCP"].astype(np.uint64))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29577", "-m", "psac_amd", "-f", str(f), "-l", "-o", str(tmp_path / "b")],
+                       capture_output=True, text=True, env=dict(env, PSACX_CLI_FORCE_DIST="1"), cwd=root)
+    assert r.returncode == 0 and "PSAC time:" in r.stderr, r.stderr[-2000:]
+    assert np.array_equal(np.fromfile(str(tmp_path / "b.sa64"), np.uint64), ref["SA"].astype(np.uint64))
+    assert np.array_equal(np.fromfile(str(tmp_path / "b.lcp64"), np.uint64), ref["LCP"].astype(np.uint64))
+    # -r draws the reference's generator (alphabet.hpp:32-45)
+    r = subprocess.run([sys.executable, "-m", "psac_amd", "-r", "20000", "-s", "0", "-c"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr[-2000:]
