@@ -420,16 +420,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
         if (gsa) {
             PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>());
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1);
         }
         PSACX_HIP(c, hipGetLastError());
     }
@@ -442,7 +443,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);
-        for (int L = 1; L < w.pyr.nlev; ++L) {
+        for (int L = 2; L < w.pyr.nlev; ++L) {
             hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, w.pyr.len[L] * 64, 256, 8)), dim3(256), 0,
                                c->stream, w.pyr.lvl[L - 1], w.pyr.len[L - 1], w.pyr.lvl[L], w.pyr.len[L]);
             PSACX_HIP(c, hipGetLastError());

@@ -326,8 +326,11 @@ template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
-    uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd) {
+    uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
+    T* __restrict__ pyr1 = nullptr) {
     // n: records in this block; ng: length of the whole text (LCP sentinel, suffix lengths)
+    // pyr1 (optional): level 1 of the min-pyramid over LCP, pyr1[g] = min(LCP[64 g .. 64 g + 63]), written
+    // here so that nobody has to read the fresh LCP array again
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
@@ -412,6 +415,15 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     }
     store_run<T, ITEMS>(Bsa, e0, n, id);
     if (WITH_LCP) store_run<T, ITEMS>(LCP, e0, n, lc);
+    if (WITH_LCP && pyr1) {
+        static_assert(64 % ITEMS == 0 && (64 / ITEMS) <= WAVE, "a group of 64 entries must sit inside one wave");
+        T m = ~(T)0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) if (e0 + j < n && lc[j] < m) m = lc[j];
+#pragma unroll
+        for (int d = 1; d < 64 / ITEMS; d <<= 1) { const T o = shfl_xor<T>(m, d); m = o < m ? o : m; }
+        if ((threadIdx.x & (64 / ITEMS - 1)) == 0 && e0 < n) pyr1[e0 >> 6] = m;
+    }
 }
 
 // ------------------------------------------------------------------ K8
