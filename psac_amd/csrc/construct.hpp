@@ -170,9 +170,13 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 // through destination-partition passes + an LDS window scatter (see partition_pairs_kernel);
 // t1/t2 are two scratch pair buffers of n entries each.
 // koff: the keys are a permutation of [koff, koff + n) (a rank's block in the distributed path)
+// sc != nullptr (single-GPU engine, 32-bit words): the partition levels are run as stable LSD passes of
+// the two-word radix scatter kernel instead (deterministic tile order keeps neighbouring runs in one
+// XCD's L2: 1.3 ms per level including its tile histogram, against 1.5 ms for the reservation kernel;
+// with 64-bit words the reservation kernel is the faster one).
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
-                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0) {
+                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr) {
     constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16, 32-bit destinations with staged class bytes, and cursors padded to their own cache lines all measured the same or worse)
     const unsigned idx_bits = bits_for(n - 1);
     if (n < (1ull << 22) || idx_bits > INV_WINDOW_BITS + 24) {
@@ -183,7 +187,17 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     const int levels = (int)((idx_bits - INV_WINDOW_BITS + 7) / 8);
     const T* kin = d_sa; const T* vin = val;
     SortBufs<T> bufs[2] = {t1, t2};
-    for (int lv = 0; lv < levels; ++lv) {
+    const bool radix_levels = sc && sizeof(T) == 4 && koff == 0 && levels <= MAX_PASSES && !getenv("PSACX_ISA_PARTITION");
+    for (int lv = 0; radix_levels && lv < levels; ++lv) {
+        SortBufs<T> o = bufs[lv & 1];
+        PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
+        dispatch_pass3<T>(c, ScatterCfg<T>::DEF, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
+                          sc->d_base + (size_t)lv * RADIX, sc->d_desc, (unsigned long long*)nullptr, 0, 0);
+        PSACX_HIP(c, hipGetLastError());
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 4ull * sizeof(T) * n;
+        kin = o.k1; vin = o.k2;
+    }
+    for (int lv = 0; !radix_levels && lv < levels; ++lv) {
         const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
         const size_t ncur = (size_t)(n >> shift) + 1;
         PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
@@ -439,7 +453,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         ProfScope ps(c, TC_ISA_SCATTER);
         SortBufs<T> t2 = w.y;
         if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
-        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2));
+        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2, 0, &w.sc));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);
