@@ -191,7 +191,7 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     for (int lv = 0; radix_levels && lv < levels; ++lv) {
         SortBufs<T> o = bufs[lv & 1];
         PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
-        dispatch_pass3<T>(c, ScatterCfg<T>::DEF, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
+        dispatch_pass3<T>(c, ScatterCfg<T>::DEF2, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
                           sc->d_base + (size_t)lv * RADIX, sc->d_desc, (unsigned long long*)nullptr, 0, 0);
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 4ull * sizeof(T) * n;
