@@ -142,7 +142,11 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
                                                           const T* __restrict__ slen = nullptr) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int HALO = 2 * 64 + 8;             // 2k <= 128 always
-    __shared__ uint16_t codes[TILE + HALO];
+    // code i of the tile lives at SW(i): every 8 codes are followed by a 4-byte gap, so the lanes of a
+    // wave, which walk windows that start 8 codes apart, read from different LDS banks
+    // (stride 20 bytes instead of 16: 5 t mod 32 is a permutation of the banks)
+#define SW(i) ((i) + (((i) >> 3) << 1))
+    __shared__ uint16_t codes[SW(TILE + HALO) + 8];
     __shared__ uint16_t ctab[256];
     for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
     __syncthreads();
@@ -150,9 +154,30 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
     const uint64_t base = (uint64_t)blockIdx.x * TILE;                 // first record of the tile
     const uint64_t i_lo = (base > ks.spec ? base : ks.spec) - ks.spec; // first regular suffix of the tile
     const unsigned need = TILE + two_k;
-    for (unsigned i = threadIdx.x; i < need; i += BLOCK) {
-        const uint64_t g = i_lo + i;
-        codes[i] = g < n_text ? ctab[text[g]] : (uint16_t)0;   // n_text >= n: the block plus its halo
+    // the text window of the tile, 16 bytes per lane where a whole aligned chunk lies inside the text
+    // (the text pointer itself is 16-byte aligned: device allocations are), single bytes at the edges
+    {
+        const uint64_t a_lo = i_lo & ~15ull;                       // aligned start at or before the window
+        const unsigned lead = (unsigned)(i_lo - a_lo);
+        const bool aligned_ptr = (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
+        for (unsigned v = threadIdx.x * 16u; v < need + lead; v += BLOCK * 16u) {
+            const uint64_t g0 = a_lo + v;
+            if (aligned_ptr && g0 + 16 <= n_text) {
+                const uint4 x = *reinterpret_cast<const uint4*>(text + g0);
+                const unsigned wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int i = (int)v + b - (int)lead;          // window index of this byte
+                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = ctab[(wds[b >> 2] >> ((b & 3) * 8)) & 255u];
+                }
+            } else {
+#pragma unroll 1
+                for (int b = 0; b < 16; ++b) {
+                    const int i = (int)v + b - (int)lead;
+                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = (g0 + b) < n_text ? ctab[text[g0 + b]] : (uint16_t)0;
+                }
+            }
+        }
     }
     __syncthreads();
     const unsigned lc = ks.lc;
@@ -164,12 +189,13 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
         // ITEMS consecutive regular suffixes: rolling pack out of LDS
         const unsigned q = (unsigned)(j0 - ks.spec - i_lo);
         T w1 = 0, w2 = 0;
-        for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[q + t];
-        for (unsigned t = 0; t + 1 < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)codes[q + ks.c1 + t];
+        for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[SW(q + t)];
+        const bool want2 = ks.c2 != 0 && C2 != nullptr;          // word 2 is dropped when the first round sorts on word 1 only
+        for (unsigned t = 0; want2 && t + 1 < ks.c2; ++t) w2 = (T)(w2 << lc) | (T)codes[SW(q + ks.c1 + t)];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            w1 = ((T)(w1 << lc) | (T)codes[q + j + ks.c1 - 1]) & mask1;
-            if (ks.c2) w2 = ((T)(w2 << lc) | (T)codes[q + j + two_k - 1]) & mask2;
+            w1 = ((T)(w1 << lc) | (T)codes[SW(q + j + ks.c1 - 1)]) & mask1;
+            if (want2) w2 = ((T)(w2 << lc) | (T)codes[SW(q + j + two_k - 1)]) & mask2;
             o1[j] = w1; o2[j] = w2;
         }
         if (GSA) {
@@ -206,6 +232,7 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
     for (int j = 0; j < ITEMS; ++j)
         if (j0 + j < n) { so1 |= o1[j]; sa1 &= o1[j]; so2 |= o2[j]; sa2 &= o2[j]; }
     key_summary_add<T>(summary, so1, sa1, so2, sa2);
+#undef SW
 }
 
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
