@@ -25,6 +25,7 @@ template <typename T> struct Work {
     uint64_t cap_active;
     bool diet;                         // large-n layout: the output buffers double as sort scratch
     Pyramid<T> pyr;
+    T *aux_pre[PYR_MAX], *aux_suf[PYR_MAX];   // storage for pyr.pre / pyr.suf of levels >= 1
     unsigned long long* d_hist256;     // char histogram
     uint64_t* d_carry;                 // per scan tile: id of the last head (then its exclusive max-scan)
     uint64_t* d_nact;                  // per scan tile: active positions (then exclusive sum-scan)
@@ -54,8 +55,8 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
         w.ry.k1 = a.take<T>(cap); w.ry.k2 = a.take<T>(cap); w.ry.v = a.take<T>(cap);
         w.pos_a = a.take<T>(cap); w.pos_b = a.take<T>(cap);
     }
-    w.pyr.nlev = 0;
-    for (int i = 0; i < PYR_MAX; ++i) { w.pyr.lvl[i] = nullptr; w.pyr.len[i] = 0; }
+    w.pyr = Pyramid<T>();
+    for (int i = 0; i < PYR_MAX; ++i) { w.aux_pre[i] = nullptr; w.aux_suf[i] = nullptr; }
     if (with_lcp) {
         w.pyr.lvl[0] = d_lcp; w.pyr.len[0] = n; w.pyr.nlev = 1;
         uint64_t len = n;
@@ -63,6 +64,8 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
             len = (len + 63) / 64;
             w.pyr.lvl[w.pyr.nlev] = a.take<T>(len);
             w.pyr.len[w.pyr.nlev] = len;
+            w.aux_pre[w.pyr.nlev] = a.take<T>(len);      // range-minimum helpers of the upper levels (level 0: ctx->aux)
+            w.aux_suf[w.pyr.nlev] = a.take<T>(len);
             w.pyr.nlev++;
         }
     }
@@ -216,6 +219,41 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
 
 // d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
 // d_text holds the strings back to back, d_slen[i] the characters from i to the end of its string.
+// Range minima of a refinement round (suffix_array.hpp:1457-1476 issues one per freshly split boundary)
+// read LCP values set in earlier rounds only, so per-group running minima can be tabulated once per
+// round: a query then costs two loads per level instead of up to 126.  Levels >= 1 are tiny and always
+// tabulated when the round has enough queries to matter; level 0 (two arrays of n entries in a lazily
+// allocated second workspace) only when a large part of the suffixes is still active.
+template <typename T>
+int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n) {
+    for (int L = 0; L < PYR_MAX; ++L) { w.pyr.pre[L] = nullptr; w.pyr.suf[L] = nullptr; }
+    if (queries < (1u << 16) || getenv("PSACX_NO_RMQ_AUX")) return PSACX_OK;
+    ProfScope ps(c, TC_RMQ_BUILD);
+    for (int L = 1; L + 1 < w.pyr.nlev; ++L) {
+        hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, w.pyr.len[L], 256, 8)), dim3(256), 0, c->stream,
+                           w.pyr.lvl[L], w.pyr.len[L], w.aux_pre[L], w.aux_suf[L]);
+        PSACX_HIP(c, hipGetLastError());
+        w.pyr.pre[L] = w.aux_pre[L]; w.pyr.suf[L] = w.aux_suf[L];
+    }
+    if (queries >= n / 32 && !w.diet && w.pyr.nlev > 1) {
+        const size_t need = 2 * n * sizeof(T);
+        if (c->aux_bytes < need) {
+            if (c->aux) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->aux); c->aux = nullptr; c->aux_bytes = 0; }
+            if (hipMalloc((void**)&c->aux, need) == hipSuccess) c->aux_bytes = need;
+            else { (void)hipGetLastError(); c->aux = nullptr; }
+        }
+        if (c->aux) {
+            T* pre0 = reinterpret_cast<T*>(c->aux);
+            T* suf0 = pre0 + n;
+            hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream,
+                               w.pyr.lvl[0], n, pre0, suf0);
+            PSACX_HIP(c, hipGetLastError());
+            w.pyr.pre[0] = pre0; w.pyr.suf[0] = suf0;
+        }
+    }
+    return PSACX_OK;
+}
+
 template <typename T, bool WITH_LCP>
 int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_req, uint32_t flags,
                   T* d_sa, T* d_isa, T* d_lcp, const T* d_slen = nullptr) {
@@ -493,6 +531,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr, 0, 0,
                                /*summary_ready=*/true));
         T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
+        if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n));
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;

@@ -30,6 +30,8 @@ struct psacx_ctx {
     bool own_stream = false;
     char* slab = nullptr;
     size_t slab_bytes = 0;
+    char* aux = nullptr;             // second, lazily allocated workspace (range-minimum helpers of level 0)
+    size_t aux_bytes = 0;
     char* pinned = nullptr;          // host-pinned scratch (histograms, counters)
     size_t pinned_bytes = 0;
     std::string hip_err;

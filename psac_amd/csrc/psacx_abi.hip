@@ -56,6 +56,7 @@ void psacx_destroy(psacx_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->slab) (void)hipFree(c->slab);
+    if (c->aux) (void)hipFree(c->aux);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -81,6 +82,7 @@ int psacx_trim(psacx_ctx* c) {
     PSACX_HIP(c, hipSetDevice(c->device));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     if (c->slab) { PSACX_HIP(c, hipFree(c->slab)); c->slab = nullptr; c->slab_bytes = 0; }
+    if (c->aux) { PSACX_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
     return PSACX_OK;
 }
 

@@ -807,10 +807,32 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
 // lvl[0] is the LCP array itself, lvl[L][i] = min(lvl[L-1][64 i .. 64 i + 63]).
 constexpr int PYR_MAX = 8;
 template <typename T> struct Pyramid {
-    T* lvl[PYR_MAX];
-    uint64_t len[PYR_MAX];
-    int nlev;
+    T* lvl[PYR_MAX] = {};
+    uint64_t len[PYR_MAX] = {};
+    int nlev = 0;
+    // optional per-level helpers for range minima, rebuilt at the start of a refinement round:
+    // pre[L][i] = min(lvl[L][64 (i / 64) .. i]), suf[L][i] = min(lvl[L][i .. 64 (i / 64) + 63])
+    T* pre[PYR_MAX] = {};
+    T* suf[PYR_MAX] = {};
 };
+
+// one wave per group of 64 entries: running minima from the left and from the right
+template <typename T>
+__global__ void pyramid_aux_kernel(const T* __restrict__ in, uint64_t len, T* __restrict__ pre, T* __restrict__ suf) {
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
+    const unsigned lane = lane_id();
+    const uint64_t ngroups = (len + 63) >> 6;
+    for (uint64_t c = wave_id; c < ngroups; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        const T v = i < len ? in[i] : ~(T)0;
+        const T p = wave_scan_inclusive<T>(v, OpMin());
+        const T vr = shfl<T>(v, 63 - (int)lane);
+        const T sr = wave_scan_inclusive<T>(vr, OpMin());
+        const T sfx = shfl<T>(sr, 63 - (int)lane);
+        if (i < len) { pre[i] = p; suf[i] = sfx; }
+    }
+}
 
 template <typename T>
 __global__ void pyramid_level_kernel(const T* __restrict__ in, uint64_t len_in, T* __restrict__ out,
@@ -850,8 +872,14 @@ __device__ __forceinline__ T pyramid_min(const Pyramid<T>& P, uint64_t l, uint64
         const T* a = P.lvl[L];
         if (r - l <= 128 || L == P.nlev - 1) return pyramid_edge_min<T>(a, l, r, m);
         const uint64_t lb = (l + 63) >> 6, rb = r >> 6;
-        m = pyramid_edge_min<T>(a, l, lb << 6, m);
-        m = pyramid_edge_min<T>(a, rb << 6, r, m);
+        if (P.pre[L]) {
+            // lb <= rb here (the range is longer than 128): both partial groups are whole prefixes / suffixes
+            if (l & 63) { const T x = P.suf[L][l]; m = x < m ? x : m; }
+            if (r & 63) { const T x = P.pre[L][r - 1]; m = x < m ? x : m; }
+        } else {
+            m = pyramid_edge_min<T>(a, l, lb << 6, m);
+            m = pyramid_edge_min<T>(a, rb << 6, r, m);
+        }
         l = lb; r = rb;
         if (l >= r) return m;
     }
