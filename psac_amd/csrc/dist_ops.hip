@@ -405,12 +405,25 @@ int op_compact(psacx_ctx* c, const T* ids, const T* pos, uint64_t cnt, uint64_t 
     return PSACX_OK;
 }
 
+// aux_queries > 0: also tabulates the running minima pyramid_min uses (see prepare_range_min in
+// construct.hpp) when that many queries make it worth while
 template <typename T>
-int build_block_pyramid(psacx_ctx* c, const T* block, uint64_t m, Pyramid<T>& P, unsigned long long** scalar = nullptr) {
+int build_block_pyramid(psacx_ctx* c, const T* block, uint64_t m, Pyramid<T>& P, unsigned long long** scalar = nullptr,
+                        uint64_t aux_queries = 0) {
+    const bool aux_up = aux_queries >= (1u << 16);
+    const bool aux0 = aux_up && aux_queries >= m / 32;
+    T *pre[PYR_MAX] = {}, *suf[PYR_MAX] = {};
     auto layout = [&](Arena& a) {
+        P = Pyramid<T>();
         P.lvl[0] = const_cast<T*>(block); P.len[0] = m; P.nlev = 1;
         uint64_t len = m;
-        while (len > 128 && P.nlev < PYR_MAX) { len = (len + 63) / 64; P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len; P.nlev++; }
+        if (aux0) { pre[0] = a.take<T>(m); suf[0] = a.take<T>(m); }
+        while (len > 128 && P.nlev < PYR_MAX) {
+            len = (len + 63) / 64;
+            P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len;
+            if (aux_up) { pre[P.nlev] = a.take<T>(len); suf[P.nlev] = a.take<T>(len); }
+            P.nlev++;
+        }
         unsigned long long* sc = a.take<unsigned long long>(8);
         if (scalar) *scalar = sc;
     };
@@ -421,6 +434,13 @@ int build_block_pyramid(psacx_ctx* c, const T* block, uint64_t m, Pyramid<T>& P,
         hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream, P.lvl[L - 1],
                            P.len[L - 1], P.lvl[L], P.len[L]);
         PSACX_HIP(c, hipGetLastError());
+    }
+    for (int L = 0; L + 1 < P.nlev; ++L) {
+        if (!pre[L]) continue;
+        hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, P.len[L], 256, 8)), dim3(256), 0, c->stream, P.lvl[L], P.len[L],
+                           pre[L], suf[L]);
+        PSACX_HIP(c, hipGetLastError());
+        P.pre[L] = pre[L]; P.suf[L] = suf[L];
     }
     return PSACX_OK;
 }
@@ -459,7 +479,7 @@ int op_range_min(psacx_ctx* c, const T* block, uint64_t m, const T* lo, const T*
     if (cnt == 0) return PSACX_OK;
     Pyramid<T> P;
     std::memset(&P, 0, sizeof(P));
-    if (m) PSACX_TRY(build_block_pyramid<T>(c, block, m, P));
+    if (m) PSACX_TRY(build_block_pyramid<T>(c, block, m, P, nullptr, cnt));
     hipLaunchKernelGGL((range_min_kernel<T>), dim3(grid_for(c, cnt, 256, 16)), dim3(256), 0, c->stream, P, lo, hi, cnt, off, out);
     PSACX_HIP(c, hipGetLastError());
     return PSACX_OK;
