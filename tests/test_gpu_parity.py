@@ -292,6 +292,27 @@ def test_distributed_ops_larger(ctx):
     assert np.array_equal(O.kasai(text, sa, isa), lcp)
 
 
+def test_low_entropy_text_many_range_minima(ctx):
+    # 2^21 characters with geometric symbol frequencies: most suffixes stay unresolved after the first round, so
+    # the refinement issues ~10^6 range minima per round and the running-minimum tables (levels 0 and up) are in
+    # use -- on the single-GPU engine and in the distributed range_min op; PSACX_NO_RMQ_AUX covers the plain scans
+    rng = np.random.RandomState(5)
+    p = 0.5 ** np.arange(1, 21); p /= p.sum()
+    text = (97 + rng.choice(20, size=(1 << 21) + 77, p=p)).astype(np.uint8)
+    ref = O.construct(text, bits=32)
+    got = run(ctx, text, bits=32)
+    assert np.array_equal(got.local_SA, ref["SA"]) and np.array_equal(got.local_B, ref["ISA"]) and np.array_equal(got.local_LCP, ref["LCP"])
+    assert [(h, b, e) for h, b, e, *_ in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    os.environ["PSACX_NO_RMQ_AUX"] = "1"
+    try:
+        plain = run(ctx, text, bits=64)
+    finally:
+        del os.environ["PSACX_NO_RMQ_AUX"]
+    assert np.array_equal(plain.local_LCP, ref["LCP"].astype(np.uint64))
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, 2, 32)
+    assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+
+
 def _device_run_and_check(ctx, text, bits, corrupt=False):
     import psac_amd
     n = int(text.size); w = bits // 8
