@@ -176,7 +176,9 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 // sc != nullptr (single-GPU engine, 32-bit words): the partition levels are run as stable LSD passes of
 // the two-word radix scatter kernel instead (deterministic tile order keeps neighbouring runs in one
 // XCD's L2: 1.3 ms per level including its tile histogram, against 1.5 ms for the reservation kernel;
-// with 64-bit words the reservation kernel is the faster one).
+// with 64-bit words the reservation kernel is the faster one).  Letting the first level make up its payload
+// (ISA[SA[i]] = i, members of unresolved buckets repaired afterwards) was measured: the pass is not
+// read-bound, no gain.
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
                        SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr) {
@@ -217,8 +219,6 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     return PSACX_OK;
 }
 
-// d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
-// d_text holds the strings back to back, d_slen[i] the characters from i to the end of its string.
 // Range minima of a refinement round (suffix_array.hpp:1457-1476 issues one per freshly split boundary)
 // read LCP values set in earlier rounds only, so per-group running minima can be tabulated once per
 // round: a query then costs two loads per level instead of up to 126.  Levels >= 1 are tiny and always
@@ -254,6 +254,8 @@ int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n) {
     return PSACX_OK;
 }
 
+// d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
+// d_text holds the strings back to back, d_slen[i] the characters from i to the end of its string.
 template <typename T, bool WITH_LCP>
 int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_req, uint32_t flags,
                   T* d_sa, T* d_isa, T* d_lcp, const T* d_slen = nullptr) {
