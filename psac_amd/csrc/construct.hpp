@@ -192,7 +192,8 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     const int levels = (int)((idx_bits - INV_WINDOW_BITS + 7) / 8);
     const T* kin = d_sa; const T* vin = val;
     SortBufs<T> bufs[2] = {t1, t2};
-    const bool radix_levels = sc && sizeof(T) == 4 && koff == 0 && levels <= MAX_PASSES && !getenv("PSACX_ISA_PARTITION");
+    // (measured: 3.07 against 3.46 ms at 2^28, 18.7 against 19.4 ms at 2^30, 75.5 against 68.4 ms at 2^32 - 2)
+    const bool radix_levels = sc && sizeof(T) == 4 && koff == 0 && n <= (1ull << 30) && !getenv("PSACX_ISA_PARTITION");
     for (int lv = 0; radix_levels && lv < levels; ++lv) {
         SortBufs<T> o = bufs[lv & 1];
         PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
