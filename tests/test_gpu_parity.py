@@ -602,3 +602,14 @@ def test_python_cli_single_and_torchrun(tmp_path):
     # -r draws the reference's generator (alphabet.hpp:32-45)
     r = subprocess.run([sys.executable, "-m", "psac_amd", "-r", "20000", "-s", "0", "-c"], capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr[-2000:]
+
+
+def test_degenerate_texts_above_the_two_stage_threshold(ctx):
+    # n >= 2^21 switches on the two-stage first round and the three-kernel radix passes: single-symbol and
+    # period-2 texts (every suffix ties, 15-18 rounds), a lone different last character, and n = 2^21 exactly
+    # (the only uint32 size where stage 1 leaves low bits of word 1 unsorted)
+    a = np.full((1 << 21) + 3, 65, np.uint8)
+    cases = [(a, 32), (inputs.cyclic(1 << 22, "AB"), 32), (a[:1 << 21], 64),
+             (np.concatenate([np.full((1 << 22) - 1, 65, np.uint8), np.array([66], np.uint8)]), 32), (inputs.dna(1 << 21, 3), 32)]
+    for text, bits in cases:
+        same_as_oracle(ctx, text, bits=bits)
