@@ -81,13 +81,16 @@ __global__ void key_summary_kernel(const T* __restrict__ k1, const T* __restrict
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void char_hist_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                           unsigned long long* __restrict__ hist) {
-    __shared__ unsigned lh[4][256];
-    for (int i = threadIdx.x; i < 1024; i += BLOCK) (&lh[0][0])[i] = 0;
+    // 32 private histograms per workgroup, 257 words apart: the lanes of a wave that meet the same symbol (four
+    // symbols for DNA) hit 32 different counters in 32 different banks instead of serialising on one
+    constexpr int COPIES = 32, PITCH = 257;
+    __shared__ unsigned lh[COPIES * PITCH];
+    for (int i = threadIdx.x; i < COPIES * PITCH; i += BLOCK) lh[i] = 0;
     __syncthreads();
     const uint64_t nvec = ((uintptr_t)text % 16 == 0) ? n / 16 : 0;
     const uint4* tv = reinterpret_cast<const uint4*>(text);
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    unsigned* my = lh[threadIdx.x & 3];
+    unsigned* my = lh + (threadIdx.x & (COPIES - 1)) * PITCH;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) {
         const uint4 v = tv[i];
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(BLOCK) void char_hist_kernel(const uint8_t* __restr
         atomicAdd(&my[text[i]], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += BLOCK) {
-        const unsigned c = lh[0][i] + lh[1][i] + lh[2][i] + lh[3][i];
+        unsigned c = 0;
+#pragma unroll 8
+        for (int k = 0; k < COPIES; ++k) c += lh[k * PITCH + i];
         if (c) atomicAdd(&hist[i], (unsigned long long)c);
     }
 }
