@@ -355,6 +355,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     const bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
                            lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
+    const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !getenv("PSACX_NO_KEY_HIST");
 
     // In the diet layout the sorted keys must end up in the workspace set x (the other set is the
     // LCP / ISA output), so an odd number of passes starts from y.
@@ -371,11 +372,19 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     {
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
-        const uint64_t nb = (n + KB * KI - 1) / (KB * KI);
+        uint64_t nb = (n + KB * KI - 1) / (KB * KI);
         if (gsa)
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, d_slen);
-        else
+        else if (hist_in_keys) {
+            // tile shape of the stage-1 sort (ScatterCfg<T>::DEF2), pass-1 histograms written on the way
+            constexpr int HB = 512, HI = sizeof(T) == 4 ? 12 : 8;
+            static_assert(ScatterCfg<T>::DEF2 == (sizeof(T) == 4 ? 7 : 2), "key tile must match the scatter tile");
+            nb = (n + HB * HI - 1) / (HB * HI);
+            hipLaunchKernelGGL((key_pairs_kernel<T, HB, HI, false, true>), dim3((unsigned)nb), dim3(HB), 0, c->stream, d_text, n, n,
+                               tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr,
+                               reinterpret_cast<unsigned*>(w.sc.d_desc + 256), (int)lo1);
+        } else
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
@@ -388,7 +397,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
-                               ks.spec, n, /*summary_ready=*/true, lo1));
+                               ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
         if (w.diet) {
             if (sorted.k1 != w.x.k1) {        // a skipped pass changed the parity
                 PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

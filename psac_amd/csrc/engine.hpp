@@ -245,7 +245,7 @@ inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three k
 template <typename T, int BLOCK, int ITEMS, int MINW = 1>
 inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
                          uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
+                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
@@ -253,8 +253,9 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     {
         ProfScope ps(c, TC_SORT_TILEHIST);
-        hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
-                           shift, tile_hist);
+        if (!have_hist)        // (the producer of the keys may have left this pass's tile histograms in place)
+            hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
+                               shift, tile_hist);
         hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
         hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs,
                            const_cast<unsigned long long*>(base));
@@ -273,8 +274,8 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
 template <typename T>
 inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out,
                            T* v_out, uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n) {
-#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n)
+                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false) {
+#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist)
     switch (cfg) {
         case 0: PSACX_P3(256, 8); break;
         case 2: PSACX_P3(512, 8); break;
@@ -330,7 +331,10 @@ inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
 template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
-              uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0) {
+              uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0,
+              int ready_hist_shift = -1) {
+    // ready_hist_shift >= 0: the tile histograms of word 1 at that bit position are already in the scratch
+    // (written by key_pairs_kernel<..., HIST> with the tile shape of this sort)
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
     if (!in.k2) bits2 = 0;
@@ -415,7 +419,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
         if (three) {
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
-            dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n);
+            const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
+            dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n,
+                              have_hist);
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);

@@ -139,12 +139,17 @@ __device__ __forceinline__ uint64_t record_suffix(uint64_t j, uint64_t spec, uin
 // GSA (string sets, kmer.hpp:269-355): the codes are psac's 1..sigma with lc = l bits, 0 is the
 // end marker, spec = 0, and every window is cut at the end of its string: slen[i] = characters
 // from position i to the end of the string holding it.
-template <typename T, int BLOCK, int ITEMS, bool GSA = false>
+//
+// HIST: the tile shape equals the radix scatter tile of the sort that follows, and the digit histogram of
+// word 1 at bit hist_shift is left in tile_hist[tile][256] -- the first pass then needs no
+// radix_tile_hist_kernel (one read of the key word saved).
+template <typename T, int BLOCK, int ITEMS, bool GSA = false, bool HIST = false>
 __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                           uint64_t n_text, CodeTable tab, KeyShape ks,
                                                           T* __restrict__ C1, T* __restrict__ C2,
                                                           unsigned long long* __restrict__ summary,
-                                                          const T* __restrict__ slen = nullptr) {
+                                                          const T* __restrict__ slen = nullptr,
+                                                          unsigned* __restrict__ tile_hist = nullptr, int hist_shift = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int HALO = 2 * 64 + 8;             // 2k <= 128 always
     // code i of the tile lives at SW(i): every 8 codes are followed by a 4-byte gap, so the lanes of a
@@ -153,7 +158,9 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
 #define SW(i) ((i) + (((i) >> 3) << 1))
     __shared__ uint16_t codes[SW(TILE + HALO) + 8];
     __shared__ uint16_t ctab[256];
+    __shared__ unsigned dh[HIST ? 4 * RADIX : 1];
     for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    if (HIST) for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) dh[HIST ? i : 0] = 0;
     __syncthreads();
     const unsigned two_k = ks.c1 + ks.c2;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;                 // first record of the tile
@@ -232,6 +239,14 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
     }
     store_run<T, ITEMS>(C1, j0, n, o1);
     if (C2) store_run<T, ITEMS>(C2, j0, n, o2);      // (not kept when the first round sorts on word 1 only)
+    if (HIST) {
+        unsigned* my = dh + ((threadIdx.x / WAVE) & 3) * RADIX;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) wave_hist_add(my, (unsigned)(o1[j] >> hist_shift) & (RADIX - 1), j0 + j < n);
+        __syncthreads();
+        for (int d = threadIdx.x; d < RADIX; d += BLOCK)
+            tile_hist[(uint64_t)blockIdx.x * RADIX + d] = dh[d] + dh[RADIX + d] + dh[2 * RADIX + d] + dh[3 * RADIX + d];
+    }
     T so1 = 0, sa1 = ~(T)0, so2 = 0, sa2 = ~(T)0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
