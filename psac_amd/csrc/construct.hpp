@@ -13,8 +13,8 @@
 
 namespace psacx {
 
-constexpr int SCAN_BLOCK = 1024;
-constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = 768;
+constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 template <typename T> struct Work {
@@ -169,6 +169,12 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     return PSACX_OK;
 }
 
+// whether the inversion of n records of T runs its partition levels as radix passes (see invert_permutation)
+template <typename T>
+inline bool isa_radix_levels(uint64_t n) {
+    return sizeof(T) == 4 && n >= (1ull << 22) && n <= (1ull << 30) && !getenv("PSACX_ISA_PARTITION");
+}
+
 // ISA[SA[i]] = val[i] - 1 for a full permutation SA (bulk_permute.hpp:14-73).  Large inputs go
 // through destination-partition passes + an LDS window scatter (see partition_pairs_kernel);
 // t1/t2 are two scratch pair buffers of n entries each.
@@ -181,7 +187,8 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 // read-bound, no gain.
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
-                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr) {
+                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr, bool have_hist0 = false) {
+    // have_hist0: the tile histograms of the first radix level are already in sc->d_desc (rebucket_first_kernel)
     constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16, 32-bit destinations with staged class bytes, and cursors padded to their own cache lines all measured the same or worse)
     const unsigned idx_bits = bits_for(n - 1);
     if (n < (1ull << 22) || idx_bits > INV_WINDOW_BITS + 24) {
@@ -193,12 +200,13 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     const T* kin = d_sa; const T* vin = val;
     SortBufs<T> bufs[2] = {t1, t2};
     // (measured: 3.07 against 3.46 ms at 2^28, 18.7 against 19.4 ms at 2^30, 75.5 against 68.4 ms at 2^32 - 2)
-    const bool radix_levels = sc && sizeof(T) == 4 && koff == 0 && n <= (1ull << 30) && !getenv("PSACX_ISA_PARTITION");
+    const bool radix_levels = sc && koff == 0 && isa_radix_levels<T>(n);
     for (int lv = 0; radix_levels && lv < levels; ++lv) {
         SortBufs<T> o = bufs[lv & 1];
         PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
         dispatch_pass3<T>(c, ScatterCfg<T>::DEF2, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
-                          sc->d_base + (size_t)lv * RADIX, sc->d_desc, (unsigned long long*)nullptr, 0, 0);
+                          sc->d_base + (size_t)lv * RADIX, sc->d_desc, (unsigned long long*)nullptr, 0, 0,
+                          lv == 0 && have_hist0);
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 4ull * sizeof(T) * n;
         kin = o.k1; vin = o.k2;
@@ -481,20 +489,25 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     }
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
+    bool isa_hist_ready = false;
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
         T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
+        // ... and so do the tile histograms of the inversion's first radix level when the tiles agree
+        isa_hist_ready = isa_radix_levels<T>(n) && (uint64_t)SCAN_TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
+                         !getenv("PSACX_NO_KEY_HIST");
+        unsigned* const sa_hist = isa_hist_ready ? reinterpret_cast<unsigned*>(w.sc.d_desc + 256) : (unsigned*)nullptr;
         if (gsa) {
             PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1);
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
-                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1);
+                               w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
         }
         PSACX_HIP(c, hipGetLastError());
     }
@@ -503,7 +516,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         ProfScope ps(c, TC_ISA_SCATTER);
         SortBufs<T> t2 = w.y;
         if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
-        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2, 0, &w.sc));
+        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2, 0, &w.sc, isa_hist_ready));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);

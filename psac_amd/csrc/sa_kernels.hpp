@@ -374,7 +374,9 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
-    T* __restrict__ pyr1 = nullptr) {
+    T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0) {
+    // sa_hist (optional): per-tile histogram of the digit of SA at sa_hist_shift, for the first level of the
+    // SA -> ISA inversion when it runs as radix passes over tiles of this size
     // n: records in this block; ng: length of the whole text (LCP sentinel, suffix lengths)
     // pyr1 (optional): level 1 of the min-pyramid over LCP, pyr1[g] = min(LCP[64 g .. 64 g + 63]), written
     // here so that nobody has to read the fresh LCP array again
@@ -462,6 +464,17 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     }
     store_run<T, ITEMS>(Bsa, e0, n, id);
     if (WITH_LCP) store_run<T, ITEMS>(LCP, e0, n, lc);
+    if (sa_hist) {
+        __shared__ unsigned dh[4 * RADIX];
+        for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) dh[i] = 0;
+        __syncthreads();
+        unsigned* my = dh + ((threadIdx.x / WAVE) & 3) * RADIX;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) wave_hist_add(my, (unsigned)(sa[j] >> sa_hist_shift) & (RADIX - 1), e0 + j < n);
+        __syncthreads();
+        for (int d = threadIdx.x; d < RADIX; d += BLOCK)
+            sa_hist[(uint64_t)tile * RADIX + d] = dh[d] + dh[RADIX + d] + dh[2 * RADIX + d] + dh[3 * RADIX + d];
+    }
     if (WITH_LCP && pyr1) {
         static_assert(64 % ITEMS == 0 && (64 / ITEMS) <= WAVE, "a group of 64 entries must sit inside one wave");
         T m = ~(T)0;
