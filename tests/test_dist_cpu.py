@@ -164,3 +164,35 @@ def test_gloo_two_processes():
     lcp = np.concatenate([out[0][2], out[1][2]])
     ref = O.construct(text, bits=32)
     assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+
+
+def _gloo_ansv_worker(rank, world, port, vals, bits, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, HERE)
+    from numpy_ops import NumpyOps as Ops
+    from psac_amd import dist as DD
+    from psac_amd.comm import TorchComm
+    ops = Ops(bits)
+    sizes = DD.blk_sizes(vals.size, world)
+    offs = DD.prefix(sizes)
+    blk = ops.t(vals[offs[rank]:offs[rank] + sizes[rank]])
+    L, R = DD.run(DD.dist_ansv(TorchComm(), ops, blk, 2, 0))        # the pair psac's suffix tree uses
+    out[rank] = (ops.u(L).copy(), ops.u(R).copy())
+    dist.destroy_process_group()
+
+
+def test_gloo_two_processes_ansv():
+    import torch.multiprocessing as mp
+    text = O.rand_dna(3001, 2)
+    lcp = O.construct(text, bits=64)["LCP"]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_ansv_worker, args=(2, port, lcp, 64, out), nprocs=2, join=True)
+    L = np.concatenate([out[0][0], out[1][0]]).astype(np.uint64)
+    R = np.concatenate([out[0][1], out[1][1]]).astype(np.uint64)
+    none = (1 << 64) - 1
+    assert np.array_equal(L, O.ansv(lcp, True, 2, none)) and np.array_equal(R, O.ansv(lcp, False, 0, none))
