@@ -186,6 +186,11 @@ int psacx_ansv_u32(psacx_ctx* ctx, const uint32_t* in, uint64_t n, int left_type
                    uint64_t nonsv, uint64_t* left_nsv, uint64_t* right_nsv);
 int psacx_ansv_u64(psacx_ctx* ctx, const uint64_t* in, uint64_t n, int left_type, int right_type,
                    uint64_t nonsv, uint64_t* left_nsv, uint64_t* right_nsv);
+/* same with the input (e.g. the LCP array psacx_construct_dev_* left in HBM) and both results in device memory */
+int psacx_ansv_dev_u32(psacx_ctx* ctx, const uint32_t* d_in, uint64_t n, int left_type, int right_type,
+                       uint64_t nonsv, uint64_t* d_left_nsv, uint64_t* d_right_nsv);
+int psacx_ansv_dev_u64(psacx_ctx* ctx, const uint64_t* d_in, uint64_t n, int left_type, int right_type,
+                       uint64_t nonsv, uint64_t* d_left_nsv, uint64_t* d_right_nsv);
 
 /* suffix tree topology -------------------------------------------------------
  * Replaces construct_suffix_tree(sa, begin, end, comm) (suffix_tree.hpp:413-499, parents by

@@ -22,7 +22,7 @@ EXPORTS = [
     "psacx_construct_gsa_u32", "psacx_construct_gsa_u64", "psacx_construct_gsa_dev_u32", "psacx_construct_gsa_dev_u64",
     "psacx_construct_lc_u32", "psacx_construct_lc_u64", "psacx_construct_lc_dev_u32", "psacx_construct_lc_dev_u64",
     "psacx_get_stats", "psacx_profile", "psacx_check_dev_u32", "psacx_check_dev_u64", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
-    "psacx_ansv_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
+    "psacx_ansv_u64", "psacx_ansv_dev_u32", "psacx_ansv_dev_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
 ]
 
 
@@ -84,6 +84,7 @@ def load():
             getattr(lib, name + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp, vp]
         getattr(lib, "psacx_pair_sort_dev_" + suf).argtypes = [vp, vp, vp, vp, u64, u32]
         getattr(lib, "psacx_ansv_" + suf).argtypes = [vp, vp, u64, i32, i32, u64, vp, vp]
+        getattr(lib, "psacx_ansv_dev_" + suf).argtypes = [vp, vp, u64, i32, i32, u64, vp, vp]
     lib.psacx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.psacx_profile.argtypes = [vp, i32]
     lib.psacx_suffix_tree_u32.argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(C.c_uint32)]

@@ -37,44 +37,54 @@ __device__ __forceinline__ uint64_t nsv_typed(const Pyramid<T>& P, uint64_t n, u
 template <typename T>
 __global__ void ansv_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type, uint64_t nonsv,
                             uint64_t* __restrict__ left, uint64_t* __restrict__ right) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t l = nsv_typed<T, true>(P, n, i, left_type);
-        const uint64_t r = nsv_typed<T, false>(P, n, i, right_type);
-        left[i] = l == NSV_NONE ? nonsv : l;
-        right[i] = r == NSV_NONE ? nonsv : r;
+    const T* __restrict__ a = P.lvl[0];
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
+    const unsigned lane = lane_id();
+    for (uint64_t base = wave_id * 64; base < n; base += nwaves * 64) {      // one wave per 64 consecutive elements
+        const uint64_t i = base + lane;
+        const T cur = i < n ? a[i] : (T)0;
+        const T prev = i >= 64 ? a[i - 64] : (T)0;
+        const T next = i + 64 < n ? a[i + 64] : (T)0;
+        const uint64_t l = nsv_tile_wave<T, true>(P, n, base, cur, prev, left_type);
+        const uint64_t r = nsv_tile_wave<T, false>(P, n, base, cur, next, right_type);
+        if (i < n) {
+            left[i] = l == NSV_NONE ? nonsv : l;
+            right[i] = r == NSV_NONE ? nonsv : r;
+        }
     }
 }
 
+// dev: in / left / right are device pointers (results stay in HBM); otherwise host pointers, staged here
 template <typename T>
-int ansv_host(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* left, uint64_t* right) {
+int ansv_run(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* left, uint64_t* right, bool dev) {
     if (!c || !in || !left || !right || n == 0 || lt < 0 || lt > 2 || rt < 0 || rt > 2) return PSACX_EINVAL;
     PSACX_HIP(c, hipSetDevice(c->device));
     Pyramid<T> P;
     T* d_in = nullptr; uint64_t *d_l = nullptr, *d_r = nullptr;
     auto layout = [&](Arena& a) {
-        d_in = a.take<T>(n); d_l = a.take<uint64_t>(n); d_r = a.take<uint64_t>(n);
-        P.lvl[0] = d_in; P.len[0] = n; P.nlev = 1;
-        uint64_t len = n;
-        while (len > 64 && P.nlev < PYR_MAX) {
-            len = (len + 63) / 64;
-            P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len; P.nlev++;
-        }
+        if (dev) { d_in = const_cast<T*>(in); d_l = left; d_r = right; }
+        else { d_in = a.take<T>(n); d_l = a.take<uint64_t>(n); d_r = a.take<uint64_t>(n); }
+        nsv_pyramid_layout<T>(a, d_in, n, P);
     };
     { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
     Arena ar(c->slab);
     layout(ar);
-    PSACX_HIP(c, hipMemcpyAsync(d_in, in, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (!dev) PSACX_HIP(c, hipMemcpyAsync(d_in, in, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    ProfScope* ps = new ProfScope(c, TC_TOTAL);
     for (int L = 1; L < P.nlev; ++L) {
         hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
                            P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
-        PSACX_HIP(c, hipGetLastError());
     }
     hipLaunchKernelGGL((ansv_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r);
+    delete ps;
     PSACX_HIP(c, hipGetLastError());
-    PSACX_HIP(c, hipMemcpyAsync(left, d_l, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    PSACX_HIP(c, hipMemcpyAsync(right, d_r, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (!dev) {
+        PSACX_HIP(c, hipMemcpyAsync(left, d_l, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipMemcpyAsync(right, d_r, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->profile) prof_collect(c);
     return PSACX_OK;
 }
 
@@ -89,13 +99,22 @@ template <typename T>
 __global__ void st_nodes_kernel(Pyramid<T> P, uint64_t n, const T* __restrict__ SA, const uint8_t* __restrict__ text,
                                 CodeTable tab, uint64_t row, unsigned long long* __restrict__ nodes) {
     const T* __restrict__ LCP = P.lvl[0];
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
+    const unsigned lane = lane_id();
+    for (uint64_t base = wave_id * 64; base < n; base += nwaves * 64) {      // one wave per 64 consecutive LCP indices
+        const uint64_t i = base + lane;
+        const T cur = i < n ? LCP[i] : (T)0;
+        const T prv = i >= 64 ? LCP[i - 64] : (T)0;
+        const T nxt = i + 64 < n ? LCP[i + 64] : (T)0;
+        // both searches are wave-wide (every lane takes part), so they come before any per-element branch
+        const uint64_t ln = nsv_tile_wave<T, true>(P, n, base, cur, prv, 2);
+        const uint64_t rn = nsv_tile_wave<T, false>(P, n, base, cur, nxt, 0);
+        if (i >= n) continue;
         const uint64_t sa = SA[i];
-        const uint64_t li = LCP[i];
+        const uint64_t li = cur;
         // ---- the leaf n + i (suffix_tree.hpp:72-143)
         uint64_t parent, lcp_val;
-        const uint64_t ln = i ? nsv_typed<T, true>(P, n, i, 2) : NSV_NONE;
         if (i == 0) {
             lcp_val = n > 1 ? (uint64_t)LCP[1] : 0;
             parent = lcp_val > 0 ? 1 : 0;
@@ -110,7 +129,6 @@ __global__ void st_nodes_kernel(Pyramid<T> P, uint64_t n, const T* __restrict__ 
         nodes[parent * row + (ci < n ? tab.c[text[ci]] : 0)] = n + i;
         // ---- the internal node i (suffix_tree.hpp:146-222)
         if (i == 0 || li == 0) continue;
-        const uint64_t rn = nsv_typed<T, false>(P, n, i, 0);
         const uint64_t lv = LCP[ln];                  // exists because LCP[0] = 0
         if (rn == NSV_NONE) {
             if (lv == li) continue;                   // duplicate of the node further left
@@ -174,10 +192,16 @@ int suffix_tree_host_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint6
 }
 
 int ansv_host_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
-    return ansv_host<uint32_t>(c, in, n, lt, rt, nonsv, l, r);
+    return ansv_run<uint32_t>(c, in, n, lt, rt, nonsv, l, r, false);
 }
 int ansv_host_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
-    return ansv_host<uint64_t>(c, in, n, lt, rt, nonsv, l, r);
+    return ansv_run<uint64_t>(c, in, n, lt, rt, nonsv, l, r, false);
+}
+int ansv_dev_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_run<uint32_t>(c, in, n, lt, rt, nonsv, l, r, true);
+}
+int ansv_dev_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_run<uint64_t>(c, in, n, lt, rt, nonsv, l, r, true);
 }
 
 } // namespace psacx

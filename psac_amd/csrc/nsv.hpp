@@ -51,6 +51,93 @@ __device__ __forceinline__ uint64_t nsv_search(const Pyramid<T>& P, uint64_t i, 
 }
 
 
+// ---- wave-cooperative forms: all 64 lanes of the calling wave take part, arguments are wave-uniform.
+// One step looks at a whole 64-entry group with one coalesced load and one ballot, so a search costs a
+// handful of memory round trips instead of one per entry walked.
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t nsv_search_wave(const Pyramid<T>& P, uint64_t pos, T v, bool strict) {
+    const unsigned lane = lane_id();
+    uint64_t p = pos, j = 0;
+    int L = 0;
+    for (;;) {
+        const T* a = P.lvl[L];
+        const uint64_t len = P.len[L];
+        const uint64_t gstart = p & ~63ull;
+        const uint64_t idx = gstart + lane;
+        const bool in = idx < len && (LEFT ? idx < p : idx > p);
+        const T x = in ? a[idx] : (T)0;
+        const uint64_t m = __ballot(in && (strict ? x < v : x <= v));
+        if (m) { j = gstart + (LEFT ? 63u - (unsigned)__builtin_clzll(m) : (unsigned)__builtin_ctzll(m)); break; }
+        if (LEFT ? gstart == 0 : gstart + 64 >= len) return NSV_NONE;
+        p >>= 6; ++L;
+    }
+    while (L > 0) {
+        const T* a = P.lvl[L - 1];
+        const uint64_t idx = (j << 6) + lane;
+        const bool in = idx < P.len[L - 1];
+        const T x = in ? a[idx] : (T)0;
+        const uint64_t m = __ballot(in && (strict ? x < v : x <= v));      // never empty: the parent qualified
+        j = (j << 6) + (LEFT ? 63u - (unsigned)__builtin_clzll(m) : (unsigned)__builtin_ctzll(m));
+        --L;
+    }
+    return j;
+}
+
+// type 0 nearest_sm, 1 nearest_eq, 2 furthest_eq (ansv_common.hpp:20-22) for element i with value v
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t nsv_typed_wave(const Pyramid<T>& P, uint64_t n, uint64_t i, T v, int type) {
+    if (type == 0) return nsv_search_wave<T, LEFT>(P, i, v, true);
+    const uint64_t j = nsv_search_wave<T, LEFT>(P, i, v, false);
+    if (type == 1 || j == NSV_NONE) return j;
+    const T u = P.lvl[0][j];
+    const uint64_t s = nsv_search_wave<T, LEFT>(P, j, u, true);      // first strictly smaller beyond j
+    if (LEFT) {
+        if (s == NSV_NONE) { if (P.lvl[0][0] <= u) return 0; return nsv_search_wave<T, false>(P, 0, u, false); }
+        return nsv_search_wave<T, false>(P, s, u, false);
+    } else {
+        if (s == NSV_NONE) { if (P.lvl[0][n - 1] <= u) return n - 1; return nsv_search_wave<T, true>(P, n - 1, u, false); }
+        return nsv_search_wave<T, true>(P, s, u, false);
+    }
+}
+
+// Nearest smaller value of the 64 consecutive elements base .. base + 63 (one per lane, base a multiple of
+// 64) on one side.  First every lane looks at its 64 neighbours on that side, which the wave already holds
+// in registers (`cur` = in[base + lane], `other` = in[base - 64 + lane] for LEFT / in[base + 64 + lane]):
+// 64 shuffle steps, no memory access, resolves all but a few per cent of the elements of an LCP array.
+// The rest are taken one at a time by the whole wave (nsv_typed_wave).
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t nsv_tile_wave(const Pyramid<T>& P, uint64_t n, uint64_t base, T cur, T other, int type) {
+    const unsigned lane = lane_id();
+    const uint64_t i = base + lane;
+    unsigned phase = i < n ? 0u : 3u;      // 0 look for the first hit, 1 extend the run of equal values, 2 found, 3 none
+    unsigned best = 0;
+    T u = 0;
+    for (unsigned d = 1; d <= 64; ++d) {
+        const int src = LEFT ? (int)lane - (int)d : (int)lane + (int)d;
+        const T xc = shfl<T>(cur, src & 63);
+        const T xo = shfl<T>(other, src & 63);
+        const T x = (src >= 0 && src < 64) ? xc : xo;
+        const bool valid = LEFT ? i >= d : i + d < n;
+        if (phase < 2) {
+            if (!valid) phase = phase == 1 ? 2u : 3u;                 // ran off the array
+            else if (phase == 0) {
+                if (type == 0 ? x < cur : x <= cur) { best = d; if (type == 2) { u = x; phase = 1; } else phase = 2; }
+            } else if (x < u) phase = 2;
+            else if (x == u) best = d;
+        }
+    }
+    uint64_t res = phase == 3 ? NSV_NONE : (LEFT ? i - best : i + best);
+    uint64_t pending = __ballot(phase < 2);
+    while (pending) {
+        const int src = __builtin_ctzll(pending);
+        const T vv = shfl<T>(cur, src);
+        const uint64_t r = nsv_typed_wave<T, LEFT>(P, n, base + (unsigned)src, vv, type);
+        if ((int)lane == src) res = r;
+        pending &= pending - 1;
+    }
+    return res;
+}
+
 // levels of a search pyramid over `m` values: the top level is a single group of <= 64 entries
 template <typename T>
 inline void nsv_pyramid_layout(Arena& a, const T* values, uint64_t m, Pyramid<T>& P) {

@@ -22,6 +22,8 @@ int suffix_tree_host_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, 
 int suffix_tree_host_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t*, uint32_t*);
 int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 int ansv_host_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
+int ansv_dev_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
+int ansv_dev_u64(psacx_ctx*, const uint64_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
 }
 
 using namespace psacx;
@@ -152,6 +154,12 @@ int psacx_check_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64
     return check_dev_u64(c, t, n, sa, isa, lcp, e);
 }
 
+int psacx_ansv_dev_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_dev_u32(c, in, n, lt, rt, nonsv, l, r);
+}
+int psacx_ansv_dev_u64(psacx_ctx* c, const uint64_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
+    return ansv_dev_u64(c, in, n, lt, rt, nonsv, l, r);
+}
 int psacx_ansv_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {
     return ansv_host_u32(c, in, n, lt, rt, nonsv, l, r);
 }

@@ -237,6 +237,14 @@ def check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, index_bits):
     return list(err)
 
 
+def ansv_device(ctx, d_in, n, d_left, d_right, index_bits, left_type=NEAREST_SM, right_type=NEAREST_SM, nonsv=0):
+    """ansv<T, left_type, right_type> with the input (n index_t) and both results (n uint64 each) resident in
+    HBM, e.g. over the LCP array construct_device left there (suffix_tree.hpp:62)."""
+    fn = getattr(ctx._lib, "psacx_ansv_dev_u%d" % index_bits)
+    ctx.check(fn(ctx.handle, C.c_void_p(d_in), int(n), int(left_type), int(right_type), int(nonsv),
+                 C.c_void_p(d_left), C.c_void_p(d_right)))
+
+
 def ansv(values, left_type=NEAREST_SM, right_type=NEAREST_SM, nonsv=0, ctx=None):
     """ansv<T,left_type,right_type>(in, left_nsv, right_nsv, comm) (ansv.hpp:2042-2051), one rank."""
     v = np.ascontiguousarray(values)

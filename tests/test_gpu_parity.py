@@ -613,3 +613,23 @@ def test_degenerate_texts_above_the_two_stage_threshold(ctx):
              (np.concatenate([np.full((1 << 22) - 1, 65, np.uint8), np.array([66], np.uint8)]), 32), (inputs.dna(1 << 21, 3), 32)]
     for text, bits in cases:
         same_as_oracle(ctx, text, bits=bits)
+
+
+def test_ansv_device_resident(ctx):
+    # psacx_ansv_dev_*: LCP left in HBM by the construction -> ANSV without leaving the device (psac -t's
+    # pair: left furthest_eq, right nearest_sm, suffix_tree.hpp:62); 2^24 characters, compared with the oracle
+    import psac_amd
+    n = 1 << 24
+    text = inputs.dna(n, 21)
+    d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+    d_sa, d_isa, d_lcp = ctx.alloc(n * 4), ctx.alloc(n * 4), ctx.alloc(n * 4)
+    d_l, d_r = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    sa = psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
+    sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+    none = (1 << 64) - 1
+    psac_amd.ansv_device(ctx, d_lcp, n, d_l, d_r, 32, 2, 0, none)
+    lcp = np.empty(n, np.uint32); L = np.empty(n, np.uint64); R = np.empty(n, np.uint64)
+    ctx.d2h(lcp, d_lcp); ctx.d2h(L, d_l); ctx.d2h(R, d_r)
+    assert np.array_equal(L, O.ansv(lcp, True, 2, none)) and np.array_equal(R, O.ansv(lcp, False, 0, none))
+    for p in (d_text, d_sa, d_isa, d_lcp, d_l, d_r):
+        ctx.free(p)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""ANSV over an LCP array resident in HBM: tools/ansv_time.py <log2 n> <bits>.  Constructs SA+LCP of random DNA,
+then times psacx_ansv_dev_* (left furthest_eq, right nearest_sm: the pair psac -t uses)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import inputs
+import psac_amd
+
+logn = int(sys.argv[1]); bits = int(sys.argv[2])
+n = 1 << logn; w = bits // 8
+ctx = psac_amd.Context(0)
+text = inputs.dna(n, 1)
+d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+d_sa, d_isa, d_lcp = ctx.alloc(n * w), ctx.alloc(n * w), ctx.alloc(n * w)
+d_l, d_r = ctx.alloc(n * 8), ctx.alloc(n * 8)
+sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
+sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+for it in range(3):
+    t0 = time.perf_counter()
+    psac_amd.ansv_device(ctx, d_lcp, n, d_l, d_r, bits, 2, 0, (1 << 64) - 1)
+    dt = time.perf_counter() - t0
+print("ANSV(furthest_eq, nearest_sm) over the LCP of 2^%d random DNA characters, uint%d, HBM-resident: %.2f ms = %.1f G elements/s"
+      % (logn, bits, dt * 1e3, n / dt / 1e9))
