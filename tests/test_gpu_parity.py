@@ -633,3 +633,15 @@ def test_ansv_device_resident(ctx):
     assert np.array_equal(L, O.ansv(lcp, True, 2, none)) and np.array_equal(R, O.ansv(lcp, False, 0, none))
     for p in (d_text, d_sa, d_isa, d_lcp, d_l, d_r):
         ctx.free(p)
+
+
+def test_no_fast_and_k_above_the_two_stage_threshold(ctx):
+    # fast_resolval = false (every round works on all n records) and a caller-supplied k with the two-stage first
+    # round active (n >= 2^21); uint32 and uint64
+    text = inputs.dna((1 << 21) + 100, 17)
+    same_as_oracle(ctx, text, bits=32, fast=False)
+    same_as_oracle(ctx, text, bits=64, fast=False, k=12)
+    same_as_oracle(ctx, text, bits=32, k=7)
+    text = inputs.ascii128((1 << 21) + 5, 4)
+    same_as_oracle(ctx, text, bits=64)
+    same_as_oracle(ctx, text, bits=32, fast=False)
