@@ -128,9 +128,6 @@ __device__ __forceinline__ uint64_t nsv_tile_wave(const Pyramid<T>& P, uint64_t 
     }
     uint64_t res = phase == 3 ? NSV_NONE : (LEFT ? i - best : i + best);
     uint64_t pending = __ballot(phase < 2);
-#ifdef PSACX_NSV_NO_PENDING
-    pending = 0;
-#endif
     while (pending) {
         const int src = __builtin_ctzll(pending);
         const T vv = shfl<T>(cur, src);
