@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # (profiles/): FETCH_SIZE doubled (the gfx950 correction for coalesced streams) + WRITE_SIZE.
 # Valid for the default workload only (2^28 uint32 records per launch).
 # [1] three-word form, profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
-# [2] two-word form, profiles/r01c_pmc_*.txt: (2 x 5903929.6 + 12708385.0) KiB over 6 launches
-TRAFFIC_PER_LAUNCH = {1: 6553287372, 2: 4184105676}
+# [2] two-word form, profiles/r01d_pmc_*.txt: (2 x 5903929.2 + 12713084.0) KiB over 6 launches
+TRAFFIC_PER_LAUNCH = {1: 6553287372, 2: 4184907503}
 
 
 def parse():
