@@ -294,7 +294,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_HIP(c, hipMemGetInfo(&free_b, &total_b));
         const size_t margin = (size_t)512 << 20;
         const size_t avail = free_b + c->slab_bytes > margin ? free_b + c->slab_bytes - margin : 0;
-        if (getenv("PSACX_FORCE_DIET") || (need > c->slab_bytes && need > avail)) {
+        if ((getenv("PSACX_FORCE_DIET") && !no_fast) || (need > c->slab_bytes && need > avail)) {
             Arena d0(nullptr);
             carve<T>(d0, w, n, WITH_LCP, d_lcp, true, 0, d_sa, d_isa);
             const size_t base = d0.off + 8192;
@@ -304,7 +304,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             }
             cap = std::min<uint64_t>(n, (avail - base) / (5 * sizeof(T)) > 4096 ? (avail - base) / (5 * sizeof(T)) - 4096 : 0);
             if (const char* e = getenv("PSACX_DIET_CAP")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 10));
-            if (cap < 1024) { c->hip_err = "workspace does not fit in HBM"; return PSACX_ENOMEM; }
+            if (cap < std::min<uint64_t>(n, 1024)) { c->hip_err = "workspace does not fit in HBM"; return PSACX_ENOMEM; }
             diet = true;
             Arena d1(nullptr);
             carve<T>(d1, w, n, WITH_LCP, d_lcp, true, cap, d_sa, d_isa);
