@@ -195,10 +195,11 @@ inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
 }
 
 template <typename T> struct ScatterCfg;
-// DEF: three-word records, DEF2: two-word records (measured per word size: 2^29 uint64 two-word records
-// take 3.8 ms per pass with 512 x 8 tiles against 5.2 ms with 256 x 8)
+// DEF: three-word records, DEF2: two-word records.  Measured per word size: uint32 512 x 12; uint64 512 x 8
+// (two-word: 3.8 ms per 2^29-record pass against 5.2 ms with 256 x 8; three-word: 2.35 against 2.60 ms at 2^28,
+// 22 against 32 ms at 2^31, 47 against 78 ms at 2^32 where the smaller tiles hit a stride artefact)
 template <> struct ScatterCfg<uint32_t> { static constexpr int DEF = 7; static constexpr int DEF2 = 7; };
-template <> struct ScatterCfg<uint64_t> { static constexpr int DEF = 0; static constexpr int DEF2 = 2; };
+template <> struct ScatterCfg<uint64_t> { static constexpr int DEF = 2; static constexpr int DEF2 = 2; };
 
 inline int sort_cfg_env() {
     static int v = -2;
