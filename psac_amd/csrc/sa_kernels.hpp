@@ -760,11 +760,13 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
             else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
         }
         // adjacent exchanges of strictly descending neighbours only: stable
+        bool moved = false;                 // a group that is already in order writes back word 2 only
 #pragma unroll
         for (int r = 0; r < G; ++r) {
 #pragma unroll
             for (int i = r & 1; i + 1 < G; i += 2) {
                 const bool sw = k1[i] > k1[i + 1] || (k1[i] == k1[i + 1] && k2[i] > k2[i + 1]);
+                moved |= sw;
                 const T a1 = sw ? k1[i + 1] : k1[i], b1 = sw ? k1[i] : k1[i + 1];
                 const T a2 = sw ? k2[i + 1] : k2[i], b2 = sw ? k2[i] : k2[i + 1];
                 const T a3 = sw ? sa[i + 1] : sa[i], b3 = sw ? sa[i] : sa[i + 1];
@@ -774,8 +776,9 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             if ((unsigned)i < len) {
-                if (lo1) S1[e + i] = k1[i];
-                S2[e + i] = k2[i]; SA[e + i] = sa[i];
+                if (lo1 && moved) S1[e + i] = k1[i];
+                S2[e + i] = k2[i];
+                if (moved) SA[e + i] = sa[i];
             }
         }
     }
