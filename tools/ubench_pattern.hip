@@ -26,6 +26,26 @@ __global__ __launch_bounds__(BLOCK) void pattern_kernel(const uint32_t* __restri
         oa[d] = x[j]; ob[d] = y[j]; oc[d] = z[j];
     }
 }
+// the same pattern for two-word records (the prefix sort / inversion levels): 6144-record tiles as used there
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void pattern2_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                               uint32_t* __restrict__ oa, uint32_t* __restrict__ ob, uint64_t n, int nb) {
+    constexpr int TILE = BLOCK * ITEMS;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t base = tile * TILE;
+    const unsigned run = TILE / nb;
+    const uint64_t bin_stride = n / nb;
+    uint32_t x[ITEMS], y[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { unsigned p = threadIdx.x + j * BLOCK; x[j] = a[base + p]; y[j] = b[base + p]; }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        unsigned p = threadIdx.x + j * BLOCK;
+        unsigned bin = p / run, r = p % run;
+        uint64_t d = (uint64_t)bin * bin_stride + tile * run + r;
+        if (d < n) { oa[d] = x[j]; ob[d] = y[j]; }
+    }
+}
 __global__ void copy3(const uint4* a, const uint4* b, const uint4* c, uint4* oa, uint4* ob, uint4* oc, uint64_t n4) {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) { oa[i] = a[i]; ob[i] = b[i]; oc[i] = c[i]; }
@@ -61,6 +81,13 @@ int main() {
         snprintf(nm, 64, "pattern 256x16 tile 4096, %d bins", nb); timeit(nm, GB3, [&] { pattern_kernel<256, 16><<<(unsigned)(n / 4096), 256>>>(a, b, c, oa, ob, oc, n, nb); });
         snprintf(nm, 64, "pattern 512x16 tile 8192, %d bins", nb); timeit(nm, GB3, [&] { pattern_kernel<512, 16><<<(unsigned)(n / 8192), 512>>>(a, b, c, oa, ob, oc, n, nb); });
         snprintf(nm, 64, "pattern 1024x16 tile 16384, %d bins", nb); timeit(nm, GB3, [&] { pattern_kernel<1024, 16><<<(unsigned)(n / 16384), 1024>>>(a, b, c, oa, ob, oc, n, nb); });
+    }
+    const double GB2 = 4.0 * n * 4 / 1e9;
+    const uint64_t n2 = n / 6144 * 6144;
+    for (int nb : {1, 256}) {
+        char nm[64];
+        snprintf(nm, 64, "two-word pattern 512x12 tile 6144, %d bins", nb);
+        timeit(nm, GB2 * n2 / n, [&] { pattern2_kernel<512, 12><<<(unsigned)(n2 / 6144), 512>>>(a, b, oa, ob, n2, nb); });
     }
     return 0;
 }
