@@ -338,11 +338,12 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
         halo = got[r + 1] if r + 1 < P else text_block[:0]
     else:
         halo = text_block[:0]
-    K1, K2 = ops.make_keys(text_block, halo, m, two_k, pcodes, lc, c1, c2)
-    V = ops.iota(m, off)
     spec = min(two_k - 1, n)
+    front = spec if r == 0 else 0                        # room for the moved records in front of rank 0's own
+    K1, K2 = ops.make_keys(text_block, halo, m, two_k, pcodes, lc, c1, c2, front)
+    V = ops.iota(m, off, front)
     mine = min(m, max(0, off + m - (n - spec)))          # short suffixes in this block (its tail)
-    tails = [torch.flip(a[m - mine:], [0]) for a in (K1, K2, V)]
+    tails = [torch.flip(a[front + m - mine:], [0]) for a in (K1, K2, V)]
     if P > 1:
         moved, rc = yield from comm.exchange(tails, [0] + [mine] * P)      # everything to rank 0
         if r == 0:
@@ -350,11 +351,10 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
             moved = [torch.cat([a[cuts[s]:cuts[s + 1]] for s in range(P - 1, -1, -1)]) for a in moved]
     else:
         moved = tails
-    keep = [a[:m - mine] for a in (K1, K2, V)]
     if r == 0:
-        K1, K2, V = [torch.cat([mv, kp]) for mv, kp in zip(moved, keep)]
-    else:
-        K1, K2, V = keep
+        for a, mv in zip((K1, K2, V), moved):
+            a[:front] = mv                               # (the exchange hands rank 0 exactly `spec` records)
+    K1, K2, V = [a[:front + m - mine] for a in (K1, K2, V)]
     S1, S2, SA = yield from dist_sort(comm, ops, K1, K2, V, sizes, c1 * lc, c2 * lc)
     del K1, K2, V
 

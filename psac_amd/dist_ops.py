@@ -91,17 +91,20 @@ class HipOps(object):
         self._chk(self.lib.psacx_op_char_hist(self.ctx, self._p(text), int(text.numel()), self._p(h)))
         return h
 
-    def make_keys(self, text, halo, m, two_k, codes, l, c1, c2):
+    def make_keys(self, text, halo, m, two_k, codes, l, c1, c2, front=0):
+        """front: the arrays get `front` extra entries before the keys (filled in by the caller), so that
+        records can be put in front of this rank's own without copying the block."""
         pad = torch.zeros(max(0, two_k - int(halo.numel())), dtype=torch.uint8, device=self.device)
         buf = torch.cat([text, halo[:two_k], pad])            # the block followed by its halo (zeros past the end)
-        k1, k2 = self.empty_idx(m), self.empty_idx(m)
+        k1, k2 = self.empty_idx(front + m), self.empty_idx(front + m)
         tab = (C.c_uint16 * 256)(*codes)
-        self._chk(self._f("make_keys")(self.ctx, self._p(buf), int(m), int(buf.numel()), tab, l, c1, c2, self._p(k1), self._p(k2)))
+        self._chk(self._f("make_keys")(self.ctx, self._p(buf), int(m), int(buf.numel()), tab, l, c1, c2,
+                                       self._p(k1[front:]), self._p(k2[front:])))
         return k1, k2
 
-    def iota(self, m, start):
-        t = self.empty_idx(m)
-        self._chk(self._f("iota")(self.ctx, self._p(t), int(m), int(start)))
+    def iota(self, m, start, front=0):
+        t = self.empty_idx(front + m)
+        self._chk(self._f("iota")(self.ctx, self._p(t[front:]), int(m), int(start)))
         return t
 
     # -- sorting -------------------------------------------------------------------------

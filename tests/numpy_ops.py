@@ -27,8 +27,8 @@ class NumpyOps(object):
     def empty_like(self, t):
         return torch.zeros_like(t)
 
-    def iota(self, m, start):
-        return self.t(np.arange(start, start + m, dtype=np.uint64))
+    def iota(self, m, start, front=0):
+        return self.t(np.concatenate([np.zeros(front, np.uint64), np.arange(start, start + m, dtype=np.uint64)]))
 
     def value_at(self, t, j):
         return int(self.u(t)[j])
@@ -43,7 +43,7 @@ class NumpyOps(object):
     def char_hist(self, text):
         return torch.from_numpy(np.bincount(text.numpy(), minlength=256).astype(np.int64))
 
-    def make_keys(self, text, halo, m, two_k, codes, l, c1, c2):
+    def make_keys(self, text, halo, m, two_k, codes, l, c1, c2, front=0):
         buf = np.zeros(m + two_k, np.uint64)
         lut = np.array(codes, np.uint64)
         buf[:m] = lut[text.numpy()]
@@ -54,7 +54,8 @@ class NumpyOps(object):
             k1 = (k1 << np.uint64(l)) | buf[t:t + m]
         for t in range(c2):
             k2 = (k2 << np.uint64(l)) | buf[c1 + t:c1 + t + m]
-        return self.t(k1), self.t(k2)
+        z = np.zeros(front, np.uint64)
+        return self.t(np.concatenate([z, k1])), self.t(np.concatenate([z, k2]))
 
     # -- sorting -------------------------------------------------------------------------
     def put_perm(self, block, gidx, off, vals):
