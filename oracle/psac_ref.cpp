@@ -15,6 +15,10 @@
 // captured from the reference run in its container,
 // committed under tests/golden/.  See tests/test_oracle_golden.py.
 //
+// The independent loops carry OpenMP pragmas; they only take effect in the second build
+// (libpsac_oracle_mt.so: -fopenmp -D_GLIBCXX_PARALLEL, std::sort becomes the libstdc++ parallel
+// sort), which bench.py's cpu_baseline leg times on all host cores.  The tests use the scalar build.
+//
 // Each function cites the reference file:line whose behaviour it follows.
 // All citations are relative to /root/reference/.
 #include <algorithm>
@@ -116,7 +120,8 @@ template <typename T>
 void shift_left(const std::vector<T>& B, uint64_t h, std::vector<T>& B2) {
     const uint64_t n = B.size();
     B2.assign(n, 0);
-    for (uint64_t i = 0; i + h < n; ++i) B2[i] = B[i + h];
+    #pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < (h < n ? n - h : 0); ++i) B2[i] = B[i + h];
 }
 
 // include/idxsort.hpp:10-14, :23-83: (v1, v2, idx) tuples sorted by (v1, v2);
@@ -126,11 +131,13 @@ template <typename T>
 void pair_sort(std::vector<T>& B1, std::vector<T>& B2, std::vector<T>& SA) {
     const uint64_t n = B1.size();
     std::vector<Tup<T> > t(n);
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; ++i) { t[i].a = B1[i]; t[i].b = B2[i]; t[i].idx = (T)i; }
     std::sort(t.begin(), t.end(), [](const Tup<T>& x, const Tup<T>& y) {
         return x.a < y.a || (x.a == y.a && x.b < y.b);
     });
     SA.resize(n);
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; ++i) { B1[i] = t[i].a; B2[i] = t[i].b; SA[i] = t[i].idx; }
 }
 // idxsort_vectors<T, T, true> (idxsort.hpp:23-83 with _STABLE): equal pairs keep their input order
@@ -138,11 +145,13 @@ template <typename T>
 void pair_sort_stable(std::vector<T>& B1, std::vector<T>& B2, std::vector<T>& SA) {
     const uint64_t n = B1.size();
     std::vector<Tup<T> > t(n);
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; ++i) { t[i].a = B1[i]; t[i].b = B2[i]; t[i].idx = (T)i; }
     std::stable_sort(t.begin(), t.end(), [](const Tup<T>& x, const Tup<T>& y) {
         return x.a < y.a || (x.a == y.a && x.b < y.b);
     });
     SA.resize(n);
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; ++i) { B1[i] = t[i].a; B2[i] = t[i].b; SA[i] = t[i].idx; }
 }
 
@@ -158,11 +167,13 @@ void rebucket_pairs(std::vector<T>& B1, const std::vector<T>& B2, uint64_t& unf_
     const uint64_t n = B1.size();
     std::vector<uint8_t> head(n);
     head[0] = 1;
+#pragma omp parallel for schedule(static)
     for (uint64_t i = 1; i < n; ++i) {
         bool same = B1[i] == B1[i - 1] && B2[i] == B2[i - 1];
         if (gsa_mask && (B2[i - 1] & gsa_mask) == 0) same = false;
         head[i] = !same;
     }
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < n; ++i) B1[i] = head[i] ? (T)(i + 1) : (T)0;
     unf_b = 0; unf_e = 0;
     for (uint64_t i = 1; i < n; ++i) {
@@ -177,6 +188,7 @@ void rebucket_pairs(std::vector<T>& B1, const std::vector<T>& B2, uint64_t& unf_
 template <typename T>
 void permute_to_isa(std::vector<T>& val, const std::vector<T>& idx) {
     std::vector<T> out(val.size());
+    #pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < val.size(); ++i) out[idx[i]] = val[i];
     val.swap(out);
 }
@@ -260,6 +272,7 @@ struct Engine {
         LCP[0] = 0;
         if (want_lc) Lc.assign(n, 0);
         const unsigned l = alpha.bits;
+#pragma omp parallel for schedule(static)
         for (uint64_t i = 1; i < n; ++i) {
             if (B1[i - 1] != B1[i] || B2[i - 1] != B2[i]) {
                 unsigned v = kmer_lcp<T>(B1[i - 1], B1[i], k, l);
@@ -486,6 +499,7 @@ struct Engine {
         }
         if (!did_round) return 2;
         if (unf_b > 0 && !Bsa.empty()) chase(Bsa, 2 * h);
+        #pragma omp parallel for schedule(static)
         for (uint64_t i = 0; i < n; ++i) B[i] -= 1;      // suffix_array.hpp:460-464
         return 0;
     }

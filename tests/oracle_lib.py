@@ -40,6 +40,27 @@ def lib():
     return _lib
 
 
+_SO_MT = os.path.join(ROOT, "oracle", "libpsac_oracle_mt.so")
+
+
+def construct_all_cores(text, bits=32):
+    """The same restatement built with OpenMP loops and the libstdc++ parallel-mode sort
+    (oracle/Makefile: libpsac_oracle_mt.so), for bench.py's CPU baseline leg.  Returns (SA, LCP)."""
+    src = os.path.join(ROOT, "oracle", "psac_ref.cpp")
+    if (not os.path.exists(_SO_MT)) or os.path.getmtime(_SO_MT) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libpsac_oracle_mt.so"], stdout=subprocess.DEVNULL)
+    mt = C.CDLL(_SO_MT)
+    t = as_text(text)
+    n = t.size
+    dt = _dt(bits)
+    SA = np.zeros(n, dt); ISA = np.zeros(n, dt); LCP = np.zeros(n, dt)
+    rc = getattr(mt, "psac_ref_construct_u%d" % bits)(_p(t), C.c_uint64(n), C.c_int(1), C.c_uint(0), _p(SA), _p(ISA), _p(LCP),
+                                                     None, C.c_uint32(0), None, None, None)
+    if rc != 0:
+        raise RuntimeError("oracle construct failed rc=%d" % rc)
+    return SA, LCP
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
