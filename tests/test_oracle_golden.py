@@ -265,3 +265,11 @@ def test_gsa_random_sets_against_definition():
             SA, LCP = O.gsa_by_definition(strings)
             assert np.array_equal(r["SA"].astype(np.uint64), SA), (trial, bits, k)
             assert np.array_equal(r["LCP"].astype(np.uint64), LCP), (trial, bits, k)
+
+
+def test_all_cores_build_matches_scalar_build():
+    # oracle/libpsac_oracle_mt.so (OpenMP loops + parallel-mode sort; bench.py's CPU baseline) against the scalar build
+    for text in (O.rand_dna(200000, 4), inputs.tandem(50000, 100, O.rand_dna(100, 2)), inputs.ascii128(100000, 7)):
+        SA, LCP = O.construct_all_cores(text, bits=32)
+        ref = O.construct(text, bits=32)
+        assert np.array_equal(SA, ref["SA"]) and np.array_equal(LCP, ref["LCP"])
