@@ -360,6 +360,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     const unsigned bits_w1 = ks.c1 * lc, bits_w2 = ks.c2 * lc;
     unsigned lead = bits_for(n - 1) + 3;                      // leading bits stage 1 sorts on (ties: ~ n / 2^lead)
     lead = (lead + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
+    // word 1 slightly too short for that (DNA, 32-bit words, 2^29 < n <= 2^30): all of word 1 still leaves
+    // fewer than a quarter of the suffixes tied, which is cheaper than carrying word 2 through five passes
+    const unsigned slack = getenv("PSACX_LEAD_SLACK") ? (unsigned)atoi(getenv("PSACX_LEAD_SLACK")) : 2u;
+    if (lead > bits_w1 && bits_for(n - 1) + slack <= bits_w1 && bits_w1 % RADIX_BITS == 0) lead = bits_w1;
     const bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
                            lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
