@@ -645,3 +645,19 @@ def test_no_fast_and_k_above_the_two_stage_threshold(ctx):
     text = inputs.ascii128((1 << 21) + 5, 4)
     same_as_oracle(ctx, text, bits=64)
     same_as_oracle(ctx, text, bits=32, fast=False)
+
+
+def test_scaled_down_twins_of_the_baseline_configs(ctx):
+    # every BASELINE config divided by 256 must match the CPU restatement bit for bit.
+    #   C3 / 256: 2^24 random ASCII (sigma = 128), uint64, one GPU
+    #   C4 / 256: 2^26 random DNA, uint64, 8 ranks of 2^23 (virtual ranks sharing this GPU, the HIP step ops)
+    text = inputs.ascii128(1 << 24, 42)
+    got = run(ctx, text, bits=64)
+    SA, LCP = O.construct_all_cores(text, bits=64)
+    assert np.array_equal(got.local_SA, SA) and np.array_equal(got.local_LCP, LCP)
+    assert np.array_equal(got.local_B[got.local_SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
+    text = inputs.dna(1 << 26, 1)
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, 8, 64)
+    SA, LCP = O.construct_all_cores(text, bits=64)
+    assert np.array_equal(sa, SA) and np.array_equal(lcp, LCP)
+    assert np.array_equal(isa[sa.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
