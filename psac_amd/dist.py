@@ -76,12 +76,16 @@ def bits_for(v):
 # ---------------------------------------------------------------------------------------
 # distributed primitives
 # ---------------------------------------------------------------------------------------
-def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
-    """Globally sorts records by (K1, K2); rank r ends with exactly targets[r] records, the
+def dist_sort(comm, ops, records, targets, bits1, bits2):
+    """records: list [K1, K2, V]; it is emptied, so the inputs can be released as soon as the partition pass
+    has copied them (they are three of the thirteen words per record this path holds at its peak).
+    Globally sorts records by (K1, K2); rank r ends with exactly targets[r] records, the
     concatenation over ranks being sorted (the contract psac needs from mxx::sort,
     idxsort.hpp:67-79).  Sample sort: sampled splitters -> one partition pass by destination ->
     all-to-all -> one local radix sort -> exact re-balance to the target sizes."""
     P, r = comm.size, comm.rank
+    K1, K2, V = records
+    del records[:]
     if P == 1:
         return ops.pair_sort(K1, K2, V, bits1, bits2, destroy=True)
     c = int(K1.numel())
@@ -94,6 +98,7 @@ def dist_sort(comm, ops, K1, K2, V, targets, bits1, bits2):
     splitters = [flat[min(len(flat) - 1, (len(flat) * d) // P)] for d in range(1, P)] if flat else []
     splitters = sorted(set(splitters))
     G1, G2, GV, bounds = ops.split_by(K1, K2, V, splitters, r)
+    del K1, K2, V
     bounds = list(bounds[:len(splitters) + 1]) + [c] * (P + 1 - (len(splitters) + 1))   # empty trailing groups
     parts, _ = yield from comm.exchange([G1, G2, GV], bounds)
     del G1, G2, GV
@@ -355,8 +360,9 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
         for a, mv in zip((K1, K2, V), moved):
             a[:front] = mv                               # (the exchange hands rank 0 exactly `spec` records)
     K1, K2, V = [a[:front + m - mine] for a in (K1, K2, V)]
-    S1, S2, SA = yield from dist_sort(comm, ops, K1, K2, V, sizes, c1 * lc, c2 * lc)
+    recs = [K1, K2, V]
     del K1, K2, V
+    S1, S2, SA = yield from dist_sort(comm, ops, recs, sizes, c1 * lc, c2 * lc)
 
     rounds = []
     shape = (lc, c1, c2)
@@ -401,7 +407,9 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
         ans = yield from dist_take(comm, ops, ISA, off, q, n)
         K2 = ops.finish_b2(ans, q, n)
         K1 = ops.take(Bsa, pos, off, n)
-        T1, T2, TV = yield from dist_sort(comm, ops, K1, K2, sa_act, counts, id_bits, id_bits)
+        recs = [K1, K2, sa_act]
+        del K1, K2, sa_act
+        T1, T2, TV = yield from dist_sort(comm, ops, recs, counts, id_bits, id_bits)
         prev, nxt = yield from neighbours(T1, T2, TV)
         lh = ops.last_head_refine(T1, T2, pos, prev)
         heads = yield from comm.all_gather_obj(lh)
