@@ -4,8 +4,14 @@
 One "step" = one full suffix-array + inverse-SA + LCP construction of the
 synthetic text, text already resident in HBM, results left in HBM.
 
-N = 1 workload (BASELINE.json configs[1]): 256 MiB random DNA (sigma = 4,
-splitmix64 seed 1), uint32 indices, SA + LCP.
+N = 1 workload: the north-star's headline shape, a 4 GiB random DNA string
+(sigma = 4, splitmix64 seed 1, n = 2^32), uint64 indices, SA + ISA + LCP on one
+MI355X (the largest single-GPU configuration; BASELINE.json configs[2], 4 GiB
+random ASCII, is `--alphabet ascii128`; configs[1], 256 MiB DNA with uint32
+indices, is `--n 268435456 --index 32`).  The text is generated in HBM
+(psacx_synth_text_dev), the result of the last timed step is verified in HBM
+(psacx_check_dev_*), and the PCIe-inclusive construct() time on host pointers
+(SURVEY 8(d) Metric 1) is reported beside `value` as `construct_host`.
 
 Prints ONE JSON line (rank 0): metric MChars/s, plus
   roofline     -- the dominant kernel (the radix scatter pass of the rank-pair
@@ -30,7 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Valid for the default workload only (2^28 uint32 records per launch).
 # [1] three-word form, profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
 # [2] two-word form, profiles/r01d_pmc_*.txt: (2 x 5903929.2 + 12713084.0) KiB over 6 launches
-TRAFFIC_PER_LAUNCH = {1: 6553287372, 2: 4184907503}
+# Keyed by (scatter form, records per launch, index bits).
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503}
 
 
 def parse():
@@ -38,16 +45,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 28, help="characters per GPU")
-    ap.add_argument("--index", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--n", type=int, default=None, help="characters per GPU (default: 2^32 at one GPU, 2^28 per GPU otherwise)")
+    ap.add_argument("--index", type=int, default=None, choices=(32, 64), help="index width (default: 64 above 2^31 characters)")
     ap.add_argument("--alphabet", default="dna", choices=("dna", "ascii128", "tandem"))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=1 << 28, help="characters for the CPU baseline leg (0 = skip); the default is the whole workload, ~8 s on the GPU box's 256 host threads")
     ap.add_argument("--no-lcp", action="store_true")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also time psacx_construct_* with host pointers (H2D of the text, D2H of SA/ISA/LCP); reported "
-                         "as an extra field, never as `value`")
-    return ap.parse_args()
+    ap.add_argument("--host-path", default="auto", choices=("auto", "full", "off"),
+                    help="also time psacx_construct_* with host pointers (H2D of the text, D2H of SA/ISA/LCP: SURVEY 8(d) "
+                         "Metric 1); reported as the extra field construct_host, never as `value`.  auto: the full workload "
+                         "when the host has the memory for its results, else 2^28 characters")
+    ap.add_argument("--no-check", action="store_true", help="skip the device checker on the last result")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.n is None:
+        a.n = (1 << 32) if (world == 1 and a.gpus == 1) else (1 << 28)
+    return a
 
 
 def make_text(kind, n, seed):
@@ -89,8 +102,10 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
         "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u%d" % bits, "data": "synthetic",
-        "config": {"workload": "%d MiB random %s per GPU (splitmix64 seed %d + rank), %d MiB in total, uint%d indices, "
-                               "SA+%s on %d x MI355X" % (n >> 20, a.alphabet, a.seed, (world * n) >> 20, bits,
+        "config": {"workload": "%d MiB %s per GPU (splitmix64 seed %d + rank), %d MiB in total, uint%d indices, "
+                               "SA+%s on %d x MI355X" % (n >> 20, {"dna": "random DNA (sigma 4)", "ascii128": "random ASCII (sigma 128)",
+                                                                   "tandem": "period-1024 tandem repeat of random DNA"}[a.alphabet],
+                                                         a.seed, (world * n) >> 20, bits,
                                                          "ISA" if a.no_lcp else "ISA+LCP", world),
                    "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism},
         "roofline": {"bound": "hbm", "kernel": kname,
@@ -100,7 +115,8 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                      "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                      "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
                      "bytes_per_record_per_pass": 2 * rec_words * w,
-                     "traffic": TRAFFIC_PER_LAUNCH.get(dom) if (world == 1 and n == (1 << 28) and bits == 32) else None},
+                     "traffic": TRAFFIC.get((dom, n, bits)) if world == 1 else None,
+                     "traffic_source": "PMC counters of the committed profile of this workload (profiles/), not measured in this run"},
     }
     if phases:
         out["phase_ms_last_step"] = phases
@@ -120,7 +136,8 @@ def main_distributed(a, rank, world, local_rank):
     from psac_amd import dist as D
     from psac_amd.comm import TorchComm
     from psac_amd.dist_ops import HipOps
-    n, bits = a.n, a.index
+    n = a.n
+    bits = a.index if a.index else (32 if world * n <= (1 << 31) else 64)
     if world * n > 0xFFFFFFFE:
         bits = 64
     ops = HipOps(bits, local_rank)
@@ -156,6 +173,19 @@ def main_distributed(a, rank, world, local_rank):
     dist.destroy_process_group()
 
 
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+KIND_ID = {"dna": 0, "ascii128": 1, "tandem": 2}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -163,17 +193,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("PSACX_BENCH_FORCE_DIST"):
         return main_distributed(a, rank, world, local_rank)
+    import ctypes as C
     import numpy as np
     import torch
     import psac_amd
 
     n = a.n
-    bits = a.index
+    bits = a.index if a.index else (32 if n <= (1 << 31) else 64)
     w = bits // 8
     ctx = psac_amd.Context(local_rank)
-    text = make_text(a.alphabet, n, a.seed + rank)
+    lib = ctx._lib
+    # the text is generated where it is used (psacx_synth_text_dev: the splitmix64 streams of SURVEY 8(d))
     d_text = ctx.alloc(n)
-    ctx.h2d(d_text, text)
+    ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID[a.alphabet], a.seed + rank, 1024))
     d_sa = ctx.alloc(n * w); d_isa = ctx.alloc(n * w); d_lcp = ctx.alloc(n * w)
     sa = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=ctx)
 
@@ -188,7 +220,7 @@ def main():
         step(False)
     barrier()
     # dominant kernel: the scatter kernel of a radix pass.  Large sorts use
-    # radix_scatter3_kernel (index 1), small ones radix_scatter_kernel (index 0); the
+    # radix_scatter3_kernel (index 1, or 2 for two-word records), small ones radix_scatter_kernel (index 0); the
     # roofline is quoted on whichever moved more bytes in the timed region.
     scat_ms = [0.0, 0.0, 0.0]; scat_bytes = [0, 0, 0]; scat_launches = [0, 0, 0]
     t0 = time.perf_counter()
@@ -200,10 +232,6 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    # sanity on the result of the last step (cheap device->host spot check)
-    head = np.empty(4, np.uint32 if bits == 32 else np.uint64)
-    ctx.d2h(head, d_lcp if not a.no_lcp else d_sa)
-
     phases = {"total": round(s.ms_total, 3), "alphabet": round(s.ms_alphabet, 3), "kmer": round(s.ms_kmer, 3),
               "sort_hist": round(s.ms_sort_hist, 3), "sort_scatter": round(s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, 3),
               "sort_tile_hist": round(s.ms_sort_tilehist, 3), "rebucket": round(s.ms_rebucket, 3),
@@ -211,20 +239,43 @@ def main():
               "rmq_build": round(s.ms_rmq_build, 3)}
     out = report(a, 1, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, int(s.k), int(s.bits_per_char),
                  int(s.n_rounds), "1 process per GPU")
-    if a.host_path:
-        hs = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=ctx)
-        hs.construct(text)                       # first call pays for page faults of the result arrays
+    out["config"]["workspace_GiB"] = round(s.workspace_bytes / 2.0 ** 30, 1)
+    # the result of the last timed step, verified where it lies (psacx_check_dev_*: SA a permutation inverse to ISA,
+    # suffix order, every LCP entry against a direct character comparison)
+    if not a.no_check:
         t1 = time.perf_counter()
-        hs.construct(text)
+        err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp, bits)
+        out["check"] = {"verified": err == [0, 0, 0, 0], "errors": err, "seconds": round(time.perf_counter() - t1, 2),
+                        "what": "device checker over the full result of the last timed step"}
+    # SURVEY 8(d) Metric 1 spans what psac brackets (src/psac.cpp:95-121): construct() on host memory, i.e. H2D of
+    # the text and D2H of SA / ISA / LCP included.  Reported beside `value`, never as `value`.
+    host_bytes = n * (1 + w * (2 if a.no_lcp else 3))
+    if a.host_path != "off":
+        hn = n
+        if a.host_path == "auto" and mem_available_bytes() < 1.3 * host_bytes + (8 << 30):
+            hn = 1 << 28
+        for p in (d_sa, d_isa, d_lcp):
+            ctx.free(p)
+        d_sa = d_isa = d_lcp = None
+        ctx.check(lib.psacx_trim(ctx.handle))
+        text = np.empty(hn, np.uint8)
+        ctx.d2h(text, d_text)
+        hs = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=ctx)
+        hs.construct(text)                       # first call pays for page faults of the result arrays + workspace
+        t1 = time.perf_counter()
+        hs.local_SA, hs.local_B, hs.local_LCP = hs.construct_into(text, hs.local_SA, hs.local_B, hs.local_LCP)
         ht = time.perf_counter() - t1
-        out["host_pointer_path"] = {"ms": round(ht * 1e3, 1), "MChars_per_s": round(n / ht / 1e6, 1),
-                                    "note": "pageable host buffers: H2D %d MiB + D2H %d MiB over PCIe, device buffers allocated per call"
-                                            % (n >> 20, (n * w * (2 if a.no_lcp else 3)) >> 20)}
+        out["construct_host"] = {"ms": round(ht * 1e3, 1), "MChars_per_s": round(hn / ht / 1e6, 1), "n": hn,
+                                 "note": "psacx_construct_u%d on host pointers (SURVEY 8(d) Metric 1): H2D %d MiB + D2H %d MiB through "
+                                         "pinned staging buffers, second call on touched pageable memory"
+                                         % (bits, hn >> 20, (hn * w * (2 if a.no_lcp else 3)) >> 20)}
+        del text, hs
     if a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)
     print(json.dumps(out))
     for p in (d_text, d_sa, d_isa, d_lcp):
-        ctx.free(p)
+        if p:
+            ctx.free(p)
     ctx.close()
 
 

@@ -167,6 +167,16 @@ int psacx_check_dev_u32(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const
 int psacx_check_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const uint64_t* d_SA,
                         const uint64_t* d_ISA, const uint64_t* d_LCP, uint64_t errors[4]);
 
+/* benchmark inputs ----------------------------------------------------------------
+ * psacx_rand_dna: the reference's generator rand_dna(size, seed) (alphabet.hpp:32-45, used by psac -r,
+ * src/psac.cpp:89-93): srand(1337 * seed), then "ACGT"[rand() % 4] per character (glibc rand; host memory).
+ * psacx_synth_text_dev: the synthetic texts of the benchmark configurations written straight
+ * into HBM: characters first .. first + n of kind 0 = DNA(seed), 1 = ASCII128(seed) (splitmix64 streams, the same
+ * definition as tests/inputs.py), 2 = TANDEM: DNA(seed) repeated with `period`. */
+int psacx_rand_dna(uint8_t* out, uint64_t n, int seed);
+int psacx_synth_text_dev(psacx_ctx* ctx, uint8_t* d_text, uint64_t n, uint64_t first, int kind, uint64_t seed,
+                         uint64_t period);
+
 /* the rank-pair sort on its own -------------------------------------------
  * Replaces idxsort_vectors(vec1, vec2, comm) (idxsort.hpp:23-83) at one rank:
  * sorts records (b1[i], b2[i], i) by (b1, b2); on return b1/b2 hold the sorted

@@ -63,7 +63,9 @@ int psacx_op_char_hist(psacx_ctx*, const uint8_t* text, uint64_t n, uint64_t* hi
        only delta = -1 is supported; s1..s4: scratch arrays of cnt entries */                          \
     int psacx_op_put_perm_##S(psacx_ctx*, T* block, const T* gidx, uint64_t cnt, uint64_t off,         \
                               const T* vals, T* s1, T* s2, T* s3, T* s4);                              \
-    int psacx_op_add_scalar_##S(psacx_ctx*, const T* in, uint64_t cnt, uint64_t s, T* out);            \
+    /* out = min(in + s, cap), formed in 64 bits (SA + h of suffix_array.hpp:978 cannot wrap) */      \
+    int psacx_op_add_scalar_##S(psacx_ctx*, const T* in, uint64_t cnt, uint64_t s, uint64_t cap,       \
+                                T* out);                                                               \
     /* suffix_array.hpp:972-996: out = q < n ? ans + 1 : 0 */                                          \
     int psacx_op_finish_b2_##S(psacx_ctx*, const T* ans, const T* q, uint64_t cnt, uint64_t n, T* out); \
     /* bucketing.hpp:57-123 on one block.  mode 0: first round (s3 = suffix starts, packed windows   \

@@ -23,14 +23,13 @@ import numpy as np
 
 
 def _rand_dna(size, seed):
-    """alphabet.hpp:32-45: srand(1337 * seed); "ACGT"[rand() % 4] with the C library's generator."""
-    libc = ctypes.CDLL(None)
-    libc.srand(ctypes.c_uint(1337 * seed))
+    """alphabet.hpp:32-45: srand(1337 * seed); "ACGT"[rand() % 4] with the C library's generator
+    (filled by psacx_rand_dna in libpsacx.so: one native loop, the same glibc sequence as the reference)."""
+    from psac_amd import _lib
     out = np.empty(size, np.uint8)
-    lut = np.frombuffer(b"ACGT", np.uint8)
-    rand = libc.rand
-    for i in range(size):
-        out[i] = lut[rand() & 3]
+    rc = _lib.load().psacx_rand_dna(out.ctypes.data_as(ctypes.c_void_p), size, int(seed))
+    if rc != 0:
+        raise RuntimeError("psacx_rand_dna failed: %d" % rc)
     return out
 
 

@@ -23,6 +23,7 @@ EXPORTS = [
     "psacx_construct_lc_u32", "psacx_construct_lc_u64", "psacx_construct_lc_dev_u32", "psacx_construct_lc_dev_u64",
     "psacx_get_stats", "psacx_profile", "psacx_check_dev_u32", "psacx_check_dev_u64", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
     "psacx_ansv_u64", "psacx_ansv_dev_u32", "psacx_ansv_dev_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
+    "psacx_rand_dna", "psacx_synth_text_dev",
 ]
 
 
@@ -96,6 +97,8 @@ def load():
     lib.psacx_copy_h2d.argtypes = [vp, vp, vp, u64]
     lib.psacx_copy_d2h.argtypes = [vp, vp, vp, u64]
     lib.psacx_sync.argtypes = [vp]
+    lib.psacx_rand_dna.argtypes = [vp, u64, i32]
+    lib.psacx_synth_text_dev.argtypes = [vp, vp, u64, u64, i32, u64, u64]
     # step-level ops of the distributed path (include/psacx_ops.h)
     i64, u16p = C.c_int64, C.POINTER(C.c_uint16)
     u64p = C.POINTER(C.c_uint64)
@@ -110,7 +113,7 @@ def load():
         "owners": [vp, vp, u64, u64, u32, vp],
         "take": [vp, vp, vp, u64, u64, u64, vp],
         "put": [vp, vp, vp, u64, u64, vp, i64],
-        "add_scalar": [vp, vp, u64, u64, vp],
+        "add_scalar": [vp, vp, u64, u64, u64, vp],
         "finish_b2": [vp, vp, vp, u64, u64, vp],
         "last_head": [vp, i32, vp, vp, vp, u64, u64, u32, u32, u32, vp, u64p],
         "rebucket_first": [vp, vp, vp, vp, u64, u64, u32, u32, u32, vp, vp, vp, u64p, u64p],

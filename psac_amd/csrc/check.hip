@@ -54,6 +54,51 @@ int check_dev(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa, const 
     return PSACX_OK;
 }
 
+// Synthetic benchmark texts of SURVEY.md section 8(d), generated where they are used: character g of
+// DNA(n, seed) is "ACGT"[z & 3], of ASCII128(n, seed) z & 127, with z the g-th output (counting from 1) of
+// splitmix64 started at `seed`; TANDEM repeats the first `period` characters of DNA(period, seed).
+// tests/inputs.py defines the same streams on the host.
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t g) {
+    uint64_t z = seed + (g + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_text_kernel(uint8_t* __restrict__ out, uint64_t n, uint64_t first, int kind, uint64_t seed, uint64_t period) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i0 < n; i0 += stride) {
+        uint8_t b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint64_t g = first + i0 + j;
+            if (kind == 2) g %= period;
+            const uint64_t z = splitmix64_at(seed, g);
+            b[j] = kind == 1 ? (uint8_t)(z & 127) : (uint8_t)"ACGT"[z & 3];
+        }
+        if (i0 + 16 <= n && ((uintptr_t)(out + i0) & 15) == 0) {
+            uint4 v;
+            v.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24);
+            v.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((unsigned)b[7] << 24);
+            v.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((unsigned)b[11] << 24);
+            v.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((unsigned)b[15] << 24);
+            *reinterpret_cast<uint4*>(out + i0) = v;
+        } else {
+            for (int j = 0; j < 16 && i0 + j < n; ++j) out[i0 + j] = b[j];
+        }
+    }
+}
+
+int synth_text_dev(psacx_ctx* c, uint8_t* d_text, uint64_t n, uint64_t first, int kind, uint64_t seed, uint64_t period) {
+    if (!c || !d_text || kind < 0 || kind > 2 || (kind == 2 && period == 0)) return PSACX_EINVAL;
+    if (n == 0) return PSACX_OK;
+    PSACX_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(c, n / 16 + 1, 256, 16)), dim3(256), 0, c->stream, d_text, n, first, kind, seed, period);
+    PSACX_HIP(c, hipGetLastError());
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    return PSACX_OK;
+}
+
 int check_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32_t* sa, const uint32_t* isa, const uint32_t* lcp, uint64_t* e) {
     return check_dev<uint32_t>(c, t, n, sa, isa, lcp, e);
 }

@@ -139,7 +139,8 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
                 uint64_t* active, uint64_t* unf_buckets, uint64_t capacity, unsigned shift = 0,
-                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr) {
+                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0) {
+    // pos_off: SA position of ids[0] when pos_in is null (a slab of the reduced-memory layout)
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     {
@@ -158,11 +159,11 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
         ProfScope ps(c, TC_COMPACT);
         if (payload)
             hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0, shift,
+                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
                                payload, out_id, out_payload);
         else
             hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, (uint64_t)0, (T)0, (T)0, shift,
+                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
                                (const T*)nullptr, (T*)nullptr, (T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
     }
@@ -364,8 +365,13 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // fewer than a quarter of the suffixes tied, which is cheaper than carrying word 2 through five passes
     const unsigned slack = getenv("PSACX_LEAD_SLACK") ? (unsigned)atoi(getenv("PSACX_LEAD_SLACK")) : 2u;
     if (lead > bits_w1 && bits_for(n - 1) + slack <= bits_w1 && bits_w1 % RADIX_BITS == 0) lead = bits_w1;
-    const bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
-                           lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
+    bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
+                     lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
+    psacx_round* r0 = &st.rounds[0];
+    SortBufs<T> sorted;
+    // (second attempt: only when the two-stage form met more ties than the reduced-memory layout has room for)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool retry_one_stage = false;
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
     const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !getenv("PSACX_NO_KEY_HIST");
 
@@ -403,9 +409,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
     }
 
-    psacx_round* r0 = &st.rounds[0];
     std::memset(r0, 0, sizeof(*r0));
-    SortBufs<T> sorted;
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
@@ -453,8 +457,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             uint64_t ties = 0, unused = 0;
             PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &unused, w.cap_active, lo1, d_sa, a.k1, a.v));
             if (ties > w.cap_active) {
-                c->hip_err = "too many unresolved suffixes for the reduced-memory layout";
-                return PSACX_ENOMEM;
+                // repetitive text in the reduced-memory layout: there is no room to sort all ties at once, so the
+                // first round is run again as one sort over both words (the keys were sorted in place: rebuilt)
+                two_stage = false; retry_one_stage = true;
+                ties = 0;
             }
             if (ties) {
                 {
@@ -477,6 +483,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             }
         }
         sorted.k2 = S2; sorted.v = d_sa;
+        if (retry_one_stage) continue;
     } else {
         PSACX_TRY(pair_sort<T>(c, w.sc, first_in, first_alt, n, /*iota=*/true, bits_w1, bits_w2, w.diet ? (T*)nullptr : d_sa,
                                &sorted, r0, ks.spec, n, /*summary_ready=*/true));
@@ -490,6 +497,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             sorted.v = d_sa;
         }
+    }
+    if (!retry_one_stage) break;
     }
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
@@ -536,19 +545,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active));
     r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;
     st.n_rounds = 1;
-    if (active > w.cap_active) {
-        c->hip_err = "too many unresolved suffixes for the reduced-memory layout";
-        return PSACX_ENOMEM;
-    }
+    // The list of unresolved SA positions exists only while it fits the workspace.  In the reduced-memory layout a
+    // round with more unresolved suffixes than `cap_active` is worked off in slabs of whole buckets (see below).
+    bool have_list = active <= w.cap_active;
 
     T* pos = w.pos_a;
     T* pos_next = w.pos_b;
     const unsigned id_bits = bits_for(n);
-    for (uint64_t h = 2ull * k; unf_b > 0 && h < n; h <<= 1) {
-        const uint64_t cnt = no_fast ? n : active;
-        const T* plist = no_fast ? nullptr : pos;
-        psacx_round* rr = st.n_rounds < PSACX_MAX_ROUNDS ? &st.rounds[st.n_rounds] : nullptr;
-        if (rr) std::memset(rr, 0, sizeof(*rr));
+    // one refinement pass over the `cnt` list entries plist (suffix_array.hpp:1092-1157 for one bucket range):
+    // B2 = rank of the suffix h further, sort by (bucket, B2), new ids / LCP / ISA written in place
+    auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf) -> int {
         {
             ProfScope ps(c, TC_GATHER);
             const int gg = grid_for(c, cnt, 256, 16);
@@ -557,8 +563,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipGetLastError());
             PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
-        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, rr, 0, 0,
+        psacx_round rs; std::memset(&rs, 0, sizeof(rs));
+        PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, &rs, 0, 0,
                                /*summary_ready=*/true));
+        if (rr) { rr->sort_passes += rs.sort_passes; rr->sort_passes_skipped += rs.sort_passes_skipped; }
         T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
         if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n));
         {
@@ -571,14 +579,82 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr);
             PSACX_HIP(c, hipGetLastError());
         }
+        return run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active);
+    };
+
+    for (uint64_t h = 2ull * k; unf_b > 0 && h < n; h <<= 1) {
+        psacx_round* rr = st.n_rounds < PSACX_MAX_ROUNDS ? &st.rounds[st.n_rounds] : nullptr;
+        if (rr) std::memset(rr, 0, sizeof(*rr));
         uint64_t nactive = 0;
-        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, pos_next, &nactive, &unf_b, w.cap_active));
+        const uint64_t round_cnt = no_fast ? n : active;
+        if (!no_fast && !have_list && active <= w.cap_active) {
+            // back under the capacity: rebuild the list of unresolved positions from the bucket ids
+            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+            hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+                               c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u);
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
+            uint64_t a2 = 0, u2 = 0;
+            PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, pos, &a2, &u2, w.cap_active));
+            if (a2 != active) { c->hip_err = "active list rebuild disagrees with the round counters"; return PSACX_EDEVICE; }
+            have_list = true;
+        }
+        if (no_fast || have_list) {
+            PSACX_TRY(refine(no_fast ? (const T*)nullptr : pos, round_cnt, h, rr, pos_next, &nactive, &unf_b));
+            std::swap(pos, pos_next);
+        } else {
+            // Slabs.  Buckets are contiguous in SA order and a refinement only permutes inside buckets, so any range
+            // of SA positions that ends on a bucket boundary can be refined on its own.  The ranks read for later
+            // slabs may already carry this round's refinement (Larsson-Sadakane style): the order stays a
+            // refinement of the true suffix order and every new LCP is still h + a range minimum over final entries,
+            // only the per-round counters may run ahead of the reference's log.
+            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+            hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+                               c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u);
+            PSACX_HIP(c, hipGetLastError());
+            std::vector<uint64_t> tile_act(ntiles);
+            PSACX_HIP(c, hipMemcpyAsync(tile_act.data(), w.d_nact, ntiles * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            const uint64_t room = w.cap_active > 2ull * SCAN_TILE ? w.cap_active - 2ull * SCAN_TILE : 0;
+            uint64_t sum_act = 0, sum_unf = 0, s0 = 0;
+            T* h_id = reinterpret_cast<T*>(c->pinned + 128);
+            while (s0 < n) {
+                // furthest tile boundary whose tiles (from the one holding s0) hold at most `room` unresolved positions
+                uint64_t t = s0 / SCAN_TILE, acc = 0;
+                while (t < ntiles && acc + tile_act[t] <= room) acc += tile_act[t++];
+                uint64_t e = std::min<uint64_t>(t * (uint64_t)SCAN_TILE, n);
+                if (e < n) {
+                    // back to the head of the bucket that holds position e (bucket id = head position + 1)
+                    PSACX_HIP(c, hipMemcpyAsync(h_id, w.bsa + e, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+                    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+                    e = (uint64_t)*h_id - 1;
+                }
+                if (e <= s0) {
+                    c->hip_err = "a bucket of unresolved suffixes is larger than the reduced-memory layout has room for";
+                    return PSACX_ENOMEM;
+                }
+                const uint64_t len = e - s0, lt = (len + SCAN_TILE - 1) / SCAN_TILE;
+                hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)lt), dim3(SCAN_BLOCK), 0,
+                                   c->stream, w.bsa + s0, len, (T)0, (T)0, w.d_nact, 0u);
+                PSACX_HIP(c, hipGetLastError());
+                PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, lt * sizeof(uint64_t), c->stream));
+                uint64_t cnt = 0, unused = 0;
+                PSACX_TRY(run_compact<T>(c, w, w.bsa + s0, nullptr, len, pos, &cnt, &unused, w.cap_active, 0, nullptr, nullptr, nullptr, s0));
+                if (cnt > w.cap_active) { c->hip_err = "slab larger than planned"; return PSACX_EDEVICE; }
+                if (cnt) {
+                    uint64_t na = 0, nu = 0;
+                    PSACX_TRY(refine(pos, cnt, h, rr, pos_next, &na, &nu));
+                    sum_act += na; sum_unf += nu;
+                }
+                s0 = e;
+            }
+            nactive = sum_act; unf_b = sum_unf;
+        }
         if (rr) {
-            rr->h = h; rr->active = cnt; rr->unfinished_buckets = unf_b; rr->unfinished_elements = nactive;
+            rr->h = h; rr->active = round_cnt; rr->unfinished_buckets = unf_b; rr->unfinished_elements = nactive;
             st.n_rounds++;
         }
         active = nactive;
-        std::swap(pos, pos_next);
     }
 
     // ISA already holds 0-based ranks (the -1 of suffix_array.hpp:460-464 is applied on every write)
@@ -610,6 +686,7 @@ int construct_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t
     if (rc == PSACX_OK && d_lc) {
         hipLaunchKernelGGL((left_chars_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_text, n, d_sa, d_lcp, d_lc);
         PSACX_HIP(c, hipGetLastError());
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));      // like SA / ISA / LCP, Lc is complete when the call returns
     }
     if (rc == PSACX_OK && c->profile) prof_collect(c);
     return rc;
@@ -628,6 +705,19 @@ int construct_gsa_dispatch(psacx_ctx* c, const uint8_t* d_text, uint64_t n, cons
     std::memset(&c->stats, 0, sizeof(c->stats));
     c->profile = (flags & PSACX_PROFILE) != 0;
     c->ev_used = 0;
+    // the offsets must describe m non-empty strings covering [0, n) (stringset.hpp:53-72); a malformed array would
+    // send the window kernels out of bounds
+    {
+        PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
+        PSACX_TRY(ensure_slab(c, 4096));
+        unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(c->slab);
+        PSACX_HIP(c, hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(check_offsets_kernel<0>, dim3(grid_for(c, m + 1, 256, 8)), dim3(256), 0, c->stream, d_off, m, n, d_bad);
+        PSACX_HIP(c, hipGetLastError());
+        PSACX_HIP(c, hipMemcpyAsync(c->pinned, d_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        if (*reinterpret_cast<unsigned long long*>(c->pinned)) return PSACX_EINVAL;
+    }
     T* d_slen = nullptr;
     hipError_t e = hipMalloc((void**)&d_slen, n * sizeof(T));
     if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(string lengths): ") + hipGetErrorString(e); (void)hipGetLastError(); return PSACX_ENOMEM; }
@@ -678,7 +768,8 @@ int construct_gsa_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const uint
     return rc;
 }
 
-// host-pointer form: stage over PCIe, run, copy back
+// host-pointer form: stage over PCIe, run, copy back.  The device copies live in the ctx between calls
+// (suffix_array<>::construct may be called repeatedly on one object, test/test_psac.cpp:148-170).
 template <typename T>
 int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp,
                    uint8_t* lc = nullptr) {
@@ -687,31 +778,25 @@ int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, ui
     if (lc && !(flags & PSACX_LCP)) return PSACX_EINVAL;
     if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
     PSACX_HIP(c, hipSetDevice(c->device));
+    const bool with_lcp = (flags & PSACX_LCP) != 0;
     uint8_t *d_text = nullptr, *d_lc = nullptr; T *d_sa = nullptr, *d_isa = nullptr, *d_lcp = nullptr;
-    auto cleanup = [&]() {
-        if (d_text) (void)hipFree(d_text); if (d_sa) (void)hipFree(d_sa);
-        if (d_isa) (void)hipFree(d_isa); if (d_lcp) (void)hipFree(d_lcp); if (d_lc) (void)hipFree(d_lc);
+    auto layout = [&](Arena& a) {
+        d_sa = a.take<T>(n); d_isa = a.take<T>(n);
+        if (with_lcp) d_lcp = a.take<T>(n);
+        d_text = a.take<uint8_t>(n);
+        if (lc) d_lc = a.take<uint8_t>(n);
     };
-    hipError_t e = hipMalloc((void**)&d_text, n);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_sa, n * sizeof(T));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_isa, n * sizeof(T));
-    if (e == hipSuccess && (flags & PSACX_LCP)) e = hipMalloc((void**)&d_lcp, n * sizeof(T));
-    if (e == hipSuccess && lc) e = hipMalloc((void**)&d_lc, n);
-    if (e != hipSuccess) { c->hip_err = std::string("hipMalloc(io): ") + hipGetErrorString(e); (void)hipGetLastError(); cleanup(); return PSACX_ENOMEM; }
-    int rc = PSACX_OK;
-    e = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); cleanup(); return PSACX_EHIP; }
-    rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_lc);
-    if (rc == PSACX_OK) {
-        e = hipMemcpyAsync(sa, d_sa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(isa, d_isa, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && d_lcp) e = hipMemcpyAsync(lcp, d_lcp, n * sizeof(T), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && d_lc) e = hipMemcpyAsync(lc, d_lc, n, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { c->hip_err = hipGetErrorString(e); rc = PSACX_EHIP; }
-    }
-    cleanup();
-    return rc;
+    { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_io(c, dry.off + 4096)); }
+    Arena ar(c->io);
+    layout(ar);
+    PSACX_TRY(staged_h2d(c, d_text, text, n));
+    int rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_lc);
+    if (rc != PSACX_OK) return rc;
+    PSACX_TRY(staged_d2h(c, sa, d_sa, n * sizeof(T)));
+    PSACX_TRY(staged_d2h(c, isa, d_isa, n * sizeof(T)));
+    if (d_lcp) PSACX_TRY(staged_d2h(c, lcp, d_lcp, n * sizeof(T)));
+    if (d_lc) PSACX_TRY(staged_d2h(c, lc, d_lc, n));
+    return PSACX_OK;
 }
 
 // stand-alone rank-pair sort (idxsort.hpp:23-83): sorts in place, idx receives the permutation

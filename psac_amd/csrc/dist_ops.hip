@@ -53,9 +53,14 @@ __global__ void put_kernel(T* __restrict__ block, const T* __restrict__ g, uint6
         block[(uint64_t)g[i] - off] = (T)((int64_t)vals[i] + delta);
 }
 template <typename T>
-__global__ void add_scalar_kernel(const T* __restrict__ in, uint64_t cnt, uint64_t s, T* __restrict__ out) {
+__global__ void add_scalar_kernel(const T* __restrict__ in, uint64_t cnt, uint64_t s, uint64_t cap, T* __restrict__ out) {
+    // saturating: in + s is formed in 64 bits and clamped to cap (= n, "past the end"), so SA + h cannot wrap
+    // around a 32-bit index type and come back as a valid position
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)((uint64_t)in[i] + s);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const uint64_t v = (uint64_t)in[i] + s;
+        out[i] = (T)(v < cap ? v : cap);
+    }
 }
 template <typename T>
 __global__ void finish_b2_kernel(const T* __restrict__ ans, const T* __restrict__ q, uint64_t cnt, uint64_t n, T* __restrict__ out) {
@@ -598,8 +603,8 @@ int psacx_op_char_hist(psacx_ctx* c, const uint8_t* text, uint64_t n, uint64_t* 
     int psacx_op_put_##S(psacx_ctx* c, T* b, const T* g, uint64_t cnt, uint64_t off, const T* v, int64_t d) {  \
         OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (put_kernel<T>), cnt, b, g, cnt, off, v, d); return PSACX_OK;          \
     }                                                                                                          \
-    int psacx_op_add_scalar_##S(psacx_ctx* c, const T* in, uint64_t cnt, uint64_t s, T* out) {                 \
-        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt, in, cnt, s, out); return PSACX_OK;        \
+    int psacx_op_add_scalar_##S(psacx_ctx* c, const T* in, uint64_t cnt, uint64_t s, uint64_t cap, T* out) {   \
+        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt, in, cnt, s, cap, out); return PSACX_OK;   \
     }                                                                                                          \
     int psacx_op_finish_b2_##S(psacx_ctx* c, const T* a, const T* q, uint64_t cnt, uint64_t n, T* out) {       \
         OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt, a, q, cnt, n, out); return PSACX_OK;       \

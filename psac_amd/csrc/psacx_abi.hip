@@ -18,6 +18,7 @@ int pair_sort_dev_u32(psacx_ctx*, uint32_t*, uint32_t*, uint32_t*, uint64_t, uin
 int pair_sort_dev_u64(psacx_ctx*, uint64_t*, uint64_t*, uint64_t*, uint64_t, uint32_t);
 int check_dev_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, const uint32_t*, const uint32_t*, uint64_t*);
 int check_dev_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t*);
+int synth_text_dev(psacx_ctx*, uint8_t*, uint64_t, uint64_t, int, uint64_t, uint64_t);
 int suffix_tree_host_u32(psacx_ctx*, const uint8_t*, uint64_t, const uint32_t*, const uint32_t*, uint64_t*, uint32_t*);
 int suffix_tree_host_u64(psacx_ctx*, const uint8_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t*, uint32_t*);
 int ansv_host_u32(psacx_ctx*, const uint32_t*, uint64_t, int, int, uint64_t, uint64_t*, uint64_t*);
@@ -59,6 +60,11 @@ void psacx_destroy(psacx_ctx* c) {
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->slab) (void)hipFree(c->slab);
     if (c->aux) (void)hipFree(c->aux);
+    if (c->io) (void)hipFree(c->io);
+    for (int i = 0; i < 2; ++i) {
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+    }
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -85,6 +91,7 @@ int psacx_trim(psacx_ctx* c) {
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     if (c->slab) { PSACX_HIP(c, hipFree(c->slab)); c->slab = nullptr; c->slab_bytes = 0; }
     if (c->aux) { PSACX_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
+    if (c->io) { PSACX_HIP(c, hipFree(c->io)); c->io = nullptr; c->io_bytes = 0; }
     return PSACX_OK;
 }
 
@@ -152,6 +159,16 @@ int psacx_check_dev_u32(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint32
 }
 int psacx_check_dev_u64(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* sa, const uint64_t* isa, const uint64_t* lcp, uint64_t* e) {
     return check_dev_u64(c, t, n, sa, isa, lcp, e);
+}
+
+int psacx_synth_text_dev(psacx_ctx* c, uint8_t* d_text, uint64_t n, uint64_t first, int kind, uint64_t seed, uint64_t period) {
+    return synth_text_dev(c, d_text, n, first, kind, seed, period);
+}
+int psacx_rand_dna(uint8_t* out, uint64_t n, int seed) {
+    if (!out) return PSACX_EINVAL;
+    srand(1337u * (unsigned)seed);
+    for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)"ACGT"[rand() % 4];
+    return PSACX_OK;
 }
 
 int psacx_ansv_dev_u32(psacx_ctx* c, const uint32_t* in, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* l, uint64_t* r) {

@@ -1068,6 +1068,17 @@ __global__ void string_len_kernel(const uint64_t* __restrict__ off, uint64_t m, 
     }
 }
 
+// bad[0] += offsets that break off[0] = 0, off[m] = n or strict ascent
+template <int TAG>
+__global__ void check_offsets_kernel(const uint64_t* __restrict__ off, uint64_t m, uint64_t n, unsigned long long* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= m; t += stride) {
+        const uint64_t o = off[t];
+        const bool ok = (t == 0 ? o == 0 : o > off[t - 1]) && (t == m ? o == n : o < n);
+        if (!ok) atomicAdd(bad, 1ull);
+    }
+}
+
 // Left-branching characters (/root/reference/include/suffix_array.hpp:211-212, built there
 // by :1365-1383 in the first round and carried through the range minima, par_rmq.hpp:334-481):
 // Lc[i] = S[SA[i-1] + LCP[i]], the character of the left neighbour at the first mismatch, '\0'

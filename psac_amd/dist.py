@@ -403,7 +403,7 @@ def construct(comm, ops, text_block, want_lcp=True, k_req=0, log=None):
         counts = yield from comm.all_gather_obj(cnt)
         # B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
         sa_act = ops.take(SA, pos, off, n)
-        q = ops.add_scalar(sa_act, h)
+        q = ops.add_scalar(sa_act, h, n)        # saturates at n: SA + h must not wrap a 32-bit index
         ans = yield from dist_take(comm, ops, ISA, off, q, n)
         K2 = ops.finish_b2(ans, q, n)
         K1 = ops.take(Bsa, pos, off, n)

@@ -166,9 +166,10 @@ class HipOps(object):
         self._chk(self._f("put_perm")(self.ctx, self._p(block), self._p(gidx), int(gidx.numel()), int(off), self._p(vals),
                                       *[self._p(x) for x in s]))
 
-    def add_scalar(self, t, s):
+    def add_scalar(self, t, s, cap):
+        """min(t + s, cap), formed in 64 bits."""
         out = self.empty_like(t)
-        self._chk(self._f("add_scalar")(self.ctx, self._p(t), int(t.numel()), int(s), self._p(out)))
+        self._chk(self._f("add_scalar")(self.ctx, self._p(t), int(t.numel()), int(s), int(cap), self._p(out)))
         return out
 
     def finish_b2(self, ans, q, n):

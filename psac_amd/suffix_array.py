@@ -173,6 +173,20 @@ class SuffixArray(object):
         self.ctx.check(fn(*args))
         return self._after()
 
+    def construct_into(self, text, SA, B, LCP=None, fast_resolval=True, k=0):
+        """construct() writing into result arrays the caller already holds (a second construct() on the same
+        object reuses its vectors in the reference, test/test_psac.cpp:148-170).  Returns (SA, B, LCP)."""
+        t = np.ascontiguousarray(text, dtype=np.uint8)
+        n = int(t.size)
+        assert SA.size == n and B.size == n and SA.dtype == self.dtype and B.dtype == self.dtype
+        assert (LCP is not None and LCP.size == n) or not self.lcp
+        fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
+        self.ctx.check(fn(self.ctx.handle, _ptr(t), n, int(k), self._flags(fast_resolval, False), _ptr(SA), _ptr(B),
+                          _ptr(LCP) if self.lcp else None))
+        self.n = self.local_size = n
+        self._after()
+        return SA, B, LCP
+
     def construct_ss(self, strings, sep=None, k=0, profile=False):
         """suffix_array::construct_ss(simple_dstringset&, alphabet) (suffix_array.hpp:267-363): the
         generalized suffix array of a set of strings.  `strings` is a list of byte strings, or one

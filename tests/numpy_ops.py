@@ -36,8 +36,8 @@ class NumpyOps(object):
     def record_at(self, a, b, c, j):
         return (int(self.u(a)[j]), int(self.u(b)[j]), int(self.u(c)[j]))
 
-    def add_scalar(self, t, s):
-        return self.t(self.u(t).astype(np.uint64) + np.uint64(s))
+    def add_scalar(self, t, s, cap):
+        return self.t(np.minimum(self.u(t).astype(np.uint64) + np.uint64(s), np.uint64(cap)))
 
     # -- round 1 -------------------------------------------------------------------------
     def char_hist(self, text):

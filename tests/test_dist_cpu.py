@@ -121,6 +121,17 @@ def test_loopback_round_log_matches_oracle():
     assert [(h, b, e) for (h, b, e) in info["rounds"]] == [(h, b, e) for (h, b, e, _) in ref["trace"]]
 
 
+def test_shift_by_h_saturates_instead_of_wrapping():
+    # 32-bit indices, n > 2^31: SA + h of a deep round (suffix_array.hpp:978) must become "past the end" (>= n),
+    # never a small in-range position (the wrap would fetch ISA[(SA + h) mod 2^32] + 1 instead of key 0)
+    ops = NumpyOps(32)
+    n = 0xFFFFFF00
+    sa = ops.t(np.array([5, 0x80000000, 0xFFFFFE00, 0xFFFFFEFF], np.uint32))
+    q = ops.u(ops.add_scalar(sa, 0x200, n))
+    assert q.tolist() == [0x205, 0x80000200, n, n]
+    assert ops.u(ops.finish_b2(ops.t(np.array([7, 8, 9, 10], np.uint32)), ops.t(q), n)).tolist() == [8, 9, 0, 0]
+
+
 def test_block_distribution_is_enforced():
     text = O.rand_dna(1000, 1)
 

@@ -1,0 +1,123 @@
+"""Full-size single-GPU configurations, run by the driver's `-m gpu` suite (round 1 only had them in
+tools/bigrun.py): BASELINE.json configs[2] (4 GiB random ASCII, uint64), the north-star's headline shape
+(4 GiB random DNA, uint64), the largest uint32 input (2^32 - 2 characters), 2 GiB with uint64 indices in the
+normal layout, and the /256 twin of configs[4] (period-1024 tandem repeat) on one GPU.
+
+The texts are generated in HBM (psacx_synth_text_dev, the same splitmix64 streams as tests/inputs.py) and
+the results are verified where they lie by psacx_check_dev_* -- size-independent properties: SA is a
+permutation inverse to ISA, adjacent suffixes are in order, every LCP entry equals a direct character
+comparison.  This file sorts before test_gpu_parity.py, so the 283 GiB of the 4 GiB runs are taken while
+nothing else holds device memory, and are released at the end of the module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+KIND = {"dna": 0, "ascii128": 1, "tandem": 2}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import psac_amd
+    c = psac_amd.Context(0)
+    yield c
+    c.close()
+
+
+def device_text(ctx, n, kind, seed, period=1024):
+    d = ctx.alloc(n)
+    ctx.check(ctx._lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d), n, 0, KIND[kind], seed, period))
+    return d
+
+
+def construct_and_check(ctx, n, bits, kind, seed):
+    import psac_amd
+    w = bits // 8
+    d_text = device_text(ctx, n, kind, seed)
+    d_sa, d_isa, d_lcp = ctx.alloc(n * w), ctx.alloc(n * w), ctx.alloc(n * w)
+    try:
+        sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
+        s = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+        err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, bits)
+    finally:
+        for p in (d_text, d_sa, d_isa, d_lcp):
+            ctx.free(p)
+    return s, err, sa
+
+
+def test_synthetic_text_generator_matches_the_host_definition(ctx):
+    # the device generator against tests/inputs.py (the definition of SURVEY 8(d)), ragged length and offsets
+    n = (1 << 20) + 13
+    for kind, ref in (("dna", inputs.dna(n, 5)), ("ascii128", inputs.ascii128(n, 42)),
+                      ("tandem", inputs.tandem(n, 1024, inputs.dna(1024, 3)))):
+        seed = {"dna": 5, "ascii128": 42, "tandem": 3}[kind]
+        d = device_text(ctx, n, kind, seed)
+        got = np.empty(n, np.uint8)
+        ctx.d2h(got, d)
+        ctx.free(d)
+        assert np.array_equal(got, ref), kind
+    d = ctx.alloc(1000)
+    ctx.check(ctx._lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d + 3), 990, 777, 0, 9, 1024))   # unaligned start, offset stream
+    got = np.empty(1000, np.uint8)
+    ctx.d2h(got, d)
+    ctx.free(d)
+    assert np.array_equal(got[3:993], inputs.dna(777 + 990, 9)[777:])
+
+
+def test_headline_4gib_dna_uint64(ctx):
+    # north-star shape: n = 2^32, uint64, reduced-memory layout, two-stage first round (5 two-word passes)
+    s, err, _ = construct_and_check(ctx, 1 << 32, 64, "dna", 1)
+    assert err == [0, 0, 0, 0]
+    assert s.k == 21 and s.bits_per_char == 3 and s.n_rounds >= 1
+
+
+def test_config_c3_4gib_ascii_uint64(ctx):
+    # BASELINE.json configs[2]: 4 GiB random ASCII (sigma = 128), uint64 indices
+    s, err, _ = construct_and_check(ctx, 1 << 32, 64, "ascii128", 42)
+    assert err == [0, 0, 0, 0]
+    assert s.k == 8 and s.bits_per_char == 8 and s.sigma == 128
+
+
+def test_largest_uint32_input(ctx):
+    # n = 2^32 - 2 (idxsort.hpp:39), one-stage first sort, partition_pairs_kernel above 2^30 records
+    s, err, _ = construct_and_check(ctx, (1 << 32) - 2, 32, "dna", 1)
+    assert err == [0, 0, 0, 0]
+    assert s.k == 10
+
+
+def test_2gib_dna_uint64_normal_layout(ctx):
+    s, err, _ = construct_and_check(ctx, 1 << 31, 64, "dna", 7)
+    assert err == [0, 0, 0, 0]
+
+
+def _tandem_twin(ctx, monkeypatch, cap):
+    # configs[4] / 256: 2^27 characters, period-1024 tandem repeat of DNA(1024, 3), uint64, against the CPU restatement
+    n = 1 << 27
+    text = inputs.tandem(n, 1024, inputs.dna(1024, 3))
+    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
+    if cap:
+        monkeypatch.setenv("PSACX_DIET_CAP", str(cap))
+    import psac_amd
+    sa = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+    sa.construct(text)
+    return text, sa
+
+
+def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
+    text, sa = _tandem_twin(ctx, monkeypatch, 0)
+    SA, LCP = O.construct_all_cores(text, bits=64)
+    assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_LCP, LCP)
+    assert np.array_equal(sa.local_B[SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
+    # deep prefix doubling: h = 21 * 2^i until the 1024 phase buckets are resolved
+    hs = [r[0] for r in sa.rounds]
+    assert hs == [21 << i for i in range(len(hs))] and len(hs) >= 20
+    # the same with room for only a quarter of the unresolved suffixes per slab of a refinement round
+    text2, sb = _tandem_twin(ctx, monkeypatch, 1 << 25)
+    assert np.array_equal(sb.local_SA, SA) and np.array_equal(sb.local_LCP, LCP) and np.array_equal(sb.local_B, sa.local_B)
