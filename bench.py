@@ -82,9 +82,22 @@ def cpu_baseline(kind, sample, seed, bits):
     t0 = time.perf_counter()
     O.construct_all_cores(text, bits=bits)
     dt = time.perf_counter() - t0
-    return {"value": round(sample / dt / 1e6, 3), "unit": "MChars/s", "cores": cores, "kind": "port",
-            "sample": "%d chars of the same generator (%s, seed %d), SA+LCP, uint%d, %.1f s on %d threads"
-                      % (sample, kind, seed, bits, dt, cores)}
+    out = {"value": round(sample / dt / 1e6, 3), "unit": "MChars/s", "cores": cores, "kind": "port",
+           "sample": "%d chars of the same generator (%s, seed %d), SA+LCP, uint%d, %.1f s on %d threads"
+                     % (sample, kind, seed, bits, dt, cores)}
+    # SURVEY 8(d) CPU baseline leg (1): libdivsufsort (the reference's own CPU comparison, src/psac_vs_dss.cpp:
+    # 87-119; oracle/_ref build of /root/reference/ext/libdivsufsort) + Kasai LCP, one thread, bounded sample
+    if O.have_divsufsort():
+        ds = min(sample, 1 << 26)
+        t0 = time.perf_counter()
+        SA = O.divsufsort(text[:ds], bits)
+        t1 = time.perf_counter()
+        O.kasai(text[:ds], SA, O.inverse(SA))
+        t2 = time.perf_counter()
+        out["divsufsort"] = {"value": round(ds / (t2 - t0) / 1e6, 3), "unit": "MChars/s", "cores": 1, "kind": "reference",
+                             "sample": "%d chars, divsufsort%s %.1f s + inverse/Kasai %.1f s, 1 thread"
+                                       % (ds, "64" if bits == 64 else "", t1 - t0, t2 - t1)}
+    return out
 
 
 def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism):

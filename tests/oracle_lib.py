@@ -292,3 +292,66 @@ def fnv(arr):
         return lib().psac_ref_fnv64_u32(_p(a), C.c_uint64(a.size))
     a = a.astype(np.uint64)
     return lib().psac_ref_fnv64_u64(_p(a), C.c_uint64(a.size))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# libdivsufsort, the reference's own checker (test/test_psac.cpp:77-98 compares psac's SA with dss::construct) and
+# CPU baseline (src/psac_vs_dss.cpp:87-119), built by oracle/Makefile from the sources under
+# /root/reference/ext/libdivsufsort into oracle/_ref/ (git-ignored; the built files travel to the GPU box).
+# ---------------------------------------------------------------------------------------------------------------
+_DSS = {32: os.path.join(ROOT, "oracle", "_ref", "libdivsufsort.so"), 64: os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64.so")}
+_dss_libs = {}
+
+
+def have_divsufsort():
+    if not all(os.path.exists(p) for p in _DSS.values()) and os.path.isdir("/root/reference/ext/libdivsufsort/lib"):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    return all(os.path.exists(p) for p in _DSS.values())
+
+
+def divsufsort(text, bits=32):
+    """dss::construct (divsufsort_wrapper.hpp:54-74): the suffix array by libdivsufsort (divsufsort for 32-bit
+    indices, n < 2^31 - 1; divsufsort64 otherwise), returned as unsigned index_t like psac's local_SA."""
+    if not have_divsufsort():
+        raise RuntimeError("oracle/_ref/libdivsufsort*.so not built")
+    t = as_text(text)
+    n = t.size
+    if bits == 32 and n >= (1 << 31) - 1:
+        raise ValueError("Input size is too large for 32bit indexing.")
+    if bits not in _dss_libs:
+        _dss_libs[bits] = C.CDLL(_DSS[bits])
+    L = _dss_libs[bits]
+    SA = np.zeros(n, np.int32 if bits == 32 else np.int64)
+    fn = L.divsufsort if bits == 32 else L.divsufsort64
+    fn.restype = C.c_int32
+    rc = fn(_p(t), _p(SA), C.c_int32(n) if bits == 32 else C.c_int64(n))
+    if rc != 0:
+        raise RuntimeError("divsufsort failed rc=%d" % rc)
+    return SA.view(np.uint32 if bits == 32 else np.uint64)
+
+
+def sufcheck(text, SA):
+    """dss::check -> sufcheck (divsufsort_wrapper.hpp:76-100): 0 if SA is the suffix array of text."""
+    t = as_text(text)
+    bits = SA.dtype.itemsize * 8
+    if bits not in _dss_libs:
+        _dss_libs[bits] = C.CDLL(_DSS[bits])
+    L = _dss_libs[bits]
+    fn = L.sufcheck if bits == 32 else L.sufcheck64
+    fn.restype = C.c_int32
+    a = np.ascontiguousarray(SA).view(np.int32 if bits == 32 else np.int64)
+    return fn(_p(t), _p(a), C.c_int32(t.size) if bits == 32 else C.c_int64(t.size), C.c_int32(0))
+
+
+def inverse(SA):
+    isa = np.empty_like(SA)
+    isa[SA.astype(np.int64)] = np.arange(SA.size, dtype=SA.dtype)
+    return isa
+
+
+def divsufsort_sa_lcp(text, bits=32):
+    """SA by libdivsufsort, ISA by inversion, LCP by Kasai (lcp.hpp:46-77) -- what test/test_psac.cpp compares
+    psac's results with (:77-98 SA, :50-74 LCP)."""
+    SA = divsufsort(text, bits)
+    ISA = inverse(SA)
+    return SA, ISA, kasai(text, SA, ISA)

@@ -97,6 +97,22 @@ def test_2gib_dna_uint64_normal_layout(ctx):
     assert err == [0, 0, 0, 0]
 
 
+def test_config_c2_bit_exact_vs_divsufsort(ctx):
+    # BASELINE.json configs[1]: 256 MiB random DNA, uint32, "bit-exact vs dss": SA against libdivsufsort (the
+    # reference's own checker, built into oracle/_ref), ISA by inversion, LCP against Kasai (lcp.hpp:46-77)
+    if not O.have_divsufsort():
+        pytest.skip("oracle/_ref/libdivsufsort*.so not built")
+    import psac_amd
+    text = inputs.dna(1 << 28, 1)
+    sa = psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
+    sa.construct(text)
+    dSA = O.divsufsort(text, 32)
+    assert np.array_equal(sa.local_SA, dSA)
+    del dSA
+    assert np.array_equal(sa.local_B[sa.local_SA.astype(np.int64)], np.arange(text.size, dtype=np.uint32))
+    assert np.array_equal(sa.local_LCP, O.kasai(text, sa.local_SA, sa.local_B))
+
+
 def _tandem_twin(ctx, monkeypatch, cap):
     # configs[4] / 256: 2^27 characters, period-1024 tandem repeat of DNA(1024, 3), uint64, against the CPU restatement
     n = 1 << 27
@@ -114,6 +130,8 @@ def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     text, sa = _tandem_twin(ctx, monkeypatch, 0)
     SA, LCP = O.construct_all_cores(text, bits=64)
     assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_LCP, LCP)
+    if O.have_divsufsort():
+        assert np.array_equal(SA, O.divsufsort(text, 64))
     assert np.array_equal(sa.local_B[SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
     # deep prefix doubling: h = 21 * 2^i until the 1024 phase buckets are resolved
     hs = [r[0] for r in sa.rounds]

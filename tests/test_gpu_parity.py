@@ -503,6 +503,23 @@ def _gsa(ctx, strings, bits, lcp=True, k=0, sep=None):
     return sa
 
 
+def test_psac_vs_dss_command_line(tmp_path):
+    # src/psac_vs_dss.cpp:59-119: the engine and libdivsufsort on the same input, -c = sufcheck on both
+    import subprocess
+    if not O.have_divsufsort():
+        pytest.skip("oracle/_ref/libdivsufsort*.so not built")
+    from test_oracle_golden import build_dss_tool
+    exe = build_dss_tool("psac_vs_dss", tmp_path, with_engine=True)
+    r = subprocess.run([exe, "-r", "500000", "-s", "5", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "PSAC time:" in r.stderr and "divsufsort time:" in r.stderr and "[SUCCESS]" in r.stderr
+    f = tmp_path / "t.txt"
+    f.write_bytes(bytes(inputs.ascii128(300001, 5)))
+    r = subprocess.run([exe, "-f", str(f), "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr
+    assert subprocess.run([exe], capture_output=True).returncode != 0
+
+
 def test_gsa_reference_vectors(ctx):
     # test/test_gsa.cpp:73-105 (SimpleTiny) and :107-179 (IncRepeats*): the reference's expected arrays
     from test_oracle_golden import GSA_REPEATS, repeat_inc_gsa, repeat_inc_glcp, repeat_inc_seq
@@ -692,13 +709,19 @@ def test_scaled_down_twins_of_the_baseline_configs(ctx):
     # every BASELINE config divided by 256 must match the CPU restatement bit for bit.
     #   C3 / 256: 2^24 random ASCII (sigma = 128), uint64, one GPU
     #   C4 / 256: 2^26 random DNA, uint64, 8 ranks of 2^23 (virtual ranks sharing this GPU, the HIP step ops)
+    # ... and, independently, libdivsufsort + Kasai (the reference's own check, test/test_psac.cpp:77-98, :50-74)
     text = inputs.ascii128(1 << 24, 42)
     got = run(ctx, text, bits=64)
     SA, LCP = O.construct_all_cores(text, bits=64)
     assert np.array_equal(got.local_SA, SA) and np.array_equal(got.local_LCP, LCP)
     assert np.array_equal(got.local_B[got.local_SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
+    if O.have_divsufsort():
+        dSA, dISA, dLCP = O.divsufsort_sa_lcp(text, 64)
+        assert np.array_equal(got.local_SA, dSA) and np.array_equal(got.local_B, dISA) and np.array_equal(got.local_LCP, dLCP)
     text = inputs.dna(1 << 26, 1)
     sa, isa, lcp, _ = _dist_loopback_gpu(text, 8, 64)
     SA, LCP = O.construct_all_cores(text, bits=64)
     assert np.array_equal(sa, SA) and np.array_equal(lcp, LCP)
     assert np.array_equal(isa[sa.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
+    if O.have_divsufsort():
+        assert np.array_equal(sa, O.divsufsort(text, 64))

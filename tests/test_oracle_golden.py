@@ -273,3 +273,83 @@ def test_all_cores_build_matches_scalar_build():
         SA, LCP = O.construct_all_cores(text, bits=32)
         ref = O.construct(text, bits=32)
         assert np.array_equal(SA, ref["SA"]) and np.array_equal(LCP, ref["LCP"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The oracle against the reference's own checker run here: libdivsufsort compiled from the sources under
+# /root/reference/ext/libdivsufsort (oracle/Makefile -> oracle/_ref/), SA == dss::construct and LCP == Kasai on the
+# shapes test/test_psac.cpp uses (:77-98, :50-74, :131-274), for both index widths and k / fast_resolval variants.
+# ---------------------------------------------------------------------------------------------------------------
+needs_dss = pytest.mark.skipif(not O.have_divsufsort(), reason="oracle/_ref/libdivsufsort*.so not built")
+
+
+def _dss_cases():
+    import inputs
+    words = ["helloworld", "blahlablah", "ellow", "worldblah", "rld", "hello"]
+    rng = np.random.default_rng(3)
+    rep = "".join(words[i] for i in rng.integers(0, len(words), 15000)).encode()
+    return [("mississippi", b"mississippi"), ("rand_dna_130370_7", O.rand_dna(130370, 7)),
+            ("rand_dna_66763_23", O.rand_dna(66763, 23)), ("repeats", rep), ("abc13333", b"abc" * 13333),
+            ("tandem_64", inputs.tandem(50000, 64, O.rand_dna(64, 1))), ("ascii128", inputs.ascii128(100000, 42)),
+            ("all_bytes", bytes(range(256)) * 40), ("single_symbol", b"A" * 3000), ("n9", O.rand_dna(9, 13))]
+
+
+@needs_dss
+@pytest.mark.parametrize("name,text", _dss_cases(), ids=[c[0] for c in _dss_cases()])
+def test_oracle_equals_divsufsort_and_kasai(name, text):
+    for bits in (32, 64):
+        SA, ISA, LCP = O.divsufsort_sa_lcp(text, bits)
+        assert O.sufcheck(text, SA) == 0
+        for fast, k in ((True, 0), (True, 3), (False, 2)):
+            if len(text) < 30 and k:
+                continue
+            ref = O.construct(text, bits=bits, fast=fast, k=k)
+            assert np.array_equal(ref["SA"], SA), (name, bits, fast, k)
+            assert np.array_equal(ref["ISA"], ISA)
+            assert np.array_equal(ref["LCP"], LCP)
+
+
+@needs_dss
+def test_divsufsort_reproduces_the_reference_known_answers():
+    # the library build itself, against vectors the reference holds: mississippi (test/test_psac.cpp:105)
+    m = KAT["mississippi"]
+    assert O.divsufsort(m["text"], 32).tolist() == m["SA"]
+    assert O.divsufsort(m["text"], 64).tolist() == m["SA"]
+    # and against the survey-captured divsufsort + Kasai checksums
+    for row in KAT["checksums"]:
+        if row["n"] > (1 << 20):
+            continue
+        text = make_input(row)
+        SA, ISA, LCP = O.divsufsort_sa_lcp(text, 64)
+        assert "%016x" % O.fnv(SA) == row["sa"], row["name"]
+        assert "%016x" % O.fnv(LCP) == row["lcp"], row["name"]
+
+
+def build_dss_tool(name, out_dir, with_engine=False):
+    """g++ of tests/cpp/<name>.cpp against oracle/_ref (libdivsufsort) and, for psac-vs-dss, libpsacx.so."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    ref = os.path.join(root, "oracle", "_ref")
+    exe = os.path.join(str(out_dir), name)
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I" + os.path.join(ref, "include"), "-o", exe,
+           os.path.join(HERE, "cpp", name + ".cpp"), os.path.join(ref, "libdivsufsort.so"), os.path.join(ref, "libdivsufsort64.so"),
+           "-Wl,-rpath," + ref]
+    if with_engine:
+        lib = os.path.join(root, "psac_amd", "lib")
+        cmd += ["-L" + lib, "-lpsacx", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+@needs_dss
+def test_dss_command_line(tmp_path):
+    # src/dss.cpp:41-84: one "<ms> ms" line per iteration; -f and -r exclude each other
+    import subprocess
+    exe = build_dss_tool("dss", tmp_path)
+    r = subprocess.run([exe, "-r", "200000", "-s", "3", "-i", "2"], capture_output=True, text=True)
+    assert r.returncode == 0 and len([l for l in r.stderr.splitlines() if l.endswith(" ms")]) == 2, r.stderr
+    f = tmp_path / "m.txt"
+    f.write_bytes(b"mississippi")
+    assert subprocess.run([exe, "-f", str(f)], capture_output=True).returncode == 0
+    assert subprocess.run([exe], capture_output=True).returncode != 0
+    assert subprocess.run([exe, "-f", str(f), "-r", "5"], capture_output=True).returncode != 0
