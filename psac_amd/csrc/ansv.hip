@@ -5,12 +5,12 @@
 // caller suffix_tree.hpp:43-63 with left = furthest_eq, right = nearest_sm).
 //
 // The reference walks a monotone stack per rank and exchanges unmatched prefix minima.  On the
-// GPU every element searches a 64-ary min-pyramid of the array instead: scan the rest of the
-// own 64-block, climb while no sibling block holds a small enough value, then descend into the
-// nearest block that does.  The expected work per element is a few cache lines because the
-// nearest smaller value of an LCP entry is almost always close by.
+// GPU the array is cut into tiles; inside a tile every search is a binary descent over window
+// minima held in registers and LDS, and the few searches that leave a tile share one walk of a
+// global 64-ary min-pyramid per distinct value (ansv_tile.hpp).
 #include "engine.hpp"
 #include "nsv.hpp"
+#include "ansv_tile.hpp"
 
 namespace psacx {
 
@@ -31,27 +31,6 @@ __device__ __forceinline__ uint64_t nsv_typed(const Pyramid<T>& P, uint64_t n, u
     } else {
         if (s == NSV_NONE) { if (P.lvl[0][n - 1] <= u) return n - 1; return nsv_search<T, true>(P, n - 1, u, false); }
         return nsv_search<T, true>(P, s, u, false);
-    }
-}
-
-template <typename T>
-__global__ void ansv_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type, uint64_t nonsv,
-                            uint64_t* __restrict__ left, uint64_t* __restrict__ right) {
-    const T* __restrict__ a = P.lvl[0];
-    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
-    const unsigned lane = lane_id();
-    for (uint64_t base = wave_id * 64; base < n; base += nwaves * 64) {      // one wave per 64 consecutive elements
-        const uint64_t i = base + lane;
-        const T cur = i < n ? a[i] : (T)0;
-        const T prev = i >= 64 ? a[i - 64] : (T)0;
-        const T next = i + 64 < n ? a[i + 64] : (T)0;
-        const uint64_t l = nsv_tile_wave<T, true>(P, n, base, cur, prev, left_type);
-        const uint64_t r = nsv_tile_wave<T, false>(P, n, base, cur, next, right_type);
-        if (i < n) {
-            left[i] = l == NSV_NONE ? nonsv : l;
-            right[i] = r == NSV_NONE ? nonsv : r;
-        }
     }
 }
 
@@ -76,7 +55,11 @@ int ansv_run(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t non
         hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
                            P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
     }
-    hipLaunchKernelGGL((ansv_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r);
+    {
+        constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
+        hipLaunchKernelGGL((ansv_tile_kernel<T>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(ANSV_THREADS), 0, c->stream, P, n, lt, rt,
+                           nonsv, d_l, d_r);
+    }
     delete ps;
     PSACX_HIP(c, hipGetLastError());
     if (!dev) {
@@ -96,23 +79,15 @@ int ansv_run(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t non
 // right = nearest_sm (suffix_tree.hpp:62).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void st_nodes_kernel(Pyramid<T> P, uint64_t n, const T* __restrict__ SA, const uint8_t* __restrict__ text,
-                                CodeTable tab, uint64_t row, unsigned long long* __restrict__ nodes) {
-    const T* __restrict__ LCP = P.lvl[0];
-    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
-    const unsigned lane = lane_id();
-    for (uint64_t base = wave_id * 64; base < n; base += nwaves * 64) {      // one wave per 64 consecutive LCP indices
-        const uint64_t i = base + lane;
-        const T cur = i < n ? LCP[i] : (T)0;
-        const T prv = i >= 64 ? LCP[i - 64] : (T)0;
-        const T nxt = i + 64 < n ? LCP[i + 64] : (T)0;
-        // both searches are wave-wide (every lane takes part), so they come before any per-element branch
-        const uint64_t ln = nsv_tile_wave<T, true>(P, n, base, cur, prv, 2);
-        const uint64_t rn = nsv_tile_wave<T, false>(P, n, base, cur, nxt, 0);
-        if (i >= n) continue;
+__global__ void st_nodes_kernel(const T* __restrict__ LCP, uint64_t n, const T* __restrict__ SA, const uint8_t* __restrict__ text,
+                                CodeTable tab, uint64_t row, const uint64_t* __restrict__ lnsv, const uint64_t* __restrict__ rnsv,
+                                unsigned long long* __restrict__ nodes) {
+    // lnsv / rnsv: ANSV of LCP with left = furthest_eq, right = nearest_sm (suffix_tree.hpp:62), NSV_NONE where none
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t ln = lnsv[i], rn = rnsv[i];
         const uint64_t sa = SA[i];
-        const uint64_t li = cur;
+        const uint64_t li = LCP[i];
         // ---- the leaf n + i (suffix_tree.hpp:72-143)
         uint64_t parent, lcp_val;
         if (i == 0) {
@@ -159,8 +134,10 @@ int suffix_tree_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa,
     const uint64_t row = (uint64_t)*sigma + 1;
     Pyramid<T> P;
     T* d_lcp = nullptr; T* d_sa = nullptr; uint8_t* d_text = nullptr; unsigned long long* d_nodes = nullptr;
+    uint64_t *d_ln = nullptr, *d_rn = nullptr;
     auto layout = [&](Arena& a) {
         d_lcp = a.take<T>(n); d_sa = a.take<T>(n); d_text = a.take<uint8_t>(n); d_nodes = a.take<unsigned long long>(n * row);
+        d_ln = a.take<uint64_t>(n); d_rn = a.take<uint64_t>(n);
         P.lvl[0] = d_lcp; P.len[0] = n; P.nlev = 1;
         uint64_t len = n;
         while (len > 64 && P.nlev < PYR_MAX) { len = (len + 63) / 64; P.lvl[P.nlev] = a.take<T>(len); P.len[P.nlev] = len; P.nlev++; }
@@ -177,7 +154,14 @@ int suffix_tree_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa,
                            P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
         PSACX_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL((st_nodes_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, P, n, d_sa, d_text, tab, row, d_nodes);
+    {
+        constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
+        hipLaunchKernelGGL((ansv_tile_kernel<T>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(ANSV_THREADS), 0, c->stream, P, n, 2, 0,
+                           NSV_NONE, d_ln, d_rn);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL((st_nodes_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_lcp, n, d_sa, d_text, tab, row,
+                       d_ln, d_rn, d_nodes);
     PSACX_HIP(c, hipGetLastError());
     PSACX_HIP(c, hipMemcpyAsync(nodes, d_nodes, n * row * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));

@@ -100,44 +100,6 @@ __device__ __forceinline__ uint64_t nsv_typed_wave(const Pyramid<T>& P, uint64_t
     }
 }
 
-// Nearest smaller value of the 64 consecutive elements base .. base + 63 (one per lane, base a multiple of
-// 64) on one side.  First every lane looks at its 64 neighbours on that side, which the wave already holds
-// in registers (`cur` = in[base + lane], `other` = in[base - 64 + lane] for LEFT / in[base + 64 + lane]):
-// 64 shuffle steps, no memory access, resolves all but a few per cent of the elements of an LCP array.
-// The rest are taken one at a time by the whole wave (nsv_typed_wave).
-template <typename T, bool LEFT>
-__device__ __forceinline__ uint64_t nsv_tile_wave(const Pyramid<T>& P, uint64_t n, uint64_t base, T cur, T other, int type) {
-    const unsigned lane = lane_id();
-    const uint64_t i = base + lane;
-    unsigned phase = i < n ? 0u : 3u;      // 0 look for the first hit, 1 extend the run of equal values, 2 found, 3 none
-    unsigned best = 0;
-    T u = 0;
-    for (unsigned d = 1; d <= 64; ++d) {
-        const int src = LEFT ? (int)lane - (int)d : (int)lane + (int)d;
-        const T xc = shfl<T>(cur, src & 63);
-        const T xo = shfl<T>(other, src & 63);
-        const T x = (src >= 0 && src < 64) ? xc : xo;
-        const bool valid = LEFT ? i >= d : i + d < n;
-        if (phase < 2) {
-            if (!valid) phase = phase == 1 ? 2u : 3u;                 // ran off the array
-            else if (phase == 0) {
-                if (type == 0 ? x < cur : x <= cur) { best = d; if (type == 2) { u = x; phase = 1; } else phase = 2; }
-            } else if (x < u) phase = 2;
-            else if (x == u) best = d;
-        }
-    }
-    uint64_t res = phase == 3 ? NSV_NONE : (LEFT ? i - best : i + best);
-    uint64_t pending = __ballot(phase < 2);
-    while (pending) {
-        const int src = __builtin_ctzll(pending);
-        const T vv = shfl<T>(cur, src);
-        const uint64_t r = nsv_typed_wave<T, LEFT>(P, n, base + (unsigned)src, vv, type);
-        if ((int)lane == src) res = r;
-        pending &= pending - 1;
-    }
-    return res;
-}
-
 // levels of a search pyramid over `m` values: the top level is a single group of <= 64 entries
 template <typename T>
 inline void nsv_pyramid_layout(Arena& a, const T* values, uint64_t m, Pyramid<T>& P) {

@@ -19,9 +19,12 @@ d_sa, d_isa, d_lcp = ctx.alloc(n * w), ctx.alloc(n * w), ctx.alloc(n * w)
 d_l, d_r = ctx.alloc(n * 8), ctx.alloc(n * 8)
 sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
 sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
-for it in range(3):
-    t0 = time.perf_counter()
-    psac_amd.ansv_device(ctx, d_lcp, n, d_l, d_r, bits, 2, 0, (1 << 64) - 1)
-    dt = time.perf_counter() - t0
-print("ANSV(furthest_eq, nearest_sm) over the LCP of 2^%d random DNA characters, uint%d, HBM-resident: %.2f ms = %.1f G elements/s"
-      % (logn, bits, dt * 1e3, n / dt / 1e9))
+names = ("nearest_sm", "nearest_eq", "furthest_eq")
+for lt, rt in ((2, 0), (0, 0), (1, 1), (2, 2)):
+    for it in range(3):
+        t0 = time.perf_counter()
+        psac_amd.ansv_device(ctx, d_lcp, n, d_l, d_r, bits, lt, rt, (1 << 64) - 1)
+        dt = time.perf_counter() - t0
+    # algorithmic bytes: the input once, both uint64 results once
+    print("ANSV(%s, %s) over the LCP of 2^%d random DNA characters, uint%d, HBM-resident: %.2f ms = %.1f G elements/s = %.0f GB/s algorithmic"
+          % (names[lt], names[rt], logn, bits, dt * 1e3, n / dt / 1e9, n * (w + 16) / dt / 1e9))
