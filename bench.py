@@ -36,8 +36,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Valid for the default workload only (2^28 uint32 records per launch).
 # [1] three-word form, profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
 # [2] two-word form, profiles/r01d_pmc_*.txt: (2 x 5903929.2 + 12713084.0) KiB over 6 launches
+# [2] at 2^32 uint64 records (the default workload), profiles/r02b_pmc_*.txt: (2 x 153707781.4 + 360349094.5) KiB over 5 launches
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 136758201815}
 
 
 def parse():
@@ -137,52 +138,76 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
 
 
 def main_distributed(a, rank, world, local_rank):
-    """N > 1: the text is block-partitioned over the ranks (one block of --n characters per GPU);
-    sort shuffle, SA->ISA scatter, B2 fetch and range-min queries go through RCCL all-to-all."""
+    """N > 1: one process per GPU.  The text (one stream DNA(world * n, seed), ...) is block-partitioned over the
+    ranks like psac partitions it over MPI ranks; the construction is the C++ multi-GPU engine behind
+    psacx_multi_* (psac_amd/csrc/multi.hpp): sample-sort shuffle, SA->ISA scatter, B2 fetch and range-min queries
+    as grouped ncclSend / ncclRecv over xGMI on a second stream.  torch.distributed only carries the communicator
+    id to the ranks and brackets the timed region."""
+    import ctypes as C
     import torch
     import torch.distributed as dist
+    import psac_amd
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from psac_amd import dist as D
-    from psac_amd.comm import TorchComm
-    from psac_amd.dist_ops import HipOps
     n = a.n
     bits = a.index if a.index else (32 if world * n <= (1 << 31) else 64)
     if world * n > 0xFFFFFFFE:
         bits = 64
-    ops = HipOps(bits, local_rank)
-    comm = TorchComm()
-    text = torch.from_numpy(make_text(a.alphabet, n, a.seed + rank)).cuda()
+    w = bits // 8
+    box = [psac_amd.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    mg = psac_amd.MultiContext.for_rank(rank, world, local_rank, box[0])
+    lib = mg._lib
+    ctx = mg.rank_ctx(0)
+
+    def alloc(nbytes):
+        p = C.c_void_p()
+        rc = lib.psacx_dev_alloc(ctx, C.byref(p), nbytes)
+        if rc != 0:
+            raise RuntimeError("device allocation of %d bytes failed" % nbytes)
+        return p.value
+
+    d_text = alloc(n)
+    rc = lib.psacx_synth_text_dev(ctx, C.c_void_p(d_text), n, rank * n, KIND_ID[a.alphabet], a.seed, 1024)
+    assert rc == 0
+    d_sa, d_isa, d_lcp = alloc(n * w), alloc(n * w), alloc(n * w)
 
     def step():
-        return D.run(D.construct(comm, ops, text, want_lcp=not a.no_lcp))
+        return mg.construct_device([d_text], [n], [d_sa], [d_isa], None if a.no_lcp else [d_lcp], bits)
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
+        lib.psacx_sync(ctx)
 
     for _ in range(a.warmup):
         step()
     barrier()
-    ops.profile(True)
+    lib.psacx_profile(ctx, 1)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        res = step()
+        st, sent, nex, nga = step()
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    s = ops.stats()
+    s = psac_amd._lib.Stats()
+    lib.psacx_get_stats(ctx, C.byref(s))
     if rank == 0:
         out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3, s.ms_sort_scatter2], list(s.scatter_bytes),
-                     list(s.scatter_launches), None, res["k"], res["l"], len(res["rounds"]),
-                     "block-partitioned text, 1 rank per GPU, RCCL all-to-all (sort shuffle, ISA scatter, B2 fetch)")
+                     list(s.scatter_launches), None, int(st.k), int(st.bits_per_char), int(st.n_rounds),
+                     "block-partitioned text, 1 rank per GPU, C++ host over RCCL (grouped ncclSend/ncclRecv: sort shuffle, "
+                     "ISA scatter, B2 fetch, range minima) on a second stream per GPU")
+        out["exchange"] = {"payload_bytes_sent_by_rank0_per_step": sent, "all_to_all_exchanges_per_step": nex,
+                           "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl}
         print(json.dumps(out))
-    ops.close()
+    for p in (d_text, d_sa, d_isa, d_lcp):
+        lib.psacx_dev_free(ctx, C.c_void_p(p))
+    mg.close()
     dist.destroy_process_group()
 
 

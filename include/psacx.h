@@ -212,6 +212,57 @@ int psacx_suffix_tree_u32(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const
 int psacx_suffix_tree_u64(psacx_ctx* ctx, const uint8_t* text, uint64_t n, const uint64_t* SA,
                           const uint64_t* LCP, uint64_t* nodes, uint32_t* sigma);
 
+/* several GPUs -------------------------------------------------------------------
+ * The reference's suffix_array<> IS distributed: every MPI rank holds one block of the text and of SA / ISA / LCP
+ * (suffix_array.hpp:183-194, :217-228; src/psac.cpp:85-93 block-decomposes the input).  A psacx_multi stands for the
+ * communicator: nranks ranks, one GPU each, of which nlocal live in this process.
+ *   psacx_multi_create       one process (one host thread) drives ndev GPUs: ranks 0..ndev-1 = dev_ids[0..ndev-1]
+ *                            (NULL: devices 0..ndev-1).  Distinct devices share one RCCL communicator
+ *                            (ncclCommInitAll); a device listed more than once carries several ranks that exchange
+ *                            by device-to-device copies (how the tests run P ranks on a one-GPU box).
+ *   psacx_multi_create_rank  one process per GPU, psac's own deployment (one MPI rank per device): every process
+ *                            passes the same 128-byte id, made by psacx_multi_unique_id on one of them and
+ *                            broadcast by the host (MPI_Bcast in psac, torch.distributed in bench.py).
+ * Exchanges replace mxx's collectives: grouped ncclSend / ncclRecv for MPI_Alltoallv (idxsort.hpp:60-62 via
+ * mxx::sort, bulk_permute.hpp:60-61, bulk_rma.hpp:20-49, par_rmq.hpp:273-293), one small all-gather for the
+ * scalars (bucketing.hpp:39,70,117), on a second stream per GPU.
+ * psacx_multi_construct_dev_*: d_text[i] / m[i] / d_SA[i] ... are the block of local rank i (device pointers on that
+ * rank's GPU); the blocks must follow mxx::blk_dist (the first n mod p ranks hold one character more,
+ * suffix_array.hpp:226-227: PSACX_EINVAL otherwise).  psacx_multi_construct_*: the whole text and results on the
+ * host of the single process that owns every rank (psac --gpus N).
+ * Errors: the codes above, -7 for an RCCL failure; psacx_multi_last_error gives the text. */
+typedef struct psacx_multi psacx_multi;
+int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids);
+int psacx_multi_unique_id(void* id128);
+int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device, const void* id128);
+void psacx_multi_destroy(psacx_multi* mg);
+int psacx_multi_nranks(const psacx_multi* mg);
+int psacx_multi_nlocal(const psacx_multi* mg);
+int psacx_multi_uses_rccl(const psacx_multi* mg);
+const char* psacx_multi_last_error(const psacx_multi* mg);
+psacx_ctx* psacx_multi_ctx(psacx_multi* mg, int local_rank);
+int psacx_multi_construct_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags,
+                                  uint32_t* const* d_SA, uint32_t* const* d_ISA, uint32_t* const* d_LCP);
+int psacx_multi_construct_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags,
+                                  uint64_t* const* d_SA, uint64_t* const* d_ISA, uint64_t* const* d_LCP);
+int psacx_multi_construct_u32(psacx_multi* mg, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint32_t* SA,
+                              uint32_t* ISA, uint32_t* LCP);
+int psacx_multi_construct_u64(psacx_multi* mg, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint64_t* SA,
+                              uint64_t* ISA, uint64_t* LCP);
+/* Distributed verification of block-distributed results without gathering them on one rank: d_check_sa
+ * (check_suffix_array.hpp:207-267: SA a permutation with inverse ISA, S[SA[i-1]] <= S[SA[i]], ties decided by the
+ * ranks of the suffixes one further) through the engine's own exchanges, plus -- beyond the reference, whose
+ * distributed checker leaves LCP out -- every LCP entry through the recurrence LCP[i] = 0 | 1 | 1 + min(LCP[ISA[SA[i-1]
+ * +1]+1 .. ISA[SA[i]+1]]).  errors[0..3] as psacx_check_dev_*, summed over all ranks (every rank gets the totals).
+ * d_LCP may be NULL. */
+int psacx_multi_check_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint32_t* const* d_SA,
+                              const uint32_t* const* d_ISA, const uint32_t* const* d_LCP, uint64_t errors[4]);
+int psacx_multi_check_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* const* d_SA,
+                              const uint64_t* const* d_ISA, const uint64_t* const* d_LCP, uint64_t errors[4]);
+/* statistics of the last call (sigma, k, the per-round log) and what this process moved: payload bytes sent to other
+ * ranks, number of all-to-all exchanges and of scalar all-gathers */
+int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* bytes_sent, uint64_t* exchanges, uint64_t* gathers);
+
 /* device memory helpers for hosts without their own HIP bindings ------------ */
 int psacx_dev_alloc(psacx_ctx* ctx, void** out, uint64_t bytes);
 int psacx_dev_free(psacx_ctx* ctx, void* p);

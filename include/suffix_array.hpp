@@ -3,8 +3,10 @@
 // Same class name, template parameters, public fields and construct() signatures as
 // /root/reference/include/suffix_array.hpp:170-228, :365-486, so that a caller such as
 // src/psac.cpp:117-128 compiles against this header unchanged apart from the communicator
-// type: the reference takes an mxx::comm (one MPI rank per text block); this engine runs one
-// process per GPU and takes a psacx::comm naming the HIP device.  All compute happens in the
+// type: the reference takes an mxx::comm (one MPI rank per text block); this engine takes a
+// psacx::comm naming the HIP device(s): one device = one rank; several devices = that many ranks,
+// one GPU each, all driven by this process (the text is block-decomposed over them exactly as
+// src/psac.cpp:85-93 decomposes it over MPI ranks, the exchanges run over RCCL).  All compute happens in the
 // HIP engine behind the C ABI of psacx.h; this header only moves data and re-throws errors
 // (std::runtime_error, as suffix_array.hpp:226-227 does).
 #ifndef PSACX_SUFFIX_ARRAY_HPP
@@ -25,17 +27,20 @@
 
 namespace psacx {
 
-// Stand-in for mxx::comm at one rank (Appendix A of SURVEY.md lists the surface psac uses).
+// Stand-in for mxx::comm (Appendix A of SURVEY.md lists the surface psac uses).  One process holds every rank:
+// rank() is 0, size() the number of GPUs (ranks) the communicator spans.
 class comm {
 public:
-    explicit comm(int device = 0) : device_(device) {}
+    explicit comm(int device = 0) : devices_(1, device) {}
+    explicit comm(const std::vector<int>& devices) : devices_(devices.empty() ? std::vector<int>(1, 0) : devices) {}
     int rank() const { return 0; }
-    int size() const { return 1; }
+    int size() const { return (int)devices_.size(); }
     bool is_first() const { return true; }
-    int device() const { return device_; }
-    comm copy() const { return comm(device_); }
+    int device() const { return devices_[0]; }
+    const std::vector<int>& devices() const { return devices_; }
+    comm copy() const { return comm(devices_); }
 private:
-    int device_;
+    std::vector<int> devices_;
 };
 
 // mxx::blk_dist at one rank (suffix_array.hpp:194, bulk_permute.hpp:23)
@@ -167,18 +172,24 @@ class suffix_array {
     static_assert(sizeof(index_t) == 4 || sizeof(index_t) == 8, "index_t must be a 32 or 64 bit unsigned integer");
     static_assert(!_CONSTRUCT_LC || _CONSTRUCT_LCP, "_CONSTRUCT_LC needs _CONSTRUCT_LCP (the reference fills Lc inside its LCP code)");
 public:
-    explicit suffix_array(const psacx::comm& _comm) : n(0), local_size(0), comm(_comm.copy()), p(1), verbose(true), ctx_(nullptr) {
+    explicit suffix_array(const psacx::comm& _comm)
+        : n(0), local_size(0), comm(_comm.copy()), p(_comm.size()), verbose(true), ctx_(nullptr), multi_(nullptr) {
         psacx::check(nullptr, psacx_create(&ctx_, comm.device(), nullptr));
+        if (p > 1) {
+            const int rc = psacx_multi_create(&multi_, p, comm.devices().data());
+            if (rc != PSACX_OK) { psacx_destroy(ctx_); ctx_ = nullptr; psacx::check(nullptr, rc); }
+        }
     }
-    virtual ~suffix_array() { if (ctx_) psacx_destroy(ctx_); }
+    virtual ~suffix_array() { if (multi_) psacx_multi_destroy(multi_); if (ctx_) psacx_destroy(ctx_); }
     suffix_array(const suffix_array&) = delete;
     suffix_array& operator=(const suffix_array&) = delete;
 
     /// The global size of the input string and suffix array (suffix_array.hpp:180)
     std::size_t n;
-    /// The local size (== n: one rank holds the whole text) (suffix_array.hpp:185)
+    /// The local size (== n: this process holds the blocks of all p ranks, in rank order) (suffix_array.hpp:185)
     std::size_t local_size;
     psacx::comm comm;
+    /// number of ranks = GPUs the construction is distributed over (suffix_array.hpp:191)
     int p;
     psacx::blk_dist part;
     using char_type = char_t;
@@ -195,7 +206,7 @@ public:
     bool verbose;                     // print the reference's stderr lines
 
     void init_size(std::size_t lsize) {      // suffix_array.hpp:217-228
-        local_size = lsize; n = lsize; p = 1; part = psacx::blk_dist(n);
+        local_size = lsize; n = lsize; part = psacx::blk_dist(n);
     }
 
     // suffix_array.hpp:469-486
@@ -211,9 +222,19 @@ public:
         uint32_t flags = (_CONSTRUCT_LCP ? PSACX_LCP : 0u) | (fast_resolval ? 0u : PSACX_NO_FAST);
         std::vector<uint8_t> lc;
         if (_CONSTRUCT_LC) lc.assign(n, 0);
-        int rc = run(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr,
+        int rc;
+        if (multi_) {
+            // p ranks, one GPU each: blocks of n / p characters (mxx::blk_dist), results gathered in rank order
+            if (_CONSTRUCT_LC) throw std::runtime_error("psacx: left-branching characters need a single-rank communicator");
+            if (!fast_resolval) throw std::runtime_error("psacx: fast_resolval = false needs a single-rank communicator");
+            rc = run_multi(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr);
+            if (rc != PSACX_OK) throw std::runtime_error(std::string("psacx: ") + (rc > -7 ? psacx_strerror(rc) : "RCCL failure") + " [" +
+                                                         psacx_multi_last_error(multi_) + "]");
+        } else {
+            rc = run(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr,
                      _CONSTRUCT_LC ? lc.data() : nullptr);
-        psacx::check(ctx_, rc);
+            psacx::check(ctx_, rc);
+        }
         local_Lc.clear();
         if (_CONSTRUCT_LC) {
             // positions past the end carry '\0' (alphabet.hpp:168); they are exactly those with SA[i-1] + LCP[i] == n
@@ -224,7 +245,8 @@ public:
             }
         }
         psacx_stats st;
-        psacx::check(ctx_, psacx_get_stats(ctx_, &st));
+        if (multi_) psacx::check(nullptr, psacx_multi_get_stats(multi_, &st, nullptr, nullptr, nullptr));
+        else psacx::check(ctx_, psacx_get_stats(ctx_, &st));
         alpha.set(chars);
         if (verbose) {
             PSACX_INFO("Alphabet: " << alpha);                       // suffix_array.hpp:481
@@ -239,6 +261,7 @@ public:
     void construct_ss(simple_dstringset& ss, const alphabet_type& a) {
         static_assert(sizeof(char_t) == 1, "string sets hold bytes");
         static_assert(!_CONSTRUCT_LC, "left-branching characters are not defined for string sets");
+        if (multi_) throw std::runtime_error("psacx: string sets need a single-rank communicator");
         init_size(ss.sum_sizes);
         if (n == 0) throw std::runtime_error("psacx: empty input");
         std::vector<uint8_t> bytes; bytes.reserve(n);
@@ -287,9 +310,24 @@ public:
     }
 
     psacx_ctx* context() { return ctx_; }
+    psacx_multi* multi_context() { return multi_; }
 
 private:
     psacx_ctx* ctx_;
+    psacx_multi* multi_;
+
+    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+        return psacx_multi_construct_u32(multi_, t, n, k, flags, sa, isa, lcp);
+    }
+    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+        return psacx_multi_construct_u64(multi_, t, n, k, flags, sa, isa, lcp);
+    }
+    template <typename U>
+    typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
+    run_multi(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp) {
+        typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
+        return run_multi(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
+    }
 
     int run(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp, uint8_t* lc) {
         return lc ? psacx_construct_lc_u32(ctx_, t, n, k, flags, sa, isa, lcp, lc) : psacx_construct_u32(ctx_, t, n, k, flags, sa, isa, lcp);

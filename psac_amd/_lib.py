@@ -24,6 +24,10 @@ EXPORTS = [
     "psacx_get_stats", "psacx_profile", "psacx_check_dev_u32", "psacx_check_dev_u64", "psacx_pair_sort_dev_u32", "psacx_pair_sort_dev_u64", "psacx_ansv_u32",
     "psacx_ansv_u64", "psacx_ansv_dev_u32", "psacx_ansv_dev_u64", "psacx_suffix_tree_u32", "psacx_suffix_tree_u64", "psacx_dev_alloc", "psacx_dev_free", "psacx_copy_h2d", "psacx_copy_d2h", "psacx_sync",
     "psacx_rand_dna", "psacx_synth_text_dev",
+    "psacx_multi_create", "psacx_multi_unique_id", "psacx_multi_create_rank", "psacx_multi_destroy", "psacx_multi_nranks",
+    "psacx_multi_nlocal", "psacx_multi_uses_rccl", "psacx_multi_last_error", "psacx_multi_ctx", "psacx_multi_construct_dev_u32",
+    "psacx_multi_construct_dev_u64", "psacx_multi_construct_u32", "psacx_multi_construct_u64", "psacx_multi_get_stats",
+    "psacx_multi_check_dev_u32", "psacx_multi_check_dev_u64",
 ]
 
 
@@ -99,6 +103,23 @@ def load():
     lib.psacx_sync.argtypes = [vp]
     lib.psacx_rand_dna.argtypes = [vp, u64, i32]
     lib.psacx_synth_text_dev.argtypes = [vp, vp, u64, u64, i32, u64, u64]
+    # several GPUs behind the same boundary (psacx_multi_*)
+    lib.psacx_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int)]
+    lib.psacx_multi_unique_id.argtypes = [vp]
+    lib.psacx_multi_create_rank.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
+    lib.psacx_multi_destroy.argtypes = [vp]
+    lib.psacx_multi_destroy.restype = None
+    for nm in ("psacx_multi_nranks", "psacx_multi_nlocal", "psacx_multi_uses_rccl"):
+        getattr(lib, nm).argtypes = [vp]
+    lib.psacx_multi_last_error.argtypes = [vp]
+    lib.psacx_multi_last_error.restype = C.c_char_p
+    lib.psacx_multi_ctx.argtypes = [vp, i32]
+    lib.psacx_multi_ctx.restype = vp
+    for suf in ("u32", "u64"):
+        getattr(lib, "psacx_multi_construct_dev_" + suf).argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
+        getattr(lib, "psacx_multi_construct_" + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
+        getattr(lib, "psacx_multi_check_dev_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
+    lib.psacx_multi_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     # step-level ops of the distributed path (include/psacx_ops.h)
     i64, u16p = C.c_int64, C.POINTER(C.c_uint16)
     u64p = C.POINTER(C.c_uint64)

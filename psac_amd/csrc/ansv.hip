@@ -55,11 +55,7 @@ int ansv_run(psacx_ctx* c, const T* in, uint64_t n, int lt, int rt, uint64_t non
         hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, P.len[L] * 64, 256, 8)), dim3(256), 0, c->stream,
                            P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
     }
-    {
-        constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
-        hipLaunchKernelGGL((ansv_tile_kernel<T>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(ANSV_THREADS), 0, c->stream, P, n, lt, rt,
-                           nonsv, d_l, d_r);
-    }
+    launch_ansv_tiles<T>(c, P, n, lt, rt, nonsv, d_l, d_r);
     delete ps;
     PSACX_HIP(c, hipGetLastError());
     if (!dev) {
@@ -154,12 +150,8 @@ int suffix_tree_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa,
                            P.lvl[L - 1], P.len[L - 1], P.lvl[L], P.len[L]);
         PSACX_HIP(c, hipGetLastError());
     }
-    {
-        constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
-        hipLaunchKernelGGL((ansv_tile_kernel<T>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(ANSV_THREADS), 0, c->stream, P, n, 2, 0,
-                           NSV_NONE, d_ln, d_rn);
-        PSACX_HIP(c, hipGetLastError());
-    }
+    launch_ansv_tiles<T>(c, P, n, 2, 0, NSV_NONE, d_ln, d_rn);
+    PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((st_nodes_kernel<T>), dim3(grid_for(c, n, 256, 16)), dim3(256), 0, c->stream, d_lcp, n, d_sa, d_text, tab, row,
                        d_ln, d_rn, d_nodes);
     PSACX_HIP(c, hipGetLastError());

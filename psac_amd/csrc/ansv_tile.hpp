@@ -26,20 +26,28 @@ constexpr unsigned ANSV_MEMO = 16;
 constexpr uint64_t ANSV_NOCONT = ~0ull - 1;      // a run of equal values does not continue beyond the tile edge
 
 template <typename T> struct AnsvTile { static constexpr int TB = sizeof(T) == 4 ? 64 : 32; };   // 64-blocks per tile
+// a search that starts at a tile edge finds nothing in the edge element's own 64-block, and nothing in the 64 blocks
+// around it when a tile is exactly one level-1 group: the global walk may start that many levels up
+template <typename T> struct ANSV_SKIP { static constexpr int LEVELS = AnsvTile<T>::TB == 64 ? 2 : 1; };
 
 template <typename T> struct AnsvMemo {
     T val[ANSV_MEMO];
-    unsigned long long res[ANSV_MEMO];
+    unsigned long long res[ANSV_MEMO];      // the answer
+    unsigned long long first[ANSV_MEMO];    // the nearest qualifying element the answer was derived from (NSV_NONE: none)
     unsigned kind[ANSV_MEMO];
     unsigned ready[ANSV_MEMO];
     unsigned cnt;
 };
 
-template <typename T, int TB> struct AnsvShared {
+template <typename T, int TB, bool LF, bool RF> struct AnsvShared {
     T sm[TB * 64];              // sm[e] = min(v[e .. end of its block])
     T pm[TB * 64];              // pm[e] = min(v[start of its block .. e])
     T bm[64];                   // block minima (all ones beyond the tile)
-    uint16_t link[2][TB * 64];  // equal-run links of furthest_eq (ping-pong)
+    // furthest_eq only: tile position of the nearest <= element of every element (bit 15: it has the same value;
+    // 0x7FFF: beyond the tile), and the equal-run links derived from it (ping-pong)
+    uint16_t code_l[LF ? TB * 64 : 1];
+    uint16_t code_r[RF ? TB * 64 : 1];
+    uint16_t link[(LF || RF) ? 2 : 1][(LF || RF) ? TB * 64 : 1];
     AnsvMemo<T> memo[2];        // shared answers of searches that leave the tile, per side
 };
 
@@ -100,14 +108,35 @@ __device__ __forceinline__ bool ansv_memo_find(AnsvMemo<T>& m, T v, unsigned kin
     return true;
 }
 template <typename T>
-__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind, uint64_t res) {
+__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind, uint64_t res, uint64_t first) {
     if (lane_id() == 0) {
         const unsigned idx = atomicAdd(&m.cnt, 1u);
         if (idx < ANSV_MEMO) {
-            m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res;
+            m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res; m.first[idx] = first;
             __hip_atomic_store(&m.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+}
+
+// A workgroup walks its tiles in ascending order and keeps the shared answers while they stay true (one thread,
+// between two tiles).  Left side: an answer for value v found beyond the left edge of the tile just finished is
+// also the answer beyond the left edge of the next tile unless the finished tile holds a qualifying element
+// itself (its minimum decides).  Right side: it stays true while the element it was derived from lies beyond
+// the right edge of the next tile.  type: the side's search type (strictness of kind 0).
+template <typename T>
+__device__ __forceinline__ void ansv_memo_carry(AnsvMemo<T>& m, bool left, int type, T finished_min, uint64_t next_end) {
+    unsigned c = m.cnt < ANSV_MEMO ? m.cnt : ANSV_MEMO, o = 0;
+    for (unsigned i = 0; i < c; ++i) {
+        if (!m.ready[i]) continue;
+        const T v = m.val[i];
+        const bool strict = m.kind[i] == 0 && type == 0;
+        bool keep;
+        if (left) keep = strict ? !(finished_min < v) : !(finished_min <= v);
+        else keep = m.first[i] == NSV_NONE || m.first[i] >= next_end;
+        if (keep) { m.val[o] = v; m.kind[o] = m.kind[i]; m.res[o] = m.res[i]; m.first[o] = m.first[i]; m.ready[o] = 1; ++o; }
+    }
+    for (unsigned i = o; i < ANSV_MEMO; ++i) m.ready[i] = 0;
+    m.cnt = o;
 }
 
 // Answer of a search that leaves the tile (whole wave, wave-uniform arguments).  kind 0: the typed nearest
@@ -120,178 +149,230 @@ __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n,
     if (ansv_memo_find<T>(memo, v, kind, &r)) return r;
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
-    if (kind == 0) {
-        r = edge ? NSV_NONE : nsv_typed_wave<T, LEFT>(P, n, start, v, type);
-    } else {
-        r = ANSV_NOCONT;
-        if (!edge) {
-            const uint64_t j = nsv_search_wave<T, LEFT>(P, start, v, false);
-            if (j != NSV_NONE && P.lvl[0][j] == v) r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
+    uint64_t j = NSV_NONE;
+    r = kind == 0 ? NSV_NONE : ANSV_NOCONT;
+    if (!edge) {
+        j = nsv_search_wave<T, LEFT>(P, start, v, kind == 0 && type == 0, ANSV_SKIP<T>::LEVELS);
+        if (kind == 0) {
+            r = j;
+            if (type == 2 && j != NSV_NONE) r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
+        } else if (j != NSV_NONE && P.lvl[0][j] == v) {
+            r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
         }
     }
-    ansv_memo_add<T>(memo, v, kind, r);
+    ansv_memo_add<T>(memo, v, kind, r, j);
     return r;
 }
 
-// One side of the tile.  val[k]: the lane's element of block (wave * BPW + k).  bmv: block minimum of block
-// `lane`.  out: result array of the side.
-template <typename T, int TB, bool LEFT>
-__device__ __forceinline__ void ansv_side(AnsvShared<T, TB>& sh, const Pyramid<T>& P, uint64_t n, uint64_t tile_base,
-                                          const T (&val)[TB / ANSV_WAVES], T bmv, int type, uint64_t nonsv,
-                                          uint64_t* __restrict__ out) {
-    constexpr int BPW = TB / ANSV_WAVES;
-    constexpr unsigned TILE = TB * 64;
-    constexpr unsigned MASK = 0x7FFFu, EXT = 0x8000u, PEND = 0xFFFFu;
+// Nearest element of the tile with a value < v (strict) or <= v on one side of element `lane` of block b.
+// Returns its tile position or PEND (0x7FFF) when the search leaves the tile; *u receives its value when WANT_U.
+constexpr unsigned ANSV_PEND = 0x7FFFu;
+template <typename T, int TB, bool LEFT, bool WANT_U, typename SH>
+__device__ __forceinline__ unsigned ansv_tile_search(SH& sh, const T (&BW)[6], unsigned b, T v, bool strict, uint64_t tile_base,
+                                                     uint64_t n, T* u) {
     const unsigned lane = lane_id();
-    const unsigned wave = threadIdx.x / WAVE;
-    const bool strict = type == 0;
-    const uint64_t tile_end = tile_base + TILE < n ? tile_base + TILE : n;
-    AnsvMemo<T>& memo = sh.memo[LEFT ? 0 : 1];
-
-    T BW[6];                                   // window minima over the block minima of the tile
-    if (LEFT) ansv_tables_left<T>(bmv, BW); else ansv_tables_right<T>(bmv, BW);
-
-    unsigned pend = 0, pend_cont = 0;          // bit k: the search of block k's element leaves the tile
-    unsigned code[BPW];                        // furthest_eq: tile position of the nearest <= element, or PEND
-    T q[BPW];                                  // furthest_eq: value whose run has to be followed
+    T W[6];
+    if (LEFT) ansv_tables_left<T>(v, W); else ansv_tables_right<T>(v, W);
+    const unsigned c = ansv_descend<T, LEFT>(W, lane, v, strict);
+    unsigned p = ANSV_PEND;
+    T uu = 0;
+    if (WANT_U) { const T x = shfl<T>(v, (int)(c & 63u)); if (c < 64) uu = x; }
+    if (c < 64) p = b * 64 + c;
+    // not inside the block: nearest block of the tile with a small enough minimum, then the nearest such element
+    // inside it by binary search in its suffix (prefix) minima
+    const unsigned bb = ansv_descend<T, LEFT>(BW, b, v, strict);
+    const bool need = c >= 64 && bb < (unsigned)TB;
+    if (__ballot(need)) {
+        const unsigned base = (need ? bb : b) * 64;
+        int lo = LEFT ? 0 : -1, hi = LEFT ? 64 : 63;
 #pragma unroll
-    for (int k = 0; k < BPW; ++k) {
-        const unsigned b = wave * BPW + k;
-        const unsigned e = b * 64 + lane;
-        const uint64_t g = tile_base + e;
-        const T v = val[k];
-        T W[6];
-        if (LEFT) ansv_tables_left<T>(v, W); else ansv_tables_right<T>(v, W);
-        unsigned c = ansv_descend<T, LEFT>(W, lane, v, strict);
-        unsigned p = PEND;
-        T u = 0;
-        if (type == 2) { const T uu = shfl<T>(v, (int)(c & 63u)); if (c < 64) u = uu; }
-        if (c < 64) p = b * 64 + c;
-        // not inside the block: nearest block of the tile with a small enough minimum, then the nearest such
-        // element inside it by binary search in its suffix (prefix) minima
-        const unsigned bb = ansv_descend<T, LEFT>(BW, b, v, strict);
-        const bool need = c >= 64 && bb < 64;
-        {
-            const unsigned base = (need ? bb : b) * 64;
-            int lo = LEFT ? 0 : -1, hi = LEFT ? 64 : 63;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int mid = (lo + hi) >> 1;
-                const T x = LEFT ? sh.sm[base + mid] : sh.pm[base + mid];
-                const bool ok = strict ? x < v : x <= v;
-                if (LEFT) { if (ok) lo = mid; else hi = mid; } else { if (ok) hi = mid; else lo = mid; }
-            }
-            if (need) {
-                p = base + (unsigned)(LEFT ? lo : hi);
-                if (type == 2) u = LEFT ? sh.sm[p] : sh.pm[p];
-            }
+        for (int s = 0; s < 6; ++s) {
+            const int mid = (lo + hi) >> 1;
+            const T x = LEFT ? sh.sm[base + mid] : sh.pm[base + mid];
+            const bool ok = strict ? x < v : x <= v;
+            if (LEFT) { if (ok) lo = mid; else hi = mid; } else { if (ok) hi = mid; else lo = mid; }
         }
-        if (tile_base + p >= n && p != PEND) p = PEND;     // padding past the end of the array is never an answer (right side)
-        if (g >= n) { code[k] = PEND; q[k] = 0; continue; }
-        if (type != 2) {
-            if (p != PEND) out[g] = tile_base + p;
-            else pend |= 1u << k;
-            code[k] = 0; q[k] = v;
-        } else {
-            code[k] = p; q[k] = u;
-            sh.link[0][e] = (uint16_t)((p != PEND && u == v) ? p : (e | (p == PEND ? EXT : 0u)));
+        if (need) {
+            p = base + (unsigned)(LEFT ? lo : hi);
+            if (WANT_U) uu = LEFT ? sh.sm[p] : sh.pm[p];
         }
     }
-    if (type == 2) {
-        // elements past the end of the array must not carry stale links
-#pragma unroll
-        for (int k = 0; k < BPW; ++k) {
-            const unsigned e = (wave * BPW + k) * 64 + lane;
-            if (tile_base + e >= n) sh.link[0][e] = (uint16_t)e;
-        }
-        __syncthreads();
-        // far end of every run of equal values inside the tile: link = link[link], log2(TILE) rounds
-        int cur = 0;
-#pragma unroll 1
-        for (unsigned span = 1; span < TILE; span <<= 1) {
-#pragma unroll
-            for (int k = 0; k < BPW; ++k) {
-                const unsigned e = (wave * BPW + k) * 64 + lane;
-                sh.link[cur ^ 1][e] = sh.link[cur][sh.link[cur][e] & MASK];
-            }
-            cur ^= 1;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < BPW; ++k) {
-            const unsigned e = (wave * BPW + k) * 64 + lane;
-            const uint64_t g = tile_base + e;
-            if (g >= n) continue;
-            if (code[k] == PEND) { pend |= 1u << k; q[k] = val[k]; continue; }       // nearest <= lies beyond the tile
-            const unsigned hh = sh.link[cur][code[k]];
-            out[g] = tile_base + (hh & MASK);
-            if (hh & EXT) pend_cont |= 1u << k;            // the run may go on beyond the tile edge (q[k] = its value)
-        }
-        __syncthreads();                                   // the link buffers are reused by the other side
-    }
-    // searches that leave the tile: one shared walk of the global pyramid per distinct value
-#pragma unroll
-    for (int k = 0; k < BPW; ++k) {
-        const uint64_t g = tile_base + (uint64_t)(wave * BPW + k) * 64 + lane;
-        uint64_t m = __ballot((pend >> k) & 1u);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            const T vq = shfl<T>(q[k], src);
-            const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, 0u, memo);
-            const bool mine = ((pend >> k) & 1u) && q[k] == vq;
-            if (mine) out[g] = r == NSV_NONE ? nonsv : r;
-            m &= ~__ballot(mine);
-        }
-        m = __ballot((pend_cont >> k) & 1u);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            const T vq = shfl<T>(q[k], src);
-            const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, 2, 1u, memo);
-            const bool mine = ((pend_cont >> k) & 1u) && q[k] == vq;
-            if (mine && r != ANSV_NOCONT) out[g] = r;
-            m &= ~__ballot(mine);
-        }
-    }
-    // elements without any answer on this side inside the tile and beyond were written as NSV_NONE -> nonsv above
+    if (p != ANSV_PEND && tile_base + p >= n) p = ANSV_PEND;     // padding past the end of the array is never an answer
+    if (WANT_U) *u = uu;
+    return p;
 }
 
-template <typename T>
+// The lanes flagged in `pend` ask for the answer beyond the tile edge for their value myq: one shared walk per
+// distinct value (whole wave).  kind 0: out = answer (nonsv if none); kind 1: out = far end of the run if it continues.
+template <typename T, bool LEFT>
+__device__ __forceinline__ void ansv_resolve_pending(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
+                                                     bool pend, T myq, int type, unsigned kind, AnsvMemo<T>& memo, uint64_t nonsv,
+                                                     uint64_t* __restrict__ out, uint64_t g) {
+    uint64_t m = __ballot(pend);
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        const T vq = shfl<T>(myq, src);
+        const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, kind, memo);
+        const bool mine = pend && myq == vq;
+        if (mine) {
+            if (kind == 0) out[g] = r == NSV_NONE ? nonsv : r;
+            else if (r != ANSV_NOCONT) out[g] = r;
+        }
+        m &= ~__ballot(mine);
+    }
+}
+
+// furthest_eq, after the searches of all blocks: follow the runs of equal values inside the tile (pointer
+// jumping over the links, log2(tile) rounds), then the runs that reach the tile edge beyond it.
+template <typename T, int TB, bool LEFT, typename SH>
+__device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t nonsv,
+                                                     uint64_t* __restrict__ out) {
+    constexpr int BPW = TB / ANSV_WAVES;
+    constexpr unsigned TILE = TB * 64;
+    constexpr unsigned MASK = 0x7FFFu, EXT = 0x8000u;
+    const unsigned lane = lane_id();
+    const unsigned wave = threadIdx.x / WAVE;
+    const uint16_t* code = LEFT ? sh.code_l : sh.code_r;
+    const T* __restrict__ in = P.lvl[0];
+    const uint64_t tile_end = tile_base + TILE < n ? tile_base + TILE : n;
+    AnsvMemo<T>& memo = sh.memo[LEFT ? 0 : 1];
+#pragma unroll 1
+    for (int k = 0; k < BPW; ++k) {
+        const unsigned e = (wave * BPW + k) * 64 + lane;
+        const unsigned cd = code[e];
+        const unsigned p = cd & MASK;
+        // same value as the nearest <= element: part of its run; otherwise the element heads its own run, which
+        // may go on beyond the tile edge when nothing <= was found inside
+        sh.link[0][e] = (uint16_t)((p != ANSV_PEND && (cd & EXT)) ? p : (e | (p == ANSV_PEND ? EXT : 0u)));
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (unsigned span = 1; span < TILE; span <<= 1) {
+        // (runs are short on real data: stop as soon as a round moves nothing)
+        bool moved = false;
+#pragma unroll 4
+        for (int k = 0; k < BPW; ++k) {
+            const unsigned e = (wave * BPW + k) * 64 + lane;
+            const uint16_t a = sh.link[cur][e];
+            const uint16_t b = sh.link[cur][a & MASK];
+            moved |= a != b;
+            sh.link[cur ^ 1][e] = b;
+        }
+        cur ^= 1;
+        if (!__syncthreads_or(moved)) break;
+    }
+#pragma unroll 1
+    for (int k = 0; k < BPW; ++k) {
+        const unsigned e = (wave * BPW + k) * 64 + lane;
+        const uint64_t g = tile_base + e;
+        const bool in_range = g < n;
+        const unsigned p = code[e] & MASK;
+        const bool direct = in_range && p == ANSV_PEND;              // the nearest <= element lies beyond the tile
+        bool cont = false;
+        T q = 0;
+        if (in_range && !direct) {
+            const unsigned hh = sh.link[cur][p];
+            out[g] = tile_base + (hh & MASK);
+            cont = (hh & EXT) != 0;                                     // the run may go on beyond the tile edge
+            if (cont) q = in[tile_base + p];
+        }
+        if (direct) q = in[g];
+        ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, direct, q, 2, 0u, memo, nonsv, out, g);
+        ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, q, 2, 1u, memo, nonsv, out, g);
+    }
+    __syncthreads();                                                    // the link buffers are reused by the other side
+}
+
+template <typename T, bool LF, bool RF>
 __global__ __launch_bounds__(ANSV_THREADS) void ansv_tile_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type,
                                                                  uint64_t nonsv, uint64_t* __restrict__ left,
-                                                                 uint64_t* __restrict__ right) {
+                                                                 uint64_t* __restrict__ right, uint64_t ntiles) {
     constexpr int TB = AnsvTile<T>::TB;
     constexpr int BPW = TB / ANSV_WAVES;
     constexpr unsigned TILE = TB * 64;
-    __shared__ AnsvShared<T, TB> sh;
+    typedef AnsvShared<T, TB, LF, RF> SH;
+    __shared__ SH sh;
     const T* __restrict__ in = P.lvl[0];
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x / WAVE;
-    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
-    if (threadIdx.x < 64) sh.bm[threadIdx.x] = ~(T)0;
+    const int lt = LF ? 2 : left_type, rt = RF ? 2 : right_type;
+    const bool lstrict = lt == 0, rstrict = rt == 0;
+    // a contiguous range of tiles per workgroup, so that answers found beyond a tile edge carry over to the next tile
+    const uint64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t_lo = (uint64_t)blockIdx.x * per;
+    const uint64_t t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
     if (threadIdx.x < 2) sh.memo[threadIdx.x].cnt = 0;
     if (threadIdx.x < 2 * ANSV_MEMO) sh.memo[threadIdx.x / ANSV_MEMO].ready[threadIdx.x % ANSV_MEMO] = 0;
-    __syncthreads();
-    T val[BPW];
-#pragma unroll
-    for (int k = 0; k < BPW; ++k) {
-        const uint64_t g = tile_base + (uint64_t)(wave * BPW + k) * 64 + lane;
-        val[k] = g < n ? in[g] : ~(T)0;
+    T prev_min = ~(T)0;
+    for (uint64_t t = t_lo; t < t_hi; ++t) {
+        const uint64_t tile_base = t * TILE;
+        const uint64_t tile_end = tile_base + TILE < n ? tile_base + TILE : n;
+        __syncthreads();                       // every wave is done with the previous tile (LDS arrays, shared answers)
+        if (threadIdx.x < 64) sh.bm[threadIdx.x] = ~(T)0;
+        if (t > t_lo && threadIdx.x == 0) {
+            ansv_memo_carry<T>(sh.memo[0], true, lt, prev_min, tile_end);
+            ansv_memo_carry<T>(sh.memo[1], false, rt, prev_min, tile_end);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < BPW; ++k) {
+            const unsigned b = wave * BPW + k;
+            const unsigned e = b * 64 + lane;
+            const uint64_t g = tile_base + e;
+            const T v = g < n ? in[g] : ~(T)0;
+            const T pre = wave_scan_inclusive<T>(v, OpMin());
+            const T rev = shfl<T>(v, 63 - (int)lane);
+            const T srv = wave_scan_inclusive<T>(rev, OpMin());
+            const T suf = shfl<T>(srv, 63 - (int)lane);
+            sh.pm[e] = pre; sh.sm[e] = suf;
+            if (lane == 63) sh.bm[b] = pre;
+        }
+        __syncthreads();
+        const T bmv = sh.bm[lane];
+        prev_min = wave_reduce<T>(bmv, OpMin());
+        T BL[6], BR[6];                        // window minima over the block minima of the tile
+        ansv_tables_left<T>(bmv, BL);
+        ansv_tables_right<T>(bmv, BR);
+#pragma unroll 1
+        for (int k = 0; k < BPW; ++k) {
+            const unsigned b = wave * BPW + k;
+            const unsigned e = b * 64 + lane;
+            const uint64_t g = tile_base + e;
+            const bool in_range = g < n;
+            const T v = in_range ? in[g] : ~(T)0;      // (second read of the tile: L2)
+            T ul = 0, ur = 0;
+            const unsigned pl = ansv_tile_search<T, TB, true, LF>(sh, BL, b, v, lstrict, tile_base, n, &ul);
+            const unsigned pr = ansv_tile_search<T, TB, false, RF>(sh, BR, b, v, rstrict, tile_base, n, &ur);
+            if (LF) sh.code_l[LF ? e : 0] = (uint16_t)(pl | ((pl != ANSV_PEND && ul == v) ? 0x8000u : 0u));
+            else {
+                if (in_range && pl != ANSV_PEND) left[g] = tile_base + pl;
+                ansv_resolve_pending<T, true>(P, n, tile_base, tile_end, in_range && pl == ANSV_PEND, v, lt, 0u, sh.memo[0], nonsv, left, g);
+            }
+            if (RF) sh.code_r[RF ? e : 0] = (uint16_t)(pr | ((pr != ANSV_PEND && ur == v) ? 0x8000u : 0u));
+            else {
+                if (in_range && pr != ANSV_PEND) right[g] = tile_base + pr;
+                ansv_resolve_pending<T, false>(P, n, tile_base, tile_end, in_range && pr == ANSV_PEND, v, rt, 0u, sh.memo[1], nonsv, right, g);
+            }
+        }
+        if (LF || RF) __syncthreads();
+        if (LF) ansv_finish_furthest<T, TB, true>(sh, P, n, tile_base, nonsv, left);
+        if (RF) ansv_finish_furthest<T, TB, false>(sh, P, n, tile_base, nonsv, right);
     }
-#pragma unroll
-    for (int k = 0; k < BPW; ++k) {
-        const unsigned b = wave * BPW + k;
-        const unsigned e = b * 64 + lane;
-        const T pre = wave_scan_inclusive<T>(val[k], OpMin());
-        const T rev = shfl<T>(val[k], 63 - (int)lane);
-        const T srv = wave_scan_inclusive<T>(rev, OpMin());
-        const T suf = shfl<T>(srv, 63 - (int)lane);
-        sh.pm[e] = pre; sh.sm[e] = suf;
-        if (lane == 63) sh.bm[b] = pre;
-    }
-    __syncthreads();
-    const T bmv = sh.bm[lane];
-    ansv_side<T, TB, true>(sh, P, n, tile_base, val, bmv, left_type, nonsv, left);
-    ansv_side<T, TB, false>(sh, P, n, tile_base, val, bmv, right_type, nonsv, right);
+}
+
+// grid: a few workgroups per CU, each with a contiguous share of the tiles
+template <typename T>
+inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
+    constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * 4);
+#define PSACX_ANSV(LF, RF) hipLaunchKernelGGL((ansv_tile_kernel<T, LF, RF>), dim3(grid), dim3(ANSV_THREADS), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles)
+    if (lt == 2 && rt == 2) PSACX_ANSV(true, true);
+    else if (lt == 2) PSACX_ANSV(true, false);
+    else if (rt == 2) PSACX_ANSV(false, true);
+    else PSACX_ANSV(false, false);
+#undef PSACX_ANSV
 }
 
 } // namespace psacx

@@ -2,7 +2,9 @@
 // (/root/reference/src/psac.cpp:56-153):
 //   psac (-f <file> | -r <size>) [-s <seed>] [-o <basename>] [-l] [-t] [-c]
 // writes <basename>.sa64 (and .lcp64 with -l) as raw little-endian uint64 arrays and prints
-// "PSAC time: <ms> ms".  Extra flags: --device N, --index {32,64,auto} (files stay uint64).
+// "PSAC time: <ms> ms".  Extra flags: --device N, --index {32,64,auto} (files stay uint64), --gpus N: the text is
+// block-decomposed over GPUs 0..N-1 (src/psac.cpp:85-93 over MPI ranks) and built by the multi-GPU engine;
+// --gpus-on-device D,N: N ranks sharing device D (how a one-GPU box exercises that path).
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +27,7 @@ static std::string rand_dna(std::size_t size, int seed) {   // alphabet.hpp:32-4
 }
 
 static void usage() {
-    std::cerr << "USAGE: psac {-f <filename>|-r <size>} [-s <int>] [-o <filename>] [-l] [-t] [-c] [--device N] [--index 32|64|auto]\n"
+    std::cerr << "USAGE: psac {-f <filename>|-r <size>} [-s <int>] [-o <filename>] [-l] [-t] [-c] [--device N] [--gpus N] [--index 32|64|auto]\n"
                  "Parallel distributed suffix array and LCP construction (MI355X engine).\n";
 }
 
@@ -56,9 +58,11 @@ static void tree_step(suffix_array<char, IT, true>& sa, const std::string& str, 
 template <typename IT>
 static void tree_step(suffix_array<char, IT, false>&, const std::string&, const std::string&, int, double) {}
 
+static std::vector<int> g_devices;      // --gpus: the devices of the communicator (empty: the single --device)
+
 template <typename IT, bool LCP>
 static int run(const std::string& str, const std::string& out, bool check, int device, bool tree) {
-    suffix_array<char, IT, LCP> sa((psacx::comm(device)));
+    suffix_array<char, IT, LCP> sa(g_devices.empty() ? psacx::comm(device) : psacx::comm(g_devices));
     auto t0 = std::chrono::steady_clock::now();
     sa.construct(str.begin(), str.end(), true);
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -95,6 +99,13 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--tree") tree = true;
         else if (a == "-c" || a == "--check") check = true;
         else if (a == "--device") device = atoi(need("--device"));
+        else if (a == "--gpus") { const int g = atoi(need("--gpus")); g_devices.clear(); for (int d = 0; d < g; ++d) g_devices.push_back(d); }
+        else if (a == "--gpus-on-device") {
+            const std::string v = need("--gpus-on-device");
+            const std::size_t c = v.find(',');
+            const int d = atoi(v.substr(0, c).c_str()), g = c == std::string::npos ? 1 : atoi(v.substr(c + 1).c_str());
+            g_devices.assign((std::size_t)std::max(g, 1), d);
+        }
         else if (a == "--index") index = need("--index");
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { std::cerr << "error: unknown argument " << a << std::endl; usage(); return EXIT_FAILURE; }

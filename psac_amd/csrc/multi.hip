@@ -1,0 +1,211 @@
+// multi.hip -- extern "C" surface of the multi-GPU construction (include/psacx.h, psacx_multi_*) over multi.hpp.
+#include "multi.hpp"
+
+using namespace psacx;
+
+namespace {
+
+int make_rank(psacx_multi* g, int i, int grank, int device) {
+    MRank& R = g->R[i];
+    R.grank = grank;
+    int rc = psacx_create(&R.ctx, device, nullptr);
+    if (rc != PSACX_OK) { g->err = std::string("psacx_create: ") + psacx_strerror(rc); return rc; }
+    MG_HIP(g, hipSetDevice(device));
+    MG_HIP(g, hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
+    MG_HIP(g, hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming));
+    MG_HIP(g, hipEventCreateWithFlags(&R.ev_done, hipEventDisableTiming));
+    // keep freed blocks in the stream-ordered pool: the rounds allocate the same sizes again and again
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    return PSACX_OK;
+}
+
+template <typename T>
+int run_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags, T* const* sa, T* const* isa,
+            T* const* lcp) {
+    if (!g || !d_text || !m || !sa || !isa) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    g->err.clear();
+    MultiRun<T> run(g);
+    std::vector<const uint8_t*> t(g->nlocal); std::vector<uint64_t> mm(g->nlocal);
+    std::vector<T*> a(g->nlocal), b(g->nlocal), c(g->nlocal, nullptr);
+    for (int i = 0; i < g->nlocal; ++i) { t[i] = d_text[i]; mm[i] = m[i]; a[i] = sa[i]; b[i] = isa[i]; if (flags & PSACX_LCP) c[i] = lcp[i]; }
+    return run.construct(t, mm, k, flags, a, b, c);
+}
+
+template <typename T>
+int check_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, const T* const* sa, const T* const* isa, const T* const* lcp,
+              uint64_t errors[4]) {
+    if (!g || !d_text || !m || !sa || !isa || !errors) return PSACX_EINVAL;
+    g->err.clear();
+    MultiRun<T> run(g);
+    std::vector<const uint8_t*> t(g->nlocal); std::vector<uint64_t> mm(g->nlocal);
+    std::vector<T*> a(g->nlocal), b(g->nlocal), c(g->nlocal, nullptr);
+    for (int i = 0; i < g->nlocal; ++i) { t[i] = d_text[i]; mm[i] = m[i]; a[i] = const_cast<T*>(sa[i]); b[i] = const_cast<T*>(isa[i]); if (lcp) c[i] = const_cast<T*>(lcp[i]); }
+    return run.check(t, mm, a, b, c, lcp != nullptr, errors);
+}
+
+// whole text on the host of a single process that owns every rank: blocks to the GPUs, results back in rank order
+template <typename T>
+int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp) {
+    if (!g || !text || !sa || !isa || n == 0) return PSACX_EINVAL;
+    if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    if (g->nlocal != g->nranks) { g->err = "the host-pointer form needs every rank in this process"; return PSACX_EINVAL; }
+    if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+    const int P = g->nranks;
+    const bool want_lcp = (flags & PSACX_LCP) != 0;
+    std::vector<uint64_t> m(P), off(P + 1, 0);
+    for (int r = 0; r < P; ++r) { m[r] = n / P + ((uint64_t)r < n % P ? 1 : 0); off[r + 1] = off[r] + m[r]; }
+    std::vector<DBuf<uint8_t>> dt(P);
+    std::vector<DBuf<T>> dsa(P), disa(P), dlcp(P);
+    std::vector<const uint8_t*> tp(P); std::vector<T*> a(P), b(P), c(P, nullptr);
+    for (int r = 0; r < P; ++r) {
+        psacx_ctx* cx = g->R[r].ctx;
+        MG_OP(g, cx, dt[r].alloc(cx, m[r])); MG_OP(g, cx, dsa[r].alloc(cx, m[r])); MG_OP(g, cx, disa[r].alloc(cx, m[r]));
+        if (want_lcp) MG_OP(g, cx, dlcp[r].alloc(cx, m[r]));
+        if (m[r]) MG_OP(g, cx, staged_h2d(cx, dt[r].p, text + off[r], m[r]));
+        tp[r] = dt[r].p; a[r] = dsa[r].p; b[r] = disa[r].p; c[r] = want_lcp ? dlcp[r].p : nullptr;
+    }
+    int rc = run_dev<T>(g, tp.data(), m.data(), k, flags, a.data(), b.data(), c.data());
+    if (rc != PSACX_OK) return rc;
+    for (int r = 0; r < P; ++r) {
+        psacx_ctx* cx = g->R[r].ctx;
+        MG_HIP(g, hipSetDevice(cx->device));
+        if (!m[r]) continue;
+        MG_OP(g, cx, staged_d2h(cx, sa + off[r], dsa[r].p, m[r] * sizeof(T)));
+        MG_OP(g, cx, staged_d2h(cx, isa + off[r], disa[r].p, m[r] * sizeof(T)));
+        if (want_lcp) MG_OP(g, cx, staged_d2h(cx, lcp + off[r], dlcp[r].p, m[r] * sizeof(T)));
+    }
+    return PSACX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) {
+    if (!out || ndev < 1 || ndev > 64) return PSACX_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return PSACX_ENOGPU; }
+    std::vector<int> devs(ndev);
+    bool distinct = true;
+    for (int i = 0; i < ndev; ++i) {
+        devs[i] = dev_ids ? dev_ids[i] : i;
+        if (devs[i] < 0 || devs[i] >= count) return PSACX_EINVAL;
+        for (int j = 0; j < i; ++j) distinct = distinct && devs[j] != devs[i];
+    }
+    psacx_multi* g = new psacx_multi();
+    g->nranks = g->nlocal = ndev; g->first = 0;
+    g->R.resize(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        const int rc = make_rank(g, i, i, devs[i]);
+        if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
+    }
+    // one RCCL communicator over the devices; ranks that share a device (and a single rank) exchange by copies
+    g->use_rccl = distinct && ndev > 1 && !getenv("PSACX_MULTI_NO_RCCL");
+    if (g->use_rccl) {
+        std::string err;
+        std::vector<ncclComm_t> comms(ndev);
+        if (!rccl().load(err) || rccl().CommInitAll(comms.data(), ndev, devs.data()) != ncclSuccess) {
+            (void)hipGetLastError();
+            g->use_rccl = false;           // peer copies still work
+        } else {
+            for (int i = 0; i < ndev; ++i) g->R[i].comm = comms[i];
+        }
+    }
+    *out = g;
+    return PSACX_OK;
+}
+
+int psacx_multi_unique_id(void* id128) {
+    if (!id128) return PSACX_EINVAL;
+    std::string err;
+    if (!rccl().load(err)) return PSACX_MULTI_EPEER;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return PSACX_MULTI_EPEER;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, 128);
+    return PSACX_OK;
+}
+
+int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device, const void* id128) {
+    if (!out || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || device < 0) return PSACX_EINVAL;
+    if (nranks > 1 && !id128) return PSACX_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return PSACX_ENOGPU; }
+    if (device >= count) return PSACX_EINVAL;
+    psacx_multi* g = new psacx_multi();
+    g->nranks = nranks; g->nlocal = 1; g->first = rank;
+    g->R.resize(1);
+    int rc = make_rank(g, 0, rank, device);
+    if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
+    if (id128) {
+        std::string err;
+        ncclUniqueId id;
+        std::memcpy(&id, id128, 128);
+        if (!rccl().load(err)) { psacx_multi_destroy(g); return PSACX_MULTI_EPEER; }
+        if (hipSetDevice(device) != hipSuccess || rccl().CommInitRank(&g->R[0].comm, nranks, id, rank) != ncclSuccess) {
+            psacx_multi_destroy(g);
+            return PSACX_MULTI_EPEER;
+        }
+        g->use_rccl = true;
+    }
+    *out = g;
+    return PSACX_OK;
+}
+
+void psacx_multi_destroy(psacx_multi* g) {
+    if (!g) return;
+    for (auto& R : g->R) {
+        if (!R.ctx) continue;
+        (void)hipSetDevice(R.ctx->device);
+        (void)hipStreamSynchronize(R.ctx->stream);
+        if (R.comm_stream) (void)hipStreamSynchronize(R.comm_stream);
+        if (R.comm) (void)rccl().CommDestroy(R.comm);
+        if (R.d_scal) (void)hipFree(R.d_scal);
+        if (R.ev_ready) (void)hipEventDestroy(R.ev_ready);
+        if (R.ev_done) (void)hipEventDestroy(R.ev_done);
+        if (R.comm_stream) (void)hipStreamDestroy(R.comm_stream);
+        psacx_destroy(R.ctx);
+    }
+    delete g;
+}
+
+int psacx_multi_nranks(const psacx_multi* g) { return g ? g->nranks : 0; }
+int psacx_multi_nlocal(const psacx_multi* g) { return g ? g->nlocal : 0; }
+int psacx_multi_uses_rccl(const psacx_multi* g) { return g && g->use_rccl ? 1 : 0; }
+const char* psacx_multi_last_error(const psacx_multi* g) { return g ? g->err.c_str() : ""; }
+
+int psacx_multi_get_stats(const psacx_multi* g, psacx_stats* out, uint64_t* bytes_sent, uint64_t* exchanges, uint64_t* gathers) {
+    if (!g || !out) return PSACX_EINVAL;
+    *out = g->stats;
+    if (bytes_sent) *bytes_sent = g->bytes_sent;
+    if (exchanges) *exchanges = g->n_exchanges;
+    if (gathers) *gathers = g->n_gathers;
+    return PSACX_OK;
+}
+
+int psacx_multi_construct_dev_u32(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, uint32_t k, uint32_t f, uint32_t* const* sa,
+                                  uint32_t* const* isa, uint32_t* const* lcp) { return run_dev<uint32_t>(g, t, m, k, f, sa, isa, lcp); }
+int psacx_multi_construct_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, uint32_t k, uint32_t f, uint64_t* const* sa,
+                                  uint64_t* const* isa, uint64_t* const* lcp) { return run_dev<uint64_t>(g, t, m, k, f, sa, isa, lcp); }
+int psacx_multi_construct_u32(psacx_multi* g, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+    return run_host<uint32_t>(g, t, n, k, f, sa, isa, lcp);
+}
+int psacx_multi_construct_u64(psacx_multi* g, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+    return run_host<uint64_t>(g, t, n, k, f, sa, isa, lcp);
+}
+
+int psacx_multi_check_dev_u32(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint32_t* const* sa, const uint32_t* const* isa,
+                              const uint32_t* const* lcp, uint64_t errors[4]) { return check_dev<uint32_t>(g, t, m, sa, isa, lcp, errors); }
+int psacx_multi_check_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* isa,
+                              const uint64_t* const* lcp, uint64_t errors[4]) { return check_dev<uint64_t>(g, t, m, sa, isa, lcp, errors); }
+
+/* the rank-local psacx_ctx of local rank i (its device, compute stream and workspace), e.g. for psacx_dev_alloc */
+psacx_ctx* psacx_multi_ctx(psacx_multi* g, int i) { return (g && i >= 0 && i < g->nlocal) ? g->R[i].ctx : nullptr; }
+
+} // extern "C"

@@ -1,0 +1,1041 @@
+// multi.hpp -- the block-distributed construction on several GPUs, host side in C++ behind include/psacx.h
+// (psacx_multi_*).  One rank per GPU, text / SA / ISA / LCP block-partitioned the way psac partitions them over
+// MPI ranks (suffix_array.hpp:183-194, mxx::blk_dist).  Two ways to run it:
+//   * one process, one host thread driving all GPUs of the node (psacx_multi_create; `psac --gpus N`): the ranks are
+//     local objects, every collective is issued for all of them inside one RCCL group;
+//   * one process per GPU (psacx_multi_create_rank; psac's own model of one MPI rank per device, and what
+//     `bench.py --gpus N` runs under torchrun): the communicator is built from a unique id the host broadcasts.
+//
+//   psac step (MPI through mxx)                          here
+//   ---------------------------------------------------  ----------------------------------------------------------
+//   alphabet allreduce            alphabet.hpp:98        all-gather of the 256-bin histograms, summed on the host
+//   k-mer left_shift              kmer.hpp:142           first 2k characters sent to the left rank
+//   mxx::sort (sample sort)       idxsort.hpp:60-62      regular samples -> splitters -> classify + one stable
+//                                                        partition pass -> grouped ncclSend/ncclRecv of the three record
+//                                                        arrays -> local radix sort -> exact re-balance
+//   right_shift / exscan(max)     bucketing.hpp:39,77    all-gather of boundary records and last bucket heads
+//   bulk_permute_inplace          bulk_permute.hpp:14    partition (index, value) by owner -> all-to-all -> local scatter
+//   bulk_rma / sparse_get_b2      suffix_array.hpp:972   queries to owners, answers back, un-permute
+//   bulk_rmq_v2                   par_rmq.hpp:199-332    edge sub-queries to owners + all-gathered block minima
+//
+// Exchanges run on a second HIP stream per GPU (events order them against the compute stream), so that the local
+// work which does not depend on an exchange proceeds while it is in flight.  Small per-round scalars travel in one
+// fixed-size all-gather through pinned host memory (or not at all when every rank lives in this process).
+// Ranks that share one device (dev_ids with repeats: the test configuration on a one-GPU box) exchange by
+// device-to-device copies, because RCCL refuses two ranks on one device.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is opened with dlopen when a communicator is needed
+
+#include <functional>
+
+#include "dist_ops.hpp"
+
+namespace psacx {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+
+    bool load(std::string& err) {
+        if (handle) return true;
+        // the copy PyTorch (or the host program) already mapped, else the ROCm one
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names) { handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (handle) break; }
+        for (const char* nm : names) { if (handle) break; handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); }
+        if (!handle) { err = std::string("librccl not found: ") + dlerror(); return false; }
+#define PSACX_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(handle, "nccl" #f)); if (!f) { err = "librccl lacks nccl" #f; return false; }
+        PSACX_SYM(GetUniqueId) PSACX_SYM(CommInitRank) PSACX_SYM(CommInitAll) PSACX_SYM(CommDestroy) PSACX_SYM(GroupStart)
+        PSACX_SYM(GroupEnd) PSACX_SYM(Send) PSACX_SYM(Recv) PSACX_SYM(AllGather) PSACX_SYM(GetErrorString)
+#undef PSACX_SYM
+        return true;
+    }
+};
+inline RcclApi& rccl() { static RcclApi a; return a; }
+
+struct MRank {
+    int grank = 0;
+    psacx_ctx* ctx = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    ncclComm_t comm = nullptr;
+    uint64_t* d_scal = nullptr;      // device staging of the scalar all-gather (process-per-GPU mode)
+    size_t scal_words = 0;
+};
+
+} // namespace psacx
+
+constexpr int PSACX_MULTI_EPEER = -7;     // RCCL failure
+
+struct psacx_multi {
+    int nranks = 0, nlocal = 0, first = 0;
+    bool use_rccl = false;
+    std::vector<psacx::MRank> R;
+    std::string err;
+    psacx_stats stats;
+    uint64_t bytes_sent = 0;          // payload bytes this process sent to other ranks in the last call
+    uint64_t n_exchanges = 0, n_gathers = 0;
+};
+
+namespace psacx {
+
+#define MG_HIP(g, call)                                                                   \
+    do { hipError_t e__ = (call); if (e__ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e__); return PSACX_EHIP; } } while (0)
+#define MG_NCCL(g, call)                                                                  \
+    do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (g)->err = std::string(#call) + ": " + rccl().GetErrorString(r__); return PSACX_MULTI_EPEER; } } while (0)
+#define MG_OP(g, c, call)                                                                 \
+    do { int rc__ = (call); if (rc__ != PSACX_OK) { (g)->err = std::string(#call) + ": " + psacx_strerror(rc__) + " [" + (c)->hip_err + "]"; return rc__; } } while (0)
+
+// device array owned by one rank, stream-ordered allocation on the rank's compute stream
+template <typename E> struct DBuf {
+    E* p = nullptr; uint64_t n = 0; psacx_ctx* c = nullptr;
+    DBuf() {}
+    DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; o.p = nullptr; o.n = 0; } return *this; }
+    ~DBuf() { release(); }
+    int alloc(psacx_ctx* ctx, uint64_t count) {
+        release();
+        c = ctx; n = count;
+        if (hipSetDevice(c->device) != hipSuccess) return PSACX_EHIP;
+        const size_t bytes = (size_t)(count ? count : 1) * sizeof(E);
+        hipError_t e = hipMallocAsync((void**)&p, bytes, c->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void**)&p, bytes); async_ = false; } else async_ = true;
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; c->hip_err = "device allocation failed"; return PSACX_ENOMEM; }
+        return PSACX_OK;
+    }
+    void release() {
+        if (!p) return;
+        (void)hipSetDevice(c->device);
+        if (async_) (void)hipFreeAsync(p, c->stream); else { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); }
+        p = nullptr; n = 0;
+    }
+private:
+    bool async_ = true;
+};
+
+template <typename T> struct Rec { DBuf<T> k1, k2, v; uint64_t cnt = 0; };
+
+inline std::vector<uint64_t> prefix_of(const std::vector<uint64_t>& x) {
+    std::vector<uint64_t> o(x.size() + 1, 0);
+    for (size_t i = 0; i < x.size(); ++i) o[i + 1] = o[i] + x[i];
+    return o;
+}
+
+template <typename T> __global__ void gather_at_kernel(const T* __restrict__ a, const uint64_t* __restrict__ idx, unsigned cnt, uint64_t* __restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = (uint64_t)a[idx[i]];
+}
+template <typename T> __global__ void reverse_copy_kernel(const T* __restrict__ in, uint64_t cnt, T* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = in[cnt - 1 - i];
+}
+
+template <typename T> __global__ void widen_text_kernel(const uint8_t* __restrict__ t, uint64_t cnt, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)t[i];
+}
+
+// Distributed check, per block (see MultiRun::check).  For SA position p = off + i:
+//   back[i] = ISA[SA[p]] (must be p), ch[i] = S[SA[p]], nx[i] = ISA[SA[p] + 1] (undefined when SA[p] + 1 == n).
+// Queries of the LCP recurrence: LCP[p] = 0 if the first characters differ, 1 if the smaller suffix is one character
+// long, else 1 + min(LCP[ISA[SA[p-1]+1] + 1 .. ISA[SA[p]+1]]).
+template <typename T>
+__global__ void check_queries_kernel(const T* __restrict__ SA, const T* __restrict__ ch, const T* __restrict__ nx, uint64_t cnt, uint64_t n,
+                                     int has_prev, T prev_sa, T prev_ch, T prev_nx, T* __restrict__ qlo, T* __restrict__ qhi) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        T lo = 0, hi = 1;                                   // a harmless query where none is needed
+        if (i > 0 || has_prev) {
+            const uint64_t a = i ? (uint64_t)SA[i - 1] : (uint64_t)prev_sa, b = SA[i];
+            const T ca = i ? ch[i - 1] : prev_ch, na = i ? nx[i - 1] : prev_nx;
+            if (a < n && b < n && ca == ch[i] && a + 1 < n && b + 1 < n && na < nx[i]) { lo = (T)(na + 1); hi = (T)(nx[i] + 1); }
+        }
+        qlo[i] = lo; qhi[i] = hi;
+    }
+}
+template <typename T>
+__global__ void check_verdict_kernel(const T* __restrict__ SA, const T* __restrict__ back, const T* __restrict__ ch, const T* __restrict__ nx,
+                                     const T* __restrict__ LCP, const T* __restrict__ mins, uint64_t cnt, uint64_t off, uint64_t n,
+                                     int has_prev, T prev_sa, T prev_ch, T prev_nx, unsigned long long* __restrict__ err) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned e0 = 0, e1 = 0, e2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const uint64_t b = SA[i], p = off + i;
+        if (b >= n || (uint64_t)back[i] != p) { ++e0; continue; }
+        if (p == 0) { if (LCP && LCP[0] != 0) atomicAdd(&err[3], 1ull); continue; }
+        if (i == 0 && !has_prev) continue;
+        const uint64_t a = i ? (uint64_t)SA[i - 1] : (uint64_t)prev_sa;
+        if (a >= n) continue;                               // counted where it lives
+        const T ca = i ? ch[i - 1] : prev_ch, cb = ch[i];
+        const T na = i ? nx[i - 1] : prev_nx, nb = nx[i];
+        bool ok = ca < cb;
+        if (ca == cb) ok = (a + 1 == n) || (b + 1 < n && na < nb);
+        if (!ok) { ++e1; continue; }
+        if (LCP) {
+            uint64_t want;
+            if (ca != cb) want = 0;
+            else if (a + 1 == n) want = 1;
+            else want = 1 + (uint64_t)mins[i];
+            if ((uint64_t)LCP[i] != want) ++e2;
+        }
+    }
+    e0 = wave_reduce<uint32_t>(e0, OpSum()); e1 = wave_reduce<uint32_t>(e1, OpSum()); e2 = wave_reduce<uint32_t>(e2, OpSum());
+    if (lane_id() == 0) {
+        if (e0) atomicAdd(&err[0], (unsigned long long)e0);
+        if (e1) atomicAdd(&err[1], (unsigned long long)e1);
+        if (e2) atomicAdd(&err[2], (unsigned long long)e2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct MultiRun {
+    psacx_multi* g;
+    const int P, L;
+    uint64_t n = 0;
+    std::vector<uint64_t> sizes, offs;
+    bool want_lcp = true;
+    struct St {
+        psacx_ctx* c; int r; uint64_t m, off; const uint8_t* text; T *SA, *ISA, *LCP;
+        DBuf<T> Bsa, pos;
+    };
+    std::vector<St> S;
+
+    explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal) {}
+    psacx_ctx* ctx(int i) const { return g->R[i].ctx; }
+    int rank(int i) const { return g->R[i].grank; }
+
+    // ---------------------------------------------------------------- collectives
+    // every rank contributes k words; all[r * k + j] = word j of rank r
+    int gather(int k, const std::vector<std::vector<uint64_t>>& mine, std::vector<uint64_t>& all) {
+        all.assign((size_t)P * k, 0);
+        g->n_gathers++;
+        if (L == P) {                                 // every rank lives in this process: nothing has to travel
+            for (int i = 0; i < L; ++i) std::memcpy(&all[(size_t)rank(i) * k], mine[i].data(), (size_t)k * 8);
+            return PSACX_OK;
+        }
+        RcclApi& nc = rccl();
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            if (R.scal_words < (size_t)(P + 1) * k) {
+                if (R.d_scal) { MG_HIP(g, hipStreamSynchronize(R.ctx->stream)); MG_HIP(g, hipFree(R.d_scal)); }
+                R.scal_words = (size_t)(P + 1) * k * 2;
+                MG_HIP(g, hipMalloc((void**)&R.d_scal, R.scal_words * 8));
+            }
+            MG_OP(g, R.ctx, ensure_pinned(R.ctx, (size_t)(P + 1) * k * 8 + 65536));
+            uint64_t* h = reinterpret_cast<uint64_t*>(R.ctx->pinned + 32768);
+            std::memcpy(h, mine[i].data(), (size_t)k * 8);
+            MG_HIP(g, hipMemcpyAsync(R.d_scal, h, (size_t)k * 8, hipMemcpyHostToDevice, R.ctx->stream));
+        }
+        MG_NCCL(g, nc.GroupStart());
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            MG_NCCL(g, nc.AllGather(R.d_scal, R.d_scal + k, (size_t)k, ncclUint64, R.comm, R.ctx->stream));
+        }
+        MG_NCCL(g, nc.GroupEnd());
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            uint64_t* h = reinterpret_cast<uint64_t*>(R.ctx->pinned + 32768);
+            MG_HIP(g, hipMemcpyAsync(h + k, R.d_scal + k, (size_t)P * k * 8, hipMemcpyDeviceToHost, R.ctx->stream));
+            MG_HIP(g, hipStreamSynchronize(R.ctx->stream));
+            if (i == 0) std::memcpy(all.data(), h + k, (size_t)P * k * 8);
+        }
+        return PSACX_OK;
+    }
+    int gather1(const std::vector<uint64_t>& one_per_local, std::vector<uint64_t>& all) {
+        std::vector<std::vector<uint64_t>> mine(L);
+        for (int i = 0; i < L; ++i) mine[i] = {one_per_local[i]};
+        return gather(1, mine, all);
+    }
+
+    // All-to-all of `na` arrays per rank that share one partition: elements bounds[i][d] .. bounds[i][d+1] of every
+    // array of local rank i go to rank d.  out[i][a] receives the elements ordered by source rank; rcnt[i][s] =
+    // elements received from rank s.  One exchange of the counts serves all arrays; the transfers of all arrays,
+    // ranks and peers form one RCCL group on the ranks' second streams.
+    template <typename E>
+    int exchange(int na, const std::vector<std::vector<const E*>>& in, const std::vector<std::vector<uint64_t>>& bounds,
+                 std::vector<std::vector<DBuf<E>>>& out, std::vector<std::vector<uint64_t>>& rcnt) {
+        std::vector<std::vector<uint64_t>> mine(L);
+        for (int i = 0; i < L; ++i) { mine[i].resize(P); for (int d = 0; d < P; ++d) mine[i][d] = bounds[i][d + 1] - bounds[i][d]; }
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(P, mine, all));
+        g->n_exchanges++;
+        out.clear(); out.resize(L);
+        rcnt.assign(L, std::vector<uint64_t>(P, 0));
+        std::vector<std::vector<uint64_t>> roff(L);
+        for (int i = 0; i < L; ++i) {
+            for (int s = 0; s < P; ++s) rcnt[i][s] = all[(size_t)s * P + rank(i)];
+            roff[i] = prefix_of(rcnt[i]);
+            out[i].resize(na);
+            for (int a = 0; a < na; ++a) MG_OP(g, ctx(i), out[i][a].alloc(ctx(i), roff[i][P]));
+        }
+        // the sources are complete when the compute streams reach this point; the receive buffers exist by then too
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            MG_HIP(g, hipEventRecord(R.ev_ready, R.ctx->stream));
+        }
+        if (g->use_rccl) {
+            RcclApi& nc = rccl();
+            for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(g->R[i].ctx->device)); MG_HIP(g, hipStreamWaitEvent(g->R[i].comm_stream, g->R[i].ev_ready, 0)); }
+            MG_NCCL(g, nc.GroupStart());
+            for (int i = 0; i < L; ++i) {
+                MRank& R = g->R[i];
+                for (int a = 0; a < na; ++a) {
+                    for (int d = 0; d < P; ++d) {
+                        const uint64_t sc = mine[i][d], rc = rcnt[i][d];
+                        if (d == R.grank) continue;
+                        if (sc) { MG_NCCL(g, nc.Send(in[i][a] + bounds[i][d], (size_t)sc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream)); g->bytes_sent += sc * sizeof(E); }
+                        if (rc) MG_NCCL(g, nc.Recv(out[i][a].p + roff[i][d], (size_t)rc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream));
+                    }
+                }
+            }
+            MG_NCCL(g, nc.GroupEnd());
+            for (int i = 0; i < L; ++i) {
+                MRank& R = g->R[i];
+                MG_HIP(g, hipSetDevice(R.ctx->device));
+                const uint64_t sc = mine[i][R.grank];
+                for (int a = 0; a < na && sc; ++a)
+                    MG_HIP(g, hipMemcpyAsync(out[i][a].p + roff[i][R.grank], in[i][a] + bounds[i][R.grank], (size_t)sc * sizeof(E), hipMemcpyDeviceToDevice, R.comm_stream));
+                MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream));
+                MG_HIP(g, hipStreamWaitEvent(R.ctx->stream, R.ev_done, 0));
+            }
+        } else {
+            // every rank is local (possibly several on one device): the receiver's second stream pulls each piece
+            // once the sender's compute stream has produced it
+            for (int i = 0; i < L; ++i) {
+                MRank& R = g->R[i];
+                MG_HIP(g, hipSetDevice(R.ctx->device));
+                for (int s = 0; s < L; ++s) MG_HIP(g, hipStreamWaitEvent(R.comm_stream, g->R[s].ev_ready, 0));
+                for (int s = 0; s < L; ++s) {
+                    const uint64_t rc = rcnt[i][rank(s)];
+                    if (!rc) continue;
+                    for (int a = 0; a < na; ++a)
+                        MG_HIP(g, hipMemcpyAsync(out[i][a].p + roff[i][rank(s)], in[s][a] + bounds[s][R.grank], (size_t)rc * sizeof(E), hipMemcpyDefault, R.comm_stream));
+                    if (s != i) g->bytes_sent += rc * sizeof(E) * na;
+                }
+                MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream));
+            }
+            // a sender may not release or overwrite its arrays before every receiver has pulled its piece
+            for (int i = 0; i < L; ++i) {
+                MG_HIP(g, hipSetDevice(g->R[i].ctx->device));
+                for (int s = 0; s < L; ++s) MG_HIP(g, hipStreamWaitEvent(g->R[i].ctx->stream, g->R[s].ev_done, 0));
+            }
+        }
+        return PSACX_OK;
+    }
+
+    // ---------------------------------------------------------------- small helpers
+    int fetch(int i, const T* a, const std::vector<uint64_t>& idx, std::vector<uint64_t>& out) {
+        out.assign(idx.size(), 0);
+        if (idx.empty()) return PSACX_OK;
+        psacx_ctx* c = ctx(i);
+        MG_HIP(g, hipSetDevice(c->device));
+        const size_t k = idx.size();
+        MG_OP(g, c, ensure_pinned(c, 2 * k * 8 + 65536));
+        DBuf<uint64_t> d; MG_OP(g, c, d.alloc(c, 2 * k));
+        uint64_t* h = reinterpret_cast<uint64_t*>(c->pinned + 32768);
+        std::memcpy(h, idx.data(), k * 8);
+        MG_HIP(g, hipMemcpyAsync(d.p, h, k * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL((gather_at_kernel<T>), dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, a, d.p, (unsigned)k, d.p + k);
+        MG_HIP(g, hipGetLastError());
+        MG_HIP(g, hipMemcpyAsync(h, d.p + k, k * 8, hipMemcpyDeviceToHost, c->stream));
+        MG_HIP(g, hipStreamSynchronize(c->stream));
+        std::memcpy(out.data(), h, k * 8);
+        return PSACX_OK;
+    }
+
+    // stable local sort of (k1, k2, v) by the low bits1 / bits2 bits; the arrays are replaced by the sorted ones
+    int local_sort(int i, Rec<T>& rec, unsigned bits1, unsigned bits2) {
+        psacx_ctx* c = ctx(i);
+        if (rec.cnt < 2) return PSACX_OK;
+        Rec<T> alt;
+        MG_OP(g, c, alt.k1.alloc(c, rec.cnt)); MG_OP(g, c, alt.k2.alloc(c, rec.cnt)); MG_OP(g, c, alt.v.alloc(c, rec.cnt));
+        int32_t where = 0;
+        MG_OP(g, c, op_pair_sort<T>(c, rec.k1.p, rec.k2.p, rec.v.p, alt.k1.p, alt.k2.p, alt.v.p, rec.cnt, bits1, bits2, &where));
+        if (where) { std::swap(rec.k1, alt.k1); std::swap(rec.k2, alt.k2); std::swap(rec.v, alt.v); }
+        return PSACX_OK;
+    }
+
+    // first / last record of every rank's block (has, 3 + 3 words) -> nearest non-empty neighbours of each local rank
+    int neighbours(const std::vector<const T*>& a1, const std::vector<const T*>& a2, const std::vector<const T*>& a3,
+                   const std::vector<uint64_t>& cnt, int words, std::vector<psacx_boundary>& bd) {
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(7, 0));
+        for (int i = 0; i < L; ++i) {
+            if (!cnt[i]) continue;
+            mine[i][0] = 1;
+            const T* arr[3] = {a1[i], a2[i], a3[i]};
+            for (int w = 0; w < words; ++w) {
+                std::vector<uint64_t> o;
+                PSACX_TRY(fetch(i, arr[w], {0, cnt[i] - 1}, o));
+                mine[i][1 + w] = o[0]; mine[i][4 + w] = o[1];
+            }
+        }
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(7, mine, all));
+        bd.assign(L, psacx_boundary());
+        for (int i = 0; i < L; ++i) {
+            std::memset(&bd[i], 0, sizeof(psacx_boundary));
+            const int r = rank(i);
+            for (int s = r - 1; s >= 0; --s) if (all[(size_t)s * 7]) { bd[i].has_prev = 1; for (int w = 0; w < 3; ++w) bd[i].prev[w] = all[(size_t)s * 7 + 4 + w]; break; }
+            for (int s = r + 1; s < P; ++s) if (all[(size_t)s * 7]) { bd[i].has_next = 1; for (int w = 0; w < 3; ++w) bd[i].next[w] = all[(size_t)s * 7 + 1 + w]; break; }
+        }
+        return PSACX_OK;
+    }
+
+    // ---------------------------------------------------------------- distributed primitives (see the table above)
+    // Sorts the records of all ranks by (k1, k2); rank r ends with exactly targets[r] records, the concatenation
+    // over ranks being sorted -- the contract psac needs from mxx::sort (idxsort.hpp:67-79).
+    int dist_sort(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2) {
+        if (P == 1) return local_sort(0, rec[0], bits1, bits2);
+        constexpr int SAMPLES = 256;
+        // regular samples of the local records, made unique by (rank, index) so that ties are divided
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + 3 * SAMPLES, 0));
+        for (int i = 0; i < L; ++i) {
+            const uint64_t c = rec[i].cnt;
+            std::vector<uint64_t> pos;
+            for (int s = 0; s < SAMPLES && c; ++s) { const uint64_t p = (uint64_t)(((unsigned __int128)c * (2 * s + 1)) / (2 * SAMPLES)); if (pos.empty() || pos.back() != p) pos.push_back(p); }
+            std::vector<uint64_t> a, b;
+            PSACX_TRY(fetch(i, rec[i].k1.p, pos, a));
+            PSACX_TRY(fetch(i, rec[i].k2.p, pos, b));
+            mine[i][0] = pos.size();
+            for (size_t s = 0; s < pos.size(); ++s) { mine[i][1 + 3 * s] = a[s]; mine[i][2 + 3 * s] = b[s]; mine[i][3 + 3 * s] = pos[s]; }
+        }
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(1 + 3 * SAMPLES, mine, all));
+        struct Smp { uint64_t k1, k2, r, p; bool operator<(const Smp& o) const { return k1 != o.k1 ? k1 < o.k1 : k2 != o.k2 ? k2 < o.k2 : r != o.r ? r < o.r : p < o.p; }
+                     bool operator==(const Smp& o) const { return k1 == o.k1 && k2 == o.k2 && r == o.r && p == o.p; } };
+        std::vector<Smp> flat;
+        for (int r = 0; r < P; ++r) {
+            const uint64_t* row = &all[(size_t)r * (1 + 3 * SAMPLES)];
+            for (uint64_t s = 0; s < row[0]; ++s) flat.push_back(Smp{row[1 + 3 * s], row[2 + 3 * s], (uint64_t)r, row[3 + 3 * s]});
+        }
+        std::sort(flat.begin(), flat.end());
+        std::vector<Smp> spl;
+        for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
+        std::sort(spl.begin(), spl.end());
+        spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+        const uint32_t ns = (uint32_t)spl.size();
+        std::vector<uint64_t> s1(ns + 1), s2(ns + 1), sr(ns + 1), sp(ns + 1);
+        for (uint32_t s = 0; s < ns; ++s) { s1[s] = spl[s].k1; s2[s] = spl[s].k2; sr[s] = spl[s].r; sp[s] = spl[s].p; }
+        // classify + one stable partition pass by destination
+        std::vector<Rec<T>> grp(L);
+        std::vector<std::vector<uint64_t>> bounds(L);
+        std::vector<std::vector<const T*>> in(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            const uint64_t cn = rec[i].cnt;
+            MG_OP(g, c, grp[i].k1.alloc(c, cn)); MG_OP(g, c, grp[i].k2.alloc(c, cn)); MG_OP(g, c, grp[i].v.alloc(c, cn));
+            std::vector<uint64_t> cs(ns + 2, 0);
+            MG_OP(g, c, op_split_by<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, cn, s1.data(), s2.data(), sr.data(), sp.data(), ns,
+                                      (uint64_t)rank(i), grp[i].k1.p, grp[i].k2.p, grp[i].v.p, cs.data()));
+            bounds[i].assign(P + 1, cn);
+            for (uint32_t d = 0; d <= ns; ++d) bounds[i][d] = cs[d];
+            rec[i].k1.release(); rec[i].k2.release(); rec[i].v.release();
+            in[i] = {grp[i].k1.p, grp[i].k2.p, grp[i].v.p};
+        }
+        std::vector<std::vector<DBuf<T>>> got;
+        std::vector<std::vector<uint64_t>> rc;
+        PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+        std::vector<uint64_t> c2(L);
+        for (int i = 0; i < L; ++i) {
+            grp[i] = Rec<T>();
+            rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
+            rec[i].cnt = c2[i] = rec[i].k1.n;
+            PSACX_TRY(local_sort(i, rec[i], bits1, bits2));
+        }
+        // exact re-balance: the j-th record of rank r has global index G[r] + j
+        std::vector<uint64_t> counts;
+        PSACX_TRY(gather1(c2, counts));
+        if (counts == targets) return PSACX_OK;
+        const std::vector<uint64_t> G = prefix_of(counts), TP = prefix_of(targets);
+        for (int i = 0; i < L; ++i) {
+            const uint64_t gr = G[rank(i)];
+            bounds[i].assign(P + 1, c2[i]);
+            for (int d = 0; d < P; ++d) bounds[i][d] = std::min<uint64_t>(TP[d] > gr ? TP[d] - gr : 0, c2[i]);
+            in[i] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
+        }
+        PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+        for (int i = 0; i < L; ++i) {
+            rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
+            rec[i].cnt = rec[i].k1.n;
+        }
+        return PSACX_OK;
+    }
+
+    // stable partition of global positions `gidx` and one payload array by owner rank (one radix pass over the owner word)
+    int route(int i, const T* gidx, const T* payload, uint64_t cnt, Rec<T>& out, std::vector<uint64_t>& bounds) {
+        psacx_ctx* c = ctx(i);
+        out.cnt = cnt;
+        MG_OP(g, c, out.k1.alloc(c, cnt)); MG_OP(g, c, out.k2.alloc(c, cnt)); MG_OP(g, c, out.v.alloc(c, cnt));
+        bounds.assign(P + 1, cnt);
+        bounds[0] = 0;
+        if (cnt == 0) return PSACX_OK;
+        MG_OP(g, c, psacx_op_owners(c, gidx, cnt, n, (uint32_t)P, out.k1.p));
+        MG_HIP(g, hipMemcpyAsync(out.k2.p, gidx, cnt * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        MG_HIP(g, hipMemcpyAsync(out.v.p, payload, cnt * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        PSACX_TRY(local_sort(i, out, bits_for((uint64_t)(P - 1)), 0));
+        std::vector<uint64_t> q(P), z(P, 0), lb(P), ub(P);
+        for (int d = 0; d < P; ++d) q[d] = (uint64_t)d;
+        MG_OP(g, c, op_pair_bounds<T>(c, out.k1.p, out.k1.p, cnt, q.data(), z.data(), (uint32_t)P, 0, lb.data(), ub.data()));
+        for (int d = 0; d < P; ++d) bounds[d] = lb[d];
+        return PSACX_OK;
+    }
+    static int psacx_op_owners(psacx_ctx* c, const T* gi, uint64_t cnt, uint64_t n, uint32_t P, T* out) {
+        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (owners_kernel<T>), cnt, gi, cnt, make_dist(n, P), out); return PSACX_OK;
+    }
+    static int op_take(psacx_ctx* c, const T* b, const T* gi, uint64_t cnt, uint64_t off, uint64_t n, T* o) {
+        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (take_kernel<T>), cnt, b, gi, cnt, off, n, o); return PSACX_OK;
+    }
+    static int op_put(psacx_ctx* c, T* b, const T* gi, uint64_t cnt, uint64_t off, const T* v, int64_t delta) {
+        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (put_kernel<T>), cnt, b, gi, cnt, off, v, delta); return PSACX_OK;
+    }
+
+    // block[gidx - off_owner] = vals + delta on the owner of every global position (bulk_permute.hpp:14-73)
+    int dist_put(const std::vector<T*>& block, const std::vector<const T*>& gidx, const std::vector<const T*>& vals,
+                 const std::vector<uint64_t>& cnt, int64_t delta, bool permutation) {
+        std::vector<Rec<T>> routed(L);
+        std::vector<std::vector<DBuf<T>>> got;
+        std::vector<const T*> gi(L), vi(L);
+        std::vector<uint64_t> rc_tot(L);
+        if (P == 1) { gi[0] = gidx[0]; vi[0] = vals[0]; rc_tot[0] = cnt[0]; }
+        else {
+            std::vector<std::vector<uint64_t>> bounds(L), rc;
+            std::vector<std::vector<const T*>> in(L);
+            for (int i = 0; i < L; ++i) { PSACX_TRY(route(i, gidx[i], vals[i], cnt[i], routed[i], bounds[i])); in[i] = {routed[i].k2.p, routed[i].v.p}; }
+            PSACX_TRY(exchange<T>(2, in, bounds, got, rc));
+            for (int i = 0; i < L; ++i) { gi[i] = got[i][0].p; vi[i] = got[i][1].p; rc_tot[i] = got[i][0].n; }
+        }
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            if (permutation && delta == -1 && rc_tot[i]) {
+                DBuf<T> s[4];
+                for (int q = 0; q < 4; ++q) MG_OP(g, c, s[q].alloc(c, rc_tot[i]));
+                MG_OP(g, c, op_put_perm<T>(c, block[i], gi[i], rc_tot[i], S[i].off, vi[i], s[0].p, s[1].p, s[2].p, s[3].p));
+            } else MG_OP(g, c, op_put(c, block[i], gi[i], rc_tot[i], S[i].off, vi[i], delta));
+        }
+        return PSACX_OK;
+    }
+
+    // out[i][j] = block_owner[gidx[i][j] - off_owner] in the order of gidx (bulk_rma.hpp:13-135); positions >= n are clamped
+    int dist_take(const std::vector<const T*>& block, const std::vector<const T*>& gidx, const std::vector<uint64_t>& cnt,
+                  std::vector<DBuf<T>>& out) {
+        out.clear(); out.resize(L);
+        if (P == 1) {
+            MG_OP(g, ctx(0), out[0].alloc(ctx(0), cnt[0]));
+            MG_OP(g, ctx(0), op_take(ctx(0), block[0], gidx[0], cnt[0], S[0].off, n, out[0].p));
+            return PSACX_OK;
+        }
+        std::vector<Rec<T>> routed(L);
+        std::vector<std::vector<uint64_t>> bounds(L), rc, rc2;
+        std::vector<std::vector<const T*>> in(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            DBuf<T> idx; MG_OP(g, c, idx.alloc(c, cnt[i]));
+            MG_OP(g, c, psacx_op_iota(c, idx.p, cnt[i], 0));
+            PSACX_TRY(route(i, gidx[i], idx.p, cnt[i], routed[i], bounds[i]));
+            in[i] = {routed[i].k2.p};
+        }
+        std::vector<std::vector<DBuf<T>>> q, got;
+        PSACX_TRY(exchange<T>(1, in, bounds, q, rc));
+        std::vector<DBuf<T>> ans(L);
+        std::vector<std::vector<uint64_t>> back_bounds(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, ans[i].alloc(c, q[i][0].n));
+            MG_OP(g, c, op_take(c, block[i], q[i][0].p, q[i][0].n, S[i].off, n, ans[i].p));
+            back_bounds[i] = prefix_of(rc[i]);
+            in[i] = {ans[i].p};
+        }
+        PSACX_TRY(exchange<T>(1, in, back_bounds, got, rc2));
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, out[i].alloc(c, cnt[i]));
+            MG_OP(g, c, op_put(c, out[i].p, routed[i].v.p, cnt[i], 0, got[i][0].p, 0));      // undo the routing permutation
+        }
+        return PSACX_OK;
+    }
+    static int psacx_op_iota(psacx_ctx* c, T* out, uint64_t m, uint64_t start) {
+        OP_PROLOGUE(c); SIMPLE_LAUNCH(c, (iota_from_kernel<T>), m, out, m, start); return PSACX_OK;
+    }
+
+    // min(LCP[lo .. hi)) over the block-distributed LCP array for every query (bulk_rmq_v2, par_rmq.hpp:199-332)
+    int dist_range_min(const std::vector<const T*>& lo, const std::vector<const T*>& hi, const std::vector<uint64_t>& cnt,
+                       std::vector<DBuf<T>>& out) {
+        out.clear(); out.resize(L);
+        if (P == 1) {
+            MG_OP(g, ctx(0), out[0].alloc(ctx(0), cnt[0]));
+            MG_OP(g, ctx(0), op_range_min<T>(ctx(0), S[0].LCP, S[0].m, lo[0], hi[0], cnt[0], S[0].off, out[0].p));
+            return PSACX_OK;
+        }
+        std::vector<uint64_t> bm(L), mins;
+        for (int i = 0; i < L; ++i) MG_OP(g, ctx(i), op_block_min<T>(ctx(i), S[i].LCP, S[i].m, &bm[i]));
+        PSACX_TRY(gather1(bm, mins));
+        // own1/lo1/hi1: the part inside the rank of lo; own2/lo2/hi2: the part inside the rank of hi - 1; ra/rb: whole ranks between
+        std::vector<std::vector<DBuf<T>>> parts(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            parts[i].resize(8);
+            for (int q = 0; q < 8; ++q) MG_OP(g, c, parts[i][q].alloc(c, cnt[i]));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (rmq_split_kernel<T>), cnt[i], lo[i], hi[i], cnt[i], make_dist(n, (unsigned)P), parts[i][0].p, parts[i][1].p, parts[i][2].p,
+                          parts[i][3].p, parts[i][4].p, parts[i][5].p, parts[i][6].p, parts[i][7].p);
+        }
+        std::vector<std::vector<DBuf<T>>> answers(2);
+        for (int half = 0; half < 2; ++half) {
+            std::vector<Rec<T>> ra(L), rb(L);
+            std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
+            std::vector<std::vector<const T*>> in(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                const T* own = parts[i][3 * half].p; const T* a = parts[i][3 * half + 1].p; const T* b = parts[i][3 * half + 2].p;
+                // route by owner: (owner, a, b) and (owner, a, slot) through the same stable pass
+                ra[i].cnt = rb[i].cnt = cnt[i];
+                MG_OP(g, c, ra[i].k1.alloc(c, cnt[i])); MG_OP(g, c, ra[i].k2.alloc(c, cnt[i])); MG_OP(g, c, ra[i].v.alloc(c, cnt[i]));
+                MG_OP(g, c, rb[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rb[i].k2.alloc(c, cnt[i])); MG_OP(g, c, rb[i].v.alloc(c, cnt[i]));
+                if (cnt[i]) {
+                    MG_HIP(g, hipMemcpyAsync(ra[i].k1.p, own, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(ra[i].k2.p, a, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(ra[i].v.p, b, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(rb[i].k1.p, own, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(rb[i].k2.p, a, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_OP(g, c, psacx_op_iota(c, rb[i].v.p, cnt[i], 0));
+                }
+                PSACX_TRY(local_sort(i, ra[i], bits_for((uint64_t)(P - 1)), 0));
+                PSACX_TRY(local_sort(i, rb[i], bits_for((uint64_t)(P - 1)), 0));
+                bounds[i].assign(P + 1, cnt[i]); bounds[i][0] = 0;
+                if (cnt[i]) {
+                    std::vector<uint64_t> q(P), z(P, 0), lb(P), ub(P);
+                    for (int d = 0; d < P; ++d) q[d] = (uint64_t)d;
+                    MG_OP(g, c, op_pair_bounds<T>(c, ra[i].k1.p, ra[i].k1.p, cnt[i], q.data(), z.data(), (uint32_t)P, 0, lb.data(), ub.data()));
+                    for (int d = 0; d < P; ++d) bounds[i][d] = lb[d];
+                }
+                in[i] = {ra[i].k2.p, ra[i].v.p};
+            }
+            std::vector<std::vector<DBuf<T>>> q, got;
+            PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
+            std::vector<DBuf<T>> res(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, res[i].alloc(c, q[i][0].n));
+                MG_OP(g, c, op_range_min<T>(c, S[i].LCP, S[i].m, q[i][0].p, q[i][1].p, q[i][0].n, S[i].off, res[i].p));
+                b2[i] = prefix_of(rc[i]);
+                in[i] = {res[i].p};
+            }
+            PSACX_TRY(exchange<T>(1, in, b2, got, rc2));
+            answers[half].resize(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, answers[half][i].alloc(c, cnt[i]));
+                MG_OP(g, c, op_put(c, answers[half][i].p, rb[i].v.p, cnt[i], 0, got[i][0].p, 0));
+            }
+        }
+        RankMins rm;
+        for (int r = 0; r < 64; ++r) rm.v[r] = r < P ? mins[r] : ~0ull;
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, out[i].alloc(c, cnt[i]));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (rmq_combine_kernel<T>), cnt[i], answers[0][i].p, answers[1][i].p, parts[i][6].p, parts[i][7].p, cnt[i], rm, out[i].p);
+        }
+        return PSACX_OK;
+    }
+
+    // ---------------------------------------------------------------- the construction (suffix_array.hpp:365-466, :1032-1285)
+    int construct(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, uint32_t k_req, uint32_t flags,
+                  const std::vector<T*>& d_sa, const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp) {
+        want_lcp = (flags & PSACX_LCP) != 0;
+        psacx_stats& st = g->stats;
+        std::memset(&st, 0, sizeof(st));
+        g->bytes_sent = 0; g->n_exchanges = 0; g->n_gathers = 0;
+        S.resize(L);
+        for (int i = 0; i < L; ++i) {
+            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
+            S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = want_lcp ? d_lcp[i] : nullptr;
+            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+        }
+        // sizes + alphabet (alphabet.hpp:98: allreduce of the character histograms)
+        {
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(257, 0));
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                DBuf<uint64_t> h; MG_OP(g, c, h.alloc(c, 256));
+                MG_OP(g, c, psacx_op_char_hist(c, text[i], S[i].m, h.p));
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, h.p, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                mine[i][0] = S[i].m;
+                std::memcpy(&mine[i][1], c->pinned + 32768, 256 * 8);
+            }
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather(257, mine, all));
+            sizes.assign(P, 0);
+            uint64_t hist[256] = {0};
+            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 257]; for (int ch = 0; ch < 256; ++ch) hist[ch] += all[(size_t)r * 257 + 1 + ch]; }
+            offs = prefix_of(sizes);
+            n = offs[P];
+            for (int r = 0; r < P; ++r)            // suffix_array.hpp:226-227
+                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
+            for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
+            if (n == 0) return PSACX_EINVAL;
+            if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
+            uint32_t sigma = 0;
+            for (int ch = 0; ch < 256; ++ch) sigma += hist[ch] != 0;
+            uint32_t l = 0; while ((1u << l) < sigma + 1u) ++l;
+            st.sigma = sigma; st.bits_per_char = l;
+            for (int ch = 0, nx = 0; ch < 256; ++ch) codes_[ch] = hist[ch] ? (uint16_t)(nx++) : (uint16_t)0;   // packed codes 0..sigma-1
+        }
+        const uint32_t l = st.bits_per_char;
+        const uint32_t word_bits = (uint32_t)sizeof(T) * 8;
+        uint64_t min_local = sizes[0];
+        for (int r = 1; r < P; ++r) min_local = std::min(min_local, sizes[r]);
+        uint32_t k;                                    // kmer.hpp:26-40
+        {
+            const uint32_t max_k = word_bits / l;
+            k = (k_req == 0 || k_req > max_k) ? max_k : k_req;
+            if ((uint64_t)k >= min_local) { k = (uint32_t)min_local; if (P == 1 && k > 1) --k; }
+        }
+        st.k = k;
+        const uint32_t two_k = 2 * k;
+        if (P > 1 && min_local < two_k) { g->err = "text blocks shorter than 2k characters are not supported with more than one rank"; return PSACX_EINVAL; }
+        // the 2k-character window packed without an end-marker code (key_pairs_kernel): lc bits per character
+        uint32_t lc = 0; while ((1u << lc) < st.sigma) ++lc; if (!lc) lc = 1;
+        const uint32_t c1 = std::min<uint32_t>(two_k, word_bits / lc), c2 = two_k - c1;
+
+        // ---- halo: the first 2k characters of the right neighbour (kmer.hpp:142)
+        std::vector<DBuf<uint8_t>> tbuf(L);
+        {
+            std::vector<std::vector<DBuf<uint8_t>>> got;
+            if (P > 1) {
+                std::vector<std::vector<uint64_t>> bounds(L), rc;
+                std::vector<std::vector<const uint8_t*>> in(L);
+                for (int i = 0; i < L; ++i) {
+                    const int r = rank(i);
+                    bounds[i].assign(P + 1, 0);
+                    // the piece [0, 2k) goes to rank r - 1: destinations < r - 1 get nothing, r - 1 gets 2k
+                    for (int d = 0; d <= P; ++d) bounds[i][d] = (r > 0 && d >= r) ? two_k : 0;
+                    in[i] = {text[i]};
+                }
+                PSACX_TRY(exchange<uint8_t>(1, in, bounds, got, rc));
+            }
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, tbuf[i].alloc(c, S[i].m + two_k));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(tbuf[i].p + S[i].m, 0, two_k, c->stream));
+                MG_HIP(g, hipMemcpyAsync(tbuf[i].p, text[i], S[i].m, hipMemcpyDeviceToDevice, c->stream));
+                if (P > 1 && got[i][0].n) MG_HIP(g, hipMemcpyAsync(tbuf[i].p + S[i].m, got[i][0].p, std::min<uint64_t>(got[i][0].n, two_k), hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        // ---- first-round keys; the suffixes shorter than 2k (the last 2k - 1 positions) are moved to the very front
+        //      of the record order (rank 0, shortest first): see key_pairs_kernel for why that replaces the end marker
+        const uint64_t spec = std::min<uint64_t>(two_k - 1, n);
+        std::vector<Rec<T>> rec(L);
+        {
+            std::vector<Rec<T>> tails(L);
+            std::vector<uint64_t> mine_cnt(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
+                MG_OP(g, c, rec[i].k1.alloc(c, front + m)); MG_OP(g, c, rec[i].k2.alloc(c, front + m)); MG_OP(g, c, rec[i].v.alloc(c, front + m));
+                MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, rec[i].k2.p + front));
+                MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));
+                const uint64_t end = S[i].off + m, first_short = n - spec;
+                const uint64_t mine = std::min<uint64_t>(m, end > first_short ? end - first_short : 0);     // short suffixes in this block (its tail)
+                mine_cnt[i] = mine;
+                tails[i].cnt = mine;
+                MG_OP(g, c, tails[i].k1.alloc(c, mine)); MG_OP(g, c, tails[i].k2.alloc(c, mine)); MG_OP(g, c, tails[i].v.alloc(c, mine));
+                if (mine) {
+                    const T* src[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p}; T* dst[3] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p};
+                    for (int q = 0; q < 3; ++q) {
+                        hipLaunchKernelGGL((reverse_copy_kernel<T>), dim3((unsigned)((mine + 255) / 256)), dim3(256), 0, c->stream, src[q] + front + m - mine, mine, dst[q]);
+                        MG_HIP(g, hipGetLastError());
+                    }
+                }
+                rec[i].cnt = front + m - mine;
+            }
+            tbuf.clear();
+            // everything to rank 0, which places the pieces of higher ranks first
+            std::vector<std::vector<DBuf<T>>> got;
+            std::vector<std::vector<uint64_t>> rc;
+            if (P > 1) {
+                std::vector<std::vector<uint64_t>> bounds(L);
+                std::vector<std::vector<const T*>> in(L);
+                for (int i = 0; i < L; ++i) { bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0; in[i] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p}; }
+                PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+            }
+            for (int i = 0; i < L; ++i) {
+                if (rank(i) != 0) continue;
+                psacx_ctx* c = ctx(i);
+                MG_HIP(g, hipSetDevice(c->device));
+                T* dst[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
+                if (P == 1) {
+                    const T* src[3] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p};
+                    for (int q = 0; q < 3 && spec; ++q) MG_HIP(g, hipMemcpyAsync(dst[q], src[q], spec * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                } else {
+                    const std::vector<uint64_t> cuts = prefix_of(rc[i]);
+                    uint64_t at = 0;
+                    for (int s = P - 1; s >= 0; --s) {
+                        const uint64_t len = rc[i][s];
+                        for (int q = 0; q < 3 && len; ++q) MG_HIP(g, hipMemcpyAsync(dst[q] + at, got[i][q].p + cuts[s], len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                        at += len;
+                    }
+                }
+            }
+            // (the pieces are consumed before `got` and `tails` go out of scope: stream order)
+        }
+        PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc));
+
+        // ---- LCP of the 2k-mers, bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
+        std::vector<psacx_boundary> bd;
+        {
+            std::vector<const T*> a1(L), a2(L), a3(L); std::vector<uint64_t> cn(L);
+            for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; cn[i] = rec[i].cnt; }
+            PSACX_TRY(neighbours(a1, a2, a3, cn, 3, bd));
+        }
+        std::vector<uint64_t> lh(L), heads;
+        for (int i = 0; i < L; ++i) {
+            bd[i].off = S[i].off; bd[i].base = 0;
+            psacx_boundary b0 = bd[i]; b0.has_next = 0;
+            MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 0, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &b0, &lh[i]));
+        }
+        PSACX_TRY(gather1(lh, heads));
+        std::vector<uint64_t> nact(L), nunf(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            uint64_t base = 0;
+            for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
+            bd[i].base = base;
+            MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m));
+            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], S[i].Bsa.p, S[i].LCP, &nact[i], &nunf[i]));
+            MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            rec[i] = Rec<T>();
+        }
+        // ---- SA -> ISA (bulk_permute.hpp:14-73), overlapped on the second streams with the bookkeeping below
+        {
+            std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L); std::vector<uint64_t> cn(L);
+            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; va[i] = S[i].Bsa.p; cn[i] = S[i].m; }
+            PSACX_TRY(dist_put(blk, gi, va, cn, -1, true));
+        }
+        uint64_t unf_b = 0, unf_e = 0;
+        PSACX_TRY(next_active(nullptr, nact, nunf, &unf_b, &unf_e));
+        st.rounds[0].h = k; st.rounds[0].active = n; st.rounds[0].unfinished_buckets = unf_b; st.rounds[0].unfinished_elements = unf_e;
+        st.n_rounds = 1;
+
+        const unsigned id_bits = bits_for(n);
+        for (uint64_t h = two_k; unf_b > 0 && h < n; h <<= 1) {
+            std::vector<uint64_t> cnt(L), counts;
+            for (int i = 0; i < L; ++i) cnt[i] = S[i].pos.n;
+            PSACX_TRY(gather1(cnt, counts));
+            // B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
+            std::vector<DBuf<T>> q(L);
+            rec.clear(); rec.resize(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                rec[i].cnt = cnt[i];
+                MG_OP(g, c, rec[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rec[i].v.alloc(c, cnt[i])); MG_OP(g, c, q[i].alloc(c, cnt[i]));
+                MG_OP(g, c, op_take(c, S[i].SA, S[i].pos.p, cnt[i], S[i].off, n, rec[i].v.p));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], rec[i].v.p, cnt[i], h, n, q[i].p);      // saturates at n
+                MG_OP(g, c, op_take(c, S[i].Bsa.p, S[i].pos.p, cnt[i], S[i].off, n, rec[i].k1.p));
+            }
+            {
+                std::vector<const T*> blk(L), gi(L);
+                for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q[i].p; }
+                std::vector<DBuf<T>> ans;
+                PSACX_TRY(dist_take(blk, gi, cnt, ans));
+                for (int i = 0; i < L; ++i) {
+                    psacx_ctx* c = ctx(i);
+                    MG_OP(g, c, rec[i].k2.alloc(c, cnt[i]));
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
+                }
+            }
+            q.clear();
+            PSACX_TRY(dist_sort(rec, counts, id_bits, id_bits));
+            {
+                std::vector<const T*> a1(L), a2(L), a3(L);
+                for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; }
+                PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
+            }
+            for (int i = 0; i < L; ++i) {
+                bd[i].off = 0; bd[i].base = 0;
+                psacx_boundary b0 = bd[i]; b0.has_next = 0;
+                MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 1, rec[i].k1.p, rec[i].k2.p, S[i].pos.p, cnt[i], 0, 1, 1, 0, &b0, &lh[i]));
+            }
+            PSACX_TRY(gather1(lh, heads));
+            std::vector<DBuf<T>> ids(L), qa(L), ql(L), qh(L);
+            std::vector<uint64_t> nq(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                uint64_t base = 0;
+                for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
+                bd[i].off = S[i].off; bd[i].base = base;
+                MG_OP(g, c, ids[i].alloc(c, cnt[i])); MG_OP(g, c, qa[i].alloc(c, cnt[i])); MG_OP(g, c, ql[i].alloc(c, cnt[i])); MG_OP(g, c, qh[i].alloc(c, cnt[i]));
+                MG_OP(g, c, op_rebucket_refine<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, S[i].pos.p, cnt[i], n, h, &bd[i], S[i].SA, S[i].Bsa.p,
+                                                  S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i]));
+            }
+            {
+                std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L);
+                for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = rec[i].v.p; va[i] = ids[i].p; }
+                PSACX_TRY(dist_put(blk, gi, va, cnt, -1, false));
+            }
+            if (want_lcp) {
+                std::vector<const T*> lo(L), hi(L);
+                for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
+                std::vector<DBuf<T>> mins;
+                PSACX_TRY(dist_range_min(lo, hi, nq, mins));
+                for (int i = 0; i < L; ++i) {
+                    psacx_ctx* c = ctx(i);
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
+                }
+            }
+            rec.clear(); rec.resize(L);
+            PSACX_TRY(next_active(&ids, nact, nunf, &unf_b, &unf_e));
+            if (st.n_rounds < PSACX_MAX_ROUNDS) {
+                psacx_round& rr = st.rounds[st.n_rounds++];
+                std::memset(&rr, 0, sizeof(rr));
+                rr.h = h; rr.unfinished_buckets = unf_b; rr.unfinished_elements = unf_e;
+                for (int r = 0; r < P; ++r) rr.active += counts[r];
+            }
+        }
+        for (int i = 0; i < L; ++i) {
+            S[i].Bsa.release(); S[i].pos.release();
+            MG_HIP(g, hipSetDevice(ctx(i)->device));
+            MG_HIP(g, hipStreamSynchronize(ctx(i)->stream));
+        }
+        return PSACX_OK;
+    }
+
+    // Distributed verification of block-distributed SA / ISA / LCP without gathering anything on one rank: what
+    // d_check_sa does (check_suffix_array.hpp:207-267: SA a permutation whose inverse is ISA, S[SA[i-1]] <= S[SA[i]],
+    // ties decided by the ranks of the suffixes one further) with the engine's own exchanges (bulk_rma for
+    // ISA[SA[i]], S[SA[i]], ISA[SA[i]+1]), plus the LCP array through its recurrence
+    //   LCP[i] = 0 | 1 | 1 + min(LCP[ISA[SA[i-1]+1]+1 .. ISA[SA[i]+1]])      (range minima: bulk_rmq_v2)
+    // which has the true LCP array as its only solution.  errors[0..3] as psacx_check_dev_*, summed over all ranks.
+    int check(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
+              const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp, bool with_lcp, uint64_t errors[4]) {
+        want_lcp = with_lcp;
+        S.resize(L);
+        for (int i = 0; i < L; ++i) {
+            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
+            S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = with_lcp ? d_lcp[i] : nullptr;
+            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+        }
+        {
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather1(m_local, all));
+            sizes = all; offs = prefix_of(sizes); n = offs[P];
+            for (int r = 0; r < P; ++r)
+                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
+            for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
+            if (n == 0) return PSACX_EINVAL;
+        }
+        std::vector<uint64_t> cnt(L);
+        std::vector<const T*> blk(L), gi(L);
+        std::vector<DBuf<T>> wide(L), q1(L), back, ch, nx;
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            cnt[i] = S[i].m;
+            MG_OP(g, c, wide[i].alloc(c, S[i].m)); MG_OP(g, c, q1[i].alloc(c, S[i].m));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
+            SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), S[i].m, S[i].SA, S[i].m, (uint64_t)1, n, q1[i].p);
+        }
+        for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; }
+        PSACX_TRY(dist_take(blk, gi, cnt, back));
+        for (int i = 0; i < L; ++i) { blk[i] = wide[i].p; }
+        PSACX_TRY(dist_take(blk, gi, cnt, ch));
+        for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q1[i].p; }
+        PSACX_TRY(dist_take(blk, gi, cnt, nx));
+        wide.clear(); q1.clear();
+        std::vector<psacx_boundary> bd;
+        {
+            std::vector<const T*> a1(L), a2(L), a3(L);
+            for (int i = 0; i < L; ++i) { a1[i] = S[i].SA; a2[i] = ch[i].p; a3[i] = nx[i].p; }
+            PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
+        }
+        std::vector<DBuf<T>> mins;
+        if (with_lcp) {
+            std::vector<DBuf<T>> qlo(L), qhi(L);
+            std::vector<const T*> lo(L), hi(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, qlo[i].alloc(c, cnt[i])); MG_OP(g, c, qhi[i].alloc(c, cnt[i]));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (check_queries_kernel<T>), cnt[i], S[i].SA, ch[i].p, nx[i].p, cnt[i], n, bd[i].has_prev, (T)bd[i].prev[0],
+                              (T)bd[i].prev[1], (T)bd[i].prev[2], qlo[i].p, qhi[i].p);
+                lo[i] = qlo[i].p; hi[i] = qhi[i].p;
+            }
+            PSACX_TRY(dist_range_min(lo, hi, cnt, mins));
+        }
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(4, 0));
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            DBuf<unsigned long long> e; MG_OP(g, c, e.alloc(c, 4));
+            MG_HIP(g, hipMemsetAsync(e.p, 0, 32, c->stream));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (check_verdict_kernel<T>), cnt[i], S[i].SA, back[i].p, ch[i].p, nx[i].p, (const T*)S[i].LCP,
+                          with_lcp ? (const T*)mins[i].p : (const T*)nullptr, cnt[i], S[i].off, n, bd[i].has_prev, (T)bd[i].prev[0], (T)bd[i].prev[1],
+                          (T)bd[i].prev[2], e.p);
+            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, e.p, 32, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            std::memcpy(mine[i].data(), c->pinned + 32768, 32);
+        }
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(4, mine, all));
+        for (int q = 0; q < 4; ++q) { errors[q] = 0; for (int r = 0; r < P; ++r) errors[q] += all[(size_t)r * 4 + q]; }
+        return PSACX_OK;
+    }
+
+    // boundary bucket ids of every block, the list of positions that still share a bucket (suffix_array.hpp:925-965)
+    // and the global counters.  ids == nullptr: first round (ids = Bsa, every position is a list entry).
+    int next_active(std::vector<DBuf<T>>* ids, const std::vector<uint64_t>& nact, const std::vector<uint64_t>& nunf, uint64_t* unf_b, uint64_t* unf_e) {
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(5, 0));
+        std::vector<uint64_t> cnt(L);
+        for (int i = 0; i < L; ++i) {
+            const T* a = ids ? (*ids)[i].p : S[i].Bsa.p;
+            cnt[i] = ids ? (*ids)[i].n : S[i].m;
+            if (cnt[i]) {
+                std::vector<uint64_t> o;
+                PSACX_TRY(fetch(i, a, {0, cnt[i] - 1}, o));
+                mine[i][0] = 1; mine[i][1] = o[0]; mine[i][2] = o[1];
+            }
+            mine[i][3] = nact[i]; mine[i][4] = nunf[i];
+        }
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(5, mine, all));
+        *unf_b = *unf_e = 0;
+        for (int r = 0; r < P; ++r) { *unf_e += all[(size_t)r * 5 + 3]; *unf_b += all[(size_t)r * 5 + 4]; }
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            const int r = rank(i);
+            uint64_t pid = 0, nid = 0;
+            for (int s = r - 1; s >= 0; --s) if (all[(size_t)s * 5]) { pid = all[(size_t)s * 5 + 2]; break; }
+            for (int s = r + 1; s < P; ++s) if (all[(size_t)s * 5]) { nid = all[(size_t)s * 5 + 1]; break; }
+            DBuf<T> out; MG_OP(g, c, out.alloc(c, cnt[i]));
+            uint64_t kept = 0;
+            MG_OP(g, c, op_compact<T>(c, ids ? (*ids)[i].p : S[i].Bsa.p, ids ? S[i].pos.p : (const T*)nullptr, cnt[i], S[i].off, pid, nid, out.p, &kept));
+            DBuf<T> trimmed; MG_OP(g, c, trimmed.alloc(c, kept));
+            if (kept) MG_HIP(g, hipMemcpyAsync(trimmed.p, out.p, kept * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            S[i].pos = std::move(trimmed);
+        }
+        return PSACX_OK;
+    }
+
+    uint16_t codes_[256];
+};
+
+} // namespace psacx

@@ -54,11 +54,14 @@ __device__ __forceinline__ uint64_t nsv_search(const Pyramid<T>& P, uint64_t i, 
 // ---- wave-cooperative forms: all 64 lanes of the calling wave take part, arguments are wave-uniform.
 // One step looks at a whole 64-entry group with one coalesced load and one ballot, so a search costs a
 // handful of memory round trips instead of one per entry walked.
+// skip: the caller knows that the groups of `pos` on the first `skip` levels hold nothing on the searched side
+// (pos is the edge element of an aligned tile), the walk starts above them
 template <typename T, bool LEFT>
-__device__ __forceinline__ uint64_t nsv_search_wave(const Pyramid<T>& P, uint64_t pos, T v, bool strict) {
+__device__ __forceinline__ uint64_t nsv_search_wave(const Pyramid<T>& P, uint64_t pos, T v, bool strict, int skip = 0) {
     const unsigned lane = lane_id();
     uint64_t p = pos, j = 0;
     int L = 0;
+    while (L < skip && L + 1 < P.nlev) { p >>= 6; ++L; }
     for (;;) {
         const T* a = P.lvl[L];
         const uint64_t len = P.len[L];

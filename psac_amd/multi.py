@@ -1,0 +1,116 @@
+"""Python mirror of the multi-GPU boundary (psacx_multi_* in include/psacx.h): suffix_array<> on p ranks, one GPU each.
+
+Two deployments, as in the C ABI:
+  MultiContext(dev_ids)                 one process drives all GPUs (ranks 0..p-1); a device listed several times carries
+                                        several ranks (the tests' way of running p ranks on a one-GPU box)
+  MultiContext.for_rank(rank, p, device, unique_id)
+                                        one process per GPU (psac's own model; what bench.py runs under torchrun)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PSACX_LCP, PsacxError, Stats
+
+
+def unique_id():
+    """128 bytes identifying a new communicator; make it on one process and broadcast it to the others."""
+    buf = (C.c_uint8 * 128)()
+    rc = _lib.load().psacx_multi_unique_id(buf)
+    if rc != 0:
+        raise PsacxError(rc, "psacx_multi_unique_id failed (librccl not available?)")
+    return bytes(buf)
+
+
+class MultiContext(object):
+    def __init__(self, dev_ids=None, ndev=None, _handle=None):
+        self._lib = _lib.load()
+        if _handle is not None:
+            self.handle = _handle
+        else:
+            if dev_ids is None:
+                dev_ids = list(range(int(ndev)))
+            arr = (C.c_int * len(dev_ids))(*[int(d) for d in dev_ids])
+            h = C.c_void_p()
+            rc = self._lib.psacx_multi_create(C.byref(h), len(dev_ids), arr)
+            if rc != 0:
+                raise PsacxError(rc, self._lib.psacx_strerror(rc).decode())
+            self.handle = h
+        self.nranks = self._lib.psacx_multi_nranks(self.handle)
+        self.nlocal = self._lib.psacx_multi_nlocal(self.handle)
+        self.uses_rccl = bool(self._lib.psacx_multi_uses_rccl(self.handle))
+
+    @classmethod
+    def for_rank(cls, rank, nranks, device, uid):
+        lib = _lib.load()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128)(*bytearray(uid)) if uid is not None else None
+        rc = lib.psacx_multi_create_rank(C.byref(h), int(rank), int(nranks), int(device), buf)
+        if rc != 0:
+            raise PsacxError(rc, "psacx_multi_create_rank: %s" % lib.psacx_strerror(rc).decode())
+        return cls(_handle=h)
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self._lib.psacx_strerror(rc).decode() if rc > -7 else "RCCL failure"
+            det = self._lib.psacx_multi_last_error(self.handle).decode()
+            raise PsacxError(rc, msg + (" [" + det + "]" if det else ""))
+
+    def rank_ctx(self, i):
+        """psacx_ctx handle of local rank i (device memory helpers psacx_dev_alloc / psacx_copy_* take it)."""
+        return C.c_void_p(self._lib.psacx_multi_ctx(self.handle, int(i)))
+
+    def stats(self):
+        s = Stats()
+        sent, ex, ga = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.check(self._lib.psacx_multi_get_stats(self.handle, C.byref(s), C.byref(sent), C.byref(ex), C.byref(ga)))
+        return s, sent.value, ex.value, ga.value
+
+    def construct(self, text, index_bits=64, lcp=True, k=0):
+        """suffix_array<char, index_t, LCP>::construct on p ranks, the whole text and results on this host
+        (needs every rank in this process).  Returns (SA, ISA, LCP or None, rounds)."""
+        if isinstance(text, str):
+            text = text.encode("latin-1")
+        t = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        n = int(t.size)
+        dt = np.uint32 if index_bits == 32 else np.uint64
+        SA = np.empty(n, dt); ISA = np.empty(n, dt); LCP = np.empty(n, dt) if lcp else None
+        fn = getattr(self._lib, "psacx_multi_construct_u%d" % index_bits)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.check(fn(self.handle, p(t), n, int(k), PSACX_LCP if lcp else 0, p(SA), p(ISA), p(LCP) if lcp else None))
+        s = self.stats()[0]
+        rounds = [(r.h, r.unfinished_buckets, r.unfinished_elements) for r in s.rounds[:s.n_rounds]]
+        return SA, ISA, LCP, rounds
+
+    def construct_device(self, d_text, m, d_sa, d_isa, d_lcp, index_bits, k=0):
+        """Blocks resident in HBM: lists (one entry per local rank) of raw device addresses and block lengths."""
+        L = self.nlocal
+        vp = C.c_void_p * L
+        mm = (C.c_uint64 * L)(*[int(x) for x in m])
+        fn = getattr(self._lib, "psacx_multi_construct_dev_u%d" % index_bits)
+        lcp_arr = vp(*d_lcp) if d_lcp is not None else None
+        self.check(fn(self.handle, vp(*d_text), mm, int(k), PSACX_LCP if d_lcp is not None else 0, vp(*d_sa), vp(*d_isa), lcp_arr))
+        return self.stats()
+
+    def check_device(self, d_text, m, d_sa, d_isa, d_lcp, index_bits):
+        """Distributed d_check_sa (+ LCP recurrence) over blocks resident in HBM; returns the four error counters
+        summed over all ranks (all zero = correct)."""
+        L = self.nlocal
+        vp = C.c_void_p * L
+        mm = (C.c_uint64 * L)(*[int(x) for x in m])
+        err = (C.c_uint64 * 4)()
+        fn = getattr(self._lib, "psacx_multi_check_dev_u%d" % index_bits)
+        self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_isa), vp(*d_lcp) if d_lcp is not None else None, err))
+        return list(err)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.psacx_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
