@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=None, help="characters per GPU (default: 2^32 at one GPU, 2^28 per GPU otherwise)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="characters per GPU (default: 2^32 at one GPU, 2^28 per GPU otherwise)")
     ap.add_argument("--index", type=int, default=None, choices=(32, 64), help="index width (default: 64 above 2^31 characters)")
     ap.add_argument("--alphabet", default="dna", choices=("dna", "ascii128", "tandem"))
     ap.add_argument("--seed", type=int, default=1)

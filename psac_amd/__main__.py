@@ -96,45 +96,59 @@ def main(argv=None):
         barrier = lambda: None
         gathered = (text, SA, ISA, LCP)
     else:
+        # one process per GPU (psac's deployment: one MPI rank per block): the C++ multi-GPU engine behind
+        # psacx_multi_*; torch.distributed only carries the communicator id and the barriers
+        import ctypes as C
         import torch.distributed as dist
-        from psac_amd import dist as D
-        from psac_amd.comm import TorchComm
-        from psac_amd.dist_ops import HipOps
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = TorchComm()
-        ops = HipOps(bits, local_rank)
+        box = [psac_amd.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        mg = psac_amd.MultiContext.for_rank(rank, world, local_rank, box[0])
+        lib, rctx = mg._lib, mg.rank_ctx(0)
+        w = bits // 8
+
+        def dalloc(nbytes):
+            p = C.c_void_p()
+            if lib.psacx_dev_alloc(rctx, C.byref(p), max(int(nbytes), 1)) != 0:
+                raise RuntimeError("device allocation failed")
+            return p.value
 
         def barrier():
             dist.barrier()
             torch.cuda.synchronize()
-        d_text = torch.from_numpy(text).cuda()
+        d_text, d_sa, d_isa = dalloc(m), dalloc(m * w), dalloc(m * w)
+        d_lcp = dalloc(m * w) if a.lcp else None
+        lib.psacx_copy_h2d(rctx, C.c_void_p(d_text), text.ctypes.data_as(C.c_void_p), m)
         barrier()
         t0 = time.perf_counter()
-        res = D.run(D.construct(comm, ops, d_text, want_lcp=a.lcp, log=sys.stderr))
+        st = mg.construct_device([d_text], [m], [d_sa], [d_isa], [d_lcp] if a.lcp else None, bits)[0]
         barrier()
         if rank == 0:
+            for r in st.rounds[:st.n_rounds]:
+                sys.stderr.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % (r.h, r.unfinished_buckets, r.unfinished_elements))
             sys.stderr.write("PSAC time: %g ms\n" % ((time.perf_counter() - t0) * 1e3))
-        view = lambda t: t.cpu().numpy().view(udt)
-        SA, ISA = view(res["SA"]), view(res["ISA"])
-        LCP = view(res["LCP"]) if a.lcp else None
-        gathered = None
+        SA = np.empty(m, udt); LCP = np.empty(m, udt) if a.lcp else None
+        lib.psacx_copy_d2h(rctx, SA.ctypes.data_as(C.c_void_p), C.c_void_p(d_sa), m * w)
+        if a.lcp:
+            lib.psacx_copy_d2h(rctx, LCP.ctypes.data_as(C.c_void_p), C.c_void_p(d_lcp), m * w)
+        rc = 0
         if a.check:
-            def gather(t):
-                parts = []
-                for src in range(world):
-                    buf = t if src == rank else torch.empty(_blk(n, world, src)[1], dtype=t.dtype, device=t.device)
-                    dist.broadcast(buf, src=src)
-                    parts.append(buf)
-                return torch.cat(parts).cpu().numpy()
-            gt = gather(d_text)
-            gsa, gisa = gather(res["SA"]).view(udt), gather(res["ISA"]).view(udt)
-            glcp = gather(res["LCP"]).view(udt) if a.lcp else None
-            gathered = (gt, gsa, gisa, glcp)
+            # the distributed checker (d_check_sa, check_suffix_array.hpp:207-267, plus the LCP recurrence): nothing is
+            # gathered on one rank, so it works at any size the construction itself works at
+            err = mg.check_device([d_text], [m], [d_sa], [d_isa], [d_lcp] if a.lcp else None, bits)
+            if any(err):
+                if rank == 0:
+                    sys.stderr.write("[ERROR] Test unsuccessful %s\n" % err)
+                rc = 1
+            elif rank == 0:
+                sys.stderr.write("[SUCCESS] Suffix Array%s are correct\n" % (" and LCP" if a.lcp else ""))
+        a_check_done = True
 
-    rc = 0
-    if a.check and rank == 0:
+    if single:
+        rc = 0
+    if a.check and single:
         gt, gsa, gisa, glcp = gathered
         ctx = psac_amd.Context(local_rank)
         w = bits // 8
@@ -154,8 +168,7 @@ def main(argv=None):
         if a.lcp:
             _write_block(a.outfile + ".lcp64", LCP.astype(np.uint64), off, n, rank, barrier)
     if not single:
-        import torch.distributed as dist
-        ops.close()
+        mg.close()
         dist.destroy_process_group()
     return rc
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +41,12 @@ struct psacx_ctx {
     char* stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points
     size_t stage_bytes = 0;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // Freed device blocks of the multi-GPU path, kept for reuse (size -> pointer).  Every use of such a block is
+    // ordered on this ctx's stream (its second stream joins it through events), so a block handed out again is
+    // only touched after everything that used it before.  (hipMallocAsync was measured first: its pool stalls for
+    // seconds now and then once several streams of one device share it.)
+    std::multimap<size_t, void*>* pool = nullptr;
+    size_t pool_bytes = 0;
     std::string hip_err;
     psacx_stats stats;
     bool profile = false;
@@ -219,6 +226,40 @@ inline int staged_h2d(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) 
     return PSACX_OK;
 }
 
+inline void pool_flush(psacx_ctx* c) {
+    if (!c->pool) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : *c->pool) (void)hipFree(kv.second);
+    c->pool->clear();
+    c->pool_bytes = 0;
+}
+// *cap receives the size of the block actually handed out (pass it back to pool_free)
+inline void* pool_alloc(psacx_ctx* c, size_t bytes, size_t* cap) {
+    if (!c->pool) c->pool = new std::multimap<size_t, void*>();
+    const size_t want = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    auto it = c->pool->lower_bound(want);
+    if (it != c->pool->end() && it->first <= want + want / 4 + 4096) {
+        void* p = it->second; *cap = it->first;
+        c->pool_bytes -= it->first;
+        c->pool->erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        pool_flush(c);                                   // give the cached blocks back and try once more
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    *cap = want;
+    return p;
+}
+inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
+    if (!p) return;
+    if (!c->pool) c->pool = new std::multimap<size_t, void*>();
+    c->pool->emplace(cap, p);
+    c->pool_bytes += cap;
+}
+
 inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8) {
     uint64_t want = (work_items + block - 1) / block;
     uint64_t cap = (uint64_t)c->n_cu * per_cu;
@@ -338,7 +379,8 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
                          unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
-    const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
+    const unsigned slab_tiles = slab_tiles_for(ntiles);
+    const uint64_t nslabs = (ntiles + slab_tiles - 1) / slab_tiles;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     {
@@ -346,7 +388,7 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
         if (!have_hist)        // (the producer of the keys may have left this pass's tile histograms in place)
             hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
                                shift, tile_hist);
-        hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
+        hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
         hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs,
                            const_cast<unsigned long long*>(base));
     }
@@ -354,11 +396,11 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     if (ko_in)
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
     else            // two-word records (k1, v): the prefix sort of the first round
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr);
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
 }
 
 template <typename T>
@@ -387,18 +429,19 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
                     unsigned long long* class_start_host) {
     constexpr int BLOCK = 512, ITEMS = 12, TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
-    const uint64_t nslabs = (ntiles + SLAB_TILES - 1) / SLAB_TILES;
+    const unsigned slab_tiles = slab_tiles_for(ntiles);
+    const uint64_t nslabs = (ntiles + slab_tiles - 1) / slab_tiles;
     char* scratch = sc.d_desc;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
     hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, cls, n, 0, tile_hist);
-    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot);
+    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, sc.d_base);
     hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
                        c->stream, in.k1, in.k2, in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot,
                        (unsigned long long*)nullptr, (uint64_t)0, (uint64_t)0, reinterpret_cast<unsigned*>(scratch),
-                       sort_chunk_for(n, true), cls);
+                       sort_chunk_for(n, true), cls, slab_tiles);
     PSACX_HIP(c, hipGetLastError());
     PSACX_HIP(c, hipMemcpyAsync(class_start_host, sc.d_base, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));

@@ -14,13 +14,6 @@ int make_rank(psacx_multi* g, int i, int grank, int device) {
     MG_HIP(g, hipStreamCreateWithFlags(&R.comm_stream, hipStreamNonBlocking));
     MG_HIP(g, hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming));
     MG_HIP(g, hipEventCreateWithFlags(&R.ev_done, hipEventDisableTiming));
-    // keep freed blocks in the stream-ordered pool: the rounds allocate the same sizes again and again
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-    (void)hipGetLastError();
     return PSACX_OK;
 }
 

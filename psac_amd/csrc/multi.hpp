@@ -27,6 +27,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and prototypes only: librccl is opened with dlopen when a communicator is needed
 
+#include <chrono>
 #include <functional>
 
 #include "dist_ops.hpp"
@@ -95,32 +96,29 @@ namespace psacx {
 #define MG_OP(g, c, call)                                                                 \
     do { int rc__ = (call); if (rc__ != PSACX_OK) { (g)->err = std::string(#call) + ": " + psacx_strerror(rc__) + " [" + (c)->hip_err + "]"; return rc__; } } while (0)
 
-// device array owned by one rank, stream-ordered allocation on the rank's compute stream
+// device array owned by one rank; blocks come from and return to the rank's cache (engine.hpp: pool_alloc)
 template <typename E> struct DBuf {
     E* p = nullptr; uint64_t n = 0; psacx_ctx* c = nullptr;
     DBuf() {}
     DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
-    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c) { o.p = nullptr; o.n = 0; }
-    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; o.p = nullptr; o.n = 0; } return *this; }
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c), cap_(o.cap_) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; cap_ = o.cap_; o.p = nullptr; o.n = 0; } return *this; }
     ~DBuf() { release(); }
     int alloc(psacx_ctx* ctx, uint64_t count) {
         release();
         c = ctx; n = count;
         if (hipSetDevice(c->device) != hipSuccess) return PSACX_EHIP;
-        const size_t bytes = (size_t)(count ? count : 1) * sizeof(E);
-        hipError_t e = hipMallocAsync((void**)&p, bytes, c->stream);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void**)&p, bytes); async_ = false; } else async_ = true;
-        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; c->hip_err = "device allocation failed"; return PSACX_ENOMEM; }
+        p = static_cast<E*>(pool_alloc(c, (size_t)count * sizeof(E), &cap_));
+        if (!p) { c->hip_err = "device allocation failed"; n = 0; return PSACX_ENOMEM; }
         return PSACX_OK;
     }
     void release() {
         if (!p) return;
-        (void)hipSetDevice(c->device);
-        if (async_) (void)hipFreeAsync(p, c->stream); else { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); }
+        pool_free(c, p, cap_);
         p = nullptr; n = 0;
     }
 private:
-    bool async_ = true;
+    size_t cap_ = 0;
 };
 
 template <typename T> struct Rec { DBuf<T> k1, k2, v; uint64_t cnt = 0; };
@@ -211,7 +209,22 @@ struct MultiRun {
     };
     std::vector<St> S;
 
-    explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal) {}
+    explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
+        t_last_ = std::chrono::steady_clock::now();
+    }
+    // PSACX_MULTI_TRACE=1: wall time of every phase on stderr (all local streams drained at each mark)
+    bool trace_;
+    std::chrono::steady_clock::time_point t_last_;
+    void mark(const char* what) {
+        if (!trace_) return;
+        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); (void)hipStreamSynchronize(g->R[i].comm_stream); }
+        const auto now = std::chrono::steady_clock::now();
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        if (g->first == 0) fprintf(stderr, "[psacx multi] %-28s %9.3f ms   (device memory in use %.1f GiB)\n", what,
+                                   std::chrono::duration<double, std::milli>(now - t_last_).count(), (double)(tot - fr) / (1 << 30));
+        t_last_ = std::chrono::steady_clock::now();
+    }
     psacx_ctx* ctx(int i) const { return g->R[i].ctx; }
     int rank(int i) const { return g->R[i].grank; }
 
@@ -446,9 +459,11 @@ struct MultiRun {
             rec[i].k1.release(); rec[i].k2.release(); rec[i].v.release();
             in[i] = {grp[i].k1.p, grp[i].k2.p, grp[i].v.p};
         }
+        mark("    sort: samples + partition");
         std::vector<std::vector<DBuf<T>>> got;
         std::vector<std::vector<uint64_t>> rc;
         PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+        mark("    sort: shuffle");
         std::vector<uint64_t> c2(L);
         for (int i = 0; i < L; ++i) {
             grp[i] = Rec<T>();
@@ -456,6 +471,7 @@ struct MultiRun {
             rec[i].cnt = c2[i] = rec[i].k1.n;
             PSACX_TRY(local_sort(i, rec[i], bits1, bits2));
         }
+        mark("    sort: local sort");
         // exact re-balance: the j-th record of rank r has global index G[r] + j
         std::vector<uint64_t> counts;
         PSACX_TRY(gather1(c2, counts));
@@ -696,6 +712,7 @@ struct MultiRun {
             st.sigma = sigma; st.bits_per_char = l;
             for (int ch = 0, nx = 0; ch < 256; ++ch) codes_[ch] = hist[ch] ? (uint16_t)(nx++) : (uint16_t)0;   // packed codes 0..sigma-1
         }
+        mark("alphabet");
         const uint32_t l = st.bits_per_char;
         const uint32_t word_bits = (uint32_t)sizeof(T) * 8;
         uint64_t min_local = sizes[0];
@@ -795,7 +812,9 @@ struct MultiRun {
             }
             // (the pieces are consumed before `got` and `tails` go out of scope: stream order)
         }
+        mark("keys");
         PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc));
+        mark("first sort");
 
         // ---- LCP of the 2k-mers, bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
         std::vector<psacx_boundary> bd;
@@ -822,14 +841,17 @@ struct MultiRun {
             MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             rec[i] = Rec<T>();
         }
+        mark("rebucket");
         // ---- SA -> ISA (bulk_permute.hpp:14-73), overlapped on the second streams with the bookkeeping below
         {
             std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L); std::vector<uint64_t> cn(L);
             for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; va[i] = S[i].Bsa.p; cn[i] = S[i].m; }
             PSACX_TRY(dist_put(blk, gi, va, cn, -1, true));
         }
+        mark("SA -> ISA");
         uint64_t unf_b = 0, unf_e = 0;
         PSACX_TRY(next_active(nullptr, nact, nunf, &unf_b, &unf_e));
+        mark("active list");
         st.rounds[0].h = k; st.rounds[0].active = n; st.rounds[0].unfinished_buckets = unf_b; st.rounds[0].unfinished_elements = unf_e;
         st.n_rounds = 1;
 
@@ -863,7 +885,9 @@ struct MultiRun {
                 }
             }
             q.clear();
+            mark("  B2 fetch");
             PSACX_TRY(dist_sort(rec, counts, id_bits, id_bits));
+            mark("  sort");
             {
                 std::vector<const T*> a1(L), a2(L), a3(L);
                 for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; }
@@ -891,6 +915,7 @@ struct MultiRun {
                 for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = rec[i].v.p; va[i] = ids[i].p; }
                 PSACX_TRY(dist_put(blk, gi, va, cnt, -1, false));
             }
+            mark("  refine + ISA");
             if (want_lcp) {
                 std::vector<const T*> lo(L), hi(L);
                 for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
@@ -902,8 +927,10 @@ struct MultiRun {
                     SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
                 }
             }
+            mark("  range minima");
             rec.clear(); rec.resize(L);
             PSACX_TRY(next_active(&ids, nact, nunf, &unf_b, &unf_e));
+            mark("  active list");
             if (st.n_rounds < PSACX_MAX_ROUNDS) {
                 psacx_round& rr = st.rounds[st.n_rounds++];
                 std::memset(&rr, 0, sizeof(rr));

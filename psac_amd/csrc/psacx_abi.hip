@@ -61,6 +61,8 @@ void psacx_destroy(psacx_ctx* c) {
     if (c->slab) (void)hipFree(c->slab);
     if (c->aux) (void)hipFree(c->aux);
     if (c->io) (void)hipFree(c->io);
+    pool_flush(c);
+    delete c->pool;
     for (int i = 0; i < 2; ++i) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -92,6 +94,7 @@ int psacx_trim(psacx_ctx* c) {
     if (c->slab) { PSACX_HIP(c, hipFree(c->slab)); c->slab = nullptr; c->slab_bytes = 0; }
     if (c->aux) { PSACX_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
     if (c->io) { PSACX_HIP(c, hipFree(c->io)); c->io = nullptr; c->io_bytes = 0; }
+    pool_flush(c);
     return PSACX_OK;
 }
 

@@ -19,7 +19,11 @@ namespace psacx {
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int MAX_PASSES = 2 * (64 / RADIX_BITS);   // two 64-bit key words
-constexpr int SLAB_TILES = 64;                       // tiles per slab of the three-kernel offset scan
+constexpr int SLAB_TILES = 64;                       // tiles per slab of the three-kernel offset scan (smallest slab)
+// Very long inputs use longer slabs: the scan over the slab totals is one workgroup walking them one after the other
+// (1.7 ms per pass at 2^20 tiles with 64-tile slabs, 2 % of a 4 GiB construction), the scan inside a slab runs in
+// parallel over slabs.
+inline unsigned slab_tiles_for(uint64_t ntiles) { return ntiles > (1u << 16) ? 1024u : (unsigned)SLAB_TILES; }
 
 // pass p < passes_lo reads key2 (low word), the rest read key1
 struct PassPlan {
@@ -133,7 +137,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
-    const T* __restrict__ dsrc = nullptr) {
+    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     T* const stage = sh.stage;
@@ -158,7 +162,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     // offsets of this tile (three-kernel form): fetched now, used after the ranking
     uint64_t pre_excl = 0;
     if (!LB && tid < RADIX)
-        pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / SLAB_TILES) * RADIX + tid] +
+        pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / slab_tiles) * RADIX + tid] +
                    (uint64_t)digit_base[tid];
     T kd[ITEMS], ko[NOKO ? 1 : ITEMS], vv[ITEMS];
     unsigned char cls[EXT ? ITEMS : 1];
@@ -379,12 +383,13 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist_kernel(const T* __restr
 // one workgroup per slab: in-place exclusive scan of its tiles' counts per digit, slab totals out
 template <int TAG>
 __global__ __launch_bounds__(RADIX) void radix_slab_scan_kernel(unsigned* __restrict__ tile_hist, uint64_t ntiles,
-                                                                unsigned long long* __restrict__ slab_tot) {
-    const uint64_t t0 = (uint64_t)blockIdx.x * SLAB_TILES;
+                                                                unsigned long long* __restrict__ slab_tot,
+                                                                unsigned slab_tiles = SLAB_TILES) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * slab_tiles;
     const unsigned d = threadIdx.x;
     unsigned long long run = 0;
     constexpr int B = 16;
-    for (int b0 = 0; b0 < SLAB_TILES; b0 += B) {
+    for (unsigned b0 = 0; b0 < slab_tiles; b0 += B) {
         unsigned v[B];
 #pragma unroll
         for (int j = 0; j < B; ++j) v[j] = (t0 + b0 + j < ntiles) ? tile_hist[(t0 + b0 + j) * RADIX + d] : 0u;
@@ -427,7 +432,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
-    uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr) {
+    uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr,
+    unsigned slab_tiles = SLAB_TILES) {
     // (a persistent variant, one workgroup looping over tiles with its next ticket prefetched, was
     // measured: the loop raised the register count from 118 to 173 and lost 20 %)
     constexpr int TILE = BLOCK * ITEMS;
@@ -444,11 +450,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                        spec, spec_n, tile_excl, slab_excl, dsrc);
+                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
     else
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                         spec, spec_n, tile_excl, slab_excl, dsrc);
+                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
 }
 
 } // namespace psacx

@@ -136,3 +136,136 @@ def test_multi_rccl_path_at_world_size_one():
         assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
     finally:
         mg.close()
+
+
+def _blocks_on_device(mg, text, bits, P):
+    """Uploads the blocks of `text` to the ranks of mg and constructs; returns the device addresses and a free()."""
+    import ctypes as C
+    lib = mg._lib
+    n = text.size
+    w = bits // 8
+    sizes = [n // P + (1 if r < n % P else 0) for r in range(P)]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    held = []
+
+    def alloc(ctx, nbytes):
+        p = C.c_void_p()
+        assert lib.psacx_dev_alloc(ctx, C.byref(p), max(nbytes, 1)) == 0
+        held.append((ctx, p))
+        return p.value
+    d = dict(text=[], sa=[], isa=[], lcp=[])
+    for r in range(P):
+        ctx = mg.rank_ctx(r)
+        d["text"].append(alloc(ctx, sizes[r]))
+        blk = np.ascontiguousarray(text[offs[r]:offs[r + 1]])
+        assert lib.psacx_copy_h2d(ctx, C.c_void_p(d["text"][r]), blk.ctypes.data_as(C.c_void_p), sizes[r]) == 0
+        for key in ("sa", "isa", "lcp"):
+            d[key].append(alloc(ctx, sizes[r] * w))
+
+    def free():
+        for ctx, p in held:
+            lib.psacx_dev_free(ctx, p)
+    return d, sizes, free
+
+
+def test_multi_distributed_checker():
+    # d_check_sa + the LCP recurrence over block-distributed results (nothing gathered on one rank); a repetitive text
+    # has range minima that span ranks; every kind of corruption must be counted
+    import ctypes as C
+    P, bits = 4, 32
+    mg = multi(P)
+    try:
+        for text in (inputs.dna(300007, 4), inputs.tandem(120000, 512, O.rand_dna(512, 2)), np.full(9001, 66, np.uint8)):
+            d, sizes, free = _blocks_on_device(mg, text, bits, P)
+            mg.construct_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+            assert mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits) == [0, 0, 0, 0]
+            assert mg.check_device(d["text"], sizes, d["sa"], d["isa"], None, bits)[:2] == [0, 0]
+            lib = mg._lib
+            # one wrong LCP entry on rank 2, then two swapped SA entries on rank 1
+            bad = np.array([12345], np.uint32)
+            keep = np.empty(1, np.uint32)
+            at = d["lcp"][2] + 100 * 4
+            lib.psacx_copy_d2h(mg.rank_ctx(2), keep.ctypes.data_as(C.c_void_p), C.c_void_p(at), 4)
+            lib.psacx_copy_h2d(mg.rank_ctx(2), C.c_void_p(at), bad.ctypes.data_as(C.c_void_p), 4)
+            err = mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+            assert err[0] == 0 and err[1] == 0 and err[2] >= 1
+            lib.psacx_copy_h2d(mg.rank_ctx(2), C.c_void_p(at), keep.ctypes.data_as(C.c_void_p), 4)
+            two = np.empty(2, np.uint32)
+            at = d["sa"][1] + 50 * 4
+            lib.psacx_copy_d2h(mg.rank_ctx(1), two.ctypes.data_as(C.c_void_p), C.c_void_p(at), 8)
+            sw = two[::-1].copy()
+            lib.psacx_copy_h2d(mg.rank_ctx(1), C.c_void_p(at), sw.ctypes.data_as(C.c_void_p), 8)
+            err = mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+            assert err[0] >= 2                      # ISA is no longer the inverse at the two positions
+            free()
+    finally:
+        mg.close()
+
+
+def test_psac_cli_and_cpp_header_on_several_ranks(tmp_path):
+    # psac --gpus N (here N ranks on device 0) and suffix_array<> with a multi-device communicator: same outputs as one rank
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    psac = os.path.join(root, "psac_amd", "bin", "psac")
+    if not os.path.exists(psac):
+        pytest.skip("CLI not built")
+    text = O.rand_dna(250003, 9)
+    f = tmp_path / "t.txt"
+    f.write_bytes(bytes(text))
+    r = subprocess.run([psac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "m"), "--gpus-on-device", "0,3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr and "PSAC time:" in r.stderr, r.stderr
+    ref = O.construct(text, bits=32)
+    assert np.array_equal(np.fromfile(str(tmp_path / "m.sa64"), np.uint64), ref["SA"].astype(np.uint64))
+    assert np.array_equal(np.fromfile(str(tmp_path / "m.lcp64"), np.uint64), ref["LCP"].astype(np.uint64))
+    src = tmp_path / "p.cpp"
+    src.write_text(r'''
+#include "suffix_array.hpp"
+#include <cstdio>
+int main() {
+    std::string s;
+    srand(1337 * 5);
+    for (int i = 0; i < 70001; ++i) s.push_back("ACGT"[rand() % 4]);
+    suffix_array<char, uint64_t, true> one((psacx::comm(0)));
+    one.verbose = false;
+    one.construct(s.begin(), s.end());
+    suffix_array<char, uint64_t, true> many((psacx::comm(std::vector<int>(4, 0))));
+    many.verbose = false;
+    many.construct(s.begin(), s.end());
+    if (many.p != 4 || many.n != s.size()) return 2;
+    if (one.local_SA != many.local_SA || one.local_B != many.local_B || one.local_LCP != many.local_LCP) return 3;
+    many.construct(s.begin(), s.begin() + 50000);          // repeated calls on one object (test/test_psac.cpp:148-170)
+    one.construct(s.begin(), s.begin() + 50000);
+    if (one.local_SA != many.local_SA || one.local_LCP != many.local_LCP) return 4;
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = str(tmp_path / "p")
+    lib = os.path.join(root, "psac_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(root, "include"), "-o", exe, str(src), "-L" + lib, "-lpsacx",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stderr)
+
+
+def test_bench_and_cli_process_per_gpu_path(tmp_path):
+    # what the driver launches for N > 1, at world size 1 on this box: torchrun -> bench.py --gpus ... -> psacx_multi_create_rank
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSACX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", str(1 << 22)],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "roofline" in out and out["config"]["rounds"] >= 1
+    env = dict(os.environ, PSACX_CLI_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29578", "-m", "psac_amd", "-r", "300000", "-s", "2", "-l", "-c"], capture_output=True, text=True, env=env,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr[-3000:]
