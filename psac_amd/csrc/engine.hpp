@@ -438,10 +438,16 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
     hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, cls, n, 0, tile_hist);
     hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, sc.d_base);
-    hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
-                       c->stream, in.k1, in.k2, in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot,
-                       (unsigned long long*)nullptr, (uint64_t)0, (uint64_t)0, reinterpret_cast<unsigned*>(scratch),
-                       sort_chunk_for(n, true), cls, slab_tiles);
+    if (in.k2)
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
+                           c->stream, in.k1, in.k2, in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, (uint64_t)0, (uint64_t)0, reinterpret_cast<unsigned*>(scratch),
+                           sort_chunk_for(n, true), cls, slab_tiles);
+    else            // two-word records (k1, v): routing (position, value) pairs to their owners
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0,
+                           c->stream, in.k1, in.k2, in.v, out.k1, out.k2, out.v, n, 0, sc.d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, (uint64_t)0, (uint64_t)0, reinterpret_cast<unsigned*>(scratch),
+                           sort_chunk_for(n, true), cls, slab_tiles);
     PSACX_HIP(c, hipGetLastError());
     PSACX_HIP(c, hipMemcpyAsync(class_start_host, sc.d_base, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));

@@ -491,22 +491,57 @@ struct MultiRun {
         return PSACX_OK;
     }
 
-    // stable partition of global positions `gidx` and one payload array by owner rank (one radix pass over the owner word)
+    // Stable partition of global positions `gidx` and one payload array by owner rank: the owner of every position
+    // is computed into a class array, one pass of the radix scatter kernel over two-word records (position, payload)
+    // groups them by that class.  out.k2 = positions, out.v = payloads, bounds[d] = start of the records for rank d.
     int route(int i, const T* gidx, const T* payload, uint64_t cnt, Rec<T>& out, std::vector<uint64_t>& bounds) {
         psacx_ctx* c = ctx(i);
         out.cnt = cnt;
-        MG_OP(g, c, out.k1.alloc(c, cnt)); MG_OP(g, c, out.k2.alloc(c, cnt)); MG_OP(g, c, out.v.alloc(c, cnt));
+        MG_OP(g, c, out.k2.alloc(c, cnt)); MG_OP(g, c, out.v.alloc(c, cnt));
         bounds.assign(P + 1, cnt);
         bounds[0] = 0;
         if (cnt == 0) return PSACX_OK;
-        MG_OP(g, c, psacx_op_owners(c, gidx, cnt, n, (uint32_t)P, out.k1.p));
-        MG_HIP(g, hipMemcpyAsync(out.k2.p, gidx, cnt * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        MG_HIP(g, hipMemcpyAsync(out.v.p, payload, cnt * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        PSACX_TRY(local_sort(i, out, bits_for((uint64_t)(P - 1)), 0));
-        std::vector<uint64_t> q(P), z(P, 0), lb(P), ub(P);
-        for (int d = 0; d < P; ++d) q[d] = (uint64_t)d;
-        MG_OP(g, c, op_pair_bounds<T>(c, out.k1.p, out.k1.p, cnt, q.data(), z.data(), (uint32_t)P, 0, lb.data(), ub.data()));
-        for (int d = 0; d < P; ++d) bounds[d] = lb[d];
+        MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+        SortScratch sc;
+        T* cls = nullptr;
+        auto layout = [&](Arena& a) {
+            cls = a.take<T>(cnt);
+            sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+            sc.desc_bytes = sort_desc_bytes(cnt);
+            sc.d_desc = a.take<char>(sc.desc_bytes);
+        };
+        { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
+        Arena ar(c->slab);
+        layout(ar);
+        MG_OP(g, c, psacx_op_owners(c, gidx, cnt, n, (uint32_t)P, cls));
+        SortBufs<T> in{const_cast<T*>(gidx), nullptr, const_cast<T*>(payload)}, o{out.k2.p, nullptr, out.v.p};
+        unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+        MG_OP(g, c, class_partition<T>(c, sc, in, o, cls, cnt, starts));
+        for (int d = 0; d < P; ++d) bounds[d] = starts[d];
+        return PSACX_OK;
+    }
+    // the same pass with the classes given (cls[j] < P)
+    int route_by(int i, const T* cls, const T* key, const T* payload, uint64_t cnt, Rec<T>& out, std::vector<uint64_t>& bounds) {
+        psacx_ctx* c = ctx(i);
+        out.cnt = cnt;
+        MG_OP(g, c, out.k2.alloc(c, cnt)); MG_OP(g, c, out.v.alloc(c, cnt));
+        bounds.assign(P + 1, cnt);
+        bounds[0] = 0;
+        if (cnt == 0) return PSACX_OK;
+        MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+        SortScratch sc;
+        auto layout = [&](Arena& a) {
+            sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+            sc.desc_bytes = sort_desc_bytes(cnt);
+            sc.d_desc = a.take<char>(sc.desc_bytes);
+        };
+        { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
+        Arena ar(c->slab);
+        layout(ar);
+        SortBufs<T> in{const_cast<T*>(key), nullptr, const_cast<T*>(payload)}, o{out.k2.p, nullptr, out.v.p};
+        unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+        MG_OP(g, c, class_partition<T>(c, sc, in, o, cls, cnt, starts));
+        for (int d = 0; d < P; ++d) bounds[d] = starts[d];
         return PSACX_OK;
     }
     static int psacx_op_owners(psacx_ctx* c, const T* gi, uint64_t cnt, uint64_t n, uint32_t P, T* out) {
@@ -596,8 +631,11 @@ struct MultiRun {
             MG_OP(g, ctx(0), op_range_min<T>(ctx(0), S[0].LCP, S[0].m, lo[0], hi[0], cnt[0], S[0].off, out[0].p));
             return PSACX_OK;
         }
+        // one min-pyramid of every rank's LCP block serves its block minimum and both batches of sub-queries
         std::vector<uint64_t> bm(L), mins;
-        for (int i = 0; i < L; ++i) MG_OP(g, ctx(i), op_block_min<T>(ctx(i), S[i].LCP, S[i].m, &bm[i]));
+        std::vector<Pyramid<T>> pyr(L);
+        std::vector<DBuf<T>> pyr_mem(L);
+        for (int i = 0; i < L; ++i) PSACX_TRY(block_pyramid(i, pyr[i], pyr_mem[i], &bm[i]));
         PSACX_TRY(gather1(bm, mins));
         // own1/lo1/hi1: the part inside the rank of lo; own2/lo2/hi2: the part inside the rank of hi - 1; ra/rb: whole ranks between
         std::vector<std::vector<DBuf<T>>> parts(L);
@@ -616,28 +654,13 @@ struct MultiRun {
             std::vector<std::vector<const T*>> in(L);
             for (int i = 0; i < L; ++i) {
                 psacx_ctx* c = ctx(i);
-                const T* own = parts[i][3 * half].p; const T* a = parts[i][3 * half + 1].p; const T* b = parts[i][3 * half + 2].p;
-                // route by owner: (owner, a, b) and (owner, a, slot) through the same stable pass
-                ra[i].cnt = rb[i].cnt = cnt[i];
-                MG_OP(g, c, ra[i].k1.alloc(c, cnt[i])); MG_OP(g, c, ra[i].k2.alloc(c, cnt[i])); MG_OP(g, c, ra[i].v.alloc(c, cnt[i]));
-                MG_OP(g, c, rb[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rb[i].k2.alloc(c, cnt[i])); MG_OP(g, c, rb[i].v.alloc(c, cnt[i]));
-                if (cnt[i]) {
-                    MG_HIP(g, hipMemcpyAsync(ra[i].k1.p, own, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_HIP(g, hipMemcpyAsync(ra[i].k2.p, a, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_HIP(g, hipMemcpyAsync(ra[i].v.p, b, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_HIP(g, hipMemcpyAsync(rb[i].k1.p, own, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_HIP(g, hipMemcpyAsync(rb[i].k2.p, a, cnt[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_OP(g, c, psacx_op_iota(c, rb[i].v.p, cnt[i], 0));
-                }
-                PSACX_TRY(local_sort(i, ra[i], bits_for((uint64_t)(P - 1)), 0));
-                PSACX_TRY(local_sort(i, rb[i], bits_for((uint64_t)(P - 1)), 0));
-                bounds[i].assign(P + 1, cnt[i]); bounds[i][0] = 0;
-                if (cnt[i]) {
-                    std::vector<uint64_t> q(P), z(P, 0), lb(P), ub(P);
-                    for (int d = 0; d < P; ++d) q[d] = (uint64_t)d;
-                    MG_OP(g, c, op_pair_bounds<T>(c, ra[i].k1.p, ra[i].k1.p, cnt[i], q.data(), z.data(), (uint32_t)P, 0, lb.data(), ub.data()));
-                    for (int d = 0; d < P; ++d) bounds[i][d] = lb[d];
-                }
+                const T* a = parts[i][3 * half + 1].p; const T* b = parts[i][3 * half + 2].p;
+                // route by the owner of the sub-range's lower end: (a, b) and (a, slot) through the same stable pass
+                DBuf<T> slot; MG_OP(g, c, slot.alloc(c, cnt[i]));
+                MG_OP(g, c, psacx_op_iota(c, slot.p, cnt[i], 0));
+                std::vector<uint64_t> bnd2;
+                PSACX_TRY(route_by(i, parts[i][3 * half].p, a, b, cnt[i], ra[i], bounds[i]));
+                PSACX_TRY(route_by(i, parts[i][3 * half].p, a, slot.p, cnt[i], rb[i], bnd2));
                 in[i] = {ra[i].k2.p, ra[i].v.p};
             }
             std::vector<std::vector<DBuf<T>>> q, got;
@@ -646,7 +669,8 @@ struct MultiRun {
             for (int i = 0; i < L; ++i) {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, res[i].alloc(c, q[i][0].n));
-                MG_OP(g, c, op_range_min<T>(c, S[i].LCP, S[i].m, q[i][0].p, q[i][1].p, q[i][0].n, S[i].off, res[i].p));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (range_min_kernel<T>), q[i][0].n, pyr[i], q[i][0].p, q[i][1].p, q[i][0].n, S[i].off, res[i].p);
                 b2[i] = prefix_of(rc[i]);
                 in[i] = {res[i].p};
             }
@@ -666,6 +690,38 @@ struct MultiRun {
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (rmq_combine_kernel<T>), cnt[i], answers[0][i].p, answers[1][i].p, parts[i][6].p, parts[i][7].p, cnt[i], rm, out[i].p);
         }
+        return PSACX_OK;
+    }
+
+    // 64-ary min-pyramid over this rank's LCP block in its own buffer (levels >= 1; level 0 is the block), and the block minimum
+    int block_pyramid(int i, Pyramid<T>& Pm, DBuf<T>& mem, uint64_t* block_min) {
+        psacx_ctx* c = ctx(i);
+        const uint64_t m = S[i].m;
+        Pm = Pyramid<T>();
+        *block_min = (uint64_t)(T)~(T)0;
+        if (m == 0) return PSACX_OK;
+        uint64_t total = 0, len = m;
+        int nlev = 1;
+        while (len > 128 && nlev < PYR_MAX) { len = (len + 63) / 64; total += (len + 63) & ~63ull; ++nlev; }
+        MG_OP(g, c, mem.alloc(c, total + 64));
+        Pm.lvl[0] = S[i].LCP; Pm.len[0] = m; Pm.nlev = 1;
+        len = m;
+        uint64_t at = 0;
+        OP_PROLOGUE(c);
+        while (len > 128 && Pm.nlev < PYR_MAX) {
+            len = (len + 63) / 64;
+            Pm.lvl[Pm.nlev] = mem.p + at; Pm.len[Pm.nlev] = len; at += (len + 63) & ~63ull;
+            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, len * 64, 256, 8)), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1],
+                               Pm.len[Pm.nlev - 1], Pm.lvl[Pm.nlev], len);
+            MG_HIP(g, hipGetLastError());
+            Pm.nlev++;
+        }
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(mem.p + at);      // 64 spare entries at the end
+        hipLaunchKernelGGL((top_min_kernel<T>), dim3(1), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1], Pm.len[Pm.nlev - 1], d);
+        MG_HIP(g, hipGetLastError());
+        MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d, 8, hipMemcpyDeviceToHost, c->stream));
+        MG_HIP(g, hipStreamSynchronize(c->stream));
+        *block_min = *reinterpret_cast<uint64_t*>(c->pinned + 32768);
         return PSACX_OK;
     }
 
@@ -956,6 +1012,7 @@ struct MultiRun {
               const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp, bool with_lcp, uint64_t errors[4]) {
         want_lcp = with_lcp;
         S.resize(L);
+        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); pool_flush(ctx(i)); }     // the checker wants different sizes than the construction left cached
         for (int i = 0; i < L; ++i) {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
             S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = with_lcp ? d_lcp[i] : nullptr;
