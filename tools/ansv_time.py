@@ -20,7 +20,8 @@ d_l, d_r = ctx.alloc(n * 8), ctx.alloc(n * 8)
 sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
 sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
 names = ("nearest_sm", "nearest_eq", "furthest_eq")
-for lt, rt in ((2, 0), (0, 0), (1, 1), (2, 2)):
+pairs = ((0, 0),) if len(sys.argv) > 3 and sys.argv[3] == "one" else ((2, 0), (0, 0), (1, 1), (2, 2))
+for lt, rt in pairs:
     for it in range(3):
         t0 = time.perf_counter()
         psac_amd.ansv_device(ctx, d_lcp, n, d_l, d_r, bits, lt, rt, (1 << 64) - 1)
