@@ -187,7 +187,8 @@ int op_make_keys(psacx_ctx* c, const uint8_t* text, uint64_t m, uint64_t text_le
 
 template <typename T>
 int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n, uint32_t bits1, uint32_t bits2,
-                 int32_t* where) {
+                 int32_t* where, uint32_t lo1 = 0) {
+    // lo1: the low lo1 bits of word 1 are not sorted on (prefix sort by its leading bits; bits2 is then 0)
     OP_PROLOGUE(c);
     *where = 0;
     if (n < 2) return PSACX_OK;
@@ -213,7 +214,7 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t
     c->profile = c->profile_ops; c->ev_used = 0;
     SortBufs<T> in{k1, k2, v}, alt{a1, a2, av}, res;
     // a word with zero significant bits takes no pass
-    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, false, bits1, bits2, nullptr, &res, nullptr));
+    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, false, bits1, bits2, nullptr, &res, nullptr, 0, 0, false, lo1));
     *where = (res.k1 == k1) ? 0 : 1;
     if (res.v != (*where ? av : v))       // cannot happen without final_v, kept as a guard
         PSACX_HIP(c, hipMemcpyAsync(*where ? av : v, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

@@ -382,6 +382,40 @@ struct MultiRun {
         return PSACX_OK;
     }
 
+    // The local sort of the first round in two stages, as the one-GPU engine does it (construct.hpp): when the leading
+    // `lead` bits of word 1 separate almost every suffix of the whole text, the records are sorted on those bits only
+    // (DNA, 64-bit words, 2^34 characters: 5 instead of 11 passes) and the few groups that still tie are ordered by
+    // (word 1, word 2) in registers (tie_resolve_kernel reading word 2 from the record).  A group longer than 8
+    // (repetitive text) falls back to the full stable sort, which is correct on the partly ordered arrays.
+    int local_sort_first(int i, Rec<T>& rec, unsigned bits1, unsigned bits2) {
+        psacx_ctx* c = ctx(i);
+        unsigned lead = (bits_for(n - 1) + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
+        const bool two_stage = rec.cnt >= (1ull << 21) && lead <= bits1 && lead + RADIX_BITS <= bits1 + bits2 && !getenv("PSACX_ONE_STAGE");
+        if (!two_stage) return local_sort(i, rec, bits1, bits2);
+        const unsigned lo1 = bits1 - lead;
+        {
+            Rec<T> alt;
+            MG_OP(g, c, alt.k1.alloc(c, rec.cnt)); MG_OP(g, c, alt.k2.alloc(c, rec.cnt)); MG_OP(g, c, alt.v.alloc(c, rec.cnt));
+            int32_t where = 0;
+            MG_OP(g, c, op_pair_sort<T>(c, rec.k1.p, rec.k2.p, rec.v.p, alt.k1.p, alt.k2.p, alt.v.p, rec.cnt, bits1, 0, &where, lo1));
+            if (where) { std::swap(rec.k1, alt.k1); std::swap(rec.k2, alt.k2); std::swap(rec.v, alt.v); }
+        }
+        constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
+        DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
+        MG_HIP(g, hipSetDevice(c->device));
+        MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
+        const uint64_t nb = (rec.cnt + (uint64_t)TB_ * TI_ - 1) / ((uint64_t)TB_ * TI_);
+        CodeTable tab; std::memset(&tab, 0, sizeof(tab));
+        KeyShape ks; std::memset(&ks, 0, sizeof(ks));
+        hipLaunchKernelGGL((tie_resolve_kernel<T, TB_, TI_, TG_, true>), dim3((unsigned)nb), dim3(TB_), 0, c->stream, rec.k1.p, rec.v.p, rec.k2.p,
+                           rec.cnt, lo1, (const uint8_t*)nullptr, (uint64_t)0, tab, ks, big.p);
+        MG_HIP(g, hipGetLastError());
+        MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
+        MG_HIP(g, hipStreamSynchronize(c->stream));
+        if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) return local_sort(i, rec, bits1, bits2);
+        return PSACX_OK;
+    }
+
     // first / last record of every rank's block (has, 3 + 3 words) -> nearest non-empty neighbours of each local rank
     int neighbours(const std::vector<const T*>& a1, const std::vector<const T*>& a2, const std::vector<const T*>& a3,
                    const std::vector<uint64_t>& cnt, int words, std::vector<psacx_boundary>& bd) {
@@ -411,8 +445,8 @@ struct MultiRun {
     // ---------------------------------------------------------------- distributed primitives (see the table above)
     // Sorts the records of all ranks by (k1, k2); rank r ends with exactly targets[r] records, the concatenation
     // over ranks being sorted -- the contract psac needs from mxx::sort (idxsort.hpp:67-79).
-    int dist_sort(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2) {
-        if (P == 1) return local_sort(0, rec[0], bits1, bits2);
+    int dist_sort(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, bool first_round = false) {
+        if (P == 1) return first_round ? local_sort_first(0, rec[0], bits1, bits2) : local_sort(0, rec[0], bits1, bits2);
         constexpr int SAMPLES = 256;
         // regular samples of the local records, made unique by (rank, index) so that ties are divided
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + 3 * SAMPLES, 0));
@@ -469,7 +503,8 @@ struct MultiRun {
             grp[i] = Rec<T>();
             rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
             rec[i].cnt = c2[i] = rec[i].k1.n;
-            PSACX_TRY(local_sort(i, rec[i], bits1, bits2));
+            if (first_round) PSACX_TRY(local_sort_first(i, rec[i], bits1, bits2));
+            else PSACX_TRY(local_sort(i, rec[i], bits1, bits2));
         }
         mark("    sort: local sort");
         // exact re-balance: the j-th record of rank r has global index G[r] + j
@@ -869,7 +904,7 @@ struct MultiRun {
             // (the pieces are consumed before `got` and `tails` go out of scope: stream order)
         }
         mark("keys");
-        PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc));
+        PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc, true));
         mark("first sort");
 
         // ---- LCP of the 2k-mers, bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)

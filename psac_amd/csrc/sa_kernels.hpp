@@ -708,7 +708,9 @@ __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint
 // transposition network and writes it back in place (S2 is filled for tied positions only).
 // Groups longer than G are left alone and counted in big[0]; the caller then falls back to the
 // compaction + radix path for all ties.
-template <typename T, int BLOCK, int ITEMS, int G>
+// FROM_ARRAY: word 2 of every record is already in S2 (records that carried both words through the prefix sort, the
+// multi-GPU path); it is read from there instead of from the text and rewritten in the new order.
+template <typename T, int BLOCK, int ITEMS, int G, bool FROM_ARRAY = false>
 __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, T* __restrict__ SA, T* __restrict__ S2,
                                                             uint64_t n, unsigned lo1, const uint8_t* __restrict__ text,
                                                             uint64_t n_text, CodeTable tab, KeyShape ks,
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
         T k2[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            if ((unsigned)i < len) k2[i] = window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
+            if ((unsigned)i < len) k2[i] = FROM_ARRAY ? S2[e + i] : window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
             else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
         }
         // adjacent exchanges of strictly descending neighbours only: stable
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
         for (int i = 0; i < G; ++i) {
             if ((unsigned)i < len) {
                 if (lo1 && moved) S1[e + i] = k1[i];
-                S2[e + i] = k2[i];
+                if (!FROM_ARRAY || moved) S2[e + i] = k2[i];
                 if (moved) SA[e + i] = sa[i];
             }
         }
