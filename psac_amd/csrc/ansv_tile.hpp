@@ -48,7 +48,8 @@ template <typename T, int TB, bool LF, bool RF> struct AnsvShared {
     // 0x7FFF: beyond the tile), and the equal-run links derived from it (ping-pong)
     uint16_t code_l[LF ? TB * 64 : 1];
     uint16_t code_r[RF ? TB * 64 : 1];
-    uint16_t link[(LF || RF) ? 2 : 1][(LF || RF) ? TB * 64 : 1];
+    // (the two link buffers of furthest_eq live in pm: the prefix minima are dead once the searches of a tile are done)
+    __device__ __forceinline__ uint16_t* link(int which) { return reinterpret_cast<uint16_t*>(pm) + (size_t)which * TB * 64; }
     AnsvMemo<T> memo[2];        // shared answers of searches that leave the tile, per side
     int link_cur_left;          // link buffer with the final left-side links of the tile just finished (-1: none)
 };
@@ -207,7 +208,7 @@ __device__ __forceinline__ void ansv_carry_left(SH& sh, int type, T bmv_prev, ui
             if (kind == 1 && u < v) nres = ANSV_NOCONT;       // something smaller comes first: the run of v ends here
             else if (link_cur < 0) drop = true;
             else {
-                const unsigned hh = sh.link[link_cur][p];
+                const unsigned hh = sh.link(link_cur)[p];
                 nres = prev_base + (hh & 0x7FFFu);
                 if (hh & 0x8000u) {
                     // the run reaches the left edge of the finished tile: its continuation is that tile's own entry for u
@@ -403,7 +404,7 @@ __device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P
         const unsigned p = cd & MASK;
         // same value as the nearest <= element: part of its run; otherwise the element heads its own run, which
         // may go on beyond the tile edge when nothing <= was found inside
-        sh.link[0][e] = (uint16_t)((p != ANSV_PEND && (cd & EXT)) ? p : (e | (p == ANSV_PEND ? EXT : 0u)));
+        sh.link(0)[e] = (uint16_t)((p != ANSV_PEND && (cd & EXT)) ? p : (e | (p == ANSV_PEND ? EXT : 0u)));
     }
     __syncthreads();
     int cur = 0;
@@ -414,10 +415,10 @@ __device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P
 #pragma unroll 4
         for (int k = 0; k < BPW; ++k) {
             const unsigned e = (wave * BPW + k) * 64 + lane;
-            const uint16_t a = sh.link[cur][e];
-            const uint16_t b = sh.link[cur][a & MASK];
+            const uint16_t a = sh.link(cur)[e];
+            const uint16_t b = sh.link(cur)[a & MASK];
             moved |= a != b;
-            sh.link[cur ^ 1][e] = b;
+            sh.link(cur ^ 1)[e] = b;
         }
         cur ^= 1;
         if (!__syncthreads_or(moved)) break;
@@ -432,7 +433,7 @@ __device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P
         bool cont = false;
         T q = 0;
         if (in_range && !direct) {
-            const unsigned hh = sh.link[cur][p];
+            const unsigned hh = sh.link(cur)[p];
             out[g] = tile_base + (hh & MASK);
             cont = (hh & EXT) != 0;                                     // the run may go on beyond the tile edge
             if (cont) q = in[tile_base + p];
@@ -446,7 +447,7 @@ __device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P
 }
 
 template <typename T, bool LF, bool RF>
-__global__ __launch_bounds__(AnsvWaves<T>::N * WAVE) void ansv_tile_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type,
+__global__ __launch_bounds__(AnsvWaves<T>::N * WAVE, (sizeof(T) == 4 && !LF && !RF) ? 8 : 1) void ansv_tile_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type,
                                                                  uint64_t nonsv, uint64_t* __restrict__ left,
                                                                  uint64_t* __restrict__ right, uint64_t ntiles) {
     constexpr int TB = AnsvTile<T>::TB;
