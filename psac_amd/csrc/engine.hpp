@@ -367,6 +367,12 @@ inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_
 #undef PSACX_SC
 }
 
+inline int sort_match_env() {    // 1 = lane-mask table in LDS (default shapes only), anything else / unset = ballot ranking
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PSACX_SORT_MATCH"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
 inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three kernels per pass
     static int v = -2;
     if (v == -2) { const char* e = getenv("PSACX_SORT_MODE"); v = e ? atoi(e) : -1; }
@@ -393,6 +399,21 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
                            const_cast<unsigned long long*>(base));
     }
     ProfScope ps(c, ko_in ? TC_SORT_SCATTER3 : TC_SORT_SCATTER2);
+    // the default shapes exist in the lane-mask-table form as well (radix.hpp: MATCH), selected with PSACX_SORT_MATCH=1.
+    // Measured (profiles/README.md, r02p): it halves the vector instructions of the pass and changes its time by
+    // -2 % (2^32 uint64) / +3 % (2^28 uint32) -- the pass is not bound by its VALU work after all -- so the ballot form stays.
+    constexpr bool DEF_SHAPE = BLOCK == 512 && ITEMS == (sizeof(T) == 4 ? 12 : 8);
+    if (DEF_SHAPE && sort_match_env() == 1) {
+        if (ko_in)
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, false, DEF_SHAPE ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        else
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, DEF_SHAPE ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        return;
+    }
     if (ko_in)
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,

@@ -113,9 +113,15 @@ __device__ __forceinline__ uint64_t match_any8(unsigned d, bool valid) {
 // kd_*: the key word that carries this pass's digit; ko_*: the other key word;
 // v_in may be null, in which case the payload is the record's global index.
 // dbg (optional): every 64th tile stores shader-clock stamps of its phases.
-template <typename T, int TILE, int NW> struct ScatterShared {
+// MATCH = 1 (the default shapes of the large sorts): the lanes of a wave that hold the same digit find each other through
+// a per-wave table of 64-bit lane masks in LDS (one ds_or, one ds_read, one clearing store per record) instead of eight
+// ballots followed by per-lane 64-bit select-and-AND (48 vector instructions per record: the pass was bound by its
+// VALU work, PMC in profiles/r02l_*); the digit byte of every staged record is not kept either, the final position of
+// every output slot is computed once from the staged digit word and held in registers.
+template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
     T stage[TILE];
-    uint8_t sdig[TILE];          // digit of the record at each tile-sorted position
+    uint8_t sdig[MATCH ? 1 : TILE];          // digit of the record at each tile-sorted position
+    unsigned long long mtab[MATCH ? NW * RADIX : 1];   // per wave and digit: lanes holding that digit in the current round
     unsigned wcnt[NW * RADIX];   // per-wave digit counters -> per-wave exclusive bases
     unsigned bstart[RADIX];      // tile-local start of each digit
     T goff[RADIX];               // global offset of digit run minus bstart (wraps)
@@ -129,9 +135,9 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 // EXT: the 8-bit class of a record comes from a separate array (dsrc, not moved) instead of a key
 // digit: one such pass partitions records by an externally computed destination.
 // NOKO: records of two words (digit word + payload); ko_in / ko_out are not touched.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false>
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0>
 __device__ __forceinline__ void radix_scatter_tile(
-    ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
+    ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE, MATCH>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
@@ -209,7 +215,14 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const bool valid = FULL || (wbase + i * WAVE) < count;
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
-        const uint64_t m = match_any8(d, valid);
+        uint64_t m;
+        if (MATCH) {
+            unsigned long long* slot = sh.mtab + wave * RADIX + d;
+            if (valid) __hip_atomic_fetch_or(slot, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            m = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (!valid) m = 0;
+            else __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ready for the next round
+        } else m = match_any8(d, valid);
         const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (valid && (m & lt) == 0)
             __hip_atomic_fetch_add(&mycnt[d], (unsigned)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -266,13 +279,18 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
-        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; sdig[rank[i]] = (uint8_t)d; }
+        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; if (!MATCH) sdig[MATCH ? 0 : rank[i]] = (uint8_t)d; }
     }
     __syncthreads();
+    T dest[MATCH ? ITEMS : 1];          // MATCH: global position of output slot tid + j * BLOCK, reused for every word
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
-        if (FULL || p < count) kd_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+        if (FULL || p < count) {
+            const T x = stage[p];
+            if (MATCH) { dest[MATCH ? j : 0] = (T)(goff[(unsigned)(x >> shift) & (RADIX - 1)] + (T)p); kd_out[dest[MATCH ? j : 0]] = x; }
+            else kd_out[(T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = x;
+        }
     }
     __syncthreads();
     if (stamp) mydbg[4] = __builtin_amdgcn_s_memtime();
@@ -284,7 +302,7 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const unsigned p = tid + j * BLOCK;
-            if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+            if (FULL || p < count) ko_out[MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = stage[p];
         }
         __syncthreads();
     }
@@ -296,7 +314,7 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
-        if (FULL || p < count) v_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+        if (FULL || p < count) v_out[MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = stage[p];
     }
     if (stamp) mydbg[6] = __builtin_amdgcn_s_memtime();
 }
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
@@ -439,20 +457,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
-    __shared__ ScatterShared<T, TILE, NW> sh;
+    static_assert(!(MATCH && EXT), "the lane-mask table form takes its digit from the key word");
+    __shared__ ScatterShared<T, TILE, NW, MATCH> sh;
     // tiles are handed out in start order so that neighbouring runs of a digit are written
     // close in time (they share cache lines); nothing ever waits on another workgroup
     if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
+    if (MATCH) for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.mtab[MATCH ? i : 0] = 0;
     __syncthreads();
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                          spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
 }
