@@ -259,6 +259,14 @@ int psacx_multi_check_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, con
                               const uint32_t* const* d_ISA, const uint32_t* const* d_LCP, uint64_t errors[4]);
 int psacx_multi_check_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* const* d_SA,
                               const uint64_t* const* d_ISA, const uint64_t* const* d_LCP, uint64_t errors[4]);
+/* ansv<T, left_type, right_type, global_indexing>(in, left_nsv, right_nsv, comm) (ansv.hpp:2042-2051) over a
+ * block-distributed array (blocks as mxx::blk_dist, e.g. the LCP blocks psacx_multi_construct_dev_* left in HBM):
+ * d_left[i] / d_right[i] receive, per element of local rank i's block, the GLOBAL index of its nearest smaller value on
+ * that side (types as psacx_ansv_*), nonsv where there is none.  Device pointers; results are uint64. */
+int psacx_multi_ansv_dev_u32(psacx_multi* mg, const uint32_t* const* d_in, const uint64_t* m, int left_type, int right_type,
+                             uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
+int psacx_multi_ansv_dev_u64(psacx_multi* mg, const uint64_t* const* d_in, const uint64_t* m, int left_type, int right_type,
+                             uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
 /* statistics of the last call (sigma, k, the per-round log) and what this process moved: payload bytes sent to other
  * ranks, number of all-to-all exchanges and of scalar all-gathers */
 int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* bytes_sent, uint64_t* exchanges, uint64_t* gathers);

@@ -27,7 +27,7 @@ EXPORTS = [
     "psacx_multi_create", "psacx_multi_unique_id", "psacx_multi_create_rank", "psacx_multi_destroy", "psacx_multi_nranks",
     "psacx_multi_nlocal", "psacx_multi_uses_rccl", "psacx_multi_last_error", "psacx_multi_ctx", "psacx_multi_construct_dev_u32",
     "psacx_multi_construct_dev_u64", "psacx_multi_construct_u32", "psacx_multi_construct_u64", "psacx_multi_get_stats",
-    "psacx_multi_check_dev_u32", "psacx_multi_check_dev_u64",
+    "psacx_multi_check_dev_u32", "psacx_multi_check_dev_u64", "psacx_multi_ansv_dev_u32", "psacx_multi_ansv_dev_u64",
 ]
 
 
@@ -119,6 +119,7 @@ def load():
         getattr(lib, "psacx_multi_construct_dev_" + suf).argtypes = [vp, vp, vp, u32, u32, vp, vp, vp]
         getattr(lib, "psacx_multi_construct_" + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
         getattr(lib, "psacx_multi_check_dev_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
+        getattr(lib, "psacx_multi_ansv_dev_" + suf).argtypes = [vp, vp, vp, i32, i32, u64, vp, vp]
     lib.psacx_multi_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     # step-level ops of the distributed path (include/psacx_ops.h)
     i64, u16p = C.c_int64, C.POINTER(C.c_uint16)

@@ -42,6 +42,16 @@ int check_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, c
     return run.check(t, mm, a, b, c, lcp != nullptr, errors);
 }
 
+template <typename T>
+int ansv_dev(psacx_multi* g, const T* const* d_in, const uint64_t* m, int lt, int rt, uint64_t nonsv, uint64_t* const* l, uint64_t* const* r) {
+    if (!g || !d_in || !m || !l || !r) return PSACX_EINVAL;
+    g->err.clear();
+    MultiRun<T> run(g);
+    std::vector<const T*> b(g->nlocal); std::vector<uint64_t> mm(g->nlocal); std::vector<uint64_t*> ol(g->nlocal), orr(g->nlocal);
+    for (int i = 0; i < g->nlocal; ++i) { b[i] = d_in[i]; mm[i] = m[i]; ol[i] = l[i]; orr[i] = r[i]; }
+    return run.ansv(b, mm, lt, rt, nonsv, ol, orr);
+}
+
 // whole text on the host of a single process that owns every rank: blocks to the GPUs, results back in rank order
 template <typename T>
 int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp) {
@@ -197,6 +207,11 @@ int psacx_multi_check_dev_u32(psacx_multi* g, const uint8_t* const* t, const uin
                               const uint32_t* const* lcp, uint64_t errors[4]) { return check_dev<uint32_t>(g, t, m, sa, isa, lcp, errors); }
 int psacx_multi_check_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* isa,
                               const uint64_t* const* lcp, uint64_t errors[4]) { return check_dev<uint64_t>(g, t, m, sa, isa, lcp, errors); }
+
+int psacx_multi_ansv_dev_u32(psacx_multi* g, const uint32_t* const* in, const uint64_t* m, int lt, int rt, uint64_t nonsv, uint64_t* const* l,
+                             uint64_t* const* r) { return ansv_dev<uint32_t>(g, in, m, lt, rt, nonsv, l, r); }
+int psacx_multi_ansv_dev_u64(psacx_multi* g, const uint64_t* const* in, const uint64_t* m, int lt, int rt, uint64_t nonsv, uint64_t* const* l,
+                             uint64_t* const* r) { return ansv_dev<uint64_t>(g, in, m, lt, rt, nonsv, l, r); }
 
 /* the rank-local psacx_ctx of local rank i (its device, compute stream and workspace), e.g. for psacx_dev_alloc */
 psacx_ctx* psacx_multi_ctx(psacx_multi* g, int i) { return (g && i >= 0 && i < g->nlocal) ? g->R[i].ctx : nullptr; }

@@ -31,6 +31,7 @@
 #include <functional>
 
 #include "dist_ops.hpp"
+#include "ansv_tile.hpp"
 
 namespace psacx {
 
@@ -141,6 +142,103 @@ template <typename T> __global__ void reverse_copy_kernel(const T* __restrict__ 
 template <typename T> __global__ void widen_text_kernel(const uint8_t* __restrict__ t, uint64_t cnt, T* __restrict__ out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)t[i];
+}
+
+// ---- kernels of the distributed ANSV (MultiRun::ansv).  Start positions travel as T with one added (0 = before
+//      position 0, n + 1 = past the end), "none" as all ones.
+template <typename T>
+__global__ void ansv_owner_kernel(const T* __restrict__ start1, uint64_t cnt, BlkDist d, T* __restrict__ cls) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        uint64_t s = (uint64_t)start1[j];
+        s = s ? s - 1 : 0;
+        if (s >= d.n) s = d.n - 1;
+        cls[j] = (T)d.rank_of(s);
+    }
+}
+// nearest element of this block strictly beyond start (left: below it) with value < thr (strict) or <= thr
+template <typename T>
+__global__ void nsv_from_enc_kernel(Pyramid<T> P, uint64_t m, uint64_t off, const T* __restrict__ start1, const T* __restrict__ thr,
+                                    uint64_t cnt, int strict, int left, T* __restrict__ out_idx, T* __restrict__ out_val) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const long long s = (long long)(uint64_t)start1[j] - 1 - (long long)off;          // block-relative, may be < 0 or >= m
+        const T v = thr[j];
+        uint64_t r = NSV_NONE;
+        if (m) {
+            if (left) {
+                if (s > 0) {
+                    if ((uint64_t)s >= m) {
+                        const T x = P.lvl[0][m - 1];
+                        r = (strict ? x < v : x <= v) ? m - 1 : (m > 1 ? nsv_search<T, true>(P, m - 1, v, strict != 0) : NSV_NONE);
+                    } else r = nsv_search<T, true>(P, (uint64_t)s, v, strict != 0);
+                }
+            } else if (s < (long long)m - 1) {
+                if (s < 0) {
+                    const T x = P.lvl[0][0];
+                    r = (strict ? x < v : x <= v) ? 0 : (m > 1 ? nsv_search<T, false>(P, 0, v, strict != 0) : NSV_NONE);
+                } else r = nsv_search<T, false>(P, (uint64_t)s, v, strict != 0);
+            }
+        }
+        out_idx[j] = r == NSV_NONE ? ~(T)0 : (T)(off + r);
+        out_val[j] = r == NSV_NONE ? (T)0 : P.lvl[0][r];
+    }
+}
+// open queries (idx == none): the nearest rank beyond the start's owner whose block minimum qualifies, P = none
+template <typename T>
+__global__ void ansv_target_kernel(const T* __restrict__ own, const T* __restrict__ thr, const T* __restrict__ idx, uint64_t cnt, RankMins mins,
+                                   RankMins sizes, int P, int strict, int left, T* __restrict__ target) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        int t = P;
+        if (idx[j] == ~(T)0) {
+            const unsigned long long v = (unsigned long long)thr[j];
+            const int o = (int)own[j];
+            if (left) { for (int b = o - 1; b >= 0; --b) if (sizes.v[b] && (strict ? mins.v[b] < v : mins.v[b] <= v)) { t = b; break; } }
+            else { for (int b = o + 1; b < P; ++b) if (sizes.v[b] && (strict ? mins.v[b] < v : mins.v[b] <= v)) { t = b; break; } }
+        }
+        target[j] = (T)t;
+    }
+}
+template <typename T>
+__global__ void ansv_merge_kernel(T* __restrict__ idx, T* __restrict__ val, const T* __restrict__ idx2, const T* __restrict__ val2,
+                                  const T* __restrict__ target, uint64_t cnt, int P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
+        if ((int)target[j] < P) { idx[j] = idx2[j]; val[j] = val2[j]; }
+}
+template <typename T>
+__global__ void fill_t_kernel(T* __restrict__ a, uint64_t cnt, T v) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) a[j] = v;
+}
+// local tile ANSV results (block-relative uint64, NSV_NONE = not inside the block) -> idx (global T, all ones = open) and value found
+template <typename T>
+__global__ void ansv_local_to_idx_kernel(const uint64_t* __restrict__ loc, const T* __restrict__ block, uint64_t cnt, uint64_t off,
+                                         T* __restrict__ idx, T* __restrict__ val) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const uint64_t r = loc[j];
+        idx[j] = r == NSV_NONE ? ~(T)0 : (T)(off + r);
+        val[j] = r == NSV_NONE ? (T)0 : block[r];
+    }
+}
+// start positions (plus one) for the follow-up searches of furthest_eq
+template <typename T>
+__global__ void ansv_next_start_kernel(const T* __restrict__ idx, uint64_t cnt, T when_none1, T* __restrict__ start1) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
+        start1[j] = idx[j] == ~(T)0 ? when_none1 : (T)(idx[j] + 1);
+}
+template <typename T>
+__global__ void ansv_finish_kernel(const T* __restrict__ first, const T* __restrict__ far, int use_far, uint64_t cnt, uint64_t nonsv,
+                                   uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const T a = first[j];
+        const T r = (use_far && a != ~(T)0) ? far[j] : a;
+        out[j] = r == ~(T)0 ? nonsv : (uint64_t)r;
+    }
 }
 
 // Distributed check, per block (see MultiRun::check).  For SA position p = off + i:
@@ -576,7 +674,7 @@ struct MultiRun {
         SortBufs<T> in{const_cast<T*>(key), nullptr, const_cast<T*>(payload)}, o{out.k2.p, nullptr, out.v.p};
         unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
         MG_OP(g, c, class_partition<T>(c, sc, in, o, cls, cnt, starts));
-        for (int d = 0; d < P; ++d) bounds[d] = starts[d];
+        for (int d = 0; d <= P; ++d) bounds[d] = starts[d];       // bounds[P]: start of class P ("to nobody"), cnt if there is none
         return PSACX_OK;
     }
     static int psacx_op_owners(psacx_ctx* c, const T* gi, uint64_t cnt, uint64_t n, uint32_t P, T* out) {
@@ -1034,6 +1132,211 @@ struct MultiRun {
             MG_HIP(g, hipSetDevice(ctx(i)->device));
             MG_HIP(g, hipStreamSynchronize(ctx(i)->stream));
         }
+        return PSACX_OK;
+    }
+
+    // ---------------------------------------------------------------- all nearest smaller values over a block-distributed array
+    // ansv<T, left_type, right_type, global_indexing> (ansv.hpp:2042-2051; gansv_impl :1304-1740 keeps per-rank stacks
+    // and exchanges unmatched prefix minima).  Here every element first searches its own block (the tile kernel of
+    // ansv_tile.hpp); a search that leaves the block goes to the nearest further block whose all-gathered minimum
+    // qualifies and is answered from that block's edge.  furthest_eq = nearest <=, then the first strictly smaller value
+    // beyond it, then back to the first value <= (three searches, ansv_common.hpp:20-22).
+    struct AnsvState { std::vector<const T*> block; std::vector<uint64_t> m; std::vector<Pyramid<T>> pyr; std::vector<DBuf<T>> pyr_mem; std::vector<uint64_t> mins; };
+
+    int ansv_pyramid(int i, const T* block, uint64_t m, Pyramid<T>& Pm, DBuf<T>& mem, uint64_t* block_min) {
+        psacx_ctx* c = ctx(i);
+        Pm = Pyramid<T>();
+        *block_min = ~0ull;
+        if (m == 0) return PSACX_OK;
+        uint64_t total = 0, len = m;
+        while (len > 64) { len = (len + 63) / 64; total += (len + 63) & ~63ull; }
+        MG_OP(g, c, mem.alloc(c, total + 64));
+        Pm.lvl[0] = const_cast<T*>(block); Pm.len[0] = m; Pm.nlev = 1;
+        len = m;
+        uint64_t at = 0;
+        OP_PROLOGUE(c);
+        while (len > 64 && Pm.nlev < PYR_MAX) {
+            len = (len + 63) / 64;
+            Pm.lvl[Pm.nlev] = mem.p + at; Pm.len[Pm.nlev] = len; at += (len + 63) & ~63ull;
+            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, len * 64, 256, 8)), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1],
+                               Pm.len[Pm.nlev - 1], Pm.lvl[Pm.nlev], len);
+            MG_HIP(g, hipGetLastError());
+            Pm.nlev++;
+        }
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(mem.p + at);
+        hipLaunchKernelGGL((top_min_kernel<T>), dim3(1), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1], Pm.len[Pm.nlev - 1], d);
+        MG_HIP(g, hipGetLastError());
+        MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d, 8, hipMemcpyDeviceToHost, c->stream));
+        MG_HIP(g, hipStreamSynchronize(c->stream));
+        *block_min = *reinterpret_cast<uint64_t*>(c->pinned + 32768);
+        return PSACX_OK;
+    }
+
+    // queries (start1 = start + 1, thr) of every local rank sent to rank cls[j] (< P; P = nowhere), answered there from
+    // that rank's block, answers back in query order.  idx / val: all ones / 0 where nothing was found or asked.
+    int ansv_ask(AnsvState& A, const std::vector<const T*>& cls, const std::vector<const T*>& start1, const std::vector<const T*>& thr,
+                 const std::vector<uint64_t>& cnt, bool strict, bool left, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val) {
+        std::vector<Rec<T>> ra(L), rb(L);
+        std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
+        std::vector<std::vector<const T*>> in(L);
+        std::vector<DBuf<T>> slot(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, slot[i].alloc(c, cnt[i]));
+            MG_OP(g, c, psacx_op_iota(c, slot[i].p, cnt[i], 0));
+            std::vector<uint64_t> bnd2;
+            PSACX_TRY(route_by(i, cls[i], start1[i], thr[i], cnt[i], ra[i], bounds[i]));
+            PSACX_TRY(route_by(i, cls[i], start1[i], slot[i].p, cnt[i], rb[i], bnd2));
+            in[i] = {ra[i].k2.p, ra[i].v.p};
+        }
+        // class P ("nowhere") is the tail of the routed arrays: it is simply not sent (bounds[P] = its start)
+        std::vector<std::vector<DBuf<T>>> q, got;
+        PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
+        std::vector<DBuf<T>> ri(L), rv(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            const uint64_t qn = q[i][0].n;
+            MG_OP(g, c, ri[i].alloc(c, qn)); MG_OP(g, c, rv[i].alloc(c, qn));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (nsv_from_enc_kernel<T>), qn, A.pyr[i], A.m[i], S[i].off, q[i][0].p, q[i][1].p, qn, strict ? 1 : 0, left ? 1 : 0, ri[i].p, rv[i].p);
+            b2[i] = prefix_of(rc[i]);
+            in[i] = {ri[i].p, rv[i].p};
+        }
+        PSACX_TRY(exchange<T>(2, in, b2, got, rc2));
+        idx.clear(); idx.resize(L); val.clear(); val.resize(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, idx[i].alloc(c, cnt[i])); MG_OP(g, c, val[i].alloc(c, cnt[i]));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], idx[i].p, cnt[i], (T)~(T)0);
+            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], val[i].p, cnt[i], (T)0);
+            const uint64_t back = got[i][0].n;            // answers come back for the queries that were sent, in routed order
+            MG_OP(g, c, op_put(c, idx[i].p, rb[i].v.p, back, 0, got[i][0].p, 0));
+            MG_OP(g, c, op_put(c, val[i].p, rb[i].v.p, back, 0, got[i][1].p, 0));
+        }
+        return PSACX_OK;
+    }
+
+    // For every query the nearest element strictly beyond start (start1 - 1; -1 and n allowed) with value < thr (strict) or
+    // <= thr, towards lower positions if left.  have_local: idx / val already hold the answers of the block that owns the
+    // start (the tile kernel's pass); otherwise that block is asked first.
+    int ansv_search(AnsvState& A, const std::vector<const T*>& start1, const std::vector<const T*>& thr, const std::vector<uint64_t>& cnt,
+                    bool strict, bool left, bool have_local, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val) {
+        const BlkDist bd = make_dist(n, (unsigned)P);
+        std::vector<DBuf<T>> own(L);
+        std::vector<const T*> cls(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, own[i].alloc(c, cnt[i]));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (ansv_owner_kernel<T>), cnt[i], start1[i], cnt[i], bd, own[i].p);
+            cls[i] = own[i].p;
+        }
+        if (!have_local) PSACX_TRY(ansv_ask(A, cls, start1, thr, cnt, strict, left, idx, val));
+        if (P == 1) return PSACX_OK;
+        RankMins rm, rs;
+        for (int r = 0; r < 64; ++r) { rm.v[r] = r < P ? A.mins[r] : ~0ull; rs.v[r] = r < P ? sizes[r] : 0; }
+        std::vector<DBuf<T>> target(L), edge(L);
+        std::vector<const T*> tp(L), ep(L);
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, target[i].alloc(c, cnt[i])); MG_OP(g, c, edge[i].alloc(c, cnt[i]));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (ansv_target_kernel<T>), cnt[i], own[i].p, thr[i], idx[i].p, cnt[i], rm, rs, P, strict ? 1 : 0, left ? 1 : 0, target[i].p);
+            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], edge[i].p, cnt[i], (T)(left ? n + 1 : 0));     // beyond the target's far edge
+            tp[i] = target[i].p; ep[i] = edge[i].p;
+        }
+        std::vector<DBuf<T>> i2, v2;
+        PSACX_TRY(ansv_ask(A, tp, ep, thr, cnt, strict, left, i2, v2));
+        for (int i = 0; i < L; ++i) {
+            psacx_ctx* c = ctx(i);
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (ansv_merge_kernel<T>), cnt[i], idx[i].p, val[i].p, i2[i].p, v2[i].p, target[i].p, cnt[i], P);
+        }
+        return PSACX_OK;
+    }
+
+    int ansv(const std::vector<const T*>& block, const std::vector<uint64_t>& m_local, int left_type, int right_type, uint64_t nonsv,
+             const std::vector<uint64_t*>& out_left, const std::vector<uint64_t*>& out_right) {
+        if (left_type < 0 || left_type > 2 || right_type < 0 || right_type > 2) return PSACX_EINVAL;
+        S.resize(L);
+        AnsvState A;
+        A.block = block; A.m = m_local; A.pyr.resize(L); A.pyr_mem.resize(L);
+        for (int i = 0; i < L; ++i) {
+            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i];
+            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+        }
+        {
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather1(m_local, all));
+            sizes = all; offs = prefix_of(sizes); n = offs[P];
+            for (int r = 0; r < P; ++r)
+                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
+            for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
+            if (n == 0) return PSACX_EINVAL;
+            if (sizeof(T) == 4 && n > 0xFFFFFFFDull) return PSACX_ERANGE;
+        }
+        std::vector<uint64_t> bm(L);
+        for (int i = 0; i < L; ++i) PSACX_TRY(ansv_pyramid(i, block[i], m_local[i], A.pyr[i], A.pyr_mem[i], &bm[i]));
+        PSACX_TRY(gather1(bm, A.mins));
+        // every element's own position (plus one) as the start of its first search
+        std::vector<DBuf<T>> here(L);
+        std::vector<const T*> herep(L);
+        for (int i = 0; i < L; ++i) {
+            MG_OP(g, ctx(i), here[i].alloc(ctx(i), m_local[i]));
+            MG_OP(g, ctx(i), psacx_op_iota(ctx(i), here[i].p, m_local[i], S[i].off + 1));
+            herep[i] = here[i].p;
+        }
+        for (int side = 0; side < 2; ++side) {
+            const bool left = side == 0;
+            const int typ = left ? left_type : right_type;
+            const std::vector<uint64_t*>& out = left ? out_left : out_right;
+            // first search inside the own block by the tile kernel (it fills both sides; the other side's array is scratch)
+            std::vector<DBuf<T>> idx(L), val(L);
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, idx[i].alloc(c, m_local[i])); MG_OP(g, c, val[i].alloc(c, m_local[i]));
+                if (!m_local[i]) continue;
+                DBuf<uint64_t> other; MG_OP(g, c, other.alloc(c, m_local[i]));
+                const int t1 = typ == 0 ? 0 : 1;                       // strict, or nearest <=
+                MG_HIP(g, hipSetDevice(c->device));
+                if (left) launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], t1, 0, NSV_NONE, out[i], other.p);
+                else launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], 0, t1, NSV_NONE, other.p, out[i]);
+                MG_HIP(g, hipGetLastError());
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (ansv_local_to_idx_kernel<T>), m_local[i], out[i], block[i], m_local[i], S[i].off, idx[i].p, val[i].p);
+            }
+            PSACX_TRY(ansv_search(A, herep, block, m_local, typ == 0, left, true, idx, val));
+            std::vector<DBuf<T>> far(L);
+            if (typ == 2) {
+                // s = first strictly smaller value beyond j (threshold: the value found at j), f = from s back towards i the first value <= it
+                std::vector<DBuf<T>> st2(L), st3(L), si, sv, fv;
+                std::vector<const T*> p2(L), p3(L), u(L);
+                for (int i = 0; i < L; ++i) {
+                    psacx_ctx* c = ctx(i);
+                    MG_OP(g, c, st2[i].alloc(c, m_local[i]));
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], idx[i].p, m_local[i], (T)(left ? n + 1 : 0), st2[i].p);
+                    p2[i] = st2[i].p; u[i] = val[i].p;
+                }
+                PSACX_TRY(ansv_search(A, p2, u, m_local, true, left, false, si, sv));
+                for (int i = 0; i < L; ++i) {
+                    psacx_ctx* c = ctx(i);
+                    MG_OP(g, c, st3[i].alloc(c, m_local[i]));
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], si[i].p, m_local[i], (T)(left ? 0 : n + 1), st3[i].p);
+                    p3[i] = st3[i].p;
+                }
+                PSACX_TRY(ansv_search(A, p3, u, m_local, false, !left, false, far, fv));
+            }
+            for (int i = 0; i < L; ++i) {
+                psacx_ctx* c = ctx(i);
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (ansv_finish_kernel<T>), m_local[i], idx[i].p, typ == 2 ? (const T*)far[i].p : (const T*)idx[i].p, typ == 2 ? 1 : 0,
+                              m_local[i], nonsv, out[i]);
+            }
+        }
+        for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipStreamSynchronize(ctx(i)->stream)); }
         return PSACX_OK;
     }
 

@@ -104,6 +104,15 @@ class MultiContext(object):
         self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_isa), vp(*d_lcp) if d_lcp is not None else None, err))
         return list(err)
 
+    def ansv_device(self, d_in, m, d_left, d_right, index_bits, left_type=0, right_type=0, nonsv=0):
+        """ansv<T, left_type, right_type, global_indexing> over a block-distributed array resident in HBM (lists of raw
+        device addresses, one per local rank; results are uint64 global indices)."""
+        L = self.nlocal
+        vp = C.c_void_p * L
+        mm = (C.c_uint64 * L)(*[int(x) for x in m])
+        fn = getattr(self._lib, "psacx_multi_ansv_dev_u%d" % index_bits)
+        self.check(fn(self.handle, vp(*d_in), mm, int(left_type), int(right_type), int(nonsv), vp(*d_left), vp(*d_right)))
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.psacx_multi_destroy(self.handle)

@@ -269,3 +269,58 @@ def test_bench_and_cli_process_per_gpu_path(tmp_path):
                         "--master-port", "29578", "-m", "psac_amd", "-r", "300000", "-s", "2", "-l", "-c"], capture_output=True, text=True, env=env,
                        cwd=root, timeout=600)
     assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr[-3000:]
+
+
+def test_multi_distributed_ansv():
+    # psacx_multi_ansv_dev_*: ansv<T, left, right, global_indexing> over a block-distributed array, all nine type pairs,
+    # against the oracle's restatement of the reference's result contract (ansv.hpp:48-65, ansv_common.hpp:20-22)
+    import ctypes as C
+    import psac_amd
+    rng = np.random.RandomState(8)
+    text = inputs.dna(200000, 6)
+    ctx1 = psac_amd.Context(0)
+    sa = psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx1)
+    sa.construct(text)
+    lcp = sa.local_LCP.copy()
+    ctx1.close()
+    cases = [(rng.randint(0, 4, size=5000), 32), (rng.randint(0, 10**6, size=70000), 64), (lcp, 32), (np.zeros(3000), 64),
+             (np.arange(5000), 32), (np.arange(9000)[::-1].copy(), 64), (rng.randint(0, 3, size=300001), 32)]
+    for P in (1, 2, 4, 7):
+        mg = multi(P)
+        lib = mg._lib
+        try:
+            for vals, bits in cases:
+                udt = np.uint32 if bits == 32 else np.uint64
+                v = np.ascontiguousarray(vals.astype(udt))
+                n = v.size
+                w = bits // 8
+                none = (1 << 64) - 1
+                sizes = [n // P + (1 if r < n % P else 0) for r in range(P)]
+                offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+                held = []
+
+                def alloc(ctx, nbytes):
+                    p = C.c_void_p()
+                    assert lib.psacx_dev_alloc(ctx, C.byref(p), max(nbytes, 1)) == 0
+                    held.append((ctx, p))
+                    return p.value
+                d_in, d_l, d_r = [], [], []
+                for r in range(P):
+                    ctx = mg.rank_ctx(r)
+                    d_in.append(alloc(ctx, sizes[r] * w)); d_l.append(alloc(ctx, sizes[r] * 8)); d_r.append(alloc(ctx, sizes[r] * 8))
+                    blk = np.ascontiguousarray(v[offs[r]:offs[r + 1]])
+                    assert lib.psacx_copy_h2d(ctx, C.c_void_p(d_in[r]), blk.ctypes.data_as(C.c_void_p), sizes[r] * w) == 0
+                pairs = [(a, b) for a in (0, 1, 2) for b in (0, 1, 2)] if n <= 70000 else [(0, 0), (2, 0), (1, 2)]
+                for lt, rt in pairs:
+                    mg.ansv_device(d_in, sizes, d_l, d_r, bits, lt, rt, none)
+                    Lres = np.empty(n, np.uint64); Rres = np.empty(n, np.uint64)
+                    for r in range(P):
+                        ctx = mg.rank_ctx(r)
+                        lib.psacx_copy_d2h(ctx, Lres[offs[r]:offs[r + 1]].ctypes.data_as(C.c_void_p), C.c_void_p(d_l[r]), sizes[r] * 8)
+                        lib.psacx_copy_d2h(ctx, Rres[offs[r]:offs[r + 1]].ctypes.data_as(C.c_void_p), C.c_void_p(d_r[r]), sizes[r] * 8)
+                    assert np.array_equal(Lres, O.ansv(v, True, lt, none)), (bits, P, lt, n)
+                    assert np.array_equal(Rres, O.ansv(v, False, rt, none)), (bits, P, rt, n)
+                for ctx, p in held:
+                    lib.psacx_dev_free(ctx, p)
+        finally:
+            mg.close()
