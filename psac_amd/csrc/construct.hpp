@@ -375,11 +375,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
     const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !getenv("PSACX_NO_KEY_HIST");
 
-    // In the diet layout the sorted keys must end up in the workspace set x (the other set is the
-    // LCP / ISA output), so an odd number of passes starts from y.
+    // In the diet layout the second record set is the output buffers (y = ISA, LCP, SA).  One stage: both sorted key
+    // words must end up in the workspace set x (word 2 in the LCP buffer would be overwritten while its neighbours are
+    // still being read), so an odd number of passes starts from y.  Two stages: only word 1 and the suffix are sorted;
+    // word 1 may just as well end up in the ISA buffer (it is dead before the inversion writes ISA), and then the suffixes
+    // land in the SA buffer itself instead of being copied there (n w bytes read + written: 13 ms of a 4 GiB / uint64
+    // construction) -- so an even number of passes starts from y.
     const unsigned planned = two_stage ? lead / RADIX_BITS
                                        : (bits_w1 + RADIX_BITS - 1) / RADIX_BITS + (bits_w2 + RADIX_BITS - 1) / RADIX_BITS;
-    const bool start_y = w.diet && (planned & 1u);
+    const bool start_y = w.diet && (two_stage ? !(planned & 1u) : (planned & 1u) != 0);
     SortBufs<T> first_in = start_y ? w.y : w.x, first_alt = start_y ? w.x : w.y;
     // word 2 of every record is sorted along in one stage; with two stages it is not kept at all
     // (the few suffixes that need it read it from the text)
@@ -414,13 +418,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
                                ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
-        if (w.diet) {
-            if (sorted.k1 != w.x.k1) {        // a skipped pass changed the parity
-                PSACX_HIP(c, hipMemcpyAsync(w.x.k1, sorted.k1, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                sorted.k1 = w.x.k1;
-            }
-            if (sorted.v != d_sa) PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        }
+        if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
+            PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         T* const S1 = sorted.k1;
         T* const S2 = w.diet ? w.x.k2 : first_alt.k2;        // word 2 in sorted order, filled for the ties only
         T* const free_k1 = (S1 == w.x.k1) ? w.y.k1 : w.x.k1;

@@ -387,18 +387,38 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
     const unsigned two_k = ks.c1 + ks.c2;
 
+    // Word 2 of a record only matters where word 1 equals a neighbour's (window_lcp looks at it then, and the prefix sort
+    // of the two-stage first round fills it for exactly those records): it is fetched for those records only -- 6 % of
+    // random DNA -- instead of streamed (w of the 5 w bytes per record this kernel moves).  String sets read the string
+    // ends out of it, so they stream it.
+    constexpr bool LAZY2 = !GSA;
     T a1[ITEMS], a2[ITEMS], sa[ITEMS];
     load_run<T, ITEMS>(S1, e0, n, a1, (T)0);
-    load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
+    if (!LAZY2) load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
     load_run<T, ITEMS>(SA, e0, n, sa, (T)0);
     T p1 = 0, p2 = 0, psa = 0;
-    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; p2 = S2[e0 - 1]; psa = SA[e0 - 1]; }
+    bool have_p = false;
+    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; psa = SA[e0 - 1]; have_p = true; if (!LAZY2) p2 = S2[e0 - 1]; }
     else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; psa = bd.prev3; }
+    const bool have_q = e0 + ITEMS <= n && (e0 + ITEMS < n || bd.has_next);
+    const bool q_in = e0 + ITEMS < n;
+    const T q1v = have_q ? (q_in ? S1[e0 + ITEMS] : bd.next1) : (T)0;
+    if (LAZY2) {
+        if (have_p && p1 == a1[0] && e0 < n) p2 = S2[e0 - 1];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool eq_prev = j ? a1[j] == a1[j - 1] : ((have_p || (e0 == 0 && bd.has_prev)) && a1[0] == p1);
+            const bool eq_next = (e0 + j + 1 == n) ? (bd.has_next && a1[j] == bd.next1)          // last record of the block
+                                                   : (j + 1 < ITEMS ? a1[j] == a1[j + 1] : (have_q && a1[j] == q1v));
+            a2[j] = ((eq_prev || eq_next) && e0 + j < n) ? S2[e0 + j] : (T)0;
+        }
+    }
     // head flag of the first record after this run (for the activity test)
     bool next_head = true;
-    if (e0 + ITEMS <= n && (e0 + ITEMS < n || bd.has_next)) {
-        const bool in = e0 + ITEMS < n;
-        const T q1 = in ? S1[e0 + ITEMS] : bd.next1, q2 = in ? S2[e0 + ITEMS] : bd.next2;
+    if (have_q) {
+        const bool in = q_in;
+        const T q1 = q1v;
+        const T q2 = in ? ((!LAZY2 || q1 == a1[ITEMS - 1]) ? S2[e0 + ITEMS] : (T)0) : bd.next2;
         const T qsa = in ? SA[e0 + ITEMS] : bd.next3;
         uint64_t c = window_lcp<T>(a1[ITEMS - 1], a2[ITEMS - 1], q1, q2, ks);
         const uint64_t la = first_round_len<GSA, T>(ng, sa[ITEMS - 1], a1[ITEMS - 1], a2[ITEMS - 1], ks);
