@@ -534,6 +534,37 @@ def test_gsa_reference_vectors(ctx):
             assert np.array_equal(sa.local_B[sa.local_SA.astype(np.int64)], np.arange(sa.n, dtype=sa.dtype))
 
 
+def test_gsa_device_entry_point_and_offset_validation(ctx):
+    # psacx_construct_gsa_dev_*: text and offsets resident in HBM; malformed offsets (not starting at 0, not ending at n,
+    # an empty string) must give PSACX_EINVAL instead of out-of-bounds reads (stringset.hpp:53-72)
+    import ctypes as C
+    strings = [b"ACGTACGT", b"GATTACA", b"ACG", b"TTTTTTTTTT"]
+    text = np.frombuffer(b"".join(strings), np.uint8)
+    n = text.size
+    off = np.zeros(len(strings) + 1, np.uint64); off[1:] = np.cumsum([len(s) for s in strings])
+    d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+    d_off = ctx.alloc(off.nbytes)
+    d_sa, d_isa, d_lcp = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * 8)
+    fn = ctx._lib.psacx_construct_gsa_dev_u64
+
+    def call(o):
+        ctx.h2d(d_off, o)
+        return fn(ctx.handle, C.c_void_p(d_text), n, C.c_void_p(d_off), len(strings), 0, 1, C.c_void_p(d_sa), C.c_void_p(d_isa), C.c_void_p(d_lcp))
+    assert call(off) == 0
+    sa = np.empty(n, np.uint64); lcp = np.empty(n, np.uint64)
+    ctx.d2h(sa, d_sa); ctx.d2h(lcp, d_lcp)
+    ref = O.construct_ss(strings, bits=64)
+    assert np.array_equal(sa, ref["SA"]) and np.array_equal(lcp, ref["LCP"])
+    bad1 = off.copy(); bad1[0] = 1
+    bad2 = off.copy(); bad2[-1] = n - 1
+    bad3 = off.copy(); bad3[2] = bad3[1]
+    bad4 = off.copy(); bad4[2], bad4[3] = off[3], off[2]
+    for bad in (bad1, bad2, bad3, bad4):
+        assert call(bad) == -1
+    for p in (d_text, d_off, d_sa, d_isa, d_lcp):
+        ctx.free(p)
+
+
 def test_gsa_against_oracle(ctx):
     rng = np.random.RandomState(11)
     sets = []
