@@ -116,10 +116,12 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
         "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u%d" % bits, "data": "synthetic",
-        "config": {"workload": "%d MiB %s per GPU (splitmix64 seed %d + rank), %d MiB in total, uint%d indices, "
+        "config": {"workload": "%d MiB %s per GPU (%s), %d MiB in total, uint%d indices, "
                                "SA+%s on %d x MI355X" % (n >> 20, {"dna": "random DNA (sigma 4)", "ascii128": "random ASCII (sigma 128)",
                                                                    "tandem": "period-1024 tandem repeat of random DNA"}[a.alphabet],
-                                                         a.seed, (world * n) >> 20, bits,
+                                                         ("splitmix64 seed %d" % a.seed) if world == 1 else
+                                                         ("rank r holds block r of one splitmix64 stream, seed %d" % a.seed),
+                                                         (world * n) >> 20, bits,
                                                          "ISA" if a.no_lcp else "ISA+LCP", world),
                    "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism},
         "roofline": {"bound": "hbm", "kernel": kname,
@@ -204,6 +206,20 @@ def main_distributed(a, rank, world, local_rank):
                      "ISA scatter, B2 fetch, range minima) on a second stream per GPU")
         out["exchange"] = {"payload_bytes_sent_by_rank0_per_step": sent, "all_to_all_exchanges_per_step": nex,
                            "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl}
+        # for a like-for-like scaling figure: the one-GPU engine on rank 0's block alone (same size, same index width),
+        # timed after the measured region (the N = 1 bench line runs the 4 GiB headline shape instead)
+        try:
+            one = psac_amd.Context(local_rank)
+            sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
+            sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
+            t1 = (time.perf_counter() - t1) / 3
+            out["config"]["one_gpu_engine_same_block"] = {"ms": round(t1 * 1e3, 3), "MChars_per_s": round(n / t1 / 1e6, 1)}
+            one.close()
+        except Exception as e:          # never let the side measurement break the bench line
+            out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
         print(json.dumps(out))
     for p in (d_text, d_sa, d_isa, d_lcp):
         lib.psacx_dev_free(ctx, C.c_void_p(p))
