@@ -28,7 +28,10 @@
 #include <rccl/rccl.h>          // types and prototypes only: librccl is opened with dlopen when a communicator is needed
 
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 
 #include "dist_ops.hpp"
 #include "ansv_tile.hpp"
@@ -78,11 +81,61 @@ struct MRank {
 
 constexpr int PSACX_MULTI_EPEER = -7;     // RCCL failure
 
+namespace psacx {
+// one worker thread per local rank, alive as long as the communicator
+struct RankPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    const std::function<int(int)>* job = nullptr;
+    const std::function<void(int)>* prep = nullptr;
+    uint64_t gen = 0;
+    int pending = 0;
+    std::vector<int> rc;
+    bool stop = false;
+    int run(int n, const std::function<int(int)>& f, const std::function<void(int)>& p) {
+        std::unique_lock<std::mutex> lk(mu);
+        if ((int)th.size() != n) {
+            rc.assign(n, 0);
+            for (int i = (int)th.size(); i < n; ++i) th.emplace_back([this, i]() { work(i); });
+        }
+        job = &f; prep = &p; pending = n; ++gen;
+        cv_job.notify_all();
+        cv_done.wait(lk, [this]() { return pending == 0; });
+        for (int i = 0; i < n; ++i) if (rc[i] != 0) return rc[i];
+        return 0;
+    }
+    void work(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<int(int)>* f; const std::function<void(int)>* p;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&]() { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job; p = prep;
+            }
+            (*p)(i);
+            const int r = (*f)(i);
+            std::unique_lock<std::mutex> lk(mu);
+            rc[i] = r;
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    ~RankPool() {
+        { std::unique_lock<std::mutex> lk(mu); stop = true; cv_job.notify_all(); }
+        for (auto& t : th) t.join();
+    }
+};
+} // namespace psacx
+
 struct psacx_multi {
     int nranks = 0, nlocal = 0, first = 0;
     bool use_rccl = false;
     std::vector<psacx::MRank> R;
     std::string err;
+    std::mutex err_mu;
+    psacx::RankPool pool;
     psacx_stats stats;
     uint64_t bytes_sent = 0;          // payload bytes this process sent to other ranks in the last call
     uint64_t n_exchanges = 0, n_gathers = 0;
@@ -90,12 +143,13 @@ struct psacx_multi {
 
 namespace psacx {
 
+inline void mg_set_err(psacx_multi* g, const std::string& m) { std::lock_guard<std::mutex> lk(g->err_mu); g->err = m; }
 #define MG_HIP(g, call)                                                                   \
-    do { hipError_t e__ = (call); if (e__ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e__); return PSACX_EHIP; } } while (0)
+    do { hipError_t e__ = (call); if (e__ != hipSuccess) { mg_set_err(g, std::string(#call) + ": " + hipGetErrorString(e__)); return PSACX_EHIP; } } while (0)
 #define MG_NCCL(g, call)                                                                  \
-    do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (g)->err = std::string(#call) + ": " + rccl().GetErrorString(r__); return PSACX_MULTI_EPEER; } } while (0)
+    do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { mg_set_err(g, std::string(#call) + ": " + rccl().GetErrorString(r__)); return PSACX_MULTI_EPEER; } } while (0)
 #define MG_OP(g, c, call)                                                                 \
-    do { int rc__ = (call); if (rc__ != PSACX_OK) { (g)->err = std::string(#call) + ": " + psacx_strerror(rc__) + " [" + (c)->hip_err + "]"; return rc__; } } while (0)
+    do { int rc__ = (call); if (rc__ != PSACX_OK) { mg_set_err(g, std::string(#call) + ": " + psacx_strerror(rc__) + " [" + (c)->hip_err + "]"); return rc__; } } while (0)
 
 // device array owned by one rank; blocks come from and return to the rank's cache (engine.hpp: pool_alloc)
 template <typename E> struct DBuf {
@@ -324,6 +378,13 @@ struct MultiRun {
         t_last_ = std::chrono::steady_clock::now();
     }
     psacx_ctx* ctx(int i) const { return g->R[i].ctx; }
+    // body(i) for every local rank.  The step ops synchronise their stream with the host, so a single host thread would
+    // run the GPUs of a one-process communicator one after the other: every local rank has its own worker thread, the
+    // collectives in between stay on the calling thread.
+    int par(const std::function<int(int)>& body) {
+        if (L == 1) return body(0);
+        return g->pool.run(L, body, [this](int i) { (void)hipSetDevice(g->R[i].ctx->device); });
+    }
     int rank(int i) const { return g->R[i].grank; }
 
     // ---------------------------------------------------------------- collectives
@@ -518,8 +579,8 @@ struct MultiRun {
     int neighbours(const std::vector<const T*>& a1, const std::vector<const T*>& a2, const std::vector<const T*>& a3,
                    const std::vector<uint64_t>& cnt, int words, std::vector<psacx_boundary>& bd) {
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(7, 0));
-        for (int i = 0; i < L; ++i) {
-            if (!cnt[i]) continue;
+        PSACX_TRY(par([&](int i) -> int {
+            if (!cnt[i]) return PSACX_OK;
             mine[i][0] = 1;
             const T* arr[3] = {a1[i], a2[i], a3[i]};
             for (int w = 0; w < words; ++w) {
@@ -527,7 +588,8 @@ struct MultiRun {
                 PSACX_TRY(fetch(i, arr[w], {0, cnt[i] - 1}, o));
                 mine[i][1 + w] = o[0]; mine[i][4 + w] = o[1];
             }
-        }
+            return PSACX_OK;
+        }));
         std::vector<uint64_t> all;
         PSACX_TRY(gather(7, mine, all));
         bd.assign(L, psacx_boundary());
@@ -548,7 +610,7 @@ struct MultiRun {
         constexpr int SAMPLES = 256;
         // regular samples of the local records, made unique by (rank, index) so that ties are divided
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + 3 * SAMPLES, 0));
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             const uint64_t c = rec[i].cnt;
             std::vector<uint64_t> pos;
             for (int s = 0; s < SAMPLES && c; ++s) { const uint64_t p = (uint64_t)(((unsigned __int128)c * (2 * s + 1)) / (2 * SAMPLES)); if (pos.empty() || pos.back() != p) pos.push_back(p); }
@@ -557,7 +619,8 @@ struct MultiRun {
             PSACX_TRY(fetch(i, rec[i].k2.p, pos, b));
             mine[i][0] = pos.size();
             for (size_t s = 0; s < pos.size(); ++s) { mine[i][1 + 3 * s] = a[s]; mine[i][2 + 3 * s] = b[s]; mine[i][3 + 3 * s] = pos[s]; }
-        }
+            return PSACX_OK;
+        }));
         std::vector<uint64_t> all;
         PSACX_TRY(gather(1 + 3 * SAMPLES, mine, all));
         struct Smp { uint64_t k1, k2, r, p; bool operator<(const Smp& o) const { return k1 != o.k1 ? k1 < o.k1 : k2 != o.k2 ? k2 < o.k2 : r != o.r ? r < o.r : p < o.p; }
@@ -579,7 +642,7 @@ struct MultiRun {
         std::vector<Rec<T>> grp(L);
         std::vector<std::vector<uint64_t>> bounds(L);
         std::vector<std::vector<const T*>> in(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             const uint64_t cn = rec[i].cnt;
             MG_OP(g, c, grp[i].k1.alloc(c, cn)); MG_OP(g, c, grp[i].k2.alloc(c, cn)); MG_OP(g, c, grp[i].v.alloc(c, cn));
@@ -590,20 +653,22 @@ struct MultiRun {
             for (uint32_t d = 0; d <= ns; ++d) bounds[i][d] = cs[d];
             rec[i].k1.release(); rec[i].k2.release(); rec[i].v.release();
             in[i] = {grp[i].k1.p, grp[i].k2.p, grp[i].v.p};
-        }
+            return PSACX_OK;
+        }));
         mark("    sort: samples + partition");
         std::vector<std::vector<DBuf<T>>> got;
         std::vector<std::vector<uint64_t>> rc;
         PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
         mark("    sort: shuffle");
         std::vector<uint64_t> c2(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             grp[i] = Rec<T>();
             rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
             rec[i].cnt = c2[i] = rec[i].k1.n;
             if (first_round) PSACX_TRY(local_sort_first(i, rec[i], bits1, bits2));
             else PSACX_TRY(local_sort(i, rec[i], bits1, bits2));
-        }
+            return PSACX_OK;
+        }));
         mark("    sort: local sort");
         // exact re-balance: the j-th record of rank r has global index G[r] + j
         std::vector<uint64_t> counts;
@@ -702,14 +767,15 @@ struct MultiRun {
             PSACX_TRY(exchange<T>(2, in, bounds, got, rc));
             for (int i = 0; i < L; ++i) { gi[i] = got[i][0].p; vi[i] = got[i][1].p; rc_tot[i] = got[i][0].n; }
         }
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             if (permutation && delta == -1 && rc_tot[i]) {
                 DBuf<T> s[4];
                 for (int q = 0; q < 4; ++q) MG_OP(g, c, s[q].alloc(c, rc_tot[i]));
                 MG_OP(g, c, op_put_perm<T>(c, block[i], gi[i], rc_tot[i], S[i].off, vi[i], s[0].p, s[1].p, s[2].p, s[3].p));
             } else MG_OP(g, c, op_put(c, block[i], gi[i], rc_tot[i], S[i].off, vi[i], delta));
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 
@@ -725,30 +791,33 @@ struct MultiRun {
         std::vector<Rec<T>> routed(L);
         std::vector<std::vector<uint64_t>> bounds(L), rc, rc2;
         std::vector<std::vector<const T*>> in(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             DBuf<T> idx; MG_OP(g, c, idx.alloc(c, cnt[i]));
             MG_OP(g, c, psacx_op_iota(c, idx.p, cnt[i], 0));
             PSACX_TRY(route(i, gidx[i], idx.p, cnt[i], routed[i], bounds[i]));
             in[i] = {routed[i].k2.p};
-        }
+            return PSACX_OK;
+        }));
         std::vector<std::vector<DBuf<T>>> q, got;
         PSACX_TRY(exchange<T>(1, in, bounds, q, rc));
         std::vector<DBuf<T>> ans(L);
         std::vector<std::vector<uint64_t>> back_bounds(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, ans[i].alloc(c, q[i][0].n));
             MG_OP(g, c, op_take(c, block[i], q[i][0].p, q[i][0].n, S[i].off, n, ans[i].p));
             back_bounds[i] = prefix_of(rc[i]);
             in[i] = {ans[i].p};
-        }
+            return PSACX_OK;
+        }));
         PSACX_TRY(exchange<T>(1, in, back_bounds, got, rc2));
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, out[i].alloc(c, cnt[i]));
             MG_OP(g, c, op_put(c, out[i].p, routed[i].v.p, cnt[i], 0, got[i][0].p, 0));      // undo the routing permutation
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
     static int psacx_op_iota(psacx_ctx* c, T* out, uint64_t m, uint64_t start) {
@@ -772,20 +841,21 @@ struct MultiRun {
         PSACX_TRY(gather1(bm, mins));
         // own1/lo1/hi1: the part inside the rank of lo; own2/lo2/hi2: the part inside the rank of hi - 1; ra/rb: whole ranks between
         std::vector<std::vector<DBuf<T>>> parts(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             parts[i].resize(8);
             for (int q = 0; q < 8; ++q) MG_OP(g, c, parts[i][q].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (rmq_split_kernel<T>), cnt[i], lo[i], hi[i], cnt[i], make_dist(n, (unsigned)P), parts[i][0].p, parts[i][1].p, parts[i][2].p,
                           parts[i][3].p, parts[i][4].p, parts[i][5].p, parts[i][6].p, parts[i][7].p);
-        }
+            return PSACX_OK;
+        }));
         std::vector<std::vector<DBuf<T>>> answers(2);
         for (int half = 0; half < 2; ++half) {
             std::vector<Rec<T>> ra(L), rb(L);
             std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
             std::vector<std::vector<const T*>> in(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const T* a = parts[i][3 * half + 1].p; const T* b = parts[i][3 * half + 2].p;
                 // route by the owner of the sub-range's lower end: (a, b) and (a, slot) through the same stable pass
@@ -795,34 +865,38 @@ struct MultiRun {
                 PSACX_TRY(route_by(i, parts[i][3 * half].p, a, b, cnt[i], ra[i], bounds[i]));
                 PSACX_TRY(route_by(i, parts[i][3 * half].p, a, slot.p, cnt[i], rb[i], bnd2));
                 in[i] = {ra[i].k2.p, ra[i].v.p};
-            }
+                return PSACX_OK;
+            }));
             std::vector<std::vector<DBuf<T>>> q, got;
             PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
             std::vector<DBuf<T>> res(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, res[i].alloc(c, q[i][0].n));
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (range_min_kernel<T>), q[i][0].n, pyr[i], q[i][0].p, q[i][1].p, q[i][0].n, S[i].off, res[i].p);
                 b2[i] = prefix_of(rc[i]);
                 in[i] = {res[i].p};
-            }
+                return PSACX_OK;
+            }));
             PSACX_TRY(exchange<T>(1, in, b2, got, rc2));
             answers[half].resize(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, answers[half][i].alloc(c, cnt[i]));
                 MG_OP(g, c, op_put(c, answers[half][i].p, rb[i].v.p, cnt[i], 0, got[i][0].p, 0));
-            }
+                return PSACX_OK;
+            }));
         }
         RankMins rm;
         for (int r = 0; r < 64; ++r) rm.v[r] = r < P ? mins[r] : ~0ull;
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, out[i].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (rmq_combine_kernel<T>), cnt[i], answers[0][i].p, answers[1][i].p, parts[i][6].p, parts[i][7].p, cnt[i], rm, out[i].p);
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 
@@ -866,15 +940,16 @@ struct MultiRun {
         std::memset(&st, 0, sizeof(st));
         g->bytes_sent = 0; g->n_exchanges = 0; g->n_gathers = 0;
         S.resize(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
             S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = want_lcp ? d_lcp[i] : nullptr;
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-        }
+            return PSACX_OK;
+        }));
         // sizes + alphabet (alphabet.hpp:98: allreduce of the character histograms)
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(257, 0));
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 DBuf<uint64_t> h; MG_OP(g, c, h.alloc(c, 256));
                 MG_OP(g, c, psacx_op_char_hist(c, text[i], S[i].m, h.p));
@@ -882,7 +957,8 @@ struct MultiRun {
                 MG_HIP(g, hipStreamSynchronize(c->stream));
                 mine[i][0] = S[i].m;
                 std::memcpy(&mine[i][1], c->pinned + 32768, 256 * 8);
-            }
+                return PSACX_OK;
+            }));
             std::vector<uint64_t> all;
             PSACX_TRY(gather(257, mine, all));
             sizes.assign(P, 0);
@@ -935,14 +1011,15 @@ struct MultiRun {
                 }
                 PSACX_TRY(exchange<uint8_t>(1, in, bounds, got, rc));
             }
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, tbuf[i].alloc(c, S[i].m + two_k));
                 MG_HIP(g, hipSetDevice(c->device));
                 MG_HIP(g, hipMemsetAsync(tbuf[i].p + S[i].m, 0, two_k, c->stream));
                 MG_HIP(g, hipMemcpyAsync(tbuf[i].p, text[i], S[i].m, hipMemcpyDeviceToDevice, c->stream));
                 if (P > 1 && got[i][0].n) MG_HIP(g, hipMemcpyAsync(tbuf[i].p + S[i].m, got[i][0].p, std::min<uint64_t>(got[i][0].n, two_k), hipMemcpyDeviceToDevice, c->stream));
-            }
+                return PSACX_OK;
+            }));
         }
         // ---- first-round keys; the suffixes shorter than 2k (the last 2k - 1 positions) are moved to the very front
         //      of the record order (rank 0, shortest first): see key_pairs_kernel for why that replaces the end marker
@@ -951,7 +1028,7 @@ struct MultiRun {
         {
             std::vector<Rec<T>> tails(L);
             std::vector<uint64_t> mine_cnt(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
                 MG_OP(g, c, rec[i].k1.alloc(c, front + m)); MG_OP(g, c, rec[i].k2.alloc(c, front + m)); MG_OP(g, c, rec[i].v.alloc(c, front + m));
@@ -970,7 +1047,8 @@ struct MultiRun {
                     }
                 }
                 rec[i].cnt = front + m - mine;
-            }
+                return PSACX_OK;
+            }));
             tbuf.clear();
             // everything to rank 0, which places the pieces of higher ranks first
             std::vector<std::vector<DBuf<T>>> got;
@@ -981,8 +1059,8 @@ struct MultiRun {
                 for (int i = 0; i < L; ++i) { bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0; in[i] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p}; }
                 PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
             }
-            for (int i = 0; i < L; ++i) {
-                if (rank(i) != 0) continue;
+            PSACX_TRY(par([&](int i) -> int {
+                if (rank(i) != 0) return PSACX_OK;
                 psacx_ctx* c = ctx(i);
                 MG_HIP(g, hipSetDevice(c->device));
                 T* dst[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
@@ -998,7 +1076,8 @@ struct MultiRun {
                         at += len;
                     }
                 }
-            }
+                return PSACX_OK;
+            }));
             // (the pieces are consumed before `got` and `tails` go out of scope: stream order)
         }
         mark("keys");
@@ -1013,14 +1092,15 @@ struct MultiRun {
             PSACX_TRY(neighbours(a1, a2, a3, cn, 3, bd));
         }
         std::vector<uint64_t> lh(L), heads;
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             bd[i].off = S[i].off; bd[i].base = 0;
             psacx_boundary b0 = bd[i]; b0.has_next = 0;
             MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 0, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &b0, &lh[i]));
-        }
+            return PSACX_OK;
+        }));
         PSACX_TRY(gather1(lh, heads));
         std::vector<uint64_t> nact(L), nunf(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             uint64_t base = 0;
             for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
@@ -1029,7 +1109,8 @@ struct MultiRun {
             MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], S[i].Bsa.p, S[i].LCP, &nact[i], &nunf[i]));
             MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             rec[i] = Rec<T>();
-        }
+            return PSACX_OK;
+        }));
         mark("rebucket");
         // ---- SA -> ISA (bulk_permute.hpp:14-73), overlapped on the second streams with the bookkeeping below
         {
@@ -1052,7 +1133,7 @@ struct MultiRun {
             // B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
             std::vector<DBuf<T>> q(L);
             rec.clear(); rec.resize(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 rec[i].cnt = cnt[i];
                 MG_OP(g, c, rec[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rec[i].v.alloc(c, cnt[i])); MG_OP(g, c, q[i].alloc(c, cnt[i]));
@@ -1060,18 +1141,20 @@ struct MultiRun {
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], rec[i].v.p, cnt[i], h, n, q[i].p);      // saturates at n
                 MG_OP(g, c, op_take(c, S[i].Bsa.p, S[i].pos.p, cnt[i], S[i].off, n, rec[i].k1.p));
-            }
+                return PSACX_OK;
+            }));
             {
                 std::vector<const T*> blk(L), gi(L);
                 for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q[i].p; }
                 std::vector<DBuf<T>> ans;
                 PSACX_TRY(dist_take(blk, gi, cnt, ans));
-                for (int i = 0; i < L; ++i) {
+                PSACX_TRY(par([&](int i) -> int {
                     psacx_ctx* c = ctx(i);
                     MG_OP(g, c, rec[i].k2.alloc(c, cnt[i]));
                     OP_PROLOGUE(c);
                     SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
-                }
+                    return PSACX_OK;
+                }));
             }
             q.clear();
             mark("  B2 fetch");
@@ -1082,15 +1165,16 @@ struct MultiRun {
                 for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; }
                 PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
             }
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 bd[i].off = 0; bd[i].base = 0;
                 psacx_boundary b0 = bd[i]; b0.has_next = 0;
                 MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 1, rec[i].k1.p, rec[i].k2.p, S[i].pos.p, cnt[i], 0, 1, 1, 0, &b0, &lh[i]));
-            }
+                return PSACX_OK;
+            }));
             PSACX_TRY(gather1(lh, heads));
             std::vector<DBuf<T>> ids(L), qa(L), ql(L), qh(L);
             std::vector<uint64_t> nq(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 uint64_t base = 0;
                 for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
@@ -1098,7 +1182,8 @@ struct MultiRun {
                 MG_OP(g, c, ids[i].alloc(c, cnt[i])); MG_OP(g, c, qa[i].alloc(c, cnt[i])); MG_OP(g, c, ql[i].alloc(c, cnt[i])); MG_OP(g, c, qh[i].alloc(c, cnt[i]));
                 MG_OP(g, c, op_rebucket_refine<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, S[i].pos.p, cnt[i], n, h, &bd[i], S[i].SA, S[i].Bsa.p,
                                                   S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i]));
-            }
+                return PSACX_OK;
+            }));
             {
                 std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L);
                 for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = rec[i].v.p; va[i] = ids[i].p; }
@@ -1110,11 +1195,12 @@ struct MultiRun {
                 for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
                 std::vector<DBuf<T>> mins;
                 PSACX_TRY(dist_range_min(lo, hi, nq, mins));
-                for (int i = 0; i < L; ++i) {
+                PSACX_TRY(par([&](int i) -> int {
                     psacx_ctx* c = ctx(i);
                     OP_PROLOGUE(c);
                     SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
-                }
+                    return PSACX_OK;
+                }));
             }
             mark("  range minima");
             rec.clear(); rec.resize(L);
@@ -1127,11 +1213,12 @@ struct MultiRun {
                 for (int r = 0; r < P; ++r) rr.active += counts[r];
             }
         }
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             S[i].Bsa.release(); S[i].pos.release();
             MG_HIP(g, hipSetDevice(ctx(i)->device));
             MG_HIP(g, hipStreamSynchronize(ctx(i)->stream));
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 
@@ -1180,7 +1267,7 @@ struct MultiRun {
         std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
         std::vector<std::vector<const T*>> in(L);
         std::vector<DBuf<T>> slot(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, slot[i].alloc(c, cnt[i]));
             MG_OP(g, c, psacx_op_iota(c, slot[i].p, cnt[i], 0));
@@ -1188,12 +1275,13 @@ struct MultiRun {
             PSACX_TRY(route_by(i, cls[i], start1[i], thr[i], cnt[i], ra[i], bounds[i]));
             PSACX_TRY(route_by(i, cls[i], start1[i], slot[i].p, cnt[i], rb[i], bnd2));
             in[i] = {ra[i].k2.p, ra[i].v.p};
-        }
+            return PSACX_OK;
+        }));
         // class P ("nowhere") is the tail of the routed arrays: it is simply not sent (bounds[P] = its start)
         std::vector<std::vector<DBuf<T>>> q, got;
         PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
         std::vector<DBuf<T>> ri(L), rv(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             const uint64_t qn = q[i][0].n;
             MG_OP(g, c, ri[i].alloc(c, qn)); MG_OP(g, c, rv[i].alloc(c, qn));
@@ -1201,10 +1289,11 @@ struct MultiRun {
             SIMPLE_LAUNCH(c, (nsv_from_enc_kernel<T>), qn, A.pyr[i], A.m[i], S[i].off, q[i][0].p, q[i][1].p, qn, strict ? 1 : 0, left ? 1 : 0, ri[i].p, rv[i].p);
             b2[i] = prefix_of(rc[i]);
             in[i] = {ri[i].p, rv[i].p};
-        }
+            return PSACX_OK;
+        }));
         PSACX_TRY(exchange<T>(2, in, b2, got, rc2));
         idx.clear(); idx.resize(L); val.clear(); val.resize(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, idx[i].alloc(c, cnt[i])); MG_OP(g, c, val[i].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
@@ -1213,7 +1302,8 @@ struct MultiRun {
             const uint64_t back = got[i][0].n;            // answers come back for the queries that were sent, in routed order
             MG_OP(g, c, op_put(c, idx[i].p, rb[i].v.p, back, 0, got[i][0].p, 0));
             MG_OP(g, c, op_put(c, val[i].p, rb[i].v.p, back, 0, got[i][1].p, 0));
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 
@@ -1225,34 +1315,37 @@ struct MultiRun {
         const BlkDist bd = make_dist(n, (unsigned)P);
         std::vector<DBuf<T>> own(L);
         std::vector<const T*> cls(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, own[i].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (ansv_owner_kernel<T>), cnt[i], start1[i], cnt[i], bd, own[i].p);
             cls[i] = own[i].p;
-        }
+            return PSACX_OK;
+        }));
         if (!have_local) PSACX_TRY(ansv_ask(A, cls, start1, thr, cnt, strict, left, idx, val));
         if (P == 1) return PSACX_OK;
         RankMins rm, rs;
         for (int r = 0; r < 64; ++r) { rm.v[r] = r < P ? A.mins[r] : ~0ull; rs.v[r] = r < P ? sizes[r] : 0; }
         std::vector<DBuf<T>> target(L), edge(L);
         std::vector<const T*> tp(L), ep(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, target[i].alloc(c, cnt[i])); MG_OP(g, c, edge[i].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (ansv_target_kernel<T>), cnt[i], own[i].p, thr[i], idx[i].p, cnt[i], rm, rs, P, strict ? 1 : 0, left ? 1 : 0, target[i].p);
             SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], edge[i].p, cnt[i], (T)(left ? n + 1 : 0));     // beyond the target's far edge
             tp[i] = target[i].p; ep[i] = edge[i].p;
-        }
+            return PSACX_OK;
+        }));
         std::vector<DBuf<T>> i2, v2;
         PSACX_TRY(ansv_ask(A, tp, ep, thr, cnt, strict, left, i2, v2));
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (ansv_merge_kernel<T>), cnt[i], idx[i].p, val[i].p, i2[i].p, v2[i].p, target[i].p, cnt[i], P);
-        }
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 
@@ -1262,10 +1355,11 @@ struct MultiRun {
         S.resize(L);
         AnsvState A;
         A.block = block; A.m = m_local; A.pyr.resize(L); A.pyr_mem.resize(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i];
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-        }
+            return PSACX_OK;
+        }));
         {
             std::vector<uint64_t> all;
             PSACX_TRY(gather1(m_local, all));
@@ -1282,21 +1376,22 @@ struct MultiRun {
         // every element's own position (plus one) as the start of its first search
         std::vector<DBuf<T>> here(L);
         std::vector<const T*> herep(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             MG_OP(g, ctx(i), here[i].alloc(ctx(i), m_local[i]));
             MG_OP(g, ctx(i), psacx_op_iota(ctx(i), here[i].p, m_local[i], S[i].off + 1));
             herep[i] = here[i].p;
-        }
+            return PSACX_OK;
+        }));
         for (int side = 0; side < 2; ++side) {
             const bool left = side == 0;
             const int typ = left ? left_type : right_type;
             const std::vector<uint64_t*>& out = left ? out_left : out_right;
             // first search inside the own block by the tile kernel (it fills both sides; the other side's array is scratch)
             std::vector<DBuf<T>> idx(L), val(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, idx[i].alloc(c, m_local[i])); MG_OP(g, c, val[i].alloc(c, m_local[i]));
-                if (!m_local[i]) continue;
+                if (!m_local[i]) return PSACX_OK;
                 DBuf<uint64_t> other; MG_OP(g, c, other.alloc(c, m_local[i]));
                 const int t1 = typ == 0 ? 0 : 1;                       // strict, or nearest <=
                 MG_HIP(g, hipSetDevice(c->device));
@@ -1305,36 +1400,40 @@ struct MultiRun {
                 MG_HIP(g, hipGetLastError());
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (ansv_local_to_idx_kernel<T>), m_local[i], out[i], block[i], m_local[i], S[i].off, idx[i].p, val[i].p);
-            }
+                return PSACX_OK;
+            }));
             PSACX_TRY(ansv_search(A, herep, block, m_local, typ == 0, left, true, idx, val));
             std::vector<DBuf<T>> far(L);
             if (typ == 2) {
                 // s = first strictly smaller value beyond j (threshold: the value found at j), f = from s back towards i the first value <= it
                 std::vector<DBuf<T>> st2(L), st3(L), si, sv, fv;
                 std::vector<const T*> p2(L), p3(L), u(L);
-                for (int i = 0; i < L; ++i) {
+                PSACX_TRY(par([&](int i) -> int {
                     psacx_ctx* c = ctx(i);
                     MG_OP(g, c, st2[i].alloc(c, m_local[i]));
                     OP_PROLOGUE(c);
                     SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], idx[i].p, m_local[i], (T)(left ? n + 1 : 0), st2[i].p);
                     p2[i] = st2[i].p; u[i] = val[i].p;
-                }
+                    return PSACX_OK;
+                }));
                 PSACX_TRY(ansv_search(A, p2, u, m_local, true, left, false, si, sv));
-                for (int i = 0; i < L; ++i) {
+                PSACX_TRY(par([&](int i) -> int {
                     psacx_ctx* c = ctx(i);
                     MG_OP(g, c, st3[i].alloc(c, m_local[i]));
                     OP_PROLOGUE(c);
                     SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], si[i].p, m_local[i], (T)(left ? 0 : n + 1), st3[i].p);
                     p3[i] = st3[i].p;
-                }
+                    return PSACX_OK;
+                }));
                 PSACX_TRY(ansv_search(A, p3, u, m_local, false, !left, false, far, fv));
             }
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (ansv_finish_kernel<T>), m_local[i], idx[i].p, typ == 2 ? (const T*)far[i].p : (const T*)idx[i].p, typ == 2 ? 1 : 0,
                               m_local[i], nonsv, out[i]);
-            }
+                return PSACX_OK;
+            }));
         }
         for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipStreamSynchronize(ctx(i)->stream)); }
         return PSACX_OK;
@@ -1351,11 +1450,12 @@ struct MultiRun {
         want_lcp = with_lcp;
         S.resize(L);
         for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); pool_flush(ctx(i)); }     // the checker wants different sizes than the construction left cached
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
             S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = with_lcp ? d_lcp[i] : nullptr;
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-        }
+            return PSACX_OK;
+        }));
         {
             std::vector<uint64_t> all;
             PSACX_TRY(gather1(m_local, all));
@@ -1368,14 +1468,15 @@ struct MultiRun {
         std::vector<uint64_t> cnt(L);
         std::vector<const T*> blk(L), gi(L);
         std::vector<DBuf<T>> wide(L), q1(L), back, ch, nx;
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             cnt[i] = S[i].m;
             MG_OP(g, c, wide[i].alloc(c, S[i].m)); MG_OP(g, c, q1[i].alloc(c, S[i].m));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
             SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), S[i].m, S[i].SA, S[i].m, (uint64_t)1, n, q1[i].p);
-        }
+            return PSACX_OK;
+        }));
         for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; }
         PSACX_TRY(dist_take(blk, gi, cnt, back));
         for (int i = 0; i < L; ++i) { blk[i] = wide[i].p; }
@@ -1393,18 +1494,19 @@ struct MultiRun {
         if (with_lcp) {
             std::vector<DBuf<T>> qlo(L), qhi(L);
             std::vector<const T*> lo(L), hi(L);
-            for (int i = 0; i < L; ++i) {
+            PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, qlo[i].alloc(c, cnt[i])); MG_OP(g, c, qhi[i].alloc(c, cnt[i]));
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (check_queries_kernel<T>), cnt[i], S[i].SA, ch[i].p, nx[i].p, cnt[i], n, bd[i].has_prev, (T)bd[i].prev[0],
                               (T)bd[i].prev[1], (T)bd[i].prev[2], qlo[i].p, qhi[i].p);
                 lo[i] = qlo[i].p; hi[i] = qhi[i].p;
-            }
+                return PSACX_OK;
+            }));
             PSACX_TRY(dist_range_min(lo, hi, cnt, mins));
         }
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(4, 0));
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             DBuf<unsigned long long> e; MG_OP(g, c, e.alloc(c, 4));
             MG_HIP(g, hipMemsetAsync(e.p, 0, 32, c->stream));
@@ -1415,7 +1517,8 @@ struct MultiRun {
             MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, e.p, 32, hipMemcpyDeviceToHost, c->stream));
             MG_HIP(g, hipStreamSynchronize(c->stream));
             std::memcpy(mine[i].data(), c->pinned + 32768, 32);
-        }
+            return PSACX_OK;
+        }));
         std::vector<uint64_t> all;
         PSACX_TRY(gather(4, mine, all));
         for (int q = 0; q < 4; ++q) { errors[q] = 0; for (int r = 0; r < P; ++r) errors[q] += all[(size_t)r * 4 + q]; }
@@ -1427,7 +1530,7 @@ struct MultiRun {
     int next_active(std::vector<DBuf<T>>* ids, const std::vector<uint64_t>& nact, const std::vector<uint64_t>& nunf, uint64_t* unf_b, uint64_t* unf_e) {
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(5, 0));
         std::vector<uint64_t> cnt(L);
-        for (int i = 0; i < L; ++i) {
+        PSACX_TRY(par([&](int i) -> int {
             const T* a = ids ? (*ids)[i].p : S[i].Bsa.p;
             cnt[i] = ids ? (*ids)[i].n : S[i].m;
             if (cnt[i]) {
@@ -1436,7 +1539,8 @@ struct MultiRun {
                 mine[i][0] = 1; mine[i][1] = o[0]; mine[i][2] = o[1];
             }
             mine[i][3] = nact[i]; mine[i][4] = nunf[i];
-        }
+            return PSACX_OK;
+        }));
         std::vector<uint64_t> all;
         PSACX_TRY(gather(5, mine, all));
         *unf_b = *unf_e = 0;
