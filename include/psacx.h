@@ -270,6 +270,26 @@ int psacx_multi_ansv_dev_u64(psacx_multi* mg, const uint64_t* const* d_in, const
 /* statistics of the last call (sigma, k, the per-round log) and what this process moved: payload bytes sent to other
  * ranks, number of all-to-all exchanges and of scalar all-gathers */
 int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* bytes_sent, uint64_t* exchanges, uint64_t* gathers);
+/* Memory layout of the distributed construction.  psac plans "6 words per character" for its distributed sort
+ * (idxsort.hpp:43, suffix_array.hpp:751).  The normal layout here keeps every intermediate array of a phase at once
+ * (fastest; up to ~14 words per character beside the three result arrays).  The reduced-memory layout lets the records of
+ * the first round alternate between the rank's three result arrays and ONE allocated set of three arrays, runs SA -> ISA in
+ * chunks, and works a refinement round with more unresolved suffixes than SLAB on some rank off in slabs of whole buckets
+ * (results identical; the per-round counters of such a round may run ahead of the one-step log).
+ *   PSACX_MULTI_OPT_LAYOUT        0 = choose by the free device memory of every rank (default), 1 = normal, 2 = reduced
+ *   PSACX_MULTI_OPT_SLAB          unresolved suffixes per slab and rank (0 = block size / 16)
+ *   PSACX_MULTI_OPT_OUTPUT_SLACK  the d_SA / d_ISA / d_LCP arrays handed to psacx_multi_construct_dev_* hold this many
+ *                                 elements MORE than the block (m / 8 + 256 lets every rank use them as record arrays
+ *                                 despite the sample sort's imbalance; without slack a rank falls back to allocating)
+ * Environment for tests: PSACX_MULTI_DIET=1, PSACX_MULTI_SLAB=<elements>. */
+#define PSACX_MULTI_OPT_LAYOUT 1
+#define PSACX_MULTI_OPT_SLAB 2
+#define PSACX_MULTI_OPT_OUTPUT_SLACK 3
+int psacx_multi_configure(psacx_multi* mg, int option, uint64_t value);
+/* after a construction: peak_bytes[i] = high-water mark of the device memory local rank i's block cache held (every
+ * array the engine allocated; the caller's text and result arrays are not in it), *reduced = 1 if the reduced-memory
+ * layout ran, *slab_rounds = refinement rounds worked off in more than one slab.  Any pointer may be null. */
+int psacx_multi_get_memory(const psacx_multi* mg, uint64_t* peak_bytes, int* reduced, uint32_t* slab_rounds);
 
 /* device memory helpers for hosts without their own HIP bindings ------------ */
 int psacx_dev_alloc(psacx_ctx* ctx, void** out, uint64_t bytes);

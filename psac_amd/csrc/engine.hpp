@@ -46,7 +46,10 @@ struct psacx_ctx {
     // only touched after everything that used it before.  (hipMallocAsync was measured first: its pool stalls for
     // seconds now and then once several streams of one device share it.)
     std::multimap<size_t, void*>* pool = nullptr;
-    size_t pool_bytes = 0;
+    size_t pool_bytes = 0;           // bytes of cached (free) blocks
+    size_t pool_live = 0;            // bytes of blocks handed out
+    size_t pool_peak = 0;            // high-water mark of pool_live + pool_bytes (what the cache really holds of the device)
+    size_t pool_cache_limit = 0;     // > 0: a miss first returns the cached blocks to the device once they exceed this many bytes
     std::string hip_err;
     psacx_stats stats;
     bool profile = false;
@@ -241,9 +244,11 @@ inline void* pool_alloc(psacx_ctx* c, size_t bytes, size_t* cap) {
     if (it != c->pool->end() && it->first <= want + want / 4 + 4096) {
         void* p = it->second; *cap = it->first;
         c->pool_bytes -= it->first;
+        c->pool_live += it->first;
         c->pool->erase(it);
         return p;
     }
+    if (c->pool_cache_limit && c->pool_bytes > c->pool_cache_limit) pool_flush(c);
     void* p = nullptr;
     if (hipMalloc(&p, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -251,6 +256,8 @@ inline void* pool_alloc(psacx_ctx* c, size_t bytes, size_t* cap) {
         if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
     *cap = want;
+    c->pool_live += want;
+    c->pool_peak = std::max(c->pool_peak, c->pool_live + c->pool_bytes);
     return p;
 }
 inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
@@ -258,6 +265,8 @@ inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
     if (!c->pool) c->pool = new std::multimap<size_t, void*>();
     c->pool->emplace(cap, p);
     c->pool_bytes += cap;
+    c->pool_live -= std::min(c->pool_live, cap);
+    if (c->pool_cache_limit && c->pool_bytes > 2 * c->pool_cache_limit) pool_flush(c);
 }
 
 inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8) {

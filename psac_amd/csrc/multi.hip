@@ -63,17 +63,22 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
     const bool want_lcp = (flags & PSACX_LCP) != 0;
     std::vector<uint64_t> m(P), off(P + 1, 0);
     for (int r = 0; r < P; ++r) { m[r] = n / P + ((uint64_t)r < n % P ? 1 : 0); off[r + 1] = off[r] + m[r]; }
+    const uint64_t slack = m[0] / 8 + 256;
     std::vector<DBuf<uint8_t>> dt(P);
     std::vector<DBuf<T>> dsa(P), disa(P), dlcp(P);
     std::vector<const uint8_t*> tp(P); std::vector<T*> a(P), b(P), c(P, nullptr);
     for (int r = 0; r < P; ++r) {
         psacx_ctx* cx = g->R[r].ctx;
-        MG_OP(g, cx, dt[r].alloc(cx, m[r])); MG_OP(g, cx, dsa[r].alloc(cx, m[r])); MG_OP(g, cx, disa[r].alloc(cx, m[r]));
-        if (want_lcp) MG_OP(g, cx, dlcp[r].alloc(cx, m[r]));
+        // the result arrays get the slack that lets the reduced-memory layout use them as record arrays
+        MG_OP(g, cx, dt[r].alloc(cx, m[r])); MG_OP(g, cx, dsa[r].alloc(cx, m[r], m[r] + slack)); MG_OP(g, cx, disa[r].alloc(cx, m[r], m[r] + slack));
+        if (want_lcp) MG_OP(g, cx, dlcp[r].alloc(cx, m[r], m[r] + slack));
         if (m[r]) MG_OP(g, cx, staged_h2d(cx, dt[r].p, text + off[r], m[r]));
         tp[r] = dt[r].p; a[r] = dsa[r].p; b[r] = disa[r].p; c[r] = want_lcp ? dlcp[r].p : nullptr;
     }
+    const uint64_t user_slack = g->out_slack;
+    g->out_slack = slack;
     int rc = run_dev<T>(g, tp.data(), m.data(), k, flags, a.data(), b.data(), c.data());
+    g->out_slack = user_slack;
     if (rc != PSACX_OK) return rc;
     for (int r = 0; r < P; ++r) {
         psacx_ctx* cx = g->R[r].ctx;
@@ -189,6 +194,24 @@ int psacx_multi_get_stats(const psacx_multi* g, psacx_stats* out, uint64_t* byte
     if (bytes_sent) *bytes_sent = g->bytes_sent;
     if (exchanges) *exchanges = g->n_exchanges;
     if (gathers) *gathers = g->n_gathers;
+    return PSACX_OK;
+}
+
+int psacx_multi_configure(psacx_multi* g, int option, uint64_t value) {
+    if (!g) return PSACX_EINVAL;
+    switch (option) {
+    case PSACX_MULTI_OPT_LAYOUT: if (value > 2) return PSACX_EINVAL; g->opt_layout = (int)value; return PSACX_OK;
+    case PSACX_MULTI_OPT_SLAB: g->opt_slab = value; return PSACX_OK;
+    case PSACX_MULTI_OPT_OUTPUT_SLACK: g->out_slack = value; return PSACX_OK;
+    default: return PSACX_EINVAL;
+    }
+}
+
+int psacx_multi_get_memory(const psacx_multi* g, uint64_t* peak_bytes, int* reduced, uint32_t* slab_rounds) {
+    if (!g) return PSACX_EINVAL;
+    if (peak_bytes) for (int i = 0; i < g->nlocal; ++i) peak_bytes[i] = g->R[i].ctx->pool_peak;
+    if (reduced) *reduced = g->last_reduced ? 1 : 0;
+    if (slab_rounds) *slab_rounds = g->last_slab_rounds;
     return PSACX_OK;
 }
 

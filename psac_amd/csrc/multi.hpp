@@ -139,6 +139,12 @@ struct psacx_multi {
     psacx_stats stats;
     uint64_t bytes_sent = 0;          // payload bytes this process sent to other ranks in the last call
     uint64_t n_exchanges = 0, n_gathers = 0;
+    // psacx_multi_configure
+    int opt_layout = 0;               // 0: choose by free device memory, 1: normal, 2: reduced-memory
+    uint64_t opt_slab = 0;            // unresolved suffixes per refinement slab of the reduced-memory layout (0: block / 16)
+    uint64_t out_slack = 0;           // the output arrays given to construct_dev hold this many elements beyond the block
+    bool last_reduced = false;        // layout the last construction ran in
+    uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
 };
 
 namespace psacx {
@@ -156,24 +162,30 @@ template <typename E> struct DBuf {
     E* p = nullptr; uint64_t n = 0; psacx_ctx* c = nullptr;
     DBuf() {}
     DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
-    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c), cap_(o.cap_) { o.p = nullptr; o.n = 0; }
-    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; cap_ = o.cap_; o.p = nullptr; o.n = 0; } return *this; }
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c), cap_(o.cap_), own_(o.own_) { o.p = nullptr; o.n = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; cap_ = o.cap_; own_ = o.own_; o.p = nullptr; o.n = 0; } return *this; }
     ~DBuf() { release(); }
-    int alloc(psacx_ctx* ctx, uint64_t count) {
+    // `count` elements; the block is sized for max(count, reserve) so that arrays of slightly different lengths reuse
+    // one cached block (reduced-memory layout)
+    int alloc(psacx_ctx* ctx, uint64_t count, uint64_t reserve = 0) {
         release();
-        c = ctx; n = count;
+        c = ctx; n = count; own_ = true;
         if (hipSetDevice(c->device) != hipSuccess) return PSACX_EHIP;
-        p = static_cast<E*>(pool_alloc(c, (size_t)count * sizeof(E), &cap_));
+        p = static_cast<E*>(pool_alloc(c, (size_t)std::max(count, reserve) * sizeof(E), &cap_));
         if (!p) { c->hip_err = "device allocation failed"; n = 0; return PSACX_ENOMEM; }
         return PSACX_OK;
     }
+    // a view of memory somebody else owns (an output array used as scratch)
+    void borrow(psacx_ctx* ctx, E* ptr, uint64_t count) { release(); c = ctx; p = ptr; n = count; own_ = false; cap_ = 0; }
+    bool owned() const { return own_; }
     void release() {
         if (!p) return;
-        pool_free(c, p, cap_);
+        if (own_) pool_free(c, p, cap_);
         p = nullptr; n = 0;
     }
 private:
     size_t cap_ = 0;
+    bool own_ = true;
 };
 
 template <typename T> struct Rec { DBuf<T> k1, k2, v; uint64_t cnt = 0; };
@@ -348,6 +360,13 @@ __global__ void check_verdict_kernel(const T* __restrict__ SA, const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// number of leading entries <= key of a non-decreasing array (one thread)
+template <typename T> __global__ void upper_bound_kernel(const T* __restrict__ a, uint64_t n, uint64_t key, uint64_t* __restrict__ out) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)a[mid] <= key) lo = mid + 1; else hi = mid; }
+    *out = lo;
+}
+
 template <typename T>
 struct MultiRun {
     psacx_multi* g;
@@ -358,8 +377,54 @@ struct MultiRun {
     struct St {
         psacx_ctx* c; int r; uint64_t m, off; const uint8_t* text; T *SA, *ISA, *LCP;
         DBuf<T> Bsa, pos;
+        uint64_t out_cap = 0;          // elements every output array holds
+        bool out_busy = true;          // the output arrays hold results (or records): not available as scratch
     };
     std::vector<St> S;
+    // Reduced-memory layout: the records of the first round alternate between the rank's three
+    // output arrays and ONE allocated set, SA -> ISA runs in chunks, and a refinement round with more unresolved
+    // suffixes than `slab_cap` on some rank is worked off in slabs of whole buckets.
+    bool diet = false, first_round_ = false;
+    uint64_t sort_calls_ = 0;
+    uint64_t slab_cap = 0;
+
+    // first round of the reduced-memory layout: every record array is cut from a block of one size (a little more than
+    // the text block), so the cached blocks serve each other's successors whatever the sample sort's imbalance
+    uint64_t reserve_of(int i) const { return diet && first_round_ ? S[i].m + S[i].m / 8 + 256 : 0; }
+    // three record arrays of cnt entries: the output arrays of the rank while they are free and large enough, else its cache
+    int take3(int i, Rec<T>& r, uint64_t cnt) {
+        psacx_ctx* c = ctx(i);
+        r = Rec<T>();
+        r.cnt = cnt;
+        if (diet && !S[i].out_busy && cnt <= S[i].out_cap) {
+            r.v.borrow(c, S[i].SA, cnt); r.k1.borrow(c, S[i].ISA, cnt);
+            if (S[i].LCP) r.k2.borrow(c, S[i].LCP, cnt); else MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
+            S[i].out_busy = true;
+            return PSACX_OK;
+        }
+        MG_OP(g, c, r.k1.alloc(c, cnt, reserve_of(i))); MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i))); MG_OP(g, c, r.v.alloc(c, cnt, reserve_of(i)));
+        return PSACX_OK;
+    }
+    void drop3(int i, Rec<T>& r) {
+        if (r.k1.p && !r.k1.owned()) S[i].out_busy = false;
+        r = Rec<T>();
+    }
+    void swap3(Rec<T>& a, Rec<T>& b) { std::swap(a.k1, b.k1); std::swap(a.k2, b.k2); std::swap(a.v, b.v); }
+    // records that live in the output arrays move to allocated ones (before the outputs receive results)
+    int own3(int i, Rec<T>& r) {
+        if (!r.k1.p || (r.k1.owned() && r.k2.owned() && r.v.owned())) return PSACX_OK;
+        psacx_ctx* c = ctx(i);
+        MG_HIP(g, hipSetDevice(c->device));
+        DBuf<T>* a[3] = {&r.k1, &r.k2, &r.v};
+        for (int q = 0; q < 3; ++q) {
+            if (a[q]->owned()) continue;
+            DBuf<T> o; MG_OP(g, c, o.alloc(c, a[q]->n, reserve_of(i)));
+            MG_HIP(g, hipMemcpyAsync(o.p, a[q]->p, a[q]->n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            *a[q] = std::move(o);
+        }
+        S[i].out_busy = false;
+        return PSACX_OK;
+    }
 
     explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
         t_last_ = std::chrono::steady_clock::now();
@@ -373,8 +438,11 @@ struct MultiRun {
         const auto now = std::chrono::steady_clock::now();
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
-        if (g->first == 0) fprintf(stderr, "[psacx multi] %-28s %9.3f ms   (device memory in use %.1f GiB)\n", what,
-                                   std::chrono::duration<double, std::milli>(now - t_last_).count(), (double)(tot - fr) / (1 << 30));
+        int w = 0;                                       // the local rank whose block cache peaked highest
+        for (int i = 1; i < L; ++i) if (ctx(i)->pool_peak > ctx(w)->pool_peak) w = i;
+        if (g->first == 0) fprintf(stderr, "[psacx multi] %-28s %9.3f ms   (device memory in use %.1f GiB; rank %d's cache: %.1f MiB live, %.1f cached, peak %.1f)\n", what,
+                                   std::chrono::duration<double, std::milli>(now - t_last_).count(), (double)(tot - fr) / (1 << 30), rank(w),
+                                   ctx(w)->pool_live / 1048576.0, ctx(w)->pool_bytes / 1048576.0, ctx(w)->pool_peak / 1048576.0);
         t_last_ = std::chrono::steady_clock::now();
     }
     psacx_ctx* ctx(int i) const { return g->R[i].ctx; }
@@ -436,9 +504,11 @@ struct MultiRun {
     // array of local rank i go to rank d.  out[i][a] receives the elements ordered by source rank; rcnt[i][s] =
     // elements received from rank s.  One exchange of the counts serves all arrays; the transfers of all arrays,
     // ranks and peers form one RCCL group on the ranks' second streams.
+    // recv (optional): provides the `na` receive arrays of local rank i for `total` elements instead of the cache
     template <typename E>
     int exchange(int na, const std::vector<std::vector<const E*>>& in, const std::vector<std::vector<uint64_t>>& bounds,
-                 std::vector<std::vector<DBuf<E>>>& out, std::vector<std::vector<uint64_t>>& rcnt) {
+                 std::vector<std::vector<DBuf<E>>>& out, std::vector<std::vector<uint64_t>>& rcnt,
+                 const std::function<int(int, uint64_t, std::vector<DBuf<E>>&)>& recv = nullptr) {
         std::vector<std::vector<uint64_t>> mine(L);
         for (int i = 0; i < L; ++i) { mine[i].resize(P); for (int d = 0; d < P; ++d) mine[i][d] = bounds[i][d + 1] - bounds[i][d]; }
         std::vector<uint64_t> all;
@@ -451,7 +521,8 @@ struct MultiRun {
             for (int s = 0; s < P; ++s) rcnt[i][s] = all[(size_t)s * P + rank(i)];
             roff[i] = prefix_of(rcnt[i]);
             out[i].resize(na);
-            for (int a = 0; a < na; ++a) MG_OP(g, ctx(i), out[i][a].alloc(ctx(i), roff[i][P]));
+            if (recv) { PSACX_TRY(recv(i, roff[i][P], out[i])); if ((int)out[i].size() != na) return PSACX_EINVAL; }
+            else for (int a = 0; a < na; ++a) MG_OP(g, ctx(i), out[i][a].alloc(ctx(i), roff[i][P]));
         }
         // the sources are complete when the compute streams reach this point; the receive buffers exist by then too
         for (int i = 0; i < L; ++i) {
@@ -534,10 +605,11 @@ struct MultiRun {
         psacx_ctx* c = ctx(i);
         if (rec.cnt < 2) return PSACX_OK;
         Rec<T> alt;
-        MG_OP(g, c, alt.k1.alloc(c, rec.cnt)); MG_OP(g, c, alt.k2.alloc(c, rec.cnt)); MG_OP(g, c, alt.v.alloc(c, rec.cnt));
+        PSACX_TRY(take3(i, alt, rec.cnt));
         int32_t where = 0;
         MG_OP(g, c, op_pair_sort<T>(c, rec.k1.p, rec.k2.p, rec.v.p, alt.k1.p, alt.k2.p, alt.v.p, rec.cnt, bits1, bits2, &where));
-        if (where) { std::swap(rec.k1, alt.k1); std::swap(rec.k2, alt.k2); std::swap(rec.v, alt.v); }
+        if (where) swap3(rec, alt);
+        drop3(i, alt);
         return PSACX_OK;
     }
 
@@ -554,10 +626,11 @@ struct MultiRun {
         const unsigned lo1 = bits1 - lead;
         {
             Rec<T> alt;
-            MG_OP(g, c, alt.k1.alloc(c, rec.cnt)); MG_OP(g, c, alt.k2.alloc(c, rec.cnt)); MG_OP(g, c, alt.v.alloc(c, rec.cnt));
+            PSACX_TRY(take3(i, alt, rec.cnt));
             int32_t where = 0;
             MG_OP(g, c, op_pair_sort<T>(c, rec.k1.p, rec.k2.p, rec.v.p, alt.k1.p, alt.k2.p, alt.v.p, rec.cnt, bits1, 0, &where, lo1));
-            if (where) { std::swap(rec.k1, alt.k1); std::swap(rec.k2, alt.k2); std::swap(rec.v, alt.v); }
+            if (where) swap3(rec, alt);
+            drop3(i, alt);
         }
         constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
         DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
@@ -606,14 +679,24 @@ struct MultiRun {
     // Sorts the records of all ranks by (k1, k2); rank r ends with exactly targets[r] records, the concatenation
     // over ranks being sorted -- the contract psac needs from mxx::sort (idxsort.hpp:67-79).
     int dist_sort(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, bool first_round = false) {
+        ++sort_calls_;
         if (P == 1) return first_round ? local_sort_first(0, rec[0], bits1, bits2) : local_sort(0, rec[0], bits1, bits2);
-        constexpr int SAMPLES = 256;
-        // regular samples of the local records, made unique by (rank, index) so that ties are divided
+        constexpr int SAMPLES = 1024;
+        // One sample from a pseudo-random place in each of SAMPLES equal strata of the local records, made unique by
+        // (rank, index) so that ties are divided.  (Evenly spaced samples alias with periodic text: in a tandem repeat whose
+        // period divides the spacing every sample of every rank carries the same key, and one rank received 2.8 blocks.)
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + 3 * SAMPLES, 0));
         PSACX_TRY(par([&](int i) -> int {
             const uint64_t c = rec[i].cnt;
             std::vector<uint64_t> pos;
-            for (int s = 0; s < SAMPLES && c; ++s) { const uint64_t p = (uint64_t)(((unsigned __int128)c * (2 * s + 1)) / (2 * SAMPLES)); if (pos.empty() || pos.back() != p) pos.push_back(p); }
+            for (int s = 0; s < SAMPLES && c; ++s) {
+                const uint64_t lo = (uint64_t)(((unsigned __int128)c * s) / SAMPLES), hi = (uint64_t)(((unsigned __int128)c * (s + 1)) / SAMPLES);
+                if (hi <= lo) continue;
+                uint64_t z = ((uint64_t)rank(i) << 32 | (uint64_t)s) + 0x9E3779B97F4A7C15ull * (sort_calls_ + 1);      // splitmix64
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+                const uint64_t p = lo + z % (hi - lo);
+                if (pos.empty() || pos.back() != p) pos.push_back(p);
+            }
             std::vector<uint64_t> a, b;
             PSACX_TRY(fetch(i, rec[i].k1.p, pos, a));
             PSACX_TRY(fetch(i, rec[i].k2.p, pos, b));
@@ -645,24 +728,31 @@ struct MultiRun {
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             const uint64_t cn = rec[i].cnt;
-            MG_OP(g, c, grp[i].k1.alloc(c, cn)); MG_OP(g, c, grp[i].k2.alloc(c, cn)); MG_OP(g, c, grp[i].v.alloc(c, cn));
+            PSACX_TRY(take3(i, grp[i], cn));
             std::vector<uint64_t> cs(ns + 2, 0);
             MG_OP(g, c, op_split_by<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, cn, s1.data(), s2.data(), sr.data(), sp.data(), ns,
                                       (uint64_t)rank(i), grp[i].k1.p, grp[i].k2.p, grp[i].v.p, cs.data()));
             bounds[i].assign(P + 1, cn);
             for (uint32_t d = 0; d <= ns; ++d) bounds[i][d] = cs[d];
-            rec[i].k1.release(); rec[i].k2.release(); rec[i].v.release();
+            drop3(i, rec[i]);
             in[i] = {grp[i].k1.p, grp[i].k2.p, grp[i].v.p};
             return PSACX_OK;
         }));
         mark("    sort: samples + partition");
         std::vector<std::vector<DBuf<T>>> got;
         std::vector<std::vector<uint64_t>> rc;
-        PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+        const std::function<int(int, uint64_t, std::vector<DBuf<T>>&)> recv3 = [this](int i, uint64_t tot, std::vector<DBuf<T>>& o) -> int {
+            Rec<T> r;
+            PSACX_TRY(take3(i, r, tot));
+            o.clear(); o.resize(3);
+            o[0] = std::move(r.k1); o[1] = std::move(r.k2); o[2] = std::move(r.v);
+            return PSACX_OK;
+        };
+        PSACX_TRY(exchange<T>(3, in, bounds, got, rc, recv3));
         mark("    sort: shuffle");
         std::vector<uint64_t> c2(L);
         PSACX_TRY(par([&](int i) -> int {
-            grp[i] = Rec<T>();
+            drop3(i, grp[i]);
             rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
             rec[i].cnt = c2[i] = rec[i].k1.n;
             if (first_round) PSACX_TRY(local_sort_first(i, rec[i], bits1, bits2));
@@ -681,8 +771,9 @@ struct MultiRun {
             for (int d = 0; d < P; ++d) bounds[i][d] = std::min<uint64_t>(TP[d] > gr ? TP[d] - gr : 0, c2[i]);
             in[i] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
         }
-        PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+        PSACX_TRY(exchange<T>(3, in, bounds, got, rc, recv3));
         for (int i = 0; i < L; ++i) {
+            drop3(i, rec[i]);
             rec[i].k1 = std::move(got[i][0]); rec[i].k2 = std::move(got[i][1]); rec[i].v = std::move(got[i][2]);
             rec[i].cnt = rec[i].k1.n;
         }
@@ -932,6 +1023,129 @@ struct MultiRun {
         return PSACX_OK;
     }
 
+    // One refinement pass (suffix_array.hpp:1092-1157, :1181-1285) over the list entries plist[i][0 .. cnt[i]) of every local
+    // rank -- global SA positions inside its block, whole buckets: B2 = rank of the suffix h further, sort by (bucket, B2), new bucket ids / SA /
+    // ISA / LCP written in place.  kept[i]: the entries that still share a bucket; counts = cnt of every rank.
+    int refine_step(uint64_t h, const std::vector<const T*>& plist, const std::vector<uint64_t>& cnt, const std::vector<uint64_t>& counts,
+                    unsigned id_bits, std::vector<DBuf<T>>& kept, uint64_t* unf_b, uint64_t* unf_e) {
+        std::vector<Rec<T>> rec(L);
+        std::vector<DBuf<T>> q(L);
+        std::vector<psacx_boundary> bd;
+        std::vector<uint64_t> lh(L), heads, nact(L), nunf(L);
+        // B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            rec[i].cnt = cnt[i];
+            MG_OP(g, c, rec[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rec[i].v.alloc(c, cnt[i])); MG_OP(g, c, q[i].alloc(c, cnt[i]));
+            MG_OP(g, c, op_take(c, S[i].SA, plist[i], cnt[i], S[i].off, n, rec[i].v.p));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], rec[i].v.p, cnt[i], h, n, q[i].p);      // saturates at n
+            MG_OP(g, c, op_take(c, S[i].Bsa.p, plist[i], cnt[i], S[i].off, n, rec[i].k1.p));
+            return PSACX_OK;
+        }));
+        {
+            std::vector<const T*> blk(L), gi(L);
+            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q[i].p; }
+            std::vector<DBuf<T>> ans;
+            PSACX_TRY(dist_take(blk, gi, cnt, ans));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, rec[i].k2.alloc(c, cnt[i]));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
+                return PSACX_OK;
+            }));
+        }
+        q.clear();
+        mark("  B2 fetch");
+        PSACX_TRY(dist_sort(rec, counts, id_bits, id_bits));
+        mark("  sort");
+        {
+            std::vector<const T*> a1(L), a2(L), a3(L);
+            for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; }
+            PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
+        }
+        PSACX_TRY(par([&](int i) -> int {
+            bd[i].off = 0; bd[i].base = 0;
+            psacx_boundary b0 = bd[i]; b0.has_next = 0;
+            MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 1, rec[i].k1.p, rec[i].k2.p, plist[i], cnt[i], 0, 1, 1, 0, &b0, &lh[i]));
+            return PSACX_OK;
+        }));
+        PSACX_TRY(gather1(lh, heads));
+        std::vector<DBuf<T>> ids(L), qa(L), ql(L), qh(L);
+        std::vector<uint64_t> nq(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            uint64_t base = 0;
+            for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
+            bd[i].off = S[i].off; bd[i].base = base;
+            MG_OP(g, c, ids[i].alloc(c, cnt[i])); MG_OP(g, c, qa[i].alloc(c, cnt[i])); MG_OP(g, c, ql[i].alloc(c, cnt[i])); MG_OP(g, c, qh[i].alloc(c, cnt[i]));
+            MG_OP(g, c, op_rebucket_refine<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, plist[i], cnt[i], n, h, &bd[i], S[i].SA, S[i].Bsa.p,
+                                              S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i]));
+            return PSACX_OK;
+        }));
+        {
+            std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L);
+            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = rec[i].v.p; va[i] = ids[i].p; }
+            PSACX_TRY(dist_put(blk, gi, va, cnt, -1, false));
+        }
+        mark("  refine + ISA");
+        if (want_lcp) {
+            std::vector<const T*> lo(L), hi(L);
+            for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
+            std::vector<DBuf<T>> mins;
+            PSACX_TRY(dist_range_min(lo, hi, nq, mins));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
+                return PSACX_OK;
+            }));
+        }
+        mark("  range minima");
+        rec.clear(); rec.resize(L);
+        PSACX_TRY(next_active(&ids, &plist, nact, nunf, kept, unf_b, unf_e));
+        return PSACX_OK;
+    }
+
+    // Piece boundaries e[0 .. steps] of the list of unresolved positions of local rank i: about equal pieces, every cut moved
+    // back to the head of the bucket it falls into; a bucket that enters from the previous rank stays whole in piece 0, one
+    // that leaves to the next rank in the last piece.
+    int slab_bounds(int i, uint64_t steps, std::vector<uint64_t>& e) {
+        const uint64_t a = S[i].pos.n, m = S[i].m;
+        e.assign(steps + 1, 0);
+        e[steps] = a;
+        if (a == 0) return PSACX_OK;
+        psacx_ctx* c = ctx(i);
+        std::vector<uint64_t> t(steps + 1), p, id;
+        for (uint64_t j = 0; j < steps; ++j) t[j] = (uint64_t)(((unsigned __int128)a * j) / steps);
+        t[steps] = a - 1;
+        PSACX_TRY(fetch(i, S[i].pos.p, t, p));                  // the list holds global SA positions
+        for (auto& x : p) x -= S[i].off;
+        PSACX_TRY(fetch(i, S[i].Bsa.p, p, id));
+        uint64_t lead = 0;
+        if (id[0] - 1 < S[i].off) {                       // the first bucket began on an earlier rank: its members are positions 0 .. lead - 1
+            DBuf<uint64_t> d; MG_OP(g, c, d.alloc(c, 1));
+            MG_HIP(g, hipSetDevice(c->device));
+            hipLaunchKernelGGL((upper_bound_kernel<T>), dim3(1), dim3(1), 0, c->stream, S[i].Bsa.p, m, id[0], d.p);
+            MG_HIP(g, hipGetLastError());
+            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d.p, 8, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            lead = std::min<uint64_t>(*reinterpret_cast<uint64_t*>(c->pinned + 32768), a);
+        }
+        if (lead == a && p[steps] == m - 1 && P > 1) {
+            g->err = "a bucket of unresolved suffixes covers a whole block: the reduced-memory layout cannot cut it into slabs";
+            return PSACX_ENOMEM;
+        }
+        for (uint64_t j = 1; j < steps; ++j) {
+            uint64_t cut;
+            if (t[j] < lead) cut = lead;
+            else { const uint64_t head = id[j] - 1 - S[i].off; cut = t[j] - (p[j] - head); }     // every member of the bucket is a list entry
+            e[j] = std::max(cut, e[j - 1]);
+        }
+        return PSACX_OK;
+    }
+
     // ---------------------------------------------------------------- the construction (suffix_array.hpp:365-466, :1032-1285)
     int construct(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, uint32_t k_req, uint32_t flags,
                   const std::vector<T*>& d_sa, const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp) {
@@ -943,12 +1157,29 @@ struct MultiRun {
         PSACX_TRY(par([&](int i) -> int {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
             S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = want_lcp ? d_lcp[i] : nullptr;
+            S[i].out_cap = m_local[i] + g->out_slack; S[i].out_busy = false;
+            S[i].c->pool_peak = S[i].c->pool_live + S[i].c->pool_bytes;
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
             return PSACX_OK;
         }));
+        diet = false; slab_cap = 0; first_round_ = true;
+        g->last_reduced = false; g->last_slab_rounds = 0;
         // sizes + alphabet (alphabet.hpp:98: allreduce of the character histograms)
         {
-            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(257, 0));
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(258, 0));
+            // the normal layout holds up to ~14 words per character beside the outputs; a rank whose share of the free
+            // device memory is smaller asks for the reduced-memory layout, and then every rank uses it
+            const char* env_diet = getenv("PSACX_MULTI_DIET");
+            for (int i = 0; i < L; ++i) {
+                int same = 0;
+                for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
+                size_t fr = 0, tot = 0;
+                MG_HIP(g, hipSetDevice(ctx(i)->device));
+                MG_HIP(g, hipMemGetInfo(&fr, &tot));
+                const double avail = ((double)fr + (double)ctx(i)->pool_bytes * same) / same;
+                const bool tight = 14.0 * (double)S[i].m * sizeof(T) > 0.9 * avail;
+                mine[i][257] = g->opt_layout == 2 || (g->opt_layout == 0 && ((env_diet && atoi(env_diet)) || tight)) ? 1 : 0;
+            }
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 DBuf<uint64_t> h; MG_OP(g, c, h.alloc(c, 256));
@@ -960,16 +1191,32 @@ struct MultiRun {
                 return PSACX_OK;
             }));
             std::vector<uint64_t> all;
-            PSACX_TRY(gather(257, mine, all));
+            PSACX_TRY(gather(258, mine, all));
             sizes.assign(P, 0);
             uint64_t hist[256] = {0};
-            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 257]; for (int ch = 0; ch < 256; ++ch) hist[ch] += all[(size_t)r * 257 + 1 + ch]; }
+            for (int r = 0; r < P; ++r) {
+                sizes[r] = all[(size_t)r * 258];
+                for (int ch = 0; ch < 256; ++ch) hist[ch] += all[(size_t)r * 258 + 1 + ch];
+                if (all[(size_t)r * 258 + 257]) diet = true;
+            }
             offs = prefix_of(sizes);
             n = offs[P];
             for (int r = 0; r < P; ++r)            // suffix_array.hpp:226-227
                 if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
+            if (diet) {
+                const char* env_slab = getenv("PSACX_MULTI_SLAB");
+                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                if (slab_cap < 64) slab_cap = 64;
+                for (int i = 0; i < L; ++i) {
+                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
+                    MG_HIP(g, hipSetDevice(ctx(i)->device));
+                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
+                    ctx(i)->pool_peak = ctx(i)->pool_live;
+                }
+                g->last_reduced = true;
+            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
             if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
             uint32_t sigma = 0;
             for (int ch = 0; ch < 256; ++ch) sigma += hist[ch] != 0;
@@ -1031,7 +1278,7 @@ struct MultiRun {
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
-                MG_OP(g, c, rec[i].k1.alloc(c, front + m)); MG_OP(g, c, rec[i].k2.alloc(c, front + m)); MG_OP(g, c, rec[i].v.alloc(c, front + m));
+                PSACX_TRY(take3(i, rec[i], front + m));
                 MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, rec[i].k2.p + front));
                 MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));
                 const uint64_t end = S[i].off + m, first_short = n - spec;
@@ -1082,6 +1329,7 @@ struct MultiRun {
         }
         mark("keys");
         PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc, true));
+        PSACX_TRY(par([&](int i) -> int { return own3(i, rec[i]); }));
         mark("first sort");
 
         // ---- LCP of the 2k-mers, bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
@@ -1105,22 +1353,43 @@ struct MultiRun {
             uint64_t base = 0;
             for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
             bd[i].base = base;
-            MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m));
-            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], S[i].Bsa.p, S[i].LCP, &nact[i], &nunf[i]));
+            // reduced-memory layout: the bucket ids are written into the (still unused) ISA array and move to their own
+            // array once the records are gone
+            T* bsa_out = S[i].ISA;
+            if (!diet) { MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m)); bsa_out = S[i].Bsa.p; }
+            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i]));
             MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-            rec[i] = Rec<T>();
+            drop3(i, rec[i]);
+            S[i].out_busy = true;
+            if (diet) {
+                MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m));
+                MG_HIP(g, hipMemcpyAsync(S[i].Bsa.p, S[i].ISA, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            }
             return PSACX_OK;
         }));
+        first_round_ = false;
         mark("rebucket");
-        // ---- SA -> ISA (bulk_permute.hpp:14-73), overlapped on the second streams with the bookkeeping below
+        // ---- SA -> ISA (bulk_permute.hpp:14-73); in chunks of the block in the reduced-memory layout
         {
-            std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L); std::vector<uint64_t> cn(L);
-            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; va[i] = S[i].Bsa.p; cn[i] = S[i].m; }
-            PSACX_TRY(dist_put(blk, gi, va, cn, -1, true));
+            uint64_t chunks = 1;
+            if (diet) for (int r = 0; r < P; ++r) chunks = std::max<uint64_t>(chunks, (sizes[r] + slab_cap - 1) / slab_cap);
+            chunks = std::min<uint64_t>(chunks, 64);
+            for (uint64_t q = 0; q < chunks; ++q) {
+                std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L); std::vector<uint64_t> cn(L);
+                for (int i = 0; i < L; ++i) {
+                    const uint64_t a = (uint64_t)(((unsigned __int128)S[i].m * q) / chunks), b = (uint64_t)(((unsigned __int128)S[i].m * (q + 1)) / chunks);
+                    blk[i] = S[i].ISA; gi[i] = S[i].SA + a; va[i] = S[i].Bsa.p + a; cn[i] = b - a;
+                }
+                PSACX_TRY(dist_put(blk, gi, va, cn, -1, chunks == 1));
+            }
         }
         mark("SA -> ISA");
         uint64_t unf_b = 0, unf_e = 0;
-        PSACX_TRY(next_active(nullptr, nact, nunf, &unf_b, &unf_e));
+        {
+            std::vector<DBuf<T>> kept;
+            PSACX_TRY(next_active(nullptr, nullptr, nact, nunf, kept, &unf_b, &unf_e));
+            for (int i = 0; i < L; ++i) S[i].pos = std::move(kept[i]);
+        }
         mark("active list");
         st.rounds[0].h = k; st.rounds[0].active = n; st.rounds[0].unfinished_buckets = unf_b; st.rounds[0].unfinished_elements = unf_e;
         st.n_rounds = 1;
@@ -1130,81 +1399,65 @@ struct MultiRun {
             std::vector<uint64_t> cnt(L), counts;
             for (int i = 0; i < L; ++i) cnt[i] = S[i].pos.n;
             PSACX_TRY(gather1(cnt, counts));
-            // B2 = rank of the suffix h further (sparse_get_b2, suffix_array.hpp:972-996)
-            std::vector<DBuf<T>> q(L);
-            rec.clear(); rec.resize(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                rec[i].cnt = cnt[i];
-                MG_OP(g, c, rec[i].k1.alloc(c, cnt[i])); MG_OP(g, c, rec[i].v.alloc(c, cnt[i])); MG_OP(g, c, q[i].alloc(c, cnt[i]));
-                MG_OP(g, c, op_take(c, S[i].SA, S[i].pos.p, cnt[i], S[i].off, n, rec[i].v.p));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], rec[i].v.p, cnt[i], h, n, q[i].p);      // saturates at n
-                MG_OP(g, c, op_take(c, S[i].Bsa.p, S[i].pos.p, cnt[i], S[i].off, n, rec[i].k1.p));
-                return PSACX_OK;
-            }));
-            {
-                std::vector<const T*> blk(L), gi(L);
-                for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q[i].p; }
-                std::vector<DBuf<T>> ans;
-                PSACX_TRY(dist_take(blk, gi, cnt, ans));
-                PSACX_TRY(par([&](int i) -> int {
+            uint64_t steps = 1;
+            if (diet) for (int r = 0; r < P; ++r) steps = std::max<uint64_t>(steps, (counts[r] + slab_cap - 1) / slab_cap);
+            steps = std::min<uint64_t>(steps, 64);
+            if (steps == 1) {
+                std::vector<const T*> pl(L);
+                for (int i = 0; i < L; ++i) pl[i] = S[i].pos.p;
+                std::vector<DBuf<T>> kept;
+                PSACX_TRY(refine_step(h, pl, cnt, counts, id_bits, kept, &unf_b, &unf_e));
+                for (int i = 0; i < L; ++i) S[i].pos = std::move(kept[i]);
+            } else {
+                // Slabs.  Every rank cuts its list of unresolved positions into `steps` pieces at bucket heads; in step t rank
+                // r works on its piece (t + r) mod steps, so the last piece of rank r and the first of rank r + 1 -- the two
+                // halves of a bucket that crosses the block boundary -- meet in one step.  Later steps may read ranks that
+                // earlier steps of this round already refined (Larsson-Sadakane style, see construct.hpp): the result is
+                // the same, only the per-round counters may run ahead of the one-step log.
+                g->last_slab_rounds++;
+                std::vector<std::vector<uint64_t>> e(L), kept_n(L, std::vector<uint64_t>(steps, 0));
+                PSACX_TRY(par([&](int i) -> int { return slab_bounds(i, steps, e[i]); }));
+                uint64_t sum_b = 0, sum_e = 0;
+                for (uint64_t t = 0; t < steps; ++t) {
+                    std::vector<const T*> pl(L);
+                    std::vector<uint64_t> c2(L), counts2;
+                    for (int i = 0; i < L; ++i) { const uint64_t j = (t + (uint64_t)rank(i)) % steps; pl[i] = S[i].pos.p + e[i][j]; c2[i] = e[i][j + 1] - e[i][j]; }
+                    PSACX_TRY(gather1(c2, counts2));
+                    std::vector<DBuf<T>> kept;
+                    uint64_t sb = 0, se = 0;
+                    PSACX_TRY(refine_step(h, pl, c2, counts2, id_bits, kept, &sb, &se));
+                    sum_b += sb; sum_e += se;
+                    // the positions that stay unresolved replace the piece they came from
+                    PSACX_TRY(par([&](int i) -> int {
+                        const uint64_t j = (t + (uint64_t)rank(i)) % steps;
+                        kept_n[i][j] = kept[i].n;
+                        if (getenv("PSACX_MULTI_DEBUG")) fprintf(stderr, "[slab] h=%llu step %llu rank %d piece %llu [%llu,%llu) of %llu kept %llu\n", (unsigned long long)h, (unsigned long long)t, rank(i), (unsigned long long)j, (unsigned long long)e[i][j], (unsigned long long)e[i][j+1], (unsigned long long)S[i].pos.n, (unsigned long long)kept[i].n);
+                        if (kept[i].n) {
+                            MG_HIP(g, hipSetDevice(ctx(i)->device));
+                            MG_HIP(g, hipMemcpyAsync(S[i].pos.p + e[i][j], kept[i].p, kept[i].n * sizeof(T), hipMemcpyDeviceToDevice, ctx(i)->stream));
+                        }
+                        kept[i].release();
+                        return PSACX_OK;
+                    }));
+                }
+                PSACX_TRY(par([&](int i) -> int {                  // close the gaps between the pieces
                     psacx_ctx* c = ctx(i);
-                    MG_OP(g, c, rec[i].k2.alloc(c, cnt[i]));
-                    OP_PROLOGUE(c);
-                    SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
+                    MG_HIP(g, hipSetDevice(c->device));
+                    uint64_t dst = 0;
+                    for (uint64_t j = 0; j < steps; ++j) {
+                        const uint64_t len = kept_n[i][j], src = e[i][j];
+                        if (len && src != dst) {
+                            DBuf<T> tmp; MG_OP(g, c, tmp.alloc(c, len));
+                            MG_HIP(g, hipMemcpyAsync(tmp.p, S[i].pos.p + src, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                            MG_HIP(g, hipMemcpyAsync(S[i].pos.p + dst, tmp.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                        }
+                        dst += len;
+                    }
+                    S[i].pos.n = dst;
                     return PSACX_OK;
                 }));
+                unf_b = sum_b; unf_e = sum_e;
             }
-            q.clear();
-            mark("  B2 fetch");
-            PSACX_TRY(dist_sort(rec, counts, id_bits, id_bits));
-            mark("  sort");
-            {
-                std::vector<const T*> a1(L), a2(L), a3(L);
-                for (int i = 0; i < L; ++i) { a1[i] = rec[i].k1.p; a2[i] = rec[i].k2.p; a3[i] = rec[i].v.p; }
-                PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
-            }
-            PSACX_TRY(par([&](int i) -> int {
-                bd[i].off = 0; bd[i].base = 0;
-                psacx_boundary b0 = bd[i]; b0.has_next = 0;
-                MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 1, rec[i].k1.p, rec[i].k2.p, S[i].pos.p, cnt[i], 0, 1, 1, 0, &b0, &lh[i]));
-                return PSACX_OK;
-            }));
-            PSACX_TRY(gather1(lh, heads));
-            std::vector<DBuf<T>> ids(L), qa(L), ql(L), qh(L);
-            std::vector<uint64_t> nq(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                uint64_t base = 0;
-                for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
-                bd[i].off = S[i].off; bd[i].base = base;
-                MG_OP(g, c, ids[i].alloc(c, cnt[i])); MG_OP(g, c, qa[i].alloc(c, cnt[i])); MG_OP(g, c, ql[i].alloc(c, cnt[i])); MG_OP(g, c, qh[i].alloc(c, cnt[i]));
-                MG_OP(g, c, op_rebucket_refine<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, S[i].pos.p, cnt[i], n, h, &bd[i], S[i].SA, S[i].Bsa.p,
-                                                  S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i]));
-                return PSACX_OK;
-            }));
-            {
-                std::vector<T*> blk(L); std::vector<const T*> gi(L), va(L);
-                for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = rec[i].v.p; va[i] = ids[i].p; }
-                PSACX_TRY(dist_put(blk, gi, va, cnt, -1, false));
-            }
-            mark("  refine + ISA");
-            if (want_lcp) {
-                std::vector<const T*> lo(L), hi(L);
-                for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
-                std::vector<DBuf<T>> mins;
-                PSACX_TRY(dist_range_min(lo, hi, nq, mins));
-                PSACX_TRY(par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    OP_PROLOGUE(c);
-                    SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
-                    return PSACX_OK;
-                }));
-            }
-            mark("  range minima");
-            rec.clear(); rec.resize(L);
-            PSACX_TRY(next_active(&ids, nact, nunf, &unf_b, &unf_e));
             mark("  active list");
             if (st.n_rounds < PSACX_MAX_ROUNDS) {
                 psacx_round& rr = st.rounds[st.n_rounds++];
@@ -1368,6 +1621,18 @@ struct MultiRun {
                 if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
+            if (diet) {
+                const char* env_slab = getenv("PSACX_MULTI_SLAB");
+                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                if (slab_cap < 64) slab_cap = 64;
+                for (int i = 0; i < L; ++i) {
+                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
+                    MG_HIP(g, hipSetDevice(ctx(i)->device));
+                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
+                    ctx(i)->pool_peak = ctx(i)->pool_live;
+                }
+                g->last_reduced = true;
+            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
             if (sizeof(T) == 4 && n > 0xFFFFFFFDull) return PSACX_ERANGE;
         }
         std::vector<uint64_t> bm(L);
@@ -1464,6 +1729,18 @@ struct MultiRun {
                 if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
+            if (diet) {
+                const char* env_slab = getenv("PSACX_MULTI_SLAB");
+                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                if (slab_cap < 64) slab_cap = 64;
+                for (int i = 0; i < L; ++i) {
+                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
+                    MG_HIP(g, hipSetDevice(ctx(i)->device));
+                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
+                    ctx(i)->pool_peak = ctx(i)->pool_live;
+                }
+                g->last_reduced = true;
+            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
         }
         std::vector<uint64_t> cnt(L);
         std::vector<const T*> blk(L), gi(L);
@@ -1527,7 +1804,8 @@ struct MultiRun {
 
     // boundary bucket ids of every block, the list of positions that still share a bucket (suffix_array.hpp:925-965)
     // and the global counters.  ids == nullptr: first round (ids = Bsa, every position is a list entry).
-    int next_active(std::vector<DBuf<T>>* ids, const std::vector<uint64_t>& nact, const std::vector<uint64_t>& nunf, uint64_t* unf_b, uint64_t* unf_e) {
+    int next_active(std::vector<DBuf<T>>* ids, const std::vector<const T*>* plist, const std::vector<uint64_t>& nact, const std::vector<uint64_t>& nunf,
+                    std::vector<DBuf<T>>& kept_out, uint64_t* unf_b, uint64_t* unf_e) {
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(5, 0));
         std::vector<uint64_t> cnt(L);
         PSACX_TRY(par([&](int i) -> int {
@@ -1545,7 +1823,8 @@ struct MultiRun {
         PSACX_TRY(gather(5, mine, all));
         *unf_b = *unf_e = 0;
         for (int r = 0; r < P; ++r) { *unf_e += all[(size_t)r * 5 + 3]; *unf_b += all[(size_t)r * 5 + 4]; }
-        for (int i = 0; i < L; ++i) {
+        kept_out.clear(); kept_out.resize(L);
+        PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             const int r = rank(i);
             uint64_t pid = 0, nid = 0;
@@ -1553,11 +1832,12 @@ struct MultiRun {
             for (int s = r + 1; s < P; ++s) if (all[(size_t)s * 5]) { nid = all[(size_t)s * 5 + 1]; break; }
             DBuf<T> out; MG_OP(g, c, out.alloc(c, cnt[i]));
             uint64_t kept = 0;
-            MG_OP(g, c, op_compact<T>(c, ids ? (*ids)[i].p : S[i].Bsa.p, ids ? S[i].pos.p : (const T*)nullptr, cnt[i], S[i].off, pid, nid, out.p, &kept));
-            DBuf<T> trimmed; MG_OP(g, c, trimmed.alloc(c, kept));
-            if (kept) MG_HIP(g, hipMemcpyAsync(trimmed.p, out.p, kept * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-            S[i].pos = std::move(trimmed);
-        }
+            MG_OP(g, c, op_compact<T>(c, ids ? (*ids)[i].p : S[i].Bsa.p, ids ? (*plist)[i] : (const T*)nullptr, cnt[i], S[i].off, pid, nid, out.p, &kept));
+            MG_OP(g, c, kept_out[i].alloc(c, kept));
+            MG_HIP(g, hipSetDevice(c->device));
+            if (kept) MG_HIP(g, hipMemcpyAsync(kept_out[i].p, out.p, kept * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            return PSACX_OK;
+        }));
         return PSACX_OK;
     }
 

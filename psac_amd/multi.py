@@ -67,6 +67,22 @@ class MultiContext(object):
         self.check(self._lib.psacx_multi_get_stats(self.handle, C.byref(s), C.byref(sent), C.byref(ex), C.byref(ga)))
         return s, sent.value, ex.value, ga.value
 
+    LAYOUT_AUTO, LAYOUT_NORMAL, LAYOUT_REDUCED = 0, 1, 2
+
+    def configure(self, layout=None, slab=None, output_slack=None):
+        """psacx_multi_configure: memory layout of the distributed construction (include/psacx.h)."""
+        for opt, val in ((1, layout), (2, slab), (3, output_slack)):
+            if val is not None:
+                self.check(self._lib.psacx_multi_configure(self.handle, opt, int(val)))
+
+    def memory(self):
+        """(peak bytes of every local rank's block cache, reduced-memory layout used?, refinement rounds run in slabs)
+        of the last construction."""
+        peak = (C.c_uint64 * self.nlocal)()
+        red, slabs = C.c_int32(0), C.c_uint32(0)
+        self.check(self._lib.psacx_multi_get_memory(self.handle, peak, C.byref(red), C.byref(slabs)))
+        return list(peak), bool(red.value), int(slabs.value)
+
     def construct(self, text, index_bits=64, lcp=True, k=0):
         """suffix_array<char, index_t, LCP>::construct on p ranks, the whole text and results on this host
         (needs every rank in this process).  Returns (SA, ISA, LCP or None, rounds)."""

@@ -324,3 +324,106 @@ def test_multi_distributed_ansv():
                     lib.psacx_dev_free(ctx, p)
         finally:
             mg.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reduced-memory layout (psacx_multi_configure): records of the first round in the result arrays + one allocated set,
+# chunked SA -> ISA, refinement rounds in slabs of whole buckets
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_multi_reduced_memory_layout_matches_oracle(P):
+    mg = multi(P)
+    try:
+        mg.configure(layout=mg.LAYOUT_REDUCED, slab=3000)       # far fewer than a block: every deep round runs in slabs
+        for bits in (32, 64):
+            text = O.rand_dna(60011, 7)
+            SA, ISA, LCP, rounds = same(mg, text, bits)
+            ref = O.construct(text, bits=bits)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+            assert mg.memory()[1]
+        # tandem repeat: buckets of n / 256 suffixes that cross rank boundaries, ~10 rounds in which every suffix is unresolved
+        text = inputs.tandem(40000, 256, O.rand_dna(256, 3))
+        for bits in (32, 64):
+            SA, ISA, LCP, rounds = same(mg, text, bits)
+            ref = O.construct(text, bits=bits)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+            peak, reduced, slab_rounds = mg.memory()
+            assert reduced and slab_rounds >= 5
+            # h doubles every round as in the one-step log; the counters of a slab round may run ahead of it
+            assert [r[0] for r in rounds] == [t[0] for t in ref["trace"]][:len(rounds)]
+        # forced bucket refinement from k = 3 (huge first buckets), without LCP
+        text = O.rand_dna(30011, 23)
+        SA, ISA, LCP, _ = same(mg, text, 64, k=3, lcp=False)
+        assert LCP is None and np.array_equal(SA, O.naive_sa(text, 64))
+        assert np.array_equal(ISA[SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
+        # low-entropy text: range minima over many buckets
+        rng = np.random.RandomState(5)
+        p = 0.5 ** np.arange(1, 21); p /= p.sum()
+        text = (97 + rng.choice(20, size=200003, p=p)).astype(np.uint8)
+        SA, ISA, LCP, rounds = same(mg, text, 32)
+        ref = O.construct(text, bits=32)
+        assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+    finally:
+        mg.close()
+
+
+def test_multi_reduced_memory_whole_block_bucket_is_refused_or_solved():
+    # one symbol: a single bucket covers every block; with more than one rank the slabs cannot cut it
+    import psac_amd
+    mg = multi(2)
+    try:
+        mg.configure(layout=mg.LAYOUT_REDUCED, slab=500)
+        text = np.full(5003, 65, np.uint8)
+        with pytest.raises(psac_amd.PsacxError) as e:
+            same(mg, text, 32)
+        assert "covers a whole block" in str(e.value)
+        mg.configure(slab=1 << 20)                               # the whole list fits one slab: solved as usual
+        SA, ISA, LCP, _ = same(mg, text, 32)
+        ref = O.construct(text, bits=32)
+        assert np.array_equal(SA, ref["SA"]) and np.array_equal(LCP, ref["LCP"])
+    finally:
+        mg.close()
+
+
+def test_multi_reduced_memory_twin_of_config_c5_and_its_footprint():
+    # configs[4] / 256 again (2^27 characters, period-1024 tandem, 8 ranks, uint64) in the reduced-memory layout, the
+    # refinement rounds in slabs of 2^20 unresolved suffixes per rank (16 steps a round); verified by the distributed checker
+    # and against the normal layout's result.  The footprint: the normal layout against the reduced one, in words per character.
+    import ctypes as C
+    P, n, bits = 8, 1 << 27, 64
+    mg = multi(P)
+    try:
+        lib = mg._lib
+        sizes = [n // P] * P
+        slack = sizes[0] // 8 + 256
+        ctxs = [mg.rank_ctx(i) for i in range(P)]
+        def alloc(ctx, nbytes):
+            p = C.c_void_p()
+            assert lib.psacx_dev_alloc(ctx, C.byref(p), nbytes) == 0
+            return p.value
+        d_text = [alloc(c, m) for c, m in zip(ctxs, sizes)]
+        for i, (c, m) in enumerate(zip(ctxs, sizes)):
+            assert lib.psacx_synth_text_dev(c, C.c_void_p(d_text[i]), m, i * sizes[0], 2, 3, 1024) == 0
+        outs = [[alloc(c, (m + slack) * 8) for c, m in zip(ctxs, sizes)] for _ in range(3)]
+        res = {}
+        for layout in (mg.LAYOUT_NORMAL, mg.LAYOUT_REDUCED):
+            mg.configure(layout=layout, slab=1 << 20, output_slack=slack)
+            st = mg.construct_device(d_text, sizes, outs[0], outs[1], outs[2], bits)[0]
+            peak, reduced, slab_rounds = mg.memory()             # (before the checker allocates its own arrays)
+            assert mg.check_device(d_text, sizes, outs[0], outs[1], outs[2], bits) == [0, 0, 0, 0]
+            host = []
+            for a in outs:
+                parts = []
+                for i, (c, m) in enumerate(zip(ctxs, sizes)):
+                    h = np.empty(m, np.uint64)
+                    assert lib.psacx_copy_d2h(c, h.ctypes.data_as(C.c_void_p), C.c_void_p(a[i]), m * 8) == 0
+                    parts.append(h)
+                host.append(np.concatenate(parts))
+            res[layout] = (host, max(peak) / (sizes[0] * 8.0), reduced, slab_rounds, st.n_rounds)
+        (a, wa, ra, sa_, na), (b, wb, rb, sb, nb) = res[mg.LAYOUT_NORMAL], res[mg.LAYOUT_REDUCED]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert not ra and rb and sa_ == 0 and sb >= 10 and na >= 20 and nb >= 20
+        print("words per character beside the results: normal %.2f, reduced %.2f" % (wa, wb))
+        assert wb <= 5.0 and wb < wa
+    finally:
+        mg.close()

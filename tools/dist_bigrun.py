@@ -1,47 +1,47 @@
 #!/usr/bin/env python3
-"""One rank's share of the 8-GPU config through the distributed step ops: tools/dist_bigrun.py <log2 n> <bits> [P].
-P virtual ranks on one GPU; the result is verified by the device checker."""
+"""Footprint and time of the distributed construction per rank, the ranks sharing device 0 (virtual ranks):
+  tools/dist_bigrun.py <P> <log2 characters per rank> <bits> <kind: dna|ascii128|tandem> <layout: normal|reduced> [slab]
+Prints the device memory every rank's engine allocated at its peak in words per character (beside the three result
+arrays and the text the caller owns), the total against the 288 GB of one MI355X for a block of 2^32 characters with
+64-bit words (BASELINE.json configs[4]: 32 GiB over 8 GPUs), ms per construction and the distributed checker's verdict."""
+import ctypes as C
 import os
 import sys
 import time
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-import torch
-import inputs
+sys.path.insert(0, ROOT)
 import psac_amd
-from psac_amd import dist as D
-from psac_amd.comm import LoopbackWorld
-from psac_amd.dist_ops import HipOps
 
-logn = int(sys.argv[1]); bits = int(sys.argv[2]); P = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-n = 1 << logn
-m = n // P
-CH = 1 << 28
-parts = []
-for o in range(0, n, CH):
-    z = inputs.splitmix64_stream(min(CH, n - o), 1 + o)
-    parts.append(torch.from_numpy(np.frombuffer(b"ACGT", np.uint8)[(z & np.uint64(3)).astype(np.int64)]).cuda())
-text = torch.cat(parts); del parts
-ops = [HipOps(bits, 0) for _ in range(P)]
-blocks = [text[r * m:(r + 1) * m] for r in range(P)]
-
-
-def fn(comm, op, blk):
-    return (yield from D.construct(comm, op, blk, want_lcp=True))
-
-
-torch.cuda.synchronize()
-t0 = time.time()
-res = LoopbackWorld(P).run(fn, [(ops[r], blocks[r]) for r in range(P)])
-torch.cuda.synchronize()
-dt = time.time() - t0
-sa = torch.cat([r["SA"] for r in res]); isa = torch.cat([r["ISA"] for r in res]); lcp = torch.cat([r["LCP"] for r in res])
-rounds = res[0]["rounds"]
-del res
-torch.cuda.synchronize()            # the checker runs on its own stream
-ctx = psac_amd.Context(0)
-err = psac_amd.check_device(ctx, text.data_ptr(), n, sa.data_ptr(), isa.data_ptr(), lcp.data_ptr(), bits)
-print("distributed ops, %d virtual rank(s) x 2^%d / %d, uint%d: %.2f s, rounds %s, peak %.0f GiB, device check errors %s"
-      % (P, logn, P, bits, dt, rounds, torch.cuda.max_memory_allocated() / 2**30, err))
+P = int(sys.argv[1]); m = 1 << int(sys.argv[2]); bits = int(sys.argv[3]); kind = sys.argv[4]; layout = sys.argv[5]
+slab = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+w = bits // 8
+n = m * P
+mg = psac_amd.MultiContext([0] * P)
+lib = mg._lib
+slack = m // 8 + 256
+sizes = [m] * P
+d = dict(text=[], sa=[], isa=[], lcp=[])
+for r in range(P):
+    ctx = mg.rank_ctx(r)
+    def alloc(nb):
+        p = C.c_void_p(); assert lib.psacx_dev_alloc(ctx, C.byref(p), nb) == 0; return p.value
+    d["text"].append(alloc(m))
+    assert lib.psacx_synth_text_dev(ctx, C.c_void_p(d["text"][r]), m, r * m, {"dna": 0, "ascii128": 1, "tandem": 2}[kind], 3 if kind == "tandem" else 1, 1024) == 0
+    for key in ("sa", "isa", "lcp"):
+        d[key].append(alloc((m + slack) * w))
+mg.configure(layout={"normal": 1, "reduced": 2, "auto": 0}[layout], slab=slab, output_slack=slack)
+t0 = time.perf_counter()
+st, sent, ex, ga = mg.construct_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+dt = time.perf_counter() - t0
+peak, reduced, slab_rounds = mg.memory()
+words = max(peak) / float(m * w)
+own = 3.0 * (m + slack) / m + 1.0 / w
+print("P=%d, 2^%s characters per rank, uint%d, %s, layout %s%s: %.1f ms, %d rounds (%d in slabs), %.2f GB between ranks"
+      % (P, sys.argv[2], bits, kind, "reduced" if reduced else "normal", (", slab %d" % slab) if slab else "", dt * 1e3, st.n_rounds, slab_rounds, sent / 1e9))
+print("  engine allocations at their peak: %.2f words per character (max over ranks); with the results (3 x %.3f) and the text: %.2f words"
+      % (words, (m + slack) / float(m), words + own))
+print("  a block of 2^32 characters with 64-bit words would hold %.1f GB of the 288 GB of an MI355X" % ((words + own) * 8 * 2.0 ** 32 / 1e9))
+err = mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+print("  distributed check errors:", err)
+mg.close()
+sys.exit(0 if err == [0, 0, 0, 0] else 1)
