@@ -286,8 +286,9 @@ int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* byt
 #define PSACX_MULTI_OPT_SLAB 2
 #define PSACX_MULTI_OPT_OUTPUT_SLACK 3
 int psacx_multi_configure(psacx_multi* mg, int option, uint64_t value);
-/* after a construction: peak_bytes[i] = high-water mark of the device memory local rank i's block cache held (every
- * array the engine allocated; the caller's text and result arrays are not in it), *reduced = 1 if the reduced-memory
+/* after a construction: peak_bytes[i] = high-water mark of the device memory local rank i's engine had in use at once
+ * (every array it allocated; the caller's text and result arrays are not in it; free blocks the rank keeps cached for
+ * reuse beyond that are returned to the device whenever an allocation does not fit), *reduced = 1 if the reduced-memory
  * layout ran, *slab_rounds = refinement rounds worked off in more than one slab.  Any pointer may be null. */
 int psacx_multi_get_memory(const psacx_multi* mg, uint64_t* peak_bytes, int* reduced, uint32_t* slab_rounds);
 

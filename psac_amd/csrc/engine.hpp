@@ -48,7 +48,8 @@ struct psacx_ctx {
     std::multimap<size_t, void*>* pool = nullptr;
     size_t pool_bytes = 0;           // bytes of cached (free) blocks
     size_t pool_live = 0;            // bytes of blocks handed out
-    size_t pool_peak = 0;            // high-water mark of pool_live + pool_bytes (what the cache really holds of the device)
+    size_t pool_peak = 0;            // high-water mark of pool_live: what the engine needed at once.  Free blocks kept beyond
+                                     // that go back to the device whenever an allocation does not fit (pool_alloc).
     size_t pool_cache_limit = 0;     // > 0: a miss first returns the cached blocks to the device once they exceed this many bytes
     std::string hip_err;
     psacx_stats stats;
@@ -245,6 +246,7 @@ inline void* pool_alloc(psacx_ctx* c, size_t bytes, size_t* cap) {
         void* p = it->second; *cap = it->first;
         c->pool_bytes -= it->first;
         c->pool_live += it->first;
+        c->pool_peak = std::max(c->pool_peak, c->pool_live);
         c->pool->erase(it);
         return p;
     }
@@ -257,7 +259,7 @@ inline void* pool_alloc(psacx_ctx* c, size_t bytes, size_t* cap) {
     }
     *cap = want;
     c->pool_live += want;
-    c->pool_peak = std::max(c->pool_peak, c->pool_live + c->pool_bytes);
+    c->pool_peak = std::max(c->pool_peak, c->pool_live);
     return p;
 }
 inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
@@ -266,7 +268,6 @@ inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
     c->pool->emplace(cap, p);
     c->pool_bytes += cap;
     c->pool_live -= std::min(c->pool_live, cap);
-    if (c->pool_cache_limit && c->pool_bytes > 2 * c->pool_cache_limit) pool_flush(c);
 }
 
 inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8) {

@@ -1158,7 +1158,7 @@ struct MultiRun {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
             S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = want_lcp ? d_lcp[i] : nullptr;
             S[i].out_cap = m_local[i] + g->out_slack; S[i].out_busy = false;
-            S[i].c->pool_peak = S[i].c->pool_live + S[i].c->pool_bytes;
+            S[i].c->pool_peak = S[i].c->pool_live;
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
             return PSACX_OK;
         }));
@@ -1209,12 +1209,9 @@ struct MultiRun {
                 const char* env_slab = getenv("PSACX_MULTI_SLAB");
                 slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
-                for (int i = 0; i < L; ++i) {
-                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
-                    MG_HIP(g, hipSetDevice(ctx(i)->device));
-                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
-                    ctx(i)->pool_peak = ctx(i)->pool_live;
-                }
+                // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
+                //  device only when an allocation does not fit: pool_alloc)
+                for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = 0;
                 g->last_reduced = true;
             } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
             if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
@@ -1625,12 +1622,9 @@ struct MultiRun {
                 const char* env_slab = getenv("PSACX_MULTI_SLAB");
                 slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
-                for (int i = 0; i < L; ++i) {
-                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
-                    MG_HIP(g, hipSetDevice(ctx(i)->device));
-                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
-                    ctx(i)->pool_peak = ctx(i)->pool_live;
-                }
+                // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
+                //  device only when an allocation does not fit: pool_alloc)
+                for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = 0;
                 g->last_reduced = true;
             } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
             if (sizeof(T) == 4 && n > 0xFFFFFFFDull) return PSACX_ERANGE;
@@ -1721,81 +1715,125 @@ struct MultiRun {
             MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
             return PSACX_OK;
         }));
+        // The block is verified in `chunks` pieces of consecutive SA positions (every test is local to an entry and its
+        // predecessor): one piece needs about 24 words per entry, so a block that large a share of the device is cut.
+        uint64_t chunks = 1;
         {
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
+            const char* env = getenv("PSACX_MULTI_CHECK_CHUNKS");
+            for (int i = 0; i < L; ++i) {
+                int same = 0;
+                for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
+                size_t fr = 0, tot = 0;
+                MG_HIP(g, hipSetDevice(ctx(i)->device));
+                MG_HIP(g, hipMemGetInfo(&fr, &tot));
+                const double avail = 0.8 * (double)fr / same, need = 24.0 * (double)m_local[i] * sizeof(T);
+                mine[i][0] = m_local[i];
+                mine[i][1] = env ? strtoull(env, nullptr, 10) : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
+            }
             std::vector<uint64_t> all;
-            PSACX_TRY(gather1(m_local, all));
-            sizes = all; offs = prefix_of(sizes); n = offs[P];
+            PSACX_TRY(gather(2, mine, all));
+            sizes.assign(P, 0);
+            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 2]; chunks = std::max(chunks, all[(size_t)r * 2 + 1]); }
+            chunks = std::min<uint64_t>(chunks, 4096);
+            offs = prefix_of(sizes); n = offs[P];
             for (int r = 0; r < P; ++r)
                 if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
-            for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
+            for (int i = 0; i < L; ++i) { S[i].off = offs[rank(i)]; ctx(i)->pool_cache_limit = 0; }
             if (n == 0) return PSACX_EINVAL;
-            if (diet) {
-                const char* env_slab = getenv("PSACX_MULTI_SLAB");
-                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
-                if (slab_cap < 64) slab_cap = 64;
-                for (int i = 0; i < L; ++i) {
-                    ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) / 2, (size_t)1 << 20);
-                    MG_HIP(g, hipSetDevice(ctx(i)->device));
-                    pool_flush(ctx(i));                  // blocks cached by earlier calls go back to the device first
-                    ctx(i)->pool_peak = ctx(i)->pool_live;
-                }
-                g->last_reduced = true;
-            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
         }
-        std::vector<uint64_t> cnt(L);
-        std::vector<const T*> blk(L), gi(L);
-        std::vector<DBuf<T>> wide(L), q1(L), back, ch, nx;
+        // the text as index words, once (S[SA[i]] travels through the same exchanges as the indices)
+        std::vector<DBuf<T>> wide(L);
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
-            cnt[i] = S[i].m;
-            MG_OP(g, c, wide[i].alloc(c, S[i].m)); MG_OP(g, c, q1[i].alloc(c, S[i].m));
+            MG_OP(g, c, wide[i].alloc(c, S[i].m));
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
-            SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), S[i].m, S[i].SA, S[i].m, (uint64_t)1, n, q1[i].p);
             return PSACX_OK;
         }));
-        for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA; }
-        PSACX_TRY(dist_take(blk, gi, cnt, back));
-        for (int i = 0; i < L; ++i) { blk[i] = wide[i].p; }
-        PSACX_TRY(dist_take(blk, gi, cnt, ch));
-        for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q1[i].p; }
-        PSACX_TRY(dist_take(blk, gi, cnt, nx));
-        wide.clear(); q1.clear();
-        std::vector<psacx_boundary> bd;
-        {
-            std::vector<const T*> a1(L), a2(L), a3(L);
-            for (int i = 0; i < L; ++i) { a1[i] = S[i].SA; a2[i] = ch[i].p; a3[i] = nx[i].p; }
-            PSACX_TRY(neighbours(a1, a2, a3, cnt, 3, bd));
-        }
-        std::vector<DBuf<T>> mins;
-        if (with_lcp) {
-            std::vector<DBuf<T>> qlo(L), qhi(L);
-            std::vector<const T*> lo(L), hi(L);
+        // (SA, S[SA], ISA[SA + 1]) of a range of SA positions of every rank
+        auto triple = [&](const std::vector<uint64_t>& from, const std::vector<uint64_t>& cnt, std::vector<DBuf<T>>* back, std::vector<DBuf<T>>& ch,
+                          std::vector<DBuf<T>>& nx) -> int {
+            std::vector<const T*> blk(L), gi(L);
+            std::vector<DBuf<T>> q1(L);
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
-                MG_OP(g, c, qlo[i].alloc(c, cnt[i])); MG_OP(g, c, qhi[i].alloc(c, cnt[i]));
+                MG_OP(g, c, q1[i].alloc(c, cnt[i]));
                 OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (check_queries_kernel<T>), cnt[i], S[i].SA, ch[i].p, nx[i].p, cnt[i], n, bd[i].has_prev, (T)bd[i].prev[0],
-                              (T)bd[i].prev[1], (T)bd[i].prev[2], qlo[i].p, qhi[i].p);
-                lo[i] = qlo[i].p; hi[i] = qhi[i].p;
+                SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], S[i].SA + from[i], cnt[i], (uint64_t)1, n, q1[i].p);
                 return PSACX_OK;
             }));
-            PSACX_TRY(dist_range_min(lo, hi, cnt, mins));
+            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA + from[i]; }
+            if (back) PSACX_TRY(dist_take(blk, gi, cnt, *back));
+            for (int i = 0; i < L; ++i) blk[i] = wide[i].p;
+            PSACX_TRY(dist_take(blk, gi, cnt, ch));
+            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q1[i].p; }
+            PSACX_TRY(dist_take(blk, gi, cnt, nx));
+            return PSACX_OK;
+        };
+        // the last entry of every block: the predecessor of the next non-empty block's first entry
+        std::vector<psacx_boundary> edge;
+        {
+            std::vector<uint64_t> from(L), one(L);
+            std::vector<DBuf<T>> ch, nx;
+            for (int i = 0; i < L; ++i) { one[i] = S[i].m ? 1 : 0; from[i] = S[i].m ? S[i].m - 1 : 0; }
+            PSACX_TRY(triple(from, one, nullptr, ch, nx));
+            std::vector<const T*> a1(L), a2(L), a3(L);
+            for (int i = 0; i < L; ++i) { a1[i] = S[i].SA + from[i]; a2[i] = ch[i].p; a3[i] = nx[i].p; }
+            PSACX_TRY(neighbours(a1, a2, a3, one, 3, edge));
         }
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(4, 0));
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            DBuf<unsigned long long> e; MG_OP(g, c, e.alloc(c, 4));
-            MG_HIP(g, hipMemsetAsync(e.p, 0, 32, c->stream));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (check_verdict_kernel<T>), cnt[i], S[i].SA, back[i].p, ch[i].p, nx[i].p, (const T*)S[i].LCP,
-                          with_lcp ? (const T*)mins[i].p : (const T*)nullptr, cnt[i], S[i].off, n, bd[i].has_prev, (T)bd[i].prev[0], (T)bd[i].prev[1],
-                          (T)bd[i].prev[2], e.p);
-            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, e.p, 32, hipMemcpyDeviceToHost, c->stream));
-            MG_HIP(g, hipStreamSynchronize(c->stream));
-            std::memcpy(mine[i].data(), c->pinned + 32768, 32);
-            return PSACX_OK;
-        }));
+        std::vector<std::vector<uint64_t>> carry(L, std::vector<uint64_t>(3, 0));        // last entry of the previous piece
+        for (uint64_t q = 0; q < chunks; ++q) {
+            std::vector<uint64_t> from(L), cnt(L);
+            for (int i = 0; i < L; ++i) {
+                from[i] = (uint64_t)(((unsigned __int128)S[i].m * q) / chunks);
+                cnt[i] = (uint64_t)(((unsigned __int128)S[i].m * (q + 1)) / chunks) - from[i];
+            }
+            std::vector<DBuf<T>> back, ch, nx, mins;
+            PSACX_TRY(triple(from, cnt, &back, ch, nx));
+            std::vector<psacx_boundary> bd(L);
+            for (int i = 0; i < L; ++i) {
+                std::memset(&bd[i], 0, sizeof(psacx_boundary));
+                if (from[i] == 0) { bd[i].has_prev = edge[i].has_prev; for (int w = 0; w < 3; ++w) bd[i].prev[w] = edge[i].prev[w]; }
+                else { bd[i].has_prev = 1; for (int w = 0; w < 3; ++w) bd[i].prev[w] = carry[i][w]; }
+            }
+            PSACX_TRY(par([&](int i) -> int {                     // this piece's last entry, for the next one
+                if (!cnt[i]) return PSACX_OK;
+                const T* arr[3] = {S[i].SA + from[i], ch[i].p, nx[i].p};
+                for (int w = 0; w < 3; ++w) { std::vector<uint64_t> o; PSACX_TRY(fetch(i, arr[w], {cnt[i] - 1}, o)); carry[i][w] = o[0]; }
+                return PSACX_OK;
+            }));
+            if (with_lcp) {
+                std::vector<DBuf<T>> qlo(L), qhi(L);
+                std::vector<const T*> lo(L), hi(L);
+                PSACX_TRY(par([&](int i) -> int {
+                    psacx_ctx* c = ctx(i);
+                    MG_OP(g, c, qlo[i].alloc(c, cnt[i])); MG_OP(g, c, qhi[i].alloc(c, cnt[i]));
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (check_queries_kernel<T>), cnt[i], S[i].SA + from[i], ch[i].p, nx[i].p, cnt[i], n, bd[i].has_prev, (T)bd[i].prev[0],
+                                  (T)bd[i].prev[1], (T)bd[i].prev[2], qlo[i].p, qhi[i].p);
+                    lo[i] = qlo[i].p; hi[i] = qhi[i].p;
+                    return PSACX_OK;
+                }));
+                PSACX_TRY(dist_range_min(lo, hi, cnt, mins));
+            }
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                DBuf<unsigned long long> e; MG_OP(g, c, e.alloc(c, 4));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(e.p, 0, 32, c->stream));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (check_verdict_kernel<T>), cnt[i], S[i].SA + from[i], back[i].p, ch[i].p, nx[i].p, with_lcp ? (const T*)(S[i].LCP + from[i]) : (const T*)nullptr,
+                              with_lcp ? (const T*)mins[i].p : (const T*)nullptr, cnt[i], S[i].off + from[i], n, bd[i].has_prev, (T)bd[i].prev[0], (T)bd[i].prev[1],
+                              (T)bd[i].prev[2], e.p);
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, e.p, 32, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                const uint64_t* h = reinterpret_cast<const uint64_t*>(c->pinned + 32768);
+                for (int w = 0; w < 4; ++w) mine[i][w] += h[w];
+                return PSACX_OK;
+            }));
+        }
         std::vector<uint64_t> all;
         PSACX_TRY(gather(4, mine, all));
         for (int q = 0; q < 4; ++q) { errors[q] = 0; for (int r = 0; r < P; ++r) errors[q] += all[(size_t)r * 4 + q]; }

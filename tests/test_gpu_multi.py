@@ -168,11 +168,15 @@ def _blocks_on_device(mg, text, bits, P):
     return d, sizes, free
 
 
-def test_multi_distributed_checker():
+@pytest.mark.parametrize("chunks", [0, 7])
+def test_multi_distributed_checker(chunks, monkeypatch):
     # d_check_sa + the LCP recurrence over block-distributed results (nothing gathered on one rank); a repetitive text
-    # has range minima that span ranks; every kind of corruption must be counted
+    # has range minima that span ranks; every kind of corruption must be counted.  chunks = 7: every block verified in
+    # seven pieces of consecutive SA positions (what the checker does by itself when a block is a large share of the device)
     import ctypes as C
     P, bits = 4, 32
+    if chunks:
+        monkeypatch.setenv("PSACX_MULTI_CHECK_CHUNKS", str(chunks))
     mg = multi(P)
     try:
         for text in (inputs.dna(300007, 4), inputs.tandem(120000, 512, O.rand_dna(512, 2)), np.full(9001, 66, np.uint8)):
