@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="characters per GPU (default: 2^32 at one GPU, 2^28 per GPU otherwise)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="characters per GPU (default: 2^32 -- BASELINE.json configs[3] is 32 GiB over 8 GPUs; with more than one GPU 2^28 if a GPU has less than ~250 GB free)")
     ap.add_argument("--index", type=int, default=None, choices=(32, 64), help="index width (default: 64 above 2^31 characters)")
     ap.add_argument("--alphabet", default="dna", choices=("dna", "ascii128", "tandem"))
     ap.add_argument("--seed", type=int, default=1)
@@ -59,8 +59,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the device checker on the last result")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.n is None:
-        a.n = (1 << 32) if (world == 1 and a.gpus == 1) else (1 << 28)
+    if a.n is None and world == 1 and a.gpus == 1:
+        a.n = 1 << 32
     return a
 
 
@@ -154,6 +154,13 @@ def main_distributed(a, rank, world, local_rank):
     os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.n is None:
+        # 2^32 characters per GPU (the block of configs[3] / configs[4]; the engine takes its reduced-memory layout: about
+        # 7 words per character including the results) when every GPU has the room, else 2^28
+        free_b = torch.cuda.mem_get_info(local_rank)[0]
+        ok = torch.tensor([1 if free_b >= int(7.4 * 8 * (1 << 32)) else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        a.n = (1 << 32) if int(ok.item()) else (1 << 28)
     n = a.n
     bits = a.index if a.index else (32 if world * n <= (1 << 31) else 64)
     if world * n > 0xFFFFFFFE:
@@ -175,7 +182,9 @@ def main_distributed(a, rank, world, local_rank):
     d_text = alloc(n)
     rc = lib.psacx_synth_text_dev(ctx, C.c_void_p(d_text), n, rank * n, KIND_ID[a.alphabet], a.seed, 1024)
     assert rc == 0
-    d_sa, d_isa, d_lcp = alloc(n * w), alloc(n * w), alloc(n * w)
+    slack = n // 8 + 256               # lets the reduced-memory layout use the result arrays as record arrays (psacx.h)
+    d_sa, d_isa, d_lcp = alloc((n + slack) * w), alloc((n + slack) * w), alloc((n + slack) * w)
+    mg.configure(output_slack=slack)
 
     def step():
         return mg.construct_device([d_text], [n], [d_sa], [d_isa], None if a.no_lcp else [d_lcp], bits)
@@ -206,20 +215,27 @@ def main_distributed(a, rank, world, local_rank):
                      "ISA scatter, B2 fetch, range minima) on a second stream per GPU")
         out["exchange"] = {"payload_bytes_sent_by_rank0_per_step": sent, "all_to_all_exchanges_per_step": nex,
                            "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl}
+        peak, reduced, slab_rounds = mg.memory()
+        out["config"]["layout"] = {"reduced_memory": reduced, "refinement_rounds_in_slabs": slab_rounds,
+                                   "engine_words_per_char_at_peak": round(peak[0] / float(n * w), 2),
+                                   "result_arrays_words_per_char": round(3.0 * (n + slack) / n, 3)}
         # for a like-for-like scaling figure: the one-GPU engine on rank 0's block alone (same size, same index width),
-        # timed after the measured region (the N = 1 bench line runs the 4 GiB headline shape instead)
-        try:
-            one = psac_amd.Context(local_rank)
-            sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
-            sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
-            t1 = time.perf_counter()
-            for _ in range(3):
+        # timed after the measured region.  With 2^32 characters per GPU that is the N = 1 bench line itself.
+        if n >= (1 << 32):
+            out["config"]["one_gpu_engine_same_block"] = "the N = 1 line of this bench (same block, same index width)"
+        else:
+            try:
+                one = psac_amd.Context(local_rank)
+                sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
                 sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
-            t1 = (time.perf_counter() - t1) / 3
-            out["config"]["one_gpu_engine_same_block"] = {"ms": round(t1 * 1e3, 3), "MChars_per_s": round(n / t1 / 1e6, 1)}
-            one.close()
-        except Exception as e:          # never let the side measurement break the bench line
-            out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
+                t1 = (time.perf_counter() - t1) / 3
+                out["config"]["one_gpu_engine_same_block"] = {"ms": round(t1 * 1e3, 3), "MChars_per_s": round(n / t1 / 1e6, 1)}
+                one.close()
+            except Exception as e:          # never let the side measurement break the bench line
+                out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
         print(json.dumps(out))
     for p in (d_text, d_sa, d_isa, d_lcp):
         lib.psacx_dev_free(ctx, C.c_void_p(p))

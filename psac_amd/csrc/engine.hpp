@@ -134,10 +134,17 @@ struct Arena {
     }
 };
 
+inline void pool_flush(psacx_ctx* c);
+
 inline int ensure_slab(psacx_ctx* c, size_t bytes) {
     if (c->slab_bytes >= bytes) return PSACX_OK;
     if (c->slab) { (void)hipFree(c->slab); c->slab = nullptr; c->slab_bytes = 0; }
     hipError_t e = hipMalloc((void**)&c->slab, bytes);
+    if (e != hipSuccess && c->pool && !c->pool->empty()) {       // the free blocks the multi-GPU path keeps cached go back first
+        (void)hipGetLastError();
+        pool_flush(c);
+        e = hipMalloc((void**)&c->slab, bytes);
+    }
     if (e != hipSuccess) {
         c->hip_err = std::string("hipMalloc(workspace): ") + hipGetErrorString(e);
         (void)hipGetLastError();
