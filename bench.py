@@ -109,7 +109,6 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
     kname = ("radix_scatter_kernel (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort, look-back form)",
              "radix_scatter3_kernel (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
              "radix_scatter3_kernel<two-word> (one 8-bit digit pass of the first round's (B1,idx) prefix sort)")[dom]
-    rec_words = 2 if dom == 2 else 3
     achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
@@ -130,7 +129,7 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                      "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
                      "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                      "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
-                     "bytes_per_record_per_pass": 2 * rec_words * w,
+                     "bytes_per_record_per_pass": round(scat_bytes[dom] / max(scat_launches[dom], 1) / float(n), 2),
                      "traffic": TRAFFIC.get((dom, n, bits)) if world == 1 else None,
                      "traffic_source": "PMC counters of the committed profile of this workload (profiles/), not measured in this run"},
     }

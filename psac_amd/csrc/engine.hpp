@@ -384,6 +384,7 @@ inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_
 #undef PSACX_SC
 }
 
+inline bool narrow_off_env() { static const bool off = getenv("PSACX_WIDE_PAYLOAD") != nullptr; return off; }
 inline int sort_match_env() {    // 1 = lane-mask table in LDS (default shapes only), anything else / unset = ballot ranking
     static int v = -2;
     if (v == -2) { const char* e = getenv("PSACX_SORT_MATCH"); v = e ? atoi(e) : -1; }
@@ -399,7 +400,7 @@ inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three k
 template <typename T, int BLOCK, int ITEMS, int MINW = 1>
 inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
                          uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false) {
+                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const unsigned slab_tiles = slab_tiles_for(ntiles);
@@ -420,6 +421,18 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     // Measured (profiles/README.md, r02p): it halves the vector instructions of the pass and changes its time by
     // -2 % (2^32 uint64) / +3 % (2^28 uint32) -- the pass is not bound by its VALU work after all -- so the ballot form stays.
     constexpr bool DEF_SHAPE = BLOCK == 512 && ITEMS == (sizeof(T) == 4 ? 12 : 8);
+    constexpr bool NARROW_OK = DEF_SHAPE && sizeof(T) == 8;       // 32-bit payload arrays (radix.hpp: VN), default shape only (8192-record tiles measured: 33.6-34.9 against 28.1 ms per pass)
+    if (NARROW_OK && vn && !ko_in) {
+        if (vn == 1)
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        else
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? 2 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
+                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        return;
+    }
     if (DEF_SHAPE && sort_match_env() == 1) {
         if (ko_in)
             hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, false, DEF_SHAPE ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
@@ -444,8 +457,8 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
 template <typename T>
 inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out,
                            T* v_out, uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false) {
-#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist)
+                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0) {
+#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist, vn)
     switch (cfg) {
         case 0: PSACX_P3(256, 8); break;
         case 2: PSACX_P3(512, 8); break;
@@ -577,6 +590,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     int cfg = sort_cfg_env();
     if (cfg < 0) cfg = in.k2 ? ScatterCfg<T>::DEF : ScatterCfg<T>::DEF2;
     const bool small_desc = n < (1ull << 30);
+    // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
+    // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
+    const bool narrow = three && sizeof(T) == 8 && !in.k2 && iota && n <= (1ull << 32) && cfg == ScatterCfg<T>::DEF2 && !narrow_off_env();
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
     for (int p = 0; p < plan.n_pass; ++p) {
@@ -598,7 +614,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
             dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n,
-                              have_hist);
+                              have_hist, narrow ? (last ? (first ? 0 : 2) : 1) : 0);
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
@@ -624,7 +640,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
+        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? 4ull : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
     }

@@ -135,7 +135,10 @@ template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
 // EXT: the 8-bit class of a record comes from a separate array (dsrc, not moved) instead of a key
 // digit: one such pass partitions records by an externally computed destination.
 // NOKO: records of two words (digit word + payload); ko_in / ko_out are not touched.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0>
+// VN (64-bit words, payloads below 2^32 -- the suffix indices of a text of at most 2^32 characters): 1 = the payload arrays
+// hold 32-bit entries on both sides, 2 = 32-bit entries in, full words out (the last pass of a sort).  The first round's
+// prefix sort then moves 12 instead of 16 bytes per record and pass.
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0, int VN = 0>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE, MATCH>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
@@ -196,8 +199,10 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
-        if (pv) vv[i] = (FULL || loc < count) ? pv[loc] : (T)0;
-        else {
+        if (pv) {
+            if (VN) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (T)0;
+            else vv[i] = (FULL || loc < count) ? pv[loc] : (T)0;
+        } else {
             // implicit payload: the record index, or the suffix the first-round record stands for
             const uint64_t g = base + loc;
             vv[i] = (T)(spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g);
@@ -314,7 +319,11 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
-        if (FULL || p < count) v_out[MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = stage[p];
+        if (FULL || p < count) {
+            const T at = MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p);
+            if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)stage[p];
+            else v_out[at] = stage[p];
+        }
     }
     if (stamp) mydbg[6] = __builtin_amdgcn_s_memtime();
 }
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0, int VN = 0>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
@@ -458,6 +467,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
     static_assert(!(MATCH && EXT), "the lane-mask table form takes its digit from the key word");
+    static_assert(VN == 0 || (sizeof(T) == 8 && NOKO && !EXT), "narrow payloads exist for two-word records of 64-bit words");
     __shared__ ScatterShared<T, TILE, NW, MATCH> sh;
     // tiles are handed out in start order so that neighbouring runs of a digit are written
     // close in time (they share cache lines); nothing ever waits on another workgroup
@@ -468,11 +478,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH, VN>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH, VN>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                          spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
 }
