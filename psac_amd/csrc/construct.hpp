@@ -212,19 +212,47 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 4ull * sizeof(T) * n;
         kin = o.k1; vin = o.k2;
     }
+    // 64-bit words, at most 2^32 positions: the pairs are narrowed to 32 bits by the first partition level (sa_kernels.hpp)
+    const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !getenv("PSACX_ISA_WIDE");
+    if (narrow) {
+        // both 32-bit arrays of a set share that set's first array (t2.k2 may be the ISA array itself, and the window scatter
+        // below widens while it writes: it cannot run in place)
+        uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
+                              {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
+        const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
+        const uint32_t* k32 = nullptr; const uint32_t* v32 = nullptr;
+        for (int lv = 0; lv < levels; ++lv) {
+            const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
+            const size_t ncur = (size_t)(n >> shift) + 1;
+            PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
+            uint32_t* ko = nb[lv & 1][0]; uint32_t* vo = nb[lv & 1][1];
+            if (lv == 0)
+                hipLaunchKernelGGL((partition_pairs_kernel<T, uint32_t, PB, PI, true>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
+                                   ko, vo, n, shift, d_cursors, koff);
+            else
+                hipLaunchKernelGGL((partition_pairs_kernel<uint32_t, uint32_t, PB, PI, false>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, k32, v32,
+                                   ko, vo, n, shift, d_cursors, (uint64_t)0);
+            PSACX_HIP(c, hipGetLastError());
+            k32 = ko; v32 = vo;
+        }
+        const uint64_t nwin = (n + (1ull << INV_WINDOW_BITS) - 1) >> INV_WINDOW_BITS;
+        hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 512, false>), dim3((unsigned)nwin), dim3(512), 0, c->stream, k32, v32, n, d_isa);
+        PSACX_HIP(c, hipGetLastError());
+        return PSACX_OK;
+    }
     for (int lv = 0; !radix_levels && lv < levels; ++lv) {
         const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
         const size_t ncur = (size_t)(n >> shift) + 1;
         PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
         SortBufs<T> o = bufs[lv & 1];
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
-        hipLaunchKernelGGL((partition_pairs_kernel<T, PB, PI>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, kin, vin,
+        hipLaunchKernelGGL((partition_pairs_kernel<T, T, PB, PI>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, kin, vin,
                            o.k1, o.k2, n, shift, d_cursors, lv == 0 ? koff : (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
         kin = o.k1; vin = o.k2;
     }
     const uint64_t nwin = (n + (1ull << INV_WINDOW_BITS) - 1) >> INV_WINDOW_BITS;
-    hipLaunchKernelGGL((window_scatter_kernel<T, 512>), dim3((unsigned)nwin), dim3(512), 0, c->stream, kin, vin, n, d_isa);
+    hipLaunchKernelGGL((window_scatter_kernel<T, T, 512>), dim3((unsigned)nwin), dim3(512), 0, c->stream, kin, vin, n, d_isa);
     PSACX_HIP(c, hipGetLastError());
     return PSACX_OK;
 }

@@ -525,13 +525,16 @@ __global__ void isa_scatter_kernel(const T* __restrict__ SA, const T* __restrict
 // window that one workgroup scatters inside LDS and writes out as full lines.
 constexpr int INV_WINDOW_BITS = 12;
 
-template <typename T, int BLOCK, int ITEMS>
+// TI / TO: entry types of the pairs read and written.  A permutation of at most 2^32 positions held in 64-bit words is
+// narrowed by its first level (SUB1: the value's -1 is applied there, so that bucket id n = 2^32 fits) and travels as
+// 32-bit pairs from then on: 24 + 16 + 16 bytes per record over three levels instead of 3 x 32.
+template <typename TI, typename TO, int BLOCK, int ITEMS, bool SUB1 = false>
 __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
-    const T* __restrict__ key_in, const T* __restrict__ val_in, T* __restrict__ key_out,
-    T* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
+    const TI* __restrict__ key_in, const TI* __restrict__ val_in, TO* __restrict__ key_out,
+    TO* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
     // koff is subtracted from every key on the way in (first level of a rank's block)
     constexpr int TILE = BLOCK * ITEMS;
-    __shared__ T stage[TILE];
+    __shared__ TO stage[TILE];
     __shared__ unsigned cnt[RADIX_P];
     __shared__ unsigned bstart[RADIX_P];
     __shared__ uint64_t gbase[RADIX_P];
@@ -542,12 +545,12 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
     for (int i = tid; i < RADIX_P; i += BLOCK) cnt[i] = 0;
     __syncthreads();
-    T key[ITEMS], val[ITEMS];
+    TO key[ITEMS], val[ITEMS];
     unsigned slot[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
-        if (loc < count) { key[i] = (T)((uint64_t)key_in[base + loc] - koff); val[i] = val_in[base + loc]; }
+        if (loc < count) { key[i] = (TO)((uint64_t)key_in[base + loc] - koff); val[i] = (TO)((uint64_t)val_in[base + loc] - (SUB1 ? 1u : 0u)); }
         else { key[i] = 0; val[i] = 0; }
     }
 #pragma unroll
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (p < count) {
-            const T x = stage[p];
+            const TO x = stage[p];
             dest[j] = gbase[(unsigned)(x >> shift) & (RADIX_P - 1)] + p;
             key_out[dest[j]] = x;
         }
@@ -600,16 +603,16 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     }
 }
 
-// one workgroup per window of 2^INV_WINDOW_BITS destinations
-template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const T* __restrict__ key, const T* __restrict__ val,
-                                                               uint64_t n, T* __restrict__ out) {
+// one workgroup per window of 2^INV_WINDOW_BITS destinations (SUB1: the value's -1 is still to be applied)
+template <typename TI, typename TO, int BLOCK, bool SUB1 = true>
+__global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const TI* __restrict__ key, const TI* __restrict__ val,
+                                                               uint64_t n, TO* __restrict__ out) {
     constexpr unsigned W = 1u << INV_WINDOW_BITS;
-    __shared__ T win[W];
+    __shared__ TO win[W];
     const uint64_t base = (uint64_t)blockIdx.x * W;
     const uint64_t remain = n - base;
     const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
-    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (T)(val[base + p] - 1);
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (TO)((TO)val[base + p] - (SUB1 ? 1u : 0u));
     __syncthreads();
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = win[p];
 }
