@@ -91,9 +91,12 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
 inline int ensure_pinned(psacx_ctx* c, size_t bytes) {
     if (c->pinned_bytes >= bytes) return PSACX_OK;
     if (c->pinned) (void)hipHostFree(c->pinned);
-    c->pinned = nullptr; c->pinned_bytes = 0;
+    c->pinned = nullptr; c->pinned_bytes = 0; c->pinned_dev = nullptr;
     PSACX_HIP(c, hipHostMalloc((void**)&c->pinned, bytes, hipHostMallocDefault));
     c->pinned_bytes = bytes;
+    void* dp = nullptr;
+    if (!getenv("PSACX_NO_HOST_STORES") && hipHostGetDevicePointer(&dp, c->pinned, 0) == hipSuccess) c->pinned_dev = static_cast<char*>(dp);
+    else (void)hipGetLastError();
     return PSACX_OK;
 }
 
@@ -145,13 +148,12 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     {
         ProfScope ps(c, TC_COMPACT);
-        hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, w.d_nact, ntiles, OpSum(),
-                           (uint64_t)0, w.d_totals);
-        hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, w.d_nunf, ntiles, OpSum(),
-                           (uint64_t)0, w.d_totals + 1);
+        // the kernel stores the two totals into the pinned host words itself when the device can address them
+        hipLaunchKernelGGL((tile_scan2_kernel<1024>), dim3(2), dim3(1024), 0, c->stream, w.d_nact, w.d_nunf, ntiles, w.d_totals,
+                           c->pinned_dev ? reinterpret_cast<uint64_t*>(c->pinned_dev) : (uint64_t*)nullptr);
         PSACX_HIP(c, hipGetLastError());
     }
-    PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (!c->pinned_dev) PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *active = h_cnt[0];
     *unf_buckets = h_cnt[1];
@@ -214,6 +216,37 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     }
     // 64-bit words, at most 2^32 positions: the pairs are narrowed to 32 bits by the first partition level (sa_kernels.hpp)
     const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !getenv("PSACX_ISA_WIDE");
+    if (narrow && !getenv("PSACX_ISA_CB8")) {
+        // 2^14-entry windows (64 KiB of 32-bit values in LDS) and 512-way levels: 2^32 positions need two partition
+        // levels instead of three (24 + 16 + 16 = 56 instead of 72 bytes per record)
+        constexpr int WB = 14, CB = 9;
+        uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
+                              {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
+        const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
+        const int lv9 = idx_bits > WB ? (int)((idx_bits - WB + CB - 1) / CB) : 0;
+        const uint32_t* k32 = nullptr; const uint32_t* v32 = nullptr;
+        for (int lv = 0; lv < lv9; ++lv) {
+            const unsigned shift = WB + CB * (lv9 - 1 - lv);
+            const size_t ncur = (size_t)(n >> shift) + 1;
+            PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
+            uint32_t* ko = nb[lv & 1][0]; uint32_t* vo = nb[lv & 1][1];
+            if (lv == 0)
+                hipLaunchKernelGGL((partition_pairs_kernel<T, uint32_t, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
+                                   ko, vo, n, shift, d_cursors, koff);
+            else
+                hipLaunchKernelGGL((partition_pairs_kernel<uint32_t, uint32_t, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, k32, v32,
+                                   ko, vo, n, shift, d_cursors, (uint64_t)0);
+            PSACX_HIP(c, hipGetLastError());
+            k32 = ko; v32 = vo;
+        }
+        if (lv9 == 0) {     // (not reached: the narrow form starts at 2^22 positions)
+            c->hip_err = "inversion: no partition level"; return PSACX_EINVAL;
+        }
+        const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
+        hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 1024, false, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, k32, v32, n, d_isa);
+        PSACX_HIP(c, hipGetLastError());
+        return PSACX_OK;
+    }
     if (narrow) {
         // both 32-bit arrays of a set share that set's first array (t2.k2 may be the ISA array itself, and the window scatter
         // below widens while it writes: it cannot run in place)
@@ -588,7 +621,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
                                plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v, w.sc.d_partials, d_slen);
             PSACX_HIP(c, hipGetLastError());
-            PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
+            // (only the three-kernel form of the sort reads the key summary)
+            if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
         psacx_round rs; std::memset(&rs, 0, sizeof(rs));
         PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, &rs, 0, 0,

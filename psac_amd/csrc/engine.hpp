@@ -35,6 +35,7 @@ struct psacx_ctx {
     char* aux = nullptr;             // second, lazily allocated workspace (range-minimum helpers of level 0)
     size_t aux_bytes = 0;
     char* pinned = nullptr;          // host-pinned scratch (histograms, counters)
+    char* pinned_dev = nullptr;      // the same memory as the device addresses it (kernels store round counters there), or null
     size_t pinned_bytes = 0;
     char* io = nullptr;              // device copies of text / SA / ISA / LCP for the host-pointer entry points (kept between calls)
     size_t io_bytes = 0;
@@ -310,12 +311,18 @@ struct SortScratch {
 };
 
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
+constexpr uint64_t SMALL_SORT_MAX = 1ull << 21;   // below: single-sweep scatter passes with decoupled look-back
 
 inline size_t sort_desc_bytes(uint64_t n) {
     const uint64_t nt = (n + SORT_TILE_MIN - 1) / SORT_TILE_MIN + 1;
     // look-back descriptors, or (three-kernel form) per-tile counters + per-slab totals
-    return 1024 + nt * RADIX * sizeof(uint64_t) + (nt / SLAB_TILES + 2) * RADIX * sizeof(uint64_t);
+    size_t b = 1024 + nt * RADIX * sizeof(uint64_t) + (nt / SLAB_TILES + 2) * RADIX * sizeof(uint64_t);
+    // small sorts (look-back form): one descriptor region per pass, so that one memset serves the whole sort
+    if (n < SMALL_SORT_MAX) b = std::max<size_t>(b, (size_t)MAX_PASSES * (512 + nt * RADIX * sizeof(uint32_t)));
+    return b;
 }
+
+inline bool sort_host_scan_env() { static const bool on = getenv("PSACX_SORT_HOST_SCAN") != nullptr; return on; }
 
 inline unsigned sort_chunk_env() {   // tiles per XCD-local chunk (0 = plain ticket order)
     static int v = -2;
@@ -506,6 +513,13 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
     return PSACX_OK;
 }
 
+// whether a sort of n records runs its passes in the three-kernel form (else: single sweep with look-back).
+// Default: three kernels for large inputs (no workgroup ever waits on another), look-back for small ones where the
+// launch count matters more; records without a second key word exist only in the three-kernel form.
+inline bool sort_is_three(uint64_t n, bool has_k2) {
+    return !has_k2 || (sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= SMALL_SORT_MAX);
+}
+
 // folds the per-workgroup key summaries a producer kernel left in sc.d_partials into sc.d_summary
 inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
     hipLaunchKernelGGL(summary_reduce_kernel<0>, dim3(1), dim3(1024), 0, c->stream, sc.d_partials, nblocks, sc.d_summary);
@@ -533,9 +547,21 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
     // single-sweep look-back form for small ones where launch count matters more
     // (records without a second key word exist only in the three-kernel form)
-    const bool three = !in.k2 || (sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= (1ull << 21));
+    const bool three = sort_is_three(n, in.k2 != nullptr);
     bool skip[MAX_PASSES];
     int n_exec = 0;
+    // look-back form: digit starts scanned on the device, one descriptor region per pass (zeroed by one memset together
+    // with the histograms); the host only learns which passes have a constant digit (flags the scan kernel stores into
+    // pinned host memory).  Needs the scratch laid out as carve() lays it out.
+    int cfg = sort_cfg_env();
+    if (cfg < 0) cfg = in.k2 ? ScatterCfg<T>::DEF : ScatterCfg<T>::DEF2;
+    const bool small_desc = n < (1ull << 30);
+    const size_t hist_bytes = sizeof(unsigned long long) * MAX_PASSES * RADIX;
+    const size_t desc_stride = (256 + ((n + cfg_tile(cfg) - 1) / cfg_tile(cfg)) * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t)) + 255) & ~(size_t)255;
+    const bool dev_scan = !three && !sort_host_scan_env() && !sc.d_dbg && c->pinned_dev && c->pinned_bytes >= 512 &&
+                          reinterpret_cast<char*>(sc.d_base) == reinterpret_cast<char*>(sc.d_hist) + hist_bytes &&
+                          sc.d_desc == reinterpret_cast<char*>(sc.d_base) + hist_bytes &&
+                          (size_t)plan.n_pass * desc_stride <= sc.desc_bytes;
     if (three) {
         // constant digits from the OR/AND summary of the keys; digit starts come from each pass's own scan
         if (!summary_ready) {
@@ -553,6 +579,23 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             skip[p] = ((diff >> plan.shift[p]) & (RADIX - 1)) == 0;
             if (!skip[p]) ++n_exec;
         }
+    } else if (dev_scan) {
+        HistArgs ha;
+        ha.n_pass = plan.n_pass;
+        for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
+        {
+            ProfScope ps(c, TC_SORT_HIST);
+            PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, 2 * hist_bytes + (size_t)plan.n_pass * desc_stride, c->stream));
+            const int grid = grid_for(c, (n + 3) / 4, 256, 8);
+            hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n, ha, sc.d_hist);
+            hipLaunchKernelGGL(radix_hist_scan_kernel<0>, dim3(plan.n_pass), dim3(RADIX), 0, c->stream, sc.d_hist, sc.d_base,
+                               (unsigned long long)n, reinterpret_cast<unsigned*>(c->pinned_dev + 384));
+            PSACX_HIP(c, hipGetLastError());
+        }
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        const unsigned* constant = reinterpret_cast<const unsigned*>(c->pinned + 384);
+        for (int p = 0; p < plan.n_pass; ++p) { skip[p] = constant[p] != 0; if (!skip[p]) ++n_exec; }
+        c->stats.hist_bytes += 2ull * sizeof(T) * n;
     } else {
         HistArgs ha;
         ha.n_pass = plan.n_pass;
@@ -587,9 +630,6 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     }
     if (rs) { rs->sort_passes = (uint32_t)n_exec; rs->sort_passes_skipped = (uint32_t)(plan.n_pass - n_exec); }
 
-    int cfg = sort_cfg_env();
-    if (cfg < 0) cfg = in.k2 ? ScatterCfg<T>::DEF : ScatterCfg<T>::DEF2;
-    const bool small_desc = n < (1ull << 30);
     // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
     const bool narrow = three && sizeof(T) == 8 && !in.k2 && iota && n <= (1ull << 32) && cfg == ScatterCfg<T>::DEF2 && !narrow_off_env();
@@ -609,7 +649,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         const uint64_t tile = cfg_tile(cfg);
         const uint64_t ntiles = (n + tile - 1) / tile;
         const size_t dbytes = 256 + ntiles * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t));
-        PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
+        char* const desc = dev_scan ? sc.d_desc + (size_t)(done - 1) * desc_stride : sc.d_desc;
+        if (!dev_scan) PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
         if (three) {
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
@@ -620,9 +661,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             ProfScope ps(c, TC_SORT_SCATTER);
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             if (small_desc)
-                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
+                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, sc.d_dbg, spec, spec_n);
             else
-                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_err, sc.d_dbg, spec, spec_n);
+                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, sc.d_dbg, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
         }
         if (sc.d_dbg && ntiles >= 64) {

@@ -97,6 +97,23 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const T* __restrict__
     }
 }
 
+// Digit starts of every pass of a small sort, on the device: block p turns the histogram of pass p into its exclusive
+// scan (the look-back form used to fetch the histograms, scan them on the host and send the starts back: one host
+// synchronisation, two copies and a memset per pass).
+// constant[p] (host-pinned memory the device can write) = 1 when one digit of pass p holds all n keys: the host skips it.
+template <int DUMMY>
+__global__ __launch_bounds__(RADIX) void radix_hist_scan_kernel(const unsigned long long* __restrict__ hist,
+                                                                 unsigned long long* __restrict__ base,
+                                                                 unsigned long long n, unsigned* __restrict__ constant) {
+    __shared__ unsigned long long tmp[RADIX / WAVE + 1];
+    const unsigned long long h = hist[(size_t)blockIdx.x * RADIX + threadIdx.x];
+    unsigned long long tot;
+    const unsigned long long ex = block_scan_exclusive<RADIX, unsigned long long>(h, OpSum(), 0ull, tmp, &tot);
+    base[(size_t)blockIdx.x * RADIX + threadIdx.x] = ex;
+    const bool all = __syncthreads_or(h == n);
+    if (threadIdx.x == 0) constant[blockIdx.x] = all ? 1u : 0u;
+}
+
 // ------------------------------------------------------------ scatter pass
 __device__ __forceinline__ uint64_t match_any8(unsigned d, bool valid) {
     uint64_t m = __ballot(valid);

@@ -364,6 +364,37 @@ __global__ __launch_bounds__(BLOCK) void tile_scan_kernel(uint64_t* __restrict__
     if (threadIdx.x == 0 && total) total[0] = carry;
 }
 
+// The two sum scans that follow a rebucket step (active positions, buckets with more than one member) in one launch:
+// block 0 scans a0, block 1 scans a1.  totals[b] receives block b's sum; host_totals (optional) is the same pair in
+// host-pinned memory the device can write, so that the host reads the counters after a stream synchronisation without
+// a copy operation in between.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tile_scan2_kernel(uint64_t* __restrict__ a0, uint64_t* __restrict__ a1, uint64_t len,
+                                                           uint64_t* __restrict__ totals, uint64_t* __restrict__ host_totals) {
+    constexpr int PER = 4;
+    __shared__ uint64_t tmp[BLOCK / WAVE + 1];
+    uint64_t* const a = blockIdx.x ? a1 : a0;
+    const OpSum op;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < len; base += (uint64_t)BLOCK * PER) {
+        const uint64_t e0 = base + (uint64_t)threadIdx.x * PER;
+        uint64_t v[PER];
+        uint64_t run = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { v[j] = (e0 + j < len) ? a[e0 + j] : 0; run += v[j]; }
+        uint64_t tot;
+        uint64_t ex = block_scan_exclusive<BLOCK, uint64_t>(run, op, (uint64_t)0, tmp, &tot);
+        ex += carry;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { if (e0 + j < len) a[e0 + j] = ex; ex += v[j]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x] = carry;
+        if (host_totals) host_totals[blockIdx.x] = carry;
+    }
+}
+
 // ------------------------------------------------------------------ K6 + K7, first round
 // Sorted (S1,S2): writes the bucket id of every position, the LCP of the 2k-mers at
 // every bucket boundary (suffix_array.hpp:1353-1396; sentinel n elsewhere) and, per
@@ -528,22 +559,25 @@ constexpr int INV_WINDOW_BITS = 12;
 // TI / TO: entry types of the pairs read and written.  A permutation of at most 2^32 positions held in 64-bit words is
 // narrowed by its first level (SUB1: the value's -1 is applied there, so that bucket id n = 2^32 fits) and travels as
 // 32-bit pairs from then on: 24 + 16 + 16 bytes per record over three levels instead of 3 x 32.
-template <typename TI, typename TO, int BLOCK, int ITEMS, bool SUB1 = false>
+// CB: class bits of a level (2^CB destination classes per parent bucket; BLOCK >= 2^CB).
+template <typename TI, typename TO, int BLOCK, int ITEMS, bool SUB1 = false, int CB = 8>
 __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     const TI* __restrict__ key_in, const TI* __restrict__ val_in, TO* __restrict__ key_out,
     TO* __restrict__ val_out, uint64_t n, unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
     // koff is subtracted from every key on the way in (first level of a rank's block)
+    constexpr int NCLS = 1 << CB;
+    static_assert(BLOCK >= NCLS, "one thread per class");
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ TO stage[TILE];
-    __shared__ unsigned cnt[RADIX_P];
-    __shared__ unsigned bstart[RADIX_P];
-    __shared__ uint64_t gbase[RADIX_P];
+    __shared__ unsigned cnt[NCLS];
+    __shared__ unsigned bstart[NCLS];
+    __shared__ uint64_t gbase[NCLS];
     __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
     const unsigned tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
     const uint64_t remain = n - base;
     const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
-    for (int i = tid; i < RADIX_P; i += BLOCK) cnt[i] = 0;
+    for (int i = tid; i < NCLS; i += BLOCK) cnt[i] = 0;
     __syncthreads();
     TO key[ITEMS], val[ITEMS];
     unsigned slot[ITEMS];
@@ -556,19 +590,19 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
-        const unsigned d = (unsigned)(key[i] >> shift) & (RADIX_P - 1);
+        const unsigned d = (unsigned)(key[i] >> shift) & (NCLS - 1);
         slot[i] = loc < count ? atomicAdd(&cnt[d], 1u) : 0u;
     }
     __syncthreads();
-    // all keys of a tile share the bits above shift + 8 (tiles never straddle a parent bucket)
-    const unsigned tot = tid < RADIX_P ? cnt[tid] : 0u;
+    // all keys of a tile share the bits above shift + CB (tiles never straddle a parent bucket)
+    const unsigned tot = tid < NCLS ? cnt[tid] : 0u;
     unsigned total;
     const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, scan_tmp, &total);
-    if (tid < RADIX_P) {
+    if (tid < NCLS) {
         bstart[tid] = bs;
         if (tot) {
-            const uint64_t parent = ((uint64_t)key_in[base] - koff) >> shift >> 8;   // same for the whole tile
-            const uint64_t g = (parent << 8) | tid;
+            const uint64_t parent = ((uint64_t)key_in[base] - koff) >> shift >> CB;   // same for the whole tile
+            const uint64_t g = (parent << CB) | tid;
             const unsigned at = atomicAdd(&cursors[g], tot);
             gbase[tid] = (g << shift) + at - bs;
         }
@@ -576,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const unsigned d = (unsigned)(key[i] >> shift) & (RADIX_P - 1);
+        const unsigned d = (unsigned)(key[i] >> shift) & (NCLS - 1);
         slot[i] += bstart[d];
         if (tid + i * BLOCK < count) stage[slot[i]] = key[i];
     }
@@ -587,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
         const unsigned p = tid + j * BLOCK;
         if (p < count) {
             const TO x = stage[p];
-            dest[j] = gbase[(unsigned)(x >> shift) & (RADIX_P - 1)] + p;
+            dest[j] = gbase[(unsigned)(x >> shift) & (NCLS - 1)] + p;
             key_out[dest[j]] = x;
         }
     }
@@ -604,17 +638,19 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
 }
 
 // one workgroup per window of 2^INV_WINDOW_BITS destinations (SUB1: the value's -1 is still to be applied)
-template <typename TI, typename TO, int BLOCK, bool SUB1 = true>
+// WB: window bits.  The window is held in LDS in the narrower of the two entry types (32-bit pairs widened into 64-bit
+// results keep 4 bytes per entry there: 2^14 entries = 64 KiB).
+template <typename TI, typename TO, int BLOCK, bool SUB1 = true, int WB = INV_WINDOW_BITS>
 __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const TI* __restrict__ key, const TI* __restrict__ val,
                                                                uint64_t n, TO* __restrict__ out) {
-    constexpr unsigned W = 1u << INV_WINDOW_BITS;
-    __shared__ TO win[W];
+    constexpr unsigned W = 1u << WB;
+    __shared__ TI win[W];
     const uint64_t base = (uint64_t)blockIdx.x * W;
     const uint64_t remain = n - base;
     const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
-    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (TO)((TO)val[base + p] - (SUB1 ? 1u : 0u));
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (TI)(val[base + p] - (SUB1 ? 1u : 0u));
     __syncthreads();
-    for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = win[p];
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
 }
 
 // ------------------------------------------------------------------ K12
