@@ -188,9 +188,22 @@ inline bool isa_radix_levels(uint64_t n) {
 // with 64-bit words the reservation kernel is the faster one).  Letting the first level make up its payload
 // (ISA[SA[i]] = i, members of unresolved buckets repaired afterwards) was measured: the pass is not
 // read-bound, no gain.
+// 64-bit words, at most 2^32 positions: the inversion moves 32-bit (position, rank) pairs through 512-way partition
+// levels down to windows of 2^14 positions.  Returns the number of levels (0: the form does not apply).
+constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;
+template <typename T>
+inline int isa_narrow_levels(uint64_t n) {
+    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || getenv("PSACX_ISA_WIDE") || getenv("PSACX_ISA_CB8")) return 0;
+    const unsigned idx_bits = bits_for(n - 1);
+    return (int)((idx_bits - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
+}
+inline unsigned isa_narrow_shift(int levels, int lv) { return ISA_NARROW_WB + ISA_NARROW_CB * (levels - 1 - lv); }
+
+// fused_l1: the first narrow level has been run by rebucket_first_kernel (pairs in the two halves of t1.k1)
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
-                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr, bool have_hist0 = false) {
+                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr, bool have_hist0 = false,
+                       bool fused_l1 = false) {
     // have_hist0: the tile histograms of the first radix level are already in sc->d_desc (rebucket_first_kernel)
     constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16, 32-bit destinations with staged class bytes, and cursors padded to their own cache lines all measured the same or worse)
     const unsigned idx_bits = bits_for(n - 1);
@@ -216,17 +229,18 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     }
     // 64-bit words, at most 2^32 positions: the pairs are narrowed to 32 bits by the first partition level (sa_kernels.hpp)
     const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !getenv("PSACX_ISA_WIDE");
-    if (narrow && !getenv("PSACX_ISA_CB8")) {
+    if (fused_l1 && !(narrow && isa_narrow_levels<T>(n) > 0)) { c->hip_err = "inversion: fused first level without the narrow form"; return PSACX_EINVAL; }
+    if (narrow && isa_narrow_levels<T>(n) > 0) {
         // 2^14-entry windows (64 KiB of 32-bit values in LDS) and 512-way levels: 2^32 positions need two partition
         // levels instead of three (24 + 16 + 16 = 56 instead of 72 bytes per record)
-        constexpr int WB = 14, CB = 9;
+        constexpr int WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
         uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
                               {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
-        const int lv9 = idx_bits > WB ? (int)((idx_bits - WB + CB - 1) / CB) : 0;
-        const uint32_t* k32 = nullptr; const uint32_t* v32 = nullptr;
-        for (int lv = 0; lv < lv9; ++lv) {
-            const unsigned shift = WB + CB * (lv9 - 1 - lv);
+        const int lv9 = isa_narrow_levels<T>(n);
+        const uint32_t* k32 = fused_l1 ? nb[0][0] : nullptr; const uint32_t* v32 = fused_l1 ? nb[0][1] : nullptr;
+        for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
+            const unsigned shift = isa_narrow_shift(lv9, lv);
             const size_t ncur = (size_t)(n >> shift) + 1;
             PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
             uint32_t* ko = nb[lv & 1][0]; uint32_t* vo = nb[lv & 1][1];
@@ -323,6 +337,17 @@ int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n) {
         }
     }
     return PSACX_OK;
+}
+
+// rebucket_first_kernel with the first narrow level of the inversion fused in (64-bit words only)
+template <typename T, bool WITH_LCP>
+inline void launch_rebucket_first_fused(psacx_ctx* c, unsigned ntiles, const T* s1, const T* s2, const T* sa, uint64_t n, KeyShape ks,
+                                        T* bsa, T* lcp, uint64_t* carry, uint64_t* nact, uint64_t* nunf, T* pyr1,
+                                        uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors) {
+    if constexpr (sizeof(T) == 8)
+        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
+                           dim3(SCAN_BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
+                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
 }
 
 // d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
@@ -563,6 +588,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     bool isa_hist_ready = false;
+    const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n) > 0 && !getenv("PSACX_NO_FUSED_L1");
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -576,6 +602,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
                                w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
+        } else if (fuse_l1) {
+            // the first level of the SA -> ISA inversion rides along: its (position, rank) pairs go to the payload scratch
+            // array of the sort, which nobody reads any more (word 1 / word 2 / SA are read from other arrays)
+            PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
+            PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
+            uint32_t* const pk = reinterpret_cast<uint32_t*>(w.x.v);
+            launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
+                                                     w.d_nunf, pyr1, pk, pk + n, isa_narrow_shift(isa_narrow_levels<T>(n), 0), w.d_cursors);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
@@ -587,9 +621,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
     {
         ProfScope ps(c, TC_ISA_SCATTER);
-        SortBufs<T> t2 = w.y;
+        SortBufs<T> t1 = w.x, t2 = w.y;
         if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
-        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, t2, 0, &w.sc, isa_hist_ready));
+        if (fuse_l1) { t1.k1 = w.x.v; t2.k1 = w.x.k1; }     // level 1 is in x.v; level 2 writes over word 1 (or its twin), dead by now
+        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, t1, t2, 0, &w.sc, isa_hist_ready, fuse_l1));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);

@@ -400,12 +400,18 @@ __global__ __launch_bounds__(BLOCK) void tile_scan2_kernel(uint64_t* __restrict_
 // every bucket boundary (suffix_array.hpp:1353-1396; sentinel n elsewhere) and, per
 // tile, how many positions stay active (share their bucket) and how many buckets
 // hold more than one suffix (bucketing.hpp:98-118).
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false>
+// PCB > 0 (64-bit words, at most 2^32 positions, one GPU): the kernel also runs the first level of the SA -> ISA
+// inversion on the records it holds anyway: the (position, rank) pairs (SA[e], id[e] - 1) leave as 32-bit pairs
+// partitioned into 2^PCB destination classes by SA >> part_shift (see partition_pairs_kernel, whose first level this
+// replaces: its 16 bytes per record of reads are saved).  part_key / part_val: the pair arrays, part_cursors: zeroed.
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
-    T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0) {
+    T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0,
+    uint32_t* __restrict__ part_key = nullptr, uint32_t* __restrict__ part_val = nullptr, unsigned part_shift = 0,
+    unsigned* __restrict__ part_cursors = nullptr) {
     // sa_hist (optional): per-tile histogram of the digit of SA at sa_hist_shift, for the first level of the
     // SA -> ISA inversion when it runs as radix passes over tiles of this size
     // n: records in this block; ng: length of the whole text (LCP sentinel, suffix lengths)
@@ -534,6 +540,65 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
 #pragma unroll
         for (int d = 1; d < 64 / ITEMS; d <<= 1) { const T o = shfl_xor<T>(m, d); m = o < m ? o : m; }
         if ((threadIdx.x & (64 / ITEMS - 1)) == 0 && e0 < n) pyr1[e0 >> 6] = m;
+    }
+    if constexpr (PCB > 0) {
+        constexpr int NCLS = 1 << PCB;
+        static_assert(BLOCK >= NCLS, "one thread per class");
+        __shared__ uint32_t stage[TILE];
+        __shared__ unsigned pcnt[NCLS];
+        __shared__ unsigned pstart[NCLS];
+        __shared__ uint64_t pbase[NCLS];
+        __shared__ unsigned pscan_tmp[BLOCK / WAVE + 1];
+        const unsigned tid = threadIdx.x;
+        const uint64_t tbase = (uint64_t)tile * TILE;
+        const unsigned count = n - tbase < (uint64_t)TILE ? (unsigned)(n - tbase) : (unsigned)TILE;
+        for (int i = tid; i < NCLS; i += BLOCK) pcnt[i] = 0;
+        __syncthreads();
+        unsigned slot[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned d = (unsigned)((uint64_t)sa[j] >> part_shift) & (NCLS - 1);
+            slot[j] = e0 + j < n ? atomicAdd(&pcnt[d], 1u) : 0u;
+        }
+        __syncthreads();
+        const unsigned tot = tid < NCLS ? pcnt[tid] : 0u;
+        unsigned total;
+        const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, pscan_tmp, &total);
+        if (tid < NCLS) {
+            pstart[tid] = bs;
+            if (tot) {
+                const unsigned at = atomicAdd(&part_cursors[tid], tot);
+                pbase[tid] = ((uint64_t)tid << part_shift) + at - bs;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned d = (unsigned)((uint64_t)sa[j] >> part_shift) & (NCLS - 1);
+            slot[j] += pstart[d];
+            if (e0 + j < n) stage[slot[j]] = (uint32_t)sa[j];
+        }
+        __syncthreads();
+        uint64_t dest[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned p = tid + j * BLOCK;
+            if (p < count) {
+                const uint32_t x = stage[p];
+                dest[j] = pbase[(x >> part_shift) & (NCLS - 1)] + p;
+                part_key[dest[j]] = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (e0 + j < n) stage[slot[j]] = (uint32_t)(id[j] - 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned p = tid + j * BLOCK;
+            if (p < count) part_val[dest[j]] = stage[p];
+        }
     }
 }
 
