@@ -198,6 +198,33 @@ inline int isa_narrow_levels(uint64_t n) {
     return (int)((idx_bits - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
 }
 inline unsigned isa_narrow_shift(int levels, int lv) { return ISA_NARROW_WB + ISA_NARROW_CB * (levels - 1 - lv); }
+// the same levels for 32-bit words (their pairs are 32-bit anyway), used when rebucket_first_kernel runs the first one
+inline int isa_levels32(uint64_t n) {
+    if (n < (1ull << 22) || n > (1ull << 32)) return 0;
+    return (int)((bits_for(n - 1) - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
+}
+
+// Levels 1.. of the inversion on 32-bit (position, rank) pairs whose first level rebucket_first_kernel has run
+// (pairs in k32 / v32, ranks already 0-based), then the window scatter into ISA.  ko / vo: a second pair of arrays.
+template <typename T>
+int finish_inversion32(psacx_ctx* c, unsigned* d_cursors, uint32_t* k32, uint32_t* v32, uint32_t* ko, uint32_t* vo, uint64_t n,
+                       int levels, T* d_isa) {
+    constexpr int PB = 512, PI = 16, WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
+    const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
+    for (int lv = 1; lv < levels; ++lv) {
+        const unsigned shift = isa_narrow_shift(levels, lv);
+        PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ((size_t)(n >> shift) + 1) * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL((partition_pairs_kernel<uint32_t, uint32_t, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream,
+                           (const uint32_t*)k32, (const uint32_t*)v32, ko, vo, n, shift, d_cursors, (uint64_t)0);
+        PSACX_HIP(c, hipGetLastError());
+        std::swap(k32, ko); std::swap(v32, vo);
+    }
+    const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
+    hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 1024, false, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream,
+                       (const uint32_t*)k32, (const uint32_t*)v32, n, d_isa);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
 
 // fused_l1: the first narrow level has been run by rebucket_first_kernel (pairs in the two halves of t1.k1)
 template <typename T>
@@ -339,15 +366,14 @@ int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n) {
     return PSACX_OK;
 }
 
-// rebucket_first_kernel with the first narrow level of the inversion fused in (64-bit words only)
+// rebucket_first_kernel with the first level of the inversion fused in
 template <typename T, bool WITH_LCP>
 inline void launch_rebucket_first_fused(psacx_ctx* c, unsigned ntiles, const T* s1, const T* s2, const T* sa, uint64_t n, KeyShape ks,
                                         T* bsa, T* lcp, uint64_t* carry, uint64_t* nact, uint64_t* nunf, T* pyr1,
                                         uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors) {
-    if constexpr (sizeof(T) == 8)
-        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
-                           dim3(SCAN_BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
-                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
+    hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
+                       dim3(SCAN_BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
+                       (unsigned*)nullptr, 0, pk, pv, shift, cursors);
 }
 
 // d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
@@ -589,12 +615,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     bool isa_hist_ready = false;
     const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n) > 0 && !getenv("PSACX_NO_FUSED_L1");
+    // 32-bit words, normal layout: the same fusion; the pairs use two payload scratch arrays of the sort, the second level
+    // the two position lists (all idle between the sort and the first compaction)
+    const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0 && !getenv("PSACX_NO_FUSED_L1") &&
+                        !getenv("PSACX_ISA_PARTITION");
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
         T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
         // ... and so do the tile histograms of the inversion's first radix level when the tiles agree
-        isa_hist_ready = isa_radix_levels<T>(n) && (uint64_t)SCAN_TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
+        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n) && (uint64_t)SCAN_TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
                          !getenv("PSACX_NO_KEY_HIST");
         unsigned* const sa_hist = isa_hist_ready ? reinterpret_cast<unsigned*>(w.sc.d_desc + 256) : (unsigned*)nullptr;
         if (gsa) {
@@ -602,6 +632,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
                                dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
                                w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
+        } else if (fuse32) {
+            PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
+            PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
+            launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
+                                                     w.d_nunf, pyr1, reinterpret_cast<uint32_t*>(w.x.v), reinterpret_cast<uint32_t*>(w.y.v),
+                                                     isa_narrow_shift(isa_levels32(n), 0), w.d_cursors);
         } else if (fuse_l1) {
             // the first level of the SA -> ISA inversion rides along: its (position, rank) pairs go to the payload scratch
             // array of the sort, which nobody reads any more (word 1 / word 2 / SA are read from other arrays)
@@ -624,7 +660,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         SortBufs<T> t1 = w.x, t2 = w.y;
         if (w.diet) { t2.k1 = w.x.v; t2.k2 = d_isa; }       // the last partition level may write the values into ISA itself
         if (fuse_l1) { t1.k1 = w.x.v; t2.k1 = w.x.k1; }     // level 1 is in x.v; level 2 writes over word 1 (or its twin), dead by now
-        PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, t1, t2, 0, &w.sc, isa_hist_ready, fuse_l1));
+        if (fuse32)
+            PSACX_TRY(finish_inversion32<T>(c, w.d_cursors, reinterpret_cast<uint32_t*>(w.x.v), reinterpret_cast<uint32_t*>(w.y.v),
+                                            reinterpret_cast<uint32_t*>(w.pos_a), reinterpret_cast<uint32_t*>(w.pos_b), n, isa_levels32(n), d_isa));
+        else
+            PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, t1, t2, 0, &w.sc, isa_hist_ready, fuse_l1));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);
