@@ -129,7 +129,7 @@ template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
                 KeyShape ks) {
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)ntiles), dim3(256), 0, c->stream,
                        a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),

@@ -295,10 +295,10 @@ int run_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3,
                   Boundary<T> bd, TileScratch& ts) {
     const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
     if (mode == 0)
-        hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, s1, s2,
+        hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2,
                            (const T*)nullptr, cnt, (unsigned)SCAN_TILE, ntiles, ts.carry, s3, ks, n, bd);
     else
-        hipLaunchKernelGGL((last_head_kernel<T, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, s1, s2, s3,
+        hipLaunchKernelGGL((last_head_kernel<T, true>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2, s3,
                            cnt, (unsigned)SCAN_TILE, ntiles, ts.carry, (const T*)nullptr, ks, n, bd);
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, ts.carry, ntiles, OpMax(), (uint64_t)0,

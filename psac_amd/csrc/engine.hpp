@@ -555,6 +555,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     // pinned host memory).  Needs the scratch laid out as carve() lays it out.
     int cfg = sort_cfg_env();
     if (cfg < 0) cfg = in.k2 ? ScatterCfg<T>::DEF : ScatterCfg<T>::DEF2;
+    // (2048-record tiles for the small sorts were measured: three times the look-back chain, 0.27 -> 0.29 ms per round at 2^20)
     const bool small_desc = n < (1ull << 30);
     const size_t hist_bytes = sizeof(unsigned long long) * MAX_PASSES * RADIX;
     const size_t desc_stride = (256 + ((n + cfg_tile(cfg) - 1) / cfg_tile(cfg)) * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t)) + 255) & ~(size_t)255;
