@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Valid for the default workload only (2^28 uint32 records per launch).
 # [1] three-word form, profiles/r01_pmc_*.txt: (2 x 7454089 + 17090295) KiB over 5 launches
 # [2] two-word form, profiles/r01d_pmc_*.txt: (2 x 5903929.2 + 12713084.0) KiB over 6 launches
-# [2] at 2^32 uint64 records (the default workload; 32-bit payload between the passes), profiles/r02u_pmc_*.txt: (2 x 120112344.2 + 279421749.4) KiB over 5 launches
+# [2] at 2^32 uint64 records (the default workload; 32-bit payload between the passes), profiles/r02v_pmc_*.txt: (2 x 120112043.4 + 280974031.5) KiB over 5 launches
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 106423590462}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 106741374627}
 
 
 def parse():
