@@ -13,9 +13,15 @@
 
 namespace psacx {
 
-constexpr int SCAN_BLOCK = 768;
+// Tile shape of the scan-structured kernels (last head / rebucket / compaction).  64-bit words run 512-thread
+// workgroups (two per CU at their register count: rebucket_first_kernel 60.8 -> 51.1 ms at 2^32), 32-bit words
+// 768-thread ones (the tile of their radix scatter passes; 512 and 1024 measured the same or slower).
 constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+template <typename T> struct ScanCfg {
+    static constexpr int BLOCK = sizeof(T) == 8 ? 512 : 768;
+    static constexpr int TILE = BLOCK * SCAN_ITEMS;
+};
+constexpr int SCAN_TILE_MIN = 512 * SCAN_ITEMS;      // sizes per-tile arrays where the word type is not known
 
 template <typename T> struct Work {
     T *bsa;
@@ -70,7 +76,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
         }
     }
     w.d_hist256 = a.take<unsigned long long>(256);
-    const uint64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+    const uint64_t nt = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE + 1;
     w.d_carry = a.take<uint64_t>(nt);
     w.d_nact = a.take<uint64_t>(nt);
     w.d_nunf = a.take<uint64_t>(nt);
@@ -128,9 +134,9 @@ inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k)
 template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
                 KeyShape ks) {
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)ntiles), dim3(256), 0, c->stream,
-                       a1, a2, pos, cnt, (unsigned)SCAN_TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
+                       a1, a2, pos, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
                        (uint64_t)0, (uint64_t*)nullptr);
@@ -145,7 +151,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
                 const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0) {
     // pos_off: SA position of ids[0] when pos_in is null (a slab of the reduced-memory layout)
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     {
         ProfScope ps(c, TC_COMPACT);
         // the kernel stores the two totals into the pinned host words itself when the device can address them
@@ -160,12 +166,12 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     if (*active > 0 && *active <= capacity) {
         ProfScope ps(c, TC_COMPACT);
         if (payload)
-            hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
+            hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
+                               dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
                                payload, out_id, out_payload);
         else
-            hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
+            hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
+                               dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
                                (const T*)nullptr, (T*)nullptr, (T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
     }
@@ -371,8 +377,8 @@ template <typename T, bool WITH_LCP>
 inline void launch_rebucket_first_fused(psacx_ctx* c, unsigned ntiles, const T* s1, const T* s2, const T* sa, uint64_t n, KeyShape ks,
                                         T* bsa, T* lcp, uint64_t* carry, uint64_t* nact, uint64_t* nunf, T* pyr1,
                                         uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors) {
-    hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
-                       dim3(SCAN_BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
+    hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
+                       dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
                        (unsigned*)nullptr, 0, pk, pv, shift, cursors);
 }
 
@@ -552,10 +558,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_HIP(c, hipStreamSynchronize(c->stream));
         if (*h_big || getenv("PSACX_TIES_RADIX")) {
             // some group is long (repetitive text): compact all ties and radix-sort them by the full window
-            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+            const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
             {
                 ProfScope ps(c, TC_COMPACT);
-                hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+                hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                                    c->stream, S1, n, (T)0, (T)0, w.d_nact, lo1);
                 PSACX_HIP(c, hipGetLastError());
                 PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
@@ -621,16 +627,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                         !getenv("PSACX_ISA_PARTITION");
     {
         ProfScope ps(c, TC_REBUCKET);
-        const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
         T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
         // ... and so do the tile histograms of the inversion's first radix level when the tiles agree
-        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n) && (uint64_t)SCAN_TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
+        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n) && (uint64_t)ScanCfg<T>::TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
                          !getenv("PSACX_NO_KEY_HIST");
         unsigned* const sa_hist = isa_hist_ready ? reinterpret_cast<unsigned*>(w.sc.d_desc + 256) : (unsigned*)nullptr;
         if (gsa) {
             PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
-            hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
+            hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, true>), dim3((unsigned)ntiles),
+                               dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
                                w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
         } else if (fuse32) {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
@@ -648,8 +654,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                                      w.d_nunf, pyr1, pk, pk + n, isa_narrow_shift(isa_narrow_levels<T>(n), 0), w.d_cursors);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
-            hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
+            hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
+                               dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp,
                                w.d_carry, w.d_nact, w.d_nunf, n, Boundary<T>(), pyr1, sa_hist, (int)INV_WINDOW_BITS);
         }
         PSACX_HIP(c, hipGetLastError());
@@ -707,10 +713,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n));
         {
             ProfScope ps(c, TC_REBUCKET);
-            const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+            const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
             PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, KeyShape())));
-            hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
-                               dim3(SCAN_BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
+            hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
+                               dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
                                d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
                                (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr);
             PSACX_HIP(c, hipGetLastError());
@@ -725,8 +731,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         const uint64_t round_cnt = no_fast ? n : active;
         if (!no_fast && !have_list && active <= w.cap_active) {
             // back under the capacity: rebuild the list of unresolved positions from the bucket ids
-            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-            hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+            const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+            hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                                c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u);
             PSACX_HIP(c, hipGetLastError());
             PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
@@ -744,21 +750,21 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             // slabs may already carry this round's refinement (Larsson-Sadakane style): the order stays a
             // refinement of the true suffix order and every new LCP is still h + a range minimum over final entries,
             // only the per-round counters may run ahead of the reference's log.
-            const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-            hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+            const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+            hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                                c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u);
             PSACX_HIP(c, hipGetLastError());
             std::vector<uint64_t> tile_act(ntiles);
             PSACX_HIP(c, hipMemcpyAsync(tile_act.data(), w.d_nact, ntiles * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
             PSACX_HIP(c, hipStreamSynchronize(c->stream));
-            const uint64_t room = w.cap_active > 2ull * SCAN_TILE ? w.cap_active - 2ull * SCAN_TILE : 0;
+            const uint64_t room = w.cap_active > 2ull * ScanCfg<T>::TILE ? w.cap_active - 2ull * ScanCfg<T>::TILE : 0;
             uint64_t sum_act = 0, sum_unf = 0, s0 = 0;
             T* h_id = reinterpret_cast<T*>(c->pinned + 128);
             while (s0 < n) {
                 // furthest tile boundary whose tiles (from the one holding s0) hold at most `room` unresolved positions
-                uint64_t t = s0 / SCAN_TILE, acc = 0;
+                uint64_t t = s0 / ScanCfg<T>::TILE, acc = 0;
                 while (t < ntiles && acc + tile_act[t] <= room) acc += tile_act[t++];
-                uint64_t e = std::min<uint64_t>(t * (uint64_t)SCAN_TILE, n);
+                uint64_t e = std::min<uint64_t>(t * (uint64_t)ScanCfg<T>::TILE, n);
                 if (e < n) {
                     // back to the head of the bucket that holds position e (bucket id = head position + 1)
                     PSACX_HIP(c, hipMemcpyAsync(h_id, w.bsa + e, sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -769,8 +775,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                     c->hip_err = "a bucket of unresolved suffixes is larger than the reduced-memory layout has room for";
                     return PSACX_ENOMEM;
                 }
-                const uint64_t len = e - s0, lt = (len + SCAN_TILE - 1) / SCAN_TILE;
-                hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)lt), dim3(SCAN_BLOCK), 0,
+                const uint64_t len = e - s0, lt = (len + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+                hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)lt), dim3(ScanCfg<T>::BLOCK), 0,
                                    c->stream, w.bsa + s0, len, (T)0, (T)0, w.d_nact, 0u);
                 PSACX_HIP(c, hipGetLastError());
                 PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, lt * sizeof(uint64_t), c->stream));

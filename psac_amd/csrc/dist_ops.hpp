@@ -155,7 +155,7 @@ inline KeyShape shape_of(uint32_t l, uint32_t c1, uint32_t c2) { KeyShape ks; ks
 // tile scratch (carry / nact / nunf / totals) out of the ctx slab
 struct TileScratch { uint64_t *carry, *nact, *nunf, *totals; };
 inline int tile_scratch(psacx_ctx* c, uint64_t cnt, TileScratch& ts, size_t extra_bytes, char** extra) {
-    const uint64_t nt = (cnt + SCAN_TILE - 1) / SCAN_TILE + 1;
+    const uint64_t nt = (cnt + SCAN_TILE_MIN - 1) / SCAN_TILE_MIN + 1;
     Arena dry(nullptr);
     auto lay = [&](Arena& a) { ts.carry = a.take<uint64_t>(nt); ts.nact = a.take<uint64_t>(nt); ts.nunf = a.take<uint64_t>(nt);
                                ts.totals = a.take<uint64_t>(8); if (extra) *extra = a.take<char>(extra_bytes); };
@@ -293,13 +293,13 @@ int op_pair_bounds(psacx_ctx* c, const T* s1, const T* s2, uint64_t n, const uin
 template <typename T>
 int run_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3, uint64_t cnt, uint64_t n, KeyShape ks,
                   Boundary<T> bd, TileScratch& ts) {
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     if (mode == 0)
         hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2,
-                           (const T*)nullptr, cnt, (unsigned)SCAN_TILE, ntiles, ts.carry, s3, ks, n, bd);
+                           (const T*)nullptr, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, ts.carry, s3, ks, n, bd);
     else
         hipLaunchKernelGGL((last_head_kernel<T, true>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2, s3,
-                           cnt, (unsigned)SCAN_TILE, ntiles, ts.carry, (const T*)nullptr, ks, n, bd);
+                           cnt, (unsigned)ScanCfg<T>::TILE, ntiles, ts.carry, (const T*)nullptr, ks, n, bd);
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, ts.carry, ntiles, OpMax(), (uint64_t)0,
                        ts.totals);
@@ -347,12 +347,12 @@ int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint6
     const KeyShape ks = shape_of(l, c1, c2);
     const Boundary<T> bd = to_boundary<T>(b);
     PSACX_TRY(run_last_head<T>(c, 0, s1, s2, sa, cnt, n, ks, bd, ts));
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     if (lcp)
-        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd);
     else
-        hipLaunchKernelGGL((rebucket_first_kernel<T, SCAN_BLOCK, SCAN_ITEMS, false>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd);
     PSACX_HIP(c, hipGetLastError());
     return counts_back<T>(c, ts, ntiles, nact, nunf);
@@ -370,18 +370,18 @@ int op_rebucket_refine(psacx_ctx* c, const T* t1, const T* t2, const T* tv, cons
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
     const Boundary<T> bd = to_boundary<T>(b);
     PSACX_TRY(run_last_head<T>(c, 1, t1, t2, pos, cnt, n, shape_of(1, 1, 0), bd, ts));
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     unsigned long long* qc = reinterpret_cast<unsigned long long*>(ts.totals + 2);
     PSACX_HIP(c, hipMemsetAsync(qc, 0, 8, c->stream));
     Pyramid<T> pyr;
     std::memset(&pyr, 0, sizeof(pyr));
     pyr.lvl[0] = lcp_block; pyr.nlev = lcp_block ? 1 : 0;
     if (lcp_block)
-        hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, true, true>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+        hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, t1, t2, tv, pos, cnt, n, h, sa_block, bsa_block, (T*)nullptr, pyr, ids_out, ts.carry, ts.nact,
                            ts.nunf, bd, q_at, q_lo, q_hi, qc);
     else
-        hipLaunchKernelGGL((rebucket_refine_kernel<T, SCAN_BLOCK, SCAN_ITEMS, false, true>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0,
+        hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, t1, t2, tv, pos, cnt, n, h, sa_block, bsa_block, (T*)nullptr, pyr, ids_out, ts.carry, ts.nact,
                            ts.nunf, bd, q_at, q_lo, q_hi, qc);
     PSACX_HIP(c, hipGetLastError());
@@ -399,11 +399,11 @@ int op_compact(psacx_ctx* c, const T* ids, const T* pos, uint64_t cnt, uint64_t 
     PSACX_TRY(ensure_pinned(c, 4096));
     TileScratch ts;
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
-    const uint64_t ntiles = (cnt + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL((count_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, c->stream, ids, cnt,
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+    hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, cnt,
                        (T)prev_id, (T)next_id, ts.nact);
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, ts.nact, ntiles, OpSum(), (uint64_t)0, ts.totals);
-    hipLaunchKernelGGL((compact_active_kernel<T, SCAN_BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, c->stream, ids, pos,
+    hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos,
                        cnt, pos_out, ts.nact, off, (T)prev_id, (T)next_id);
     PSACX_HIP(c, hipGetLastError());
     PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));
