@@ -161,6 +161,46 @@ def test_isa_inversion_partition_path(ctx):
         assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
 
 
+@pytest.mark.parametrize("env", ["PSACX_NO_FUSED_L1", "PSACX_ISA_CB8", "PSACX_ISA_WIDE", "PSACX_ISA_PARTITION"])
+def test_isa_inversion_earlier_forms(ctx, monkeypatch, env):
+    # The default SA -> ISA inversion (first level fused into rebucket_first_kernel, 512-way levels, 2^14-entry windows)
+    # against its earlier forms, which stay selectable: the results must be identical (and are checked on their own).
+    cases = (((1 << 22) + 4097, 64, 5), ((1 << 23) + 77, 32, 6), ((1 << 22) + 1, 32, 7))
+    base = []
+    for n, bits, seed in cases:
+        text = inputs.dna(n, seed)
+        sa = run(ctx, text, bits=bits)
+        assert O.check_sa(text, sa.local_SA, sa.local_B) == 0
+        base.append((sa.local_SA.copy(), sa.local_B.copy(), sa.local_LCP.copy()))
+    monkeypatch.setenv(env, "1")
+    for (n, bits, seed), (SA, B, LCP) in zip(cases, base):
+        sa = run(ctx, inputs.dna(n, seed), bits=bits)
+        assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_B, B) and np.array_equal(sa.local_LCP, LCP)
+
+
+def test_small_sort_host_scan_form():
+    # The small (look-back) sorts scan their digit histograms on the device and receive the round counters through
+    # pinned host memory; PSACX_SORT_HOST_SCAN / PSACX_NO_HOST_STORES select the earlier host-side forms (read once per
+    # process, hence the child processes).  A tandem repeat keeps 2^18 suffixes unresolved for 15 rounds.
+    prog = ("import sys, zlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import inputs, psac_amd;"
+            "t = inputs.tandem(1 << 18, 256, inputs.dna(256, 3));"
+            "sa = psac_amd.SuffixArray(index_bits=32, lcp=True); sa.construct(t);"
+            "print(zlib.crc32(sa.local_SA.tobytes()), zlib.crc32(sa.local_B.tobytes()), zlib.crc32(sa.local_LCP.tobytes()), len(sa.rounds))"
+            % (os.path.dirname(HERE), HERE))
+    import subprocess
+    import zlib
+    outs = []
+    for extra in ({}, {"PSACX_SORT_HOST_SCAN": "1"}, {"PSACX_NO_HOST_STORES": "1"}):
+        env = dict(os.environ); env.update(extra)
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
+    t = inputs.tandem(1 << 18, 256, inputs.dna(256, 3))
+    ref = O.construct(t, bits=32)
+    assert outs[0].split()[0] == str(zlib.crc32(np.asarray(ref["SA"], np.uint32).tobytes()))
+
+
 def test_pair_sort_standalone(ctx):
     # idxsort.hpp:23-83: records (b1, b2, i) sorted by (b1, b2)
     import ctypes as C
