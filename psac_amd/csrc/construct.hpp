@@ -135,7 +135,7 @@ template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
                 KeyShape ks) {
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-    hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)ntiles), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)(REFINE ? ntiles : (ntiles + 3) / 4)), dim3(256), 0, c->stream,
                        a1, a2, pos, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
     hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),

@@ -295,7 +295,7 @@ int run_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3,
                   Boundary<T> bd, TileScratch& ts) {
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     if (mode == 0)
-        hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2,
+        hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, s1, s2,
                            (const T*)nullptr, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, ts.carry, s3, ks, n, bd);
     else
         hipLaunchKernelGGL((last_head_kernel<T, true>), dim3((unsigned)ntiles), dim3(256), 0, c->stream, s1, s2, s3,

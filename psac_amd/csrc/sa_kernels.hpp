@@ -300,18 +300,22 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
                                  const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
                                  uint64_t ntiles, uint64_t* __restrict__ agg, const T* __restrict__ SA,
                                  KeyShape ks, uint64_t n_global, Boundary<T> bd) {
-    // One workgroup of four waves per tile, every wave searching its quarter of the tile backwards: in ordinary text each
-    // finds a head in its first window; in a text with long runs of equal records (tandem repeats) the whole tile is
-    // walked, and one wave per tile was 96 dependent steps = 34 us of a 230 us refinement round on 2^20 suffixes.
+    // Refinement rounds: one workgroup of four waves per tile, every wave searching its quarter of the tile backwards.  In
+    // ordinary text each finds a head in its first window; in a text with long runs of equal records (tandem repeats) the
+    // whole tile is walked, and one wave per tile was 96 dependent steps = 34 us of a 230 us refinement round on 2^20
+    // suffixes.  The first round (once per construction, 2^20 tiles at 2^32 records) keeps one wave per tile.
     constexpr unsigned NW = 256 / WAVE;
+    constexpr unsigned WPT = REFINE ? NW : 1;           // waves per tile
+    constexpr unsigned TPB = NW / WPT;                  // tiles per workgroup
     __shared__ uint64_t wfound[NW];
-    const uint64_t tile = blockIdx.x;
     const unsigned lane = lane_id(), wv = threadIdx.x / WAVE;
-    const uint64_t t_lo = tile * tile_size;
+    const uint64_t tile = (uint64_t)blockIdx.x * TPB + wv / WPT;
+    const unsigned sub = wv % WPT;
+    const uint64_t t_lo = tile < ntiles ? tile * tile_size : cnt;
     uint64_t t_hi = t_lo + tile_size;
     if (t_hi > cnt) t_hi = cnt;
-    const unsigned quarter = ((tile_size + NW - 1) / NW + WAVE - 1) / WAVE * WAVE;
-    const uint64_t lo = t_lo + (uint64_t)wv * quarter < t_hi ? t_lo + (uint64_t)wv * quarter : t_hi;
+    const unsigned quarter = ((tile_size + WPT - 1) / WPT + WAVE - 1) / WAVE * WAVE;
+    const uint64_t lo = t_lo + (uint64_t)sub * quarter < t_hi ? t_lo + (uint64_t)sub * quarter : t_hi;
     const uint64_t hi = lo + quarter < t_hi ? lo + quarter : t_hi;
     uint64_t found = 0;
     // walk backwards in windows of 64 records [w0, w0 + 64)
@@ -346,10 +350,11 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
     }
     if (lane == 0) wfound[wv] = found;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < TPB) {
+        const uint64_t t = (uint64_t)blockIdx.x * TPB + threadIdx.x;
         uint64_t f = 0;
-        for (int w = NW - 1; w >= 0 && !f; --w) f = wfound[w];
-        agg[tile] = f;
+        for (int w = (int)WPT - 1; w >= 0 && !f; --w) f = wfound[threadIdx.x * WPT + w];
+        if (t < ntiles) agg[t] = f;
     }
 }
 
