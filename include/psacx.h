@@ -259,6 +259,19 @@ int psacx_multi_check_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, con
                               const uint32_t* const* d_ISA, const uint32_t* const* d_LCP, uint64_t errors[4]);
 int psacx_multi_check_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* const* d_SA,
                               const uint64_t* const* d_ISA, const uint64_t* const* d_LCP, uint64_t errors[4]);
+/* Left-branching characters of block-distributed results (suffix_array<char_t, index_t, true, true>::local_Lc on p ranks,
+ * suffix_array.hpp:211-212; filled by :1365-1383 and par_rmq.hpp:334-481 in the reference; by definition
+ * Lc[i] = S[SA[i-1] + LCP[i]], desa.hpp:262-264, '\0' past the end and at i = 0): d_Lc[i] receives m[i] bytes for the
+ * block of local rank i.  SA and LCP as psacx_multi_construct_dev_* left them. */
+/* the host-pointer form (psacx_multi_construct_* + Lc[0..n)): flags must carry PSACX_LCP */
+int psacx_multi_construct_lc_u32(psacx_multi* mg, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint32_t* SA,
+                                 uint32_t* ISA, uint32_t* LCP, uint8_t* Lc);
+int psacx_multi_construct_lc_u64(psacx_multi* mg, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint64_t* SA,
+                                 uint64_t* ISA, uint64_t* LCP, uint8_t* Lc);
+int psacx_multi_left_chars_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint32_t* const* d_SA,
+                                   const uint32_t* const* d_LCP, uint8_t* const* d_Lc);
+int psacx_multi_left_chars_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* const* d_SA,
+                                   const uint64_t* const* d_LCP, uint8_t* const* d_Lc);
 /* ansv<T, left_type, right_type, global_indexing>(in, left_nsv, right_nsv, comm) (ansv.hpp:2042-2051) over a
  * block-distributed array (blocks as mxx::blk_dist, e.g. the LCP blocks psacx_multi_construct_dev_* left in HBM):
  * d_left[i] / d_right[i] receive, per element of local rank i's block, the GLOBAL index of its nearest smaller value on

@@ -225,9 +225,9 @@ public:
         int rc;
         if (multi_) {
             // p ranks, one GPU each: blocks of n / p characters (mxx::blk_dist), results gathered in rank order
-            if (_CONSTRUCT_LC) throw std::runtime_error("psacx: left-branching characters need a single-rank communicator");
             if (!fast_resolval) throw std::runtime_error("psacx: fast_resolval = false needs a single-rank communicator");
-            rc = run_multi(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr);
+            rc = run_multi(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr,
+                           _CONSTRUCT_LC ? lc.data() : nullptr);
             if (rc != PSACX_OK) throw std::runtime_error(std::string("psacx: ") + (rc > -7 ? psacx_strerror(rc) : "RCCL failure") + " [" +
                                                          psacx_multi_last_error(multi_) + "]");
         } else {
@@ -316,17 +316,18 @@ private:
     psacx_ctx* ctx_;
     psacx_multi* multi_;
 
-    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
-        return psacx_multi_construct_u32(multi_, t, n, k, flags, sa, isa, lcp);
+    // (lc != nullptr: also the left-branching characters, psacx_multi_construct_lc_*)
+    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp, uint8_t* lc) {
+        return lc ? psacx_multi_construct_lc_u32(multi_, t, n, k, flags, sa, isa, lcp, lc) : psacx_multi_construct_u32(multi_, t, n, k, flags, sa, isa, lcp);
     }
-    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
-        return psacx_multi_construct_u64(multi_, t, n, k, flags, sa, isa, lcp);
+    int run_multi(const uint8_t* t, unsigned int k, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp, uint8_t* lc) {
+        return lc ? psacx_multi_construct_lc_u64(multi_, t, n, k, flags, sa, isa, lcp, lc) : psacx_multi_construct_u64(multi_, t, n, k, flags, sa, isa, lcp);
     }
     template <typename U>
     typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
-    run_multi(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp) {
+    run_multi(const uint8_t* t, unsigned int k, uint32_t flags, U* sa, U* isa, U* lcp, uint8_t* lc) {
         typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
-        return run_multi(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
+        return run_multi(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp), lc);
     }
 
     int run(const uint8_t* t, unsigned int k, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp, uint8_t* lc) {

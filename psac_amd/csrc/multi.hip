@@ -52,11 +52,23 @@ int ansv_dev(psacx_multi* g, const T* const* d_in, const uint64_t* m, int lt, in
     return run.ansv(b, mm, lt, rt, nonsv, ol, orr);
 }
 
+template <typename T>
+int left_chars_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, const T* const* sa, const T* const* lcp, uint8_t* const* lc) {
+    if (!g || !d_text || !m || !sa || !lcp || !lc) return PSACX_EINVAL;
+    g->err.clear();
+    MultiRun<T> run(g);
+    std::vector<const uint8_t*> t(g->nlocal); std::vector<uint64_t> mm(g->nlocal);
+    std::vector<T*> a(g->nlocal), c(g->nlocal); std::vector<uint8_t*> o(g->nlocal);
+    for (int i = 0; i < g->nlocal; ++i) { t[i] = d_text[i]; mm[i] = m[i]; a[i] = const_cast<T*>(sa[i]); c[i] = const_cast<T*>(lcp[i]); o[i] = lc[i]; }
+    return run.left_chars(t, mm, a, c, o);
+}
+
 // whole text on the host of a single process that owns every rank: blocks to the GPUs, results back in rank order
 template <typename T>
-int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp) {
+int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp, uint8_t* lc = nullptr) {
     if (!g || !text || !sa || !isa || n == 0) return PSACX_EINVAL;
     if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
+    if (lc && !(flags & PSACX_LCP)) return PSACX_EINVAL;        // (the reference fills Lc inside its LCP code)
     if (g->nlocal != g->nranks) { g->err = "the host-pointer form needs every rank in this process"; return PSACX_EINVAL; }
     if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
     const int P = g->nranks;
@@ -80,6 +92,19 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
     int rc = run_dev<T>(g, tp.data(), m.data(), k, flags, a.data(), b.data(), c.data());
     g->out_slack = user_slack;
     if (rc != PSACX_OK) return rc;
+    if (lc) {
+        std::vector<DBuf<uint8_t>> dlc(P);
+        std::vector<uint8_t*> o(P);
+        std::vector<const T*> ca(P), cc(P);
+        for (int r = 0; r < P; ++r) { psacx_ctx* cx = g->R[r].ctx; MG_OP(g, cx, dlc[r].alloc(cx, m[r])); o[r] = dlc[r].p; ca[r] = a[r]; cc[r] = c[r]; }
+        rc = left_chars_dev<T>(g, tp.data(), m.data(), ca.data(), cc.data(), o.data());
+        if (rc != PSACX_OK) return rc;
+        for (int r = 0; r < P; ++r) {
+            psacx_ctx* cx = g->R[r].ctx;
+            MG_HIP(g, hipSetDevice(cx->device));
+            if (m[r]) MG_OP(g, cx, staged_d2h(cx, lc + off[r], dlc[r].p, m[r]));
+        }
+    }
     for (int r = 0; r < P; ++r) {
         psacx_ctx* cx = g->R[r].ctx;
         MG_HIP(g, hipSetDevice(cx->device));
@@ -230,6 +255,15 @@ int psacx_multi_check_dev_u32(psacx_multi* g, const uint8_t* const* t, const uin
                               const uint32_t* const* lcp, uint64_t errors[4]) { return check_dev<uint32_t>(g, t, m, sa, isa, lcp, errors); }
 int psacx_multi_check_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* isa,
                               const uint64_t* const* lcp, uint64_t errors[4]) { return check_dev<uint64_t>(g, t, m, sa, isa, lcp, errors); }
+
+int psacx_multi_construct_lc_u32(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint32_t* SA, uint32_t* ISA,
+                                 uint32_t* LCP, uint8_t* Lc) { return Lc ? run_host<uint32_t>(g, text, n, k, flags, SA, ISA, LCP, Lc) : PSACX_EINVAL; }
+int psacx_multi_construct_lc_u64(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, uint64_t* SA, uint64_t* ISA,
+                                 uint64_t* LCP, uint8_t* Lc) { return Lc ? run_host<uint64_t>(g, text, n, k, flags, SA, ISA, LCP, Lc) : PSACX_EINVAL; }
+int psacx_multi_left_chars_dev_u32(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint32_t* const* sa, const uint32_t* const* lcp,
+                                   uint8_t* const* lc) { return left_chars_dev<uint32_t>(g, t, m, sa, lcp, lc); }
+int psacx_multi_left_chars_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* lcp,
+                                   uint8_t* const* lc) { return left_chars_dev<uint64_t>(g, t, m, sa, lcp, lc); }
 
 int psacx_multi_ansv_dev_u32(psacx_multi* g, const uint32_t* const* in, const uint64_t* m, int lt, int rt, uint64_t nonsv, uint64_t* const* l,
                              uint64_t* const* r) { return ansv_dev<uint32_t>(g, in, m, lt, rt, nonsv, l, r); }

@@ -210,6 +210,29 @@ template <typename T> __global__ void widen_text_kernel(const uint8_t* __restric
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)t[i];
 }
 
+// ---- kernels of the distributed left-branching characters (MultiRun::left_chars): the text position SA[i-1] + LCP[i] of
+//      every entry of a piece (prev_sa: SA of the entry before the piece; has_prev = 0 at global position 0 -> n = "none"),
+//      then the fetched characters narrowed to bytes ('\0' where the position is past the end, alphabet.hpp:168)
+template <typename T>
+__global__ void lc_queries_kernel(const T* __restrict__ SA, const T* __restrict__ LCP, uint64_t cnt, uint64_t n, int has_prev, T prev_sa,
+                                  T* __restrict__ q) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        uint64_t p = n;
+        if (i || has_prev) {
+            p = (uint64_t)(i ? SA[i - 1] : prev_sa) + (uint64_t)LCP[i];
+            if (p > n) p = n;
+        }
+        q[i] = (T)p;
+    }
+}
+template <typename T>
+__global__ void lc_narrow_kernel(const T* __restrict__ ch, const T* __restrict__ q, uint64_t cnt, uint64_t n, uint8_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
+        out[i] = (uint64_t)q[i] < n ? (uint8_t)ch[i] : (uint8_t)0;
+}
+
 // ---- kernels of the distributed ANSV (MultiRun::ansv).  Start positions travel as T with one added (0 = before
 //      position 0, n + 1 = past the end), "none" as all ones.
 template <typename T>
@@ -1697,6 +1720,96 @@ struct MultiRun {
             }));
         }
         for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipStreamSynchronize(ctx(i)->stream)); }
+        return PSACX_OK;
+    }
+
+    // Left-branching characters of a block-distributed SA / LCP (suffix_array.hpp:211-212; the reference fills local_Lc
+    // inside its LCP code, :1365-1383 and par_rmq.hpp:334-481; the result is by definition Lc[i] = S[SA[i-1] + LCP[i]],
+    // desa.hpp:262-264, '\0' past the end and at i = 0): the last SA entry of every block goes to its right neighbour, the
+    // text positions are fetched from their owners through the engine's bulk-RMA exchange (dist_take), piece by piece so
+    // that a block that is a large share of its device fits.
+    int left_chars(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
+                   const std::vector<T*>& d_lcp, const std::vector<uint8_t*>& d_lc) {
+        want_lcp = true;
+        S.resize(L);
+        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); pool_flush(ctx(i)); }
+        PSACX_TRY(par([&](int i) -> int {
+            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
+            S[i].SA = d_sa[i]; S[i].ISA = nullptr; S[i].LCP = d_lcp[i];
+            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+            return PSACX_OK;
+        }));
+        uint64_t chunks = 1;
+        {
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
+            const char* env = getenv("PSACX_MULTI_CHECK_CHUNKS");
+            for (int i = 0; i < L; ++i) {
+                int same = 0;
+                for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
+                size_t fr = 0, tot = 0;
+                MG_HIP(g, hipSetDevice(ctx(i)->device));
+                MG_HIP(g, hipMemGetInfo(&fr, &tot));
+                // the widened text (1 word per character) stays; a piece wants about 12 words per entry
+                const double avail = 0.8 * (double)fr / same - (double)m_local[i] * sizeof(T), need = 12.0 * (double)m_local[i] * sizeof(T);
+                mine[i][0] = m_local[i];
+                mine[i][1] = env ? strtoull(env, nullptr, 10) : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
+            }
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather(2, mine, all));
+            sizes.assign(P, 0);
+            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 2]; chunks = std::max(chunks, all[(size_t)r * 2 + 1]); }
+            chunks = std::min<uint64_t>(chunks, 4096);
+            offs = prefix_of(sizes); n = offs[P];
+            for (int r = 0; r < P; ++r)
+                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
+            for (int i = 0; i < L; ++i) { S[i].off = offs[rank(i)]; ctx(i)->pool_cache_limit = 0; }
+            if (n == 0) return PSACX_EINVAL;
+        }
+        std::vector<DBuf<T>> wide(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, wide[i].alloc(c, S[i].m));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
+            return PSACX_OK;
+        }));
+        // SA of the entry before every block
+        std::vector<psacx_boundary> edge;
+        {
+            std::vector<uint64_t> one(L);
+            std::vector<const T*> a1(L), a2(L), a3(L);
+            for (int i = 0; i < L; ++i) { one[i] = S[i].m ? 1 : 0; a1[i] = S[i].SA + (S[i].m ? S[i].m - 1 : 0); a2[i] = a1[i]; a3[i] = a1[i]; }
+            PSACX_TRY(neighbours(a1, a2, a3, one, 1, edge));
+        }
+        std::vector<uint64_t> carry(L, 0);                       // SA of the last entry of the previous piece
+        for (uint64_t q = 0; q < chunks; ++q) {
+            std::vector<uint64_t> from(L), cnt(L);
+            for (int i = 0; i < L; ++i) {
+                from[i] = (uint64_t)(((unsigned __int128)S[i].m * q) / chunks);
+                cnt[i] = (uint64_t)(((unsigned __int128)S[i].m * (q + 1)) / chunks) - from[i];
+            }
+            std::vector<DBuf<T>> qs(L), ch;
+            std::vector<const T*> blk(L), gi(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, qs[i].alloc(c, cnt[i]));
+                const int has_prev = from[i] ? 1 : edge[i].has_prev;
+                const uint64_t prev = from[i] ? carry[i] : edge[i].prev[0];
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (lc_queries_kernel<T>), cnt[i], S[i].SA + from[i], S[i].LCP + from[i], cnt[i], n, has_prev, (T)prev, qs[i].p);
+                if (cnt[i]) { std::vector<uint64_t> o; PSACX_TRY(fetch(i, S[i].SA + from[i], {cnt[i] - 1}, o)); carry[i] = o[0]; }
+                blk[i] = wide[i].p; gi[i] = qs[i].p;
+                return PSACX_OK;
+            }));
+            PSACX_TRY(dist_take(blk, gi, cnt, ch));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (lc_narrow_kernel<T>), cnt[i], (const T*)ch[i].p, (const T*)qs[i].p, cnt[i], n, d_lc[i] + from[i]);
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                return PSACX_OK;
+            }));
+        }
         return PSACX_OK;
     }
 

@@ -120,6 +120,15 @@ class MultiContext(object):
         self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_isa), vp(*d_lcp) if d_lcp is not None else None, err))
         return list(err)
 
+    def left_chars_device(self, d_text, m, d_sa, d_lcp, d_lc, index_bits):
+        """Left-branching characters Lc[i] = S[SA[i-1] + LCP[i]] of block-distributed results resident in HBM
+        (suffix_array.hpp:211-212); d_lc[i] receives m[i] bytes."""
+        L = self.nlocal
+        vp = C.c_void_p * L
+        mm = (C.c_uint64 * L)(*[int(x) for x in m])
+        fn = getattr(self._lib, "psacx_multi_left_chars_dev_u%d" % index_bits)
+        self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_lcp), vp(*d_lc)))
+
     def ansv_device(self, d_in, m, d_left, d_right, index_bits, left_type=0, right_type=0, nonsv=0):
         """ansv<T, left_type, right_type, global_indexing> over a block-distributed array resident in HBM (lists of raw
         device addresses, one per local rank; results are uint64 global indices)."""

@@ -241,6 +241,18 @@ int main() {
     many.construct(s.begin(), s.begin() + 50000);          // repeated calls on one object (test/test_psac.cpp:148-170)
     one.construct(s.begin(), s.begin() + 50000);
     if (one.local_SA != many.local_SA || one.local_LCP != many.local_LCP) return 4;
+    // left-branching characters on four ranks (suffix_array<char, index_t, true, true>, suffix_array.hpp:211-212)
+    suffix_array<char, uint32_t, true, true> lc1((psacx::comm(0)));
+    lc1.verbose = false;
+    lc1.construct(s.begin(), s.end());
+    suffix_array<char, uint32_t, true, true> lc4((psacx::comm(std::vector<int>(4, 0))));
+    lc4.verbose = false;
+    lc4.construct(s.begin(), s.end());
+    if (lc1.local_Lc.size() != s.size() || lc1.local_Lc != lc4.local_Lc || lc1.local_SA != lc4.local_SA) return 5;
+    for (size_t i = 1; i < s.size(); ++i) {
+        const size_t p = (size_t)lc4.local_SA[i - 1] + (size_t)lc4.local_LCP[i];
+        if (lc4.local_Lc[i] != (p < s.size() ? s[p] : '\0')) return 6;
+    }
     std::puts("ok");
     return 0;
 }
@@ -273,6 +285,59 @@ def test_bench_and_cli_process_per_gpu_path(tmp_path):
                         "--master-port", "29578", "-m", "psac_amd", "-r", "300000", "-s", "2", "-l", "-c"], capture_output=True, text=True, env=env,
                        cwd=root, timeout=600)
     assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_left_branching_chars(P):
+    # psacx_multi_left_chars_dev_*: local_Lc of suffix_array<char, index_t, true, true> on p ranks (suffix_array.hpp:211-212,
+    # :1365-1383, par_rmq.hpp:334-481) -- against the oracle, which carries Lc through the leftmost range minima as the
+    # reference does, and against the definition Lc[i] = S[SA[i-1] + LCP[i]] (desa.hpp:262-264)
+    import ctypes as C
+    mg = multi(P)
+    lib = mg._lib
+    cases = [(O.as_text("mississippi"), 64), (O.rand_dna(130370, 7), 32), (inputs.tandem(100000, 1024, inputs.dna(1024, 5)), 64),
+             (inputs.ascii128(60000, 9), 32), (O.as_text("aaaaaaaaaaaaaaaa"), 32), (inputs.cyclic(39999, "abc"), 64)]
+    try:
+        for text, bits in cases:
+            n = text.size
+            if P > 1 and n < 4096:       # (blocks shorter than 2k characters are refused with more than one rank)
+                continue
+            w = bits // 8
+            udt = np.uint32 if bits == 32 else np.uint64
+            sizes = [n // P + (1 if r < n % P else 0) for r in range(P)]
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            held = []
+
+            def alloc(ctx, nbytes):
+                p = C.c_void_p()
+                assert lib.psacx_dev_alloc(ctx, C.byref(p), max(nbytes, 1)) == 0
+                held.append((ctx, p))
+                return p.value
+            d_t, d_sa, d_isa, d_lcp, d_lc = [], [], [], [], []
+            for r in range(P):
+                ctx = mg.rank_ctx(r)
+                d_t.append(alloc(ctx, sizes[r])); d_lc.append(alloc(ctx, sizes[r]))
+                for lst in (d_sa, d_isa, d_lcp):
+                    lst.append(alloc(ctx, sizes[r] * w))
+                blk = np.ascontiguousarray(text[offs[r]:offs[r + 1]])
+                assert lib.psacx_copy_h2d(ctx, C.c_void_p(d_t[r]), blk.ctypes.data_as(C.c_void_p), sizes[r]) == 0
+            mg.construct_device(d_t, sizes, d_sa, d_isa, d_lcp, bits)
+            mg.left_chars_device(d_t, sizes, d_sa, d_lcp, d_lc, bits)
+            SA = np.empty(n, udt); LCP = np.empty(n, udt); Lc = np.empty(n, np.uint8)
+            for r in range(P):
+                ctx = mg.rank_ctx(r)
+                for dst, src, ww in ((SA, d_sa, w), (LCP, d_lcp, w), (Lc, d_lc, 1)):
+                    part = np.empty(sizes[r], dst.dtype)
+                    assert lib.psacx_copy_d2h(ctx, part.ctypes.data_as(C.c_void_p), C.c_void_p(src[r]), sizes[r] * ww) == 0
+                    dst[offs[r]:offs[r + 1]] = part
+            ref = O.construct_lc(text, bits=bits)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(LCP, ref["LCP"])
+            assert np.array_equal(Lc, ref["Lc"])
+            assert np.array_equal(Lc, O.left_chars_by_definition(text, SA, LCP))
+            for ctx, p in held:
+                lib.psacx_dev_free(ctx, p)
+    finally:
+        mg.close()
 
 
 def test_multi_distributed_ansv():
