@@ -47,7 +47,7 @@ template <typename T> struct Work {
 // output buffers themselves (ISA, LCP, SA are dead until the sort is over), and the refinement
 // rounds get `cap` records of room instead of n (4 n w + 5 cap w bytes).
 template <typename T>
-size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool diet, uint64_t cap, T* d_sa, T* d_isa) {
+size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool diet, uint64_t cap, T* d_sa, T* d_isa, const Knobs& kn) {
     w.diet = diet;
     w.cap_active = diet ? cap : n;
     w.bsa = a.take<T>(n);
@@ -90,7 +90,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.sc.d_err = a.take<unsigned>(64);
     w.sc.d_summary = a.take<unsigned long long>(8);
     w.sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
-    w.sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
+    w.sc.d_dbg = kn.sort_debug ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     return a.off;
 }
 
@@ -180,8 +180,8 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 
 // whether the inversion of n records of T runs its partition levels as radix passes (see invert_permutation)
 template <typename T>
-inline bool isa_radix_levels(uint64_t n) {
-    return sizeof(T) == 4 && n >= (1ull << 22) && n <= (1ull << 30) && !getenv("PSACX_ISA_PARTITION");
+inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
+    return sizeof(T) == 4 && n >= (1ull << 22) && n <= (1ull << 30) && !kn.isa_partition;
 }
 
 // ISA[SA[i]] = val[i] - 1 for a full permutation SA (bulk_permute.hpp:14-73).  Large inputs go
@@ -198,8 +198,8 @@ inline bool isa_radix_levels(uint64_t n) {
 // levels down to windows of 2^14 positions.  Returns the number of levels (0: the form does not apply).
 constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;
 template <typename T>
-inline int isa_narrow_levels(uint64_t n) {
-    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || getenv("PSACX_ISA_WIDE") || getenv("PSACX_ISA_CB8")) return 0;
+inline int isa_narrow_levels(uint64_t n, const Knobs& kn) {
+    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || kn.isa_wide || kn.isa_cb8) return 0;
     const unsigned idx_bits = bits_for(n - 1);
     return (int)((idx_bits - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
 }
@@ -235,8 +235,8 @@ int finish_inversion32(psacx_ctx* c, unsigned* d_cursors, uint32_t* k32, uint32_
 // fused_l1: the first narrow level has been run by rebucket_first_kernel (pairs in the two halves of t1.k1)
 template <typename T>
 int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T* val, uint64_t n, T* d_isa,
-                       SortBufs<T> t1, SortBufs<T> t2, uint64_t koff = 0, SortScratch* sc = nullptr, bool have_hist0 = false,
-                       bool fused_l1 = false) {
+                       SortBufs<T> t1, SortBufs<T> t2, const Knobs& kn, uint64_t koff = 0, SortScratch* sc = nullptr,
+                       bool have_hist0 = false, bool fused_l1 = false) {
     // have_hist0: the tile histograms of the first radix level are already in sc->d_desc (rebucket_first_kernel)
     constexpr int PB = 512, PI = 16;                      // 8192-record tiles: 32-record runs on average (1024 x 16, 32-bit destinations with staged class bytes, and cursors padded to their own cache lines all measured the same or worse)
     const unsigned idx_bits = bits_for(n - 1);
@@ -249,7 +249,7 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     const T* kin = d_sa; const T* vin = val;
     SortBufs<T> bufs[2] = {t1, t2};
     // (measured: 3.07 against 3.46 ms at 2^28, 18.7 against 19.4 ms at 2^30, 75.5 against 68.4 ms at 2^32 - 2)
-    const bool radix_levels = sc && koff == 0 && isa_radix_levels<T>(n);
+    const bool radix_levels = sc && koff == 0 && isa_radix_levels<T>(n, kn);
     for (int lv = 0; radix_levels && lv < levels; ++lv) {
         SortBufs<T> o = bufs[lv & 1];
         PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
@@ -261,16 +261,16 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
         kin = o.k1; vin = o.k2;
     }
     // 64-bit words, at most 2^32 positions: the pairs are narrowed to 32 bits by the first partition level (sa_kernels.hpp)
-    const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !getenv("PSACX_ISA_WIDE");
-    if (fused_l1 && !(narrow && isa_narrow_levels<T>(n) > 0)) { c->hip_err = "inversion: fused first level without the narrow form"; return PSACX_EINVAL; }
-    if (narrow && isa_narrow_levels<T>(n) > 0) {
+    const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !kn.isa_wide;
+    if (fused_l1 && !(narrow && isa_narrow_levels<T>(n, kn) > 0)) { c->hip_err = "inversion: fused first level without the narrow form"; return PSACX_EINVAL; }
+    if (narrow && isa_narrow_levels<T>(n, kn) > 0) {
         // 2^14-entry windows (64 KiB of 32-bit values in LDS) and 512-way levels: 2^32 positions need two partition
         // levels instead of three (24 + 16 + 16 = 56 instead of 72 bytes per record)
         constexpr int WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
         uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
                               {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
-        const int lv9 = isa_narrow_levels<T>(n);
+        const int lv9 = isa_narrow_levels<T>(n, kn);
         const uint32_t* k32 = fused_l1 ? nb[0][0] : nullptr; const uint32_t* v32 = fused_l1 ? nb[0][1] : nullptr;
         for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
             const unsigned shift = isa_narrow_shift(lv9, lv);
@@ -343,9 +343,9 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
 // tabulated when the round has enough queries to matter; level 0 (two arrays of n entries in a lazily
 // allocated second workspace) only when a large part of the suffixes is still active.
 template <typename T>
-int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n) {
+int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n, const Knobs& kn) {
     for (int L = 0; L < PYR_MAX; ++L) { w.pyr.pre[L] = nullptr; w.pyr.suf[L] = nullptr; }
-    if (queries < (1u << 16) || getenv("PSACX_NO_RMQ_AUX")) return PSACX_OK;
+    if (queries < (1u << 16) || kn.no_rmq_aux) return PSACX_OK;
     ProfScope ps(c, TC_RMQ_BUILD);
     for (int L = 1; L + 1 < w.pyr.nlev; ++L) {
         hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, w.pyr.len[L], 256, 8)), dim3(256), 0, c->stream,
@@ -389,6 +389,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                   T* d_sa, T* d_isa, T* d_lcp, const T* d_slen = nullptr) {
     const bool gsa = d_slen != nullptr;
     const bool no_fast = (flags & PSACX_NO_FAST) != 0;
+    const Knobs kn = read_knobs();
     psacx_stats& st = c->stats;
     PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
 
@@ -407,32 +408,32 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     uint64_t cap = n;
     {
         Arena dry(nullptr);
-        carve<T>(dry, w, n, WITH_LCP, d_lcp, false, n, d_sa, d_isa);
+        carve<T>(dry, w, n, WITH_LCP, d_lcp, false, n, d_sa, d_isa, kn);
         size_t need = dry.off + 4096;
         size_t free_b = 0, total_b = 0;
         PSACX_HIP(c, hipMemGetInfo(&free_b, &total_b));
         const size_t margin = (size_t)512 << 20;
         const size_t avail = free_b + c->slab_bytes > margin ? free_b + c->slab_bytes - margin : 0;
-        if ((getenv("PSACX_FORCE_DIET") && !no_fast) || (need > c->slab_bytes && need > avail)) {
+        if ((kn.force_diet && !no_fast) || (need > c->slab_bytes && need > avail)) {
             Arena d0(nullptr);
-            carve<T>(d0, w, n, WITH_LCP, d_lcp, true, 0, d_sa, d_isa);
+            carve<T>(d0, w, n, WITH_LCP, d_lcp, true, 0, d_sa, d_isa, kn);
             const size_t base = d0.off + 8192;
             if (no_fast || base >= avail) {
                 c->hip_err = "workspace does not fit in HBM";
                 return PSACX_ENOMEM;
             }
             cap = std::min<uint64_t>(n, (avail - base) / (5 * sizeof(T)) > 4096 ? (avail - base) / (5 * sizeof(T)) - 4096 : 0);
-            if (const char* e = getenv("PSACX_DIET_CAP")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 10));
+            if (kn.diet_cap) cap = std::min<uint64_t>(cap, kn.diet_cap);
             if (cap < std::min<uint64_t>(n, 1024)) { c->hip_err = "workspace does not fit in HBM"; return PSACX_ENOMEM; }
             diet = true;
             Arena d1(nullptr);
-            carve<T>(d1, w, n, WITH_LCP, d_lcp, true, cap, d_sa, d_isa);
+            carve<T>(d1, w, n, WITH_LCP, d_lcp, true, cap, d_sa, d_isa, kn);
             need = d1.off + 4096;
         }
         PSACX_TRY(ensure_slab(c, need));
     }
     Arena ar(c->slab);
-    carve<T>(ar, w, n, WITH_LCP, d_lcp, diet, cap, d_sa, d_isa);
+    carve<T>(ar, w, n, WITH_LCP, d_lcp, diet, cap, d_sa, d_isa, kn);
     st.workspace_bytes = c->slab_bytes;
     w.sc.h_hist = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
     w.sc.h_base = w.sc.h_hist + (size_t)MAX_PASSES * RADIX;
@@ -481,9 +482,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     lead = (lead + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
     // word 1 slightly too short for that (DNA, 32-bit words, 2^29 < n <= 2^30): all of word 1 still leaves
     // fewer than a quarter of the suffixes tied, which is cheaper than carrying word 2 through five passes
-    const unsigned slack = getenv("PSACX_LEAD_SLACK") ? (unsigned)atoi(getenv("PSACX_LEAD_SLACK")) : 2u;
+    const unsigned slack = kn.lead_slack;
     if (lead > bits_w1 && bits_for(n - 1) + slack <= bits_w1 && bits_w1 % RADIX_BITS == 0) lead = bits_w1;
-    bool two_stage = !gsa && n >= (1ull << 21) && !getenv("PSACX_ONE_STAGE") && lead <= bits_w1 &&
+    bool two_stage = !gsa && n >= (1ull << 21) && !kn.one_stage && lead <= bits_w1 &&
                      lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
     psacx_round* r0 = &st.rounds[0];
     SortBufs<T> sorted;
@@ -491,7 +492,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     for (int attempt = 0; attempt < 2; ++attempt) {
     bool retry_one_stage = false;
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
-    const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !getenv("PSACX_NO_KEY_HIST");
+    const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.no_key_hist;
 
     // In the diet layout the second record set is the output buffers (y = ISA, LCP, SA).  One stage: both sorted key
     // words must end up in the workspace set x (word 2 in the LCP buffer would be overwritten while its neighbours are
@@ -551,14 +552,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_GATHER);
             PSACX_HIP(c, hipMemsetAsync(d_big, 0, sizeof(unsigned long long), c->stream));
             const uint64_t nb = (n + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
-            if (!getenv("PSACX_TIES_RADIX"))
+            if (!kn.ties_radix)
                 hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, S1, d_sa, S2, n, lo1,
                                    d_text, n, tab, ks, d_big);
             PSACX_HIP(c, hipGetLastError());
         }
         PSACX_HIP(c, hipMemcpyAsync(h_big, d_big, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         PSACX_HIP(c, hipStreamSynchronize(c->stream));
-        if (*h_big || getenv("PSACX_TIES_RADIX")) {
+        if (*h_big || kn.ties_radix) {
             // some group is long (repetitive text): compact all ties and radix-sort them by the full window
             const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
             {
@@ -622,18 +623,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     bool isa_hist_ready = false;
-    const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n) > 0 && !getenv("PSACX_NO_FUSED_L1");
+    const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n, kn) > 0 && !kn.no_fused_l1;
     // 32-bit words, normal layout: the same fusion; the pairs use two payload scratch arrays of the sort, the second level
     // the two position lists (all idle between the sort and the first compaction)
-    const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0 && !getenv("PSACX_NO_FUSED_L1") &&
-                        !getenv("PSACX_ISA_PARTITION");
+    const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0 && !kn.no_fused_l1 && !kn.isa_partition;
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
         T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
         // ... and so do the tile histograms of the inversion's first radix level when the tiles agree
-        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n) && (uint64_t)ScanCfg<T>::TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
-                         !getenv("PSACX_NO_KEY_HIST");
+        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n, kn) && (uint64_t)ScanCfg<T>::TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
+                         !kn.no_key_hist;
         unsigned* const sa_hist = isa_hist_ready ? reinterpret_cast<unsigned*>(w.sc.d_desc + 256) : (unsigned*)nullptr;
         if (gsa) {
             PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
@@ -653,7 +653,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
             uint32_t* const pk = reinterpret_cast<uint32_t*>(w.x.v);
             launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
-                                                     w.d_nunf, pyr1, pk, pk + n, isa_narrow_shift(isa_narrow_levels<T>(n), 0), w.d_cursors);
+                                                     w.d_nunf, pyr1, pk, pk + n, isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
@@ -672,7 +672,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_TRY(finish_inversion32<T>(c, w.d_cursors, reinterpret_cast<uint32_t*>(w.x.v), reinterpret_cast<uint32_t*>(w.y.v),
                                             reinterpret_cast<uint32_t*>(w.pos_a), reinterpret_cast<uint32_t*>(w.pos_b), n, isa_levels32(n), d_isa));
         else
-            PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, t1, t2, 0, &w.sc, isa_hist_ready, fuse_l1));
+            PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, t1, t2, kn, 0, &w.sc, isa_hist_ready, fuse_l1));
     }
     if (WITH_LCP) {
         ProfScope ps(c, TC_RMQ_BUILD);
@@ -712,7 +712,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                /*summary_ready=*/true));
         if (rr) { rr->sort_passes += rs.sort_passes; rr->sort_passes_skipped += rs.sort_passes_skipped; }
         T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
-        if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n));
+        if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n, kn));
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -960,7 +960,7 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
         sc.d_err = a.take<unsigned>(64);
         sc.d_summary = a.take<unsigned long long>(8);
         sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
-        sc.d_dbg = getenv("PSACX_SORT_DEBUG") ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
+        sc.d_dbg = read_knobs().sort_debug ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     };
     SortBufs<T> alt; SortScratch sc; T* vtmp;
     layout(dry, alt, sc, vtmp);

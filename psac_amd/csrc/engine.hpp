@@ -123,6 +123,42 @@ inline void prof_collect(psacx_ctx* c) {
     s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
 }
 
+// Tuning and test switches of a construction, read from the environment in ONE place at the start of every call (the
+// tests flip them between calls of one process, so they are not cached).  Each selects an earlier or fallback form of a
+// step that the parity suite keeps covered; none changes the result.
+struct Knobs {
+    bool force_diet;        // PSACX_FORCE_DIET: reduced-memory layout although the normal one fits
+    uint64_t diet_cap;      // PSACX_DIET_CAP: at most this many records of room for the refinement rounds (0 = no limit)
+    bool one_stage;         // PSACX_ONE_STAGE: first round as one sort over both key words
+    bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
+    bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
+    unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
+    bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
+    bool isa_wide;          // PSACX_ISA_WIDE: 64-bit words: pairs stay 64-bit
+    bool isa_cb8;           // PSACX_ISA_CB8: 256-way levels and 2^12-entry windows
+    bool no_fused_l1;       // PSACX_NO_FUSED_L1: first inversion level as its own kernel
+    bool no_rmq_aux;        // PSACX_NO_RMQ_AUX: range minima without the running-minimum tables
+    bool sort_debug;        // PSACX_SORT_DEBUG: phase stamps of sampled scatter tiles
+};
+inline Knobs read_knobs() {
+    Knobs k;
+    k.force_diet = getenv("PSACX_FORCE_DIET") != nullptr;
+    const char* e = getenv("PSACX_DIET_CAP");
+    k.diet_cap = e ? strtoull(e, nullptr, 10) : 0;
+    k.one_stage = getenv("PSACX_ONE_STAGE") != nullptr;
+    k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
+    k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
+    e = getenv("PSACX_LEAD_SLACK");
+    k.lead_slack = e ? (unsigned)atoi(e) : 2u;
+    k.isa_partition = getenv("PSACX_ISA_PARTITION") != nullptr;
+    k.isa_wide = getenv("PSACX_ISA_WIDE") != nullptr;
+    k.isa_cb8 = getenv("PSACX_ISA_CB8") != nullptr;
+    k.no_fused_l1 = getenv("PSACX_NO_FUSED_L1") != nullptr;
+    k.no_rmq_aux = getenv("PSACX_NO_RMQ_AUX") != nullptr;
+    k.sort_debug = getenv("PSACX_SORT_DEBUG") != nullptr;
+    return k;
+}
+
 // bump allocator over the ctx slab; a first pass with base == nullptr sizes it
 struct Arena {
     char* base; size_t off;
