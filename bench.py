@@ -167,7 +167,10 @@ def main_distributed(a, rank, world, local_rank):
     w = bits // 8
     box = [psac_amd.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    mg = psac_amd.MultiContext.for_rank(rank, world, local_rank, box[0])
+    mg = psac_amd.MultiContext.for_rank(rank, world, local_rank, box[0])      # raises if the communicator cannot be built
+    if mg.transport != "rccl" or mg.nranks != world:
+        raise RuntimeError("bench.py --gpus %d needs the RCCL communicator over %d ranks, got transport %s over %d"
+                           % (world, world, mg.transport, mg.nranks))
     lib = mg._lib
     ctx = mg.rank_ctx(0)
 
@@ -207,13 +210,22 @@ def main_distributed(a, rank, world, local_rank):
     dt = float(t.item())
     s = psac_amd._lib.Stats()
     lib.psacx_get_stats(ctx, C.byref(s))
+    # what every rank saw in its last step: the wire calls it issued, the time its exchanges held its second stream and the
+    # host wall time of its phases
+    mine = {"rank": rank, "wire": mg.wire(), "phases_ms": dict((k, round(v, 3)) for k, v in mg.phases()), "payload_bytes_sent": sent}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
     if rank == 0:
         out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3, s.ms_sort_scatter2], list(s.scatter_bytes),
                      list(s.scatter_launches), None, int(st.k), int(st.bits_per_char), int(st.n_rounds),
                      "block-partitioned text, 1 rank per GPU, C++ host over RCCL (grouped ncclSend/ncclRecv: sort shuffle, "
                      "ISA scatter, B2 fetch, range minima) on a second stream per GPU")
         out["exchange"] = {"payload_bytes_sent_by_rank0_per_step": sent, "all_to_all_exchanges_per_step": nex,
-                           "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl}
+                           "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl, "transport": mg.transport,
+                           "ranks_seen_by_rccl": mg.nranks,
+                           "exchange_ms_on_second_stream_per_rank": [p["wire"]["exchange_ms"][0] for p in per_rank],
+                           "nccl_calls_last_step_rank0": {k: mine["wire"][k] for k in ("sends", "recvs", "allgathers")}}
+        out["phase_ms_last_step_per_rank"] = [p["phases_ms"] for p in per_rank]
         peak, reduced, slab_rounds = mg.memory()
         out["config"]["layout"] = {"reduced_memory": reduced, "refinement_rounds_in_slabs": slab_rounds,
                                    "engine_words_per_char_at_peak": round(peak[0] / float(n * w), 2),

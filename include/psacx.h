@@ -239,6 +239,21 @@ void psacx_multi_destroy(psacx_multi* mg);
 int psacx_multi_nranks(const psacx_multi* mg);
 int psacx_multi_nlocal(const psacx_multi* mg);
 int psacx_multi_uses_rccl(const psacx_multi* mg);
+/* How the ranks reach each other: 0 = device-to-device copies inside one process (ranks may share a device), 1 = RCCL
+ * (grouped ncclSend / ncclRecv + ncclAllGather, the replacement of mxx's MPI_Alltoallv / MPI_Allgather, idxsort.hpp:60-62,
+ * bucketing.hpp:39), 2 = one process per rank on one host staged through POSIX shared memory: psacx_multi_create_rank
+ * with PSACX_MULTI_TRANSPORT=shm in the environment -- psac's own deployment without a GPU-aware MPI (src/psac.cpp:85-93),
+ * and the way two processes can share one GPU, which RCCL refuses.  id128 is then any 128 bytes all ranks agree on.
+ * A communicator that cannot be built makes psacx_multi_create / _create_rank fail with -7; nothing falls back silently.
+ * PSACX_MULTI_FORCE_WIRE=1 (test switch): data a rank addresses to itself and scalars that are already on this host still
+ * travel through ncclSend / ncclRecv / ncclAllGather. */
+int psacx_multi_transport(const psacx_multi* mg);
+/* after a call: ncclSend / ncclRecv / ncclAllGather calls this process really issued, and exchange_ms[i] = time the
+ * exchanges occupied local rank i's second stream (HIP events).  Any pointer may be null. */
+int psacx_multi_get_wire(const psacx_multi* mg, uint64_t* sends, uint64_t* recvs, uint64_t* allgathers, double* exchange_ms);
+/* host wall time of the phases of the last construction as "name=ms;name=ms;..." (the section timers of
+ * suffix_array.hpp:52-63 for this engine); PSACX_ERANGE if buf is too small */
+int psacx_multi_get_phases(const psacx_multi* mg, char* buf, uint64_t cap);
 const char* psacx_multi_last_error(const psacx_multi* mg);
 psacx_ctx* psacx_multi_ctx(psacx_multi* mg, int local_rank);
 int psacx_multi_construct_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags,

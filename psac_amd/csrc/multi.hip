@@ -138,17 +138,22 @@ int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) {
         const int rc = make_rank(g, i, i, devs[i]);
         if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
     }
-    // one RCCL communicator over the devices; ranks that share a device (and a single rank) exchange by copies
-    g->use_rccl = distinct && ndev > 1 && !getenv("PSACX_MULTI_NO_RCCL");
+    // one RCCL communicator over the devices; ranks that share a device (and a single rank) exchange by copies.
+    // A communicator that cannot be built is an error, not a silent change of transport (PSACX_MULTI_NO_RCCL=1 asks
+    // for peer copies between distinct devices explicitly).
+    g->force_wire = getenv("PSACX_MULTI_FORCE_WIRE") != nullptr;
+    g->use_rccl = distinct && (ndev > 1 || g->force_wire) && !getenv("PSACX_MULTI_NO_RCCL");
     if (g->use_rccl) {
         std::string err;
         std::vector<ncclComm_t> comms(ndev);
-        if (!rccl().load(err) || rccl().CommInitAll(comms.data(), ndev, devs.data()) != ncclSuccess) {
+        if (!rccl().load(err)) { psacx_multi_destroy(g); return PSACX_MULTI_EPEER; }
+        if (rccl().CommInitAll(comms.data(), ndev, devs.data()) != ncclSuccess) {
             (void)hipGetLastError();
-            g->use_rccl = false;           // peer copies still work
-        } else {
-            for (int i = 0; i < ndev; ++i) g->R[i].comm = comms[i];
+            psacx_multi_destroy(g);
+            return PSACX_MULTI_EPEER;
         }
+        for (int i = 0; i < ndev; ++i) g->R[i].comm = comms[i];
+        g->transport = PSACX_TR_RCCL;
     }
     *out = g;
     return PSACX_OK;
@@ -176,7 +181,14 @@ int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device,
     g->R.resize(1);
     int rc = make_rank(g, 0, rank, device);
     if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
-    if (id128) {
+    g->force_wire = getenv("PSACX_MULTI_FORCE_WIRE") != nullptr;
+    const char* tr = getenv("PSACX_MULTI_TRANSPORT");
+    if (id128 && tr && std::string(tr) == "shm") {
+        // one process per rank on one host, exchanges staged through shared memory (shm_link.hpp): ranks may share a device
+        std::string err;
+        if (!g->shm.open(rank, nranks, id128, err)) { g->err = err; psacx_multi_destroy(g); return PSACX_MULTI_EPEER; }
+        g->transport = PSACX_TR_SHM;
+    } else if (id128) {
         std::string err;
         ncclUniqueId id;
         std::memcpy(&id, id128, 128);
@@ -186,6 +198,7 @@ int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device,
             return PSACX_MULTI_EPEER;
         }
         g->use_rccl = true;
+        g->transport = PSACX_TR_RCCL;
     }
     *out = g;
     return PSACX_OK;
@@ -202,9 +215,12 @@ void psacx_multi_destroy(psacx_multi* g) {
         if (R.d_scal) (void)hipFree(R.d_scal);
         if (R.ev_ready) (void)hipEventDestroy(R.ev_ready);
         if (R.ev_done) (void)hipEventDestroy(R.ev_done);
+        for (auto& e : R.ex_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (R.comm_stream) (void)hipStreamDestroy(R.comm_stream);
         psacx_destroy(R.ctx);
     }
+    g->shm.timeout_s = 10.0;
+    g->shm.close_link();
     delete g;
 }
 
@@ -219,6 +235,26 @@ int psacx_multi_get_stats(const psacx_multi* g, psacx_stats* out, uint64_t* byte
     if (bytes_sent) *bytes_sent = g->bytes_sent;
     if (exchanges) *exchanges = g->n_exchanges;
     if (gathers) *gathers = g->n_gathers;
+    return PSACX_OK;
+}
+
+int psacx_multi_transport(const psacx_multi* g) { return g ? g->transport : -1; }
+
+int psacx_multi_get_wire(const psacx_multi* g, uint64_t* sends, uint64_t* recvs, uint64_t* allgathers, double* exchange_ms) {
+    if (!g) return PSACX_EINVAL;
+    if (sends) *sends = g->wire_sends;
+    if (recvs) *recvs = g->wire_recvs;
+    if (allgathers) *allgathers = g->wire_gathers;
+    if (exchange_ms) for (int i = 0; i < g->nlocal; ++i) exchange_ms[i] = g->R[i].exchange_ms;
+    return PSACX_OK;
+}
+
+int psacx_multi_get_phases(const psacx_multi* g, char* buf, uint64_t cap) {
+    if (!g || !buf || cap == 0) return PSACX_EINVAL;
+    std::string s;
+    for (const auto& ph : g->phases) { char t[160]; snprintf(t, sizeof(t), "%s%s=%.3f", s.empty() ? "" : ";", ph.first.c_str(), ph.second); s += t; }
+    if (s.size() + 1 > cap) return PSACX_ERANGE;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
     return PSACX_OK;
 }
 

@@ -35,6 +35,7 @@
 
 #include "dist_ops.hpp"
 #include "ansv_tile.hpp"
+#include "shm_link.hpp"
 
 namespace psacx {
 
@@ -75,6 +76,10 @@ struct MRank {
     ncclComm_t comm = nullptr;
     uint64_t* d_scal = nullptr;      // device staging of the scalar all-gather (process-per-GPU mode)
     size_t scal_words = 0;
+    // event pairs bracketing every exchange on comm_stream; their elapsed times are summed at the end of a call
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ex_ev;
+    size_t ex_used = 0;
+    double exchange_ms = 0;          // time the last call's exchanges occupied comm_stream
 };
 
 } // namespace psacx
@@ -129,9 +134,19 @@ struct RankPool {
 };
 } // namespace psacx
 
+// how the ranks of a communicator reach each other
+enum { PSACX_TR_COPY = 0,      // every rank in this process: device-to-device copies (ranks may share a device)
+       PSACX_TR_RCCL = 1,      // grouped ncclSend / ncclRecv + ncclAllGather (over xGMI between the GPUs of a node)
+       PSACX_TR_SHM = 2 };     // one process per rank on one host, staged through POSIX shared memory (shm_link.hpp)
+
 struct psacx_multi {
     int nranks = 0, nlocal = 0, first = 0;
     bool use_rccl = false;
+    int transport = PSACX_TR_COPY;
+    bool force_wire = false;          // PSACX_MULTI_FORCE_WIRE: no shortcut for data a rank sends to itself or for scalars that
+                                      // are already on this host -- every ncclSend / ncclRecv / ncclAllGather is really issued
+    psacx::ShmLink shm;
+    std::vector<std::pair<std::string, double>> phases;     // wall time of the phases of the last construction (host clock)
     std::vector<psacx::MRank> R;
     std::string err;
     std::mutex err_mu;
@@ -139,6 +154,7 @@ struct psacx_multi {
     psacx_stats stats;
     uint64_t bytes_sent = 0;          // payload bytes this process sent to other ranks in the last call
     uint64_t n_exchanges = 0, n_gathers = 0;
+    uint64_t wire_sends = 0, wire_recvs = 0, wire_gathers = 0;   // ncclSend / ncclRecv / ncclAllGather calls really issued in the last call
     // psacx_multi_configure
     int opt_layout = 0;               // 0: choose by free device memory, 1: normal, 2: reduced-memory
     uint64_t opt_slab = 0;            // unresolved suffixes per refinement slab of the reduced-memory layout (0: block / 16)
@@ -408,6 +424,9 @@ struct MultiRun {
     // output arrays and ONE allocated set, SA -> ISA runs in chunks, and a refinement round with more unresolved
     // suffixes than `slab_cap` on some rank is worked off in slabs of whole buckets.
     bool diet = false, first_round_ = false;
+    // one rank and no request to exercise the wire anyway (PSACX_MULTI_FORCE_WIRE): the distributed primitives take their
+    // local shortcuts
+    bool solo_ = false;
     uint64_t sort_calls_ = 0;
     uint64_t slab_cap = 0;
 
@@ -450,14 +469,27 @@ struct MultiRun {
     }
 
     explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
-        t_last_ = std::chrono::steady_clock::now();
+        solo_ = P == 1 && !mg->force_wire;
+        t_last_ = t_phase_ = std::chrono::steady_clock::now();
     }
     // PSACX_MULTI_TRACE=1: wall time of every phase on stderr (all local streams drained at each mark)
     bool trace_;
-    std::chrono::steady_clock::time_point t_last_;
+    std::chrono::steady_clock::time_point t_last_, t_phase_;
+    // every phase leaves its host wall time in g->phases (accumulated by name: the refinement rounds repeat theirs)
     void mark(const char* what) {
+        if (trace_) for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); (void)hipStreamSynchronize(g->R[i].comm_stream); }
+        {
+            const auto now = std::chrono::steady_clock::now();
+            const double ms = std::chrono::duration<double, std::milli>(now - t_phase_).count();
+            std::string key(what);
+            const size_t a = key.find_first_not_of(' ');
+            key = a == std::string::npos ? key : key.substr(a);
+            bool found = false;
+            for (auto& ph : g->phases) if (ph.first == key) { ph.second += ms; found = true; break; }
+            if (!found) g->phases.emplace_back(key, ms);
+            t_phase_ = now;
+        }
         if (!trace_) return;
-        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); (void)hipStreamSynchronize(g->R[i].comm_stream); }
         const auto now = std::chrono::steady_clock::now();
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
@@ -466,7 +498,7 @@ struct MultiRun {
         if (g->first == 0) fprintf(stderr, "[psacx multi] %-28s %9.3f ms   (device memory in use %.1f GiB; rank %d's cache: %.1f MiB live, %.1f cached, peak %.1f)\n", what,
                                    std::chrono::duration<double, std::milli>(now - t_last_).count(), (double)(tot - fr) / (1 << 30), rank(w),
                                    ctx(w)->pool_live / 1048576.0, ctx(w)->pool_bytes / 1048576.0, ctx(w)->pool_peak / 1048576.0);
-        t_last_ = std::chrono::steady_clock::now();
+        t_last_ = t_phase_ = std::chrono::steady_clock::now();
     }
     psacx_ctx* ctx(int i) const { return g->R[i].ctx; }
     // body(i) for every local rank.  The step ops synchronise their stream with the host, so a single host thread would
@@ -483,10 +515,24 @@ struct MultiRun {
     int gather(int k, const std::vector<std::vector<uint64_t>>& mine, std::vector<uint64_t>& all) {
         all.assign((size_t)P * k, 0);
         g->n_gathers++;
-        if (L == P) {                                 // every rank lives in this process: nothing has to travel
+        if (L == P && !(g->force_wire && g->transport == PSACX_TR_RCCL)) {   // every rank lives in this process: nothing has to travel
             for (int i = 0; i < L; ++i) std::memcpy(&all[(size_t)rank(i) * k], mine[i].data(), (size_t)k * 8);
             return PSACX_OK;
         }
+        if (g->transport == PSACX_TR_SHM) {
+            ShmLink& sh = g->shm;
+            std::string e;
+            for (size_t at = 0; at < (size_t)k; ) {        // in pieces of one slot
+                const size_t part = std::min<size_t>((size_t)k - at, sh.slot_bytes / 8);
+                std::memcpy(sh.slot(rank(0)), mine[0].data() + at, part * 8);
+                if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                for (int r = 0; r < P; ++r) std::memcpy(&all[(size_t)r * k + at], sh.slot(r), part * 8);
+                if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                at += part;
+            }
+            return PSACX_OK;
+        }
+        if (g->transport != PSACX_TR_RCCL) { mg_set_err(g, "scalar all-gather without a transport between the processes"); return PSACX_EINVAL; }
         RcclApi& nc = rccl();
         for (int i = 0; i < L; ++i) {
             MRank& R = g->R[i];
@@ -501,12 +547,18 @@ struct MultiRun {
             std::memcpy(h, mine[i].data(), (size_t)k * 8);
             MG_HIP(g, hipMemcpyAsync(R.d_scal, h, (size_t)k * 8, hipMemcpyHostToDevice, R.ctx->stream));
         }
-        MG_NCCL(g, nc.GroupStart());
-        for (int i = 0; i < L; ++i) {
-            MRank& R = g->R[i];
-            MG_NCCL(g, nc.AllGather(R.d_scal, R.d_scal + k, (size_t)k, ncclUint64, R.comm, R.ctx->stream));
+        {
+            MG_NCCL(g, nc.GroupStart());
+            ncclResult_t bad = ncclSuccess;
+            for (int i = 0; i < L && bad == ncclSuccess; ++i) {
+                MRank& R = g->R[i];
+                bad = nc.AllGather(R.d_scal, R.d_scal + k, (size_t)k, ncclUint64, R.comm, R.ctx->stream);
+            }
+            const ncclResult_t end = nc.GroupEnd();           // the group is closed on every path
+            if (bad != ncclSuccess) { mg_set_err(g, std::string("ncclAllGather: ") + nc.GetErrorString(bad)); return PSACX_MULTI_EPEER; }
+            MG_NCCL(g, end);
         }
-        MG_NCCL(g, nc.GroupEnd());
+        g->wire_gathers++;
         for (int i = 0; i < L; ++i) {
             MRank& R = g->R[i];
             MG_HIP(g, hipSetDevice(R.ctx->device));
@@ -521,6 +573,41 @@ struct MultiRun {
         std::vector<std::vector<uint64_t>> mine(L);
         for (int i = 0; i < L; ++i) mine[i] = {one_per_local[i]};
         return gather(1, mine, all);
+    }
+    // The ranks of different processes agree on a status: a rank that failed locally (an allocation, a kernel launch)
+    // would otherwise leave the next collective while its peers block in it.  Returns the first non-zero code of any rank.
+    int agree(int rc_local) {
+        if (L == P) return rc_local;
+        std::vector<uint64_t> one(L, (uint64_t)(int64_t)rc_local), all;
+        const int rc = gather1(one, all);
+        if (rc != PSACX_OK) return rc;
+        for (int r = 0; r < P; ++r) if ((int64_t)all[r] != 0) {
+            if (rc_local == PSACX_OK) mg_set_err(g, "rank " + std::to_string(r) + " reported error " + std::to_string((long long)(int64_t)all[r]) + ": all ranks leave the step");
+            return (int)(int64_t)all[r];
+        }
+        return PSACX_OK;
+    }
+
+    // event pair around the work an exchange puts on a rank's second stream
+    int ex_begin(MRank& R) {
+        if (R.ex_used == R.ex_ev.size()) {
+            std::pair<hipEvent_t, hipEvent_t> e;
+            MG_HIP(g, hipEventCreate(&e.first)); MG_HIP(g, hipEventCreate(&e.second));
+            R.ex_ev.push_back(e);
+        }
+        MG_HIP(g, hipEventRecord(R.ex_ev[R.ex_used].first, R.comm_stream));
+        return PSACX_OK;
+    }
+    int ex_end(MRank& R) { MG_HIP(g, hipEventRecord(R.ex_ev[R.ex_used].second, R.comm_stream)); R.ex_used++; return PSACX_OK; }
+    void ex_collect() {
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            (void)hipSetDevice(R.ctx->device);
+            (void)hipStreamSynchronize(R.comm_stream);
+            double ms = 0;
+            for (size_t q = 0; q < R.ex_used; ++q) { float t = 0; if (hipEventElapsedTime(&t, R.ex_ev[q].first, R.ex_ev[q].second) == hipSuccess) ms += t; }
+            R.exchange_ms = ms; R.ex_used = 0;
+        }
     }
 
     // All-to-all of `na` arrays per rank that share one partition: elements bounds[i][d] .. bounds[i][d+1] of every
@@ -540,51 +627,106 @@ struct MultiRun {
         out.clear(); out.resize(L);
         rcnt.assign(L, std::vector<uint64_t>(P, 0));
         std::vector<std::vector<uint64_t>> roff(L);
-        for (int i = 0; i < L; ++i) {
+        int rc_alloc = PSACX_OK;
+        for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
             for (int s = 0; s < P; ++s) rcnt[i][s] = all[(size_t)s * P + rank(i)];
             roff[i] = prefix_of(rcnt[i]);
             out[i].resize(na);
-            if (recv) { PSACX_TRY(recv(i, roff[i][P], out[i])); if ((int)out[i].size() != na) return PSACX_EINVAL; }
-            else for (int a = 0; a < na; ++a) MG_OP(g, ctx(i), out[i][a].alloc(ctx(i), roff[i][P]));
+            if (recv) { rc_alloc = recv(i, roff[i][P], out[i]); if (rc_alloc == PSACX_OK && (int)out[i].size() != na) rc_alloc = PSACX_EINVAL; }
+            else for (int a = 0; a < na && rc_alloc == PSACX_OK; ++a) { rc_alloc = out[i][a].alloc(ctx(i), roff[i][P]); if (rc_alloc != PSACX_OK) mg_set_err(g, "receive array: " + ctx(i)->hip_err); }
         }
+        PSACX_TRY(agree(rc_alloc));       // (process-per-GPU: a rank without its receive arrays must not leave its peers in the group)
         // the sources are complete when the compute streams reach this point; the receive buffers exist by then too
         for (int i = 0; i < L; ++i) {
             MRank& R = g->R[i];
             MG_HIP(g, hipSetDevice(R.ctx->device));
             MG_HIP(g, hipEventRecord(R.ev_ready, R.ctx->stream));
         }
-        if (g->use_rccl) {
+        if (g->transport == PSACX_TR_RCCL) {
             RcclApi& nc = rccl();
-            for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(g->R[i].ctx->device)); MG_HIP(g, hipStreamWaitEvent(g->R[i].comm_stream, g->R[i].ev_ready, 0)); }
-            MG_NCCL(g, nc.GroupStart());
+            const bool self_wire = g->force_wire;
             for (int i = 0; i < L; ++i) {
+                MG_HIP(g, hipSetDevice(g->R[i].ctx->device)); MG_HIP(g, hipStreamWaitEvent(g->R[i].comm_stream, g->R[i].ev_ready, 0));
+                PSACX_TRY(ex_begin(g->R[i]));
+            }
+            MG_NCCL(g, nc.GroupStart());
+            ncclResult_t bad = ncclSuccess;
+            for (int i = 0; i < L && bad == ncclSuccess; ++i) {
                 MRank& R = g->R[i];
-                for (int a = 0; a < na; ++a) {
-                    for (int d = 0; d < P; ++d) {
+                for (int a = 0; a < na && bad == ncclSuccess; ++a) {
+                    for (int d = 0; d < P && bad == ncclSuccess; ++d) {
                         const uint64_t sc = mine[i][d], rc = rcnt[i][d];
-                        if (d == R.grank) continue;
-                        if (sc) { MG_NCCL(g, nc.Send(in[i][a] + bounds[i][d], (size_t)sc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream)); g->bytes_sent += sc * sizeof(E); }
-                        if (rc) MG_NCCL(g, nc.Recv(out[i][a].p + roff[i][d], (size_t)rc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream));
+                        if (d == R.grank && !self_wire) continue;
+                        if (sc) { bad = nc.Send(in[i][a] + bounds[i][d], (size_t)sc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream); if (d != R.grank) g->bytes_sent += sc * sizeof(E); g->wire_sends++; }
+                        if (rc && bad == ncclSuccess) { bad = nc.Recv(out[i][a].p + roff[i][d], (size_t)rc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream); g->wire_recvs++; }
                     }
                 }
             }
-            MG_NCCL(g, nc.GroupEnd());
+            const ncclResult_t end = nc.GroupEnd();           // closed on every path: an open group would swallow the next collective
+            if (bad != ncclSuccess) { mg_set_err(g, std::string("ncclSend / ncclRecv: ") + nc.GetErrorString(bad)); return PSACX_MULTI_EPEER; }
+            MG_NCCL(g, end);
             for (int i = 0; i < L; ++i) {
                 MRank& R = g->R[i];
                 MG_HIP(g, hipSetDevice(R.ctx->device));
                 const uint64_t sc = mine[i][R.grank];
-                for (int a = 0; a < na && sc; ++a)
+                for (int a = 0; a < na && sc && !self_wire; ++a)
                     MG_HIP(g, hipMemcpyAsync(out[i][a].p + roff[i][R.grank], in[i][a] + bounds[i][R.grank], (size_t)sc * sizeof(E), hipMemcpyDeviceToDevice, R.comm_stream));
+                PSACX_TRY(ex_end(R));
                 MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream));
                 MG_HIP(g, hipStreamWaitEvent(R.ctx->stream, R.ev_done, 0));
             }
+        } else if (g->transport == PSACX_TR_SHM) {
+            // one process per rank on one host: the sender's stream of every array (its segments for ranks 0 .. P-1 are
+            // contiguous) goes through its box of the shared segment in rounds of one box; after each round's barrier
+            // every receiver picks the part of each sender's window that is addressed to it
+            ShmLink& sh = g->shm;
+            MRank& R = g->R[0];
+            const int me = R.grank;
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            MG_HIP(g, hipStreamWaitEvent(R.comm_stream, R.ev_ready, 0));
+            PSACX_TRY(ex_begin(R));
+            std::vector<std::vector<uint64_t>> sb(P);           // sb[s][d]: start (elements) of s's segment for d inside s's stream
+            uint64_t longest = 0;
+            for (int s = 0; s < P; ++s) {
+                std::vector<uint64_t> row(P);
+                for (int d = 0; d < P; ++d) row[d] = all[(size_t)s * P + d];
+                sb[s] = prefix_of(row);
+                longest = std::max(longest, sb[s][P]);
+            }
+            const uint64_t per = std::max<uint64_t>(sh.box_bytes / sizeof(E), 1);
+            std::string e;
+            for (int a = 0; a < na; ++a) {
+                for (uint64_t w0 = 0; w0 < longest; w0 += per) {
+                    const uint64_t w1 = w0 + per;
+                    if (w0 < sb[me][P]) {
+                        const uint64_t len = std::min(w1, sb[me][P]) - w0;
+                        MG_HIP(g, hipMemcpyAsync(sh.box(me), in[0][a] + bounds[0][0] + w0, (size_t)len * sizeof(E), hipMemcpyDeviceToHost, R.comm_stream));
+                        MG_HIP(g, hipStreamSynchronize(R.comm_stream));
+                    }
+                    if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                    for (int s = 0; s < P; ++s) {
+                        const uint64_t lo = std::max(w0, sb[s][me]), hi = std::min(w1, sb[s][me + 1]);
+                        if (lo >= hi) continue;
+                        MG_HIP(g, hipMemcpyAsync(out[0][a].p + roff[0][s] + (lo - sb[s][me]), sh.box(s) + (size_t)(lo - w0) * sizeof(E), (size_t)(hi - lo) * sizeof(E),
+                                                 hipMemcpyHostToDevice, R.comm_stream));
+                        if (s != me) g->bytes_sent += (hi - lo) * sizeof(E);      // (counted on the receiving side: the volumes are symmetric over a step)
+                    }
+                    MG_HIP(g, hipStreamSynchronize(R.comm_stream));
+                    if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                }
+            }
+            PSACX_TRY(ex_end(R));
+            MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream));
+            MG_HIP(g, hipStreamWaitEvent(R.ctx->stream, R.ev_done, 0));
         } else {
             // every rank is local (possibly several on one device): the receiver's second stream pulls each piece
             // once the sender's compute stream has produced it
+            if (L != P) { mg_set_err(g, "exchange without a transport between the processes"); return PSACX_EINVAL; }
             for (int i = 0; i < L; ++i) {
                 MRank& R = g->R[i];
                 MG_HIP(g, hipSetDevice(R.ctx->device));
                 for (int s = 0; s < L; ++s) MG_HIP(g, hipStreamWaitEvent(R.comm_stream, g->R[s].ev_ready, 0));
+                PSACX_TRY(ex_begin(R));
                 for (int s = 0; s < L; ++s) {
                     const uint64_t rc = rcnt[i][rank(s)];
                     if (!rc) continue;
@@ -592,6 +734,7 @@ struct MultiRun {
                         MG_HIP(g, hipMemcpyAsync(out[i][a].p + roff[i][rank(s)], in[s][a] + bounds[s][R.grank], (size_t)rc * sizeof(E), hipMemcpyDefault, R.comm_stream));
                     if (s != i) g->bytes_sent += rc * sizeof(E) * na;
                 }
+                PSACX_TRY(ex_end(R));
                 MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream));
             }
             // a sender may not release or overwrite its arrays before every receiver has pulled its piece
@@ -703,7 +846,7 @@ struct MultiRun {
     // over ranks being sorted -- the contract psac needs from mxx::sort (idxsort.hpp:67-79).
     int dist_sort(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, bool first_round = false) {
         ++sort_calls_;
-        if (P == 1) return first_round ? local_sort_first(0, rec[0], bits1, bits2) : local_sort(0, rec[0], bits1, bits2);
+        if (solo_) return first_round ? local_sort_first(0, rec[0], bits1, bits2) : local_sort(0, rec[0], bits1, bits2);
         // 8192 samples per rank: with P ranks a rank's share deviates by about sqrt(P) / sqrt(8192 P) of a block (1.1 %), so the
         // 12.5 % slack of the reduced-memory layout's record arrays is nine standard deviations away
         constexpr int SAMPLES = 8192;
@@ -875,7 +1018,7 @@ struct MultiRun {
         std::vector<std::vector<DBuf<T>>> got;
         std::vector<const T*> gi(L), vi(L);
         std::vector<uint64_t> rc_tot(L);
-        if (P == 1) { gi[0] = gidx[0]; vi[0] = vals[0]; rc_tot[0] = cnt[0]; }
+        if (solo_) { gi[0] = gidx[0]; vi[0] = vals[0]; rc_tot[0] = cnt[0]; }
         else {
             std::vector<std::vector<uint64_t>> bounds(L), rc;
             std::vector<std::vector<const T*>> in(L);
@@ -899,7 +1042,7 @@ struct MultiRun {
     int dist_take(const std::vector<const T*>& block, const std::vector<const T*>& gidx, const std::vector<uint64_t>& cnt,
                   std::vector<DBuf<T>>& out) {
         out.clear(); out.resize(L);
-        if (P == 1) {
+        if (solo_) {
             MG_OP(g, ctx(0), out[0].alloc(ctx(0), cnt[0]));
             MG_OP(g, ctx(0), op_take(ctx(0), block[0], gidx[0], cnt[0], S[0].off, n, out[0].p));
             return PSACX_OK;
@@ -944,7 +1087,7 @@ struct MultiRun {
     int dist_range_min(const std::vector<const T*>& lo, const std::vector<const T*>& hi, const std::vector<uint64_t>& cnt,
                        std::vector<DBuf<T>>& out) {
         out.clear(); out.resize(L);
-        if (P == 1) {
+        if (solo_) {
             MG_OP(g, ctx(0), out[0].alloc(ctx(0), cnt[0]));
             MG_OP(g, ctx(0), op_range_min<T>(ctx(0), S[0].LCP, S[0].m, lo[0], hi[0], cnt[0], S[0].off, out[0].p));
             return PSACX_OK;
@@ -1159,7 +1302,7 @@ struct MultiRun {
             lead = std::min<uint64_t>(*reinterpret_cast<uint64_t*>(c->pinned + 32768), a);
         }
         if (lead == a && p[steps] == m - 1 && P > 1) {
-            g->err = "a bucket of unresolved suffixes covers a whole block: the reduced-memory layout cannot cut it into slabs";
+            mg_set_err(g, "a bucket of unresolved suffixes covers a whole block: the reduced-memory layout cannot cut it into slabs");
             return PSACX_ENOMEM;
         }
         for (uint64_t j = 1; j < steps; ++j) {
@@ -1178,6 +1321,10 @@ struct MultiRun {
         psacx_stats& st = g->stats;
         std::memset(&st, 0, sizeof(st));
         g->bytes_sent = 0; g->n_exchanges = 0; g->n_gathers = 0;
+        g->wire_sends = g->wire_recvs = g->wire_gathers = 0;
+        g->phases.clear();
+        t_phase_ = std::chrono::steady_clock::now();
+        for (int i = 0; i < L; ++i) g->R[i].ex_used = 0;
         S.resize(L);
         PSACX_TRY(par([&](int i) -> int {
             S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
@@ -1259,7 +1406,9 @@ struct MultiRun {
         }
         st.k = k;
         const uint32_t two_k = 2 * k;
-        if (P > 1 && min_local < two_k) { g->err = "text blocks shorter than 2k characters are not supported with more than one rank"; return PSACX_EINVAL; }
+        // (blocks shorter than 2k characters: k was shrunk to the smallest block as kmer.hpp:33-39 does; the 2k-character halo
+        //  then spans several right neighbours, see below)
+        const bool tiny_blocks = P > 1 && min_local < two_k;
         // the 2k-character window packed without an end-marker code (key_pairs_kernel): lc bits per character
         uint32_t lc = 0; while ((1u << lc) < st.sigma) ++lc; if (!lc) lc = 1;
         const uint32_t c1 = std::min<uint32_t>(two_k, word_bits / lc), c2 = two_k - c1;
@@ -1268,7 +1417,26 @@ struct MultiRun {
         std::vector<DBuf<uint8_t>> tbuf(L);
         {
             std::vector<std::vector<DBuf<uint8_t>>> got;
-            if (P > 1) {
+            std::vector<std::vector<uint8_t>> halo_host(L);
+            if (tiny_blocks) {
+                // the halo [end of block, end of block + 2k) reaches beyond the right neighbour: the whole text is at most
+                // 2k P characters, so every rank gets all of it through the scalar all-gather and cuts its halo on the host
+                const uint64_t words = (sizes[0] + 7) / 8 + 1;
+                std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(words, 0));
+                for (int i = 0; i < L; ++i) {
+                    MG_HIP(g, hipSetDevice(ctx(i)->device));
+                    if (S[i].m) MG_HIP(g, hipMemcpy(mine[i].data(), text[i], S[i].m, hipMemcpyDeviceToHost));
+                }
+                std::vector<uint64_t> all;
+                PSACX_TRY(gather((int)words, mine, all));
+                std::vector<uint8_t> whole(n);
+                for (int r = 0; r < P; ++r) std::memcpy(whole.data() + offs[r], reinterpret_cast<const uint8_t*>(&all[(size_t)r * words]), sizes[r]);
+                for (int i = 0; i < L; ++i) {
+                    const uint64_t e = S[i].off + S[i].m;
+                    halo_host[i].assign(two_k, 0);
+                    for (uint64_t t = 0; t < two_k && e + t < n; ++t) halo_host[i][t] = whole[e + t];
+                }
+            } else if (!solo_) {
                 std::vector<std::vector<uint64_t>> bounds(L), rc;
                 std::vector<std::vector<const uint8_t*>> in(L);
                 for (int i = 0; i < L; ++i) {
@@ -1286,7 +1454,8 @@ struct MultiRun {
                 MG_HIP(g, hipSetDevice(c->device));
                 MG_HIP(g, hipMemsetAsync(tbuf[i].p + S[i].m, 0, two_k, c->stream));
                 MG_HIP(g, hipMemcpyAsync(tbuf[i].p, text[i], S[i].m, hipMemcpyDeviceToDevice, c->stream));
-                if (P > 1 && got[i][0].n) MG_HIP(g, hipMemcpyAsync(tbuf[i].p + S[i].m, got[i][0].p, std::min<uint64_t>(got[i][0].n, two_k), hipMemcpyDeviceToDevice, c->stream));
+                if (tiny_blocks) { MG_HIP(g, hipMemcpyAsync(tbuf[i].p + S[i].m, halo_host[i].data(), two_k, hipMemcpyHostToDevice, c->stream)); MG_HIP(g, hipStreamSynchronize(c->stream)); }
+                else if (!solo_ && got[i][0].n) MG_HIP(g, hipMemcpyAsync(tbuf[i].p + S[i].m, got[i][0].p, std::min<uint64_t>(got[i][0].n, two_k), hipMemcpyDeviceToDevice, c->stream));
                 return PSACX_OK;
             }));
         }
@@ -1322,7 +1491,7 @@ struct MultiRun {
             // everything to rank 0, which places the pieces of higher ranks first
             std::vector<std::vector<DBuf<T>>> got;
             std::vector<std::vector<uint64_t>> rc;
-            if (P > 1) {
+            if (!solo_) {
                 std::vector<std::vector<uint64_t>> bounds(L);
                 std::vector<std::vector<const T*>> in(L);
                 for (int i = 0; i < L; ++i) { bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0; in[i] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p}; }
@@ -1333,7 +1502,7 @@ struct MultiRun {
                 psacx_ctx* c = ctx(i);
                 MG_HIP(g, hipSetDevice(c->device));
                 T* dst[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
-                if (P == 1) {
+                if (solo_) {
                     const T* src[3] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p};
                     for (int q = 0; q < 3 && spec; ++q) MG_HIP(g, hipMemcpyAsync(dst[q], src[q], spec * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
                 } else {
@@ -1494,6 +1663,7 @@ struct MultiRun {
             MG_HIP(g, hipStreamSynchronize(ctx(i)->stream));
             return PSACX_OK;
         }));
+        ex_collect();
         return PSACX_OK;
     }
 
@@ -1599,7 +1769,7 @@ struct MultiRun {
             return PSACX_OK;
         }));
         if (!have_local) PSACX_TRY(ansv_ask(A, cls, start1, thr, cnt, strict, left, idx, val));
-        if (P == 1) return PSACX_OK;
+        if (solo_) return PSACX_OK;
         RankMins rm, rs;
         for (int r = 0; r < 64; ++r) { rm.v[r] = r < P ? A.mins[r] : ~0ull; rs.v[r] = r < P ? sizes[r] : 0; }
         std::vector<DBuf<T>> target(L), edge(L);

@@ -40,6 +40,7 @@ class MultiContext(object):
         self.nranks = self._lib.psacx_multi_nranks(self.handle)
         self.nlocal = self._lib.psacx_multi_nlocal(self.handle)
         self.uses_rccl = bool(self._lib.psacx_multi_uses_rccl(self.handle))
+        self.transport = ("copy", "rccl", "shm")[self._lib.psacx_multi_transport(self.handle)]
 
     @classmethod
     def for_rank(cls, rank, nranks, device, uid):
@@ -66,6 +67,25 @@ class MultiContext(object):
         sent, ex, ga = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self.check(self._lib.psacx_multi_get_stats(self.handle, C.byref(s), C.byref(sent), C.byref(ex), C.byref(ga)))
         return s, sent.value, ex.value, ga.value
+
+    def wire(self):
+        """After a call: {"sends", "recvs", "allgathers"}: ncclSend / ncclRecv / ncclAllGather calls this process really
+        issued, and "exchange_ms": time the exchanges occupied each local rank's second stream."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        ms = (C.c_double * self.nlocal)()
+        self.check(self._lib.psacx_multi_get_wire(self.handle, C.byref(a), C.byref(b), C.byref(c), ms))
+        return {"sends": a.value, "recvs": b.value, "allgathers": c.value, "exchange_ms": [round(x, 3) for x in ms]}
+
+    def phases(self):
+        """Host wall time (ms) of the phases of the last construction, in order of first appearance."""
+        buf = C.create_string_buffer(1 << 14)
+        self.check(self._lib.psacx_multi_get_phases(self.handle, buf, len(buf)))
+        out = []
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.rsplit("=", 1)
+                out.append((k, float(v)))
+        return out
 
     LAYOUT_AUTO, LAYOUT_NORMAL, LAYOUT_REDUCED = 0, 1, 2
 

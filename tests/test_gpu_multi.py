@@ -300,7 +300,7 @@ def test_multi_left_branching_chars(P):
     try:
         for text, bits in cases:
             n = text.size
-            if P > 1 and n < 4096:       # (blocks shorter than 2k characters are refused with more than one rank)
+            if n < P:
                 continue
             w = bits // 8
             udt = np.uint32 if bits == 32 else np.uint64
@@ -494,5 +494,98 @@ def test_multi_reduced_memory_twin_of_config_c5_and_its_footprint():
         assert not ra and rb and sa_ == 0 and sb >= 10 and na >= 20 and nb >= 20
         print("words per character beside the results: normal %.2f, reduced %.2f" % (wa, wb))
         assert wb <= 5.0 and wb < wa
+    finally:
+        mg.close()
+
+
+def test_multi_rccl_wire_forced_at_world_size_one(monkeypatch):
+    # PSACX_MULTI_FORCE_WIRE=1: the shortcuts for data a rank addresses to itself and for scalars already on this host are
+    # off, so ncclAllGather and ncclSend / ncclRecv (to self) are really issued at world size 1 -- the calls the driver's
+    # 8-GPU run makes -- and the result is still the oracle's.  Both ways to build a communicator.
+    import psac_amd
+    monkeypatch.setenv("PSACX_MULTI_FORCE_WIRE", "1")
+    text = O.rand_dna(150001, 11)
+    ref = O.construct(text, bits=64)
+    for how in ("rank", "all"):
+        mg = psac_amd.MultiContext.for_rank(0, 1, 0, psac_amd.unique_id()) if how == "rank" else psac_amd.MultiContext([0])
+        try:
+            assert mg.transport == "rccl" and mg.uses_rccl
+            SA, ISA, LCP, rounds = mg.construct(text, index_bits=64)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+            wire = mg.wire()
+            assert wire["allgathers"] > 0 and wire["sends"] > 0 and wire["recvs"] == wire["sends"], wire
+            assert wire["exchange_ms"][0] > 0
+            # repetitive text: refinement rounds with B2 fetches, ISA updates and range minima through the wire
+            t2 = inputs.tandem(30000, 256, O.rand_dna(256, 3))
+            SA, ISA, LCP, rounds = mg.construct(t2, index_bits=32)
+            r2 = O.construct(t2, bits=32)
+            assert np.array_equal(SA, r2["SA"]) and np.array_equal(LCP, r2["LCP"])
+            assert rounds == [(h, b, e) for h, b, e, _ in r2["trace"]]
+        finally:
+            mg.close()
+
+
+def _run_rank_processes(tmp_path, P, kind, n, seed, bits, extras=(), env_extra=None):
+    """P processes, one rank each, all on device 0, exchanging through shared memory (PSACX_MULTI_TRANSPORT=shm)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    uid = os.urandom(128).hex()
+    env = dict(os.environ, PSACX_MULTI_TRANSPORT="shm")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "multi_rank_proc.py"), str(r), str(P), "0", uid, kind, str(n), str(seed), str(bits),
+                               str(tmp_path)] + list(extras), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(P)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, e[-3000:]
+    cat = lambda what: np.concatenate([np.load(os.path.join(str(tmp_path), "r%d_%s.npy" % (r, what))) for r in range(P)])
+    info = [json.load(open(os.path.join(str(tmp_path), "r%d.json" % r))) for r in range(P)]
+    return cat, info
+
+
+@pytest.mark.parametrize("P,bits,kind,n", [(2, 32, "dna", 200003), (3, 64, "tandem", 90001), (2, 64, "single", 4099)])
+def test_multi_process_per_rank_sharing_one_gpu(tmp_path, P, bits, kind, n):
+    # psacx_multi_create_rank with L = 1 < P: one process per rank as under torchrun / mpirun, here with the host-staged
+    # transport because RCCL refuses two ranks on one device.  The count all-gathers, rank(i) != i, the receive offsets by
+    # source rank and the agreement on a status all run; a small box forces the streams through several rounds.
+    import multi_rank_proc
+    cat, info = _run_rank_processes(tmp_path, P, kind, n, 5, bits, extras=("check", "ansv"), env_extra={"PSACX_SHM_BOX": "65536"})
+    text = multi_rank_proc.make_text(kind, n, 5)
+    ref = O.construct(text, bits=bits)
+    assert np.array_equal(cat("sa"), ref["SA"]) and np.array_equal(cat("isa"), ref["ISA"]) and np.array_equal(cat("lcp"), ref["LCP"])
+    for r, inf in enumerate(info):
+        assert inf["rank"] == r and inf["nranks"] == P and inf["nlocal"] == 1 and inf["transport"] == "shm"
+        assert inf["check"] == [0, 0, 0, 0]
+        assert [tuple(x) for x in inf["rounds"]] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+        assert inf["exchanges"] > 0 and inf["gathers"] > 0
+    assert sum(inf["bytes_sent"] for inf in info) > 0
+    # the distributed ANSV over the LCP blocks of the p processes (psac -t on p ranks, ansv.hpp:2042-2051)
+    lcp = ref["LCP"].astype(np.uint64)
+    assert np.array_equal(cat("left"), O.ansv(lcp, True, 2, n)) and np.array_equal(cat("right"), O.ansv(lcp, False, 0, n))
+
+
+@pytest.mark.parametrize("P", [2, 5, 8])
+def test_multi_blocks_shorter_than_the_kmer_window(P):
+    # kmer.hpp:33-39 shrinks k to the smallest block; the 2k-character window of a position then reaches over several right
+    # neighbours.  (Round 2 refused these inputs with PSACX_EINVAL.)
+    mg = multi(P)
+    try:
+        for text, bits in ((O.as_text("mississippi"), 64), (O.rand_dna(3 * P + 1, 3), 32), (O.rand_dna(97, 5), 64), (O.as_text("a" * (P + 1)), 32),
+                           (inputs.cyclic(61, "abc"), 64)):
+            if text.size < P:
+                continue
+            SA, ISA, LCP, _ = same(mg, text, bits)
+            ref = O.construct(text, bits=bits)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, text.size)
     finally:
         mg.close()
