@@ -254,6 +254,10 @@ int psacx_multi_get_wire(const psacx_multi* mg, uint64_t* sends, uint64_t* recvs
 /* host wall time of the phases of the last construction as "name=ms;name=ms;..." (the section timers of
  * suffix_array.hpp:52-63 for this engine); PSACX_ERANGE if buf is too small */
 int psacx_multi_get_phases(const psacx_multi* mg, char* buf, uint64_t cap);
+/* which forms the last construction took: bit 0 = first round in two-word form (records (B1, idx), ties repaired from the
+ * text owners; idxsort.hpp:23-83 moves (B1, B2, idx)), bit 1 = reduced-memory layout, bit 2 = SA -> ISA slice by slice
+ * through the destination-partition levels (bulk_permute.hpp:14-73) */
+int psacx_multi_last_form(const psacx_multi* mg);
 const char* psacx_multi_last_error(const psacx_multi* mg);
 psacx_ctx* psacx_multi_ctx(psacx_multi* mg, int local_rank);
 int psacx_multi_construct_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags,

@@ -29,7 +29,7 @@ EXPORTS = [
     "psacx_multi_construct_dev_u64", "psacx_multi_construct_u32", "psacx_multi_construct_u64", "psacx_multi_get_stats",
     "psacx_multi_check_dev_u32", "psacx_multi_check_dev_u64", "psacx_multi_ansv_dev_u32", "psacx_multi_ansv_dev_u64",
     "psacx_multi_left_chars_dev_u32", "psacx_multi_left_chars_dev_u64", "psacx_multi_construct_lc_u32", "psacx_multi_construct_lc_u64",
-    "psacx_multi_configure", "psacx_multi_get_memory", "psacx_multi_transport", "psacx_multi_get_wire", "psacx_multi_get_phases",
+    "psacx_multi_configure", "psacx_multi_get_memory", "psacx_multi_transport", "psacx_multi_get_wire", "psacx_multi_get_phases", "psacx_multi_last_form",
 ]
 
 
@@ -113,7 +113,7 @@ def load():
     lib.psacx_multi_destroy.restype = None
     lib.psacx_multi_get_wire.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     lib.psacx_multi_get_phases.argtypes = [vp, C.c_char_p, u64]
-    for nm in ("psacx_multi_nranks", "psacx_multi_nlocal", "psacx_multi_uses_rccl", "psacx_multi_transport"):
+    for nm in ("psacx_multi_nranks", "psacx_multi_nlocal", "psacx_multi_uses_rccl", "psacx_multi_transport", "psacx_multi_last_form"):
         getattr(lib, nm).argtypes = [vp]
     lib.psacx_multi_last_error.argtypes = [vp]
     lib.psacx_multi_last_error.restype = C.c_char_p

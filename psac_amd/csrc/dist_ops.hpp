@@ -412,6 +412,34 @@ int op_compact(psacx_ctx* c, const T* ids, const T* pos, uint64_t cnt, uint64_t 
     return PSACX_OK;
 }
 
+// Records of a prefix sort that still tie on the leading bits of word 1 (S1 >> lo1 equal to a neighbour's).  Phase 1
+// (out arrays null): *n_out = their number.  Phase 2: pos_out = their positions, k1_out / v_out = their word 1 and payload,
+// in order.  Tie groups never straddle a rank (the shuffle keeps equal prefixes together), so there is no neighbour id.
+template <typename T>
+int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigned lo1, T* pos_out, T* k1_out, T* v_out, uint64_t* n_out) {
+    OP_PROLOGUE(c);
+    if (!pos_out) *n_out = 0;
+    if (cnt == 0) return PSACX_OK;
+    PSACX_TRY(ensure_pinned(c, 4096));
+    TileScratch ts;
+    PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+    hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, cnt,
+                       (T)0, (T)0, ts.nact, lo1);
+    hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, ts.nact, ntiles, OpSum(), (uint64_t)0, ts.totals);
+    PSACX_HIP(c, hipGetLastError());
+    if (!pos_out) {
+        PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        *n_out = *reinterpret_cast<uint64_t*>(c->pinned);
+        return PSACX_OK;
+    }
+    hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1,
+                       (const T*)nullptr, cnt, pos_out, ts.nact, (uint64_t)0, (T)0, (T)0, lo1, v, k1_out, v_out);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
 // aux_queries > 0: also tabulates the running minima pyramid_min uses (see prepare_range_min in
 // construct.hpp) when that many queries make it worth while
 template <typename T>

@@ -578,7 +578,6 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
     if (!in.k2) bits2 = 0;
-    if (!in.k2 && !summary_ready) return PSACX_EINVAL;
     const PassPlan plan = make_plan((int)bits1, (int)bits2, (int)lo1);
     // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
     // single-sweep look-back form for small ones where launch count matters more

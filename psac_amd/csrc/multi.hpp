@@ -160,6 +160,8 @@ struct psacx_multi {
     uint64_t opt_slab = 0;            // unresolved suffixes per refinement slab of the reduced-memory layout (0: block / 16)
     uint64_t out_slack = 0;           // the output arrays given to construct_dev hold this many elements beyond the block
     bool last_reduced = false;        // layout the last construction ran in
+    bool last_two_word = false;       // the first round ran in two-word form (sort_first_two_word)
+    bool last_slice_inversion = false;   // SA -> ISA ran slice by slice through the partition levels + window scatter
     uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
 };
 
@@ -928,11 +930,26 @@ struct MultiRun {
             return PSACX_OK;
         }));
         mark("    sort: local sort");
-        // exact re-balance: the j-th record of rank r has global index G[r] + j
-        std::vector<uint64_t> counts;
+        return rebalance(rec, targets);
+    }
+
+    // exact re-balance of globally sorted records to the block sizes: the j-th record of rank r has global index G[r] + j
+    int rebalance(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets) {
+        std::vector<uint64_t> c2(L), counts;
+        for (int i = 0; i < L; ++i) c2[i] = rec[i].cnt;
         PSACX_TRY(gather1(c2, counts));
         if (counts == targets) return PSACX_OK;
         const std::vector<uint64_t> G = prefix_of(counts), TP = prefix_of(targets);
+        std::vector<std::vector<uint64_t>> bounds(L), rc;
+        std::vector<std::vector<const T*>> in(L);
+        std::vector<std::vector<DBuf<T>>> got;
+        const std::function<int(int, uint64_t, std::vector<DBuf<T>>&)> recv3 = [this](int i, uint64_t tot, std::vector<DBuf<T>>& o) -> int {
+            Rec<T> r;
+            PSACX_TRY(take3(i, r, tot));
+            o.clear(); o.resize(3);
+            o[0] = std::move(r.k1); o[1] = std::move(r.k2); o[2] = std::move(r.v);
+            return PSACX_OK;
+        };
         for (int i = 0; i < L; ++i) {
             const uint64_t gr = G[rank(i)];
             bounds[i].assign(P + 1, c2[i]);
@@ -946,6 +963,240 @@ struct MultiRun {
             rec[i].cnt = rec[i].k1.n;
         }
         return PSACX_OK;
+    }
+
+    // Both words of the packed 2k-character window of the suffixes gidx[i][0 .. cnt[i]) (global positions), computed by the
+    // ranks that own those positions from their text blocks + halos (tbuf: block + 2k characters) and sent back in query
+    // order: the remote form of window_word2() for the suffixes that tie on the leading bits of word 1.
+    int dist_windows(const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, const std::vector<const T*>& gidx,
+                     const std::vector<uint64_t>& cnt, std::vector<DBuf<T>>& w1, std::vector<DBuf<T>>& w2) {
+        w1.clear(); w1.resize(L); w2.clear(); w2.resize(L);
+        auto answer = [&](int i, const T* q, uint64_t qn, T* o1, T* o2) -> int {
+            psacx_ctx* c = ctx(i);
+            OP_PROLOGUE(c);
+            if (qn) {
+                hipLaunchKernelGGL((window_at_kernel<T, 256>), dim3(grid_for(c, qn, 256, 16)), dim3(256), 0, c->stream, tbuf[i].p, S[i].m + two_k, S[i].off, q, qn,
+                                   tab, ks, o1, o2);
+                PSACX_HIP(c, hipGetLastError());
+            }
+            return PSACX_OK;
+        };
+        if (solo_) {
+            MG_OP(g, ctx(0), w1[0].alloc(ctx(0), cnt[0])); MG_OP(g, ctx(0), w2[0].alloc(ctx(0), cnt[0]));
+            MG_OP(g, ctx(0), answer(0, gidx[0], cnt[0], w1[0].p, w2[0].p));
+            return PSACX_OK;
+        }
+        std::vector<Rec<T>> routed(L);
+        std::vector<std::vector<uint64_t>> bounds(L), rc, rc2;
+        std::vector<std::vector<const T*>> in(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            DBuf<T> idx; MG_OP(g, c, idx.alloc(c, cnt[i]));
+            MG_OP(g, c, psacx_op_iota(c, idx.p, cnt[i], 0));
+            PSACX_TRY(route(i, gidx[i], idx.p, cnt[i], routed[i], bounds[i]));
+            in[i] = {routed[i].k2.p};
+            return PSACX_OK;
+        }));
+        std::vector<std::vector<DBuf<T>>> q, got;
+        PSACX_TRY(exchange<T>(1, in, bounds, q, rc));
+        std::vector<DBuf<T>> a1(L), a2(L);
+        std::vector<std::vector<uint64_t>> back_bounds(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, a1[i].alloc(c, q[i][0].n)); MG_OP(g, c, a2[i].alloc(c, q[i][0].n));
+            MG_OP(g, c, answer(i, q[i][0].p, q[i][0].n, a1[i].p, a2[i].p));
+            back_bounds[i] = prefix_of(rc[i]);
+            in[i] = {a1[i].p, a2[i].p};
+            return PSACX_OK;
+        }));
+        PSACX_TRY(exchange<T>(2, in, back_bounds, got, rc2));
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, w1[i].alloc(c, cnt[i])); MG_OP(g, c, w2[i].alloc(c, cnt[i]));
+            MG_OP(g, c, op_put(c, w1[i].p, routed[i].v.p, cnt[i], 0, got[i][0].p, 0));      // undo the routing permutation
+            MG_OP(g, c, op_put(c, w2[i].p, routed[i].v.p, cnt[i], 0, got[i][1].p, 0));
+            return PSACX_OK;
+        }));
+        return PSACX_OK;
+    }
+
+    // The first sort in two-word form (what the one-GPU engine does, construct.hpp "two stages"): the records are (word 1,
+    // suffix) only.  When the leading `lead` = bits1 - lo1 bits of word 1 separate almost every suffix of the whole text,
+    //   1. the shuffle goes by those leading bits alone -- splitters are prefix values and equal prefixes never part, so a
+    //      group of suffixes that tie on them is whole on one rank -- and moves two words per record instead of three;
+    //   2. the local sort is a prefix sort of two-word records on the leading bits (lead / 8 passes of 4w bytes per record
+    //      instead of all digits of both words at 6w);
+    //   3. the few suffixes that still tie are compacted, the full window of each is fetched from the rank that owns its text
+    //      (dist_windows), the groups are ordered by it (in registers when every group is tiny, else by a radix sort of the
+    //      compacted records) and written back; word 2 exists for those records only, which is all rebucket_first_kernel reads.
+    // rec[i]: k1 and v filled, k2 allocated but unused until step 3.  Returns PSACX_RETRY_ before anything has moved when the
+    // samples say the text is repetitive (many equal prefixes) or the prefixes cannot balance the ranks: the caller then runs
+    // the three-word path.
+    static constexpr int PSACX_RETRY_ = 1;
+    int sort_first_two_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1,
+                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust) {
+        ++sort_calls_;
+        constexpr int SAMPLES = 8192;
+        std::vector<uint64_t> spl;
+        {
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + SAMPLES, 0));
+            PSACX_TRY(par([&](int i) -> int {
+                const uint64_t c = rec[i].cnt;
+                std::vector<uint64_t> pos;
+                for (int s = 0; s < SAMPLES && c; ++s) {
+                    const uint64_t lo = (uint64_t)(((unsigned __int128)c * s) / SAMPLES), hi = (uint64_t)(((unsigned __int128)c * (s + 1)) / SAMPLES);
+                    if (hi <= lo) continue;
+                    uint64_t z = ((uint64_t)rank(i) << 32 | (uint64_t)s) + 0x9E3779B97F4A7C15ull * (sort_calls_ + 1);      // splitmix64
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+                    const uint64_t p = lo + z % (hi - lo);
+                    if (pos.empty() || pos.back() != p) pos.push_back(p);
+                }
+                std::vector<uint64_t> a;
+                PSACX_TRY(fetch(i, rec[i].k1.p, pos, a));
+                mine[i][0] = pos.size();
+                for (size_t s = 0; s < pos.size(); ++s) mine[i][1 + s] = a[s] >> lo1;
+                return PSACX_OK;
+            }));
+            std::vector<uint64_t> all, flat;
+            PSACX_TRY(gather(1 + SAMPLES, mine, all));
+            for (int r = 0; r < P; ++r) {
+                const uint64_t* row = &all[(size_t)r * (1 + SAMPLES)];
+                flat.insert(flat.end(), row + 1, row + 1 + row[0]);
+            }
+            std::sort(flat.begin(), flat.end());
+            if (!trust && !flat.empty()) {
+                // equal prefixes among a few thousand samples of a 2^lead space: a repetitive text, whose tie groups are long
+                size_t dup = 0;
+                for (size_t j = 1; j < flat.size(); ++j) dup += flat[j] == flat[j - 1];
+                if (dup * 64 > flat.size()) return PSACX_RETRY_;
+            }
+            for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
+            spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+            if (!trust && !flat.empty() && P > 1) {
+                // the share of the samples each destination would receive (destination = splitters <= prefix)
+                std::vector<size_t> share(P, 0);
+                for (uint64_t x : flat) share[std::upper_bound(spl.begin(), spl.end(), x) - spl.begin()]++;
+                for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
+            }
+        }
+        if (!solo_) {
+            const uint32_t ns = (uint32_t)spl.size();
+            Splitters sp; std::memset(&sp, 0, sizeof(sp));
+            sp.n = ns;
+            for (uint32_t s = 0; s < ns; ++s) sp.k1[s] = spl[s];
+            std::vector<Rec<T>> grp(L);
+            std::vector<std::vector<uint64_t>> bounds(L), rc;
+            std::vector<std::vector<const T*>> in(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                const uint64_t cn = rec[i].cnt;
+                PSACX_TRY(take3(i, grp[i], cn));
+                bounds[i].assign(P + 1, cn);
+                bounds[i][0] = 0;
+                if (cn) {
+                    MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+                    SortScratch sc; T* cls = nullptr;
+                    auto layout = [&](Arena& a) {
+                        cls = a.take<T>(cn);
+                        sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
+                        sc.desc_bytes = sort_desc_bytes(cn);
+                        sc.d_desc = a.take<char>(sc.desc_bytes);
+                    };
+                    { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
+                    Arena ar(c->slab);
+                    layout(ar);
+                    MG_HIP(g, hipSetDevice(c->device));
+                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3(grid_for(c, cn, 256, 16)), dim3(256), 0, c->stream, rec[i].k1.p, cn, lo1, sp, cls);
+                    MG_HIP(g, hipGetLastError());
+                    SortBufs<T> si{rec[i].k1.p, nullptr, rec[i].v.p}, so{grp[i].k1.p, nullptr, grp[i].v.p};
+                    unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
+                    MG_OP(g, c, class_partition<T>(c, sc, si, so, cls, cn, starts));
+                    for (uint32_t d = 0; d <= ns; ++d) bounds[i][d] = starts[d];
+                }
+                drop3(i, rec[i]);
+                in[i] = {grp[i].k1.p, grp[i].v.p};
+                return PSACX_OK;
+            }));
+            mark("    sort: samples + partition");
+            // the receive arrays are a whole record set (the third array becomes word 2 of the tied records later)
+            std::vector<DBuf<T>> spare(L);
+            std::vector<std::vector<DBuf<T>>> got;
+            const std::function<int(int, uint64_t, std::vector<DBuf<T>>&)> recv2 = [this, &spare](int i, uint64_t tot, std::vector<DBuf<T>>& o) -> int {
+                Rec<T> r;
+                PSACX_TRY(take3(i, r, tot));
+                o.clear(); o.resize(2);
+                o[0] = std::move(r.k1); o[1] = std::move(r.v); spare[i] = std::move(r.k2);
+                return PSACX_OK;
+            };
+            PSACX_TRY(exchange<T>(2, in, bounds, got, rc, recv2));
+            mark("    sort: shuffle");
+            for (int i = 0; i < L; ++i) {
+                drop3(i, grp[i]);
+                rec[i].k1 = std::move(got[i][0]); rec[i].v = std::move(got[i][1]); rec[i].k2 = std::move(spare[i]);
+                rec[i].cnt = rec[i].k1.n;
+            }
+        }
+        // prefix sort of (word 1, suffix) on the leading bits, then the ties
+        std::vector<uint64_t> ties(L, 0);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            if (rec[i].cnt >= 2) {
+                Rec<T> alt;
+                PSACX_TRY(take3(i, alt, rec[i].cnt));
+                int32_t where = 0;
+                MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1));
+                if (where) swap3(rec[i], alt);
+                drop3(i, alt);
+            }
+            MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &ties[i]));
+            return PSACX_OK;
+        }));
+        mark("    sort: local prefix sort");
+        std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, tpos[i].alloc(c, ties[i])); MG_OP(g, c, tk1[i].alloc(c, ties[i])); MG_OP(g, c, tv[i].alloc(c, ties[i]));
+            if (ties[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk)); }
+            return PSACX_OK;
+        }));
+        {
+            std::vector<const T*> q(L);
+            for (int i = 0; i < L; ++i) q[i] = tv[i].p;
+            PSACX_TRY(dist_windows(tbuf, two_k, tab, ks, q, ties, w1, w2));
+        }
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            const uint64_t tn = ties[i];
+            if (!tn) return PSACX_OK;
+            MG_HIP(g, hipSetDevice(c->device));
+            // every group is at most TG long: ordered in registers (tie_resolve_kernel reading both words from the arrays)
+            constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
+            DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
+            MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
+            const uint64_t nb = (tn + (uint64_t)TB_ * TI_ - 1) / ((uint64_t)TB_ * TI_);
+            hipLaunchKernelGGL((tie_resolve_kernel<T, TB_, TI_, TG_, true>), dim3((unsigned)nb), dim3(TB_), 0, c->stream, w1[i].p, tv[i].p, w2[i].p, tn, lo1,
+                               (const uint8_t*)nullptr, (uint64_t)0, tab, ks, big.p);
+            MG_HIP(g, hipGetLastError());
+            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            const T *s1 = w1[i].p, *s2 = w2[i].p, *sv = tv[i].p;
+            DBuf<T> b1, b2, bv;
+            if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) {
+                // some group is long (repetitive text): a stable sort of all tied records by the full window; the groups come in
+                // ascending order of their prefix, so the sorted records go back to the same positions in order
+                MG_OP(g, c, b1.alloc(c, tn)); MG_OP(g, c, b2.alloc(c, tn)); MG_OP(g, c, bv.alloc(c, tn));
+                int32_t where = 0;
+                MG_OP(g, c, op_pair_sort<T>(c, w1[i].p, w2[i].p, tv[i].p, b1.p, b2.p, bv.p, tn, bits1, bits2, &where));
+                if (where) { s1 = b1.p; s2 = b2.p; sv = bv.p; }
+            }
+            hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, tn, 256, 16)), dim3(256), 0, c->stream, (const T*)tpos[i].p, tn, s1, s2, sv,
+                               rec[i].k1.p, rec[i].k2.p, rec[i].v.p);
+            MG_HIP(g, hipGetLastError());
+            MG_HIP(g, hipStreamSynchronize(c->stream));          // (the compacted arrays go back to the cache when this scope ends)
+            return PSACX_OK;
+        }));
+        mark("    sort: ties");
+        return rebalance(rec, targets);
     }
 
     // Stable partition of global positions `gidx` and one payload array by owner rank: the owner of every position
@@ -1463,14 +1714,17 @@ struct MultiRun {
         //      of the record order (rank 0, shortest first): see key_pairs_kernel for why that replaces the end marker
         const uint64_t spec = std::min<uint64_t>(two_k - 1, n);
         std::vector<Rec<T>> rec(L);
-        {
+        // both: word 2 of every record is generated and carried (three-word records); otherwise the records are (word 1, suffix)
+        auto make_records = [&](bool both) -> int {
             std::vector<Rec<T>> tails(L);
             std::vector<uint64_t> mine_cnt(L);
+            const int na = both ? 3 : 2;
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
+                drop3(i, rec[i]);
                 PSACX_TRY(take3(i, rec[i], front + m));
-                MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, rec[i].k2.p + front));
+                MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, both ? rec[i].k2.p + front : (T*)nullptr));
                 MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));
                 const uint64_t end = S[i].off + m, first_short = n - spec;
                 const uint64_t mine = std::min<uint64_t>(m, end > first_short ? end - first_short : 0);     // short suffixes in this block (its tail)
@@ -1478,8 +1732,8 @@ struct MultiRun {
                 tails[i].cnt = mine;
                 MG_OP(g, c, tails[i].k1.alloc(c, mine)); MG_OP(g, c, tails[i].k2.alloc(c, mine)); MG_OP(g, c, tails[i].v.alloc(c, mine));
                 if (mine) {
-                    const T* src[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p}; T* dst[3] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p};
-                    for (int q = 0; q < 3; ++q) {
+                    const T* src[3] = {rec[i].k1.p, rec[i].v.p, rec[i].k2.p}; T* dst[3] = {tails[i].k1.p, tails[i].v.p, tails[i].k2.p};
+                    for (int q = 0; q < na; ++q) {
                         hipLaunchKernelGGL((reverse_copy_kernel<T>), dim3((unsigned)((mine + 255) / 256)), dim3(256), 0, c->stream, src[q] + front + m - mine, mine, dst[q]);
                         MG_HIP(g, hipGetLastError());
                     }
@@ -1487,39 +1741,67 @@ struct MultiRun {
                 rec[i].cnt = front + m - mine;
                 return PSACX_OK;
             }));
-            tbuf.clear();
             // everything to rank 0, which places the pieces of higher ranks first
             std::vector<std::vector<DBuf<T>>> got;
             std::vector<std::vector<uint64_t>> rc;
             if (!solo_) {
                 std::vector<std::vector<uint64_t>> bounds(L);
                 std::vector<std::vector<const T*>> in(L);
-                for (int i = 0; i < L; ++i) { bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0; in[i] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p}; }
-                PSACX_TRY(exchange<T>(3, in, bounds, got, rc));
+                for (int i = 0; i < L; ++i) {
+                    bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0;
+                    in[i] = {tails[i].k1.p, tails[i].v.p};
+                    if (both) in[i].push_back(tails[i].k2.p);
+                }
+                PSACX_TRY(exchange<T>(na, in, bounds, got, rc));
             }
             PSACX_TRY(par([&](int i) -> int {
                 if (rank(i) != 0) return PSACX_OK;
                 psacx_ctx* c = ctx(i);
                 MG_HIP(g, hipSetDevice(c->device));
-                T* dst[3] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
+                T* dst[3] = {rec[i].k1.p, rec[i].v.p, rec[i].k2.p};
                 if (solo_) {
-                    const T* src[3] = {tails[i].k1.p, tails[i].k2.p, tails[i].v.p};
-                    for (int q = 0; q < 3 && spec; ++q) MG_HIP(g, hipMemcpyAsync(dst[q], src[q], spec * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    const T* src[3] = {tails[i].k1.p, tails[i].v.p, tails[i].k2.p};
+                    for (int q = 0; q < na && spec; ++q) MG_HIP(g, hipMemcpyAsync(dst[q], src[q], spec * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
                 } else {
                     const std::vector<uint64_t> cuts = prefix_of(rc[i]);
                     uint64_t at = 0;
                     for (int s = P - 1; s >= 0; --s) {
                         const uint64_t len = rc[i][s];
-                        for (int q = 0; q < 3 && len; ++q) MG_HIP(g, hipMemcpyAsync(dst[q] + at, got[i][q].p + cuts[s], len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                        for (int q = 0; q < na && len; ++q) MG_HIP(g, hipMemcpyAsync(dst[q] + at, got[i][q].p + cuts[s], len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
                         at += len;
                     }
                 }
                 return PSACX_OK;
             }));
-            // (the pieces are consumed before `got` and `tails` go out of scope: stream order)
-        }
+            // the pieces are consumed before `got` and `tails` go back to the cache: a block handed out again is only touched
+            // in stream order (engine.hpp: pool)
+            return PSACX_OK;
+        };
+        // Two-word form (sort_first_two_word) when the leading bits of word 1 separate almost every suffix and sorting on them
+        // saves a pass -- the rule of the one-GPU engine (construct.hpp) with n the length of the WHOLE text.
+        // PSACX_MULTI_TWO_WORD: 0 = never, 1 = also below 2^21 records per rank, 2 = additionally ignore what the samples say
+        // (tests: repetitive texts through the tie machinery).
+        const unsigned bits_w1 = c1 * lc, bits_w2 = c2 * lc;
+        const unsigned lead = (bits_for(n - 1) + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
+        const char* env_tw = getenv("PSACX_MULTI_TWO_WORD");
+        const int tw_mode = env_tw ? atoi(env_tw) : -1;
+        bool two_word = tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
+                        !getenv("PSACX_ONE_STAGE");
+        PSACX_TRY(make_records(!two_word));
         mark("keys");
-        PSACX_TRY(dist_sort(rec, sizes, c1 * lc, c2 * lc, true));
+        if (two_word) {
+            CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
+            KeyShape ks; ks.lc = lc; ks.c1 = c1; ks.c2 = c2; ks.spec = 0;
+            const int rc2 = sort_first_two_word(rec, sizes, bits_w1, bits_w2, bits_w1 - lead, tbuf, two_k, tab, ks, tw_mode == 2);
+            if (rc2 == PSACX_RETRY_) {
+                two_word = false;
+                PSACX_TRY(make_records(true));
+                mark("keys");
+            } else PSACX_TRY(rc2);
+        }
+        if (!two_word) PSACX_TRY(dist_sort(rec, sizes, bits_w1, bits_w2, true));
+        tbuf.clear();
+        g->last_two_word = two_word;
         PSACX_TRY(par([&](int i) -> int { return own3(i, rec[i]); }));
         mark("first sort");
 

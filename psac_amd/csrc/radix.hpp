@@ -394,6 +394,20 @@ __global__ void classify_kernel(const T* __restrict__ k1, const T* __restrict__ 
     }
 }
 
+// Destination of a two-word record (word 1, suffix) in a shuffle by the leading bits of word 1: the number of splitters
+// that do not exceed its prefix, so that records with equal prefixes never part (their order by the rest of the window is
+// decided on the receiving rank).
+template <typename T>
+__global__ void classify_prefix_kernel(const T* __restrict__ k1, uint64_t n, unsigned lo1, Splitters sp, T* __restrict__ cls) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long a = (unsigned long long)k1[i] >> lo1;
+        unsigned lo = 0, hi = sp.n;                       // first splitter that exceeds the prefix
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (sp.k1[mid] > a) hi = mid; else lo = mid + 1; }
+        cls[i] = (T)lo;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Three-kernel form of a pass (no inter-workgroup waiting): per-tile digit
 // histograms -> exclusive scan over tiles (within slabs of SLAB_TILES tiles, then

@@ -71,11 +71,11 @@ __global__ void key_summary_kernel(const T* __restrict__ k1, const T* __restrict
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const T x = k1[i], y = k2[i];
+        const T x = k1[i], y = k2 ? k2[i] : (T)0;        // (two-word records have no second key word)
         o1 |= x; a1 &= x; o2 |= y; a2 &= y;
     }
     key_summary_add<T>(summary, o1, a1, o2, a2);
-}   // codes 1..sigma (sigma may be 256)
+}
 
 // ------------------------------------------------------------------ K1
 template <int BLOCK>
@@ -842,6 +842,25 @@ __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint
         w2 = (T)(w2 << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
     }
     return w2;
+}
+
+// Both words of the packed window of the suffixes q[j] (global positions) out of a rank's text block with its halo
+// (text[0] = position off, text_len = block + 2k characters, zero beyond the end of the whole text): what the owner of a
+// position answers when another rank asks for the window of a suffix that ties on the leading bits (multi.hpp).
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void window_at_kernel(const uint8_t* __restrict__ text, uint64_t text_len, uint64_t off, const T* __restrict__ q,
+                                                          uint64_t cnt, CodeTable tab, KeyShape ks, T* __restrict__ W1, T* __restrict__ W2) {
+    __shared__ uint16_t ctab[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const uint64_t i = (uint64_t)q[j] - off;
+        T w1 = 0;
+        for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << ks.lc) | (T)(i + t < text_len ? ctab[text[i + t]] : (uint16_t)0);
+        W1[j] = w1;
+        W2[j] = window_word2<T>(text, text_len, ctab, ks, i);
+    }
 }
 
 // Stage 2, common case: every group of suffixes that tie on the leading bits of word 1 is tiny.

@@ -589,3 +589,26 @@ def test_multi_blocks_shorter_than_the_kmer_window(P):
             assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, text.size)
     finally:
         mg.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_first_round_two_word_form(P, monkeypatch):
+    # sort_first_two_word (multi.hpp): the shuffle and the local sort move (word 1, suffix) only, on the leading bits; the
+    # suffixes that tie fetch their full window from the ranks that own their text.  Forced below its size threshold;
+    # mode 2 also sends repetitive texts through it (long tie groups -> radix sort of the compacted ties).
+    cases = [(O.rand_dna(70001, 7), 64), (O.rand_dna(70001, 7), 32), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
+             (np.full(5003, 65, np.uint8), 64), (inputs.cyclic(20011, "abc"), 32), (O.as_text("mississippi" * 40), 64)]
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
+        mg = multi(P)
+        try:
+            used = 0
+            for text, bits in cases:
+                SA, ISA, LCP, rounds = same(mg, text, bits)
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, bits, text.size)
+                assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
+                used += mg.last_form()["two_word"]
+            assert used >= (len(cases) - 1 if mode == "2" else 2), used      # (DNA on 32-bit words: word 1 is shorter than the leading bits)
+        finally:
+            mg.close()
