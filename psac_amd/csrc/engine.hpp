@@ -549,6 +549,37 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
     return PSACX_OK;
 }
 
+// The shuffle pass of the two-word first round (multi.hpp: sort_first_two_word): the records k1[0 .. n) of one piece of a
+// rank's block are grouped by the destination in the byte array cls (stable), their payload -- the suffix a record stands
+// for -- is made up on the way (spec / spec_n / voff as in radix_scatter_tile) and leaves as 32-bit entries when v32.
+// The per-class totals of the piece are known already (classify_prefix_kernel), so nothing comes back to the host.
+template <typename T>
+int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, const T* k1, const uint8_t* cls, uint64_t n, T* k1_out, void* v_out,
+                    bool v32, uint64_t spec, uint64_t spec_n, uint64_t voff) {
+    constexpr int BLOCK = 512, ITEMS = sizeof(T) == 4 ? 12 : 8, TILE = BLOCK * ITEMS;
+    if (n == 0) return PSACX_OK;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const unsigned slab_tiles = slab_tiles_for(ntiles);
+    const uint64_t nslabs = (ntiles + slab_tiles - 1) / slab_tiles;
+    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
+    PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+    hipLaunchKernelGGL((class_tile_hist_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, cls, n, tile_hist);
+    hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
+    hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, d_base);
+    const T* dsrc = reinterpret_cast<const T*>(cls);
+    if (sizeof(T) == 8 && v32)
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 1 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
+    else
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, 0, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
 // whether a sort of n records runs its passes in the three-kernel form (else: single sweep with look-back).
 // Default: three kernels for large inputs (no workgroup ever waits on another), look-back for small ones where the
 // launch count matters more; records without a second key word exist only in the three-kernel form.
@@ -572,7 +603,10 @@ template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
               uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0,
-              int ready_hist_shift = -1) {
+              int ready_hist_shift = -1, bool v32_in = false) {
+    // v32_in (64-bit words, two-word records): in.v holds 32-bit entries (payloads below 2^32 that arrived that way, the
+    // suffixes of a text of at most 2^32 characters after the multi-GPU shuffle); they stay 32-bit between the passes and the
+    // last pass widens them, as for a payload the first pass makes up
     // ready_hist_shift >= 0: the tile histograms of word 1 at that bit position are already in the scratch
     // (written by key_pairs_kernel<..., HIST> with the tile shape of this sort)
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
@@ -668,7 +702,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 
     // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
-    const bool narrow = three && sizeof(T) == 8 && !in.k2 && iota && n <= (1ull << 32) && cfg == ScatterCfg<T>::DEF2 && !narrow_off_env();
+    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in) && cfg == ScatterCfg<T>::DEF2 && (!narrow_off_env() || v32_in);
+    if (v32_in && !narrow) return PSACX_EINVAL;
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
     for (int p = 0; p < plan.n_pass; ++p) {
@@ -691,7 +726,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
             dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n,
-                              have_hist, narrow ? (last ? (first ? 0 : 2) : 1) : 0);
+                              have_hist, narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0);
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
@@ -717,7 +752,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? 4ull : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
         else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
@@ -728,6 +763,12 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         if (iota) {
             hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
+        } else if (v32_in) {
+            // (32-bit entries in, words out: through the other payload array when the widening would run in place)
+            T* const w = (dst == cur.v) ? oth.v : dst;
+            hipLaunchKernelGGL((widen32_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(cur.v), n, w);
+            PSACX_HIP(c, hipGetLastError());
+            if (w != dst) PSACX_HIP(c, hipMemcpyAsync(dst, w, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         } else if (dst != cur.v) {
             PSACX_HIP(c, hipMemcpyAsync(dst, cur.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         }

@@ -36,6 +36,7 @@
 #include "dist_ops.hpp"
 #include "ansv_tile.hpp"
 #include "shm_link.hpp"
+#include "slice_inv.hpp"
 
 namespace psacx {
 
@@ -436,17 +437,26 @@ struct MultiRun {
     // the text block), so the cached blocks serve each other's successors whatever the sample sort's imbalance
     uint64_t reserve_of(int i) const { return diet && first_round_ ? S[i].m + S[i].m / 8 + 256 : 0; }
     // three record arrays of cnt entries: the output arrays of the rank while they are free and large enough, else its cache
-    int take3(int i, Rec<T>& r, uint64_t cnt) {
+    // want_k2 = false: two-word records; the second key array is left out unless it comes for free (an output array)
+    int take3(int i, Rec<T>& r, uint64_t cnt, bool want_k2 = true) {
         psacx_ctx* c = ctx(i);
         r = Rec<T>();
         r.cnt = cnt;
         if (diet && !S[i].out_busy && cnt <= S[i].out_cap) {
             r.v.borrow(c, S[i].SA, cnt); r.k1.borrow(c, S[i].ISA, cnt);
-            if (S[i].LCP) r.k2.borrow(c, S[i].LCP, cnt); else MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
+            if (S[i].LCP) r.k2.borrow(c, S[i].LCP, cnt); else if (want_k2) MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
             S[i].out_busy = true;
             return PSACX_OK;
         }
-        MG_OP(g, c, r.k1.alloc(c, cnt, reserve_of(i))); MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i))); MG_OP(g, c, r.v.alloc(c, cnt, reserve_of(i)));
+        MG_OP(g, c, r.k1.alloc(c, cnt, reserve_of(i)));
+        if (want_k2) MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
+        MG_OP(g, c, r.v.alloc(c, cnt, reserve_of(i)));
+        return PSACX_OK;
+    }
+    // the second key array of a two-word record set, when word 2 of the tied records is about to be written
+    int need_k2(int i, Rec<T>& r) {
+        if (r.k2.p) return PSACX_OK;
+        MG_OP(g, ctx(i), r.k2.alloc(ctx(i), r.cnt, reserve_of(i)));
         return PSACX_OK;
     }
     void drop3(int i, Rec<T>& r) {
@@ -748,6 +758,172 @@ struct MultiRun {
         return PSACX_OK;
     }
 
+    // ---------------------------------------------------------------- message lists
+    // The general form of an exchange: local rank i sends the elements [off, off + cnt) of each of its arrays in[i][a] to rank
+    // `peer`, one message per list entry, and receives its recvs[i] entries (peer = source rank, off = place in out[i][a]).
+    // Several messages between one pair of ranks are matched in list order.  esz[a]: element size of array a (bytes); the
+    // receive arrays exist already.  done (optional): one event per local rank that is recorded on its second stream when its
+    // messages have arrived; the compute streams are then NOT made to wait (the caller waits on the events when it needs the
+    // data, so that later exchanges run under earlier local work).
+    struct Msg { int peer; uint64_t off, cnt; };
+    int transfer(const std::vector<std::vector<const void*>>& in, const std::vector<std::vector<void*>>& out, const std::vector<size_t>& esz,
+                 const std::vector<std::vector<Msg>>& sends, const std::vector<std::vector<Msg>>& recvs, std::vector<hipEvent_t>* done = nullptr) {
+        const int na = (int)esz.size();
+        g->n_exchanges++;
+        for (int i = 0; i < L; ++i) {
+            MRank& R = g->R[i];
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            MG_HIP(g, hipEventRecord(R.ev_ready, R.ctx->stream));
+        }
+        auto finish = [&](int i) -> int {
+            MRank& R = g->R[i];
+            PSACX_TRY(ex_end(R));
+            if (done) MG_HIP(g, hipEventRecord((*done)[i], R.comm_stream));
+            else { MG_HIP(g, hipEventRecord(R.ev_done, R.comm_stream)); MG_HIP(g, hipStreamWaitEvent(R.ctx->stream, R.ev_done, 0)); }
+            return PSACX_OK;
+        };
+        if (g->transport == PSACX_TR_RCCL) {
+            RcclApi& nc = rccl();
+            for (int i = 0; i < L; ++i) {
+                MG_HIP(g, hipSetDevice(g->R[i].ctx->device)); MG_HIP(g, hipStreamWaitEvent(g->R[i].comm_stream, g->R[i].ev_ready, 0));
+                PSACX_TRY(ex_begin(g->R[i]));
+            }
+            MG_NCCL(g, nc.GroupStart());
+            ncclResult_t bad = ncclSuccess;
+            for (int i = 0; i < L && bad == ncclSuccess; ++i) {
+                MRank& R = g->R[i];
+                for (int a = 0; a < na && bad == ncclSuccess; ++a) {
+                    for (const Msg& m : sends[i]) {
+                        if (!m.cnt || (m.peer == R.grank && !g->force_wire)) continue;
+                        bad = nc.Send(static_cast<const char*>(in[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], ncclUint8, m.peer, R.comm, R.comm_stream);
+                        if (m.peer != R.grank) g->bytes_sent += m.cnt * esz[a];
+                        g->wire_sends++;
+                        if (bad != ncclSuccess) break;
+                    }
+                    for (const Msg& m : recvs[i]) {
+                        if (bad != ncclSuccess) break;
+                        if (!m.cnt || (m.peer == R.grank && !g->force_wire)) continue;
+                        bad = nc.Recv(static_cast<char*>(out[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], ncclUint8, m.peer, R.comm, R.comm_stream);
+                        g->wire_recvs++;
+                    }
+                }
+            }
+            const ncclResult_t end = nc.GroupEnd();
+            if (bad != ncclSuccess) { mg_set_err(g, std::string("ncclSend / ncclRecv: ") + nc.GetErrorString(bad)); return PSACX_MULTI_EPEER; }
+            MG_NCCL(g, end);
+            for (int i = 0; i < L; ++i) {
+                MRank& R = g->R[i];
+                MG_HIP(g, hipSetDevice(R.ctx->device));
+                if (!g->force_wire) {                      // messages to itself: the k-th send pairs with the k-th receive
+                    std::vector<const Msg*> ss, rr;
+                    for (const Msg& m : sends[i]) if (m.peer == R.grank && m.cnt) ss.push_back(&m);
+                    for (const Msg& m : recvs[i]) if (m.peer == R.grank && m.cnt) rr.push_back(&m);
+                    if (ss.size() != rr.size()) { mg_set_err(g, "transfer: a rank's messages to itself do not pair up"); return PSACX_EINVAL; }
+                    for (size_t q = 0; q < ss.size(); ++q)
+                        for (int a = 0; a < na; ++a)
+                            MG_HIP(g, hipMemcpyAsync(static_cast<char*>(out[i][a]) + rr[q]->off * esz[a], static_cast<const char*>(in[i][a]) + ss[q]->off * esz[a],
+                                                     (size_t)ss[q]->cnt * esz[a], hipMemcpyDeviceToDevice, R.comm_stream));
+                }
+                PSACX_TRY(finish(i));
+            }
+        } else if (g->transport == PSACX_TR_SHM) {
+            // every rank publishes its list of (destination, count); a rank's stream of an array is its messages back to back
+            ShmLink& sh = g->shm;
+            MRank& R = g->R[0];
+            const int me = R.grank;
+            MG_HIP(g, hipSetDevice(R.ctx->device));
+            MG_HIP(g, hipStreamWaitEvent(R.comm_stream, R.ev_ready, 0));
+            PSACX_TRY(ex_begin(R));
+            std::string e;
+            if ((sends[0].size() * 2 + 1) * 8 > sh.slot_bytes) { mg_set_err(g, "transfer: message list too long for the shared-memory slot"); return PSACX_EINVAL; }
+            {
+                uint64_t* sl = reinterpret_cast<uint64_t*>(sh.slot(me));
+                sl[0] = sends[0].size();
+                for (size_t q = 0; q < sends[0].size(); ++q) { sl[1 + 2 * q] = (uint64_t)sends[0][q].peer; sl[2 + 2 * q] = sends[0][q].cnt; }
+            }
+            if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+            // for every source: the stream offsets (elements) of its messages to me, in order
+            std::vector<std::vector<std::pair<uint64_t, uint64_t>>> from(P);
+            std::vector<uint64_t> slen(P, 0);
+            for (int s = 0; s < P; ++s) {
+                const uint64_t* sl = reinterpret_cast<const uint64_t*>(sh.slot(s));
+                uint64_t at = 0;
+                for (uint64_t q = 0; q < sl[0]; ++q) { if ((int)sl[1 + 2 * q] == me) from[s].emplace_back(at, sl[2 + 2 * q]); at += sl[2 + 2 * q]; }
+                slen[s] = at;
+            }
+            if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+            // my receives from s, in order, take those pieces
+            std::vector<std::vector<const Msg*>> mine_from(P);
+            for (const Msg& m : recvs[0]) mine_from[m.peer].push_back(&m);
+            for (int s = 0; s < P; ++s) {
+                if (mine_from[s].size() != from[s].size()) { mg_set_err(g, "transfer: send and receive lists of a pair of ranks differ in length"); return PSACX_EINVAL; }
+                for (size_t q = 0; q < from[s].size(); ++q) if (mine_from[s][q]->cnt != from[s][q].second) { mg_set_err(g, "transfer: send and receive counts differ"); return PSACX_EINVAL; }
+            }
+            uint64_t longest = 0;
+            for (int s = 0; s < P; ++s) longest = std::max(longest, slen[s]);
+            for (int a = 0; a < na; ++a) {
+                const uint64_t per = std::max<uint64_t>(sh.box_bytes / esz[a], 1);
+                for (uint64_t w0 = 0; w0 < longest; w0 += per) {
+                    const uint64_t w1 = w0 + per;
+                    // my stream: messages back to back (their places in the source array are arbitrary)
+                    {
+                        uint64_t at = 0;
+                        for (const Msg& m : sends[0]) {
+                            const uint64_t lo = std::max(w0, at), hi = std::min(w1, at + m.cnt);
+                            if (lo < hi) MG_HIP(g, hipMemcpyAsync(sh.box(me) + (size_t)(lo - w0) * esz[a], static_cast<const char*>(in[0][a]) + (m.off + (lo - at)) * esz[a],
+                                                                  (size_t)(hi - lo) * esz[a], hipMemcpyDeviceToHost, R.comm_stream));
+                            at += m.cnt;
+                        }
+                        MG_HIP(g, hipStreamSynchronize(R.comm_stream));
+                    }
+                    if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                    for (int s = 0; s < P; ++s)
+                        for (size_t q = 0; q < from[s].size(); ++q) {
+                            const uint64_t a0 = from[s][q].first, lo = std::max(w0, a0), hi = std::min(w1, a0 + from[s][q].second);
+                            if (lo >= hi) continue;
+                            MG_HIP(g, hipMemcpyAsync(static_cast<char*>(out[0][a]) + (mine_from[s][q]->off + (lo - a0)) * esz[a], sh.box(s) + (size_t)(lo - w0) * esz[a],
+                                                     (size_t)(hi - lo) * esz[a], hipMemcpyHostToDevice, R.comm_stream));
+                            if (s != me) g->bytes_sent += (hi - lo) * esz[a];
+                        }
+                    MG_HIP(g, hipStreamSynchronize(R.comm_stream));
+                    if (!sh.barrier(e)) { mg_set_err(g, e); return PSACX_MULTI_EPEER; }
+                }
+            }
+            PSACX_TRY(finish(0));
+        } else {
+            if (L != P) { mg_set_err(g, "transfer without a transport between the processes"); return PSACX_EINVAL; }
+            // per sender and destination: its messages in order
+            std::vector<std::vector<std::vector<const Msg*>>> to(L, std::vector<std::vector<const Msg*>>(P));
+            for (int s = 0; s < L; ++s) for (const Msg& m : sends[s]) to[s][m.peer].push_back(&m);
+            for (int i = 0; i < L; ++i) {
+                MRank& R = g->R[i];
+                MG_HIP(g, hipSetDevice(R.ctx->device));
+                for (int s = 0; s < L; ++s) MG_HIP(g, hipStreamWaitEvent(R.comm_stream, g->R[s].ev_ready, 0));
+                PSACX_TRY(ex_begin(R));
+                std::vector<size_t> taken(L, 0);
+                for (const Msg& m : recvs[i]) {
+                    int ls = -1;
+                    for (int s = 0; s < L; ++s) if (rank(s) == m.peer) ls = s;
+                    if (ls < 0 || taken[ls] >= to[ls][R.grank].size() || to[ls][R.grank][taken[ls]]->cnt != m.cnt) { mg_set_err(g, "transfer: send and receive lists do not match"); return PSACX_EINVAL; }
+                    const Msg* sm = to[ls][R.grank][taken[ls]++];
+                    if (!m.cnt) continue;
+                    for (int a = 0; a < na; ++a)
+                        MG_HIP(g, hipMemcpyAsync(static_cast<char*>(out[i][a]) + m.off * esz[a], static_cast<const char*>(in[ls][a]) + sm->off * esz[a], (size_t)m.cnt * esz[a],
+                                                 hipMemcpyDefault, R.comm_stream));
+                    if (ls != i) for (int a = 0; a < na; ++a) g->bytes_sent += m.cnt * esz[a];
+                }
+                PSACX_TRY(ex_end(R));
+                MG_HIP(g, hipEventRecord(done ? (*done)[i] : R.ev_done, R.comm_stream));
+            }
+            if (!done)       // a sender may not release or overwrite its arrays before every receiver has pulled its piece
+                for (int i = 0; i < L; ++i) {
+                    MG_HIP(g, hipSetDevice(g->R[i].ctx->device));
+                    for (int s = 0; s < L; ++s) MG_HIP(g, hipStreamWaitEvent(g->R[i].ctx->stream, g->R[s].ev_done, 0));
+                }
+        }
+        return PSACX_OK;
+    }
+
     // ---------------------------------------------------------------- small helpers
     int fetch(int i, const T* a, const std::vector<uint64_t>& idx, std::vector<uint64_t>& out) {
         out.assign(idx.size(), 0);
@@ -1034,7 +1210,7 @@ struct MultiRun {
     // the three-word path.
     static constexpr int PSACX_RETRY_ = 1;
     int sort_first_two_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1,
-                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust) {
+                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec_front) {
         ++sort_calls_;
         constexpr int SAMPLES = 8192;
         std::vector<uint64_t> spl;
@@ -1079,79 +1255,156 @@ struct MultiRun {
                 for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
             }
         }
+        const bool v32 = sizeof(T) == 8 && n <= (1ull << 32);       // the suffixes travel and are sorted as 32-bit entries
+        const size_t vb = v32 ? 4 : sizeof(T);
+        // record j of local rank i stands for suffix: the spec short suffixes first on rank 0 (n - 1 - j), then the block in order
+        auto payload_of = [&](int i, uint64_t a, uint64_t* spec_q, uint64_t* specn_q, uint64_t* voff_q) {
+            const uint64_t front = rank(i) == 0 ? spec_front : 0;
+            if (a == 0 && front) { *spec_q = front; *specn_q = n; *voff_q = 0; }          // (rank 0's block starts at position 0)
+            else { *spec_q = 0; *specn_q = 0; *voff_q = S[i].off + a - front; }
+        };
         if (!solo_) {
             const uint32_t ns = (uint32_t)spl.size();
             Splitters sp; std::memset(&sp, 0, sizeof(sp));
             sp.n = ns;
-            for (uint32_t s = 0; s < ns; ++s) sp.k1[s] = spl[s];
-            std::vector<Rec<T>> grp(L);
-            std::vector<std::vector<uint64_t>> bounds(L), rc;
-            std::vector<std::vector<const T*>> in(L);
+            for (uint32_t s2 = 0; s2 < ns; ++s2) sp.k1[s2] = spl[s2];
+            // The shuffle in Q pieces: piece q + 1 is partitioned by destination on the compute stream while piece q travels on
+            // the second stream (idxsort.hpp:58-62 hands the whole tuple array to MPI_Alltoallv at once).
+            int Q = 4;
+            if (const char* e = getenv("PSACX_MULTI_PIECES")) Q = std::max(1, std::min(16, atoi(e)));
+            constexpr uint64_t SPAN = 256 * 32;
+            std::vector<uint64_t> piece(L);
+            std::vector<std::vector<uint64_t>> cnt_q(L, std::vector<uint64_t>((size_t)Q * P, 0));
+            std::vector<DBuf<uint8_t>> cls(L);
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const uint64_t cn = rec[i].cnt;
-                PSACX_TRY(take3(i, grp[i], cn));
-                bounds[i].assign(P + 1, cn);
-                bounds[i][0] = 0;
+                piece[i] = std::max<uint64_t>(SPAN, ((cn + Q - 1) / Q + SPAN - 1) / SPAN * SPAN);
+                MG_OP(g, c, cls[i].alloc(c, cn + 16));
+                DBuf<unsigned long long> d_counts; MG_OP(g, c, d_counts.alloc(c, (size_t)Q * 64));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(d_counts.p, 0, (size_t)Q * 64 * 8, c->stream));
                 if (cn) {
-                    MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-                    SortScratch sc; T* cls = nullptr;
-                    auto layout = [&](Arena& a) {
-                        cls = a.take<T>(cn);
-                        sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
-                        sc.desc_bytes = sort_desc_bytes(cn);
-                        sc.d_desc = a.take<char>(sc.desc_bytes);
-                    };
+                    const uint64_t per_piece = (piece[i] + SPAN - 1) / SPAN, nq = (cn + piece[i] - 1) / piece[i];
+                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3((unsigned)(per_piece * nq)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, cn, lo1, sp, cls[i].p,
+                                       piece[i], d_counts.p);
+                    MG_HIP(g, hipGetLastError());
+                }
+                MG_OP(g, c, ensure_pinned(c, (size_t)Q * 64 * 8 + 65536 + 32768));
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d_counts.p, (size_t)Q * 64 * 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                const unsigned long long* h = reinterpret_cast<const unsigned long long*>(c->pinned + 32768);
+                for (int q = 0; q < Q; ++q) for (int d = 0; d < P; ++d) cnt_q[i][(size_t)q * P + d] = h[(size_t)q * 64 + d];
+                return PSACX_OK;
+            }));
+            std::vector<uint64_t> table;                       // table[(r * Q + q) * P + d]
+            PSACX_TRY(gather(Q * P, cnt_q, table));
+            // receive arrays: a whole record set (the third array becomes word 2 of the tied records later)
+            std::vector<Rec<T>> grp(L), rcv(L);
+            std::vector<std::vector<uint64_t>> roff(L);
+            int rc_alloc = PSACX_OK;
+            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
+                roff[i].assign(P + 1, 0);
+                for (int r = 0; r < P; ++r) { uint64_t t = 0; for (int q = 0; q < Q; ++q) t += table[((size_t)r * Q + q) * P + rank(i)]; roff[i][r + 1] = roff[i][r] + t; }
+                rc_alloc = take3(i, grp[i], rec[i].cnt, false);
+            }
+            PSACX_TRY(agree(rc_alloc));
+            std::vector<std::vector<hipEvent_t>> done(Q, std::vector<hipEvent_t>(L, nullptr));
+            auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
+            for (int q = 0; q < Q; ++q) for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming)); }
+            // (the receive arrays come after the senders' second record set exists: in the reduced-memory layout a rank's records
+            //  sit in its output arrays, the partitioned copy in its one allocated set, and the received records need a third
+            //  place -- taken from the cache like any other array)
+            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, rcv[i], roff[i][P], false);
+            PSACX_TRY(agree(rc_alloc));
+            int rc = PSACX_OK;
+            for (int q = 0; q < Q && rc == PSACX_OK; ++q) {
+                rc = par([&](int i) -> int {
+                    psacx_ctx* c = ctx(i);
+                    const uint64_t cn = rec[i].cnt, a = std::min<uint64_t>((uint64_t)q * piece[i], cn), b = std::min<uint64_t>(a + piece[i], cn);
+                    if (b <= a) return PSACX_OK;
+                    SortScratch sc;
+                    auto layout = [&](Arena& ar) { sc.d_base = ar.take<unsigned long long>((size_t)RADIX); sc.desc_bytes = sort_desc_bytes(b - a); sc.d_desc = ar.take<char>(sc.desc_bytes); };
                     { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
                     Arena ar(c->slab);
                     layout(ar);
+                    uint64_t sq, snq, vq;
+                    payload_of(i, a, &sq, &snq, &vq);
                     MG_HIP(g, hipSetDevice(c->device));
-                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3(grid_for(c, cn, 256, 16)), dim3(256), 0, c->stream, rec[i].k1.p, cn, lo1, sp, cls);
-                    MG_HIP(g, hipGetLastError());
-                    SortBufs<T> si{rec[i].k1.p, nullptr, rec[i].v.p}, so{grp[i].k1.p, nullptr, grp[i].v.p};
-                    unsigned long long* starts = reinterpret_cast<unsigned long long*>(c->pinned + 1024);
-                    MG_OP(g, c, class_partition<T>(c, sc, si, so, cls, cn, starts));
-                    for (uint32_t d = 0; d <= ns; ++d) bounds[i][d] = starts[d];
+                    MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p + a, cls[i].p + a, b - a, grp[i].k1.p + a,
+                                                  reinterpret_cast<char*>(grp[i].v.p) + a * vb, v32, sq, snq, vq));
+                    return PSACX_OK;
+                });
+                if (rc != PSACX_OK) break;
+                std::vector<std::vector<Msg>> sends(L), recvs(L);
+                std::vector<std::vector<const void*>> in(L);
+                std::vector<std::vector<void*>> out(L);
+                for (int i = 0; i < L; ++i) {
+                    const int me = rank(i);
+                    uint64_t at = std::min<uint64_t>((uint64_t)q * piece[i], rec[i].cnt);
+                    for (int d = 0; d < P; ++d) { const uint64_t cn = cnt_q[i][(size_t)q * P + d]; sends[i].push_back(Msg{d, at, cn}); at += cn; }
+                    for (int r = 0; r < P; ++r) {
+                        uint64_t before = 0;
+                        for (int q2 = 0; q2 < q; ++q2) before += table[((size_t)r * Q + q2) * P + me];
+                        recvs[i].push_back(Msg{r, roff[i][r] + before, table[((size_t)r * Q + q) * P + me]});
+                    }
+                    in[i] = {grp[i].k1.p, grp[i].v.p};
+                    out[i] = {rcv[i].k1.p, rcv[i].v.p};
                 }
-                drop3(i, rec[i]);
-                in[i] = {grp[i].k1.p, grp[i].v.p};
-                return PSACX_OK;
-            }));
-            mark("    sort: samples + partition");
-            // the receive arrays are a whole record set (the third array becomes word 2 of the tied records later)
-            std::vector<DBuf<T>> spare(L);
-            std::vector<std::vector<DBuf<T>>> got;
-            const std::function<int(int, uint64_t, std::vector<DBuf<T>>&)> recv2 = [this, &spare](int i, uint64_t tot, std::vector<DBuf<T>>& o) -> int {
-                Rec<T> r;
-                PSACX_TRY(take3(i, r, tot));
-                o.clear(); o.resize(2);
-                o[0] = std::move(r.k1); o[1] = std::move(r.v); spare[i] = std::move(r.k2);
-                return PSACX_OK;
-            };
-            PSACX_TRY(exchange<T>(2, in, bounds, got, rc, recv2));
-            mark("    sort: shuffle");
+                rc = transfer(in, out, {sizeof(T), vb}, sends, recvs, &done[q]);
+            }
+            // everything has arrived (and, with ranks in one process, has been pulled) before the sorted copies go away
+            for (int i = 0; i < L; ++i) {
+                (void)hipSetDevice(ctx(i)->device);
+                for (int q = 0; q < Q; ++q) for (int s2 = 0; s2 < L; ++s2) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
+            }
+            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
+            drop_events();
+            if (rc != PSACX_OK) return rc;
+            mark("    sort: partition + shuffle");
             for (int i = 0; i < L; ++i) {
                 drop3(i, grp[i]);
-                rec[i].k1 = std::move(got[i][0]); rec[i].v = std::move(got[i][1]); rec[i].k2 = std::move(spare[i]);
-                rec[i].cnt = rec[i].k1.n;
+                drop3(i, rec[i]);
+                rec[i] = std::move(rcv[i]);
+                rec[i].cnt = roff[i][P];
             }
         }
         // prefix sort of (word 1, suffix) on the leading bits, then the ties
         std::vector<uint64_t> ties(L, 0);
+        bool general_ties = !solo_;
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
-            if (rec[i].cnt >= 2) {
+            if (rec[i].cnt >= 1) {
                 Rec<T> alt;
-                PSACX_TRY(take3(i, alt, rec[i].cnt));
+                PSACX_TRY(take3(i, alt, rec[i].cnt, false));
                 int32_t where = 0;
-                MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1));
+                if (solo_) {
+                    // the first pass makes up the payload (the suffix a record stands for), as on one GPU
+                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n));
+                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32));
                 if (where) swap3(rec[i], alt);
                 drop3(i, alt);
             }
-            MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &ties[i]));
+            PSACX_TRY(need_k2(i, rec[i]));
+            if (solo_ && rec[i].cnt) {
+                // one rank: the text is here, every tie group of at most 8 suffixes is ordered in place (tie_resolve_kernel, construct.hpp)
+                constexpr int TB = 256, TI = sizeof(T) == 8 ? 32 : 16, TG = 8;
+                DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
+                const uint64_t nb = (rec[i].cnt + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
+                hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, rec[i].k1.p, rec[i].v.p, rec[i].k2.p, rec[i].cnt, lo1,
+                                   (const uint8_t*)tbuf[i].p, S[i].m + two_k, tab, ks, big.p);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) general_ties = true;
+            }
+            if (general_ties) MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &ties[i]));
             return PSACX_OK;
         }));
         mark("    sort: local prefix sort");
+        if (!general_ties) { mark("    sort: ties"); return rebalance(rec, targets); }
         std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
@@ -1287,6 +1540,209 @@ struct MultiRun {
             return PSACX_OK;
         }));
         return PSACX_OK;
+    }
+
+    // ISA[SA[j]] = Bsa[j] - 1 for the full permutation of the first round (bulk_permute_inplace, bulk_permute.hpp:14-73),
+    // slice by slice: see slice_inv.hpp.  Needs blocks of at most 2^32 positions (32-bit block-relative keys).
+    // V: type the ranks travel in (32 bits while the whole text has at most 2^32 characters).
+    template <typename V>
+    int isa_by_slices_t() {
+        constexpr unsigned WBMAX = sizeof(V) == 4 ? 14 : 13;
+        constexpr int PB = 512, PI = 16, TILE_BITS = 13;
+        uint64_t max_m = 0;
+        for (int r = 0; r < P; ++r) max_m = std::max(max_m, sizes[r]);
+        const unsigned kb = bits_for(max_m > 1 ? max_m - 1 : 1);
+        unsigned cap_bits = 0;
+        while ((2u << cap_bits) * (unsigned)P <= (unsigned)SLICE_MAX_CLASSES) ++cap_bits;        // most slice bits with P * 2^bits classes
+        unsigned wbmax = WBMAX;
+        if (const char* e = getenv("PSACX_SLICE_WB")) wbmax = std::min<unsigned>(WBMAX, std::max(4, atoi(e)));     // (tests: levels on small inputs)
+        if (const char* e = getenv("PSACX_SLICE_S1")) cap_bits = std::min<unsigned>(cap_bits, (unsigned)atoi(e));
+        unsigned s1 = std::min<unsigned>(cap_bits, kb > wbmax ? kb - wbmax : 0);
+        // a further level walks tiles of 2^13 pairs that must not straddle slices
+        if (kb - s1 > wbmax && kb - s1 < (unsigned)TILE_BITS) s1 = kb > (unsigned)TILE_BITS ? kb - TILE_BITS : 0;
+        const unsigned sb = kb - s1;
+        const unsigned spo = (unsigned)((max_m + (1ull << sb) - 1) >> sb);
+        const unsigned wb = std::min(sb, wbmax);
+        const unsigned rbits = sb - wb;
+        // levels of at most 9 bits each; a level's parent buckets (2^(shift + cb) pairs) must hold whole tiles, which only
+        // binds the last level when a test shrinks the windows below a tile
+        std::vector<unsigned> cbs;
+        if (rbits) {
+            const unsigned last_min = wb >= (unsigned)TILE_BITS ? 1u : std::min(rbits, (unsigned)TILE_BITS - wb);
+            unsigned nl = (rbits + 8) / 9;
+            cbs.assign(nl, 0);
+            for (unsigned j = 0; j < nl; ++j) cbs[j] = rbits / nl + (j < rbits % nl ? 1 : 0);
+            if (cbs.back() < last_min) {
+                const unsigned rest = rbits - last_min;
+                nl = 1 + (rest + 8) / 9;
+                cbs.assign(nl, 0);
+                for (unsigned j = 0; j + 1 < nl; ++j) cbs[j] = rest / (nl - 1) + (j < rest % (nl - 1) ? 1 : 0);
+                cbs.back() = last_min;
+            }
+        }
+        const unsigned levels2 = (unsigned)cbs.size();
+        const unsigned C = (unsigned)P * spo;
+        SliceMap map;
+        map.div = n / P; map.mod = n % P; map.P = (unsigned)P; map.sb = sb; map.spo = spo; map.dshift = -1;
+        if (map.mod == 0 && map.div && (map.div & (map.div - 1)) == 0) { map.dshift = 0; while ((1ull << map.dshift) < map.div) ++map.dshift; }
+        const uint64_t slice = 1ull << sb;
+
+        // 1. pairs per class on every rank; every rank learns the whole table
+        std::vector<std::vector<uint64_t>> counts(L, std::vector<uint64_t>(C, 0));
+        std::vector<DBuf<unsigned long long>> d_cnt(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, d_cnt[i].alloc(c, SLICE_MAX_CLASSES));
+            MG_HIP(g, hipSetDevice(c->device));
+            MG_HIP(g, hipMemsetAsync(d_cnt[i].p, 0, SLICE_MAX_CLASSES * 8, c->stream));
+            if (S[i].m) {
+                hipLaunchKernelGGL((slice_hist_kernel<T>), dim3(grid_for(c, S[i].m, 512, 8)), dim3(512), 0, c->stream, (const T*)S[i].SA, S[i].m, map, d_cnt[i].p);
+                MG_HIP(g, hipGetLastError());
+            }
+            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d_cnt[i].p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            std::memcpy(counts[i].data(), c->pinned + 32768, (size_t)C * 8);
+            return PSACX_OK;
+        }));
+        std::vector<uint64_t> table;
+        PSACX_TRY(gather((int)C, counts, table));
+        auto slice_len = [&](int owner, unsigned sl) -> uint64_t { const uint64_t lo = (uint64_t)sl << sb; return sizes[owner] > lo ? std::min(slice, sizes[owner] - lo) : 0; };
+        for (int o = 0; o < P; ++o)
+            for (unsigned sl = 0; sl < spo; ++sl) {
+                uint64_t tot = 0;
+                for (int r = 0; r < P; ++r) tot += table[(size_t)r * C + o * spo + sl];
+                if (tot != slice_len(o, sl)) { mg_set_err(g, "SA -> ISA: the suffix array is not a permutation (a destination slice receives the wrong number of entries)"); return PSACX_EDEVICE; }
+            }
+        // 2. first level on every rank.  All arrays of this routine are cut from a few byte blocks; in the reduced-memory layout
+        //    the blocks have the one size every record array of the first round had, so the rank's cache serves them (a miss
+        //    there means hipFree + hipMalloc of tens of GB: about a second each)
+        //    (normal layout: every array its own block of the usual array size, which the cache holds from the sort)
+        struct Cut {
+            DBuf<uint8_t> b; size_t used = 0, cap = 0;
+            void* take(size_t bytes) { used = (used + 255) & ~(size_t)255; void* q = b.p + used; used += bytes; return q; }
+        };
+        struct Ptrs { uint32_t* k; V* v; };
+        std::vector<std::vector<Cut>> blocks(L);
+        std::vector<Ptrs> pk_(L), A0(L), A1(L), Bb(L);
+        std::vector<unsigned*> cur(L, nullptr);
+        uint64_t G = spo;
+        if (diet && !solo_) G = std::max<uint64_t>(1, std::max<uint64_t>(slice, max_m / 8) >> sb);
+        if (const char* e = getenv("PSACX_SLICE_STEP")) G = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        G = std::min<uint64_t>(G, spo);
+        const uint64_t nsteps = (spo + G - 1) / G;
+        const uint64_t step_cap = G << sb;
+        std::vector<std::vector<uint64_t>> cstart(L);
+        const int rc_part = par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            const uint64_t m = S[i].m;
+            cstart[i] = prefix_of(counts[i]);
+            const size_t std_bytes = diet ? (size_t)(m + m / 8 + 256) * sizeof(T) : (size_t)m * sizeof(T);
+            int rc_a = PSACX_OK;
+            auto arr = [&](size_t bytes) -> void* {
+                auto& v = blocks[i];
+                bytes += 256;
+                if (diet && !v.empty() && ((v.back().used + 255) & ~(size_t)255) + bytes <= v.back().cap) return v.back().take(bytes);
+                v.emplace_back();
+                Cut& ct = v.back();
+                const size_t res = bytes <= std_bytes ? std_bytes : 0;
+                rc_a = ct.b.alloc(c, bytes, res);
+                if (rc_a != PSACX_OK) { mg_set_err(g, "SA -> ISA arrays: " + c->hip_err); return nullptr; }
+                ct.cap = std::max(bytes, res); ct.used = 0;
+                return ct.take(bytes);
+            };
+            auto pair = [&](Ptrs& q, uint64_t cnt) { q.k = (uint32_t*)arr((size_t)cnt * 4); q.v = rc_a == PSACX_OK ? (V*)arr((size_t)cnt * sizeof(V)) : nullptr; };
+            pair(pk_[i], m);
+            const uint64_t cap = std::min<uint64_t>(step_cap, std::max<uint64_t>(m, 1));
+            if (rc_a == PSACX_OK && !solo_) pair(A0[i], cap);
+            if (rc_a == PSACX_OK && !solo_ && nsteps > 1) pair(A1[i], cap);
+            if (rc_a == PSACX_OK && levels2) { pair(Bb[i], cap); if (rc_a == PSACX_OK) cur[i] = (unsigned*)arr(((cap >> wb) + 2) * sizeof(unsigned)); }
+            if (rc_a != PSACX_OK) return rc_a;
+            if (!m) return PSACX_OK;
+            MG_HIP(g, hipSetDevice(c->device));
+            std::memset(c->pinned + 32768, 0, SLICE_MAX_CLASSES * 8);
+            std::memcpy(c->pinned + 32768, cstart[i].data(), (size_t)C * 8);
+            MG_HIP(g, hipMemcpyAsync(d_cnt[i].p, c->pinned + 32768, SLICE_MAX_CLASSES * 8, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL((slice_partition_kernel<T, V, PB, PI>), dim3((unsigned)((m + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
+                               (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, pk_[i].k, pk_[i].v);
+            MG_HIP(g, hipGetLastError());
+            MG_HIP(g, hipStreamSynchronize(c->stream));       // (the pinned words are reused)
+            return PSACX_OK;
+        });
+        PSACX_TRY(agree(rc_part));      // (a rank without its arrays must not leave its peers in the transfers below)
+        mark("    ISA: classes");
+        // 3. slices to their owners, G per step; the remaining levels + the window scatter on the owner
+        std::vector<hipEvent_t> done[2];
+        done[0].assign(L, nullptr); done[1].assign(L, nullptr);
+        auto drop_events = [&]() { for (int q = 0; q < 2; ++q) for (int i = 0; i < L; ++i) if (done[q][i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(done[q][i]); done[q][i] = nullptr; } };
+        for (int i = 0; i < L; ++i) {
+            MG_HIP(g, hipSetDevice(ctx(i)->device));
+            for (int q = 0; q < 2; ++q) MG_HIP(g, hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming));
+        }
+        auto issue = [&](uint64_t t) -> int {
+            const unsigned s0 = (unsigned)(t * G), s1e = (unsigned)std::min<uint64_t>(spo, (t + 1) * G);
+            std::vector<std::vector<Msg>> sends(L), recvs(L);
+            std::vector<std::vector<const void*>> in(L);
+            std::vector<std::vector<void*>> out(L);
+            for (int i = 0; i < L; ++i) {
+                const int me = rank(i);
+                for (int d = 0; d < P; ++d)
+                    for (unsigned sl = s0; sl < s1e; ++sl) { const unsigned cl = (unsigned)d * spo + sl; sends[i].push_back(Msg{d, cstart[i][cl], counts[i][cl]}); }
+                for (unsigned sl = s0; sl < s1e; ++sl) {
+                    uint64_t at = (uint64_t)(sl - s0) << sb;
+                    for (int r = 0; r < P; ++r) { const uint64_t cn = table[(size_t)r * C + (unsigned)me * spo + sl]; recvs[i].push_back(Msg{r, at, cn}); at += cn; }
+                }
+                Ptrs& A = (t & 1) ? A1[i] : A0[i];
+                in[i] = {pk_[i].k, pk_[i].v};
+                out[i] = {A.k, A.v};
+            }
+            return transfer(in, out, {sizeof(uint32_t), sizeof(V)}, sends, recvs, &done[t & 1]);
+        };
+        int rc = PSACX_OK;
+        if (!solo_) rc = issue(0);
+        for (uint64_t t = 0; t < nsteps && rc == PSACX_OK; ++t) {
+            if (!solo_ && t + 1 < nsteps) rc = issue(t + 1);          // the next slices travel while these are worked on
+            if (rc != PSACX_OK) break;
+            rc = par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_HIP(g, hipSetDevice(c->device));
+                const uint64_t lo = (t * G) << sb;
+                const uint64_t len = S[i].m > lo ? std::min<uint64_t>(S[i].m - lo, step_cap) : 0;
+                if (!solo_) MG_HIP(g, hipStreamWaitEvent(c->stream, done[t & 1][i], 0));
+                if (!len) return PSACX_OK;
+                Ptrs& A = (t & 1) ? A1[i] : A0[i];
+                const uint32_t* ks = solo_ ? pk_[i].k : A.k; const V* vs = solo_ ? pk_[i].v : A.v;
+                uint32_t* ka = solo_ ? pk_[i].k : A.k; V* va = solo_ ? pk_[i].v : A.v;
+                unsigned below = rbits;                        // bits still to partition on beneath the current level
+                for (unsigned j = 0; j < levels2; ++j) {
+                    below -= cbs[j];
+                    const unsigned shift = wb + below;
+                    MG_HIP(g, hipMemsetAsync(cur[i], 0, ((len >> shift) + 2) * sizeof(unsigned), c->stream));
+                    uint32_t* ko = (j & 1) ? ka : Bb[i].k; V* vo = (j & 1) ? va : Bb[i].v;
+                    hipLaunchKernelGGL((pairs_partition_kernel<V, PB, PI>), dim3((unsigned)((len + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, ks, vs, ko, vo, len,
+                                       shift, cbs[j], cur[i], j == 0 ? (uint32_t)lo : 0u);
+                    MG_HIP(g, hipGetLastError());
+                    ks = ko; vs = vo;
+                }
+                hipLaunchKernelGGL((pairs_window_kernel<V, T, 1024, WBMAX>), dim3((unsigned)((len + (1ull << wb) - 1) >> wb)), dim3(1024), 0, c->stream, ks, vs, len, wb,
+                                   levels2 ? 0u : (uint32_t)lo, S[i].ISA + lo);
+                MG_HIP(g, hipGetLastError());
+                return PSACX_OK;
+            });
+        }
+        // nobody releases its classes before every receiver has pulled its pieces
+        for (int i = 0; i < L; ++i) {
+            (void)hipSetDevice(ctx(i)->device);
+            for (int q = 0; q < 2 && !solo_; ++q) for (int s2 = 0; s2 < L; ++s2) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
+        }
+        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
+        drop_events();
+        if (rc != PSACX_OK) return rc;
+        g->last_slice_inversion = true;
+        return PSACX_OK;
+    }
+    int isa_by_slices() {
+        if (sizeof(T) == 4 || n <= (1ull << 32)) return isa_by_slices_t<uint32_t>();
+        return isa_by_slices_t<T>();
     }
 
     // out[i][j] = block_owner[gidx[i][j] - off_owner] in the order of gidx (bulk_rma.hpp:13-135); positions >= n are clamped
@@ -1718,21 +2174,21 @@ struct MultiRun {
         auto make_records = [&](bool both) -> int {
             std::vector<Rec<T>> tails(L);
             std::vector<uint64_t> mine_cnt(L);
-            const int na = both ? 3 : 2;
+            const int na = both ? 3 : 1;
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
                 drop3(i, rec[i]);
-                PSACX_TRY(take3(i, rec[i], front + m));
+                PSACX_TRY(take3(i, rec[i], front + m, both));
                 MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, both ? rec[i].k2.p + front : (T*)nullptr));
-                MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));
+                if (both) MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));       // (two-word form: the shuffle or the sort makes the suffixes up)
                 const uint64_t end = S[i].off + m, first_short = n - spec;
                 const uint64_t mine = std::min<uint64_t>(m, end > first_short ? end - first_short : 0);     // short suffixes in this block (its tail)
                 mine_cnt[i] = mine;
                 tails[i].cnt = mine;
                 MG_OP(g, c, tails[i].k1.alloc(c, mine)); MG_OP(g, c, tails[i].k2.alloc(c, mine)); MG_OP(g, c, tails[i].v.alloc(c, mine));
                 if (mine) {
-                    const T* src[3] = {rec[i].k1.p, rec[i].v.p, rec[i].k2.p}; T* dst[3] = {tails[i].k1.p, tails[i].v.p, tails[i].k2.p};
+                    const T* src[3] = {rec[i].k1.p, rec[i].v.p, both ? rec[i].k2.p : (T*)nullptr}; T* dst[3] = {tails[i].k1.p, tails[i].v.p, tails[i].k2.p};
                     for (int q = 0; q < na; ++q) {
                         hipLaunchKernelGGL((reverse_copy_kernel<T>), dim3((unsigned)((mine + 255) / 256)), dim3(256), 0, c->stream, src[q] + front + m - mine, mine, dst[q]);
                         MG_HIP(g, hipGetLastError());
@@ -1749,8 +2205,8 @@ struct MultiRun {
                 std::vector<std::vector<const T*>> in(L);
                 for (int i = 0; i < L; ++i) {
                     bounds[i].assign(P + 1, mine_cnt[i]); bounds[i][0] = 0;
-                    in[i] = {tails[i].k1.p, tails[i].v.p};
-                    if (both) in[i].push_back(tails[i].k2.p);
+                    in[i] = {tails[i].k1.p};
+                    if (both) { in[i].push_back(tails[i].v.p); in[i].push_back(tails[i].k2.p); }
                 }
                 PSACX_TRY(exchange<T>(na, in, bounds, got, rc));
             }
@@ -1792,7 +2248,7 @@ struct MultiRun {
         if (two_word) {
             CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
             KeyShape ks; ks.lc = lc; ks.c1 = c1; ks.c2 = c2; ks.spec = 0;
-            const int rc2 = sort_first_two_word(rec, sizes, bits_w1, bits_w2, bits_w1 - lead, tbuf, two_k, tab, ks, tw_mode == 2);
+            const int rc2 = sort_first_two_word(rec, sizes, bits_w1, bits_w2, bits_w1 - lead, tbuf, two_k, tab, ks, tw_mode == 2, spec);
             if (rc2 == PSACX_RETRY_) {
                 two_word = false;
                 PSACX_TRY(make_records(true));
@@ -1842,8 +2298,11 @@ struct MultiRun {
         }));
         first_round_ = false;
         mark("rebucket");
-        // ---- SA -> ISA (bulk_permute.hpp:14-73); in chunks of the block in the reduced-memory layout
-        {
+        // ---- SA -> ISA (bulk_permute.hpp:14-73): by destination slices (slice_inv.hpp); the earlier form (pairs routed by owner,
+        //      plain scatter in chunks of the block in the reduced-memory layout) with PSACX_MULTI_NO_SLICES=1 or blocks beyond 2^32
+        g->last_slice_inversion = false;
+        if (!getenv("PSACX_MULTI_NO_SLICES") && sizes[0] <= (1ull << 32)) PSACX_TRY(isa_by_slices());
+        else {
             uint64_t chunks = 1;
             if (diet) for (int r = 0; r < P; ++r) chunks = std::max<uint64_t>(chunks, (sizes[r] + slab_cap - 1) / slab_cap);
             chunks = std::min<uint64_t>(chunks, 64);

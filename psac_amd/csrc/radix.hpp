@@ -155,7 +155,9 @@ template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
 // VN (64-bit words, payloads below 2^32 -- the suffix indices of a text of at most 2^32 characters): 1 = the payload arrays
 // hold 32-bit entries on both sides, 2 = 32-bit entries in, full words out (the last pass of a sort).  The first round's
 // prefix sort then moves 12 instead of 16 bytes per record and pass.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0, int VN = 0>
+// CLSB (EXT only): bytes per entry of the class array dsrc (sizeof(T), or 1 for a byte array).
+// voff: added to the payload a pass makes up itself (v_in == nullptr): the records of a rank's block, or of a piece of it.
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0, int VN = 0, int CLSB = sizeof(T)>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE, MATCH>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
@@ -163,7 +165,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
-    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES) {
+    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     T* const stage = sh.stage;
@@ -195,10 +197,12 @@ __device__ __forceinline__ void radix_scatter_tile(
     const unsigned wbase = wave * (WAVE * ITEMS) + lane;
     if (EXT) {
         const T* __restrict__ pd = dsrc + base;
+        const unsigned char* __restrict__ pb = reinterpret_cast<const unsigned char*>(dsrc) + base;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const unsigned loc = wbase + i * WAVE;
-            cls[EXT ? i : 0] = (FULL || loc < count) ? (unsigned char)pd[loc] : (unsigned char)0;
+            if (CLSB == 1) cls[EXT ? i : 0] = (FULL || loc < count) ? pb[loc] : (unsigned char)0;
+            else cls[EXT ? i : 0] = (FULL || loc < count) ? (unsigned char)pd[loc] : (unsigned char)0;
         }
     }
 #pragma unroll
@@ -222,7 +226,7 @@ __device__ __forceinline__ void radix_scatter_tile(
         } else {
             // implicit payload: the record index, or the suffix the first-round record stands for
             const uint64_t g = base + loc;
-            vv[i] = (T)(spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g);
+            vv[i] = (T)((spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff);
         }
     }
 
@@ -397,15 +401,52 @@ __global__ void classify_kernel(const T* __restrict__ k1, const T* __restrict__ 
 // Destination of a two-word record (word 1, suffix) in a shuffle by the leading bits of word 1: the number of splitters
 // that do not exceed its prefix, so that records with equal prefixes never part (their order by the rest of the window is
 // decided on the receiving rank).
+// The classes leave as bytes; counts[q * 64 + d] += records of piece q (pieces of `piece` records; a workgroup never
+// straddles two) that go to destination d.
 template <typename T>
-__global__ void classify_prefix_kernel(const T* __restrict__ k1, uint64_t n, unsigned lo1, Splitters sp, T* __restrict__ cls) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+__global__ __launch_bounds__(256) void classify_prefix_kernel(const T* __restrict__ k1, uint64_t n, unsigned lo1, Splitters sp, uint8_t* __restrict__ cls,
+                                                              uint64_t piece, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned lh[64];
+    __shared__ unsigned long long skey[64];
+    if (threadIdx.x < 64) { lh[threadIdx.x] = 0; skey[threadIdx.x] = threadIdx.x < sp.n ? sp.k1[threadIdx.x] : ~0ull; }
+    __syncthreads();
+    // workgroup b works on [b * span, (b + 1) * span) of its piece
+    constexpr uint64_t SPAN = 256 * 32;
+    const uint64_t per_piece = (piece + SPAN - 1) / SPAN;
+    const uint64_t q = blockIdx.x / per_piece, b = blockIdx.x % per_piece;
+    const uint64_t lo_i = q * piece + b * SPAN;
+    uint64_t hi_i = lo_i + SPAN;
+    if (hi_i > (q + 1) * piece) hi_i = (q + 1) * piece;
+    if (hi_i > n) hi_i = n;
+    const unsigned ns = sp.n;
+    for (uint64_t i = lo_i + threadIdx.x; i < hi_i; i += 256) {
         const unsigned long long a = (unsigned long long)k1[i] >> lo1;
-        unsigned lo = 0, hi = sp.n;                       // first splitter that exceeds the prefix
-        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (sp.k1[mid] > a) hi = mid; else lo = mid + 1; }
-        cls[i] = (T)lo;
+        unsigned lo = 0, hi = ns;                         // first splitter that exceeds the prefix
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (skey[mid] > a) hi = mid; else lo = mid + 1; }
+        cls[i] = (uint8_t)lo;
+        atomicAdd(&lh[lo], 1u);
     }
+    __syncthreads();
+    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&counts[q * 64 + threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+// per-tile class counts of a byte class array (the tile shape of the scatter pass that follows)
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void class_tile_hist_kernel(const uint8_t* __restrict__ cls, uint64_t n, unsigned* __restrict__ tile_hist) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ unsigned lh[4][RADIX];
+    for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    unsigned* my = lh[(threadIdx.x / WAVE) & 3];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint64_t e = base + (uint64_t)i * BLOCK + threadIdx.x;
+        wave_hist_add(my, e < n ? (unsigned)cls[e] : 0u, e < n);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX; d += BLOCK)
+        tile_hist[(uint64_t)blockIdx.x * RADIX + d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
 // ---------------------------------------------------------------------------
@@ -484,21 +525,21 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0, int VN = 0>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0, int VN = 0, int CLSB = sizeof(T)>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
     uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr,
-    unsigned slab_tiles = SLAB_TILES) {
+    unsigned slab_tiles = SLAB_TILES, uint64_t voff = 0) {
     // (a persistent variant, one workgroup looping over tiles with its next ticket prefetched, was
     // measured: the loop raised the register count from 118 to 173 and lost 20 %)
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
     static_assert(!(MATCH && EXT), "the lane-mask table form takes its digit from the key word");
-    static_assert(VN == 0 || (sizeof(T) == 8 && NOKO && !EXT), "narrow payloads exist for two-word records of 64-bit words");
+    static_assert(VN == 0 || (sizeof(T) == 8 && NOKO), "narrow payloads exist for two-word records of 64-bit words");
     __shared__ ScatterShared<T, TILE, NW, MATCH> sh;
     // tiles are handed out in start order so that neighbouring runs of a digit are written
     // close in time (they share cache lines); nothing ever waits on another workgroup
@@ -509,13 +550,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH, VN>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
+                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH, VN>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles);
+                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff);
 }
 
 } // namespace psacx

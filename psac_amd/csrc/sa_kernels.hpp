@@ -1263,6 +1263,12 @@ __global__ void left_chars_kernel(const uint8_t* __restrict__ text, uint64_t n, 
 }
 
 template <typename T>
+__global__ void widen32_kernel(const uint32_t* __restrict__ in, uint64_t n, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (T)in[i];
+}
+
+template <typename T>
 __global__ void fill_kernel(T* __restrict__ a, uint64_t n, T v) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;

@@ -612,3 +612,24 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
             assert used >= (len(cases) - 1 if mode == "2" else 2), used      # (DNA on 32-bit words: word 1 is shorter than the leading bits)
         finally:
             mg.close()
+
+
+@pytest.mark.parametrize("P,wb,s1,step", [(1, 6, 9, 0), (2, 5, 2, 1), (3, 14, 9, 0), (7, 4, 1, 1), (4, 6, 3, 2)])
+def test_multi_isa_by_destination_slices(P, wb, s1, step, monkeypatch):
+    # SA -> ISA of the first round slice by slice (slice_inv.hpp): first level by (owner, slice) on the senders, the slices
+    # travel in steps (double-buffered), further reservation levels + the LDS window scatter on the owners.  Small windows
+    # and few slice bits force the deeper levels on test-sized inputs.
+    monkeypatch.setenv("PSACX_SLICE_WB", str(wb))
+    monkeypatch.setenv("PSACX_SLICE_S1", str(s1))
+    if step:
+        monkeypatch.setenv("PSACX_SLICE_STEP", str(step))
+    mg = multi(P)
+    try:
+        for text, bits in ((O.rand_dna(300007, 7), 64), (O.rand_dna(131072 * P, 9), 32), (inputs.tandem(90001, 256, O.rand_dna(256, 3)), 32),
+                           (inputs.ascii128(70000, 3), 64), (O.as_text("mississippi"), 64), (np.full(9001, 65, np.uint8), 32)):
+            SA, ISA, LCP, rounds = same(mg, text, bits)
+            ref = O.construct(text, bits=bits)
+            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, text.size)
+            assert mg.last_form()["slice_inversion"]
+    finally:
+        mg.close()
