@@ -1640,7 +1640,7 @@ struct MultiRun {
             int rc_a = PSACX_OK;
             auto arr = [&](size_t bytes) -> void* {
                 auto& v = blocks[i];
-                bytes += 256;
+                bytes = std::max<size_t>(bytes, 256);        // (exactly the usual array size when that is what an array needs: the cache holds such blocks)
                 if (diet && !v.empty() && ((v.back().used + 255) & ~(size_t)255) + bytes <= v.back().cap) return v.back().take(bytes);
                 v.emplace_back();
                 Cut& ct = v.back();
@@ -2092,7 +2092,7 @@ struct MultiRun {
                 //  device only when an allocation does not fit: pool_alloc)
                 for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = 0;
                 g->last_reduced = true;
-            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
+            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 16, (size_t)64 << 20);   // free blocks kept for reuse: at most sixteen block-sized arrays (a flush is hipFree + hipMalloc of everything: seconds with eight ranks)
             if (sizeof(T) == 4 && n > 0xFFFFFFFEull) return PSACX_ERANGE;
             uint32_t sigma = 0;
             for (int ch = 0; ch < 256; ++ch) sigma += hist[ch] != 0;
@@ -2562,7 +2562,7 @@ struct MultiRun {
                 //  device only when an allocation does not fit: pool_alloc)
                 for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = 0;
                 g->last_reduced = true;
-            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 6, (size_t)64 << 20);   // free blocks kept for reuse: at most six block-sized arrays
+            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 16, (size_t)64 << 20);   // free blocks kept for reuse: at most sixteen block-sized arrays (a flush is hipFree + hipMalloc of everything: seconds with eight ranks)
             if (sizeof(T) == 4 && n > 0xFFFFFFFDull) return PSACX_ERANGE;
         }
         std::vector<uint64_t> bm(L);

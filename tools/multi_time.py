@@ -30,6 +30,8 @@ for it in range(3):
     dt = time.perf_counter() - t0
 print("P=%d n=2^%s uint%d %s: %.2f ms per construction = %.1f MChars/s; rounds %d; %d exchanges, %d scalar gathers, %.2f GB moved between ranks"
       % (P, sys.argv[2], bits, kind, dt * 1e3, n / dt / 1e6, st.n_rounds, ex, ga, sent / 1e9))
+print("phases (host wall ms):", "; ".join("%s %.1f" % (k, v) for k, v in mg.phases()))
+print("exchange ms on the second streams:", mg.wire()["exchange_ms"], mg.last_form())
 err = mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
 print("distributed check errors:", err)
 mg.close()
