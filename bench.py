@@ -57,6 +57,10 @@ def parse():
                          "Metric 1); reported as the extra field construct_host, never as `value`.  auto: the full workload "
                          "when the host has the memory for its results, else 2^28 characters")
     ap.add_argument("--no-check", action="store_true", help="skip the device checker on the last result")
+    ap.add_argument("--side", default="auto", choices=("auto", "off"),
+                    help="after the timed region of the default workload also time BASELINE.json configs[2] (4 GiB ASCII, uint64), "
+                         "configs[1] (256 MiB DNA, uint32) and the three-word (B1,B2,idx) form of the scatter pass; reported as "
+                         "the extra field other_workloads, never as `value`")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.n is None and world == 1 and a.gpus == 1:
@@ -122,7 +126,10 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                                                          ("rank r holds block r of one splitmix64 stream, seed %d" % a.seed),
                                                          (world * n) >> 20, bits,
                                                          "ISA" if a.no_lcp else "ISA+LCP", world),
-                   "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism},
+                   "n_per_gpu": n, "k": k, "bits_per_char": l, "rounds": rounds, "parallelism": parallelism,
+                   "value_definition": "characters / construction time with the text resident in HBM and SA, ISA, LCP left in HBM; "
+                                       "SURVEY 8(d) Metric 1 (construct() on host pointers, PCIe copies included) is the field "
+                                       "construct_host, never `value`"},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -254,6 +261,59 @@ def main_distributed(a, rank, world, local_rank):
     dist.destroy_process_group()
 
 
+def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
+    """The other single-GPU configurations of BASELINE.json and the scatter form the north-star names literally, timed in
+    the same run AFTER the timed region (buffers of the default workload reused; the DNA text is restored at the end)."""
+    import ctypes as C
+    import psac_amd
+    lib = ctx._lib
+    res = {}
+
+    def run(tag, kind, n, bits, steps, env=None):
+        try:
+            old = {}
+            for k_, v_ in (env or {}).items():
+                old[k_] = os.environ.get(k_); os.environ[k_] = v_
+            ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID[kind], a.seed, 1024))
+            s_ = sa64 if bits == 64 else psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
+            s_.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+            ctx.check(lib.psacx_sync(ctx.handle))
+            t0 = time.perf_counter()
+            ms = [0.0, 0.0, 0.0]; by = [0, 0, 0]; la = [0, 0, 0]
+            for _ in range(steps):
+                st = s_.construct_device(d_text, n, d_sa, d_isa, d_lcp, profile=True)
+                ms[0] += st.ms_sort_scatter; ms[1] += st.ms_sort_scatter3; ms[2] += st.ms_sort_scatter2
+                for q in (0, 1, 2):
+                    by[q] += st.scatter_bytes[q]; la[q] += st.scatter_launches[q]
+            ctx.check(lib.psacx_sync(ctx.handle))
+            dt = (time.perf_counter() - t0) / steps
+            q = max((0, 1, 2), key=lambda j: by[j])
+            gbs = by[q] / (ms[q] * 1e-3) / 1e9 if ms[q] > 0 else 0.0
+            err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, bits)
+            res[tag] = {"n": n, "index_bits": bits, "ms_per_construction": round(dt * 1e3, 3), "MChars_per_s": round(n / dt / 1e6, 1),
+                        "rounds": int(st.n_rounds), "verified": list(err) == [0, 0, 0, 0],
+                        "scatter_pass": {"form": ("look-back", "three-word (B1,B2,idx)", "two-word (B1,idx)")[q],
+                                         "launches_per_construction": la[q] // steps, "avg_launch_ms": round(ms[q] / max(la[q], 1), 4),
+                                         "bytes_per_record_per_pass": round(by[q] / max(la[q], 1) / float(n), 2),
+                                         "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}}
+        except Exception as e:              # a side measurement never breaks the bench line
+            res[tag] = {"error": str(e)[:200]}
+        finally:
+            for k_, v_ in old.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+
+    run("configs[2]: 4096 MiB random ASCII (sigma 128), uint64", "ascii128", 1 << 32, 64, 3)
+    run("configs[1]: 256 MiB random DNA, uint32", "dna", 1 << 28, 32, 5)
+    # the (B1,B2,idx) records of idxsort.hpp:58-62 through every digit of both words (PSACX_ONE_STAGE=1 switches the
+    # two-stage first round off): 6w = 48 bytes per record and pass, SURVEY 8(d)'s per-unit figure
+    run("three-word scatter form: 2048 MiB random DNA, uint64, one-stage first round", "dna", 1 << 31, 64, 2, {"PSACX_ONE_STAGE": "1"})
+    ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), 1 << 32, 0, KIND_ID[a.alphabet], a.seed, 1024))
+    return res
+
+
 def mem_available_bytes():
     try:
         for line in open("/proc/meminfo"):
@@ -339,6 +399,8 @@ def main():
             what = "device checker over the full result of the last timed step"
         out["check"] = {"verified": list(err) == [0, 0, 0, 0], "errors": list(err), "seconds": round(time.perf_counter() - t1, 2),
                         "what": what}
+    if a.side == "auto" and n == (1 << 32) and bits == 64 and a.alphabet == "dna" and not a.no_lcp:
+        out["other_workloads"] = side_workloads(a, ctx, sa, d_text, d_sa, d_isa, d_lcp)
     # SURVEY 8(d) Metric 1 spans what psac brackets (src/psac.cpp:95-121): construct() on host memory, i.e. H2D of
     # the text and D2H of SA / ISA / LCP included.  Reported beside `value`, never as `value`.
     host_bytes = n * (1 + w * (2 if a.no_lcp else 3))

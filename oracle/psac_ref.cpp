@@ -6,14 +6,18 @@
 // CHECK the HIP engine; nothing in psac_amd/ (the product) may link, import or
 // call it.
 //
-// Parity pinning: the reference itself (header-only C++ over the un-vendored
-// mxx submodule) and its libdivsufsort oracle (needs cmake-generated headers)
-// are unbuildable in this image under the round's rules, so this restatement
-// is pinned against (a) the reference's own known-answer vectors
+// Parity pinning: psac itself (header-only C++ over the un-vendored, empty mxx
+// submodule) cannot be built in this image.  Its own checker and CPU
+// comparison, libdivsufsort, IS built from the reference tree into oracle/_ref/
+// (oracle/Makefile: the four C files compiled where they lie, the two public
+// headers instantiated from the reference's .h.cmake templates).  This
+// restatement is pinned against (a) the reference's own known-answer vectors
 // (test/test_psac.cpp:105 mississippi SA, test/test_bitops.cpp KATs,
-// README.md print64 listing) and (b) the SA/LCP/ISA checksums the survey
-// captured from the reference run in its container,
-// committed under tests/golden/.  See tests/test_oracle_golden.py.
+// README.md print64 listing, test/test_gsa.cpp arrays, test/test_suffixtree.cpp
+// table), (b) the SA/LCP/ISA checksums the survey captured from psac run in
+// its container, committed under tests/golden/, and
+// (c) outputs of the reference's libdivsufsort run here + Kasai (lcp.hpp:46-77)
+// on the shapes of test/test_psac.cpp.  See tests/test_oracle_golden.py.
 //
 // The independent loops carry OpenMP pragmas; they only take effect in the second build
 // (libpsac_oracle_mt.so: -fopenmp -D_GLIBCXX_PARALLEL, std::sort becomes the libstdc++ parallel

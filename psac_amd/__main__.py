@@ -120,7 +120,12 @@ def main(argv=None):
             torch.cuda.synchronize()
         d_text, d_sa, d_isa = dalloc(m), dalloc(m * w), dalloc(m * w)
         d_lcp = dalloc(m * w) if a.lcp else None
-        lib.psacx_copy_h2d(rctx, C.c_void_p(d_text), text.ctypes.data_as(C.c_void_p), m)
+        bufs = [d_text, d_sa, d_isa] + ([d_lcp] if a.lcp else [])
+
+        def ok(rcode, what):
+            if rcode != 0:
+                raise RuntimeError("%s failed on rank %d (status %d)" % (what, rank, rcode))
+        ok(lib.psacx_copy_h2d(rctx, C.c_void_p(d_text), text.ctypes.data_as(C.c_void_p), m), "copy of the text block to the device")
         barrier()
         t0 = time.perf_counter()
         st = mg.construct_device([d_text], [m], [d_sa], [d_isa], [d_lcp] if a.lcp else None, bits)[0]
@@ -130,9 +135,11 @@ def main(argv=None):
                 sys.stderr.write("iteration %d: unfinished buckets = %d, unfinished elements = %d\n" % (r.h, r.unfinished_buckets, r.unfinished_elements))
             sys.stderr.write("PSAC time: %g ms\n" % ((time.perf_counter() - t0) * 1e3))
         SA = np.empty(m, udt); LCP = np.empty(m, udt) if a.lcp else None
-        lib.psacx_copy_d2h(rctx, SA.ctypes.data_as(C.c_void_p), C.c_void_p(d_sa), m * w)
+        if rank == 0 and mg.memory()[2]:
+            sys.stderr.write("note: %d refinement rounds ran in slabs (reduced-memory layout); their counters may run ahead of psac's log\n" % mg.memory()[2])
+        ok(lib.psacx_copy_d2h(rctx, SA.ctypes.data_as(C.c_void_p), C.c_void_p(d_sa), m * w), "copy of the SA block to the host")
         if a.lcp:
-            lib.psacx_copy_d2h(rctx, LCP.ctypes.data_as(C.c_void_p), C.c_void_p(d_lcp), m * w)
+            ok(lib.psacx_copy_d2h(rctx, LCP.ctypes.data_as(C.c_void_p), C.c_void_p(d_lcp), m * w), "copy of the LCP block to the host")
         rc = 0
         if a.check:
             # the distributed checker (d_check_sa, check_suffix_array.hpp:207-267, plus the LCP recurrence): nothing is
@@ -144,7 +151,8 @@ def main(argv=None):
                 rc = 1
             elif rank == 0:
                 sys.stderr.write("[SUCCESS] Suffix Array%s are correct\n" % (" and LCP" if a.lcp else ""))
-        a_check_done = True
+        for p in bufs:
+            lib.psacx_dev_free(rctx, C.c_void_p(p))
 
     if single:
         rc = 0

@@ -413,6 +413,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         size_t free_b = 0, total_b = 0;
         PSACX_HIP(c, hipMemGetInfo(&free_b, &total_b));
         const size_t margin = (size_t)512 << 20;
+        // the device copies an earlier host-pointer call left in the ctx (construct_host keeps them between calls) are
+        // reclaimable when this call does not run on them: they go back before the reduced-memory layout is chosen
+        const bool io_idle = c->io && !(reinterpret_cast<const char*>(d_sa) >= c->io && reinterpret_cast<const char*>(d_sa) < c->io + c->io_bytes);
+        if (io_idle && need > c->slab_bytes && need + margin > free_b + c->slab_bytes) {
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            PSACX_HIP(c, hipFree(c->io));
+            c->io = nullptr; c->io_bytes = 0;
+            PSACX_HIP(c, hipMemGetInfo(&free_b, &total_b));
+        }
         const size_t avail = free_b + c->slab_bytes > margin ? free_b + c->slab_bytes - margin : 0;
         if ((kn.force_diet && !no_fast) || (need > c->slab_bytes && need > avail)) {
             Arena d0(nullptr);

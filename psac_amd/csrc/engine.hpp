@@ -192,7 +192,7 @@ inline int ensure_slab(psacx_ctx* c, size_t bytes) {
 }
 
 inline int ensure_io(psacx_ctx* c, size_t bytes) {
-    if (c->io_bytes >= bytes) return PSACX_OK;
+    if (c->io_bytes >= bytes && c->io_bytes / 4 <= bytes) return PSACX_OK;      // a much smaller request gives the rest back
     if (c->io) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->io); c->io = nullptr; c->io_bytes = 0; }
     hipError_t e = hipMalloc((void**)&c->io, bytes);
     if (e != hipSuccess) {

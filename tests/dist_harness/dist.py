@@ -21,9 +21,9 @@ single-GPU one (psac_amd/csrc/construct.hpp) with every global step made explici
                                                 per-rank minima for whole ranks in between
 
 All arithmetic on the arrays happens in a LocalOps object (HIP kernels on the GPU:
-psac_amd/dist_ops.py); this module only slices, concatenates and exchanges tensors.
+tests/dist_harness/dist_ops.py); this module only slices, concatenates and exchanges tensors.
 Written as a generator so that it runs unchanged under torch.distributed or under the
-in-process LoopbackWorld (psac_amd/comm.py).
+in-process LoopbackWorld (tests/dist_harness/comm.py).
 """
 import torch
 

@@ -1,4 +1,4 @@
-"""HIP implementation of the LocalOps interface of psac_amd/dist.py.
+"""HIP implementation of the LocalOps interface of tests/dist_harness/dist.py.
 
 Every method is one call into the step-level C ABI (include/psacx_ops.h) on device
 tensors that PyTorch merely owns (memory + stream + RCCL); there is no CPU or torch-op
@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from psac_amd import _lib
 
 
 class Boundary(C.Structure):

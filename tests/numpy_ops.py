@@ -1,4 +1,4 @@
-"""CPU implementation of the LocalOps interface of psac_amd/dist.py (numpy on CPU torch
+"""CPU implementation of the LocalOps interface of tests/dist_harness/dist.py (numpy on CPU torch
 tensors).  Test infrastructure: lets the distributed choreography run on the CPU (gloo /
 loopback) where the HIP ops cannot.  Each op states the semantics the HIP op must match."""
 import numpy as np

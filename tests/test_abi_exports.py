@@ -28,7 +28,8 @@ def declared_op_symbols():
 
 
 def test_ops_header_symbols_are_exported():
-    from psac_amd import _lib, dist_ops
+    from psac_amd import _lib
+    from dist_harness import dist_ops
     lib = _lib.load()
     syms = declared_op_symbols()
     assert len(syms) == 43

@@ -1,4 +1,4 @@
-"""The distributed choreography (psac_amd/dist.py) on the CPU: virtual ranks in one process
+"""The distributed choreography (tests/dist_harness/dist.py) on the CPU: virtual ranks in one process
 (LoopbackWorld) for many rank counts and inputs, and two real processes over gloo."""
 import os
 import sys
@@ -10,8 +10,8 @@ import torch
 import inputs
 import oracle_lib as O
 from numpy_ops import NumpyOps
-from psac_amd import dist as D
-from psac_amd.comm import LoopbackWorld
+from dist_harness import dist as D
+from dist_harness.comm import LoopbackWorld
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -149,8 +149,8 @@ def _gloo_worker(rank, world, port, text, bits, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, HERE)
     from numpy_ops import NumpyOps as Ops
-    from psac_amd import dist as DD
-    from psac_amd.comm import TorchComm
+    from dist_harness import dist as DD
+    from dist_harness.comm import TorchComm
     blk = split_blocks(text, world)[rank]
     gen = DD.construct(TorchComm(), Ops(bits), blk)
     try:
@@ -184,8 +184,8 @@ def _gloo_ansv_worker(rank, world, port, vals, bits, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, HERE)
     from numpy_ops import NumpyOps as Ops
-    from psac_amd import dist as DD
-    from psac_amd.comm import TorchComm
+    from dist_harness import dist as DD
+    from dist_harness.comm import TorchComm
     ops = Ops(bits)
     sizes = DD.blk_sizes(vals.size, world)
     offs = DD.prefix(sizes)

@@ -287,9 +287,9 @@ def test_cli_and_cpp_header(ctx, tmp_path):
 
 def _dist_loopback_gpu(text, P, bits, k=0):
     import torch
-    from psac_amd import dist as D
-    from psac_amd.comm import LoopbackWorld
-    from psac_amd.dist_ops import HipOps
+    from dist_harness import dist as D
+    from dist_harness.comm import LoopbackWorld
+    from dist_harness.dist_ops import HipOps
     sizes = D.blk_sizes(text.size, P)
     offs = D.prefix(sizes)
     ops = [HipOps(bits, 0) for _ in range(P)]
@@ -328,7 +328,7 @@ def test_distributed_ops_on_one_gpu(ctx, P):
 def test_distributed_shift_saturates(ctx):
     # psacx_op_add_scalar: SA + h in 64 bits, clamped to n (see tests/test_dist_cpu.py for the CPU twin)
     import torch
-    from psac_amd.dist_ops import HipOps
+    from dist_harness.dist_ops import HipOps
     ops = HipOps(32, 0)
     n = 0xFFFFFF00
     sa = torch.from_numpy(np.array([5, 0x80000000, 0xFFFFFE00, 0xFFFFFEFF], np.uint32).view(np.int32)).cuda()
@@ -677,9 +677,9 @@ def test_gsac_cli(tmp_path):
 def test_distributed_ansv_on_gpu(ctx):
     # the HIP search op (psacx_op_nsv_from_*) under the loopback world: P virtual ranks sharing this GPU
     import torch
-    from psac_amd import dist as D
-    from psac_amd.comm import LoopbackWorld
-    from psac_amd.dist_ops import HipOps
+    from dist_harness import dist as D
+    from dist_harness.comm import LoopbackWorld
+    from dist_harness.dist_ops import HipOps
     rng = np.random.RandomState(8)
     text = inputs.dna(200000, 6)
     lcp = run(ctx, text, bits=32).local_LCP

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Footprint and time of the distributed construction per rank, the ranks sharing device 0 (virtual ranks):
   tools/dist_bigrun.py <P> <log2 characters per rank> <bits> <kind: dna|ascii128|tandem> <layout: normal|reduced> [slab]
+(BIGRUN_EXTRA=e adds e characters to every block: 2 ranks of 2^31 + e characters are a text of more than 2^32 characters
+on one GPU, i.e. the 64-bit payload forms of the exchanges; BIGRUN_ITERS=k times the k-th construction)
 Prints the device memory every rank's engine allocated at its peak in words per character (beside the three result
 arrays and the text the caller owns), the total against the 288 GB of one MI355X for a block of 2^32 characters with
 64-bit words (BASELINE.json configs[4]: 32 GiB over 8 GPUs), ms per construction and the distributed checker's verdict."""
@@ -12,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import psac_amd
 
-P = int(sys.argv[1]); m = 1 << int(sys.argv[2]); bits = int(sys.argv[3]); kind = sys.argv[4]; layout = sys.argv[5]
+P = int(sys.argv[1]); m = (1 << int(sys.argv[2])) + int(os.environ.get("BIGRUN_EXTRA", "0")); bits = int(sys.argv[3]); kind = sys.argv[4]; layout = sys.argv[5]
 slab = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 w = bits // 8
 n = m * P

@@ -5,9 +5,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, inputs
-from psac_amd import dist as D
-from psac_amd.comm import LoopbackWorld
-from psac_amd.dist_ops import HipOps
+from dist_harness import dist as D
+from dist_harness.comm import LoopbackWorld
+from dist_harness.dist_ops import HipOps
 logn = int(sys.argv[1]); bits = int(sys.argv[2]); P = int(sys.argv[3])
 m = 1 << logn
 ops = [HipOps(bits, 0) for _ in range(P)]

@@ -11,9 +11,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import oracle_lib as O
-from psac_amd import dist as D
-from psac_amd.comm import LoopbackWorld
-from psac_amd.dist_ops import HipOps
+from dist_harness import dist as D
+from dist_harness.comm import LoopbackWorld
+from dist_harness.dist_ops import HipOps
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
