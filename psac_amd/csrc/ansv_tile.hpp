@@ -304,7 +304,7 @@ __device__ __forceinline__ unsigned ansv_tile_search(SH& sh, const T (&BW)[6], u
 // following each other (the kernel is bound by these round trips, not by instruction issue).
 template <typename T, int TB, bool WANT_UL, bool WANT_UR, typename SH>
 __device__ __forceinline__ void ansv_tile_search2(SH& sh, const T (&BL)[6], const T (&BR)[6], unsigned b, T v, bool lstrict, bool rstrict,
-                                                  uint64_t tile_base, uint64_t n, unsigned* pl_out, unsigned* pr_out, T* ul_out, T* ur_out) {
+                                                  uint64_t tile_base, uint64_t n, unsigned* pl_out, unsigned* pr_out, T* ul_out, T* ur_out, unsigned dbg = 0) {
     const int lane = (int)lane_id();
     const int a4 = lane << 2;
     // window minima inside the block, both directions
@@ -342,7 +342,7 @@ __device__ __forceinline__ void ansv_tile_search2(SH& sh, const T (&BL)[6], cons
     if (cl < 64) pl = b * 64 + cl;
     if (cr < 64) pr = b * 64 + cr;
     const bool needl = cl >= 64 && bl < (unsigned)TB, needr = cr >= 64 && br < (unsigned)TB;
-    if (__ballot(needl || needr)) {
+    if (!(dbg & 2u) && __ballot(needl || needr)) {
         // nearest qualifying element inside the block found on the tile level: binary search in its suffix / prefix minima
         const unsigned basel = (needl ? bl : b) * 64, baser = (needr ? br : b) * 64;
         int lol = 0, hil = 64, lor = -1, hir = 63;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void ansv_finish_furthest(SH& sh, const Pyramid<T>& P
 template <typename T, bool LF, bool RF>
 __global__ __launch_bounds__(AnsvWaves<T>::N * WAVE, (sizeof(T) == 4 && !LF && !RF) ? 8 : 1) void ansv_tile_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type,
                                                                  uint64_t nonsv, uint64_t* __restrict__ left,
-                                                                 uint64_t* __restrict__ right, uint64_t ntiles) {
+                                                                 uint64_t* __restrict__ right, uint64_t ntiles, unsigned dbg) {
     constexpr int TB = AnsvTile<T>::TB;
     constexpr int BPW = TB / AnsvWaves<T>::N;
     constexpr unsigned TILE = TB * 64;
@@ -509,16 +509,16 @@ __global__ __launch_bounds__(AnsvWaves<T>::N * WAVE, (sizeof(T) == 4 && !LF && !
             if (k + 1 < BPW) { const uint64_t g1 = g + 64; vnext = g1 < n ? in[g1] : ~(T)0; }
             T ul = 0, ur = 0;
             unsigned pl, pr;
-            ansv_tile_search2<T, TB, LF, RF>(sh, BL, BR, b, v, lstrict, rstrict, tile_base, n, &pl, &pr, &ul, &ur);
+            ansv_tile_search2<T, TB, LF, RF>(sh, BL, BR, b, v, lstrict, rstrict, tile_base, n, &pl, &pr, &ul, &ur, dbg);
             if (LF) sh.code_l[LF ? e : 0] = (uint16_t)(pl | ((pl != ANSV_PEND && ul == v) ? 0x8000u : 0u));
             else {
-                if (in_range && pl != ANSV_PEND) left[g] = tile_base + pl;
-                ansv_resolve_pending<T, true>(P, n, tile_base, tile_end, in_range && pl == ANSV_PEND, v, lt, 0u, sh.memo[0], nonsv, left, g);
+                if (in_range && pl != ANSV_PEND && !(dbg & 4u)) left[g] = tile_base + pl;
+                if (!(dbg & 1u)) ansv_resolve_pending<T, true>(P, n, tile_base, tile_end, in_range && pl == ANSV_PEND, v, lt, 0u, sh.memo[0], nonsv, left, g);
             }
             if (RF) sh.code_r[RF ? e : 0] = (uint16_t)(pr | ((pr != ANSV_PEND && ur == v) ? 0x8000u : 0u));
             else {
-                if (in_range && pr != ANSV_PEND) right[g] = tile_base + pr;
-                ansv_resolve_pending<T, false>(P, n, tile_base, tile_end, in_range && pr == ANSV_PEND, v, rt, 0u, sh.memo[1], nonsv, right, g);
+                if (in_range && pr != ANSV_PEND && !(dbg & 4u)) right[g] = tile_base + pr;
+                if (!(dbg & 1u)) ansv_resolve_pending<T, false>(P, n, tile_base, tile_end, in_range && pr == ANSV_PEND, v, rt, 0u, sh.memo[1], nonsv, right, g);
             }
         }
         if (LF || RF) __syncthreads();
@@ -532,13 +532,14 @@ template <typename T>
 inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
     constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const unsigned dbg = getenv("PSACX_ANSV_DBG") ? (unsigned)atoi(getenv("PSACX_ANSV_DBG")) : 0u;      // (tuning aid: parts of the kernel left out, results wrong)
     // exactly as many workgroups as fit on the chip at once: every workgroup then walks an equal, contiguous share of the tiles
 #define PSACX_ANSV(LF, RF)                                                                                                       \
     do {                                                                                                                         \
         int occ = 0;                                                                                                             \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_tile_kernel<T, LF, RF>, AnsvWaves<T>::N * WAVE, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 2; } \
         const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * occ);                                     \
-        hipLaunchKernelGGL((ansv_tile_kernel<T, LF, RF>), dim3(grid), dim3(AnsvWaves<T>::N * WAVE), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles); \
+        hipLaunchKernelGGL((ansv_tile_kernel<T, LF, RF>), dim3(grid), dim3(AnsvWaves<T>::N * WAVE), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles, dbg); \
     } while (0)
     if (lt == 2 && rt == 2) PSACX_ANSV(true, true);
     else if (lt == 2) PSACX_ANSV(true, false);

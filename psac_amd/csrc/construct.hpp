@@ -501,6 +501,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     for (int attempt = 0; attempt < 2; ++attempt) {
     bool retry_one_stage = false;
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
+    // the suffix a record stands for travels in the unsorted low bits of word 1 + one or two bytes (radix.hpp: VN 3 .. 6)
+    // (measured slower than 32-bit payload entries on one GPU, engine.hpp: packed_form_for -- off unless PSACX_PACKED=1)
+    const PackedForm pf = two_stage ? packed_form_for(n, lo1, sizeof(T), false) : PackedForm();
     const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.no_key_hist;
 
     // In the diet layout the second record set is the output buffers (y = ISA, LCP, SA).  One stage: both sorted key
@@ -544,8 +547,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     std::memset(r0, 0, sizeof(*r0));
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
+        bool packed1 = false;            // the sort ran in the packed form: word 1 comes back with payload bits in its low end
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
-                               ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
+                               ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1, false, pf, false, &packed1));
         if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
             PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         T* const S1 = sorted.k1;
@@ -563,7 +567,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             const uint64_t nb = (n + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
             if (!kn.ties_radix)
                 hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, S1, d_sa, S2, n, lo1,
-                                   d_text, n, tab, ks, d_big);
+                                   d_text, n, tab, ks, d_big, packed1);
             PSACX_HIP(c, hipGetLastError());
         }
         PSACX_HIP(c, hipMemcpyAsync(h_big, d_big, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -596,7 +600,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                     ProfScope ps(c, TC_GATHER);
                     const int gg = grid_for(c, ties, 256, 16);
                     hipLaunchKernelGGL((gather_prefix_ties_kernel<T, 256>), dim3(gg), dim3(256), 0, c->stream, ties, a.k1, a.v,
-                                       d_text, n, tab, ks, a.k2, w.sc.d_partials);
+                                       d_text, n, tab, ks, a.k2, w.sc.d_partials, packed1);
                     PSACX_HIP(c, hipGetLastError());
                     PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
                 }

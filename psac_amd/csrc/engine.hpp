@@ -397,6 +397,36 @@ inline int sort_cfg_env() {
     return v;
 }
 
+// Packed payload of the first round's prefix sort (radix.hpp: VN 3 .. 6): the low `bits` bits of word 1 lie below the sorted
+// prefix and carry the low bits of the suffix a record stands for, `bytes` (1 or 2) = size of the entries that hold the rest.
+// bytes == 0: not packed.
+struct PackedForm {
+    unsigned bits = 0, bytes = 0;
+    bool local = true;      // records that arrive packed stay packed between the passes of the local sort (else its first pass widens them)
+    bool on() const { return bytes != 0; }
+};
+// the form for payloads below `count` when the low lo1 bits of a 64-bit word 1 are free; none when more than 16 bits remain.
+// Measured on one GPU (4 GiB DNA, uint64, profiles/r03c_*): a pass over (8-byte word, 1-byte entry) records takes 32.4 ms
+// against 28.0 ms for (8-byte word, 32-bit entry) records although it moves 18 instead of 24 bytes per record, and 33.5 ms
+// with 2-byte entries (profiles/r03d_*): entries narrower than 32 bits cost more than they save in this scatter pattern --
+// so the one-GPU engine keeps its 32-bit payloads and the packed form is for the multi-GPU shuffle of texts beyond 2^32
+// characters, where the alternative is a 64-bit payload on the wire; there the first pass of the local sort widens the
+// entries again (two ranks of 2^31 + 2^20 characters: local sort 214 ms packed throughout against 184 ms)
+// (PSACX_PACKED=1 / 0 forces the form on / off wherever it applies, PSACX_PACKED_LOCAL=1 keeps the local passes packed).
+inline PackedForm packed_form_for(uint64_t count, unsigned lo1, size_t word_bytes, bool by_default) {
+    PackedForm pf;
+    const char* e = getenv("PSACX_PACKED");
+    const bool on = e ? atoi(e) != 0 : by_default;
+    if (!on || word_bytes != 8 || lo1 == 0) return pf;
+    const unsigned need = bits_for(count > 1 ? count - 1 : 1);
+    const unsigned rest = need > lo1 ? need - lo1 : 0;
+    if (rest > 16) return pf;
+    pf.bits = lo1 < 63 ? lo1 : 63; pf.bytes = rest > 8 ? 2 : 1;
+    if (const char* b = getenv("PSACX_PACKED_BYTES")) if (atoi(b) == 2) pf.bytes = 2;      // (measurements: 16-bit entries where 8 would do)
+    pf.local = getenv("PSACX_PACKED_LOCAL") != nullptr;
+    return pf;
+}
+
 struct ScatterShape { int block, items; };
 // scatter configurations selectable with PSACX_SORT_CFG (tuning aid)
 static const ScatterShape kShapes[] = {{256, 8}, {256, 16}, {512, 8}, {512, 16}, {256, 12}, {1024, 4}, {1024, 8}, {512, 12}};
@@ -443,7 +473,7 @@ inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three k
 template <typename T, int BLOCK, int ITEMS, int MINW = 1>
 inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
                          uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0) {
+                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0, unsigned pack = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const unsigned slab_tiles = slab_tiles_for(ntiles);
@@ -466,14 +496,20 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     constexpr bool DEF_SHAPE = BLOCK == 512 && ITEMS == (sizeof(T) == 4 ? 12 : 8);
     constexpr bool NARROW_OK = DEF_SHAPE && sizeof(T) == 8;       // 32-bit payload arrays (radix.hpp: VN), default shape only (8192-record tiles measured: 33.6-34.9 against 28.1 ms per pass)
     if (NARROW_OK && vn && !ko_in) {
-        if (vn == 1)
-            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
-        else
-            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? 2 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        // (radix.hpp: VN -- 1 / 2: 32-bit payload entries; 3 .. 6: payload packed into the low bits of the key word + 8- or 16-bit entries)
+#define PSACX_VN(V)                                                                                                                          \
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
+                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,                    \
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles, (uint64_t)0, pack)
+        switch (vn) {
+            case 1: PSACX_VN(1); break;
+            case 2: PSACX_VN(2); break;
+            case 3: PSACX_VN(3); break;
+            case 4: PSACX_VN(4); break;
+            case 5: PSACX_VN(5); break;
+            default: PSACX_VN(6); break;
+        }
+#undef PSACX_VN
         return;
     }
     if (DEF_SHAPE && sort_match_env() == 1) {
@@ -500,8 +536,8 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
 template <typename T>
 inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out,
                            T* v_out, uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0) {
-#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist, vn)
+                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0, unsigned pack = 0) {
+#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist, vn, pack)
     switch (cfg) {
         case 0: PSACX_P3(256, 8); break;
         case 2: PSACX_P3(512, 8); break;
@@ -555,7 +591,7 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
 // The per-class totals of the piece are known already (classify_prefix_kernel), so nothing comes back to the host.
 template <typename T>
 int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, const T* k1, const uint8_t* cls, uint64_t n, T* k1_out, void* v_out,
-                    bool v32, uint64_t spec, uint64_t spec_n, uint64_t voff) {
+                    bool v32, uint64_t spec, uint64_t spec_n, uint64_t voff, PackedForm pf = PackedForm()) {
     constexpr int BLOCK = 512, ITEMS = sizeof(T) == 4 ? 12 : 8, TILE = BLOCK * ITEMS;
     if (n == 0) return PSACX_OK;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
@@ -568,7 +604,15 @@ int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, con
     hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, d_base);
     const T* dsrc = reinterpret_cast<const T*>(cls);
-    if (sizeof(T) == 8 && v32)
+    if (sizeof(T) == 8 && pf.bytes == 1)
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 3 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
+    else if (sizeof(T) == 8 && pf.bytes == 2)
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 5 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
+                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
+    else if (sizeof(T) == 8 && v32)
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 1 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
@@ -603,7 +647,10 @@ template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
               uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0,
-              int ready_hist_shift = -1, bool v32_in = false) {
+              int ready_hist_shift = -1, bool v32_in = false, PackedForm pf = PackedForm(), bool packed_in = false, bool* ran_packed = nullptr) {
+    // pf.on(): two-word records of 64-bit words whose payload travels packed (radix.hpp: VN 3 .. 6): made up and packed by
+    // the first pass (iota), or arriving that way in in.k1 / in.v (packed_in: after the multi-GPU shuffle); put together
+    // again by the last pass
     // v32_in (64-bit words, two-word records): in.v holds 32-bit entries (payloads below 2^32 that arrived that way, the
     // suffixes of a text of at most 2^32 characters after the multi-GPU shuffle); they stay 32-bit between the passes and the
     // last pass widens them, as for a payload the first pass makes up
@@ -704,6 +751,10 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
     const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in) && cfg == ScatterCfg<T>::DEF2 && (!narrow_off_env() || v32_in);
     if (v32_in && !narrow) return PSACX_EINVAL;
+    const bool packed = pf.on() && three && sizeof(T) == 8 && !in.k2 && (iota || packed_in) && cfg == ScatterCfg<T>::DEF2 && pf.bits <= lo1;
+    if (packed_in && !packed) return PSACX_EINVAL;
+    // (a sort of one executed pass makes its payload up in full and leaves word 1 as it is)
+    if (ran_packed) *ran_packed = packed && (packed_in || n_exec > 1);
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
     for (int p = 0; p < plan.n_pass; ++p) {
@@ -725,8 +776,12 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         if (three) {
             const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
+            int vn = narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
+            const bool widen_first = packed && packed_in && !pf.local;      // packed on the wire only
+            if (widen_first) vn = first ? (pf.bytes == 1 ? 4 : 6) : 0;
+            else if (packed) vn = last ? ((first && !packed_in) ? 0 : (pf.bytes == 1 ? 4 : 6)) : (pf.bytes == 1 ? 3 : 5);
             dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n,
-                              have_hist, narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0);
+                              have_hist, vn, pf.bits);
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
@@ -752,7 +807,9 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        if (packed && packed_in && !pf.local) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (first ? (uint64_t)pf.bytes : sizeof(T)) + sizeof(T)) * n;
+        else if (packed) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? (uint64_t)pf.bytes : 0ull) + (last ? sizeof(T) : (uint64_t)pf.bytes)) * n;
+        else if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
         else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
@@ -763,6 +820,11 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         if (iota) {
             hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
+        } else if (packed_in) {
+            T* const w = (dst == cur.v) ? oth.v : dst;
+            hipLaunchKernelGGL((unpack_payload_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const T*)cur.k1, (const void*)cur.v, n, pf.bits, pf.bytes, w);
+            PSACX_HIP(c, hipGetLastError());
+            if (w != dst) PSACX_HIP(c, hipMemcpyAsync(dst, w, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         } else if (v32_in) {
             // (32-bit entries in, words out: through the other payload array when the widening would run in place)
             T* const w = (dst == cur.v) ? oth.v : dst;

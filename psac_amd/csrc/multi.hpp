@@ -162,6 +162,7 @@ struct psacx_multi {
     uint64_t out_slack = 0;           // the output arrays given to construct_dev hold this many elements beyond the block
     bool last_reduced = false;        // layout the last construction ran in
     bool last_two_word = false;       // the first round ran in two-word form (sort_first_two_word)
+    bool last_packed = false;         // ... with the suffixes packed into the low bits of word 1 + one or two bytes
     bool last_slice_inversion = false;   // SA -> ISA ran slice by slice through the partition levels + window scatter
     uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
 };
@@ -1255,8 +1256,13 @@ struct MultiRun {
                 for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
             }
         }
-        const bool v32 = sizeof(T) == 8 && n <= (1ull << 32);       // the suffixes travel and are sorted as 32-bit entries
-        const size_t vb = v32 ? 4 : sizeof(T);
+        // The suffix a record stands for travels in the low bits of word 1 that lie below the sorted prefix + one or two bytes
+        // (radix.hpp: VN 3 .. 6; 9 or 10 bytes per record on the wire and in every pass of the local sort); else as 32-bit
+        // entries while the text has at most 2^32 characters; else as words.
+        const PackedForm pf = packed_form_for(n, lo1, sizeof(T), n > (1ull << 32));
+        const bool v32 = !pf.on() && sizeof(T) == 8 && n <= (1ull << 32);
+        const size_t vb = pf.on() ? pf.bytes : (v32 ? 4 : sizeof(T));
+        g->last_packed = pf.on();
         // record j of local rank i stands for suffix: the spec short suffixes first on rank 0 (n - 1 - j), then the block in order
         auto payload_of = [&](int i, uint64_t a, uint64_t* spec_q, uint64_t* specn_q, uint64_t* voff_q) {
             const uint64_t front = rank(i) == 0 ? spec_front : 0;
@@ -1332,7 +1338,7 @@ struct MultiRun {
                     payload_of(i, a, &sq, &snq, &vq);
                     MG_HIP(g, hipSetDevice(c->device));
                     MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p + a, cls[i].p + a, b - a, grp[i].k1.p + a,
-                                                  reinterpret_cast<char*>(grp[i].v.p) + a * vb, v32, sq, snq, vq));
+                                                  reinterpret_cast<char*>(grp[i].v.p) + a * vb, v32, sq, snq, vq, pf));
                     return PSACX_OK;
                 });
                 if (rc != PSACX_OK) break;
@@ -1372,6 +1378,7 @@ struct MultiRun {
         // prefix sort of (word 1, suffix) on the leading bits, then the ties
         std::vector<uint64_t> ties(L, 0);
         bool general_ties = !solo_;
+        bool solo_packed = false;        // one rank: the sort ran packed, word 1 of a tied record is read from the text again
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             if (rec[i].cnt >= 1) {
@@ -1380,8 +1387,10 @@ struct MultiRun {
                 int32_t where = 0;
                 if (solo_) {
                     // the first pass makes up the payload (the suffix a record stands for), as on one GPU
-                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n));
-                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32));
+                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n,
+                                                false, pf, false, &solo_packed));
+                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32,
+                                                   pf, pf.on()));
                 if (where) swap3(rec[i], alt);
                 drop3(i, alt);
             }
@@ -1394,7 +1403,7 @@ struct MultiRun {
                 MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
                 const uint64_t nb = (rec[i].cnt + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
                 hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, rec[i].k1.p, rec[i].v.p, rec[i].k2.p, rec[i].cnt, lo1,
-                                   (const uint8_t*)tbuf[i].p, S[i].m + two_k, tab, ks, big.p);
+                                   (const uint8_t*)tbuf[i].p, S[i].m + two_k, tab, ks, big.p, solo_packed);
                 MG_HIP(g, hipGetLastError());
                 MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
                 MG_HIP(g, hipStreamSynchronize(c->stream));
@@ -2258,6 +2267,7 @@ struct MultiRun {
         if (!two_word) PSACX_TRY(dist_sort(rec, sizes, bits_w1, bits_w2, true));
         tbuf.clear();
         g->last_two_word = two_word;
+        if (!two_word) g->last_packed = false;
         PSACX_TRY(par([&](int i) -> int { return own3(i, rec[i]); }));
         mark("first sort");
 

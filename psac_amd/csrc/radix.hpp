@@ -155,6 +155,12 @@ template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
 // VN (64-bit words, payloads below 2^32 -- the suffix indices of a text of at most 2^32 characters): 1 = the payload arrays
 // hold 32-bit entries on both sides, 2 = 32-bit entries in, full words out (the last pass of a sort).  The first round's
 // prefix sort then moves 12 instead of 16 bytes per record and pass.
+// VN 3 / 5 (packed payload, the prefix sort of the first round): the low `pack` bits of the key word are not part of the
+// sorted prefix (pack <= lo1) and nothing reads them after the sort (the records that tie on the prefix get their window
+// from the text again), so they carry the low `pack` bits of the payload; the payload array holds the rest as 8-bit (3) or
+// 16-bit (5) entries: 9 or 10 instead of 12 (16) bytes per record and pass.  A pass without v_in makes the payload up and
+// packs it.  VN 4 / 6: packed 8- / 16-bit entries in, full words out (the last pass of a sort puts the payload together again;
+// the key word leaves with the payload bits still in its low end).
 // CLSB (EXT only): bytes per entry of the class array dsrc (sizeof(T), or 1 for a byte array).
 // voff: added to the payload a pass makes up itself (v_in == nullptr): the records of a rank's block, or of a piece of it.
 template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0, int VN = 0, int CLSB = sizeof(T)>
@@ -165,9 +171,12 @@ __device__ __forceinline__ void radix_scatter_tile(
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
-    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0) {
+    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
+    constexpr bool PK = VN >= 3;                       // packed payload
+    constexpr bool PK_OUT_FULL = VN == 4 || VN == 6;   // ... put together again on the way out
+    const T pmask = PK ? (T)((((uint64_t)1 << pack) - 1)) : (T)0;
     T* const stage = sh.stage;
     uint8_t* const sdig = sh.sdig;
     unsigned* const wcnt = sh.wcnt;
@@ -221,12 +230,15 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
         if (pv) {
-            if (VN) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (T)0;
+            if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (T)0;
+            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint8_t*>(v_in) + base)[loc] : (T)0;
+            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint16_t*>(v_in) + base)[loc] : (T)0;
             else vv[i] = (FULL || loc < count) ? pv[loc] : (T)0;
         } else {
             // implicit payload: the record index, or the suffix the first-round record stands for
             const uint64_t g = base + loc;
             vv[i] = (T)((spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff);
+            if (PK) { kd[i] = (T)((kd[i] & ~pmask) | (vv[i] & pmask)); vv[i] = (T)((uint64_t)vv[i] >> pack); }
         }
     }
 
@@ -309,11 +321,13 @@ __device__ __forceinline__ void radix_scatter_tile(
     }
     __syncthreads();
     T dest[MATCH ? ITEMS : 1];          // MATCH: global position of output slot tid + j * BLOCK, reused for every word
+    T xlow[PK_OUT_FULL ? ITEMS : 1];    // packed payload on its way out: the bits the key word of output slot tid + j * BLOCK carries
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (FULL || p < count) {
             const T x = stage[p];
+            if (PK_OUT_FULL) xlow[PK_OUT_FULL ? j : 0] = (T)(x & pmask);
             if (MATCH) { dest[MATCH ? j : 0] = (T)(goff[(unsigned)(x >> shift) & (RADIX - 1)] + (T)p); kd_out[dest[MATCH ? j : 0]] = x; }
             else kd_out[(T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = x;
         }
@@ -343,6 +357,9 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (FULL || p < count) {
             const T at = MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p);
             if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)stage[p];
+            else if (VN == 3) reinterpret_cast<uint8_t*>(v_out)[at] = (uint8_t)stage[p];
+            else if (VN == 5) reinterpret_cast<uint16_t*>(v_out)[at] = (uint16_t)stage[p];
+            else if (PK_OUT_FULL) v_out[at] = (T)(xlow[PK_OUT_FULL ? j : 0] | (T)((uint64_t)stage[p] << pack));
             else v_out[at] = stage[p];
         }
     }
@@ -532,7 +549,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
     uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr,
-    unsigned slab_tiles = SLAB_TILES, uint64_t voff = 0) {
+    unsigned slab_tiles = SLAB_TILES, uint64_t voff = 0, unsigned pack = 0) {
     // (a persistent variant, one workgroup looping over tiles with its next ticket prefetched, was
     // measured: the loop raised the register count from 118 to 173 and lost 20 %)
     constexpr int TILE = BLOCK * ITEMS;
@@ -552,11 +569,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff);
+                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
     else
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff);
+                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
 }
 
 } // namespace psacx

@@ -833,6 +833,17 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
 // moves only (word 1, suffix) and the few suffixes that still tie on word 1 are ordered by the
 // full window afterwards.  K2rec holds word 2 in RECORD order (see record_suffix).
 // word 2 of the packed window of suffix `sa`, straight from the text (same packing as key_pairs_kernel)
+// word 1 of the packed window of suffix `sa`
+template <typename T>
+__device__ __forceinline__ T window_word1(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
+                                          const KeyShape& ks, uint64_t sa) {
+    T w1 = 0;
+    for (unsigned t = 0; t < ks.c1; ++t) {
+        const uint64_t q = sa + t;
+        w1 = (T)(w1 << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
+    }
+    return w1;
+}
 template <typename T>
 __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
                                           const KeyShape& ks, uint64_t sa) {
@@ -875,7 +886,7 @@ template <typename T, int BLOCK, int ITEMS, int G, bool FROM_ARRAY = false>
 __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, T* __restrict__ SA, T* __restrict__ S2,
                                                             uint64_t n, unsigned lo1, const uint8_t* __restrict__ text,
                                                             uint64_t n_text, CodeTable tab, KeyShape ks,
-                                                            unsigned long long* __restrict__ big) {
+                                                            unsigned long long* __restrict__ big, bool packed = false) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ uint16_t ctab[256];
     __shared__ unsigned leaders[TILE / 2 + 1];     // tile-relative position of the first member of every group
@@ -919,8 +930,11 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
         T k2[G];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            if ((unsigned)i < len) k2[i] = FROM_ARRAY ? S2[e + i] : window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
-            else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
+            if ((unsigned)i < len) {
+                k2[i] = FROM_ARRAY ? S2[e + i] : window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
+                // packed payload (radix.hpp: VN 3 .. 6): the bits of word 1 below the sorted prefix went to the payload
+                if (!FROM_ARRAY && packed) k1[i] = window_word1<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
+            } else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
         }
         // adjacent exchanges of strictly descending neighbours only: stable
         bool moved = false;                 // a group that is already in order writes back word 2 only
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             if ((unsigned)i < len) {
-                if (lo1 && moved) S1[e + i] = k1[i];
+                if ((lo1 && moved) || (!FROM_ARRAY && packed)) S1[e + i] = k1[i];
                 if (!FROM_ARRAY || moved) S2[e + i] = k2[i];
                 if (moved) SA[e + i] = sa[i];
             }
@@ -950,16 +964,18 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
 // Stage 2, fallback: K1 / V are word 1 and suffix of the tied records (written by the compaction);
 // fetches word 2 from the text.
 template <typename T, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt, const T* __restrict__ K1, const T* __restrict__ V,
+__global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt, T* __restrict__ K1, const T* __restrict__ V,
                                           const uint8_t* __restrict__ text, uint64_t n_text, CodeTable tab, KeyShape ks,
-                                          T* __restrict__ K2, unsigned long long* __restrict__ summary) {
+                                          T* __restrict__ K2, unsigned long long* __restrict__ summary, bool packed = false) {
     __shared__ uint16_t ctab[256];
     for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const T k1 = K1[j], k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        T k1 = K1[j];
+        const T k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        if (packed) { k1 = window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]); K1[j] = k1; }      // (its low bits carried the payload)
         K2[j] = k2;
         o1 |= k1; a1 &= k1; o2 |= k2; a2 &= k2;
     }
@@ -1259,6 +1275,17 @@ __global__ void left_chars_kernel(const uint8_t* __restrict__ text, uint64_t n, 
             if (p < n) ch = text[p];
         }
         Lc[i] = ch;
+    }
+}
+
+// packed payload of an already sorted input (radix.hpp: VN 3 .. 6): put together again without a sort pass
+template <typename T>
+__global__ void unpack_payload_kernel(const T* __restrict__ k1, const void* __restrict__ hi, uint64_t n, unsigned pack, unsigned bytes, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const T mask = (T)(((uint64_t)1 << pack) - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(hi)[i] : (uint64_t)static_cast<const uint16_t*>(hi)[i];
+        out[i] = (T)((k1[i] & mask) | (T)(h << pack));
     }
 }
 

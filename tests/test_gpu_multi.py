@@ -614,6 +614,35 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
             mg.close()
 
 
+@pytest.mark.parametrize("P,entry_bytes,local", [(1, 1, 0), (2, 2, 0), (3, 1, 1), (7, 2, 1), (4, 1, 0)])
+def test_multi_packed_payload_on_the_wire(P, entry_bytes, local, monkeypatch):
+    # The form a text beyond 2^32 characters takes by default, forced on small inputs (PSACX_PACKED=1): the suffix of a
+    # two-word record travels in the unsorted low bits of word 1 + a one- or two-byte entry (9 or 10 bytes per record on the
+    # wire and in the passes of the local sort, radix.hpp: VN 3 .. 6); ties fetch both words from the text owners.
+    monkeypatch.setenv("PSACX_PACKED", "1")
+    monkeypatch.setenv("PSACX_PACKED_BYTES", str(entry_bytes))
+    if local:                # the local sort keeps the entries packed between its passes (else its first pass widens them)
+        monkeypatch.setenv("PSACX_PACKED_LOCAL", "1")
+    cases = [(O.rand_dna(70001, 7), 64), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
+             (O.rand_dna((1 << 21) + 11, 8), 64), (O.rand_dna(70001, 7), 32)]
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
+        mg = multi(P)
+        try:
+            packed = 0
+            for text, bits in cases:
+                SA, ISA, LCP, rounds = same(mg, text, bits)
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, bits, text.size)
+                assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
+                f = mg.last_form()
+                assert not f["packed"] or (f["two_word"] and bits == 64)
+                packed += f["packed"]
+            assert packed >= 3, packed
+        finally:
+            mg.close()
+
+
 @pytest.mark.parametrize("P,wb,s1,step", [(1, 6, 9, 0), (2, 5, 2, 1), (3, 14, 9, 0), (7, 4, 1, 1), (4, 6, 3, 2)])
 def test_multi_isa_by_destination_slices(P, wb, s1, step, monkeypatch):
     # SA -> ISA of the first round slice by slice (slice_inv.hpp): first level by (owner, slice) on the senders, the slices

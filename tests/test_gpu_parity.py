@@ -744,6 +744,25 @@ def test_degenerate_texts_above_the_two_stage_threshold(ctx):
         same_as_oracle(ctx, text, bits=bits)
 
 
+@pytest.mark.parametrize("entry_bytes", [1, 2])
+def test_packed_payload_form_of_the_prefix_sort(ctx, monkeypatch, entry_bytes):
+    # PSACX_PACKED=1: the suffix of a first-round record travels in the unsorted low bits of word 1 + a one- or
+    # two-byte entry (radix.hpp: VN 3 .. 6), word 1 of the tied suffixes is read from the text again.  64-bit words
+    # only; random DNA (tiny tie groups), ASCII (63-bit word 1, 16-bit entries anyway), a text whose tie groups are
+    # long (the radix fallback for the ties), and the reduced-memory layout.
+    monkeypatch.setenv("PSACX_PACKED", "1")
+    monkeypatch.setenv("PSACX_PACKED_BYTES", str(entry_bytes))
+    same_as_oracle(ctx, inputs.dna((1 << 22) + 77, 5), bits=64)
+    same_as_oracle(ctx, inputs.ascii128((1 << 21) + 5, 4), bits=64)
+    rep = np.tile(inputs.dna(1 << 12, 9), 1 << 10)
+    rep[::4099] = 84
+    same_as_oracle(ctx, rep, bits=64)
+    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
+    same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
+    monkeypatch.setenv("PSACX_TIES_RADIX", "1")
+    same_as_oracle(ctx, inputs.dna((1 << 21) + 9, 7), bits=64)
+
+
 def test_ansv_device_resident(ctx):
     # psacx_ansv_dev_*: LCP left in HBM by the construction -> ANSV without leaving the device (psac -t's
     # pair: left furthest_eq, right nearest_sm, suffix_tree.hpp:62); 2^24 characters, compared with the oracle
