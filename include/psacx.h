@@ -300,6 +300,21 @@ int psacx_multi_ansv_dev_u32(psacx_multi* mg, const uint32_t* const* d_in, const
                              uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
 int psacx_multi_ansv_dev_u64(psacx_multi* mg, const uint64_t* const* d_in, const uint64_t* m, int left_type, int right_type,
                              uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
+/* construct_suffix_tree(sa, begin, end, comm) on p ranks (suffix_tree.hpp:413-499; parents by for_each_parent :43-223 from
+ * the ANSV of LCP :62, cells sent to the owners of their rows like bulk_permute's pairs): d_nodes[i] receives the rows of the
+ * LCP indices of local rank i's block, m[i] x (sigma + 1) cells of 64 bits, row-major; cell (j, c) = the child of internal
+ * node off_i + j through the character with alphabet code c (0 = end of text), leaves numbered n + index, 0 = none -- the
+ * table psacx_suffix_tree_* builds on one rank, block-distributed by rows.  *sigma = number of distinct characters of the
+ * whole text; d_nodes == NULL only queries it.  SA and LCP as psacx_multi_construct_dev_* left them. */
+int psacx_multi_suffix_tree_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint32_t* const* d_SA,
+                                    const uint32_t* const* d_LCP, uint64_t* const* d_nodes, uint32_t* sigma);
+int psacx_multi_suffix_tree_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* const* d_SA,
+                                    const uint64_t* const* d_LCP, uint64_t* const* d_nodes, uint32_t* sigma);
+/* the host-pointer form (the signature of psacx_suffix_tree_*; needs every rank in this process): nodes[n x (sigma + 1)] */
+int psacx_multi_suffix_tree_u32(psacx_multi* mg, const uint8_t* text, uint64_t n, const uint32_t* SA, const uint32_t* LCP,
+                                uint64_t* nodes, uint32_t* sigma);
+int psacx_multi_suffix_tree_u64(psacx_multi* mg, const uint8_t* text, uint64_t n, const uint64_t* SA, const uint64_t* LCP,
+                                uint64_t* nodes, uint32_t* sigma);
 /* statistics of the last call (sigma, k, the per-round log) and what this process moved: payload bytes sent to other
  * ranks, number of all-to-all exchanges and of scalar all-gathers */
 int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* bytes_sent, uint64_t* exchanges, uint64_t* gathers);

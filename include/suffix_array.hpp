@@ -421,7 +421,21 @@ std::vector<std::size_t> construct_suffix_tree(suffix_array<char, index_t, true>
         static int run(psacx_ctx* c, const uint8_t* t, uint64_t n, const uint64_t* a, const uint64_t* l, uint64_t* o, uint32_t* s) {
             return psacx_suffix_tree_u64(c, t, n, a, l, o, s);
         }
+        // p > 1: the table is built by the ranks of the suffix array's communicator (suffix_tree.hpp:440-499)
+        static int run(psacx_multi* g, const uint8_t* t, uint64_t n, const uint32_t* a, const uint32_t* l, uint64_t* o, uint32_t* s) {
+            return psacx_multi_suffix_tree_u32(g, t, n, a, l, o, s);
+        }
+        static int run(psacx_multi* g, const uint8_t* t, uint64_t n, const uint64_t* a, const uint64_t* l, uint64_t* o, uint32_t* s) {
+            return psacx_multi_suffix_tree_u64(g, t, n, a, l, o, s);
+        }
     };
+    if (psacx_multi* mg = sa.multi_context()) {
+        auto must = [&](int rc) { if (rc != PSACX_OK) throw std::runtime_error(std::string("psacx: ") + psacx_strerror(rc) + " [" + psacx_multi_last_error(mg) + "]"); };
+        must(Call::run(mg, text.data(), sa.n, (const W*)nullptr, (const W*)nullptr, nullptr, &sigma));
+        std::vector<std::size_t> nodes((std::size_t)(sigma + 1) * sa.n, 0);
+        must(Call::run(mg, text.data(), sa.n, p_sa, p_lcp, reinterpret_cast<uint64_t*>(nodes.data()), &sigma));
+        return nodes;
+    }
     psacx::check(sa.context(), Call::run(sa.context(), text.data(), sa.n, (const W*)nullptr, (const W*)nullptr, nullptr, &sigma));
     std::vector<std::size_t> nodes((std::size_t)(sigma + 1) * sa.n, 0);
     psacx::check(sa.context(), Call::run(sa.context(), text.data(), sa.n, p_sa, p_lcp, reinterpret_cast<uint64_t*>(nodes.data()), &sigma));

@@ -710,17 +710,32 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     const unsigned id_bits = bits_for(n);
     // one refinement pass over the `cnt` list entries plist (suffix_array.hpp:1092-1157 for one bucket range):
     // B2 = rank of the suffix h further, sort by (bucket, B2), new ids / LCP / ISA written in place
-    auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf) -> int {
+    // whole: the round takes all n suffixes in TEXT order (shift_keys_kernel) and ISA is rebuilt by inverting the new SA
+    // (the destination-partition levels of the first round) instead of one random store per record
+    auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false) -> int {
+        // 64-bit words, fewer than 2^32 characters: bucket id and rank h further share one word, the suffix is a 32-bit entry --
+        // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass
+        const bool both = sizeof(T) == 8 && n < (1ull << 32) && cnt >= SMALL_SORT_MAX && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.wide_refine;
+        T* const key2 = both ? (T*)nullptr : w.x.k2;
         {
             ProfScope ps(c, TC_GATHER);
             const int gg = grid_for(c, cnt, 256, 16);
-            hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
-                               plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, w.x.k2, w.x.v, w.sc.d_partials, d_slen);
+            if (whole)
+                hipLaunchKernelGGL((shift_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
+            else
+                hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
+                                   plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
             PSACX_HIP(c, hipGetLastError());
             // (only the three-kernel form of the sort reads the key summary)
             if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
         psacx_round rs; std::memset(&rs, 0, sizeof(rs));
+        if (both) {
+            SortBufs<T> in2{w.x.k1, nullptr, w.x.v}, alt2{w.ry.k1, nullptr, w.ry.v};
+            PSACX_TRY(pair_sort<T>(c, w.sc, in2, alt2, cnt, /*iota=*/false, 32 + id_bits, 0, nullptr, &sorted, &rs, 0, 0,
+                                   /*summary_ready=*/true, 0, -1, /*v32_in=*/true));
+            sorted.k2 = nullptr;
+        } else
         PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, &rs, 0, 0,
                                /*summary_ready=*/true));
         if (rr) { rr->sort_passes += rs.sort_passes; rr->sort_passes_skipped += rs.sort_passes_skipped; }
@@ -732,11 +747,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, KeyShape())));
             hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
-                               d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
+                               d_sa, w.bsa, whole ? (T*)nullptr : d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
                                (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr);
             PSACX_HIP(c, hipGetLastError());
         }
-        return run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active);
+        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active));
+        if (whole) {
+            ProfScope ps(c, TC_ISA_SCATTER);
+            PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, w.ry, kn, 0, &w.sc, false, false));
+        }
+        return PSACX_OK;
     };
 
     for (uint64_t h = 2ull * k; unf_b > 0 && h < n; h <<= 1) {
@@ -756,7 +776,27 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             if (a2 != active) { c->hip_err = "active list rebuild disagrees with the round counters"; return PSACX_EDEVICE; }
             have_list = true;
         }
-        if (no_fast || have_list) {
+        // rounds in which at least 7/8 of the suffixes are unresolved (repetitive texts) take all n in text order, as psac's
+        // doubling rounds do: the random fetch of the ranks h further and the random ISA stores turn into streams
+        bool whole = !no_fast && !w.diet && have_list && w.cap_active >= n && n >= (1ull << 16) &&
+                     active >= n - n / 8 && !kn.no_whole_rounds;
+        if (whole) {
+            // ... unless SA order is nearly text order (sa_locality_kernel): 2^27 equal characters take 9.2 ms per round through
+            // the list and 12.0 ms as whole rounds, a period-1024 tandem repeat 18.0 against 14.7 (profiles/r03g_*)
+            unsigned long long* d_near = reinterpret_cast<unsigned long long*>(w.d_totals + 2);
+            unsigned long long* h_near = reinterpret_cast<unsigned long long*>(c->pinned + 64);
+            const uint64_t samples = 1u << 16;
+            PSACX_HIP(c, hipMemsetAsync(d_near, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL((sa_locality_kernel<T>), dim3(64), dim3(256), 0, c->stream, d_sa, n, samples, d_near);
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_HIP(c, hipMemcpyAsync(h_near, d_near, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            if (*h_near * 2 > samples) whole = false;
+        }
+        if (whole) {
+            PSACX_TRY(refine((const T*)nullptr, n, h, rr, pos_next, &nactive, &unf_b, true));
+            std::swap(pos, pos_next);
+        } else if (no_fast || have_list) {
             PSACX_TRY(refine(no_fast ? (const T*)nullptr : pos, round_cnt, h, rr, pos_next, &nactive, &unf_b));
             std::swap(pos, pos_next);
         } else {

@@ -63,6 +63,21 @@ int left_chars_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t*
     return run.left_chars(t, mm, a, c, o);
 }
 
+template <typename T>
+int suffix_tree_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, const T* const* sa, const T* const* lcp, uint64_t* const* nodes, uint32_t* sigma) {
+    if (!g || !d_text || !m || !sigma) return PSACX_EINVAL;
+    if (nodes && (!sa || !lcp)) return PSACX_EINVAL;
+    g->err.clear();
+    MultiRun<T> run(g);
+    std::vector<const uint8_t*> t(g->nlocal); std::vector<uint64_t> mm(g->nlocal);
+    std::vector<T*> a(g->nlocal, nullptr), c(g->nlocal, nullptr); std::vector<unsigned long long*> o(g->nlocal, nullptr);
+    for (int i = 0; i < g->nlocal; ++i) {
+        t[i] = d_text[i]; mm[i] = m[i];
+        if (nodes) { a[i] = const_cast<T*>(sa[i]); c[i] = const_cast<T*>(lcp[i]); o[i] = reinterpret_cast<unsigned long long*>(nodes[i]); }
+    }
+    return run.suffix_tree(t, mm, a, c, nodes ? &o : nullptr, sigma);
+}
+
 // whole text on the host of a single process that owns every rank: blocks to the GPUs, results back in rank order
 template <typename T>
 int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp, uint8_t* lc = nullptr) {
@@ -112,6 +127,45 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
         MG_OP(g, cx, staged_d2h(cx, sa + off[r], dsa[r].p, m[r] * sizeof(T)));
         MG_OP(g, cx, staged_d2h(cx, isa + off[r], disa[r].p, m[r] * sizeof(T)));
         if (want_lcp) MG_OP(g, cx, staged_d2h(cx, lcp + off[r], dlcp[r].p, m[r] * sizeof(T)));
+    }
+    return PSACX_OK;
+}
+
+// host-pointer form of the node table: blocks of text / SA / LCP to the ranks, the rows back in rank order
+template <typename T>
+int suffix_tree_host(psacx_multi* g, const uint8_t* text, uint64_t n, const T* sa, const T* lcp, uint64_t* nodes, uint32_t* sigma) {
+    if (!g || !text || !sigma || n == 0) return PSACX_EINVAL;
+    if (nodes && (!sa || !lcp)) return PSACX_EINVAL;
+    if (g->nlocal != g->nranks) { g->err = "the host-pointer form needs every rank in this process"; return PSACX_EINVAL; }
+    const int P = g->nranks;
+    std::vector<uint64_t> m(P), off(P + 1, 0);
+    for (int r = 0; r < P; ++r) { m[r] = n / P + ((uint64_t)r < n % P ? 1 : 0); off[r + 1] = off[r] + m[r]; }
+    std::vector<DBuf<uint8_t>> dt(P);
+    std::vector<DBuf<T>> dsa(P), dlcp(P);
+    std::vector<const uint8_t*> tp(P); std::vector<const T*> a(P), c(P);
+    for (int r = 0; r < P; ++r) {
+        psacx_ctx* cx = g->R[r].ctx;
+        MG_OP(g, cx, dt[r].alloc(cx, m[r]));
+        if (m[r]) MG_OP(g, cx, staged_h2d(cx, dt[r].p, text + off[r], m[r]));
+        tp[r] = dt[r].p;
+        if (nodes) {
+            MG_OP(g, cx, dsa[r].alloc(cx, m[r])); MG_OP(g, cx, dlcp[r].alloc(cx, m[r]));
+            if (m[r]) { MG_OP(g, cx, staged_h2d(cx, dsa[r].p, sa + off[r], m[r] * sizeof(T))); MG_OP(g, cx, staged_h2d(cx, dlcp[r].p, lcp + off[r], m[r] * sizeof(T))); }
+        }
+        a[r] = dsa[r].p; c[r] = dlcp[r].p;
+    }
+    int rc = suffix_tree_dev<T>(g, tp.data(), m.data(), (const T* const*)nullptr, (const T* const*)nullptr, (uint64_t* const*)nullptr, sigma);
+    if (rc != PSACX_OK || !nodes) return rc;
+    const uint64_t row = (uint64_t)*sigma + 1;
+    std::vector<DBuf<uint64_t>> dn(P);
+    std::vector<uint64_t*> o(P);
+    for (int r = 0; r < P; ++r) { psacx_ctx* cx = g->R[r].ctx; MG_OP(g, cx, dn[r].alloc(cx, m[r] * row)); o[r] = dn[r].p; }
+    rc = suffix_tree_dev<T>(g, tp.data(), m.data(), a.data(), c.data(), o.data(), sigma);
+    if (rc != PSACX_OK) return rc;
+    for (int r = 0; r < P; ++r) {
+        psacx_ctx* cx = g->R[r].ctx;
+        MG_HIP(g, hipSetDevice(cx->device));
+        if (m[r]) MG_OP(g, cx, staged_d2h(cx, nodes + off[r] * row, dn[r].p, m[r] * row * sizeof(uint64_t)));
     }
     return PSACX_OK;
 }
@@ -301,6 +355,18 @@ int psacx_multi_left_chars_dev_u32(psacx_multi* g, const uint8_t* const* t, cons
                                    uint8_t* const* lc) { return left_chars_dev<uint32_t>(g, t, m, sa, lcp, lc); }
 int psacx_multi_left_chars_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* lcp,
                                    uint8_t* const* lc) { return left_chars_dev<uint64_t>(g, t, m, sa, lcp, lc); }
+
+int psacx_multi_suffix_tree_dev_u32(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint32_t* const* sa, const uint32_t* const* lcp,
+                                    uint64_t* const* nodes, uint32_t* sigma) { return suffix_tree_dev<uint32_t>(g, t, m, sa, lcp, nodes, sigma); }
+int psacx_multi_suffix_tree_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* const* sa, const uint64_t* const* lcp,
+                                    uint64_t* const* nodes, uint32_t* sigma) { return suffix_tree_dev<uint64_t>(g, t, m, sa, lcp, nodes, sigma); }
+
+int psacx_multi_suffix_tree_u32(psacx_multi* g, const uint8_t* text, uint64_t n, const uint32_t* sa, const uint32_t* lcp, uint64_t* nodes, uint32_t* sigma) {
+    return suffix_tree_host<uint32_t>(g, text, n, sa, lcp, nodes, sigma);
+}
+int psacx_multi_suffix_tree_u64(psacx_multi* g, const uint8_t* text, uint64_t n, const uint64_t* sa, const uint64_t* lcp, uint64_t* nodes, uint32_t* sigma) {
+    return suffix_tree_host<uint64_t>(g, text, n, sa, lcp, nodes, sigma);
+}
 
 int psacx_multi_ansv_dev_u32(psacx_multi* g, const uint32_t* const* in, const uint64_t* m, int lt, int rt, uint64_t nonsv, uint64_t* const* l,
                              uint64_t* const* r) { return ansv_dev<uint32_t>(g, in, m, lt, rt, nonsv, l, r); }

@@ -404,6 +404,72 @@ __global__ void check_verdict_kernel(const T* __restrict__ SA, const T* __restri
 
 // ------------------------------------------------------------------------------------------------------------
 // number of leading entries <= key of a non-decreasing array (one thread)
+// ---- suffix-tree node table over block-distributed SA / LCP (suffix_tree.hpp:43-223 for_each_parent, :440-499)
+// For the LCP index i = off + j: the parent of leaf n + i and (when there is one) of internal node i, from the ANSV of LCP
+// (left furthest_eq, right nearest_sm, suffix_tree.hpp:62) and the LCP values found there; q = the text position whose
+// character labels the edge.  An index without an internal-node record gets parent = i and q2 = ST_NOREC.
+constexpr uint64_t ST_NOREC = ~0ull;
+template <typename T>
+__global__ void st_parents_kernel(const T* __restrict__ LCP, const T* __restrict__ SA, uint64_t m, uint64_t off, uint64_t n,
+                                  const uint64_t* __restrict__ lnsv, const uint64_t* __restrict__ rnsv, const T* __restrict__ lcp_l,
+                                  const T* __restrict__ lcp_r, int has_next, T next_lcp, T* __restrict__ p1, uint64_t* __restrict__ q1,
+                                  T* __restrict__ p2, uint64_t* __restrict__ q2) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const uint64_t i = off + j, ln = lnsv[j], rn = rnsv[j], sa = SA[j], li = LCP[j];
+        const uint64_t lnext = j + 1 < m ? (uint64_t)LCP[j + 1] : (has_next ? (uint64_t)next_lcp : 0);
+        const uint64_t lv = ln != NSV_NONE ? (uint64_t)lcp_l[j] : 0, rv = rn != NSV_NONE ? (uint64_t)lcp_r[j] : 0;
+        uint64_t parent, lcp_val;
+        if (i == 0) { lcp_val = n > 1 ? lnext : 0; parent = lcp_val > 0 ? 1 : 0; }
+        else if (i == n - 1 || li >= lnext) {
+            lcp_val = lv;
+            if (ln != NSV_NONE && lcp_val == li) parent = ln; else { parent = i; lcp_val = li; }
+        } else { parent = i + 1; lcp_val = lnext; }
+        p1[j] = (T)parent; q1[j] = sa + lcp_val;
+        bool rec = !(i == 0 || li == 0);
+        if (rec) {
+            if (rn == NSV_NONE) { if (lv == li) rec = false; else { parent = ln; lcp_val = lv; } }
+            else if (lv >= rv) { if (lv == li) rec = false; else { parent = ln; lcp_val = lv; } }
+            else { parent = rn; lcp_val = rv; }
+        }
+        p2[j] = rec ? (T)parent : (T)i;
+        q2[j] = rec ? sa + lcp_val : ST_NOREC;
+    }
+}
+// the positions as index words for the bulk fetch (past the end / no record: position 0, the answer is not used)
+template <typename T>
+__global__ void st_positions_kernel(const uint64_t* __restrict__ q, uint64_t m, uint64_t n, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = q[j] < n ? (T)q[j] : (T)0;
+}
+template <typename T>
+__global__ void st_nsv_positions_kernel(const uint64_t* __restrict__ q, uint64_t m, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = q[j] != NSV_NONE ? (T)q[j] : (T)0;
+}
+// what travels to the owner of the parent's row: x = the LCP index the child stands for, y = column | leaf flag << 16
+// (0xFFFF: no record)
+template <typename T>
+__global__ void st_payload_kernel(const uint64_t* __restrict__ q, const T* __restrict__ ch, uint64_t m, uint64_t off, uint64_t n, CodeTable tab,
+                                  int leaf, T* __restrict__ x, T* __restrict__ y) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        x[j] = (T)(off + j);
+        if (q[j] == ST_NOREC) y[j] = (T)0xFFFFu;
+        else y[j] = (T)((q[j] < n ? (unsigned)tab.c[(unsigned)ch[j] & 255u] : 0u) | ((unsigned)leaf << 16));
+    }
+}
+template <typename T>
+__global__ void st_put_kernel(unsigned long long* __restrict__ nodes, uint64_t off, uint64_t row, const T* __restrict__ pos, const T* __restrict__ x,
+                              const T* __restrict__ y, uint64_t cnt, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const unsigned yy = (unsigned)y[j];
+        if ((yy & 0xFFFFu) == 0xFFFFu) continue;
+        nodes[((uint64_t)pos[j] - off) * row + (yy & 0xFFFFu)] = (yy >> 16) ? n + (uint64_t)x[j] : (uint64_t)x[j];
+    }
+}
+
 template <typename T> __global__ void upper_bound_kernel(const T* __restrict__ a, uint64_t n, uint64_t key, uint64_t* __restrict__ out) {
     uint64_t lo = 0, hi = n;
     while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)a[mid] <= key) lo = mid + 1; else hi = mid; }
@@ -2727,6 +2793,156 @@ struct MultiRun {
                 psacx_ctx* c = ctx(i);
                 OP_PROLOGUE(c);
                 SIMPLE_LAUNCH(c, (lc_narrow_kernel<T>), cnt[i], (const T*)ch[i].p, (const T*)qs[i].p, cnt[i], n, d_lc[i] + from[i]);
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                return PSACX_OK;
+            }));
+        }
+        return PSACX_OK;
+    }
+
+    // Suffix-tree node table of a block-distributed SA / LCP (construct_suffix_tree on p ranks, suffix_tree.hpp:413-499): rank r
+    // receives the rows of the LCP indices of its block, nodes[i][(sigma + 1) columns], column c = the child reached through
+    // the character with alphabet code c (0 = end of text), leaves numbered n + i, 0 = none.  Parents from the distributed
+    // ANSV of LCP (suffix_tree.hpp:62), the LCP values at the parents and the edge characters S[SA[i] + lcp] through the bulk
+    // fetch (dist_take), the cells to the owners of the parents' rows like bulk_permute's (index, value) pairs.
+    // d_nodes == nullptr: only *sigma is computed (the size query of psacx_suffix_tree_*).
+    int suffix_tree(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
+                    const std::vector<T*>& d_lcp, const std::vector<unsigned long long*>* d_nodes, uint32_t* sigma) {
+        want_lcp = true;
+        // ---- alphabet over all blocks (alphabet.hpp:147-164: codes 1 .. sigma in byte order)
+        CodeTable tab;
+        {
+            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(256, 0));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+                DBuf<unsigned long long> h; MG_OP(g, c, h.alloc(c, 256));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(h.p, 0, 256 * 8, c->stream));
+                if (m_local[i]) {
+                    hipLaunchKernelGGL((char_hist_kernel<256>), dim3(grid_for(c, m_local[i] / 16 + 1, 256, 8)), dim3(256), 0, c->stream, text[i], m_local[i], h.p);
+                    MG_HIP(g, hipGetLastError());
+                }
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, h.p, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                std::memcpy(mine[i].data(), c->pinned + 32768, 256 * 8);
+                return PSACX_OK;
+            }));
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather(256, mine, all));
+            uint16_t next = 1;
+            for (int ch = 0; ch < 256; ++ch) {
+                uint64_t tot = 0;
+                for (int r = 0; r < P; ++r) tot += all[(size_t)r * 256 + ch];
+                tab.c[ch] = tot ? next++ : (uint16_t)0;
+            }
+            *sigma = next - 1u;
+        }
+        if (!d_nodes) return PSACX_OK;
+        const uint64_t row = (uint64_t)*sigma + 1;
+        // ---- ANSV of LCP: left furthest_eq, right nearest_sm
+        std::vector<DBuf<uint64_t>> ln(L), rn(L);
+        {
+            std::vector<const T*> blk(L); std::vector<uint64_t*> ol(L), orr(L);
+            for (int i = 0; i < L; ++i) {
+                MG_OP(g, ctx(i), ln[i].alloc(ctx(i), m_local[i])); MG_OP(g, ctx(i), rn[i].alloc(ctx(i), m_local[i]));
+                blk[i] = d_lcp[i]; ol[i] = ln[i].p; orr[i] = rn[i].p;
+            }
+            PSACX_TRY(ansv(blk, m_local, 2, 0, NSV_NONE, ol, orr));          // (sets sizes / offs / n)
+        }
+        S.resize(L);
+        for (int i = 0; i < L; ++i) {
+            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i]; S[i].SA = d_sa[i]; S[i].ISA = nullptr; S[i].LCP = d_lcp[i];
+            S[i].off = offs[rank(i)];
+        }
+        // ---- LCP at the two parents; the first LCP entry of the next block
+        std::vector<DBuf<T>> lcp_l, lcp_r;
+        {
+            std::vector<DBuf<T>> pl(L), pr(L);
+            std::vector<const T*> blk(L), g1(L), g2(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, pl[i].alloc(c, S[i].m)); MG_OP(g, c, pr[i].alloc(c, S[i].m));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (st_nsv_positions_kernel<T>), S[i].m, (const uint64_t*)ln[i].p, S[i].m, pl[i].p);
+                SIMPLE_LAUNCH(c, (st_nsv_positions_kernel<T>), S[i].m, (const uint64_t*)rn[i].p, S[i].m, pr[i].p);
+                blk[i] = S[i].LCP; g1[i] = pl[i].p; g2[i] = pr[i].p;
+                return PSACX_OK;
+            }));
+            PSACX_TRY(dist_take(blk, g1, m_local, lcp_l));
+            PSACX_TRY(dist_take(blk, g2, m_local, lcp_r));
+        }
+        std::vector<psacx_boundary> edge;
+        {
+            std::vector<const T*> a1(L);
+            for (int i = 0; i < L; ++i) a1[i] = S[i].LCP;
+            PSACX_TRY(neighbours(a1, a1, a1, m_local, 1, edge));
+        }
+        // ---- parents and edge positions, edge characters
+        std::vector<DBuf<T>> p1(L), p2(L);
+        std::vector<DBuf<uint64_t>> q1(L), q2(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, p1[i].alloc(c, S[i].m)); MG_OP(g, c, p2[i].alloc(c, S[i].m)); MG_OP(g, c, q1[i].alloc(c, S[i].m)); MG_OP(g, c, q2[i].alloc(c, S[i].m));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (st_parents_kernel<T>), S[i].m, (const T*)S[i].LCP, (const T*)S[i].SA, S[i].m, S[i].off, n, (const uint64_t*)ln[i].p, (const uint64_t*)rn[i].p,
+                          (const T*)lcp_l[i].p, (const T*)lcp_r[i].p, (int)edge[i].has_next, (T)edge[i].next[0], p1[i].p, q1[i].p, p2[i].p, q2[i].p);
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            return PSACX_OK;
+        }));
+        for (int i = 0; i < L; ++i) { ln[i].release(); rn[i].release(); lcp_l[i].release(); lcp_r[i].release(); }
+        std::vector<DBuf<T>> wide(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            MG_OP(g, c, wide[i].alloc(c, S[i].m));
+            MG_HIP(g, hipSetDevice(c->device));
+            MG_HIP(g, hipMemsetAsync((*d_nodes)[i], 0, S[i].m * row * sizeof(unsigned long long), c->stream));
+            OP_PROLOGUE(c);
+            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
+            return PSACX_OK;
+        }));
+        for (int which = 0; which < 2; ++which) {
+            std::vector<DBuf<uint64_t>>& q = which ? q2 : q1;
+            std::vector<DBuf<T>>& par_ = which ? p2 : p1;
+            std::vector<DBuf<T>> qs(L), ch, x(L), y(L);
+            std::vector<const T*> blk(L), gi(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, qs[i].alloc(c, S[i].m));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (st_positions_kernel<T>), S[i].m, (const uint64_t*)q[i].p, S[i].m, n, qs[i].p);
+                blk[i] = wide[i].p; gi[i] = qs[i].p;
+                return PSACX_OK;
+            }));
+            PSACX_TRY(dist_take(blk, gi, m_local, ch));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, x[i].alloc(c, S[i].m)); MG_OP(g, c, y[i].alloc(c, S[i].m));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (st_payload_kernel<T>), S[i].m, (const uint64_t*)q[i].p, (const T*)ch[i].p, S[i].m, S[i].off, n, tab, which == 0 ? 1 : 0, x[i].p, y[i].p);
+                return PSACX_OK;
+            }));
+            // the cells to the owners of their rows: the same stable partition by owner for both payload words
+            std::vector<const T*> pos(L), xs(L), ys(L);
+            std::vector<uint64_t> tot(L);
+            std::vector<Rec<T>> r1(L), r2(L);
+            std::vector<std::vector<DBuf<T>>> got1, got2;
+            if (solo_) { for (int i = 0; i < L; ++i) { pos[i] = par_[i].p; xs[i] = x[i].p; ys[i] = y[i].p; tot[i] = S[i].m; } }
+            else {
+                std::vector<std::vector<uint64_t>> b1(L), b2(L), rc;
+                std::vector<std::vector<const T*>> in1(L), in2(L);
+                for (int i = 0; i < L; ++i) {
+                    PSACX_TRY(route(i, par_[i].p, x[i].p, S[i].m, r1[i], b1[i])); in1[i] = {r1[i].k2.p, r1[i].v.p};
+                    PSACX_TRY(route(i, par_[i].p, y[i].p, S[i].m, r2[i], b2[i])); in2[i] = {r2[i].v.p};
+                }
+                PSACX_TRY(exchange<T>(2, in1, b1, got1, rc));
+                PSACX_TRY(exchange<T>(1, in2, b2, got2, rc));
+                for (int i = 0; i < L; ++i) { pos[i] = got1[i][0].p; xs[i] = got1[i][1].p; ys[i] = got2[i][0].p; tot[i] = got1[i][0].n; }
+            }
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (st_put_kernel<T>), tot[i], (*d_nodes)[i], S[i].off, row, pos[i], xs[i], ys[i], tot[i], n);
                 MG_HIP(g, hipStreamSynchronize(c->stream));
                 return PSACX_OK;
             }));

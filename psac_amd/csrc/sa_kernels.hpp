@@ -326,8 +326,9 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
         if (e < wend) {
             if (e == 0 && !bd.has_prev) head = true;
             else {
-                const T x1 = A1[e], x2 = A2[e];
-                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = e ? A2[e - 1] : bd.prev2;
+                // (A2 == nullptr: 64-bit words holding both 32-bit keys of a refinement record, K1 << 32 | K2)
+                const T x1 = A1[e], x2 = A2 ? A2[e] : (T)((uint64_t)x1 & 0xFFFFFFFFull);
+                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = A2 ? (e ? A2[e - 1] : bd.prev2) : (T)((uint64_t)y1 & 0xFFFFFFFFull);
                 head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
                 if (!REFINE && !head) {
                     // equal packed windows: still a boundary if either suffix is shorter than 2k
@@ -1012,8 +1013,53 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
         // 1-based bucket id, 0 = past the end of the text, or of the own string (suffix_array.hpp:1010-1016)
         const bool inside = slen ? h < (uint64_t)slen[sa] : q < n;
         const T b2 = inside ? (T)(ISA[q] + 1) : (T)0;
-        K1[j] = b1; K2[j] = b2; V[j] = sa;
-        o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2;
+        if (K2) { K1[j] = b1; K2[j] = b2; V[j] = sa; o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2; }
+        else {
+            // both keys in one 64-bit word, the suffix as a 32-bit entry (texts below 2^32 characters): two-word records
+            const T kk = (T)(((uint64_t)b1 << 32) | (uint64_t)b2);
+            K1[j] = kk; reinterpret_cast<uint32_t*>(V)[j] = (uint32_t)sa; o1 |= kk; a1 &= kk;
+        }
+    }
+    key_summary_add<T>(summary, o1, a1, o2, a2);
+}
+
+// How local is a walk through the text in SA order?  near[0] += the pairs of neighbouring SA entries (out of `samples`
+// evenly spread ones) that lie within 64 text positions of each other.  Mostly near (one symbol repeated: SA is the text
+// backwards): the fetch of the ranks h further and the ISA stores of a round are streams already, and sorting all n
+// records in text order would only add work.  Mostly far (a tandem repeat: every bucket walks the text in strides of the
+// period): the whole-round form below turns them into streams.
+template <typename T>
+__global__ void sa_locality_kernel(const T* __restrict__ SA, uint64_t n, uint64_t samples, unsigned long long* __restrict__ near) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned mine = 0;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < samples; s += stride) {
+        // runs of 64 consecutive positions, the runs spread evenly over the array
+        const uint64_t runs = (samples + 63) / 64, r = s / 64;
+        const uint64_t p = (uint64_t)(((unsigned __int128)r * (n - 65)) / runs) + (s % 64);
+        const uint64_t a = SA[p], b = SA[p + 1];
+        mine += (a > b ? a - b : b - a) < 64 ? 1u : 0u;
+    }
+    if (mine) atomicAdd(near, (unsigned long long)mine);
+}
+
+// The same records for ALL suffixes in text order (what psac's doubling rounds sort, suffix_array.hpp:381-450 with
+// shifting.hpp:33-122): K1[i] = id of suffix i, K2[i] = id of suffix i + h, V[i] = i -- two streaming reads of ISA
+// instead of one random read per record.  Used for rounds in which almost every suffix is still unresolved.
+template <typename T>
+__global__ void shift_keys_kernel(const T* __restrict__ ISA, uint64_t n, uint64_t h, T* __restrict__ K1, T* __restrict__ K2,
+                                  T* __restrict__ V, unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t q = i + h;
+        const T b1 = (T)(ISA[i] + 1);
+        const bool inside = slen ? h < (uint64_t)slen[i] : q < n;
+        const T b2 = inside ? (T)(ISA[q] + 1) : (T)0;
+        if (K2) { K1[i] = b1; K2[i] = b2; V[i] = (T)i; o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2; }
+        else {
+            const T kk = (T)(((uint64_t)b1 << 32) | (uint64_t)b2);
+            K1[i] = kk; reinterpret_cast<uint32_t*>(V)[i] = (uint32_t)i; o1 |= kk; a1 &= kk;
+        }
     }
     key_summary_add<T>(summary, o1, a1, o2, a2);
 }
@@ -1142,21 +1188,31 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
+    // K2 == nullptr: both keys of a record in one 64-bit word (K1 << 32 | K2; texts below 2^32 characters, one GPU)
+    const bool both = K2 == nullptr;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
     load_run<T, ITEMS>(K1, e0, cnt, a1, (T)0);
-    load_run<T, ITEMS>(K2, e0, cnt, a2, (T)0);
+    if (!both) load_run<T, ITEMS>(K2, e0, cnt, a2, (T)0);
+    else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { a2[j] = (T)((uint64_t)a1[j] & 0xFFFFFFFFull); a1[j] = (T)((uint64_t)a1[j] >> 32); }
+    }
     if (pos) load_run<T, ITEMS>(pos, e0, cnt, ps, (T)0);
     else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) ps[j] = (T)(e0 + j);
     }
     T p1 = 0, p2 = 0;
-    if (e0 > 0 && e0 - 1 < cnt) { p1 = K1[e0 - 1]; p2 = K2[e0 - 1]; }
+    if (e0 > 0 && e0 - 1 < cnt) {
+        p1 = K1[e0 - 1];
+        if (both) { p2 = (T)((uint64_t)p1 & 0xFFFFFFFFull); p1 = (T)((uint64_t)p1 >> 32); } else p2 = K2[e0 - 1];
+    }
     else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; }
     bool next_head = true;
     if (e0 + ITEMS <= cnt && (e0 + ITEMS < cnt || bd.has_next)) {
         const bool in = e0 + ITEMS < cnt;
-        const T q1 = in ? K1[e0 + ITEMS] : bd.next1, q2 = in ? K2[e0 + ITEMS] : bd.next2;
+        T q1 = in ? K1[e0 + ITEMS] : bd.next1, q2 = in ? (both ? (T)0 : K2[e0 + ITEMS]) : bd.next2;
+        if (in && both) { q2 = (T)((uint64_t)q1 & 0xFFFFFFFFull); q1 = (T)((uint64_t)q1 >> 32); }
         next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
     }
 
@@ -1223,7 +1279,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         if (e < cnt) {
             SA[(uint64_t)ps[j] - bd.off] = sa[j];
             Bsa[(uint64_t)ps[j] - bd.off] = id[j];
-            if (!DIST) ISA[sa[j]] = id[j] - 1;
+            if (!DIST && ISA) ISA[sa[j]] = id[j] - 1;
         }
     }
     store_run<T, ITEMS>(ids_out, e0, cnt, id);

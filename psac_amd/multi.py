@@ -154,6 +154,20 @@ class MultiContext(object):
         fn = getattr(self._lib, "psacx_multi_left_chars_dev_u%d" % index_bits)
         self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_lcp), vp(*d_lc)))
 
+    def suffix_tree_device(self, d_text, m, d_sa, d_lcp, d_nodes, index_bits):
+        """construct_suffix_tree on p ranks (suffix_tree.hpp:413-499) over blocks resident in HBM: d_nodes[i] receives the
+        m[i] x (sigma + 1) rows of local rank i's LCP indices (uint64 cells); d_nodes=None only returns sigma."""
+        L = self.nlocal
+        vp = C.c_void_p * L
+        mm = (C.c_uint64 * L)(*[int(x) for x in m])
+        sg = C.c_uint32(0)
+        fn = getattr(self._lib, "psacx_multi_suffix_tree_dev_u%d" % index_bits)
+        if d_nodes is None:
+            self.check(fn(self.handle, vp(*d_text), mm, None, None, None, C.byref(sg)))
+        else:
+            self.check(fn(self.handle, vp(*d_text), mm, vp(*d_sa), vp(*d_lcp), vp(*d_nodes), C.byref(sg)))
+        return int(sg.value)
+
     def ansv_device(self, d_in, m, d_left, d_right, index_bits, left_type=0, right_type=0, nonsv=0):
         """ansv<T, left_type, right_type, global_indexing> over a block-distributed array resident in HBM (lists of raw
         device addresses, one per local rank; results are uint64 global indices)."""

@@ -222,6 +222,13 @@ def test_psac_cli_and_cpp_header_on_several_ranks(tmp_path):
     ref = O.construct(text, bits=32)
     assert np.array_equal(np.fromfile(str(tmp_path / "m.sa64"), np.uint64), ref["SA"].astype(np.uint64))
     assert np.array_equal(np.fromfile(str(tmp_path / "m.lcp64"), np.uint64), ref["LCP"].astype(np.uint64))
+    # psac -t on several ranks (src/psac.cpp:96-114): the same number of suffix-tree edges as on one
+    edges = []
+    for extra in ([], ["--gpus-on-device", "0,3"]):
+        r = subprocess.run([psac, "-f", str(f), "-t"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0 and "ST time:" in r.stderr, r.stderr
+        edges.append([ln for ln in r.stderr.splitlines() if ln.startswith("ST edges:")])
+    assert edges[0] and edges[0] == edges[1]
     src = tmp_path / "p.cpp"
     src.write_text(r'''
 #include "suffix_array.hpp"
@@ -253,6 +260,10 @@ int main() {
         const size_t p = (size_t)lc4.local_SA[i - 1] + (size_t)lc4.local_LCP[i];
         if (lc4.local_Lc[i] != (p < s.size() ? s[p] : '\0')) return 6;
     }
+    // the suffix-tree node table built by the four ranks of the suffix array's communicator (suffix_tree.hpp:413-499)
+    std::vector<size_t> t1 = construct_suffix_tree(one, s.begin(), s.begin() + 50000, psacx::comm(0));
+    std::vector<size_t> t4 = construct_suffix_tree(many, s.begin(), s.begin() + 50000, psacx::comm(std::vector<int>(4, 0)));
+    if (t1.size() != 5 * 50000u || t1 != t4) return 7;
     std::puts("ok");
     return 0;
 }
@@ -612,6 +623,61 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
             assert used >= (len(cases) - 1 if mode == "2" else 2), used      # (DNA on 32-bit words: word 1 is shorter than the leading bits)
         finally:
             mg.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_suffix_tree_node_table(P):
+    # psacx_multi_suffix_tree_dev_*: construct_suffix_tree on p ranks (suffix_tree.hpp:413-499) -- the rows of the node table
+    # block-distributed like LCP, against the reference's mississippi table (test/test_suffixtree.cpp:68-83) and the oracle's
+    # one-rank restatement for the shapes of test/test_suffixtree.cpp:89-162 (random DNA, (abc)^n) and a larger alphabet
+    import ctypes as C
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kat.json")))["mississippi"]
+    mg = multi(P)
+    lib = mg._lib
+    try:
+        cases = [(O.as_text(kat["text"]), 64), (O.rand_dna(116, 13), 64), (O.rand_dna(1000, 13), 32), (O.rand_dna(23713, 13), 64),
+                 (inputs.cyclic(3000, "abc"), 32), (inputs.ascii128(5000, 2), 64), (inputs.tandem(4000, 64, O.rand_dna(64, 3)), 32)]
+        for text, bits in cases:
+            n = text.size
+            if n < P:
+                continue
+            w = bits // 8
+            udt = np.uint32 if bits == 32 else np.uint64
+            ref = O.construct(text, bits=bits)
+            want = O.suffix_tree(text, ref["SA"], ref["LCP"])
+            sizes = [n // P + (1 if r < n % P else 0) for r in range(P)]
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            held = []
+
+            def alloc(ctx, nbytes):
+                p = C.c_void_p()
+                assert lib.psacx_dev_alloc(ctx, C.byref(p), max(int(nbytes), 1)) == 0
+                held.append((ctx, p))
+                return p.value
+            d_t, d_sa, d_lcp = [], [], []
+            for r in range(P):
+                ctx = mg.rank_ctx(r)
+                d_t.append(alloc(ctx, sizes[r])); d_sa.append(alloc(ctx, sizes[r] * w)); d_lcp.append(alloc(ctx, sizes[r] * w))
+                for dst, arr in ((d_t[r], text), (d_sa[r], ref["SA"].astype(udt)), (d_lcp[r], ref["LCP"].astype(udt))):
+                    blk = np.ascontiguousarray(arr[offs[r]:offs[r + 1]])
+                    assert lib.psacx_copy_h2d(ctx, C.c_void_p(dst), blk.ctypes.data_as(C.c_void_p), blk.nbytes) == 0
+            sigma = mg.suffix_tree_device(d_t, sizes, None, None, None, bits)
+            assert sigma == want.shape[1] - 1
+            d_nodes = [alloc(mg.rank_ctx(r), sizes[r] * (sigma + 1) * 8) for r in range(P)]
+            assert mg.suffix_tree_device(d_t, sizes, d_sa, d_lcp, d_nodes, bits) == sigma
+            got = np.empty((n, sigma + 1), np.uint64)
+            for r in range(P):
+                blk = got[offs[r]:offs[r + 1]]
+                assert lib.psacx_copy_d2h(mg.rank_ctx(r), blk.ctypes.data_as(C.c_void_p), C.c_void_p(d_nodes[r]), blk.nbytes) == 0
+            assert np.array_equal(got, want), (P, bits, n)
+            if text.size == len(kat["text"]):
+                assert got.reshape(-1).tolist() == kat["suffix_tree_nodes"]
+            for ctx, p in held:
+                lib.psacx_dev_free(ctx, p)
+    finally:
+        mg.close()
 
 
 @pytest.mark.parametrize("P,entry_bytes,local", [(1, 1, 0), (2, 2, 0), (3, 1, 1), (7, 2, 1), (4, 1, 0)])

@@ -763,6 +763,23 @@ def test_packed_payload_form_of_the_prefix_sort(ctx, monkeypatch, entry_bytes):
     same_as_oracle(ctx, inputs.dna((1 << 21) + 9, 7), bits=64)
 
 
+@pytest.mark.parametrize("env", [{}, {"PSACX_NO_WHOLE_ROUNDS": "1"}, {"PSACX_WIDE_REFINE": "1"}, {"PSACX_NO_WHOLE_ROUNDS": "1", "PSACX_WIDE_REFINE": "1"}])
+def test_refinement_round_forms(ctx, monkeypatch, env):
+    # rounds with at least 7/8 of the suffixes unresolved take all n records in text order and rebuild ISA by inverting SA
+    # (shift_keys_kernel; not when SA order is nearly text order: sa_locality_kernel); 64-bit words below 2^32 characters
+    # sort two-word records (bucket id and rank h further in one word, 32-bit suffix) from 2^21 records on.  Every form
+    # must give the arrays and the per-round log of the list form with three-word records.
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    texts = [inputs.tandem((1 << 21) + 3000, 512, inputs.dna(512, 3)), np.full((1 << 21) + 17, 67, np.uint8),
+             np.tile(inputs.dna(1 << 11, 9), (1 << 10) + 1)]
+    texts[2][::4099] = 84
+    for text in texts:
+        for bits in (64, 32):
+            got, ref = same_as_oracle(ctx, text, bits=bits)
+            assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+
+
 def test_ansv_device_resident(ctx):
     # psacx_ansv_dev_*: LCP left in HBM by the construction -> ANSV without leaving the device (psac -t's
     # pair: left furthest_eq, right nearest_sm, suffix_tree.hpp:62); 2^24 characters, compared with the oracle

@@ -36,5 +36,9 @@ for name, text in (("tandem(2^%d, %d)" % (logn, period), inputs.tandem(n, period
         err = mg.check_device([d_text], [n], [d_sa], [d_isa], [d_lcp], bits)
         mg.close()
     print("%s uint%d: %.3f ms, %d rounds -> %.3f ms per round; check %s" % (name, bits, best * 1e3, s.n_rounds, best * 1e3 / s.n_rounds, err))
+    s = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp, profile=True)
+    print("   phases of one construction (ms, HIP events): keys %.1f, sort hist %.1f, tile hist %.1f, scatter %.1f, rebucket %.1f, isa %.1f, gather %.1f, compact %.1f, rmq %.1f, total %.1f"
+          % (s.ms_kmer, s.ms_sort_hist, s.ms_sort_tilehist, s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, s.ms_rebucket, s.ms_isa_scatter, s.ms_gather,
+             s.ms_compact, s.ms_rmq_build, s.ms_total))
     for p in (d_text, d_sa, d_isa, d_lcp):
         ctx.free(p)
