@@ -300,6 +300,20 @@ int psacx_multi_ansv_dev_u32(psacx_multi* mg, const uint32_t* const* d_in, const
                              uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
 int psacx_multi_ansv_dev_u64(psacx_multi* mg, const uint64_t* const* d_in, const uint64_t* m, int left_type, int right_type,
                              uint64_t nonsv, uint64_t* const* d_left, uint64_t* const* d_right);
+/* construct_ss (suffix_array.hpp:267-363: the generalized suffix array of a string set) on p ranks: the strings lie back to
+ * back without separators in the block-distributed text (kmer.hpp:269-355 cuts every k-mer at its string's end,
+ * shifting.hpp:374-418 answers "the suffix h further" with 0 beyond it, bucketing.hpp:130-143 the bucket rules); offsets =
+ * the nstr + 1 ascending GLOBAL offsets of the strings (host array, the same on every rank; offsets[0] = 0,
+ * offsets[nstr] = n, no empty string).  Results as psacx_construct_gsa_*, block-distributed as psacx_multi_construct_dev_*. */
+int psacx_multi_construct_gsa_dev_u32(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* offsets, uint64_t nstr,
+                                      uint32_t k, uint32_t flags, uint32_t* const* d_SA, uint32_t* const* d_ISA, uint32_t* const* d_LCP);
+int psacx_multi_construct_gsa_dev_u64(psacx_multi* mg, const uint8_t* const* d_text, const uint64_t* m, const uint64_t* offsets, uint64_t nstr,
+                                      uint32_t k, uint32_t flags, uint64_t* const* d_SA, uint64_t* const* d_ISA, uint64_t* const* d_LCP);
+/* the host-pointer form (every rank in this process): the signature of psacx_construct_gsa_* */
+int psacx_multi_construct_gsa_u32(psacx_multi* mg, const uint8_t* text, uint64_t n, const uint64_t* offsets, uint64_t nstr, uint32_t k,
+                                  uint32_t flags, uint32_t* SA, uint32_t* ISA, uint32_t* LCP);
+int psacx_multi_construct_gsa_u64(psacx_multi* mg, const uint8_t* text, uint64_t n, const uint64_t* offsets, uint64_t nstr, uint32_t k,
+                                  uint32_t flags, uint64_t* SA, uint64_t* ISA, uint64_t* LCP);
 /* construct_suffix_tree(sa, begin, end, comm) on p ranks (suffix_tree.hpp:413-499; parents by for_each_parent :43-223 from
  * the ANSV of LCP :62, cells sent to the owners of their rows like bulk_permute's pairs): d_nodes[i] receives the rows of the
  * LCP indices of local rank i's block, m[i] x (sigma + 1) cells of 64 bits, row-major; cell (j, c) = the child of internal

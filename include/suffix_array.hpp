@@ -261,7 +261,6 @@ public:
     void construct_ss(simple_dstringset& ss, const alphabet_type& a) {
         static_assert(sizeof(char_t) == 1, "string sets hold bytes");
         static_assert(!_CONSTRUCT_LC, "left-branching characters are not defined for string sets");
-        if (multi_) throw std::runtime_error("psacx: string sets need a single-rank communicator");
         init_size(ss.sum_sizes);
         if (n == 0) throw std::runtime_error("psacx: empty input");
         std::vector<uint8_t> bytes; bytes.reserve(n);
@@ -274,10 +273,18 @@ public:
         local_SA.assign(n, 0); local_B.assign(n, 0);
         if (_CONSTRUCT_LCP) local_LCP.assign(n, 0); else local_LCP.clear();
         const uint32_t flags = _CONSTRUCT_LCP ? PSACX_LCP : 0u;
-        psacx::check(ctx_, run_gsa(bytes.data(), off.data(), (uint64_t)ss.sizes.size(), flags, local_SA.data(), local_B.data(),
-                                   _CONSTRUCT_LCP ? local_LCP.data() : nullptr));
         psacx_stats st;
-        psacx::check(ctx_, psacx_get_stats(ctx_, &st));
+        if (multi_) {
+            // p > 1: the strings lie back to back in the block-distributed text (psacx_multi_construct_gsa_*)
+            const int rc = run_gsa_multi(bytes.data(), off.data(), (uint64_t)ss.sizes.size(), flags, local_SA.data(), local_B.data(),
+                                         _CONSTRUCT_LCP ? local_LCP.data() : nullptr);
+            if (rc != PSACX_OK) throw std::runtime_error(std::string("psacx: ") + psacx_strerror(rc) + " [" + psacx_multi_last_error(multi_) + "]");
+            psacx::check(nullptr, psacx_multi_get_stats(multi_, &st, nullptr, nullptr, nullptr));
+        } else {
+            psacx::check(ctx_, run_gsa(bytes.data(), off.data(), (uint64_t)ss.sizes.size(), flags, local_SA.data(), local_B.data(),
+                                       _CONSTRUCT_LCP ? local_LCP.data() : nullptr));
+            psacx::check(ctx_, psacx_get_stats(ctx_, &st));
+        }
         alpha = a;
         if (verbose) {
             PSACX_INFO("Alphabet: " << alpha);                       // suffix_array.hpp:273-275
@@ -341,6 +348,18 @@ private:
     }
     int run_gsa(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
         return psacx_construct_gsa_u64(ctx_, t, n, off, m, 0, flags, sa, isa, lcp);
+    }
+    int run_gsa_multi(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
+        return psacx_multi_construct_gsa_u32(multi_, t, n, off, m, 0, flags, sa, isa, lcp);
+    }
+    int run_gsa_multi(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, uint64_t* sa, uint64_t* isa, uint64_t* lcp) {
+        return psacx_multi_construct_gsa_u64(multi_, t, n, off, m, 0, flags, sa, isa, lcp);
+    }
+    template <typename U>
+    typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type
+    run_gsa_multi(const uint8_t* t, const uint64_t* off, uint64_t m, uint32_t flags, U* sa, U* isa, U* lcp) {
+        typedef typename std::conditional<sizeof(U) == 4, uint32_t, uint64_t>::type W;
+        return run_gsa_multi(t, off, m, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp));
     }
     template <typename U>
     typename std::enable_if<!std::is_same<U, uint32_t>::value && !std::is_same<U, uint64_t>::value, int>::type

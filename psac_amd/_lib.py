@@ -28,6 +28,7 @@ EXPORTS = [
     "psacx_multi_nlocal", "psacx_multi_uses_rccl", "psacx_multi_last_error", "psacx_multi_ctx", "psacx_multi_construct_dev_u32",
     "psacx_multi_construct_dev_u64", "psacx_multi_construct_u32", "psacx_multi_construct_u64", "psacx_multi_get_stats",
     "psacx_multi_check_dev_u32", "psacx_multi_check_dev_u64", "psacx_multi_ansv_dev_u32", "psacx_multi_ansv_dev_u64",
+    "psacx_multi_construct_gsa_dev_u32", "psacx_multi_construct_gsa_dev_u64", "psacx_multi_construct_gsa_u32", "psacx_multi_construct_gsa_u64",
     "psacx_multi_suffix_tree_dev_u32", "psacx_multi_suffix_tree_dev_u64", "psacx_multi_suffix_tree_u32", "psacx_multi_suffix_tree_u64",
     "psacx_multi_left_chars_dev_u32", "psacx_multi_left_chars_dev_u64", "psacx_multi_construct_lc_u32", "psacx_multi_construct_lc_u64",
     "psacx_multi_configure", "psacx_multi_get_memory", "psacx_multi_transport", "psacx_multi_get_wire", "psacx_multi_get_phases", "psacx_multi_last_form",
@@ -127,6 +128,8 @@ def load():
         getattr(lib, "psacx_multi_left_chars_dev_" + suf).argtypes = [vp, vp, vp, vp, vp, vp]
         getattr(lib, "psacx_multi_suffix_tree_dev_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(u32)]
         getattr(lib, "psacx_multi_suffix_tree_" + suf).argtypes = [vp, vp, u64, vp, vp, vp, C.POINTER(u32)]
+        getattr(lib, "psacx_multi_construct_gsa_dev_" + suf).argtypes = [vp, vp, vp, vp, u64, u32, u32, vp, vp, vp]
+        getattr(lib, "psacx_multi_construct_gsa_" + suf).argtypes = [vp, vp, u64, vp, u64, u32, u32, vp, vp, vp]
         getattr(lib, "psacx_multi_construct_lc_" + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp, vp]
         getattr(lib, "psacx_multi_ansv_dev_" + suf).argtypes = [vp, vp, vp, i32, i32, u64, vp, vp]
     lib.psacx_multi_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]

@@ -39,7 +39,7 @@ struct Args {
                 val[a] = argv[++i];
             } else if (a.size() == 2 && a[0] == '-' && switches.find(a[1]) != std::string::npos) {
                 val[a] = "1";
-            } else if (a == "--device" && i + 1 < argc) {
+            } else if ((a == "--device" || a == "--gpus" || a == "--gpus-on-device") && i + 1 < argc) {
                 val[a] = argv[++i];
             } else { std::cerr << "error: unknown argument " << a << std::endl; ok = false; return; }
         }

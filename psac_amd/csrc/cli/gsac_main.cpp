@@ -56,12 +56,13 @@ template <typename V> static void write_u64(const std::string& fn, const std::ve
 }
 
 template <bool LCP>
-static int run(const std::string& str, bool check, const std::string& out, int device) {
+static int run(const std::string& str, bool check, const std::string& out, int device, const std::vector<int>& devices) {
     simple_dstringset ss(str.begin(), str.end(), psacx::comm(device), '\n');
     if (ss.sum_sizes == 0) { std::cerr << "error: no strings in the input" << std::endl; return EXIT_FAILURE; }
     psacx::alphabet<char> alpha = psacx::alphabet<char>::from_stringset(ss, psacx::comm(device));
     bench_cli::Clock t;
-    suffix_array<char, index_t, LCP> sa((psacx::comm(device)));
+    // --gpus N / --gpus-on-device D,N: the string set is block-distributed over the ranks of the communicator
+    suffix_array<char, index_t, LCP> sa(devices.empty() ? psacx::comm(device) : psacx::comm(devices));
     sa.construct_ss(ss, alpha);
     std::cerr << "PSAC time: " << t.elapsed() << " ms" << std::endl;
     if (check && !check_gsa<LCP>(sa, ss)) return 1;
@@ -75,15 +76,24 @@ static int run(const std::string& str, bool check, const std::string& out, int d
 int main(int argc, char** argv) {
     bench_cli::Args a(argc, argv, "fo", "lc");
     if (!a.ok || !a.has("-f")) {
-        std::cerr << "USAGE: gsac -f <filename> [-l] [-c] [-o <basename>] [--device N]\n"
+        std::cerr << "USAGE: gsac -f <filename> [-l] [-c] [-o <basename>] [--device N] [--gpus N] [--gpus-on-device D,N]\n"
                      "Parallel distributed generalized suffix array and LCP construction (MI355X engine)." << std::endl;
         return EXIT_FAILURE;
     }
     std::string str;
     if (!bench_cli::read_file(a.str("-f"), str)) { std::cerr << "error: cannot open " << a.str("-f") << std::endl; return EXIT_FAILURE; }
     const int device = (int)a.num("--device", 0);
+    std::vector<int> devices;
+    for (int i = 1; i + 1 < argc; ++i) {
+        const std::string f = argv[i], v = argv[i + 1];
+        if (f == "--gpus") for (int d = 0; d < atoi(v.c_str()); ++d) devices.push_back(d);
+        if (f == "--gpus-on-device") {
+            const std::size_t c = v.find(',');
+            devices.assign((std::size_t)std::max(c == std::string::npos ? 1 : atoi(v.substr(c + 1).c_str()), 1), atoi(v.substr(0, c).c_str()));
+        }
+    }
     try {
-        return a.has("-l") ? run<true>(str, a.has("-c"), a.str("-o"), device) : run<false>(str, a.has("-c"), a.str("-o"), device);
+        return a.has("-l") ? run<true>(str, a.has("-c"), a.str("-o"), device, devices) : run<false>(str, a.has("-c"), a.str("-o"), device, devices);
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << std::endl;
         return EXIT_FAILURE;

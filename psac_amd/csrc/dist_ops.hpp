@@ -168,7 +168,9 @@ inline int tile_scratch(psacx_ctx* c, uint64_t cnt, TileScratch& ts, size_t extr
 
 template <typename T>
 int op_make_keys(psacx_ctx* c, const uint8_t* text, uint64_t m, uint64_t text_len, const uint16_t* codes, uint32_t l,
-                 uint32_t c1, uint32_t c2, T* k1, T* k2) {
+                 uint32_t c1, uint32_t c2, T* k1, T* k2, const T* slen = nullptr) {
+    // slen (string sets, construct_ss): characters from every position of the block to the end of its string; the codes are
+    // then psac's 1 .. sigma with 0 = end and every window is cut at its string's end (key_pairs_kernel<..., GSA>)
     OP_PROLOGUE(c);
     if (m == 0) return PSACX_OK;
     CodeTable tab;
@@ -179,8 +181,12 @@ int op_make_keys(psacx_ctx* c, const uint8_t* text, uint64_t m, uint64_t text_le
     PSACX_TRY(ensure_slab(c, dry.off + 4096));
     Arena ar(c->slab);
     unsigned long long* partials = ar.take<unsigned long long>(nb * 4 + 16);
-    hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, text, m, text_len, tab,
-                       shape_of(l, c1, c2), k1, k2, partials);
+    if (slen)
+        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, text, m, text_len, tab,
+                           shape_of(l, c1, c2), k1, k2, partials, slen);
+    else
+        hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, text, m, text_len, tab,
+                           shape_of(l, c1, c2), k1, k2, partials);
     PSACX_HIP(c, hipGetLastError());
     return PSACX_OK;
 }
@@ -296,9 +302,12 @@ int op_pair_bounds(psacx_ctx* c, const T* s1, const T* s2, uint64_t n, const uin
 
 template <typename T>
 int run_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3, uint64_t cnt, uint64_t n, KeyShape ks,
-                  Boundary<T> bd, TileScratch& ts) {
+                  Boundary<T> bd, TileScratch& ts, bool gsa = false) {
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-    if (mode == 0)
+    if (mode == 0 && gsa)          // string sets: a suffix shorter than 2k shows in the end markers of its own window
+        hipLaunchKernelGGL((last_head_kernel<T, false, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, s1, s2,
+                           (const T*)nullptr, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, ts.carry, s3, ks, n, bd);
+    else if (mode == 0)
         hipLaunchKernelGGL((last_head_kernel<T, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, s1, s2,
                            (const T*)nullptr, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, ts.carry, s3, ks, n, bd);
     else
@@ -313,14 +322,14 @@ int run_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3,
 
 template <typename T>
 int op_last_head(psacx_ctx* c, int mode, const T* s1, const T* s2, const T* s3, uint64_t cnt, uint64_t n, uint32_t l,
-                 uint32_t c1, uint32_t c2, const psacx_boundary* b, uint64_t* out) {
+                 uint32_t c1, uint32_t c2, const psacx_boundary* b, uint64_t* out, bool gsa = false) {
     OP_PROLOGUE(c);
     *out = 0;
     if (cnt == 0) return PSACX_OK;
     PSACX_TRY(ensure_pinned(c, 4096));
     TileScratch ts;
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
-    PSACX_TRY(run_last_head<T>(c, mode, s1, s2, s3, cnt, n, shape_of(l, c1, c2), to_boundary<T>(b), ts));
+    PSACX_TRY(run_last_head<T>(c, mode, s1, s2, s3, cnt, n, shape_of(l, c1, c2), to_boundary<T>(b), ts, gsa));
     PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *out = *reinterpret_cast<uint64_t*>(c->pinned);
@@ -341,7 +350,7 @@ int counts_back(psacx_ctx* c, TileScratch& ts, uint64_t ntiles, uint64_t* nact, 
 
 template <typename T>
 int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint64_t cnt, uint64_t n, uint32_t l, uint32_t c1,
-                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf) {
+                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf, bool gsa = false) {
     OP_PROLOGUE(c);
     *nact = *nunf = 0;
     if (cnt == 0) return PSACX_OK;
@@ -350,9 +359,15 @@ int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint6
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
     const KeyShape ks = shape_of(l, c1, c2);
     const Boundary<T> bd = to_boundary<T>(b);
-    PSACX_TRY(run_last_head<T>(c, 0, s1, s2, sa, cnt, n, ks, bd, ts));
+    PSACX_TRY(run_last_head<T>(c, 0, s1, s2, sa, cnt, n, ks, bd, ts, gsa));
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-    if (lcp)
+    if (gsa && lcp)
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
+                           c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd);
+    else if (gsa)
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
+                           c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd);
+    else if (lcp)
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd);
     else

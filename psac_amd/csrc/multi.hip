@@ -19,7 +19,7 @@ int make_rank(psacx_multi* g, int i, int grank, int device) {
 
 template <typename T>
 int run_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, uint32_t k, uint32_t flags, T* const* sa, T* const* isa,
-            T* const* lcp) {
+            T* const* lcp, const uint64_t* str_off = nullptr, uint64_t nstr = 0) {
     if (!g || !d_text || !m || !sa || !isa) return PSACX_EINVAL;
     if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
     g->err.clear();
@@ -27,7 +27,7 @@ int run_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t* m, uin
     std::vector<const uint8_t*> t(g->nlocal); std::vector<uint64_t> mm(g->nlocal);
     std::vector<T*> a(g->nlocal), b(g->nlocal), c(g->nlocal, nullptr);
     for (int i = 0; i < g->nlocal; ++i) { t[i] = d_text[i]; mm[i] = m[i]; a[i] = sa[i]; b[i] = isa[i]; if (flags & PSACX_LCP) c[i] = lcp[i]; }
-    return run.construct(t, mm, k, flags, a, b, c);
+    return run.construct(t, mm, k, flags, a, b, c, str_off, nstr);
 }
 
 template <typename T>
@@ -80,7 +80,8 @@ int suffix_tree_dev(psacx_multi* g, const uint8_t* const* d_text, const uint64_t
 
 // whole text on the host of a single process that owns every rank: blocks to the GPUs, results back in rank order
 template <typename T>
-int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp, uint8_t* lc = nullptr) {
+int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp, uint8_t* lc = nullptr,
+             const uint64_t* str_off = nullptr, uint64_t nstr = 0) {
     if (!g || !text || !sa || !isa || n == 0) return PSACX_EINVAL;
     if ((flags & PSACX_LCP) && !lcp) return PSACX_EINVAL;
     if (lc && !(flags & PSACX_LCP)) return PSACX_EINVAL;        // (the reference fills Lc inside its LCP code)
@@ -104,7 +105,7 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
     }
     const uint64_t user_slack = g->out_slack;
     g->out_slack = slack;
-    int rc = run_dev<T>(g, tp.data(), m.data(), k, flags, a.data(), b.data(), c.data());
+    int rc = run_dev<T>(g, tp.data(), m.data(), k, flags, a.data(), b.data(), c.data(), str_off, nstr);
     g->out_slack = user_slack;
     if (rc != PSACX_OK) return rc;
     if (lc) {
@@ -335,6 +336,18 @@ int psacx_multi_construct_dev_u32(psacx_multi* g, const uint8_t* const* t, const
                                   uint32_t* const* isa, uint32_t* const* lcp) { return run_dev<uint32_t>(g, t, m, k, f, sa, isa, lcp); }
 int psacx_multi_construct_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, uint32_t k, uint32_t f, uint64_t* const* sa,
                                   uint64_t* const* isa, uint64_t* const* lcp) { return run_dev<uint64_t>(g, t, m, k, f, sa, isa, lcp); }
+int psacx_multi_construct_gsa_dev_u32(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* off, uint64_t nstr, uint32_t k, uint32_t f,
+                                      uint32_t* const* sa, uint32_t* const* isa, uint32_t* const* lcp) {
+    return off ? run_dev<uint32_t>(g, t, m, k, f, sa, isa, lcp, off, nstr) : PSACX_EINVAL;
+}
+int psacx_multi_construct_gsa_dev_u64(psacx_multi* g, const uint8_t* const* t, const uint64_t* m, const uint64_t* off, uint64_t nstr, uint32_t k, uint32_t f,
+                                      uint64_t* const* sa, uint64_t* const* isa, uint64_t* const* lcp) {
+    return off ? run_dev<uint64_t>(g, t, m, k, f, sa, isa, lcp, off, nstr) : PSACX_EINVAL;
+}
+int psacx_multi_construct_gsa_u32(psacx_multi* g, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t nstr, uint32_t k, uint32_t f, uint32_t* sa,
+                                  uint32_t* isa, uint32_t* lcp) { return off ? run_host<uint32_t>(g, t, n, k, f, sa, isa, lcp, nullptr, off, nstr) : PSACX_EINVAL; }
+int psacx_multi_construct_gsa_u64(psacx_multi* g, const uint8_t* t, uint64_t n, const uint64_t* off, uint64_t nstr, uint32_t k, uint32_t f, uint64_t* sa,
+                                  uint64_t* isa, uint64_t* lcp) { return off ? run_host<uint64_t>(g, t, n, k, f, sa, isa, lcp, nullptr, off, nstr) : PSACX_EINVAL; }
 int psacx_multi_construct_u32(psacx_multi* g, const uint8_t* t, uint64_t n, uint32_t k, uint32_t f, uint32_t* sa, uint32_t* isa, uint32_t* lcp) {
     return run_host<uint32_t>(g, t, n, k, f, sa, isa, lcp);
 }

@@ -404,6 +404,36 @@ __global__ void check_verdict_kernel(const T* __restrict__ SA, const T* __restri
 
 // ------------------------------------------------------------------------------------------------------------
 // number of leading entries <= key of a non-decreasing array (one thread)
+// ---- string sets (construct_ss on p ranks, suffix_array.hpp:267-363): for the positions base .. base + cnt of the text,
+// slen = characters to the end of the string holding the position, soff = characters from its start (off: the nstr + 1
+// global string offsets).  Positions past the end of the text count as strings of one character.
+template <typename T>
+__global__ void string_pos_kernel(const uint64_t* __restrict__ off, uint64_t nstr, uint64_t n, uint64_t base, uint64_t cnt, T* __restrict__ slen,
+                                  T* __restrict__ soff) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
+        const uint64_t i = base + j;
+        if (i >= n) { if (slen) slen[j] = (T)1; if (soff) soff[j] = (T)0; continue; }
+        uint64_t lo = 0, hi = nstr;              // largest t with off[t] <= i
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+        if (slen) slen[j] = (T)(off[lo + 1] - i);
+        if (soff) soff[j] = (T)(i - off[lo]);
+    }
+}
+// the ranks a rank answers for "the suffix h further" in a string set: none (all ones) when that suffix starts in another
+// string, i.e. when the position lies fewer than h characters into its own string (shifting.hpp:374-418)
+template <typename T>
+__global__ void mask_by_string_kernel(const T* __restrict__ isa, const T* __restrict__ soff, uint64_t m, uint64_t h, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = (uint64_t)soff[j] >= h ? isa[j] : ~(T)0;
+}
+template <typename T>
+__global__ void finish_b2_masked_kernel(const T* __restrict__ ans, const T* __restrict__ q, uint64_t cnt, uint64_t n, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
+        out[j] = ((uint64_t)q[j] < n && ans[j] != ~(T)0) ? (T)(ans[j] + 1) : (T)0;
+}
+
 // ---- suffix-tree node table over block-distributed SA / LCP (suffix_tree.hpp:43-223 for_each_parent, :440-499)
 // For the LCP index i = off + j: the parent of leaf n + i and (when there is one) of internal node i, from the ANSV of LCP
 // (left furthest_eq, right nearest_sm, suffix_tree.hpp:62) and the LCP values found there; q = the text position whose
@@ -494,6 +524,10 @@ struct MultiRun {
     // output arrays and ONE allocated set, SA -> ISA runs in chunks, and a refinement round with more unresolved
     // suffixes than `slab_cap` on some rank is worked off in slabs of whole buckets.
     bool diet = false, first_round_ = false;
+    // string set (construct_ss): the nstr + 1 global string offsets on the host; per local rank the offset of every position
+    // of its block inside its string
+    const uint64_t* gsa_off_ = nullptr; uint64_t gsa_nstr_ = 0;
+    std::vector<DBuf<T>> soff_;
     // one rank and no request to exercise the wire anyway (PSACX_MULTI_FORCE_WIRE): the distributed primitives take their
     // local shortcuts
     bool solo_ = false;
@@ -1995,14 +2029,25 @@ struct MultiRun {
         }));
         {
             std::vector<const T*> blk(L), gi(L);
-            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q[i].p; }
+            std::vector<DBuf<T>> masked(L);
+            const bool gsa = gsa_off_ != nullptr;
+            if (gsa)
+                PSACX_TRY(par([&](int i) -> int {
+                    psacx_ctx* c = ctx(i);
+                    MG_OP(g, c, masked[i].alloc(c, S[i].m));
+                    OP_PROLOGUE(c);
+                    SIMPLE_LAUNCH(c, (mask_by_string_kernel<T>), S[i].m, (const T*)S[i].ISA, (const T*)soff_[i].p, S[i].m, h, masked[i].p);
+                    return PSACX_OK;
+                }));
+            for (int i = 0; i < L; ++i) { blk[i] = gsa ? masked[i].p : S[i].ISA; gi[i] = q[i].p; }
             std::vector<DBuf<T>> ans;
             PSACX_TRY(dist_take(blk, gi, cnt, ans));
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 MG_OP(g, c, rec[i].k2.alloc(c, cnt[i]));
                 OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
+                if (gsa) SIMPLE_LAUNCH(c, (finish_b2_masked_kernel<T>), cnt[i], (const T*)ans[i].p, (const T*)q[i].p, cnt[i], n, rec[i].k2.p);
+                else SIMPLE_LAUNCH(c, (finish_b2_kernel<T>), cnt[i], ans[i].p, q[i].p, cnt[i], n, rec[i].k2.p);
                 return PSACX_OK;
             }));
         }
@@ -2097,8 +2142,13 @@ struct MultiRun {
     }
 
     // ---------------------------------------------------------------- the construction (suffix_array.hpp:365-466, :1032-1285)
+    // str_off / nstr: a string set (construct_ss, suffix_array.hpp:267-363) -- the nstr + 1 ascending global offsets of the
+    // strings, which lie back to back in the block-distributed text (host array, the same on every rank)
     int construct(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, uint32_t k_req, uint32_t flags,
-                  const std::vector<T*>& d_sa, const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp) {
+                  const std::vector<T*>& d_sa, const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp,
+                  const uint64_t* str_off = nullptr, uint64_t nstr = 0) {
+        gsa_off_ = str_off; gsa_nstr_ = nstr; soff_.clear();
+        const bool gsa = str_off != nullptr;
         want_lcp = (flags & PSACX_LCP) != 0;
         psacx_stats& st = g->stats;
         std::memset(&st, 0, sizeof(st));
@@ -2174,6 +2224,12 @@ struct MultiRun {
             uint32_t l = 0; while ((1u << l) < sigma + 1u) ++l;
             st.sigma = sigma; st.bits_per_char = l;
             for (int ch = 0, nx = 0; ch < 256; ++ch) codes_[ch] = hist[ch] ? (uint16_t)(nx++) : (uint16_t)0;   // packed codes 0..sigma-1
+            if (gsa) {
+                // string ends need their own code in the key: psac's codes 1 .. sigma with l bits, 0 = end (kmer.hpp:269-355)
+                for (int ch = 0; ch < 256; ++ch) if (hist[ch]) codes_[ch] = (uint16_t)(codes_[ch] + 1);
+                if (nstr == 0 || nstr > n || str_off[0] != 0 || str_off[nstr] != n) { g->err = "string set: the offsets do not cover the text"; return PSACX_EINVAL; }
+                for (uint64_t t = 0; t < nstr; ++t) if (str_off[t + 1] <= str_off[t]) { g->err = "string set: empty string or offsets not ascending"; return PSACX_EINVAL; }
+            }
         }
         mark("alphabet");
         const uint32_t l = st.bits_per_char;
@@ -2193,6 +2249,7 @@ struct MultiRun {
         const bool tiny_blocks = P > 1 && min_local < two_k;
         // the 2k-character window packed without an end-marker code (key_pairs_kernel): lc bits per character
         uint32_t lc = 0; while ((1u << lc) < st.sigma) ++lc; if (!lc) lc = 1;
+        if (gsa) lc = l;
         const uint32_t c1 = std::min<uint32_t>(two_k, word_bits / lc), c2 = two_k - c1;
 
         // ---- halo: the first 2k characters of the right neighbour (kmer.hpp:142)
@@ -2243,8 +2300,23 @@ struct MultiRun {
         }
         // ---- first-round keys; the suffixes shorter than 2k (the last 2k - 1 positions) are moved to the very front
         //      of the record order (rank 0, shortest first): see key_pairs_kernel for why that replaces the end marker
-        const uint64_t spec = std::min<uint64_t>(two_k - 1, n);
+        const uint64_t spec = gsa ? 0 : std::min<uint64_t>(two_k - 1, n);       // (string sets: the end markers are in the keys)
         std::vector<Rec<T>> rec(L);
+        std::vector<DBuf<T>> slen(L);
+        if (gsa) {
+            soff_.resize(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                DBuf<uint64_t> d_off; MG_OP(g, c, d_off.alloc(c, nstr + 1));
+                MG_OP(g, c, slen[i].alloc(c, S[i].m)); MG_OP(g, c, soff_[i].alloc(c, S[i].m));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemcpyAsync(d_off.p, str_off, (nstr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (string_pos_kernel<T>), S[i].m, (const uint64_t*)d_off.p, nstr, n, S[i].off, S[i].m, slen[i].p, soff_[i].p);
+                MG_HIP(g, hipStreamSynchronize(c->stream));        // (the offsets leave with this scope)
+                return PSACX_OK;
+            }));
+        }
         // both: word 2 of every record is generated and carried (three-word records); otherwise the records are (word 1, suffix)
         auto make_records = [&](bool both) -> int {
             std::vector<Rec<T>> tails(L);
@@ -2255,7 +2327,8 @@ struct MultiRun {
                 const uint64_t m = S[i].m, front = rank(i) == 0 ? spec : 0;
                 drop3(i, rec[i]);
                 PSACX_TRY(take3(i, rec[i], front + m, both));
-                MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, both ? rec[i].k2.p + front : (T*)nullptr));
+                MG_OP(g, c, op_make_keys<T>(c, tbuf[i].p, m, m + two_k, codes_, lc, c1, c2, rec[i].k1.p + front, both ? rec[i].k2.p + front : (T*)nullptr,
+                                            gsa ? (const T*)slen[i].p : (const T*)nullptr));
                 if (both) MG_OP(g, c, psacx_op_iota(c, rec[i].v.p + front, m, S[i].off));       // (two-word form: the shuffle or the sort makes the suffixes up)
                 const uint64_t end = S[i].off + m, first_short = n - spec;
                 const uint64_t mine = std::min<uint64_t>(m, end > first_short ? end - first_short : 0);     // short suffixes in this block (its tail)
@@ -2316,7 +2389,7 @@ struct MultiRun {
         const unsigned lead = (bits_for(n - 1) + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
         const char* env_tw = getenv("PSACX_MULTI_TWO_WORD");
         const int tw_mode = env_tw ? atoi(env_tw) : -1;
-        bool two_word = tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
+        bool two_word = !gsa && tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
                         !getenv("PSACX_ONE_STAGE");
         PSACX_TRY(make_records(!two_word));
         mark("keys");
@@ -2348,7 +2421,7 @@ struct MultiRun {
         PSACX_TRY(par([&](int i) -> int {
             bd[i].off = S[i].off; bd[i].base = 0;
             psacx_boundary b0 = bd[i]; b0.has_next = 0;
-            MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 0, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &b0, &lh[i]));
+            MG_OP(g, ctx(i), op_last_head<T>(ctx(i), 0, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &b0, &lh[i], gsa));
             return PSACX_OK;
         }));
         PSACX_TRY(gather1(lh, heads));
@@ -2362,7 +2435,7 @@ struct MultiRun {
             // array once the records are gone
             T* bsa_out = S[i].ISA;
             if (!diet) { MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m)); bsa_out = S[i].Bsa.p; }
-            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i]));
+            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i], gsa));
             MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             drop3(i, rec[i]);
             S[i].out_busy = true;

@@ -124,6 +124,23 @@ class MultiContext(object):
         rounds = [(r.h, r.unfinished_buckets, r.unfinished_elements) for r in s.rounds[:s.n_rounds]]
         return SA, ISA, LCP, rounds
 
+    def construct_ss(self, strings, sep=None, index_bits=64, lcp=True, k=0):
+        """suffix_array::construct_ss (suffix_array.hpp:267-363) on p ranks: the generalized suffix array of a string set
+        (a list of byte strings, or one flat buffer cut at runs of `sep`), the strings back to back in the
+        block-distributed text.  Returns (SA, ISA, LCP or None, rounds, string offsets)."""
+        from .suffix_array import parse_stringset
+        t, off = parse_stringset(strings, sep)
+        n = int(t.size)
+        dt = np.uint32 if index_bits == 32 else np.uint64
+        SA = np.empty(n, dt); ISA = np.empty(n, dt); LCP = np.empty(n, dt) if lcp else None
+        fn = getattr(self._lib, "psacx_multi_construct_gsa_u%d" % index_bits)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.check(fn(self.handle, p(t), n, p(off), int(off.size - 1), int(k), PSACX_LCP if lcp else 0, p(SA), p(ISA), p(LCP) if lcp else None))
+        s = self.stats()[0]
+        rounds = [(r.h, r.unfinished_buckets, r.unfinished_elements) for r in s.rounds[:s.n_rounds]]
+        return SA, ISA, LCP, rounds, off
+
     def construct_device(self, d_text, m, d_sa, d_isa, d_lcp, index_bits, k=0):
         """Blocks resident in HBM: lists (one entry per local rank) of raw device addresses and block lengths."""
         L = self.nlocal

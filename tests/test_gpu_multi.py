@@ -626,6 +626,45 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_string_sets(P):
+    # construct_ss on p ranks (suffix_array.hpp:267-363; psacx_multi_construct_gsa_*): the reference's expected arrays
+    # (test/test_gsa.cpp:35-105), random sets against the oracle's restatement, deep ties (equal strings, prefixes of each
+    # other: text order among equal suffixes), strings longer than a block and shorter than the k-mer window
+    rng = np.random.RandomState(11)
+    sets = []
+    for sigma, m, lo, hi in ((4, 300, 1, 400), (2, 50, 1, 30), (1, 40, 1, 100), (26, 2000, 5, 60), (4, 1, 5000, 5001), (4, 3000, 1, 3), (90, 200, 100, 2000)):
+        sets.append([bytes(rng.randint(65, 65 + sigma, size=int(rng.randint(lo, hi))).astype(np.uint8)) for _ in range(m)])
+    base = bytes(inputs.dna(300, 4))
+    sets.append([base[:int(x)] for x in rng.randint(1, 300, size=500)])
+    sets.append([base] * 200)
+    mg = multi(P)
+    try:
+        from test_oracle_golden import GSA_REPEATS, repeat_inc_gsa, repeat_inc_glcp, repeat_inc_seq
+        for bits in (64, 32):
+            SA, ISA, LCP, _, _ = mg.construct_ss(["abab", "baba"], index_bits=bits)            # test/test_gsa.cpp:73-105 (SimpleTiny)
+            assert SA.tolist() == [7, 2, 5, 0, 3, 6, 1, 4] and LCP.tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+            for seq, reps in GSA_REPEATS:                                                      # test/test_gsa.cpp:107-179 (IncRepeats*)
+                SA, ISA, LCP, _, _ = mg.construct_ss(repeat_inc_seq(seq, reps), index_bits=bits)
+                assert SA.tolist() == repeat_inc_gsa(len(seq), reps) and LCP.tolist() == repeat_inc_glcp(len(seq), reps), (seq, reps, bits)
+                assert np.array_equal(ISA[SA.astype(np.int64)], np.arange(SA.size, dtype=SA.dtype))
+        for strings in sets:
+            for bits, k in ((32, 0), (64, 0), (32, 3)):
+                SA, ISA, LCP, rounds, _ = mg.construct_ss(strings, index_bits=bits, k=k)
+                ref = O.construct_ss(strings, bits=bits, k=k)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, k, len(strings))
+            SA, ISA, LCP, _, _ = mg.construct_ss(strings, index_bits=32, lcp=False)
+            assert LCP is None and np.array_equal(SA, ref["SA"].astype(np.uint32))
+        with pytest.raises(Exception):
+            mg._lib.psacx_multi_construct_gsa_u64.restype = int
+            t = np.frombuffer(b"abcabc", np.uint8); off = np.array([0, 4, 3, 6], np.uint64)
+            SA = np.empty(6, np.uint64)
+            p_ = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)
+            mg.check(mg._lib.psacx_multi_construct_gsa_u64(mg.handle, p_(t), 6, p_(off), 3, 0, 0, p_(SA), p_(SA.copy()), None))
+    finally:
+        mg.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
 def test_multi_suffix_tree_node_table(P):
     # psacx_multi_suffix_tree_dev_*: construct_suffix_tree on p ranks (suffix_tree.hpp:413-499) -- the rows of the node table
     # block-distributed like LCP, against the reference's mississippi table (test/test_suffixtree.cpp:68-83) and the oracle's

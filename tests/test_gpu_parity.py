@@ -672,6 +672,11 @@ def test_gsac_cli(tmp_path):
     r = subprocess.run([gsac, "-f", str(f), "-c"], capture_output=True, text=True)
     assert r.returncode == 0 and "[SUCCESS]" in r.stdout
     assert subprocess.run([gsac], capture_output=True).returncode != 0
+    # the same string set on three ranks (here sharing device 0): construct_ss on p ranks, suffix_array.hpp:267-363
+    r = subprocess.run([gsac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "g3"), "--gpus-on-device", "0,3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS] GSA correct" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(str(tmp_path / "g3.sa64"), dtype=np.uint64), ref["SA"])
+    assert np.array_equal(np.fromfile(str(tmp_path / "g3.lcp64"), dtype=np.uint64), ref["LCP"])
 
 
 def test_distributed_ansv_on_gpu(ctx):
