@@ -161,12 +161,21 @@ def main_distributed(a, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if a.n is None:
-        # 2^32 characters per GPU (the block of configs[3] / configs[4]; the engine takes its reduced-memory layout: about
-        # 7 words per character including the results) when every GPU has the room, else 2^28
+        # The largest block of 2^32, 2^31 (configs[3]: 16 GiB over 8 GPUs), 2^30, 2^28 characters per GPU that fits every GPU.
+        # With more than one rank the reduced-memory layout peaks at 4.75 words per character for the engine (the shuffle holds
+        # the records, their partitioned copy and the receive arrays at once; measured with two ranks of 2^31,
+        # profiles/r03n_multi_virtual_ranks.txt) + 3.375 for the result arrays with their slack + the text = 8.25 words of
+        # 8 bytes: 283 GB at 2^32 characters -- too close to the 288 GB of an MI355X once RCCL has its buffers, so a full
+        # GPU takes 2^31.  Asked for: 8.6 words + 6 GB.
         free_b = torch.cuda.mem_get_info(local_rank)[0]
-        ok = torch.tensor([1 if free_b >= int(7.4 * 8 * (1 << 32)) else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        a.n = (1 << 32) if int(ok.item()) else (1 << 28)
+        fit = 28
+        for lg in (32, 31, 30):
+            if free_b >= int(8.6 * 8 * (1 << lg)) + (6 << 30):
+                fit = lg
+                break
+        t_fit = torch.tensor([fit], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+        a.n = 1 << int(t_fit.item())
     n = a.n
     bits = a.index if a.index else (32 if world * n <= (1 << 31) else 64)
     if world * n > 0xFFFFFFFE:
@@ -243,6 +252,7 @@ def main_distributed(a, rank, world, local_rank):
             out["config"]["one_gpu_engine_same_block"] = "the N = 1 line of this bench (same block, same index width)"
         else:
             try:
+                lib.psacx_trim(ctx)              # the multi-GPU engine's cached blocks go back to the device first
                 one = psac_amd.Context(local_rank)
                 sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
                 sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)

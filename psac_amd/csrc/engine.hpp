@@ -501,8 +501,10 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
     constexpr bool NARROW_OK = DEF_SHAPE && sizeof(T) == 8;       // 32-bit payload arrays (radix.hpp: VN), default shape only (8192-record tiles measured: 33.6-34.9 against 28.1 ms per pass)
     if (NARROW_OK && vn && !ko_in) {
         // (radix.hpp: VN -- 1 / 2: 32-bit payload entries; 3 .. 6: payload packed into the low bits of the key word + 8- or 16-bit entries)
+        // registers capped for six waves per SIMD = three workgroups per CU: the narrow forms need 82, the cap costs them a
+        // few spilled registers and gains a third tile in flight (the pass is bound by the latency chain of a tile)
 #define PSACX_VN(V)                                                                                                                          \
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, 0, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, (NARROW_OK ? 6 : MINW), true, 0, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,                    \
                            reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles, (uint64_t)0, pack)
         switch (vn) {

@@ -571,13 +571,17 @@ struct MultiRun {
         psacx_ctx* c = ctx(i);
         MG_HIP(g, hipSetDevice(c->device));
         DBuf<T>* a[3] = {&r.k1, &r.k2, &r.v};
+        bool kept = false;
         for (int q = 0; q < 3; ++q) {
             if (a[q]->owned()) continue;
+            // the suffixes may stay where they are when that is the SA array itself: the rebucket step only reads them, and
+            // they would be copied there next anyway (two copies of the block less)
+            if (q == 2 && a[q]->p == S[i].SA && a[q]->n == S[i].m) { kept = true; continue; }
             DBuf<T> o; MG_OP(g, c, o.alloc(c, a[q]->n, reserve_of(i)));
             MG_HIP(g, hipMemcpyAsync(o.p, a[q]->p, a[q]->n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             *a[q] = std::move(o);
         }
-        S[i].out_busy = false;
+        S[i].out_busy = kept;          // (the output arrays stay off limits as scratch while the suffixes sit in one)
         return PSACX_OK;
     }
 
@@ -2436,7 +2440,7 @@ struct MultiRun {
             T* bsa_out = S[i].ISA;
             if (!diet) { MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m)); bsa_out = S[i].Bsa.p; }
             MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i], gsa));
-            MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            if (rec[i].v.p != S[i].SA) MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             drop3(i, rec[i]);
             S[i].out_busy = true;
             if (diet) {

@@ -12,6 +12,7 @@
 // Algorithmic HBM traffic: 2w bytes/record for the histogram and 6w
 // bytes/record per scatter pass (w = sizeof(T)), SURVEY.md section 8(d).
 #pragma once
+#include <type_traits>
 #include "dev_common.hpp"
 
 namespace psacx {
@@ -196,12 +197,18 @@ __device__ __forceinline__ void radix_scatter_tile(
     const T* __restrict__ pkd = kd_in + base;
     const T* __restrict__ pko = ko_in + base;
     const T* __restrict__ pv = v_in ? v_in + base : nullptr;
-    // offsets of this tile (three-kernel form): fetched now, used after the ranking
+    // offsets of this tile (three-kernel form): fetched now, used after the ranking -- except in the narrow forms, which run
+    // under a register cap (engine.hpp: launch_pass3) and rank with two registers less when the fetch comes afterwards; the
+    // three-word pass loses 1.5 ms of 20 when the fetch comes late (its latency is then exposed before the barrier)
+    constexpr bool LATE_EXCL = NOKO && VN != 0;
     uint64_t pre_excl = 0;
-    if (!LB && tid < RADIX)
+    if (!LATE_EXCL && !LB && tid < RADIX)
         pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / slab_tiles) * RADIX + tid] +
                    (uint64_t)digit_base[tid];
-    T kd[ITEMS], ko[NOKO ? 1 : ITEMS], vv[ITEMS];
+    // (payload registers: 32 bits wide whenever the entries are -- the narrow and packed forms of 64-bit words)
+    typedef typename std::conditional<(VN != 0) && sizeof(T) == 8, uint32_t, T>::type PV;
+    T kd[ITEMS], ko[NOKO ? 1 : ITEMS];
+    PV vv[ITEMS];
     unsigned char cls[EXT ? ITEMS : 1];
     const unsigned wbase = wave * (WAVE * ITEMS) + lane;
     if (EXT) {
@@ -230,15 +237,16 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
         if (pv) {
-            if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (T)0;
-            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint8_t*>(v_in) + base)[loc] : (T)0;
-            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (T)(reinterpret_cast<const uint16_t*>(v_in) + base)[loc] : (T)0;
-            else vv[i] = (FULL || loc < count) ? pv[loc] : (T)0;
+            if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (PV)0;
+            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint8_t*>(v_in) + base)[loc] : (PV)0;
+            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint16_t*>(v_in) + base)[loc] : (PV)0;
+            else vv[i] = (FULL || loc < count) ? (PV)pv[loc] : (PV)0;
         } else {
             // implicit payload: the record index, or the suffix the first-round record stands for
             const uint64_t g = base + loc;
-            vv[i] = (T)((spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff);
-            if (PK) { kd[i] = (T)((kd[i] & ~pmask) | (vv[i] & pmask)); vv[i] = (T)((uint64_t)vv[i] >> pack); }
+            const uint64_t made = (spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff;
+            if (PK) { kd[i] = (T)((kd[i] & ~pmask) | ((T)made & pmask)); vv[i] = (PV)(made >> pack); }
+            else vv[i] = (PV)made;
         }
     }
 
@@ -248,7 +256,6 @@ __device__ __forceinline__ void radix_scatter_tile(
     // through the counters without any explicit wait between them.
     unsigned rank[ITEMS];
     unsigned* mycnt = wcnt + wave * RADIX;
-    const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const bool valid = FULL || (wbase + i * WAVE) < count;
@@ -262,10 +269,15 @@ __device__ __forceinline__ void radix_scatter_tile(
             else __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ready for the next round
         } else m = match_any8(d, valid);
         const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (valid && (m & lt) == 0)
+        // lanes of the group below this one (mbcnt: no lane mask held in registers)
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (valid && below == 0)
             __hip_atomic_fetch_add(&mycnt[d], (unsigned)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        rank[i] = prior + (unsigned)__builtin_popcountll(m & lt);
+        rank[i] = prior + below;
     }
+    if (LATE_EXCL && !LB && tid < RADIX)
+        pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / slab_tiles) * RADIX + tid] +
+                   (uint64_t)digit_base[tid];
     __syncthreads();
     if (stamp) mydbg[1] = __builtin_amdgcn_s_memtime();
 
@@ -349,7 +361,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     if (stamp) mydbg[5] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = vv[i];
+        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = (T)vv[i];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {

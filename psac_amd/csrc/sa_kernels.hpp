@@ -11,6 +11,7 @@
 //   pyramid_level_kernel    rmq.hpp:87-179 / par_rmq.hpp:199-332 (range-minimum structure)
 //   isa_finalize_kernel     suffix_array.hpp:460-464   ISA -= 1
 #pragma once
+#include <type_traits>
 #include "dev_common.hpp"
 
 namespace psacx {
@@ -644,6 +645,8 @@ constexpr int INV_WINDOW_BITS = 12;
 // narrowed by its first level (SUB1: the value's -1 is applied there, so that bucket id n = 2^32 fits) and travels as
 // 32-bit pairs from then on: 24 + 16 + 16 bytes per record over three levels instead of 3 x 32.
 // CB: class bits of a level (2^CB destination classes per parent bucket; BLOCK >= 2^CB).
+// (a register cap for a third workgroup per CU, as in the narrow scatter passes of radix.hpp, spills 13 registers here and
+//  loses: 34.8-35.8 against 33.0-33.4 ms for the second inversion level + window scatter at 2^32)
 template <typename TI, typename TO, int BLOCK, int ITEMS, bool SUB1 = false, int CB = 8>
 __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
     const TI* __restrict__ key_in, const TI* __restrict__ val_in, TO* __restrict__ key_out,
@@ -699,13 +702,15 @@ __global__ __launch_bounds__(BLOCK) void partition_pairs_kernel(
         if (tid + i * BLOCK < count) stage[slot[i]] = key[i];
     }
     __syncthreads();
-    uint64_t dest[ITEMS];
+    // (32-bit pairs exist for at most 2^32 positions: their places fit 32 bits, sixteen registers less per thread)
+    typedef typename std::conditional<sizeof(TO) == 4, uint32_t, uint64_t>::type DT;
+    DT dest[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (p < count) {
             const TO x = stage[p];
-            dest[j] = gbase[(unsigned)(x >> shift) & (NCLS - 1)] + p;
+            dest[j] = (DT)(gbase[(unsigned)(x >> shift) & (NCLS - 1)] + p);
             key_out[dest[j]] = x;
         }
     }
