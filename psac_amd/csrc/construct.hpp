@@ -271,6 +271,29 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
                               {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
         const int lv9 = isa_narrow_levels<T>(n, kn);
+        if (!kn.isa_two_arrays) {
+            // packed pairs: one array of (position | rank << 32) entries per level (sa_kernels.hpp: partition_packed_kernel)
+            uint64_t* pb[2] = {reinterpret_cast<uint64_t*>(t1.k1), reinterpret_cast<uint64_t*>(t2.k1)};
+            const uint64_t* cur = fused_l1 ? pb[0] : nullptr;
+            for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
+                const unsigned shift = isa_narrow_shift(lv9, lv);
+                PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ((size_t)(n >> shift) + 1) * sizeof(unsigned), c->stream));
+                uint64_t* o = pb[lv & 1];
+                if (lv == 0)
+                    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
+                                       (const uint64_t*)nullptr, o, n, shift, d_cursors, koff);
+                else
+                    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, (const T*)nullptr,
+                                       (const T*)nullptr, cur, o, n, shift, d_cursors, (uint64_t)0);
+                PSACX_HIP(c, hipGetLastError());
+                cur = o;
+            }
+            if (!cur) { c->hip_err = "inversion: no partition level"; return PSACX_EINVAL; }
+            const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
+            hipLaunchKernelGGL((window_scatter_packed_kernel<T, 1024, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, cur, n, d_isa);
+            PSACX_HIP(c, hipGetLastError());
+            return PSACX_OK;
+        }
         const uint32_t* k32 = fused_l1 ? nb[0][0] : nullptr; const uint32_t* v32 = fused_l1 ? nb[0][1] : nullptr;
         for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
             const unsigned shift = isa_narrow_shift(lv9, lv);
@@ -377,9 +400,15 @@ template <typename T, bool WITH_LCP>
 inline void launch_rebucket_first_fused(psacx_ctx* c, unsigned ntiles, const T* s1, const T* s2, const T* sa, uint64_t n, KeyShape ks,
                                         T* bsa, T* lcp, uint64_t* carry, uint64_t* nact, uint64_t* nunf, T* pyr1,
                                         uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors) {
-    hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
-                       dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
-                       (unsigned*)nullptr, 0, pk, pv, shift, cursors);
+    // pv == nullptr: packed pairs (64-bit words: one array of (position | rank << 32) entries at pk)
+    if (pv)
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
+                           dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
+                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
+    else
+        hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB, true>), dim3(ntiles),
+                           dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
+                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
 }
 
 // d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
@@ -666,7 +695,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
             uint32_t* const pk = reinterpret_cast<uint32_t*>(w.x.v);
             launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
-                                                     w.d_nunf, pyr1, pk, pk + n, isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors);
+                                                     w.d_nunf, pyr1, pk, kn.isa_two_arrays ? pk + n : (uint32_t*)nullptr,
+                                                     isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),

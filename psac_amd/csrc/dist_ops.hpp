@@ -350,7 +350,7 @@ int counts_back(psacx_ctx* c, TileScratch& ts, uint64_t ntiles, uint64_t* nact, 
 
 template <typename T>
 int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint64_t cnt, uint64_t n, uint32_t l, uint32_t c1,
-                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf, bool gsa = false) {
+                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf, bool gsa = false, T* sa_out = nullptr) {
     OP_PROLOGUE(c);
     *nact = *nunf = 0;
     if (cnt == 0) return PSACX_OK;
@@ -363,16 +363,16 @@ int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint6
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
     if (gsa && lcp)
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                           c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd);
+                           c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd, (T*)nullptr, (unsigned*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned*)nullptr, sa_out);
     else if (gsa)
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                           c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd);
+                           c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd, (T*)nullptr, (unsigned*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned*)nullptr, sa_out);
     else if (lcp)
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                           c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd);
+                           c->stream, s1, s2, sa, cnt, ks, bsa, lcp, ts.carry, ts.nact, ts.nunf, n, bd, (T*)nullptr, (unsigned*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned*)nullptr, sa_out);
     else
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                           c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd);
+                           c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd, (T*)nullptr, (unsigned*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned*)nullptr, sa_out);
     PSACX_HIP(c, hipGetLastError());
     return counts_back<T>(c, ts, ntiles, nact, nunf);
 }

@@ -138,6 +138,7 @@ struct Knobs {
     bool isa_cb8;           // PSACX_ISA_CB8: 256-way levels and 2^12-entry windows
     bool no_fused_l1;       // PSACX_NO_FUSED_L1: first inversion level as its own kernel
     bool no_rmq_aux;        // PSACX_NO_RMQ_AUX: range minima without the running-minimum tables
+    bool isa_two_arrays;    // PSACX_ISA_TWO_ARRAYS: the 32-bit pairs of the SA -> ISA levels in two arrays instead of one of packed entries
     bool wide_refine;       // PSACX_WIDE_REFINE: refinement records of 64-bit words keep their three words below 2^32 characters too
     bool no_whole_rounds;   // PSACX_NO_WHOLE_ROUNDS: rounds with almost every suffix unresolved still go through the list of unresolved positions
     bool sort_debug;        // PSACX_SORT_DEBUG: phase stamps of sampled scatter tiles
@@ -158,6 +159,7 @@ inline Knobs read_knobs() {
     k.no_fused_l1 = getenv("PSACX_NO_FUSED_L1") != nullptr;
     k.no_rmq_aux = getenv("PSACX_NO_RMQ_AUX") != nullptr;
     k.no_whole_rounds = getenv("PSACX_NO_WHOLE_ROUNDS") != nullptr;
+    k.isa_two_arrays = getenv("PSACX_ISA_TWO_ARRAYS") != nullptr;
     k.wide_refine = getenv("PSACX_WIDE_REFINE") != nullptr;
     k.sort_debug = getenv("PSACX_SORT_DEBUG") != nullptr;
     return k;

@@ -1658,8 +1658,9 @@ struct MultiRun {
     // ISA[SA[j]] = Bsa[j] - 1 for the full permutation of the first round (bulk_permute_inplace, bulk_permute.hpp:14-73),
     // slice by slice: see slice_inv.hpp.  Needs blocks of at most 2^32 positions (32-bit block-relative keys).
     // V: type the ranks travel in (32 bits while the whole text has at most 2^32 characters).
+    // ids_in_isa: the bucket ids still sit in the ISA array (reduced-memory layout); the first level copies them to S[i].Bsa
     template <typename V>
-    int isa_by_slices_t() {
+    int isa_by_slices_t(bool ids_in_isa) {
         constexpr unsigned WBMAX = sizeof(V) == 4 ? 14 : 13;
         constexpr int PB = 512, PI = 16, TILE_BITS = 13;
         uint64_t max_m = 0;
@@ -1776,7 +1777,7 @@ struct MultiRun {
             std::memcpy(c->pinned + 32768, cstart[i].data(), (size_t)C * 8);
             MG_HIP(g, hipMemcpyAsync(d_cnt[i].p, c->pinned + 32768, SLICE_MAX_CLASSES * 8, hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL((slice_partition_kernel<T, V, PB, PI>), dim3((unsigned)((m + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
-                               (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, pk_[i].k, pk_[i].v);
+                               ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, pk_[i].k, pk_[i].v, ids_in_isa ? S[i].Bsa.p : (T*)nullptr);
             MG_HIP(g, hipGetLastError());
             MG_HIP(g, hipStreamSynchronize(c->stream));       // (the pinned words are reused)
             return PSACX_OK;
@@ -1853,9 +1854,9 @@ struct MultiRun {
         g->last_slice_inversion = true;
         return PSACX_OK;
     }
-    int isa_by_slices() {
-        if (sizeof(T) == 4 || n <= (1ull << 32)) return isa_by_slices_t<uint32_t>();
-        return isa_by_slices_t<T>();
+    int isa_by_slices(bool ids_in_isa = false) {
+        if (sizeof(T) == 4 || n <= (1ull << 32)) return isa_by_slices_t<uint32_t>(ids_in_isa);
+        return isa_by_slices_t<T>(ids_in_isa);
     }
 
     // out[i][j] = block_owner[gidx[i][j] - off_owner] in the order of gidx (bulk_rma.hpp:13-135); positions >= n are clamped
@@ -2430,6 +2431,7 @@ struct MultiRun {
         }));
         PSACX_TRY(gather1(lh, heads));
         std::vector<uint64_t> nact(L), nunf(L);
+        const bool slices = !getenv("PSACX_MULTI_NO_SLICES") && sizes[0] <= (1ull << 32);      // SA -> ISA by destination slices (below)
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             uint64_t base = 0;
@@ -2439,13 +2441,16 @@ struct MultiRun {
             // array once the records are gone
             T* bsa_out = S[i].ISA;
             if (!diet) { MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m)); bsa_out = S[i].Bsa.p; }
-            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i], gsa));
-            if (rec[i].v.p != S[i].SA) MG_HIP(g, hipMemcpyAsync(S[i].SA, rec[i].v.p, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+            // (the suffixes go to the rank's SA block on the way, unless they sit there already)
+            MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i], gsa,
+                                             rec[i].v.p != S[i].SA ? S[i].SA : (T*)nullptr));
             drop3(i, rec[i]);
             S[i].out_busy = true;
             if (diet) {
+                // the bucket ids move from the ISA array to their own: inside the first level of the slice inversion, which
+                // reads them anyway (isa_by_slices), else by a copy
                 MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m));
-                MG_HIP(g, hipMemcpyAsync(S[i].Bsa.p, S[i].ISA, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                if (!slices) MG_HIP(g, hipMemcpyAsync(S[i].Bsa.p, S[i].ISA, S[i].m * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
             }
             return PSACX_OK;
         }));
@@ -2454,7 +2459,7 @@ struct MultiRun {
         // ---- SA -> ISA (bulk_permute.hpp:14-73): by destination slices (slice_inv.hpp); the earlier form (pairs routed by owner,
         //      plain scatter in chunks of the block in the reduced-memory layout) with PSACX_MULTI_NO_SLICES=1 or blocks beyond 2^32
         g->last_slice_inversion = false;
-        if (!getenv("PSACX_MULTI_NO_SLICES") && sizes[0] <= (1ull << 32)) PSACX_TRY(isa_by_slices());
+        if (slices) PSACX_TRY(isa_by_slices(diet));
         else {
             uint64_t chunks = 1;
             if (diet) for (int r = 0; r < P; ++r) chunks = std::max<uint64_t>(chunks, (sizes[r] + slab_cap - 1) / slab_cap);

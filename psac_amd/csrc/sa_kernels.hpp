@@ -424,14 +424,18 @@ __global__ __launch_bounds__(BLOCK) void tile_scan2_kernel(uint64_t* __restrict_
 // inversion on the records it holds anyway: the (position, rank) pairs (SA[e], id[e] - 1) leave as 32-bit pairs
 // partitioned into 2^PCB destination classes by SA >> part_shift (see partition_pairs_kernel, whose first level this
 // replaces: its 16 bytes per record of reads are saved).  part_key / part_val: the pair arrays, part_cursors: zeroed.
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0>
+// PPK (with PCB): the pairs leave as ONE array of 64-bit entries (position | rank << 32, part_key viewed as uint64_t*,
+// part_val unused): a class's run of a tile is one 64-byte piece instead of two of 32 bytes, and is staged through LDS once.
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0, bool PPK = false>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
     T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0,
     uint32_t* __restrict__ part_key = nullptr, uint32_t* __restrict__ part_val = nullptr, unsigned part_shift = 0,
-    unsigned* __restrict__ part_cursors = nullptr) {
+    unsigned* __restrict__ part_cursors = nullptr, T* __restrict__ sa_out = nullptr) {
+    // sa_out (optional): the suffixes are written there as well (the multi-GPU engine's records end in scratch arrays; the
+    // copy into the rank's SA block rides along instead of reading them again)
     // sa_hist (optional): per-tile histogram of the digit of SA at sa_hist_shift, for the first level of the
     // SA -> ISA inversion when it runs as radix passes over tiles of this size
     // n: records in this block; ng: length of the whole text (LCP sentinel, suffix lengths)
@@ -541,6 +545,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     }
     store_run<T, ITEMS>(Bsa, e0, n, id);
     if (WITH_LCP) store_run<T, ITEMS>(LCP, e0, n, lc);
+    if (sa_out) store_run<T, ITEMS>(sa_out, e0, n, sa);
     if (sa_hist) {
         __shared__ unsigned dh[4 * RADIX];
         for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) dh[i] = 0;
@@ -564,7 +569,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     if constexpr (PCB > 0) {
         constexpr int NCLS = 1 << PCB;
         static_assert(BLOCK >= NCLS, "one thread per class");
-        __shared__ uint32_t stage[TILE];
+        typedef typename std::conditional<PPK, uint64_t, uint32_t>::type ST;
+        __shared__ ST stage[TILE];
         __shared__ unsigned pcnt[NCLS];
         __shared__ unsigned pstart[NCLS];
         __shared__ uint64_t pbase[NCLS];
@@ -592,32 +598,50 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
             }
         }
         __syncthreads();
+        if constexpr (PPK) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const unsigned d = (unsigned)((uint64_t)sa[j] >> part_shift) & (NCLS - 1);
-            slot[j] += pstart[d];
-            if (e0 + j < n) stage[slot[j]] = (uint32_t)sa[j];
-        }
-        __syncthreads();
-        uint64_t dest[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const unsigned p = tid + j * BLOCK;
-            if (p < count) {
-                const uint32_t x = stage[p];
-                dest[j] = pbase[(x >> part_shift) & (NCLS - 1)] + p;
-                part_key[dest[j]] = x;
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned d = (unsigned)((uint64_t)sa[j] >> part_shift) & (NCLS - 1);
+                if (e0 + j < n) stage[slot[j] + pstart[d]] = (uint64_t)(uint32_t)sa[j] | ((uint64_t)(uint32_t)(id[j] - 1) << 32);
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            uint64_t* const out = reinterpret_cast<uint64_t*>(part_key);
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-            if (e0 + j < n) stage[slot[j]] = (uint32_t)(id[j] - 1);
-        __syncthreads();
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned p = tid + j * BLOCK;
+                if (p < count) {
+                    const uint64_t x = stage[p];
+                    out[pbase[((uint32_t)x >> part_shift) & (NCLS - 1)] + p] = x;
+                }
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const unsigned p = tid + j * BLOCK;
-            if (p < count) part_val[dest[j]] = stage[p];
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned d = (unsigned)((uint64_t)sa[j] >> part_shift) & (NCLS - 1);
+                slot[j] += pstart[d];
+                if (e0 + j < n) stage[slot[j]] = (uint32_t)sa[j];
+            }
+            __syncthreads();
+            uint64_t dest[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned p = tid + j * BLOCK;
+                if (p < count) {
+                    const uint32_t x = (uint32_t)stage[p];
+                    dest[j] = pbase[(x >> part_shift) & (NCLS - 1)] + p;
+                    part_key[dest[j]] = x;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+                if (e0 + j < n) stage[slot[j]] = (uint32_t)(id[j] - 1);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned p = tid + j * BLOCK;
+                if (p < count) part_val[dest[j]] = (uint32_t)stage[p];
+            }
         }
     }
 }
@@ -738,6 +762,86 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const TI* __restr
     const uint64_t remain = n - base;
     const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(unsigned)(key[base + p]) & (W - 1)] = (TI)(val[base + p] - (SUB1 ? 1u : 0u));
+    __syncthreads();
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
+}
+
+// The same two kernels for pairs packed into one 64-bit entry (position in the low half, rank in the high half; at most
+// 2^32 positions): one array, one staging round, runs of 64 to 128 bytes where the two-array form writes two of 32 to 64.
+// FIRST: the level reads (SA, bucket id) words and packs (position - koff, id - 1).
+template <typename TI, int BLOCK, int ITEMS, bool FIRST, int CB>
+__global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __restrict__ key_in, const TI* __restrict__ val_in,
+                                                                 const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n,
+                                                                 unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
+    constexpr int NCLS = 1 << CB;
+    static_assert(BLOCK >= NCLS, "one thread per class");
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint64_t stage[TILE];
+    __shared__ unsigned cnt[NCLS];
+    __shared__ unsigned bstart[NCLS];
+    __shared__ uint64_t gbase[NCLS];
+    __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
+    const unsigned tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
+    for (int i = tid; i < NCLS; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    uint64_t rec[ITEMS];
+    unsigned slot[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        if (loc < count) {
+            if (FIRST) rec[i] = (uint64_t)(uint32_t)((uint64_t)key_in[base + loc] - koff) | ((uint64_t)(uint32_t)((uint64_t)val_in[base + loc] - 1u) << 32);
+            else rec[i] = in[base + loc];
+        } else rec[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        const unsigned d = ((uint32_t)rec[i] >> shift) & (NCLS - 1);
+        slot[i] = loc < count ? atomicAdd(&cnt[d], 1u) : 0u;
+    }
+    __syncthreads();
+    const unsigned tot = tid < NCLS ? cnt[tid] : 0u;
+    unsigned total;
+    const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, scan_tmp, &total);
+    if (tid < NCLS) {
+        bstart[tid] = bs;
+        if (tot) {
+            // all keys of a tile share the bits above shift + CB (tiles never straddle a parent bucket)
+            const uint64_t first_key = FIRST ? (uint64_t)key_in[base] - koff : (uint64_t)(uint32_t)in[base];
+            const uint64_t g = ((first_key >> shift >> CB) << CB) | tid;
+            const unsigned at = atomicAdd(&cursors[g], tot);
+            gbase[tid] = (g << shift) + at - bs;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned d = ((uint32_t)rec[i] >> shift) & (NCLS - 1);
+        if (tid + i * BLOCK < count) stage[slot[i] + bstart[d]] = rec[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (p < count) {
+            const uint64_t x = stage[p];
+            out[gbase[((uint32_t)x >> shift) & (NCLS - 1)] + p] = x;
+        }
+    }
+}
+
+template <typename TO, int BLOCK, int WB>
+__global__ __launch_bounds__(BLOCK) void window_scatter_packed_kernel(const uint64_t* __restrict__ pairs, uint64_t n, TO* __restrict__ out) {
+    constexpr unsigned W = 1u << WB;
+    __shared__ uint32_t win[W];
+    const uint64_t base = (uint64_t)blockIdx.x * W;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) { const uint64_t x = pairs[base + p]; win[(uint32_t)x & (W - 1)] = (uint32_t)(x >> 32); }
     __syncthreads();
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
 }

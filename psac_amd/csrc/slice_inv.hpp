@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512) void slice_hist_kernel(const T* __restrict__ S
 template <typename T, typename V, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void slice_partition_kernel(const T* __restrict__ SA, const T* __restrict__ B, uint64_t n, SliceMap map,
                                                                 unsigned long long* __restrict__ cursors, uint32_t* __restrict__ key_out,
-                                                                V* __restrict__ val_out) {
+                                                                V* __restrict__ val_out, T* __restrict__ b_copy = nullptr) {
+    // b_copy (optional): the bucket ids B are written there as well (reduced-memory layout: they were parked in the ISA array,
+    // which the inversion is about to overwrite)
     constexpr int TILE = BLOCK * ITEMS;
     static_assert(BLOCK >= SLICE_MAX_CLASSES, "one thread per class");
     __shared__ V stage[TILE];
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(BLOCK) void slice_partition_kernel(const T* __restr
             const uint64_t rel = g - map.off(o);
             key[i] = (uint32_t)rel;
             cls[i] = (unsigned short)(o * map.spo + (unsigned)(rel >> map.sb));
-            val[i] = (V)((uint64_t)B[base + loc] - 1u);
+            const T bb = B[base + loc];
+            val[i] = (V)((uint64_t)bb - 1u);
+            if (b_copy) b_copy[base + loc] = bb;
         } else { key[i] = 0; cls[i] = 0; val[i] = 0; }
     }
 #pragma unroll
