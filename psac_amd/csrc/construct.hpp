@@ -199,7 +199,7 @@ inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
 constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;
 template <typename T>
 inline int isa_narrow_levels(uint64_t n, const Knobs& kn) {
-    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || kn.isa_wide || kn.isa_cb8) return 0;
+    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || kn.isa_wide) return 0;
     const unsigned idx_bits = bits_for(n - 1);
     return (int)((idx_bits - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
 }
@@ -314,32 +314,6 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
         }
         const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
         hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 1024, false, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, k32, v32, n, d_isa);
-        PSACX_HIP(c, hipGetLastError());
-        return PSACX_OK;
-    }
-    if (narrow) {
-        // both 32-bit arrays of a set share that set's first array (t2.k2 may be the ISA array itself, and the window scatter
-        // below widens while it writes: it cannot run in place)
-        uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
-                              {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
-        const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
-        const uint32_t* k32 = nullptr; const uint32_t* v32 = nullptr;
-        for (int lv = 0; lv < levels; ++lv) {
-            const unsigned shift = INV_WINDOW_BITS + 8 * (levels - 1 - lv);
-            const size_t ncur = (size_t)(n >> shift) + 1;
-            PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
-            uint32_t* ko = nb[lv & 1][0]; uint32_t* vo = nb[lv & 1][1];
-            if (lv == 0)
-                hipLaunchKernelGGL((partition_pairs_kernel<T, uint32_t, PB, PI, true>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
-                                   ko, vo, n, shift, d_cursors, koff);
-            else
-                hipLaunchKernelGGL((partition_pairs_kernel<uint32_t, uint32_t, PB, PI, false>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, k32, v32,
-                                   ko, vo, n, shift, d_cursors, (uint64_t)0);
-            PSACX_HIP(c, hipGetLastError());
-            k32 = ko; v32 = vo;
-        }
-        const uint64_t nwin = (n + (1ull << INV_WINDOW_BITS) - 1) >> INV_WINDOW_BITS;
-        hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 512, false>), dim3((unsigned)nwin), dim3(512), 0, c->stream, k32, v32, n, d_isa);
         PSACX_HIP(c, hipGetLastError());
         return PSACX_OK;
     }

@@ -135,7 +135,6 @@ struct Knobs {
     unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
     bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
     bool isa_wide;          // PSACX_ISA_WIDE: 64-bit words: pairs stay 64-bit
-    bool isa_cb8;           // PSACX_ISA_CB8: 256-way levels and 2^12-entry windows
     bool no_fused_l1;       // PSACX_NO_FUSED_L1: first inversion level as its own kernel
     bool no_rmq_aux;        // PSACX_NO_RMQ_AUX: range minima without the running-minimum tables
     bool isa_two_arrays;    // PSACX_ISA_TWO_ARRAYS: the 32-bit pairs of the SA -> ISA levels in two arrays instead of one of packed entries
@@ -155,7 +154,6 @@ inline Knobs read_knobs() {
     k.lead_slack = e ? (unsigned)atoi(e) : 2u;
     k.isa_partition = getenv("PSACX_ISA_PARTITION") != nullptr;
     k.isa_wide = getenv("PSACX_ISA_WIDE") != nullptr;
-    k.isa_cb8 = getenv("PSACX_ISA_CB8") != nullptr;
     k.no_fused_l1 = getenv("PSACX_NO_FUSED_L1") != nullptr;
     k.no_rmq_aux = getenv("PSACX_NO_RMQ_AUX") != nullptr;
     k.no_whole_rounds = getenv("PSACX_NO_WHOLE_ROUNDS") != nullptr;
@@ -463,13 +461,6 @@ inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_
 #undef PSACX_SC
 }
 
-inline bool narrow_off_env() { static const bool off = getenv("PSACX_WIDE_PAYLOAD") != nullptr; return off; }
-inline int sort_match_env() {    // 1 = lane-mask table in LDS (default shapes only), anything else / unset = ballot ranking
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("PSACX_SORT_MATCH"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
 inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three kernels per pass
     static int v = -2;
     if (v == -2) { const char* e = getenv("PSACX_SORT_MODE"); v = e ? atoi(e) : -1; }
@@ -496,9 +487,6 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
                            const_cast<unsigned long long*>(base));
     }
     ProfScope ps(c, ko_in ? TC_SORT_SCATTER3 : TC_SORT_SCATTER2);
-    // the default shapes exist in the lane-mask-table form as well (radix.hpp: MATCH), selected with PSACX_SORT_MATCH=1.
-    // Measured (profiles/README.md, r02p): it halves the vector instructions of the pass and changes its time by
-    // -2 % (2^32 uint64) / +3 % (2^28 uint32) -- the pass is not bound by its VALU work after all -- so the ballot form stays.
     constexpr bool DEF_SHAPE = BLOCK == 512 && ITEMS == (sizeof(T) == 4 ? 12 : 8);
     constexpr bool NARROW_OK = DEF_SHAPE && sizeof(T) == 8;       // 32-bit payload arrays (radix.hpp: VN), default shape only (8192-record tiles measured: 33.6-34.9 against 28.1 ms per pass)
     if (NARROW_OK && vn && !ko_in) {
@@ -506,7 +494,7 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
         // registers capped for six waves per SIMD = three workgroups per CU: the narrow forms need 82, the cap costs them a
         // few spilled registers and gains a third tile in flight (the pass is bound by the latency chain of a tile)
 #define PSACX_VN(V)                                                                                                                          \
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, (NARROW_OK ? 6 : MINW), true, 0, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, (NARROW_OK ? 6 : MINW), true, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,                    \
                            reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles, (uint64_t)0, pack)
         switch (vn) {
@@ -518,17 +506,6 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
             default: PSACX_VN(6); break;
         }
 #undef PSACX_VN
-        return;
-    }
-    if (DEF_SHAPE && sort_match_env() == 1) {
-        if (ko_in)
-            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, false, DEF_SHAPE ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
-        else
-            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true, DEF_SHAPE ? 1 : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                               reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
         return;
     }
     if (ko_in)
@@ -613,19 +590,19 @@ int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, con
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, d_base);
     const T* dsrc = reinterpret_cast<const T*>(cls);
     if (sizeof(T) == 8 && pf.bytes == 1)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 3 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 3 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
     else if (sizeof(T) == 8 && pf.bytes == 2)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 5 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 5 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
     else if (sizeof(T) == 8 && v32)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, (sizeof(T) == 8 ? 1 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 1 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
     else
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, 0, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, 0, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
     PSACX_HIP(c, hipGetLastError());
@@ -757,7 +734,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 
     // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
-    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in) && cfg == ScatterCfg<T>::DEF2 && (!narrow_off_env() || v32_in);
+    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in) && cfg == ScatterCfg<T>::DEF2;
     if (v32_in && !narrow) return PSACX_EINVAL;
     const bool packed = pf.on() && three && sizeof(T) == 8 && !in.k2 && (iota || packed_in) && cfg == ScatterCfg<T>::DEF2 && pf.bits <= lo1;
     if (packed_in && !packed) return PSACX_EINVAL;

@@ -131,15 +131,12 @@ __device__ __forceinline__ uint64_t match_any8(unsigned d, bool valid) {
 // kd_*: the key word that carries this pass's digit; ko_*: the other key word;
 // v_in may be null, in which case the payload is the record's global index.
 // dbg (optional): every 64th tile stores shader-clock stamps of its phases.
-// MATCH = 1 (the default shapes of the large sorts): the lanes of a wave that hold the same digit find each other through
-// a per-wave table of 64-bit lane masks in LDS (one ds_or, one ds_read, one clearing store per record) instead of eight
-// ballots followed by per-lane 64-bit select-and-AND (48 vector instructions per record: the pass was bound by its
-// VALU work, PMC in profiles/r02l_*); the digit byte of every staged record is not kept either, the final position of
-// every output slot is computed once from the staged digit word and held in registers.
-template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
+// (A variant that found the lanes of a wave with equal digits through a per-wave table of 64-bit lane masks in LDS instead of
+//  eight ballots halved the vector instructions of the pass and changed its time by -2 % / +3 %: removed in round 3,
+//  DESIGN section 7.)
+template <typename T, int TILE, int NW> struct ScatterShared {
     T stage[TILE];
-    uint8_t sdig[MATCH ? 1 : TILE];          // digit of the record at each tile-sorted position
-    unsigned long long mtab[MATCH ? NW * RADIX : 1];   // per wave and digit: lanes holding that digit in the current round
+    uint8_t sdig[TILE];          // digit of the record at each tile-sorted position
     unsigned wcnt[NW * RADIX];   // per-wave digit counters -> per-wave exclusive bases
     unsigned bstart[RADIX];      // tile-local start of each digit
     T goff[RADIX];               // global offset of digit run minus bstart (wraps)
@@ -164,9 +161,9 @@ template <typename T, int TILE, int NW, int MATCH = 0> struct ScatterShared {
 // the key word leaves with the payload bits still in its low end).
 // CLSB (EXT only): bytes per entry of the class array dsrc (sizeof(T), or 1 for a byte array).
 // voff: added to the payload a pass makes up itself (v_in == nullptr): the records of a rank's block, or of a piece of it.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int MATCH = 0, int VN = 0, int CLSB = sizeof(T)>
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int VN = 0, int CLSB = sizeof(T)>
 __device__ __forceinline__ void radix_scatter_tile(
-    ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE, MATCH>& sh, const unsigned tile, const unsigned count,
+    ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, int shift,
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
@@ -260,14 +257,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const bool valid = FULL || (wbase + i * WAVE) < count;
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
-        uint64_t m;
-        if (MATCH) {
-            unsigned long long* slot = sh.mtab + wave * RADIX + d;
-            if (valid) __hip_atomic_fetch_or(slot, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            m = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (!valid) m = 0;
-            else __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ready for the next round
-        } else m = match_any8(d, valid);
+        const uint64_t m = match_any8(d, valid);
         const unsigned prior = __hip_atomic_load(&mycnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         // lanes of the group below this one (mbcnt: no lane mask held in registers)
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -329,10 +319,9 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
-        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; if (!MATCH) sdig[MATCH ? 0 : rank[i]] = (uint8_t)d; }
+        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; sdig[rank[i]] = (uint8_t)d; }
     }
     __syncthreads();
-    T dest[MATCH ? ITEMS : 1];          // MATCH: global position of output slot tid + j * BLOCK, reused for every word
     T xlow[PK_OUT_FULL ? ITEMS : 1];    // packed payload on its way out: the bits the key word of output slot tid + j * BLOCK carries
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -340,8 +329,7 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (FULL || p < count) {
             const T x = stage[p];
             if (PK_OUT_FULL) xlow[PK_OUT_FULL ? j : 0] = (T)(x & pmask);
-            if (MATCH) { dest[MATCH ? j : 0] = (T)(goff[(unsigned)(x >> shift) & (RADIX - 1)] + (T)p); kd_out[dest[MATCH ? j : 0]] = x; }
-            else kd_out[(T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = x;
+            kd_out[(T)(goff[sdig[p]] + (T)p)] = x;
         }
     }
     __syncthreads();
@@ -354,7 +342,7 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const unsigned p = tid + j * BLOCK;
-            if (FULL || p < count) ko_out[MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p)] = stage[p];
+            if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
         }
         __syncthreads();
     }
@@ -367,7 +355,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (FULL || p < count) {
-            const T at = MATCH ? dest[MATCH ? j : 0] : (T)(goff[sdig[MATCH ? 0 : p]] + (T)p);
+            const T at = (T)(goff[sdig[p]] + (T)p);
             if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)stage[p];
             else if (VN == 3) reinterpret_cast<uint8_t*>(v_out)[at] = (uint8_t)stage[p];
             else if (VN == 5) reinterpret_cast<uint16_t*>(v_out)[at] = (uint16_t)stage[p];
@@ -554,7 +542,7 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int MATCH = 0, int VN = 0, int CLSB = sizeof(T)>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int VN = 0, int CLSB = sizeof(T)>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
@@ -567,23 +555,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
-    static_assert(!(MATCH && EXT), "the lane-mask table form takes its digit from the key word");
     static_assert(VN == 0 || (sizeof(T) == 8 && NOKO), "narrow payloads exist for two-word records of 64-bit words");
-    __shared__ ScatterShared<T, TILE, NW, MATCH> sh;
+    __shared__ ScatterShared<T, TILE, NW> sh;
     // tiles are handed out in start order so that neighbouring runs of a digit are written
     // close in time (they share cache lines); nothing ever waits on another workgroup
     if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
-    if (MATCH) for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.mtab[MATCH ? i : 0] = 0;
     __syncthreads();
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, VN, CLSB>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, MATCH, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                          spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
 }

@@ -161,7 +161,7 @@ def test_isa_inversion_partition_path(ctx):
         assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
 
 
-@pytest.mark.parametrize("env", ["PSACX_NO_FUSED_L1", "PSACX_ISA_CB8", "PSACX_ISA_WIDE", "PSACX_ISA_PARTITION", "PSACX_ISA_TWO_ARRAYS"])
+@pytest.mark.parametrize("env", ["PSACX_NO_FUSED_L1", "PSACX_ISA_WIDE", "PSACX_ISA_PARTITION", "PSACX_ISA_TWO_ARRAYS"])
 def test_isa_inversion_earlier_forms(ctx, monkeypatch, env):
     # The default SA -> ISA inversion (first level fused into rebucket_first_kernel, 512-way levels, 2^14-entry windows)
     # against its earlier forms, which stay selectable: the results must be identical (and are checked on their own).
