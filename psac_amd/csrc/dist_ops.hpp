@@ -350,7 +350,10 @@ int counts_back(psacx_ctx* c, TileScratch& ts, uint64_t ntiles, uint64_t* nact, 
 
 template <typename T>
 int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint64_t cnt, uint64_t n, uint32_t l, uint32_t c1,
-                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf, bool gsa = false, T* sa_out = nullptr) {
+                      uint32_t c2, const psacx_boundary* b, T* bsa, T* lcp, uint64_t* nact, uint64_t* nunf, bool gsa = false, T* sa_out = nullptr,
+                      uint64_t* tile_nact_out = nullptr) {
+    // tile_nact_out (optional, ceil(cnt / ScanCfg<T>::TILE) entries): the per-tile counts of unresolved positions the kernel
+    // produces, kept for the compaction that follows (op_compact_counted) instead of counting them again
     OP_PROLOGUE(c);
     *nact = *nunf = 0;
     if (cnt == 0) return PSACX_OK;
@@ -374,6 +377,7 @@ int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint6
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, false>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, s1, s2, sa, cnt, ks, bsa, (T*)nullptr, ts.carry, ts.nact, ts.nunf, n, bd, (T*)nullptr, (unsigned*)nullptr, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (unsigned*)nullptr, sa_out);
     PSACX_HIP(c, hipGetLastError());
+    if (tile_nact_out) PSACX_HIP(c, hipMemcpyAsync(tile_nact_out, ts.nact, ntiles * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     return counts_back<T>(c, ts, ntiles, nact, nunf);
 }
 
@@ -428,6 +432,19 @@ int op_compact(psacx_ctx* c, const T* ids, const T* pos, uint64_t cnt, uint64_t 
     PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *n_out = *reinterpret_cast<uint64_t*>(c->pinned);
+    return PSACX_OK;
+}
+
+// op_compact with the per-tile counts given (tile_nact: device array, turned into offsets in place): one pass over the ids
+template <typename T>
+int op_compact_counted(psacx_ctx* c, const T* ids, uint64_t cnt, uint64_t off, uint64_t prev_id, uint64_t next_id, uint64_t* tile_nact, T* pos_out) {
+    OP_PROLOGUE(c);
+    if (cnt == 0) return PSACX_OK;
+    const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+    hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, tile_nact, ntiles, OpSum(), (uint64_t)0, (uint64_t*)nullptr);
+    hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, (const T*)nullptr,
+                       cnt, pos_out, tile_nact, off, (T)prev_id, (T)next_id);
+    PSACX_HIP(c, hipGetLastError());
     return PSACX_OK;
 }
 

@@ -1700,6 +1700,9 @@ struct MultiRun {
         map.div = n / P; map.mod = n % P; map.P = (unsigned)P; map.sb = sb; map.spo = spo; map.dshift = -1;
         if (map.mod == 0 && map.div && (map.div & (map.div - 1)) == 0) { map.dshift = 0; while ((1ull << map.dshift) < map.div) ++map.dshift; }
         const uint64_t slice = 1ull << sb;
+        // ranks below 2^32: a pair is one 64-bit entry (position | rank << 32) on the wire and in every level (slice_inv.hpp:
+        // *_packed_kernel; PSACX_SLICE_TWO_ARRAYS=1 keeps the two-array form)
+        const bool pack = sizeof(V) == 4 && !getenv("PSACX_SLICE_TWO_ARRAYS");
 
         // 1. pairs per class on every rank; every rank learns the whole table
         std::vector<std::vector<uint64_t>> counts(L, std::vector<uint64_t>(C, 0));
@@ -1764,7 +1767,10 @@ struct MultiRun {
                 ct.cap = std::max(bytes, res); ct.used = 0;
                 return ct.take(bytes);
             };
-            auto pair = [&](Ptrs& q, uint64_t cnt) { q.k = (uint32_t*)arr((size_t)cnt * 4); q.v = rc_a == PSACX_OK ? (V*)arr((size_t)cnt * sizeof(V)) : nullptr; };
+            auto pair = [&](Ptrs& q, uint64_t cnt) {
+                if (pack) { q.k = (uint32_t*)arr((size_t)cnt * 8); q.v = nullptr; }
+                else { q.k = (uint32_t*)arr((size_t)cnt * 4); q.v = rc_a == PSACX_OK ? (V*)arr((size_t)cnt * sizeof(V)) : nullptr; }
+            };
             pair(pk_[i], m);
             const uint64_t cap = std::min<uint64_t>(step_cap, std::max<uint64_t>(m, 1));
             if (rc_a == PSACX_OK && !solo_) pair(A0[i], cap);
@@ -1776,6 +1782,11 @@ struct MultiRun {
             std::memset(c->pinned + 32768, 0, SLICE_MAX_CLASSES * 8);
             std::memcpy(c->pinned + 32768, cstart[i].data(), (size_t)C * 8);
             MG_HIP(g, hipMemcpyAsync(d_cnt[i].p, c->pinned + 32768, SLICE_MAX_CLASSES * 8, hipMemcpyHostToDevice, c->stream));
+            if (pack)
+                hipLaunchKernelGGL((slice_partition_packed_kernel<T, PB, 8>), dim3((unsigned)((m + PB * 8 - 1) / (PB * 8))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
+                                   ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, reinterpret_cast<uint64_t*>(pk_[i].k),
+                                   ids_in_isa ? S[i].Bsa.p : (T*)nullptr);
+            else
             hipLaunchKernelGGL((slice_partition_kernel<T, V, PB, PI>), dim3((unsigned)((m + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
                                ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, pk_[i].k, pk_[i].v, ids_in_isa ? S[i].Bsa.p : (T*)nullptr);
             MG_HIP(g, hipGetLastError());
@@ -1806,9 +1817,10 @@ struct MultiRun {
                     for (int r = 0; r < P; ++r) { const uint64_t cn = table[(size_t)r * C + (unsigned)me * spo + sl]; recvs[i].push_back(Msg{r, at, cn}); at += cn; }
                 }
                 Ptrs& A = (t & 1) ? A1[i] : A0[i];
-                in[i] = {pk_[i].k, pk_[i].v};
-                out[i] = {A.k, A.v};
+                if (pack) { in[i] = {pk_[i].k}; out[i] = {A.k}; }
+                else { in[i] = {pk_[i].k, pk_[i].v}; out[i] = {A.k, A.v}; }
             }
+            if (pack) return transfer(in, out, {sizeof(uint64_t)}, sends, recvs, &done[t & 1]);
             return transfer(in, out, {sizeof(uint32_t), sizeof(V)}, sends, recvs, &done[t & 1]);
         };
         int rc = PSACX_OK;
@@ -1827,6 +1839,24 @@ struct MultiRun {
                 const uint32_t* ks = solo_ ? pk_[i].k : A.k; const V* vs = solo_ ? pk_[i].v : A.v;
                 uint32_t* ka = solo_ ? pk_[i].k : A.k; V* va = solo_ ? pk_[i].v : A.v;
                 unsigned below = rbits;                        // bits still to partition on beneath the current level
+                if (pack) {
+                    const uint64_t* cur_in = reinterpret_cast<const uint64_t*>(ks);
+                    uint64_t* mine = reinterpret_cast<uint64_t*>(ka);
+                    for (unsigned j = 0; j < levels2; ++j) {
+                        below -= cbs[j];
+                        const unsigned shift = wb + below;
+                        MG_HIP(g, hipMemsetAsync(cur[i], 0, ((len >> shift) + 2) * sizeof(unsigned), c->stream));
+                        uint64_t* o = (j & 1) ? mine : reinterpret_cast<uint64_t*>(Bb[i].k);
+                        hipLaunchKernelGGL((pairs_partition_packed_kernel<PB, PI>), dim3((unsigned)((len + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, cur_in, o, len,
+                                           shift, cbs[j], cur[i], j == 0 ? (uint32_t)lo : 0u);
+                        MG_HIP(g, hipGetLastError());
+                        cur_in = o;
+                    }
+                    hipLaunchKernelGGL((pairs_window_packed_kernel<T, 1024, WBMAX>), dim3((unsigned)((len + (1ull << wb) - 1) >> wb)), dim3(1024), 0, c->stream, cur_in, len, wb,
+                                       levels2 ? 0u : (uint32_t)lo, S[i].ISA + lo);
+                    MG_HIP(g, hipGetLastError());
+                    return PSACX_OK;
+                }
                 for (unsigned j = 0; j < levels2; ++j) {
                     below -= cbs[j];
                     const unsigned shift = wb + below;
@@ -2431,6 +2461,7 @@ struct MultiRun {
         }));
         PSACX_TRY(gather1(lh, heads));
         std::vector<uint64_t> nact(L), nunf(L);
+        std::vector<DBuf<uint64_t>> tile_act(L);      // per-tile counts of unresolved positions out of the rebucket kernel
         const bool slices = !getenv("PSACX_MULTI_NO_SLICES") && sizes[0] <= (1ull << 32);      // SA -> ISA by destination slices (below)
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
@@ -2442,8 +2473,9 @@ struct MultiRun {
             T* bsa_out = S[i].ISA;
             if (!diet) { MG_OP(g, c, S[i].Bsa.alloc(c, S[i].m)); bsa_out = S[i].Bsa.p; }
             // (the suffixes go to the rank's SA block on the way, unless they sit there already)
+            MG_OP(g, c, tile_act[i].alloc(c, (rec[i].cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE + 1));
             MG_OP(g, c, op_rebucket_first<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, rec[i].cnt, n, lc, c1, c2, &bd[i], bsa_out, S[i].LCP, &nact[i], &nunf[i], gsa,
-                                             rec[i].v.p != S[i].SA ? S[i].SA : (T*)nullptr));
+                                             rec[i].v.p != S[i].SA ? S[i].SA : (T*)nullptr, tile_act[i].p));
             drop3(i, rec[i]);
             S[i].out_busy = true;
             if (diet) {
@@ -2477,7 +2509,7 @@ struct MultiRun {
         uint64_t unf_b = 0, unf_e = 0;
         {
             std::vector<DBuf<T>> kept;
-            PSACX_TRY(next_active(nullptr, nullptr, nact, nunf, kept, &unf_b, &unf_e));
+            PSACX_TRY(next_active(nullptr, nullptr, nact, nunf, kept, &unf_b, &unf_e, &tile_act));
             for (int i = 0; i < L; ++i) S[i].pos = std::move(kept[i]);
         }
         mark("active list");
@@ -3176,8 +3208,10 @@ struct MultiRun {
 
     // boundary bucket ids of every block, the list of positions that still share a bucket (suffix_array.hpp:925-965)
     // and the global counters.  ids == nullptr: first round (ids = Bsa, every position is a list entry).
+    // tile_counts (first round): the per-tile counts the rebucket kernel left (op_rebucket_first); the compaction then reads the
+    // ids once instead of twice and writes straight into a list of the known length
     int next_active(std::vector<DBuf<T>>* ids, const std::vector<const T*>* plist, const std::vector<uint64_t>& nact, const std::vector<uint64_t>& nunf,
-                    std::vector<DBuf<T>>& kept_out, uint64_t* unf_b, uint64_t* unf_e) {
+                    std::vector<DBuf<T>>& kept_out, uint64_t* unf_b, uint64_t* unf_e, std::vector<DBuf<uint64_t>>* tile_counts = nullptr) {
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(5, 0));
         std::vector<uint64_t> cnt(L);
         PSACX_TRY(par([&](int i) -> int {
@@ -3202,6 +3236,11 @@ struct MultiRun {
             uint64_t pid = 0, nid = 0;
             for (int s = r - 1; s >= 0; --s) if (all[(size_t)s * 5]) { pid = all[(size_t)s * 5 + 2]; break; }
             for (int s = r + 1; s < P; ++s) if (all[(size_t)s * 5]) { nid = all[(size_t)s * 5 + 1]; break; }
+            if (tile_counts && !ids && (*tile_counts)[i].p) {
+                MG_OP(g, c, kept_out[i].alloc(c, nact[i]));
+                MG_OP(g, c, op_compact_counted<T>(c, S[i].Bsa.p, cnt[i], S[i].off, pid, nid, (*tile_counts)[i].p, kept_out[i].p));
+                return PSACX_OK;
+            }
             DBuf<T> out; MG_OP(g, c, out.alloc(c, cnt[i]));
             uint64_t kept = 0;
             MG_OP(g, c, op_compact<T>(c, ids ? (*ids)[i].p : S[i].Bsa.p, ids ? (*plist)[i] : (const T*)nullptr, cnt[i], S[i].off, pid, nid, out.p, &kept));

@@ -225,4 +225,136 @@ __global__ __launch_bounds__(BLOCK) void pairs_window_kernel(const uint32_t* __r
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
 }
 
+// ---- the same three kernels on packed pairs (ranks below 2^32: position in the low half of a 64-bit entry, rank in the high
+// half): one array on the wire and in every level, one LDS staging round, runs twice as long (see partition_packed_kernel).
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void slice_partition_packed_kernel(const T* __restrict__ SA, const T* __restrict__ B, uint64_t n, SliceMap map,
+                                                                       unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out,
+                                                                       T* __restrict__ b_copy = nullptr) {
+    constexpr int TILE = BLOCK * ITEMS;
+    static_assert(BLOCK >= SLICE_MAX_CLASSES, "one thread per class");
+    __shared__ uint64_t stage[TILE];
+    __shared__ unsigned short cstage[TILE];
+    __shared__ unsigned cnt[SLICE_MAX_CLASSES];
+    __shared__ unsigned bstart[SLICE_MAX_CLASSES];
+    __shared__ unsigned long long gbase[SLICE_MAX_CLASSES];
+    __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
+    const unsigned tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
+    for (int i = tid; i < SLICE_MAX_CLASSES; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    uint64_t rec[ITEMS];
+    unsigned short cls[ITEMS];
+    unsigned slot[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        if (loc < count) {
+            const uint64_t g = SA[base + loc];
+            const unsigned o = map.owner(g);
+            const uint64_t rel = g - map.off(o);
+            const T bb = B[base + loc];
+            rec[i] = (uint64_t)(uint32_t)rel | ((uint64_t)(uint32_t)((uint64_t)bb - 1u) << 32);
+            cls[i] = (unsigned short)(o * map.spo + (unsigned)(rel >> map.sb));
+            if (b_copy) b_copy[base + loc] = bb;
+        } else { rec[i] = 0; cls[i] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) slot[i] = (tid + i * BLOCK) < count ? atomicAdd(&cnt[cls[i]], 1u) : 0u;
+    __syncthreads();
+    const unsigned tot = tid < SLICE_MAX_CLASSES ? cnt[tid] : 0u;
+    unsigned total;
+    const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, scan_tmp, &total);
+    if (tid < SLICE_MAX_CLASSES) {
+        bstart[tid] = bs;
+        if (tot) gbase[tid] = atomicAdd(&cursors[tid], (unsigned long long)tot);
+    }
+    __syncthreads();
+    // staged by class; the class of every staged slot is kept beside it
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (tid + i * BLOCK < count) { const unsigned at = slot[i] + bstart[cls[i]]; stage[at] = rec[i]; cstage[at] = cls[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (p < count) { const unsigned cc = cstage[p]; out[gbase[cc] + (p - bstart[cc])] = stage[p]; }
+    }
+}
+
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void pairs_partition_packed_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n, unsigned shift,
+                                                                       unsigned cb, unsigned* __restrict__ cursors, uint32_t koff) {
+    constexpr int NMAX = 512;
+    static_assert(BLOCK >= NMAX, "one thread per class");
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint64_t stage[TILE];
+    __shared__ unsigned cnt[NMAX];
+    __shared__ unsigned bstart[NMAX];
+    __shared__ uint64_t gbase[NMAX];
+    __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
+    const unsigned ncls = 1u << cb;
+    const unsigned tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
+    for (int i = tid; i < NMAX; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    uint64_t rec[ITEMS];
+    unsigned slot[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = tid + i * BLOCK;
+        if (loc < count) { const uint64_t x = in[base + loc]; rec[i] = (x & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)x - koff); }
+        else rec[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned d = ((uint32_t)rec[i] >> shift) & (ncls - 1);
+        slot[i] = (tid + i * BLOCK) < count ? atomicAdd(&cnt[d], 1u) : 0u;
+    }
+    __syncthreads();
+    const unsigned tot = tid < ncls ? cnt[tid] : 0u;
+    unsigned total;
+    const unsigned bs = block_scan_exclusive<BLOCK, unsigned>(tot, OpSum(), 0u, scan_tmp, &total);
+    if (tid < ncls) {
+        bstart[tid] = bs;
+        if (tot) {
+            const uint64_t parent = (uint64_t)((uint32_t)in[base] - koff) >> shift >> cb;        // same for the whole tile
+            const uint64_t gq = (parent << cb) | tid;
+            const unsigned at = atomicAdd(&cursors[gq], tot);
+            gbase[tid] = (gq << shift) + at - bs;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned d = ((uint32_t)rec[i] >> shift) & (ncls - 1);
+        if (tid + i * BLOCK < count) stage[slot[i] + bstart[d]] = rec[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned p = tid + j * BLOCK;
+        if (p < count) {
+            const uint64_t x = stage[p];
+            out[gbase[((uint32_t)x >> shift) & (ncls - 1)] + p] = x;
+        }
+    }
+}
+
+template <typename TO, int BLOCK, int WBMAX>
+__global__ __launch_bounds__(BLOCK) void pairs_window_packed_kernel(const uint64_t* __restrict__ pairs, uint64_t n, unsigned wb, uint32_t koff, TO* __restrict__ out) {
+    __shared__ uint32_t win[1u << WBMAX];
+    const unsigned W = 1u << wb;
+    const uint64_t base = (uint64_t)blockIdx.x * W;
+    const uint64_t remain = n - base;
+    const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) { const uint64_t x = pairs[base + p]; win[((uint32_t)x - koff) & (W - 1)] = (uint32_t)(x >> 32); }
+    __syncthreads();
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
+}
+
 } // namespace psacx

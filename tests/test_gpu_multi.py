@@ -757,13 +757,17 @@ def test_multi_isa_by_destination_slices(P, wb, s1, step, monkeypatch):
     monkeypatch.setenv("PSACX_SLICE_S1", str(s1))
     if step:
         monkeypatch.setenv("PSACX_SLICE_STEP", str(step))
-    mg = multi(P)
-    try:
-        for text, bits in ((O.rand_dna(300007, 7), 64), (O.rand_dna(131072 * P, 9), 32), (inputs.tandem(90001, 256, O.rand_dna(256, 3)), 32),
-                           (inputs.ascii128(70000, 3), 64), (O.as_text("mississippi"), 64), (np.full(9001, 65, np.uint8), 32)):
-            SA, ISA, LCP, rounds = same(mg, text, bits)
-            ref = O.construct(text, bits=bits)
-            assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, text.size)
-            assert mg.last_form()["slice_inversion"]
-    finally:
-        mg.close()
+    # (the pairs travel and are partitioned as packed 64-bit entries; PSACX_SLICE_TWO_ARRAYS=1: as two 32-bit arrays)
+    for two in (False, True):
+        if two:
+            monkeypatch.setenv("PSACX_SLICE_TWO_ARRAYS", "1")
+        mg = multi(P)
+        try:
+            for text, bits in ((O.rand_dna(300007, 7), 64), (O.rand_dna(131072 * P, 9), 32), (inputs.tandem(90001, 256, O.rand_dna(256, 3)), 32),
+                               (inputs.ascii128(70000, 3), 64), (O.as_text("mississippi"), 64), (np.full(9001, 65, np.uint8), 32)):
+                SA, ISA, LCP, rounds = same(mg, text, bits)
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, bits, text.size, two)
+                assert mg.last_form()["slice_inversion"]
+        finally:
+            mg.close()
