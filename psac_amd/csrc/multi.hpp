@@ -1318,6 +1318,15 @@ struct MultiRun {
                             const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec_front) {
         ++sort_calls_;
         constexpr int SAMPLES = 8192;
+        // Shuffle by key ranges (default with more than one rank): every destination's share of the prefix space is cut into QR
+        // ranges, the block is partitioned once by (destination, range), range q of every destination travels in exchange q, and
+        // the receiver sorts range q -- complete and final as soon as it has landed -- on its compute stream while ranges
+        // q + 1 .. are still in flight on the second stream: the local sort runs under the shuffle (idxsort.hpp:58-62 sorts after
+        // its Alltoallv has returned).  PSACX_MULTI_SHUFFLE_BY_POSITION=1: the earlier form (pieces of the block by position,
+        // piece q + 1 partitioned while piece q travels, one local sort at the end).
+        const bool by_range = !solo_ && !getenv("PSACX_MULTI_SHUFFLE_BY_POSITION");
+        int QR = 1;
+        if (by_range) { QR = std::max(1, std::min(4, 64 / P)); if (const char* e = getenv("PSACX_MULTI_PIECES")) QR = std::max(1, std::min(64 / P, atoi(e))); }
         std::vector<uint64_t> spl;
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + SAMPLES, 0));
@@ -1351,12 +1360,18 @@ struct MultiRun {
                 for (size_t j = 1; j < flat.size(); ++j) dup += flat[j] == flat[j - 1];
                 if (dup * 64 > flat.size()) return PSACX_RETRY_;
             }
-            for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
-            spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+            if (by_range) {
+                // P * QR key ranges, QR consecutive ones per destination (equal splitters leave a range empty: the class numbers
+                // must stay destination * QR + range)
+                for (int cc = 1; cc < P * QR && !flat.empty(); ++cc) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * cc / (size_t)(P * QR))]);
+            } else {
+                for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
+                spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+            }
             if (!trust && !flat.empty() && P > 1) {
                 // the share of the samples each destination would receive (destination = splitters <= prefix)
                 std::vector<size_t> share(P, 0);
-                for (uint64_t x : flat) share[std::upper_bound(spl.begin(), spl.end(), x) - spl.begin()]++;
+                for (uint64_t x : flat) share[std::min<size_t>((size_t)(std::upper_bound(spl.begin(), spl.end(), x) - spl.begin()) / (by_range ? QR : 1), P - 1)]++;
                 for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
             }
         }
@@ -1373,7 +1388,145 @@ struct MultiRun {
             if (a == 0 && front) { *spec_q = front; *specn_q = n; *voff_q = 0; }          // (rank 0's block starts at position 0)
             else { *spec_q = 0; *specn_q = 0; *voff_q = S[i].off + a - front; }
         };
-        if (!solo_) {
+        bool sorted_already = false;
+        if (by_range) {
+            const int NC = P * QR;
+            Splitters sp; std::memset(&sp, 0, sizeof(sp));
+            sp.n = (uint32_t)spl.size();
+            for (uint32_t s2 = 0; s2 < sp.n; ++s2) sp.k1[s2] = spl[s2];
+            constexpr uint64_t SPAN = 256 * 32;
+            std::vector<std::vector<uint64_t>> cnt_c(L, std::vector<uint64_t>((size_t)NC, 0));
+            std::vector<DBuf<uint8_t>> cls(L);
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                const uint64_t cn = rec[i].cnt;
+                MG_OP(g, c, cls[i].alloc(c, cn + 16));
+                DBuf<unsigned long long> d_counts; MG_OP(g, c, d_counts.alloc(c, 64));
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_HIP(g, hipMemsetAsync(d_counts.p, 0, 64 * 8, c->stream));
+                if (cn) {
+                    const uint64_t one = (cn + SPAN - 1) / SPAN * SPAN;           // the whole block as one "piece"
+                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3((unsigned)(one / SPAN)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, cn, lo1, sp, cls[i].p, one, d_counts.p);
+                    MG_HIP(g, hipGetLastError());
+                }
+                MG_OP(g, c, ensure_pinned(c, 64 * 8 + 65536 + 32768));
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d_counts.p, 64 * 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                const unsigned long long* h = reinterpret_cast<const unsigned long long*>(c->pinned + 32768);
+                for (int cc = 0; cc < NC; ++cc) cnt_c[i][cc] = h[cc];
+                return PSACX_OK;
+            }));
+            std::vector<uint64_t> table;                       // table[r * NC + destination * QR + range]
+            PSACX_TRY(gather(NC, cnt_c, table));
+            std::vector<Rec<T>> grp(L), rcv(L);
+            std::vector<std::vector<uint64_t>> rbase(L), soff(L);          // start of range q in the receive arrays; start of class c in the partitioned block
+            int rc_alloc = PSACX_OK;
+            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
+                const int me = rank(i);
+                rbase[i].assign(QR + 1, 0);
+                for (int q = 0; q < QR; ++q) { uint64_t t = 0; for (int r = 0; r < P; ++r) t += table[(size_t)r * NC + me * QR + q]; rbase[i][q + 1] = rbase[i][q] + t; }
+                soff[i] = prefix_of(cnt_c[i]);
+                rc_alloc = take3(i, grp[i], rec[i].cnt, false);
+            }
+            PSACX_TRY(agree(rc_alloc));
+            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, rcv[i], rbase[i][QR], false);
+            PSACX_TRY(agree(rc_alloc));
+            // one stable partition of the block by class; the suffix a record stands for is made up on the way
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                const uint64_t cn = rec[i].cnt;
+                if (!cn) return PSACX_OK;
+                SortScratch sc;
+                auto layout = [&](Arena& ar) { sc.d_base = ar.take<unsigned long long>((size_t)RADIX); sc.desc_bytes = sort_desc_bytes(cn); sc.d_desc = ar.take<char>(sc.desc_bytes); };
+                { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
+                Arena ar(c->slab);
+                layout(ar);
+                uint64_t sq, snq, vq;
+                payload_of(i, 0, &sq, &snq, &vq);
+                MG_HIP(g, hipSetDevice(c->device));
+                MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p, cls[i].p, cn, grp[i].k1.p, grp[i].v.p, v32, sq, snq, vq, pf));
+                return PSACX_OK;
+            }));
+            // the unpartitioned records are not needed any more: in the reduced-memory layout they sat in the rank's output arrays,
+            // which now serve as the second record set of the range sorts
+            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); drop3(i, rec[i]); cls[i].release(); }
+            std::vector<Rec<T>> alt(L);
+            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, alt[i], rbase[i][QR], false);
+            PSACX_TRY(agree(rc_alloc));
+            mark("    sort: classify + partition");
+            // range q of every destination travels in exchanges 2 q (word 1) and 2 q + 1 (suffixes): all issued now, in order, on
+            // the second streams.  The narrow suffix entries of range q land at the start of the range's own word-sized region,
+            // so that the sort of an earlier range, which widens its entries in place, never touches a later range's input.
+            std::vector<std::vector<hipEvent_t>> done(2 * QR, std::vector<hipEvent_t>(L, nullptr));
+            auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
+            for (int q = 0; q < 2 * QR; ++q) for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming)); }
+            const uint64_t wide = sizeof(T) / vb;                // narrow entries per word
+            int rc = PSACX_OK;
+            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
+                for (int arr = 0; arr < 2 && rc == PSACX_OK; ++arr) {
+                    std::vector<std::vector<Msg>> sends(L), recvs(L);
+                    std::vector<std::vector<const void*>> in(L);
+                    std::vector<std::vector<void*>> out(L);
+                    for (int i = 0; i < L; ++i) {
+                        const int me = rank(i);
+                        for (int d = 0; d < P; ++d) sends[i].push_back(Msg{d, soff[i][(size_t)d * QR + q], cnt_c[i][(size_t)d * QR + q]});
+                        uint64_t within = 0;
+                        for (int r = 0; r < P; ++r) {
+                            const uint64_t cn = table[(size_t)r * NC + me * QR + q];
+                            recvs[i].push_back(Msg{r, (arr == 0 ? rbase[i][q] : rbase[i][q] * wide) + within, cn});
+                            within += cn;
+                        }
+                        if (arr == 0) { in[i] = {grp[i].k1.p}; out[i] = {rcv[i].k1.p}; }
+                        else { in[i] = {grp[i].v.p}; out[i] = {rcv[i].v.p}; }
+                    }
+                    rc = transfer(in, out, {arr == 0 ? sizeof(T) : vb}, sends, recvs, &done[2 * q + arr]);
+                }
+            }
+            if (rc != PSACX_OK) { drop_events(); return rc; }
+            // the ranges, one after the other, as they arrive
+            std::vector<std::vector<int32_t>> where(L, std::vector<int32_t>(QR, 0));
+            for (int q = 0; q < QR; ++q) {
+                PSACX_TRY(par([&](int i) -> int {
+                    psacx_ctx* c = ctx(i);
+                    MG_HIP(g, hipSetDevice(c->device));
+                    for (int s2 = 0; s2 < L; ++s2) { MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q][s2], 0)); MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q + 1][s2], 0)); }
+                    const uint64_t b0 = rbase[i][q], tq = rbase[i][q + 1] - b0;
+                    if (!tq) return PSACX_OK;
+                    MG_OP(g, c, op_pair_sort<T>(c, rcv[i].k1.p + b0, (T*)nullptr, rcv[i].v.p + b0, alt[i].k1.p + b0, (T*)nullptr, alt[i].v.p + b0, tq, bits1, 0, &where[i][q], lo1,
+                                                false, 0, 0, v32, pf, pf.on()));
+                    return PSACX_OK;
+                }));
+            }
+            // everything has arrived (and, with ranks in one process, has been pulled) before the partitioned copies go away
+            for (int i = 0; i < L; ++i) {
+                (void)hipSetDevice(ctx(i)->device);
+                for (int q = 0; q < 2 * QR; ++q) for (int s2 = 0; s2 < L; ++s2) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
+            }
+            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
+            drop_events();
+            // the sorted ranges into one record set (a sort's result lies in the set its last executed pass wrote)
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_HIP(g, hipSetDevice(c->device));
+                int in_alt = 0;
+                for (int q = 0; q < QR; ++q) in_alt += where[i][q] != 0;
+                const bool to_alt = in_alt * 2 > QR;
+                for (int q = 0; q < QR; ++q) {
+                    const uint64_t b0 = rbase[i][q], tq = rbase[i][q + 1] - b0;
+                    if (!tq || (where[i][q] != 0) == to_alt) continue;
+                    Rec<T>& from = to_alt ? rcv[i] : alt[i]; Rec<T>& to = to_alt ? alt[i] : rcv[i];
+                    MG_HIP(g, hipMemcpyAsync(to.k1.p + b0, from.k1.p + b0, tq * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(to.v.p + b0, from.v.p + b0, tq * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                }
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                drop3(i, grp[i]);
+                if (to_alt) { drop3(i, rcv[i]); rec[i] = std::move(alt[i]); } else { drop3(i, alt[i]); rec[i] = std::move(rcv[i]); }
+                rec[i].cnt = rbase[i][QR];
+                return PSACX_OK;
+            }));
+            sorted_already = true;
+            mark("    sort: shuffle by ranges + range sorts");
+        } else if (!solo_) {
             const uint32_t ns = (uint32_t)spl.size();
             Splitters sp; std::memset(&sp, 0, sizeof(sp));
             sp.n = ns;
@@ -1485,7 +1638,7 @@ struct MultiRun {
         bool solo_packed = false;        // one rank: the sort ran packed, word 1 of a tied record is read from the text again
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
-            if (rec[i].cnt >= 1) {
+            if (rec[i].cnt >= 1 && !sorted_already) {
                 Rec<T> alt;
                 PSACX_TRY(take3(i, alt, rec[i].cnt, false));
                 int32_t where = 0;

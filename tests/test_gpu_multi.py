@@ -609,15 +609,21 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
     # mode 2 also sends repetitive texts through it (long tie groups -> radix sort of the compacted ties).
     cases = [(O.rand_dna(70001, 7), 64), (O.rand_dna(70001, 7), 32), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
              (np.full(5003, 65, np.uint8), 64), (inputs.cyclic(20011, "abc"), 32), (O.as_text("mississippi" * 40), 64)]
-    for mode in ("1", "2"):
+    # shuffle by key ranges with one sort per range under the exchanges (default), by position with one sort at the end
+    # (PSACX_MULTI_SHUFFLE_BY_POSITION=1), and with other numbers of ranges / pieces
+    for mode, env in (("1", {}), ("2", {}), ("1", {"PSACX_MULTI_SHUFFLE_BY_POSITION": "1"}), ("2", {"PSACX_MULTI_PIECES": "7"}), ("1", {"PSACX_MULTI_PIECES": "1"})):
         monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
+        for k_ in ("PSACX_MULTI_SHUFFLE_BY_POSITION", "PSACX_MULTI_PIECES"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         mg = multi(P)
         try:
             used = 0
             for text, bits in cases:
                 SA, ISA, LCP, rounds = same(mg, text, bits)
                 ref = O.construct(text, bits=bits)
-                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, bits, text.size)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, env, bits, text.size)
                 assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
                 used += mg.last_form()["two_word"]
             assert used >= (len(cases) - 1 if mode == "2" else 2), used      # (DNA on 32-bit words: word 1 is shorter than the leading bits)
