@@ -65,7 +65,7 @@ def parse():
                          "the extra field other_workloads, never as `value`")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.n is None and world == 1 and a.gpus == 1:
+    if a.n is None and world == 1 and a.gpus == 1 and not os.environ.get("PSACX_BENCH_FORCE_DIST"):
         a.n = 1 << 32
     return a
 
@@ -165,14 +165,14 @@ def main_distributed(a, rank, world, local_rank):
     if a.n is None:
         # The largest block of 2^32, 2^31 (configs[3]: 16 GiB over 8 GPUs), 2^30, 2^28 characters per GPU that fits every GPU.
         # With more than one rank the reduced-memory layout peaks at 4.75 words per character for the engine (the shuffle holds
-        # the records, their partitioned copy and the receive arrays at once; measured with two ranks of 2^31,
-        # profiles/r03n_multi_virtual_ranks.txt) + 3.375 for the result arrays with their slack + the text = 8.25 words of
-        # 8 bytes: 283 GB at 2^32 characters -- too close to the 288 GB of an MI355X once RCCL has its buffers, so a full
-        # GPU takes 2^31.  Asked for: 8.6 words + 6 GB.
+        # the partitioned records, the receive arrays and the second record set at once; measured with two ranks of 2^31,
+        # profiles/r04b_*) + 3.375 for the result arrays with their slack + the text = 8.25 words of 8 bytes: 264 GiB at 2^32
+        # characters.  That does not leave room for the block cache's fragmentation and RCCL's buffers on a 288 GiB part (tried:
+        # out of memory in the first exchange, profiles/r04d_*), so a full GPU takes 2^31.  Asked for: 9.5 words + 8 GiB.
         free_b = torch.cuda.mem_get_info(local_rank)[0]
         fit = 28
         for lg in (32, 31, 30):
-            if free_b >= int(8.6 * 8 * (1 << lg)) + (6 << 30):
+            if free_b >= int(9.5 * 8 * (1 << lg)) + (8 << 30):
                 fit = lg
                 break
         t_fit = torch.tensor([fit], dtype=torch.int32, device="cuda")

@@ -750,7 +750,7 @@ struct MultiRun {
             roff[i] = prefix_of(rcnt[i]);
             out[i].resize(na);
             if (recv) { rc_alloc = recv(i, roff[i][P], out[i]); if (rc_alloc == PSACX_OK && (int)out[i].size() != na) rc_alloc = PSACX_EINVAL; }
-            else for (int a = 0; a < na && rc_alloc == PSACX_OK; ++a) { rc_alloc = out[i][a].alloc(ctx(i), roff[i][P]); if (rc_alloc != PSACX_OK) mg_set_err(g, "receive array: " + ctx(i)->hip_err); }
+            else for (int a = 0; a < na && rc_alloc == PSACX_OK; ++a) { rc_alloc = out[i][a].alloc(ctx(i), roff[i][P]); if (rc_alloc != PSACX_OK) mg_set_err(g, "receive array of " + std::to_string(roff[i][P]) + " x " + std::to_string(sizeof(E)) + " bytes: " + ctx(i)->hip_err); }
         }
         PSACX_TRY(agree(rc_alloc));       // (process-per-GPU: a rank without its receive arrays must not leave its peers in the group)
         // the sources are complete when the compute streams reach this point; the receive buffers exist by then too
@@ -1856,6 +1856,23 @@ struct MultiRun {
         // ranks below 2^32: a pair is one 64-bit entry (position | rank << 32) on the wire and in every level (slice_inv.hpp:
         // *_packed_kernel; PSACX_SLICE_TWO_ARRAYS=1 keeps the two-array form)
         const bool pack = sizeof(V) == 4 && !getenv("PSACX_SLICE_TWO_ARRAYS");
+        // ranks beyond 2^32: on the wire as 32 bits relative to the end of the sender's block, packed with the position (8 instead
+        // of 12 bytes per pair; slice_inv.hpp: SliceDecode), when no bucket of unresolved suffixes reaches further back than 2^32
+        // positions from the end of its rank's block; the first owner-side kernel widens them.  PSACX_SLICE_ABS=1: 64-bit ranks.
+        bool wpack = false;
+        if (sizeof(V) == 8 && !getenv("PSACX_SLICE_ABS")) {
+            std::vector<uint64_t> okv(L, 1), all;
+            PSACX_TRY(par([&](int i) -> int {
+                if (!S[i].m) return PSACX_OK;
+                std::vector<uint64_t> o;
+                PSACX_TRY(fetch(i, ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, {0}, o));
+                okv[i] = (o[0] - 1) + (1ull << 32) >= S[i].off + S[i].m ? 1 : 0;       // (ranks ascend along a block: the first is the smallest)
+                return PSACX_OK;
+            }));
+            PSACX_TRY(gather1(okv, all));
+            wpack = true;
+            for (uint64_t v : all) if (!v) wpack = false;
+        }
 
         // 1. pairs per class on every rank; every rank learns the whole table
         std::vector<std::vector<uint64_t>> counts(L, std::vector<uint64_t>(C, 0));
@@ -1920,11 +1937,11 @@ struct MultiRun {
                 ct.cap = std::max(bytes, res); ct.used = 0;
                 return ct.take(bytes);
             };
-            auto pair = [&](Ptrs& q, uint64_t cnt) {
-                if (pack) { q.k = (uint32_t*)arr((size_t)cnt * 8); q.v = nullptr; }
+            auto pair = [&](Ptrs& q, uint64_t cnt, bool packed = false) {
+                if (pack || packed) { q.k = (uint32_t*)arr((size_t)cnt * 8); q.v = nullptr; }
                 else { q.k = (uint32_t*)arr((size_t)cnt * 4); q.v = rc_a == PSACX_OK ? (V*)arr((size_t)cnt * sizeof(V)) : nullptr; }
             };
-            pair(pk_[i], m);
+            pair(pk_[i], m, wpack && !solo_);        // (one rank: the levels write back into this set, so it keeps both arrays; the packed entries go to its value array)
             const uint64_t cap = std::min<uint64_t>(step_cap, std::max<uint64_t>(m, 1));
             if (rc_a == PSACX_OK && !solo_) pair(A0[i], cap);
             if (rc_a == PSACX_OK && !solo_ && nsteps > 1) pair(A1[i], cap);
@@ -1935,10 +1952,11 @@ struct MultiRun {
             std::memset(c->pinned + 32768, 0, SLICE_MAX_CLASSES * 8);
             std::memcpy(c->pinned + 32768, cstart[i].data(), (size_t)C * 8);
             MG_HIP(g, hipMemcpyAsync(d_cnt[i].p, c->pinned + 32768, SLICE_MAX_CLASSES * 8, hipMemcpyHostToDevice, c->stream));
-            if (pack)
+            if (pack || wpack)
                 hipLaunchKernelGGL((slice_partition_packed_kernel<T, PB, 8>), dim3((unsigned)((m + PB * 8 - 1) / (PB * 8))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
-                                   ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, reinterpret_cast<uint64_t*>(pk_[i].k),
-                                   ids_in_isa ? S[i].Bsa.p : (T*)nullptr);
+                                   ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p,
+                                   (wpack && solo_) ? reinterpret_cast<uint64_t*>(pk_[i].v) : reinterpret_cast<uint64_t*>(pk_[i].k),
+                                   ids_in_isa ? S[i].Bsa.p : (T*)nullptr, wpack ? 1 : 0, S[i].off + m - 1);
             else
             hipLaunchKernelGGL((slice_partition_kernel<T, V, PB, PI>), dim3((unsigned)((m + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)S[i].SA,
                                ids_in_isa ? (const T*)S[i].ISA : (const T*)S[i].Bsa.p, m, map, d_cnt[i].p, pk_[i].k, pk_[i].v, ids_in_isa ? S[i].Bsa.p : (T*)nullptr);
@@ -1971,11 +1989,13 @@ struct MultiRun {
                 }
                 Ptrs& A = (t & 1) ? A1[i] : A0[i];
                 if (pack) { in[i] = {pk_[i].k}; out[i] = {A.k}; }
+                else if (wpack) { in[i] = {pk_[i].k}; out[i] = {A.v}; }           // (the packed entries land in the value array: 8 bytes per pair)
                 else { in[i] = {pk_[i].k, pk_[i].v}; out[i] = {A.k, A.v}; }
             }
-            if (pack) return transfer(in, out, {sizeof(uint64_t)}, sends, recvs, &done[t & 1]);
+            if (pack || wpack) return transfer(in, out, {sizeof(uint64_t)}, sends, recvs, &done[t & 1]);
             return transfer(in, out, {sizeof(uint32_t), sizeof(V)}, sends, recvs, &done[t & 1]);
         };
+        std::vector<std::vector<DBuf<uint64_t>>> keep_dec(L);         // segment tables of the steps (alive until the streams have drained)
         int rc = PSACX_OK;
         if (!solo_) rc = issue(0);
         for (uint64_t t = 0; t < nsteps && rc == PSACX_OK; ++t) {
@@ -2010,18 +2030,43 @@ struct MultiRun {
                     MG_HIP(g, hipGetLastError());
                     return PSACX_OK;
                 }
+                SliceDecode dec; dec.seg = nullptr; dec.base = nullptr; dec.P = (unsigned)P; dec.sb = sb;
+                if (wpack) {
+                    // where every sender's segment lies inside the slices of this step, and the last position of every sender's block
+                    const unsigned s0 = (unsigned)(t * G), s1e = (unsigned)std::min<uint64_t>(spo, (t + 1) * G);
+                    std::vector<uint64_t> h((size_t)(s1e - s0) * (P + 1) + P, 0);
+                    for (unsigned sl = s0; sl < s1e; ++sl) {
+                        uint64_t at = 0;
+                        for (int r = 0; r < P; ++r) { h[(size_t)(sl - s0) * (P + 1) + r] = at; at += solo_ ? counts[i][(size_t)rank(i) * spo + sl] : table[(size_t)r * C + (unsigned)rank(i) * spo + sl]; }
+                        h[(size_t)(sl - s0) * (P + 1) + P] = at;
+                    }
+                    for (int r = 0; r < P; ++r) h[(size_t)(s1e - s0) * (P + 1) + r] = offs[r] + sizes[r] - 1;
+                    DBuf<uint64_t> d; MG_OP(g, c, d.alloc(c, h.size()));
+                    MG_HIP(g, hipMemcpy(d.p, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+                    dec.seg = d.p; dec.base = d.p + (size_t)(s1e - s0) * (P + 1);
+                    keep_dec[i].push_back(std::move(d));
+                    ks = solo_ ? reinterpret_cast<const uint32_t*>(pk_[i].v) : reinterpret_cast<const uint32_t*>(A.v);     // the packed entries as they arrived
+                }
                 for (unsigned j = 0; j < levels2; ++j) {
                     below -= cbs[j];
                     const unsigned shift = wb + below;
                     MG_HIP(g, hipMemsetAsync(cur[i], 0, ((len >> shift) + 2) * sizeof(unsigned), c->stream));
                     uint32_t* ko = (j & 1) ? ka : Bb[i].k; V* vo = (j & 1) ? va : Bb[i].v;
-                    hipLaunchKernelGGL((pairs_partition_kernel<V, PB, PI>), dim3((unsigned)((len + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, ks, vs, ko, vo, len,
-                                       shift, cbs[j], cur[i], j == 0 ? (uint32_t)lo : 0u);
+                    if (wpack && j == 0)
+                        hipLaunchKernelGGL((pairs_partition_kernel<V, PB, PI, true>), dim3((unsigned)((len + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, ks, vs, ko, vo, len,
+                                           shift, cbs[j], cur[i], (uint32_t)lo, dec);
+                    else
+                        hipLaunchKernelGGL((pairs_partition_kernel<V, PB, PI>), dim3((unsigned)((len + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, ks, vs, ko, vo, len,
+                                           shift, cbs[j], cur[i], j == 0 ? (uint32_t)lo : 0u);
                     MG_HIP(g, hipGetLastError());
                     ks = ko; vs = vo;
                 }
-                hipLaunchKernelGGL((pairs_window_kernel<V, T, 1024, WBMAX>), dim3((unsigned)((len + (1ull << wb) - 1) >> wb)), dim3(1024), 0, c->stream, ks, vs, len, wb,
-                                   levels2 ? 0u : (uint32_t)lo, S[i].ISA + lo);
+                if (wpack && levels2 == 0)
+                    hipLaunchKernelGGL((pairs_window_kernel<V, T, 1024, WBMAX, true>), dim3((unsigned)((len + (1ull << wb) - 1) >> wb)), dim3(1024), 0, c->stream, ks, vs, len, wb,
+                                       (uint32_t)lo, S[i].ISA + lo, dec);
+                else
+                    hipLaunchKernelGGL((pairs_window_kernel<V, T, 1024, WBMAX>), dim3((unsigned)((len + (1ull << wb) - 1) >> wb)), dim3(1024), 0, c->stream, ks, vs, len, wb,
+                                       levels2 ? 0u : (uint32_t)lo, S[i].ISA + lo);
                 MG_HIP(g, hipGetLastError());
                 return PSACX_OK;
             });
@@ -2038,7 +2083,7 @@ struct MultiRun {
         return PSACX_OK;
     }
     int isa_by_slices(bool ids_in_isa = false) {
-        if (sizeof(T) == 4 || n <= (1ull << 32)) return isa_by_slices_t<uint32_t>(ids_in_isa);
+        if (sizeof(T) == 4 || (n <= (1ull << 32) && !getenv("PSACX_SLICE_WIDE"))) return isa_by_slices_t<uint32_t>(ids_in_isa);      // (PSACX_SLICE_WIDE: tests)
         return isa_by_slices_t<T>(ids_in_isa);
     }
 

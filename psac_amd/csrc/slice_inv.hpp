@@ -131,13 +131,31 @@ __global__ __launch_bounds__(BLOCK) void slice_partition_kernel(const T* __restr
     }
 }
 
+// Ranks beyond 2^32 on the wire as 32 bits (packed with the position into one 64-bit entry, slice_partition_packed_kernel with
+// rel): a sender's ranks are bucket heads at or before its own positions, so e = (last position of the sender's block) - rank
+// is >= 0, and below 2^32 as long as no bucket reaches further back than 2^32 positions from the sender's block end (checked
+// before the form is chosen).  The owner knows the sender of every record of a received slice from where it lies: the slice's
+// region holds the senders' segments in rank order.  seg[s * (P + 1) + r] = start of sender r's segment inside slice s of the
+// step (seg[.. + P] = its end), base[r] = last position of sender r's block.
+struct SliceDecode {
+    const uint64_t* seg; const uint64_t* base; unsigned P, sb;
+    __device__ __forceinline__ uint64_t rank_of(uint64_t idx, uint32_t e) const {
+        const uint64_t* row = seg + (idx >> sb) * (P + 1);
+        const uint64_t w = idx & ((1ull << sb) - 1);
+        unsigned lo = 0, hi = P;                  // sender r with row[r] <= w < row[r + 1] (empty segments share a start: the last one)
+        while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (row[mid] <= w) lo = mid; else hi = mid; }
+        return base[lo] - (uint64_t)e;
+    }
+};
+
 // A further level on 32-bit keys: 2^cb destination classes per parent bucket of 2^(shift + cb) positions.  The input holds
 // every parent bucket complete and at its own place (keys minus koff), so a parent receives exactly its size in pairs and
 // a tile reserves room in a class with one atomic (see partition_pairs_kernel).  cb <= 9 at run time.
-template <typename V, int BLOCK, int ITEMS>
+// DEC: the input is the packed wire form (key_in viewed as uint64_t*, val_in unused), decoded on the way in (SliceDecode)
+template <typename V, int BLOCK, int ITEMS, bool DEC = false>
 __global__ __launch_bounds__(BLOCK) void pairs_partition_kernel(const uint32_t* __restrict__ key_in, const V* __restrict__ val_in,
                                                                 uint32_t* __restrict__ key_out, V* __restrict__ val_out, uint64_t n, unsigned shift,
-                                                                unsigned cb, unsigned* __restrict__ cursors, uint32_t koff) {
+                                                                unsigned cb, unsigned* __restrict__ cursors, uint32_t koff, SliceDecode dec = SliceDecode()) {
     constexpr int NMAX = 512;
     static_assert(BLOCK >= NMAX, "one thread per class");
     constexpr int TILE = BLOCK * ITEMS;
@@ -158,8 +176,12 @@ __global__ __launch_bounds__(BLOCK) void pairs_partition_kernel(const uint32_t* 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
-        if (loc < count) { key[i] = key_in[base + loc] - koff; val[i] = val_in[base + loc]; }
-        else { key[i] = 0; val[i] = 0; }
+        if (loc < count) {
+            if (DEC) {
+                const uint64_t x = reinterpret_cast<const uint64_t*>(key_in)[base + loc];
+                key[i] = (uint32_t)x - koff; val[i] = (V)dec.rank_of(base + loc, (uint32_t)(x >> 32));
+            } else { key[i] = key_in[base + loc] - koff; val[i] = val_in[base + loc]; }
+        } else { key[i] = 0; val[i] = 0; }
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -173,7 +195,8 @@ __global__ __launch_bounds__(BLOCK) void pairs_partition_kernel(const uint32_t* 
     if (tid < ncls) {
         bstart[tid] = bs;
         if (tot) {
-            const uint64_t parent = (uint64_t)(key_in[base] - koff) >> shift >> cb;        // same for the whole tile
+            const uint32_t k0 = DEC ? (uint32_t)reinterpret_cast<const uint64_t*>(key_in)[base] : key_in[base];
+            const uint64_t parent = (uint64_t)(k0 - koff) >> shift >> cb;        // same for the whole tile
             const uint64_t gq = (parent << cb) | tid;
             const unsigned at = atomicAdd(&cursors[gq], tot);
             gbase[tid] = (gq << shift) + at - bs;
@@ -212,15 +235,20 @@ __global__ __launch_bounds__(BLOCK) void pairs_partition_kernel(const uint32_t* 
 
 // One workgroup per window of 2^wb (<= 2^WBMAX) destinations: the window's pairs are scattered inside LDS and leave as
 // consecutive entries of `out` (out[0] = destination koff).
-template <typename V, typename TO, int BLOCK, int WBMAX>
+template <typename V, typename TO, int BLOCK, int WBMAX, bool DEC = false>
 __global__ __launch_bounds__(BLOCK) void pairs_window_kernel(const uint32_t* __restrict__ key, const V* __restrict__ val, uint64_t n, unsigned wb,
-                                                             uint32_t koff, TO* __restrict__ out) {
+                                                             uint32_t koff, TO* __restrict__ out, SliceDecode dec = SliceDecode()) {
     __shared__ V win[1u << WBMAX];
     const unsigned W = 1u << wb;
     const uint64_t base = (uint64_t)blockIdx.x * W;
     const uint64_t remain = n - base;
     const unsigned count = remain < (uint64_t)W ? (unsigned)remain : W;
-    for (unsigned p = threadIdx.x; p < count; p += BLOCK) win[(key[base + p] - koff) & (W - 1)] = val[base + p];
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) {
+        if (DEC) {
+            const uint64_t x = reinterpret_cast<const uint64_t*>(key)[base + p];
+            win[((uint32_t)x - koff) & (W - 1)] = (V)dec.rank_of(base + p, (uint32_t)(x >> 32));
+        } else win[(key[base + p] - koff) & (W - 1)] = val[base + p];
+    }
     __syncthreads();
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
 }
@@ -230,7 +258,8 @@ __global__ __launch_bounds__(BLOCK) void pairs_window_kernel(const uint32_t* __r
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void slice_partition_packed_kernel(const T* __restrict__ SA, const T* __restrict__ B, uint64_t n, SliceMap map,
                                                                        unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out,
-                                                                       T* __restrict__ b_copy = nullptr) {
+                                                                       T* __restrict__ b_copy = nullptr, int rel = 0, uint64_t rel_base = 0) {
+    // rel: the rank leaves as rel_base - rank (SliceDecode), rel_base = last position of this rank's block
     constexpr int TILE = BLOCK * ITEMS;
     static_assert(BLOCK >= SLICE_MAX_CLASSES, "one thread per class");
     __shared__ uint64_t stage[TILE];
@@ -254,10 +283,11 @@ __global__ __launch_bounds__(BLOCK) void slice_partition_packed_kernel(const T* 
         if (loc < count) {
             const uint64_t g = SA[base + loc];
             const unsigned o = map.owner(g);
-            const uint64_t rel = g - map.off(o);
+            const uint64_t rel_pos = g - map.off(o);
             const T bb = B[base + loc];
-            rec[i] = (uint64_t)(uint32_t)rel | ((uint64_t)(uint32_t)((uint64_t)bb - 1u) << 32);
-            cls[i] = (unsigned short)(o * map.spo + (unsigned)(rel >> map.sb));
+            const uint64_t rk = (uint64_t)bb - 1u;
+            rec[i] = (uint64_t)(uint32_t)rel_pos | ((uint64_t)(uint32_t)(rel ? rel_base - rk : rk) << 32);
+            cls[i] = (unsigned short)(o * map.spo + (unsigned)(rel_pos >> map.sb));
             if (b_copy) b_copy[base + loc] = bb;
         } else { rec[i] = 0; cls[i] = 0; }
     }

@@ -763,10 +763,16 @@ def test_multi_isa_by_destination_slices(P, wb, s1, step, monkeypatch):
     monkeypatch.setenv("PSACX_SLICE_S1", str(s1))
     if step:
         monkeypatch.setenv("PSACX_SLICE_STEP", str(step))
-    # (the pairs travel and are partitioned as packed 64-bit entries; PSACX_SLICE_TWO_ARRAYS=1: as two 32-bit arrays)
-    for two in (False, True):
-        if two:
+    # (the pairs travel and are partitioned as packed 64-bit entries; PSACX_SLICE_TWO_ARRAYS=1: as two 32-bit arrays;
+    #  PSACX_SLICE_WIDE=1: the 64-bit rank form of texts beyond 2^32 characters, whose ranks travel as 32 bits relative to the
+    #  end of the sender's block and are widened by the first owner-side kernel; PSACX_SLICE_ABS=1: as 64-bit words)
+    for two in (False, True, "wide", "wide_abs"):
+        if two is True:
             monkeypatch.setenv("PSACX_SLICE_TWO_ARRAYS", "1")
+        if two in ("wide", "wide_abs"):
+            monkeypatch.setenv("PSACX_SLICE_WIDE", "1")
+        if two == "wide_abs":
+            monkeypatch.setenv("PSACX_SLICE_ABS", "1")
         mg = multi(P)
         try:
             for text, bits in ((O.rand_dna(300007, 7), 64), (O.rand_dna(131072 * P, 9), 32), (inputs.tandem(90001, 256, O.rand_dna(256, 3)), 32),
