@@ -586,6 +586,7 @@ struct MultiRun {
     }
 
     explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
+        if (const char* e = getenv("PSACX_MULTI_WIRE_PIECE")) wire_piece_ = std::max<size_t>(256, strtoull(e, nullptr, 10));
         solo_ = P == 1 && !mg->force_wire;
         t_last_ = t_phase_ = std::chrono::steady_clock::now();
     }
@@ -727,6 +728,28 @@ struct MultiRun {
         }
     }
 
+    // One message on the wire, in pieces of at most wire_piece_ bytes (sender and receiver cut a message of one length at the
+    // same places, and messages between a pair of ranks match in order): a single ncclSend / ncclRecv of 2^31 bytes or more
+    // arrived damaged in this stack (seen with a rank's message to itself: half the entries wrong at 2^28 64-bit records;
+    // profiles/r04k: 2^30-byte pieces arrive whole, 2^31 - 1 do not), and pieces keep the channels' staging independent of the message length.  PSACX_MULTI_WIRE_PIECE: bytes.
+    size_t wire_piece_ = (size_t)1 << 28;
+    ncclResult_t wire_send(RcclApi& nc, MRank& R, const void* p, size_t bytes, int peer) {
+        for (size_t o = 0; o < bytes; o += wire_piece_) {
+            const ncclResult_t r = nc.Send(static_cast<const char*>(p) + o, std::min(wire_piece_, bytes - o), ncclUint8, peer, R.comm, R.comm_stream);
+            g->wire_sends++;
+            if (r != ncclSuccess) return r;
+        }
+        return ncclSuccess;
+    }
+    ncclResult_t wire_recv(RcclApi& nc, MRank& R, void* p, size_t bytes, int peer) {
+        for (size_t o = 0; o < bytes; o += wire_piece_) {
+            const ncclResult_t r = nc.Recv(static_cast<char*>(p) + o, std::min(wire_piece_, bytes - o), ncclUint8, peer, R.comm, R.comm_stream);
+            g->wire_recvs++;
+            if (r != ncclSuccess) return r;
+        }
+        return ncclSuccess;
+    }
+
     // All-to-all of `na` arrays per rank that share one partition: elements bounds[i][d] .. bounds[i][d+1] of every
     // array of local rank i go to rank d.  out[i][a] receives the elements ordered by source rank; rcnt[i][s] =
     // elements received from rank s.  One exchange of the counts serves all arrays; the transfers of all arrays,
@@ -774,8 +797,8 @@ struct MultiRun {
                     for (int d = 0; d < P && bad == ncclSuccess; ++d) {
                         const uint64_t sc = mine[i][d], rc = rcnt[i][d];
                         if (d == R.grank && !self_wire) continue;
-                        if (sc) { bad = nc.Send(in[i][a] + bounds[i][d], (size_t)sc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream); if (d != R.grank) g->bytes_sent += sc * sizeof(E); g->wire_sends++; }
-                        if (rc && bad == ncclSuccess) { bad = nc.Recv(out[i][a].p + roff[i][d], (size_t)rc * sizeof(E), ncclUint8, d, R.comm, R.comm_stream); g->wire_recvs++; }
+                        if (sc) { bad = wire_send(nc, R, in[i][a] + bounds[i][d], (size_t)sc * sizeof(E), d); if (d != R.grank) g->bytes_sent += sc * sizeof(E); }
+                        if (rc && bad == ncclSuccess) bad = wire_recv(nc, R, out[i][a].p + roff[i][d], (size_t)rc * sizeof(E), d);
                     }
                 }
             }
@@ -900,16 +923,14 @@ struct MultiRun {
                 for (int a = 0; a < na && bad == ncclSuccess; ++a) {
                     for (const Msg& m : sends[i]) {
                         if (!m.cnt || (m.peer == R.grank && !g->force_wire)) continue;
-                        bad = nc.Send(static_cast<const char*>(in[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], ncclUint8, m.peer, R.comm, R.comm_stream);
+                        bad = wire_send(nc, R, static_cast<const char*>(in[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], m.peer);
                         if (m.peer != R.grank) g->bytes_sent += m.cnt * esz[a];
-                        g->wire_sends++;
                         if (bad != ncclSuccess) break;
                     }
                     for (const Msg& m : recvs[i]) {
                         if (bad != ncclSuccess) break;
                         if (!m.cnt || (m.peer == R.grank && !g->force_wire)) continue;
-                        bad = nc.Recv(static_cast<char*>(out[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], ncclUint8, m.peer, R.comm, R.comm_stream);
-                        g->wire_recvs++;
+                        bad = wire_recv(nc, R, static_cast<char*>(out[i][a]) + m.off * esz[a], (size_t)m.cnt * esz[a], m.peer);
                     }
                 }
             }

@@ -536,6 +536,48 @@ def test_multi_rccl_wire_forced_at_world_size_one(monkeypatch):
             mg.close()
 
 
+def test_multi_rccl_wire_in_pieces(monkeypatch):
+    # Messages travel in pieces of at most PSACX_MULTI_WIRE_PIECE bytes (default 2^28): a single ncclSend / ncclRecv of 2^31
+    # bytes arrived damaged on this stack (profiles/r04k).  (a) pieces of 4 KiB on a small text against the oracle: every
+    # message of the two-word shuffle, the tie windows and the slice inversion is cut many times; (b) 2^28 characters with
+    # 64-bit indices on one rank with the wire forced: its messages to itself are 2^29 .. 2^31 bytes long (the checker's
+    # fetches send a whole 2^31-byte array), verified by the distributed checker.
+    import ctypes as C
+    import psac_amd
+    monkeypatch.setenv("PSACX_MULTI_FORCE_WIRE", "1")
+    monkeypatch.setenv("PSACX_MULTI_TWO_WORD", "1")
+    monkeypatch.setenv("PSACX_MULTI_WIRE_PIECE", "4096")
+    text = O.rand_dna(300007, 5)
+    ref = O.construct(text, bits=64)
+    mg = psac_amd.MultiContext([0])
+    try:
+        SA, ISA, LCP, rounds = mg.construct(text, index_bits=64)
+        assert mg.last_form()["two_word"]
+        assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+        assert mg.wire()["sends"] > 1000
+    finally:
+        mg.close()
+    monkeypatch.delenv("PSACX_MULTI_WIRE_PIECE")
+    monkeypatch.delenv("PSACX_MULTI_TWO_WORD")
+    mg = psac_amd.MultiContext([0])
+    try:
+        lib, ctx, m = mg._lib, mg.rank_ctx(0), 1 << 28
+        def alloc(nbytes):
+            p = C.c_void_p()
+            assert lib.psacx_dev_alloc(ctx, C.byref(p), nbytes) == 0
+            return p.value
+        d_text = [alloc(m)]
+        assert lib.psacx_synth_text_dev(ctx, C.c_void_p(d_text[0]), m, 0, 0, 1, 1024) == 0
+        outs = [[alloc(m * 8)] for _ in range(3)]
+        mg.construct_device(d_text, [m], outs[0], outs[1], outs[2], 64)
+        assert mg.transport == "rccl" and mg.last_form()["two_word"]
+        assert mg.check_device(d_text, [m], outs[0], outs[1], outs[2], 64) == [0, 0, 0, 0]
+        for p in d_text + [o[0] for o in outs]:
+            lib.psacx_dev_free(ctx, C.c_void_p(p))
+    finally:
+        mg.close()
+
+
 def _run_rank_processes(tmp_path, P, kind, n, seed, bits, extras=(), env_extra=None):
     """P processes, one rank each, all on device 0, exchanging through shared memory (PSACX_MULTI_TRANSPORT=shm)."""
     import json
