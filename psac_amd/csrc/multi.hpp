@@ -2360,7 +2360,7 @@ struct MultiRun {
     // Piece boundaries e[0 .. steps] of the list of unresolved positions of local rank i: about equal pieces, every cut moved
     // back to the head of the bucket it falls into; a bucket that enters from the previous rank stays whole in piece 0, one
     // that leaves to the next rank in the last piece.
-    int slab_bounds(int i, uint64_t steps, std::vector<uint64_t>& e) {
+    int slab_bounds(int i, uint64_t steps, std::vector<uint64_t>& e, uint64_t* whole) {
         const uint64_t a = S[i].pos.n, m = S[i].m;
         e.assign(steps + 1, 0);
         e[steps] = a;
@@ -2382,10 +2382,8 @@ struct MultiRun {
             MG_HIP(g, hipStreamSynchronize(c->stream));
             lead = std::min<uint64_t>(*reinterpret_cast<uint64_t*>(c->pinned + 32768), a);
         }
-        if (lead == a && p[steps] == m - 1 && P > 1) {
-            mg_set_err(g, "a bucket of unresolved suffixes covers a whole block: the reduced-memory layout cannot cut it into slabs");
-            return PSACX_ENOMEM;
-        }
+        // a bucket that covers this whole block would need three ranks' pieces in one step: the round then runs unsliced
+        if (lead == a && p[steps] == m - 1 && P > 1) *whole = 1;
         for (uint64_t j = 1; j < steps; ++j) {
             uint64_t cut;
             if (t[j] < lead) cut = lead;
@@ -2743,6 +2741,16 @@ struct MultiRun {
             uint64_t steps = 1;
             if (diet) for (int r = 0; r < P; ++r) steps = std::max<uint64_t>(steps, (counts[r] + slab_cap - 1) / slab_cap);
             steps = std::min<uint64_t>(steps, 64);
+            std::vector<std::vector<uint64_t>> e(L);
+            if (steps > 1) {
+                // (a bucket longer than a block -- a homopolymer run of the length of a rank's share -- cannot be cut at bucket heads
+                //  so that its parts on three ranks meet in one step: such a round takes every unresolved suffix in one step, as in
+                //  the normal layout, and fails only if the device really has no room for its records)
+                std::vector<uint64_t> whole(L, 0), whole_all;
+                PSACX_TRY(par([&](int i) -> int { return slab_bounds(i, steps, e[i], &whole[i]); }));
+                PSACX_TRY(gather1(whole, whole_all));
+                for (uint64_t w : whole_all) if (w) steps = 1;
+            }
             if (steps == 1) {
                 std::vector<const T*> pl(L);
                 for (int i = 0; i < L; ++i) pl[i] = S[i].pos.p;
@@ -2756,8 +2764,7 @@ struct MultiRun {
                 // earlier steps of this round already refined (Larsson-Sadakane style, see construct.hpp): the result is
                 // the same, only the per-round counters may run ahead of the one-step log.
                 g->last_slab_rounds++;
-                std::vector<std::vector<uint64_t>> e(L), kept_n(L, std::vector<uint64_t>(steps, 0));
-                PSACX_TRY(par([&](int i) -> int { return slab_bounds(i, steps, e[i]); }));
+                std::vector<std::vector<uint64_t>> kept_n(L, std::vector<uint64_t>(steps, 0));
                 uint64_t sum_b = 0, sum_e = 0;
                 for (uint64_t t = 0; t < steps; ++t) {
                     std::vector<const T*> pl(L);
