@@ -39,8 +39,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # [2] at 2^32 uint64 records (the default workload; 32-bit payload between the passes), profiles/r02w_pmc_*.txt: (2 x 120112432.6 + 279687304.6) KiB over 5 launches = 106478012375
 # ... round 3 (three workgroups per CU under a register cap: the spilled registers are written through), profiles/r03s_pmc_*.txt:
 #     per launch (2 x 25644637.9 + 63871449.6) KiB for passes 1-4, (2 x 25699635.6 + 81472582.0) KiB for pass 5
+# ... end of round 3, profiles/r04m_pmc_*.txt: (2 x 25644777.8 + 64191682.1) KiB for passes 1-4, (2 x 27795142.8 + 84983547.1) KiB
+#     for pass 5; mean over the five passes = 123391751168 bytes (1.15 x the algorithmic bytes: the spilled registers)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 121551821783}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 123391751168}
 
 
 def parse():

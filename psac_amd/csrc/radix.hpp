@@ -218,29 +218,37 @@ __device__ __forceinline__ void radix_scatter_tile(
             else cls[EXT ? i : 0] = (FULL || loc < count) ? (unsigned char)pd[loc] : (unsigned char)0;
         }
     }
+    // (lane pointer + constant: the loads of a thread differ in their immediate offsets only -- with the 32-bit sum wbase + i * 64
+    //  as the index every load had its own address register)
+    const T* __restrict__ pkd_l = pkd + wbase;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
-        kd[i] = (FULL || loc < count) ? pkd[loc] : (T)0;
+        kd[i] = (FULL || loc < count) ? pkd_l[i * WAVE] : (T)0;
     }
     if (!NOKO) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const unsigned loc = wbase + i * WAVE;
-            ko[NOKO ? 0 : i] = (FULL || loc < count) ? pko[loc] : (T)0;
+            ko[NOKO ? 0 : i] = (FULL || loc < count) ? (pko + wbase)[i * WAVE] : (T)0;
         }
     }
+    // (one uniform branch around the whole group of loads: tested per record, the compiler kept it inside the unrolled loop and
+    //  waited for a load in the middle of the group to spill it)
+    if (pv) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const unsigned loc = wbase + i * WAVE;
-        if (pv) {
-            if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint32_t*>(v_in) + base)[loc] : (PV)0;
-            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint8_t*>(v_in) + base)[loc] : (PV)0;
-            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint16_t*>(v_in) + base)[loc] : (PV)0;
-            else vv[i] = (FULL || loc < count) ? (PV)pv[loc] : (PV)0;
-        } else {
+        for (int i = 0; i < ITEMS; ++i) {
+            const unsigned loc = wbase + i * WAVE;
+            if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint32_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
+            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint8_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
+            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint16_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
+            else vv[i] = (FULL || loc < count) ? (PV)(pv + wbase)[i * WAVE] : (PV)0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
             // implicit payload: the record index, or the suffix the first-round record stands for
-            const uint64_t g = base + loc;
+            const uint64_t g = base + wbase + i * WAVE;
             const uint64_t made = (spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff;
             if (PK) { kd[i] = (T)((kd[i] & ~pmask) | ((T)made & pmask)); vv[i] = (PV)(made >> pack); }
             else vv[i] = (PV)made;
@@ -347,20 +355,22 @@ __device__ __forceinline__ void radix_scatter_tile(
         __syncthreads();
     }
     if (stamp) mydbg[5] = __builtin_amdgcn_s_memtime();
+    // (the payload goes through the stage in its own width: 32-bit entries of a 64-bit word's sort are staged as 32 bits)
+    PV* const pstage = reinterpret_cast<PV*>(stage);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-        if (FULL || (wbase + i * WAVE) < count) stage[rank[i]] = (T)vv[i];
+        if (FULL || (wbase + i * WAVE) < count) pstage[rank[i]] = vv[i];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (FULL || p < count) {
             const T at = (T)(goff[sdig[p]] + (T)p);
-            if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)stage[p];
-            else if (VN == 3) reinterpret_cast<uint8_t*>(v_out)[at] = (uint8_t)stage[p];
-            else if (VN == 5) reinterpret_cast<uint16_t*>(v_out)[at] = (uint16_t)stage[p];
-            else if (PK_OUT_FULL) v_out[at] = (T)(xlow[PK_OUT_FULL ? j : 0] | (T)((uint64_t)stage[p] << pack));
-            else v_out[at] = stage[p];
+            if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)pstage[p];
+            else if (VN == 3) reinterpret_cast<uint8_t*>(v_out)[at] = (uint8_t)pstage[p];
+            else if (VN == 5) reinterpret_cast<uint16_t*>(v_out)[at] = (uint16_t)pstage[p];
+            else if (PK_OUT_FULL) v_out[at] = (T)(xlow[PK_OUT_FULL ? j : 0] | (T)((uint64_t)pstage[p] << pack));
+            else v_out[at] = (T)pstage[p];
         }
     }
     if (stamp) mydbg[6] = __builtin_amdgcn_s_memtime();
