@@ -218,6 +218,8 @@ __device__ __forceinline__ void radix_scatter_tile(
             else cls[EXT ? i : 0] = (FULL || loc < count) ? (unsigned char)pd[loc] : (unsigned char)0;
         }
     }
+    // (non-temporal loads, so that the streamed input does not push half-written output lines out of L2: 255.3 / 264.4 ms for the
+    //  4 GiB construction against 255.9 / 256.3 -- inside the run-to-run spread, dropped)
     // (lane pointer + constant: the loads of a thread differ in their immediate offsets only -- with the 32-bit sum wbase + i * 64
     //  as the index every load had its own address register)
     const T* __restrict__ pkd_l = pkd + wbase;
@@ -272,6 +274,10 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (valid && below == 0)
             __hip_atomic_fetch_add(&mycnt[d], (unsigned)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         rank[i] = prior + below;
+        // (Experiment, round 3: the whole ranking replaced by ONE returning LDS atomic add per record -- the LDS unit served the
+        //  lanes of a wave in ascending order in every run, so the sort stayed stable and all parity tests and the full-size
+        //  checker passed -- removes 600 of the 900 vector instructions of a wave's tile and leaves the pass at the same
+        //  25.0 ms: the pass is not bound by instruction issue.  Not kept: the order is not a documented property.)
     }
     if (LATE_EXCL && !LB && tid < RADIX)
         pre_excl = (uint64_t)tile_excl[(uint64_t)tile * RADIX + tid] + (uint64_t)slab_excl[(uint64_t)(tile / slab_tiles) * RADIX + tid] +
