@@ -271,6 +271,58 @@ __device__ __forceinline__ void store_run(T* __restrict__ p, uint64_t e0, uint64
     }
 }
 
+// The same runs with the memory side coalesced: a wave reads (writes) its 64 * ITEMS consecutive elements as ITEMS rows of 64
+// -- one 64 * sizeof(T)-byte piece per instruction instead of 64 pieces of 16 bytes, 64 bytes apart -- and turns rows into
+// per-thread runs through its own padded LDS region xw (XRUN_WORDS<ITEMS> elements; e + e / 8: a thread's run starts nine
+// slots after its neighbour's).  e0: first element of THIS thread, consecutive over the lanes of the wave.  LDS operations of a
+// wave execute in order, so a region needs no barrier between its uses; the fences only keep the compiler from moving them.
+template <int ITEMS> struct XRUN_WORDS { static constexpr int N = WAVE * ITEMS + WAVE * ITEMS / 8; };
+__device__ __forceinline__ void xrun_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T, int ITEMS>
+__device__ __forceinline__ void load_run_x(const T* __restrict__ p, uint64_t e0, uint64_t n, T (&out)[ITEMS], T fill, T* xw) {
+    const unsigned lane = lane_id();
+    const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
+    const T* __restrict__ q = p + wb + lane;
+    T row[ITEMS];
+    if (wb + (uint64_t)WAVE * ITEMS <= n) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) row[i] = q[i * WAVE];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) row[i] = (wb + (uint64_t)i * WAVE + lane < n) ? q[i * WAVE] : fill;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { const unsigned s = (unsigned)i * WAVE + lane; xw[s + (s >> 3)] = row[i]; }
+    xrun_order();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { const unsigned s = lane * ITEMS + j; out[j] = xw[s + (s >> 3)]; }
+    xrun_order();
+}
+template <typename T, int ITEMS>
+__device__ __forceinline__ void store_run_x(T* __restrict__ p, uint64_t e0, uint64_t n, const T (&in)[ITEMS], T* xw) {
+    const unsigned lane = lane_id();
+    const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
+    T* __restrict__ q = p + wb + lane;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { const unsigned s = lane * ITEMS + j; xw[s + (s >> 3)] = in[j]; }
+    xrun_order();
+    T row[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { const unsigned s = (unsigned)i * WAVE + lane; row[i] = xw[s + (s >> 3)]; }
+    xrun_order();
+    if (wb + (uint64_t)WAVE * ITEMS <= n) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) q[i * WAVE] = row[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) if (wb + (uint64_t)i * WAVE + lane < n) q[i * WAVE] = row[i];
+    }
+}
+
 template <typename T> __device__ __forceinline__ unsigned clz_t(T x);
 template <> __device__ __forceinline__ unsigned clz_t<uint32_t>(uint32_t x) { return x ? __clz((int)x) : 32u; }
 template <> __device__ __forceinline__ unsigned clz_t<uint64_t>(uint64_t x) { return x ? __clzll((long long)x) : 64u; }

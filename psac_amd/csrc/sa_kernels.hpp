@@ -453,10 +453,18 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     // random DNA -- instead of streamed (w of the 5 w bytes per record this kernel moves).  String sets read the string
     // ends out of it, so they stream it.
     constexpr bool LAZY2 = !GSA;
+    // (runs read and written through load_run_x / store_run_x: whole rows of a wave on the memory side instead of 16-byte pieces
+    //  64 bytes apart -- 46.2 -> 39.3 ms at 2^32 64-bit records, both forms in one process; the region doubles as the stage of the
+    //  pair partition at the end of the kernel)
+    constexpr size_t XP_RUNS = sizeof(T) * (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N;
+    constexpr size_t XP_STAGE = PCB > 0 ? (PPK ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)TILE : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char xp_raw[XP_RUNS > XP_STAGE ? XP_RUNS : XP_STAGE];
+    T* const xp = reinterpret_cast<T*>(xp_raw);
+    T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], sa[ITEMS];
-    load_run<T, ITEMS>(S1, e0, n, a1, (T)0);
-    if (!LAZY2) load_run<T, ITEMS>(S2, e0, n, a2, (T)0);
-    load_run<T, ITEMS>(SA, e0, n, sa, (T)0);
+    load_run_x<T, ITEMS>(S1, e0, n, a1, (T)0, xw);
+    if (!LAZY2) load_run_x<T, ITEMS>(S2, e0, n, a2, (T)0, xw);
+    load_run_x<T, ITEMS>(SA, e0, n, sa, (T)0, xw);
     T p1 = 0, p2 = 0, psa = 0;
     bool have_p = false;
     if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; psa = SA[e0 - 1]; have_p = true; if (!LAZY2) p2 = S2[e0 - 1]; }
@@ -543,9 +551,9 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     for (int j = 0; j < ITEMS; ++j) {
         if (id[j] == 0) id[j] = carry; else carry = id[j];
     }
-    store_run<T, ITEMS>(Bsa, e0, n, id);
-    if (WITH_LCP) store_run<T, ITEMS>(LCP, e0, n, lc);
-    if (sa_out) store_run<T, ITEMS>(sa_out, e0, n, sa);
+    store_run_x<T, ITEMS>(Bsa, e0, n, id, xw);
+    if (WITH_LCP) store_run_x<T, ITEMS>(LCP, e0, n, lc, xw);
+    if (sa_out) store_run_x<T, ITEMS>(sa_out, e0, n, sa, xw);
     if (sa_hist) {
         __shared__ unsigned dh[4 * RADIX];
         for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) dh[i] = 0;
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         constexpr int NCLS = 1 << PCB;
         static_assert(BLOCK >= NCLS, "one thread per class");
         typedef typename std::conditional<PPK, uint64_t, uint32_t>::type ST;
-        __shared__ ST stage[TILE];
+        ST* const stage = reinterpret_cast<ST*>(xp_raw);
         __shared__ unsigned pcnt[NCLS];
         __shared__ unsigned pstart[NCLS];
         __shared__ uint64_t pbase[NCLS];
@@ -1299,14 +1307,16 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
 
     // K2 == nullptr: both keys of a record in one 64-bit word (K1 << 32 | K2; texts below 2^32 characters, one GPU)
     const bool both = K2 == nullptr;
+    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
+    T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
-    load_run<T, ITEMS>(K1, e0, cnt, a1, (T)0);
-    if (!both) load_run<T, ITEMS>(K2, e0, cnt, a2, (T)0);
+    load_run_x<T, ITEMS>(K1, e0, cnt, a1, (T)0, xw);
+    if (!both) load_run_x<T, ITEMS>(K2, e0, cnt, a2, (T)0, xw);
     else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { a2[j] = (T)((uint64_t)a1[j] & 0xFFFFFFFFull); a1[j] = (T)((uint64_t)a1[j] >> 32); }
     }
-    if (pos) load_run<T, ITEMS>(pos, e0, cnt, ps, (T)0);
+    if (pos) load_run_x<T, ITEMS>(pos, e0, cnt, ps, (T)0, xw);
     else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) ps[j] = (T)(e0 + j);
@@ -1380,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if ((T)bd.base > carry) carry = (T)bd.base;
     if (excl > carry) carry = excl;
     T sa[ITEMS];
-    load_run<T, ITEMS>(V, e0, cnt, sa, (T)0);
+    load_run_x<T, ITEMS>(V, e0, cnt, sa, (T)0, xw);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
@@ -1391,7 +1401,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             if (!DIST && ISA) ISA[sa[j]] = id[j] - 1;
         }
     }
-    store_run<T, ITEMS>(ids_out, e0, cnt, id);
+    store_run_x<T, ITEMS>(ids_out, e0, cnt, id, xw);
 }
 
 // ------------------------------------------------------------------ K14
