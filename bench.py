@@ -40,9 +40,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # ... round 3 (three workgroups per CU under a register cap: the spilled registers are written through), profiles/r03s_pmc_*.txt:
 #     per launch (2 x 25644637.9 + 63871449.6) KiB for passes 1-4, (2 x 25699635.6 + 81472582.0) KiB for pass 5
 # ... end of round 3, profiles/r04m_pmc_*.txt: (2 x 25644777.8 + 64191682.1) KiB for passes 1-4, (2 x 27795142.8 + 84983547.1) KiB
-#     for pass 5; mean over the five passes = 123391751168 bytes (1.15 x the algorithmic bytes: the spilled registers)
+#     for pass 5; mean over the five passes = 123391751168 bytes
+# ... after the scratch of the narrow passes went from 20 to 4 bytes per thread, profiles/r04s_pmc_*.txt: (2 x 24602539.1 + 59913695.6) KiB
+#     for passes 1-4, (2 x 26743427.4 + 82173525.6) KiB for pass 5; mean = 117173345280 bytes (1.14 x the algorithmic bytes: runs of
+#     64-128 bytes that start anywhere write whole 32-byte sectors)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 123391751168}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280}
 
 
 def parse():

@@ -873,11 +873,13 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
+    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
+    T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]; ids are >= 1, so 0 never matches
     T raw[EMIT ? ITEMS : 1];
     {
         T mid[ITEMS];
-        load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
+        load_run_x<T, ITEMS>(ids, e0, cnt, mid, (T)0, xw);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { v[j + 1] = mid[j]; if (EMIT) raw[EMIT ? j : 0] = mid[j]; }
         v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
@@ -899,11 +901,11 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     if (agg == 0) return;
     uint64_t o = offset[tile] + excl;
     T ps[ITEMS];
-    if (pos_in) load_run<T, ITEMS>(pos_in, e0, cnt, ps, (T)0);
+    if (pos_in) load_run_x<T, ITEMS>(pos_in, e0, cnt, ps, (T)0, xw);
     T pl[EMIT ? ITEMS : 1];
-    if (EMIT && nact) {
+    if (EMIT && __ballot(nact != 0)) {          // (the whole wave or none of it: the rows are read by all its lanes)
         T tmp[ITEMS];
-        load_run<T, ITEMS>(payload, e0, cnt, tmp, (T)0);
+        load_run_x<T, ITEMS>(payload, e0, cnt, tmp, (T)0, xw);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) pl[EMIT ? j : 0] = tmp[j];
     }
@@ -923,11 +925,13 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
                                                              uint64_t* __restrict__ n_active, unsigned shift = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
+    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];
+    T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     const uint64_t e0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
     T v[ITEMS + 2];
     {
         T mid[ITEMS];
-        load_run<T, ITEMS>(ids, e0, cnt, mid, (T)0);
+        load_run_x<T, ITEMS>(ids, e0, cnt, mid, (T)0, xw);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) v[j + 1] = mid[j];
         v[0] = (e0 >= 1 && e0 - 1 < cnt) ? ids[e0 - 1] : (e0 == 0 ? prev_id : (T)0);
@@ -1013,6 +1017,8 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
     if (threadIdx.x == 0) n_leaders = 0;
     __syncthreads();
     // pass 1 (streaming): find the groups that start in this tile
+    // (Tried: the tile in pieces of BLOCK x 8 records read through whole rows of a wave as in the rebucket kernels (load_run_x):
+    //  13.6 against 10.7 ms at 2^32 -- the thirty-two-record runs keep sixteen 16-byte loads per thread in flight, the pieces do not.)
     const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
     const uint64_t e0 = t0 + (uint64_t)threadIdx.x * ITEMS;
     if (e0 < n) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of an environment switch inside one process (same memory placement): tools/_ab.py ENVNAME [log2 n] [bits]."""
+"""A/B of an environment switch inside one process (same memory placement): tools/ab_env.py ENVNAME [log2 n] [bits]."""
 import ctypes as C
 import os
 import sys
