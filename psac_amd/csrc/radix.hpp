@@ -24,7 +24,10 @@ constexpr int SLAB_TILES = 64;                       // tiles per slab of the th
 // Very long inputs use longer slabs: the scan over the slab totals is one workgroup walking them one after the other
 // (1.7 ms per pass at 2^20 tiles with 64-tile slabs, 2 % of a 4 GiB construction), the scan inside a slab runs in
 // parallel over slabs.
-inline unsigned slab_tiles_for(uint64_t ntiles) { return ntiles > (1u << 16) ? 1024u : (unsigned)SLAB_TILES; }
+// (a slab is one workgroup walking its tiles one after the other, the slab totals one workgroup walking the slabs: measured with
+//  both sizes in one process, 2^29 64-bit records (2^17 tiles): 4.3 ms of histogram + scans per sort with slabs of 1024 tiles,
+//  3.2 with 256 or 128; 2^32 records (2^20 tiles): 29.1 with 1024, 28.1 with 512, 31.3 with 128)
+inline unsigned slab_tiles_for(uint64_t ntiles) { return ntiles > (1u << 19) ? 512u : ntiles > (1u << 16) ? 256u : (unsigned)SLAB_TILES; }
 
 // pass p < passes_lo reads key2 (low word), the rest read key1
 struct PassPlan {

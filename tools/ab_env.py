@@ -17,7 +17,7 @@ sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
 sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
 for rep in range(3):
     for on in (False, True):
-        if on: os.environ[env] = "1"
+        if on: os.environ[env] = os.environ.get("AB_VALUE", "1")
         else: os.environ.pop(env, None)
         s = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp, profile=True)
         print("%s=%d: keys %.1f, tile hist %.1f, scatter %.1f, rebucket %.2f, isa %.1f, total %.1f"
