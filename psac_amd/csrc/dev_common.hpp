@@ -276,6 +276,9 @@ __device__ __forceinline__ void store_run(T* __restrict__ p, uint64_t e0, uint64
 // per-thread runs through its own padded LDS region xw (XRUN_WORDS<ITEMS> elements; e + e / 8: a thread's run starts nine
 // slots after its neighbour's).  e0: first element of THIS thread, consecutive over the lanes of the wave.  LDS operations of a
 // wave execute in order, so a region needs no barrier between its uses; the fences only keep the compiler from moving them.
+// 64-bit words only: a thread's run of eight 32-bit entries is two 16-byte pieces 32 bytes apart, which the memory side takes
+// as it is -- rebucket_first_kernel on 2^28 32-bit records 1.82 ms with plain runs, 2.74 ms through the rows (and 46.2 against
+// 39.3 ms the other way round on 2^32 64-bit records) -- so for them load_run_x / store_run_x ARE load_run / store_run.
 template <int ITEMS> struct XRUN_WORDS { static constexpr int N = WAVE * ITEMS + WAVE * ITEMS / 8; };
 __device__ __forceinline__ void xrun_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -284,6 +287,7 @@ __device__ __forceinline__ void xrun_order() {
 }
 template <typename T, int ITEMS>
 __device__ __forceinline__ void load_run_x(const T* __restrict__ p, uint64_t e0, uint64_t n, T (&out)[ITEMS], T fill, T* xw) {
+    if constexpr (sizeof(T) < 8) { load_run<T, ITEMS>(p, e0, n, out, fill); return; }
     const unsigned lane = lane_id();
     const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
     const T* __restrict__ q = p + wb + lane;
@@ -304,6 +308,7 @@ __device__ __forceinline__ void load_run_x(const T* __restrict__ p, uint64_t e0,
 }
 template <typename T, int ITEMS>
 __device__ __forceinline__ void store_run_x(T* __restrict__ p, uint64_t e0, uint64_t n, const T (&in)[ITEMS], T* xw) {
+    if constexpr (sizeof(T) < 8) { store_run<T, ITEMS>(p, e0, n, in); return; }
     const unsigned lane = lane_id();
     const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
     T* __restrict__ q = p + wb + lane;

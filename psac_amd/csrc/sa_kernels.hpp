@@ -456,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     // (runs read and written through load_run_x / store_run_x: whole rows of a wave on the memory side instead of 16-byte pieces
     //  64 bytes apart -- 46.2 -> 39.3 ms at 2^32 64-bit records, both forms in one process; the region doubles as the stage of the
     //  pair partition at the end of the kernel)
-    constexpr size_t XP_RUNS = sizeof(T) * (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N;
+    constexpr size_t XP_RUNS = sizeof(T) == 8 ? sizeof(T) * (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 16;
     constexpr size_t XP_STAGE = PCB > 0 ? (PPK ? sizeof(uint64_t) : sizeof(uint32_t)) * (size_t)TILE : 0;
     __shared__ __attribute__((aligned(16))) unsigned char xp_raw[XP_RUNS > XP_STAGE ? XP_RUNS : XP_STAGE];
     T* const xp = reinterpret_cast<T*>(xp_raw);
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
-    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
+    __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T v[ITEMS + 2];                    // ids[e0-1 .. e0+ITEMS]; ids are >= 1, so 0 never matches
     T raw[EMIT ? ITEMS : 1];
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
                                                              uint64_t* __restrict__ n_active, unsigned shift = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
-    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];
+    __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     const uint64_t e0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * ITEMS;
     T v[ITEMS + 2];
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
 
     // K2 == nullptr: both keys of a record in one 64-bit word (K1 << 32 | K2; texts below 2^32 characters, one GPU)
     const bool both = K2 == nullptr;
-    __shared__ T xp[(BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
+    __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
     load_run_x<T, ITEMS>(K1, e0, cnt, a1, (T)0, xw);
