@@ -178,10 +178,15 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
             if (aligned_ptr && g0 + 16 <= n_text) {
                 const uint4 x = *reinterpret_cast<const uint4*>(text + g0);
                 const unsigned wds[4] = {x.x, x.y, x.z, x.w};
+                // (all sixteen table look-ups first, then the stores: written as one statement per byte, every look-up waited for
+                //  the store before it -- both are LDS accesses the compiler cannot tell apart)
+                uint16_t cd[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) cd[b] = ctab[(wds[b >> 2] >> ((b & 3) * 8)) & 255u];
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     const int i = (int)v + b - (int)lead;          // window index of this byte
-                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = ctab[(wds[b >> 2] >> ((b & 3) * 8)) & 255u];
+                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = cd[b];
                 }
             } else {
 #pragma unroll 1
