@@ -508,6 +508,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // (measured slower than 32-bit payload entries on one GPU, engine.hpp: packed_form_for -- off unless PSACX_PACKED=1)
     const PackedForm pf = two_stage ? packed_form_for(n, lo1, sizeof(T), false) : PackedForm();
     const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.no_key_hist;
+    // one-word records, most significant digit first (engine.hpp: prefix_sort_1w): 64-bit words, suffixes below 2^32, the
+    // prefix without its top digit in 32 bits
+    bool one_word = two_stage && hist_in_keys && !gsa && sizeof(T) == 8 && n <= (1ull << 32) && n >= (1ull << 24) && lead >= 3 * RADIX_BITS &&
+                    lead <= 32 + RADIX_BITS && lead % RADIX_BITS == 0 && !pf.on() && !kn.no_one_word && attempt == 0;
+    const bool hist_of_top_digit = one_word;      // (what key_pairs_kernel leaves in the scratch)
 
     // In the diet layout the second record set is the output buffers (y = ISA, LCP, SA).  One stage: both sorted key
     // words must end up in the workspace set x (word 2 in the LCP buffer would be overwritten while its neighbours are
@@ -539,7 +544,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             nb = (n + HB * HI - 1) / (HB * HI);
             hipLaunchKernelGGL((key_pairs_kernel<T, HB, HI, false, true>), dim3((unsigned)nb), dim3(HB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr,
-                               reinterpret_cast<unsigned*>(w.sc.d_desc + 256), (int)lo1);
+                               reinterpret_cast<unsigned*>(w.sc.d_desc + 256), (int)(one_word ? lo1 + lead - RADIX_BITS : lo1));
         } else
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr);
@@ -551,8 +556,22 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         bool packed1 = false;            // the sort ran in the packed form: word 1 comes back with payload bits in its low end
+        if constexpr (sizeof(T) == 8) {
+            if (one_word) {
+                uint64_t* s1 = nullptr;
+                const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
+                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, ks.spec, n, r0, &s1);
+                if (rc1 == PSACX_RETRY_1W) one_word = false;          // (uneven top digit: nothing was touched)
+                else {
+                    PSACX_TRY(rc1);
+                    sorted.k1 = reinterpret_cast<T*>(s1); sorted.k2 = nullptr; sorted.v = d_sa;
+                    packed1 = true;          // (the bits of word 1 below the prefix are gone: ties read word 1 from the text)
+                }
+            }
+        } else one_word = false;
+        if (!one_word)
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
-                               ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1, false, pf, false, &packed1));
+                               ks.spec, n, /*summary_ready=*/true, lo1, (hist_in_keys && !hist_of_top_digit) ? (int)lo1 : -1, false, pf, false, &packed1));
         if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
             PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         T* const S1 = sorted.k1;

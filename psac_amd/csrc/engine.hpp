@@ -132,6 +132,7 @@ struct Knobs {
     bool one_stage;         // PSACX_ONE_STAGE: first round as one sort over both key words
     bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
     bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
+    bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
     unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
     bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
     bool isa_wide;          // PSACX_ISA_WIDE: 64-bit words: pairs stay 64-bit
@@ -150,6 +151,7 @@ inline Knobs read_knobs() {
     k.one_stage = getenv("PSACX_ONE_STAGE") != nullptr;
     k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
     k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
+    k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
     e = getenv("PSACX_LEAD_SLACK");
     k.lead_slack = e ? (unsigned)atoi(e) : 2u;
     k.isa_partition = getenv("PSACX_ISA_PARTITION") != nullptr;
@@ -822,6 +824,102 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         cur.v = dst;
     }
     *res = cur;
+    return PSACX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Prefix sort of the first round in one-word records, most significant digit first (radix.hpp: VN 7 .. 9, *1w kernels).
+// The two-stage first round sorts (word 1, suffix) on the `lead` bits of word 1 above bit lo1 and reads nothing below them
+// afterwards (ties get their windows from the text again).  With lead - 8 <= 32 and suffixes below 2^32 a record fits ONE
+// 64-bit word once the top digit of the prefix is known from the record's place: pass 0 partitions k1 by the top digit and writes
+// (rest of the prefix) << 32 | suffix; the remaining digits are LSD passes inside the 256 buckets, all buckets in one launch; the
+// last of them writes word 1 (prefix << lo1, low bits zero: the packed form of the ties machinery) and the suffixes as words.
+// Bytes per record: 16 + (lead / 8 - 2) x 16 + 24 instead of (lead / 8 - 1) x 24 + 28 (and 8 per pass for the histograms as before).
+// k0: word 1 of every record in record order (destroyed); a: scratch of n words; *s1: whichever of the two holds the sorted word 1; sa_out: sorted
+// suffixes.  The tile histograms of the top digit (shift lo1 + lead - 8) must be in the scratch (key_pairs_kernel<..., HIST>).
+// Returns PSACX_RETRY_1W without having touched k0 when the top digit is too unevenly filled for the bucket tables.
+constexpr int PSACX_RETRY_1W = 1001;
+inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
+                          uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1) {
+    constexpr int BLOCK = 512, ITEMS = 8, TILE = BLOCK * ITEMS;
+    const unsigned low = lead - RADIX_BITS;            // prefix bits that stay in the word
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    char* const scratch = sc.d_desc;
+    // pass 0: offsets from the histograms key_pairs_kernel left, top digit
+    const unsigned slab0 = slab_tiles_for(ntiles);
+    const uint64_t nslabs0 = (ntiles + slab0 - 1) / slab0;
+    unsigned* tile_hist0 = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot0 = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
+    unsigned long long* base0 = sc.d_base;
+    {
+        ProfScope ps(c, TC_SORT_TILEHIST);
+        hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs0), dim3(RADIX), 0, c->stream, tile_hist0, ntiles, slab_tot0, slab0);
+        hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot0, nslabs0, base0);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    PSACX_HIP(c, hipMemcpyAsync(sc.h_base, base0, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    uint64_t maxcnt = 0;
+    for (int d = 0; d < RADIX; ++d) {
+        const uint64_t end = d + 1 < RADIX ? sc.h_base[d + 1] : n;
+        maxcnt = std::max<uint64_t>(maxcnt, end - sc.h_base[d]);
+    }
+    const unsigned tpb = (unsigned)((maxcnt + TILE - 1) / TILE);
+    const unsigned slab = SLAB_TILES;
+    const unsigned spb = (tpb + slab - 1) / slab;
+    const size_t hist_bytes = ((size_t)RADIX * tpb * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t slab_bytes = ((size_t)RADIX * spb * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + (RADIX + 1) * 8 + 256;
+    // (a bucket twice the average would double the table of mostly empty tiles: such texts take the two-array passes)
+    if (maxcnt > n / RADIX * 3 / 2 + TILE || need > sc.desc_bytes || (uint64_t)RADIX * tpb >= (1ull << 31)) return PSACX_RETRY_1W;
+    {
+        ProfScope ps(c, TC_SORT_SCATTER2);
+        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+        hipLaunchKernelGGL((radix_scatter3_kernel<uint64_t, BLOCK, ITEMS, false, 6, true, 7>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream,
+                           (const uint64_t*)k0, (const uint64_t*)nullptr, (const uint64_t*)nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, n,
+                           (int)(lo1 + low), base0, tile_hist0, slab_tot0, (unsigned long long*)nullptr, spec, spec_n,
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1);
+        PSACX_HIP(c, hipGetLastError());
+    }
+    c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n;
+    // the buckets
+    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes);
+    unsigned long long* base2 = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes + slab_bytes);
+    unsigned long long* bucket_off = base2 + (size_t)RADIX * RADIX;
+    hipLaunchKernelGGL(radix_bucket_off_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, base0, (unsigned long long)n, bucket_off);
+    PSACX_HIP(c, hipGetLastError());
+    const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
+    uint64_t* cur = a;
+    uint64_t* oth = k0;
+    for (int j = 0; j < npass; ++j) {
+        const bool last = j + 1 == npass;
+        const int shift = 32 + j * RADIX_BITS;
+        {
+            ProfScope ps(c, TC_SORT_TILEHIST);
+            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS>), dim3(tpb, RADIX), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, bucket_off, tpb, shift, tile_hist);
+            hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3(spb, RADIX), dim3(RADIX), 0, c->stream, tile_hist, bucket_off, (unsigned)TILE, tpb, spb, slab, slab_tot);
+            hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, bucket_off, spb, base2);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        ProfScope ps(c, TC_SORT_SCATTER2);
+        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+        const unsigned grid = (unsigned)RADIX * tpb;
+        if (!last)
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 8>), dim3(grid), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
+                               bucket_off, tpb, spb, slab, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), 0u);
+        else {
+            // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 9>), dim3(grid), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
+                               bucket_off, tpb, spb, slab, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true),
+                               lo1 | (low << 8));
+        }
+        PSACX_HIP(c, hipGetLastError());
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * n;
+        std::swap(cur, oth);
+    }
+    *s1 = cur;          // (k0 after an odd number of bucket passes, `a` after an even number)
+    if (rs) { rs->sort_passes = (uint32_t)(npass + 1); rs->sort_passes_skipped = 0; }
     return PSACX_OK;
 }
 

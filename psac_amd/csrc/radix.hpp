@@ -175,8 +175,15 @@ __device__ __forceinline__ void radix_scatter_tile(
     const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
-    constexpr bool PK = VN >= 3;                       // packed payload
+    constexpr bool PK = VN >= 3 && VN <= 6;            // packed payload
     constexpr bool PK_OUT_FULL = VN == 4 || VN == 6;   // ... put together again on the way out
+    // VN 7 / 8 / 9: one-word records (the prefix sort of the first round, most significant digit first; engine.hpp: prefix_sort_1w).
+    // 7: the pass on the TOP digit of the prefix; it makes the payload up and writes ONE word per record, (prefix without its top
+    //    digit) << 32 | payload (pack = lo1, the bits of word 1 below the prefix); 8: one-word records in and out (a digit of the
+    //    upper half; the records of one top digit only: the caller offsets the arrays); 9: one-word records in, word 1
+    //    (prefix << lo1, top digit = voff, pack = lo1 | (prefix bits without the top digit) << 8) and the 64-bit payload out.
+    constexpr bool ONEW_IN = VN == 8 || VN == 9;
+    constexpr bool ONEW_OUT = VN == 7 || VN == 8;
     const T pmask = PK ? (T)((((uint64_t)1 << pack) - 1)) : (T)0;
     T* const stage = sh.stage;
     uint8_t* const sdig = sh.sdig;
@@ -240,7 +247,9 @@ __device__ __forceinline__ void radix_scatter_tile(
     }
     // (one uniform branch around the whole group of loads: tested per record, the compiler kept it inside the unrolled loop and
     //  waited for a load in the middle of the group to spill it)
-    if (pv) {
+    if (ONEW_IN) {
+        // one-word records: the payload sits in the low half of the key word
+    } else if (pv) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const unsigned loc = wbase + i * WAVE;
@@ -336,7 +345,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
-        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = kd[i]; sdig[rank[i]] = (uint8_t)d; }
+        const T staged = VN == 7 ? (T)((((uint64_t)kd[i] >> pack) << 32) | (uint64_t)(uint32_t)vv[i]) : kd[i];
+        if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = staged; sdig[rank[i]] = (uint8_t)d; }
     }
     __syncthreads();
     T xlow[PK_OUT_FULL ? ITEMS : 1];    // packed payload on its way out: the bits the key word of output slot tid + j * BLOCK carries
@@ -346,9 +356,14 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (FULL || p < count) {
             const T x = stage[p];
             if (PK_OUT_FULL) xlow[PK_OUT_FULL ? j : 0] = (T)(x & pmask);
-            kd_out[(T)(goff[sdig[p]] + (T)p)] = x;
+            const T at = (T)(goff[sdig[p]] + (T)p);
+            if (VN == 9) {
+                kd_out[at] = (T)(((voff << (pack >> 8)) | ((uint64_t)x >> 32)) << (pack & 255u));
+                v_out[at] = (T)((uint64_t)x & 0xFFFFFFFFull);
+            } else kd_out[at] = x;
         }
     }
+    if (ONEW_OUT || VN == 9) return;            // one word moved: nothing else to stage
     __syncthreads();
     if (stamp) mydbg[4] = __builtin_amdgcn_s_memtime();
     if (!NOKO) {
@@ -591,6 +606,128 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
                                                                          spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
+}
+
+// ---------------------------------------------------------------------------
+// One-word records, most significant digit first (engine.hpp: prefix_sort_1w).  After the pass on the top digit of the prefix the
+// records of top digit b lie in [bucket_off[b], bucket_off[b + 1]) as ONE 64-bit word each (rest of the prefix << 32 | suffix); the
+// remaining digits are LSD passes inside every bucket.  All 256 buckets run in one launch: a tile index is (bucket b, tile t of
+// the bucket), every bucket has room for `tpb` tiles and `spb` slabs in the histogram / offset tables (tiles beyond the end of
+// a bucket do nothing).  Eight bytes per record read and written per pass instead of twelve, one stage through LDS instead
+// of two, and no register of a thread holds payload.
+// ---------------------------------------------------------------------------
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t* __restrict__ in, const unsigned long long* __restrict__ bucket_off,
+                                                                  unsigned tpb, int shift, unsigned* __restrict__ tile_hist) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int PER = 2;
+    const unsigned b = blockIdx.y, t = blockIdx.x;
+    const uint64_t off = bucket_off[b], n = bucket_off[b + 1] - off;
+    if ((uint64_t)t * TILE >= n) return;
+    __shared__ unsigned lh[4][RADIX];
+    for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)t * TILE;
+    const uint64_t* __restrict__ kd_in = in + off;
+    unsigned* my = lh[(threadIdx.x / WAVE) & 3];
+#pragma unroll
+    for (int v = 0; v < ITEMS / PER; ++v) {
+        const uint64_t e0 = base + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
+        // (a bucket starts anywhere: 8-byte loads, two per thread and step, adjacent lanes adjacent)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool ok = e0 + j < n;
+            const uint64_t x = ok ? kd_in[e0 + j] : 0ull;
+            wave_hist_add(my, (unsigned)(x >> shift) & (RADIX - 1), ok);
+        }
+    }
+    __syncthreads();
+    unsigned* row = tile_hist + ((uint64_t)b * tpb + t) * RADIX;
+    for (int d = threadIdx.x; d < RADIX; d += BLOCK) row[d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
+}
+
+// grid (spb, 256): exclusive scan of the tile counts of one slab of one bucket per digit (in place), slab totals out
+template <int TAG>
+__global__ __launch_bounds__(RADIX) void radix_slab_scan1w_kernel(unsigned* __restrict__ tile_hist, const unsigned long long* __restrict__ bucket_off,
+                                                                  unsigned tile_records, unsigned tpb, unsigned spb, unsigned slab_tiles,
+                                                                  unsigned long long* __restrict__ slab_tot) {
+    const unsigned b = blockIdx.y;
+    const uint64_t n = bucket_off[b + 1] - bucket_off[b];
+    const uint64_t ntiles = (n + tile_records - 1) / tile_records;
+    const uint64_t t0 = (uint64_t)blockIdx.x * slab_tiles;
+    const unsigned d = threadIdx.x;
+    unsigned* __restrict__ rows = tile_hist + (uint64_t)b * tpb * RADIX;
+    unsigned long long run = 0;
+    constexpr int B = 16;
+    for (unsigned b0 = 0; b0 < slab_tiles && t0 + b0 < ntiles; b0 += B) {
+        unsigned v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) v[j] = (t0 + b0 + j < ntiles) ? rows[(t0 + b0 + j) * RADIX + d] : 0u;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (t0 + b0 + j < ntiles) rows[(t0 + b0 + j) * RADIX + d] = (unsigned)run;
+            run += v[j];
+        }
+    }
+    slab_tot[((uint64_t)b * spb + blockIdx.x) * RADIX + d] = run;
+}
+
+// grid 256: one workgroup per bucket: exclusive scan of its slab totals per digit (in place), start of every digit of the bucket
+template <int TAG>
+__global__ __launch_bounds__(RADIX) void radix_top_scan1w_kernel(unsigned long long* __restrict__ slab_tot, const unsigned long long* __restrict__ bucket_off,
+                                                                 unsigned spb, unsigned long long* __restrict__ digit_base) {
+    __shared__ unsigned long long tmp[RADIX / WAVE + 1];
+    const unsigned b = blockIdx.x, d = threadIdx.x;
+    unsigned long long* __restrict__ rows = slab_tot + (uint64_t)b * spb * RADIX;
+    unsigned long long run = 0;
+    for (unsigned s0 = 0; s0 < spb; ++s0) {
+        const unsigned long long v = rows[(uint64_t)s0 * RADIX + d];
+        rows[(uint64_t)s0 * RADIX + d] = run;
+        run += v;
+    }
+    unsigned long long total;
+    const unsigned long long start = block_scan_exclusive<RADIX, unsigned long long>(run, OpSum(), 0ull, tmp, &total);
+    digit_base[(uint64_t)b * RADIX + d] = bucket_off[b] + start;
+}
+
+// bucket_off[0 .. 256] out of the digit starts of the pass on the top digit
+template <int TAG>
+__global__ void radix_bucket_off_kernel(const unsigned long long* __restrict__ digit_base, unsigned long long n, unsigned long long* __restrict__ bucket_off) {
+    const unsigned d = threadIdx.x;
+    if (d < RADIX) bucket_off[d] = digit_base[d];
+    if (d == 0) bucket_off[RADIX] = n;
+}
+
+// grid 256 * tpb workgroups, one (bucket, tile) each, handed out in order through the per-XCD queues
+template <int BLOCK, int ITEMS, int VN>
+__global__ __launch_bounds__(BLOCK, 6) void radix_scatter1w_kernel(
+    const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift,
+    const unsigned long long* __restrict__ bucket_off, unsigned tpb, unsigned spb, unsigned slab_tiles,
+    const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
+    const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack) {
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int NW = BLOCK / WAVE;
+    static_assert(VN == 8 || VN == 9, "one-word records in");
+    __shared__ ScatterShared<uint64_t, TILE, NW> sh;
+    if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
+    for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
+    __syncthreads();
+    const unsigned vt = sh.s_tile;
+    const unsigned b = vt / tpb, t = vt - b * tpb;
+    const uint64_t off = bucket_off[b], n = bucket_off[b + 1] - off;
+    if ((uint64_t)t * TILE >= n) return;
+    const uint64_t remain = n - (uint64_t)t * TILE;
+    const unsigned* te = tile_excl + (uint64_t)b * tpb * RADIX;
+    const unsigned long long* se = slab_excl + (uint64_t)b * spb * RADIX;
+    const unsigned long long* db = digit_base + (uint64_t)b * RADIX;
+    if (remain >= (uint64_t)TILE)
+        radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, true, false, false, true, VN>(sh, t, (unsigned)TILE, in + off, nullptr, nullptr, out, nullptr, v_out,
+                                                                                          shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, slab_tiles,
+                                                                                          (uint64_t)b, pack);
+    else
+        radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, false, false, false, true, VN>(sh, t, (unsigned)remain, in + off, nullptr, nullptr, out, nullptr, v_out,
+                                                                                           shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, slab_tiles,
+                                                                                           (uint64_t)b, pack);
 }
 
 } // namespace psacx
