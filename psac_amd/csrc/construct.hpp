@@ -510,7 +510,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.no_key_hist;
     // one-word records, most significant digit first (engine.hpp: prefix_sort_1w): 64-bit words, suffixes below 2^32, the
     // prefix without its top digit in 32 bits
-    bool one_word = two_stage && hist_in_keys && !gsa && sizeof(T) == 8 && n <= (1ull << 32) && n >= (1ull << 24) && lead >= 3 * RADIX_BITS &&
+    bool one_word = two_stage && hist_in_keys && !gsa && sizeof(T) == 8 && n <= (1ull << 32) && n >= (1ull << kn.one_word_min) && lead >= 3 * RADIX_BITS &&
                     lead <= 32 + RADIX_BITS && lead % RADIX_BITS == 0 && !pf.on() && !kn.no_one_word && attempt == 0;
     const bool hist_of_top_digit = one_word;      // (what key_pairs_kernel leaves in the scratch)
 

@@ -133,6 +133,7 @@ struct Knobs {
     bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
     bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
+    unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
     unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
     bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
     bool isa_wide;          // PSACX_ISA_WIDE: 64-bit words: pairs stay 64-bit
@@ -152,6 +153,7 @@ inline Knobs read_knobs() {
     k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
     k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
     k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
+    k.one_word_min = getenv("PSACX_ONE_WORD_MIN") ? (unsigned)std::max(16, atoi(getenv("PSACX_ONE_WORD_MIN"))) : 24u;
     e = getenv("PSACX_LEAD_SLACK");
     k.lead_slack = e ? (unsigned)atoi(e) : 2u;
     k.isa_partition = getenv("PSACX_ISA_PARTITION") != nullptr;
@@ -837,7 +839,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 // Bytes per record: 16 + (lead / 8 - 2) x 16 + 24 instead of (lead / 8 - 1) x 24 + 28 (and 8 per pass for the histograms as before).
 // k0: word 1 of every record in record order (destroyed); a: scratch of n words; *s1: whichever of the two holds the sorted word 1; sa_out: sorted
 // suffixes.  The tile histograms of the top digit (shift lo1 + lead - 8) must be in the scratch (key_pairs_kernel<..., HIST>).
-// Returns PSACX_RETRY_1W without having touched k0 when the top digit is too unevenly filled for the bucket tables.
+// Returns PSACX_RETRY_1W without having touched k0 when the scratch has no room for the bucket tables.
 constexpr int PSACX_RETRY_1W = 1001;
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
                           uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1) {
@@ -859,19 +861,31 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     }
     PSACX_HIP(c, hipMemcpyAsync(sc.h_base, base0, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
-    uint64_t maxcnt = 0;
+    // tables of the buckets: every bucket owns whole slabs of tiles (radix.hpp: OneWordTabs)
+    const unsigned slab = ntiles >= (1u << 16) ? 64u : 16u;
+    unsigned long long* h_tabs = sc.h_base + RADIX;             // pinned: bucket_off[257], slab_start[257]
+    uint64_t maxcnt = 0, total_slabs = 0;
+    int used = 0;
     for (int d = 0; d < RADIX; ++d) {
         const uint64_t end = d + 1 < RADIX ? sc.h_base[d + 1] : n;
-        maxcnt = std::max<uint64_t>(maxcnt, end - sc.h_base[d]);
+        const uint64_t cnt = end - sc.h_base[d];
+        h_tabs[d] = sc.h_base[d];
+        h_tabs[RADIX + 1 + d] = total_slabs;
+        total_slabs += ((cnt + TILE - 1) / TILE + slab - 1) / slab;
+        maxcnt = std::max<uint64_t>(maxcnt, cnt);
+        used += cnt != 0;
     }
-    const unsigned tpb = (unsigned)((maxcnt + TILE - 1) / TILE);
-    const unsigned slab = SLAB_TILES;
-    const unsigned spb = (tpb + slab - 1) / slab;
-    const size_t hist_bytes = ((size_t)RADIX * tpb * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
-    const size_t slab_bytes = ((size_t)RADIX * spb * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
-    const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + (RADIX + 1) * 8 + 256;
-    // (a bucket twice the average would double the table of mostly empty tiles: such texts take the two-array passes)
-    if (maxcnt > n / RADIX * 3 / 2 + TILE || need > sc.desc_bytes || (uint64_t)RADIX * tpb >= (1ull << 31)) return PSACX_RETRY_1W;
+    h_tabs[RADIX] = n;
+    h_tabs[2 * RADIX + 1] = total_slabs;
+    if (getenv("PSACX_SORT_DEBUG"))
+        fprintf(stderr, "[psacx 1w] n=%llu lead=%u lo1=%u: %d buckets in use, largest %llu (mean %llu), %llu slabs of %u tiles for %llu tiles\n", (unsigned long long)n, lead,
+                lo1, used, (unsigned long long)maxcnt, (unsigned long long)(n / RADIX), (unsigned long long)total_slabs, slab, (unsigned long long)ntiles);
+    const uint64_t vtiles = total_slabs * slab;
+    const size_t hist_bytes = ((size_t)vtiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t slab_bytes = ((size_t)total_slabs * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    const size_t tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + total_slabs * sizeof(uint16_t) + 255) & ~(size_t)255;
+    const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + tabs_bytes;
+    if (need > sc.desc_bytes || vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
     {
         ProfScope ps(c, TC_SORT_SCATTER2);
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
@@ -882,12 +896,17 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         PSACX_HIP(c, hipGetLastError());
     }
     c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n;
-    // the buckets
+    // the buckets (the tables of pass 0 in the scratch are dead once its scatter has run: same stream)
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes);
     unsigned long long* base2 = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes + slab_bytes);
-    unsigned long long* bucket_off = base2 + (size_t)RADIX * RADIX;
-    hipLaunchKernelGGL(radix_bucket_off_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, base0, (unsigned long long)n, bucket_off);
+    unsigned long long* d_tabs = base2 + (size_t)RADIX * RADIX;
+    OneWordTabs tb;
+    tb.bucket_off = d_tabs; tb.slab_start = d_tabs + RADIX + 1; tb.slab = slab;
+    uint16_t* slab_bucket = reinterpret_cast<uint16_t*>(d_tabs + 2 * (RADIX + 1));
+    tb.slab_bucket = slab_bucket;
+    PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(radix_slab_bucket_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.slab_start, (unsigned)total_slabs, slab_bucket);
     PSACX_HIP(c, hipGetLastError());
     const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
     uint64_t* cur = a;
@@ -897,22 +916,20 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         const int shift = 32 + j * RADIX_BITS;
         {
             ProfScope ps(c, TC_SORT_TILEHIST);
-            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS>), dim3(tpb, RADIX), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, bucket_off, tpb, shift, tile_hist);
-            hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3(spb, RADIX), dim3(RADIX), 0, c->stream, tile_hist, bucket_off, (unsigned)TILE, tpb, spb, slab, slab_tot);
-            hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, bucket_off, spb, base2);
+            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
+            hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3((unsigned)total_slabs), dim3(RADIX), 0, c->stream, tile_hist, tb, (unsigned)TILE, slab_tot);
+            hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, tb, base2);
             PSACX_HIP(c, hipGetLastError());
         }
         ProfScope ps(c, TC_SORT_SCATTER2);
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        const unsigned grid = (unsigned)RADIX * tpb;
         if (!last)
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 8>), dim3(grid), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
-                               bucket_off, tpb, spb, slab, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), 0u);
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
+                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), 0u);
         else {
             // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 9>), dim3(grid), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
-                               bucket_off, tpb, spb, slab, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true),
-                               lo1 | (low << 8));
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
+                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), lo1 | (low << 8));
         }
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * n;

@@ -611,18 +611,37 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
 // ---------------------------------------------------------------------------
 // One-word records, most significant digit first (engine.hpp: prefix_sort_1w).  After the pass on the top digit of the prefix the
 // records of top digit b lie in [bucket_off[b], bucket_off[b + 1]) as ONE 64-bit word each (rest of the prefix << 32 | suffix); the
-// remaining digits are LSD passes inside every bucket.  All 256 buckets run in one launch: a tile index is (bucket b, tile t of
-// the bucket), every bucket has room for `tpb` tiles and `spb` slabs in the histogram / offset tables (tiles beyond the end of
-// a bucket do nothing).  Eight bytes per record read and written per pass instead of twelve, one stage through LDS instead
-// of two, and no register of a thread holds payload.
+// remaining digits are LSD passes inside every bucket.  All 256 buckets run in one launch.  The tiles of a bucket are numbered
+// from a slab boundary: bucket b owns the slabs slab_start[b] .. slab_start[b + 1] - 1 of `slab` tiles each (the tiles beyond
+// the end of the bucket in its last slab do nothing), slab_bucket[s] names the bucket of slab s, so a tile index finds its bucket
+// with one look-up and the tables have at most n / tile + 256 * slab rows however unevenly the top digit is filled.
+// Eight bytes per record read and written per pass instead of twelve, one stage through LDS instead of two, and no register
+// of a thread holds payload.
 // ---------------------------------------------------------------------------
+struct OneWordTabs {
+    const unsigned long long* bucket_off;    // [257]
+    const unsigned long long* slab_start;    // [257]
+    const uint16_t* slab_bucket;             // [slab_start[256]]
+    unsigned slab;                           // tiles per slab
+};
+
+template <int TAG>
+__global__ void radix_slab_bucket_kernel(const unsigned long long* __restrict__ slab_start, unsigned total_slabs, uint16_t* __restrict__ slab_bucket) {
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total_slabs) return;
+    unsigned lo = 0, hi = RADIX;            // the last b with slab_start[b] <= s (buckets without records own no slab)
+    while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (slab_start[mid] <= s) lo = mid; else hi = mid; }
+    slab_bucket[s] = (uint16_t)lo;
+}
+
 template <int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t* __restrict__ in, const unsigned long long* __restrict__ bucket_off,
-                                                                  unsigned tpb, int shift, unsigned* __restrict__ tile_hist) {
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t* __restrict__ in, OneWordTabs tb, int shift, unsigned* __restrict__ tile_hist) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int PER = 2;
-    const unsigned b = blockIdx.y, t = blockIdx.x;
-    const uint64_t off = bucket_off[b], n = bucket_off[b + 1] - off;
+    const unsigned vt = blockIdx.x;
+    const unsigned b = tb.slab_bucket[vt / tb.slab];
+    const unsigned t = vt - (unsigned)tb.slab_start[b] * tb.slab;
+    const uint64_t off = tb.bucket_off[b], n = tb.bucket_off[b + 1] - off;
     if ((uint64_t)t * TILE >= n) return;
     __shared__ unsigned lh[4][RADIX];
     for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
@@ -642,67 +661,58 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t
         }
     }
     __syncthreads();
-    unsigned* row = tile_hist + ((uint64_t)b * tpb + t) * RADIX;
+    unsigned* row = tile_hist + (uint64_t)vt * RADIX;
     for (int d = threadIdx.x; d < RADIX; d += BLOCK) row[d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
-// grid (spb, 256): exclusive scan of the tile counts of one slab of one bucket per digit (in place), slab totals out
+// one workgroup per slab: exclusive scan of the tile counts of the slab per digit (in place), slab totals out
 template <int TAG>
-__global__ __launch_bounds__(RADIX) void radix_slab_scan1w_kernel(unsigned* __restrict__ tile_hist, const unsigned long long* __restrict__ bucket_off,
-                                                                  unsigned tile_records, unsigned tpb, unsigned spb, unsigned slab_tiles,
+__global__ __launch_bounds__(RADIX) void radix_slab_scan1w_kernel(unsigned* __restrict__ tile_hist, OneWordTabs tb, unsigned tile_records,
                                                                   unsigned long long* __restrict__ slab_tot) {
-    const unsigned b = blockIdx.y;
-    const uint64_t n = bucket_off[b + 1] - bucket_off[b];
+    const unsigned gs = blockIdx.x;
+    const unsigned b = tb.slab_bucket[gs];
+    const uint64_t n = tb.bucket_off[b + 1] - tb.bucket_off[b];
     const uint64_t ntiles = (n + tile_records - 1) / tile_records;
-    const uint64_t t0 = (uint64_t)blockIdx.x * slab_tiles;
+    const uint64_t t0 = (uint64_t)(gs - (unsigned)tb.slab_start[b]) * tb.slab;
     const unsigned d = threadIdx.x;
-    unsigned* __restrict__ rows = tile_hist + (uint64_t)b * tpb * RADIX;
+    unsigned* __restrict__ rows = tile_hist + (uint64_t)gs * tb.slab * RADIX;
     unsigned long long run = 0;
     constexpr int B = 16;
-    for (unsigned b0 = 0; b0 < slab_tiles && t0 + b0 < ntiles; b0 += B) {
+    for (unsigned b0 = 0; b0 < tb.slab && t0 + b0 < ntiles; b0 += B) {
         unsigned v[B];
 #pragma unroll
-        for (int j = 0; j < B; ++j) v[j] = (t0 + b0 + j < ntiles) ? rows[(t0 + b0 + j) * RADIX + d] : 0u;
+        for (int j = 0; j < B; ++j) v[j] = (b0 + j < tb.slab && t0 + b0 + j < ntiles) ? rows[(uint64_t)(b0 + j) * RADIX + d] : 0u;
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            if (t0 + b0 + j < ntiles) rows[(t0 + b0 + j) * RADIX + d] = (unsigned)run;
+            if (b0 + j < tb.slab && t0 + b0 + j < ntiles) rows[(uint64_t)(b0 + j) * RADIX + d] = (unsigned)run;
             run += v[j];
         }
     }
-    slab_tot[((uint64_t)b * spb + blockIdx.x) * RADIX + d] = run;
+    slab_tot[(uint64_t)gs * RADIX + d] = run;
 }
 
 // grid 256: one workgroup per bucket: exclusive scan of its slab totals per digit (in place), start of every digit of the bucket
 template <int TAG>
-__global__ __launch_bounds__(RADIX) void radix_top_scan1w_kernel(unsigned long long* __restrict__ slab_tot, const unsigned long long* __restrict__ bucket_off,
-                                                                 unsigned spb, unsigned long long* __restrict__ digit_base) {
+__global__ __launch_bounds__(RADIX) void radix_top_scan1w_kernel(unsigned long long* __restrict__ slab_tot, OneWordTabs tb,
+                                                                 unsigned long long* __restrict__ digit_base) {
     __shared__ unsigned long long tmp[RADIX / WAVE + 1];
     const unsigned b = blockIdx.x, d = threadIdx.x;
-    unsigned long long* __restrict__ rows = slab_tot + (uint64_t)b * spb * RADIX;
+    const unsigned s_lo = (unsigned)tb.slab_start[b], s_hi = (unsigned)tb.slab_start[b + 1];
     unsigned long long run = 0;
-    for (unsigned s0 = 0; s0 < spb; ++s0) {
-        const unsigned long long v = rows[(uint64_t)s0 * RADIX + d];
-        rows[(uint64_t)s0 * RADIX + d] = run;
+    for (unsigned gs = s_lo; gs < s_hi; ++gs) {
+        const unsigned long long v = slab_tot[(uint64_t)gs * RADIX + d];
+        slab_tot[(uint64_t)gs * RADIX + d] = run;
         run += v;
     }
     unsigned long long total;
     const unsigned long long start = block_scan_exclusive<RADIX, unsigned long long>(run, OpSum(), 0ull, tmp, &total);
-    digit_base[(uint64_t)b * RADIX + d] = bucket_off[b] + start;
+    digit_base[(uint64_t)b * RADIX + d] = tb.bucket_off[b] + start;
 }
 
-// bucket_off[0 .. 256] out of the digit starts of the pass on the top digit
-template <int TAG>
-__global__ void radix_bucket_off_kernel(const unsigned long long* __restrict__ digit_base, unsigned long long n, unsigned long long* __restrict__ bucket_off) {
-    const unsigned d = threadIdx.x;
-    if (d < RADIX) bucket_off[d] = digit_base[d];
-    if (d == 0) bucket_off[RADIX] = n;
-}
-
-// grid 256 * tpb workgroups, one (bucket, tile) each, handed out in order through the per-XCD queues
+// one workgroup per (bucket, tile), handed out in order through the per-XCD queues
 template <int BLOCK, int ITEMS, int VN>
 __global__ __launch_bounds__(BLOCK, 6) void radix_scatter1w_kernel(
-    const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift,
-    const unsigned long long* __restrict__ bucket_off, unsigned tpb, unsigned spb, unsigned slab_tiles,
+    const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift, OneWordTabs tb,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack) {
     constexpr int TILE = BLOCK * ITEMS;
@@ -713,20 +723,22 @@ __global__ __launch_bounds__(BLOCK, 6) void radix_scatter1w_kernel(
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
     __syncthreads();
     const unsigned vt = sh.s_tile;
-    const unsigned b = vt / tpb, t = vt - b * tpb;
-    const uint64_t off = bucket_off[b], n = bucket_off[b + 1] - off;
+    const unsigned b = tb.slab_bucket[vt / tb.slab];
+    const unsigned s0 = (unsigned)tb.slab_start[b];
+    const unsigned t = vt - s0 * tb.slab;
+    const uint64_t off = tb.bucket_off[b], n = tb.bucket_off[b + 1] - off;
     if ((uint64_t)t * TILE >= n) return;
     const uint64_t remain = n - (uint64_t)t * TILE;
-    const unsigned* te = tile_excl + (uint64_t)b * tpb * RADIX;
-    const unsigned long long* se = slab_excl + (uint64_t)b * spb * RADIX;
+    const unsigned* te = tile_excl + (uint64_t)s0 * tb.slab * RADIX;
+    const unsigned long long* se = slab_excl + (uint64_t)s0 * RADIX;
     const unsigned long long* db = digit_base + (uint64_t)b * RADIX;
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, true, false, false, true, VN>(sh, t, (unsigned)TILE, in + off, nullptr, nullptr, out, nullptr, v_out,
-                                                                                          shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, slab_tiles,
+                                                                                          shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, tb.slab,
                                                                                           (uint64_t)b, pack);
     else
         radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, false, false, false, true, VN>(sh, t, (unsigned)remain, in + off, nullptr, nullptr, out, nullptr, v_out,
-                                                                                           shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, slab_tiles,
+                                                                                           shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, tb.slab,
                                                                                            (uint64_t)b, pack);
 }
 

@@ -768,6 +768,32 @@ def test_packed_payload_form_of_the_prefix_sort(ctx, monkeypatch, entry_bytes):
     same_as_oracle(ctx, inputs.dna((1 << 21) + 9, 7), bits=64)
 
 
+def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
+    # 64-bit words, at most 2^32 characters: the prefix sort of the first round partitions word 1 by the TOP digit of the prefix
+    # and moves one 64-bit word per record (rest of the prefix | suffix) through LSD passes inside the 256 buckets
+    # (engine.hpp: prefix_sort_1w; from 2^24 characters on by default, from 2^21 here).  Random DNA and ASCII (all buckets in
+    # use, ragged last tiles), alphabets of 3 and 5 symbols (most buckets empty, the others uneven), a text whose tie groups are
+    # long (radix fallback of the ties with word 1 read from the text again), a single symbol (one bucket), the reduced-memory
+    # layout, a caller-supplied k -- and the same results with the form switched off.
+    monkeypatch.setenv("PSACX_ONE_WORD_MIN", "21")
+    rng = np.random.RandomState(12)
+    three = np.frombuffer(b"ACG", np.uint8)[rng.randint(0, 3, (1 << 22) + 5)].copy()
+    five = np.frombuffer(b"ACGNT", np.uint8)[rng.choice(5, (1 << 21) + 4099, p=[0.3, 0.2, 0.2, 0.01, 0.29])].copy()
+    rep = np.tile(inputs.dna(1 << 12, 9), 1 << 10)
+    rep[::4099] = 84
+    cases = [(inputs.dna((1 << 22) + 77, 5), {}), (inputs.ascii128((1 << 21) + 5, 4), {}), (three, {}), (five, {}), (rep, {}),
+             (np.full((1 << 21) + 3, 65, np.uint8), {}), (inputs.dna((1 << 21) + 100, 17), {"k": 12})]
+    for text, kw in cases:
+        got, ref = same_as_oracle(ctx, text, bits=64, **kw)
+        assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
+    same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
+    same_as_oracle(ctx, five, bits=64)
+    monkeypatch.delenv("PSACX_FORCE_DIET")
+    monkeypatch.setenv("PSACX_NO_ONE_WORD", "1")
+    same_as_oracle(ctx, five, bits=64)
+
+
 @pytest.mark.parametrize("env", [{}, {"PSACX_NO_WHOLE_ROUNDS": "1"}, {"PSACX_WIDE_REFINE": "1"}, {"PSACX_NO_WHOLE_ROUNDS": "1", "PSACX_WIDE_REFINE": "1"}])
 def test_refinement_round_forms(ctx, monkeypatch, env):
     # rounds with at least 7/8 of the suffixes unresolved take all n records in text order and rebuild ISA by inverting SA
