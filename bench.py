@@ -44,8 +44,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # ... after the scratch of the narrow passes went from 20 to 4 bytes per thread, profiles/r04s_pmc_*.txt: (2 x 24602539.1 + 59913695.6) KiB
 #     for passes 1-4, (2 x 26743427.4 + 82173525.6) KiB for pass 5; mean = 117173345280 bytes (1.14 x the algorithmic bytes: runs of
 #     64-128 bytes that start anywhere write whole 32-byte sectors)
+# ... the prefix sort in one-word records (form 3), profiles/r04v_pmc_*.txt: top-digit pass (2 x 17320582.1 + 36377016.7) KiB, bucket passes
+#     (2 x 17323107.6 + 34451517.1) KiB x 3, widening pass (2 x 17328677.1 + 76887497.3) KiB; mean over the five = 79842555904 bytes
+#     (1.056 x the algorithmic 17.6 bytes per record and pass)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 79842555904}
 
 
 def parse():
@@ -121,6 +124,13 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
              "radix_scatter3_kernel (one 8-bit digit pass of the (B1,B2,idx) rank-pair sort)",
              "radix_scatter3_kernel<two-word> (one 8-bit digit pass of the first round's (B1,idx) prefix sort)")[dom]
     achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
+    tkey = dom
+    if dom == 2 and scat_launches[dom] and scat_bytes[dom] / float(scat_launches[dom]) / n < 20.0:
+        # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the pass on the top digit (radix_scatter3_kernel<..., 7>:
+        # word 1 in, one word out), the passes inside the buckets (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the
+        # last one (radix_scatter1w_kernel<..., 9>: one word in, word 1 + suffix out); the figures below are their mean
+        kname = "radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records; mean over the top-digit pass, the bucket passes and the widening pass)"
+        tkey = 3
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
         "value": round(value, 2), "unit": "MChars/s", "n_gpus": world, "steps": a.steps,
@@ -144,7 +154,7 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                      "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                      "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
                      "bytes_per_record_per_pass": round(scat_bytes[dom] / max(scat_launches[dom], 1) / float(n), 2),
-                     "traffic": TRAFFIC.get((dom, n, bits)) if world == 1 else None,
+                     "traffic": TRAFFIC.get((tkey, n, bits)) if world == 1 else None,
                      "traffic_source": "PMC counters of the committed profile of this workload (profiles/), not measured in this run"},
     }
     if phases:

@@ -646,19 +646,26 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t
     __shared__ unsigned lh[4][RADIX];
     for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)t * TILE;
-    const uint64_t* __restrict__ kd_in = in + off;
     unsigned* my = lh[(threadIdx.x / WAVE) & 3];
+    // a bucket starts anywhere: 16-byte loads at even global indices; the first pair of a tile that starts at an odd index
+    // holds a record of the tile before (left out), the last record of such a tile is picked up by itself
+    const uint64_t g0 = off + (uint64_t)t * TILE;                      // global index of the tile's first record
+    const uint64_t g1 = off + (n - (uint64_t)t * TILE < (uint64_t)TILE ? n : (uint64_t)(t + 1) * TILE);
+    const uint64_t a0 = g0 & ~1ull;
 #pragma unroll
     for (int v = 0; v < ITEMS / PER; ++v) {
-        const uint64_t e0 = base + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
-        // (a bucket starts anywhere: 8-byte loads, two per thread and step, adjacent lanes adjacent)
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const bool ok = e0 + j < n;
-            const uint64_t x = ok ? kd_in[e0 + j] : 0ull;
-            wave_hist_add(my, (unsigned)(x >> shift) & (RADIX - 1), ok);
-        }
+        const uint64_t e0 = a0 + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
+        uint64_t x0 = 0, x1 = 0;
+        if (e0 + 1 < g1) {
+            const uint4 q = *reinterpret_cast<const uint4*>(in + e0);
+            x0 = ((uint64_t)q.y << 32) | q.x; x1 = ((uint64_t)q.w << 32) | q.z;
+        } else if (e0 < g1) x0 = in[e0];                                // (the pair straddles the end of the tile: nothing is read beyond it)
+        wave_hist_add(my, (unsigned)(x0 >> shift) & (RADIX - 1), e0 >= g0 && e0 < g1);
+        wave_hist_add(my, (unsigned)(x1 >> shift) & (RADIX - 1), e0 + 1 < g1);
+    }
+    if (a0 != g0 && threadIdx.x == 0 && a0 + TILE < g1) {
+        const uint64_t x = in[a0 + TILE];
+        atomicAdd(&my[(unsigned)(x >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
     unsigned* row = tile_hist + (uint64_t)vt * RADIX;

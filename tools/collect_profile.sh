@@ -16,4 +16,4 @@ python $R/tools/pmc_summary.py /tmp/$TAG/write/bench_results.db > $O/pmc_write_s
 tail -n 3 $O/*.err | grep -v "^$" | tail -5
 rm -f $O/*.err
 cat $O/kernel_trace_stats.txt | head -12
-grep -E "scatter3|counter" $O/pmc_fetch_size.txt $O/pmc_write_size.txt
+grep -E "scatter|counter" $O/pmc_fetch_size.txt $O/pmc_write_size.txt
