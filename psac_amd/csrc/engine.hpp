@@ -883,7 +883,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     const uint64_t vtiles = total_slabs * slab;
     const size_t hist_bytes = ((size_t)vtiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
     const size_t slab_bytes = ((size_t)total_slabs * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
-    const size_t tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + total_slabs * sizeof(uint16_t) + 255) & ~(size_t)255;
+    const size_t tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + 64 + total_slabs * sizeof(SlabInfo) + 255) & ~(size_t)255;
     const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + tabs_bytes;
     if (need > sc.desc_bytes || vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
     {
@@ -903,10 +903,11 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     unsigned long long* d_tabs = base2 + (size_t)RADIX * RADIX;
     OneWordTabs tb;
     tb.bucket_off = d_tabs; tb.slab_start = d_tabs + RADIX + 1; tb.slab = slab;
-    uint16_t* slab_bucket = reinterpret_cast<uint16_t*>(d_tabs + 2 * (RADIX + 1));
-    tb.slab_bucket = slab_bucket;
+    SlabInfo* slab_info = reinterpret_cast<SlabInfo*>((reinterpret_cast<uintptr_t>(d_tabs + 2 * (RADIX + 1)) + 31) & ~(uintptr_t)31);
+    tb.slab_info = slab_info;
     PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(radix_slab_bucket_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.slab_start, (unsigned)total_slabs, slab_bucket);
+    hipLaunchKernelGGL(radix_slab_info_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.bucket_off, tb.slab_start,
+                       (unsigned)total_slabs, (unsigned)(slab * TILE), slab_info);
     PSACX_HIP(c, hipGetLastError());
     const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
     uint64_t* cur = a;

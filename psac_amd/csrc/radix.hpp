@@ -618,20 +618,32 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
 // Eight bytes per record read and written per pass instead of twelve, one stage through LDS instead of two, and no register
 // of a thread holds payload.
 // ---------------------------------------------------------------------------
+struct __attribute__((aligned(32))) SlabInfo {      // what a workgroup needs to know about its slab: one 32-byte read
+    unsigned long long first;                // global index of the first record of the slab's first tile
+    unsigned long long end;                  // end of the bucket
+    unsigned bucket, slab0;                  // the bucket and its first slab
+    unsigned pad[2];
+};
 struct OneWordTabs {
     const unsigned long long* bucket_off;    // [257]
     const unsigned long long* slab_start;    // [257]
-    const uint16_t* slab_bucket;             // [slab_start[256]]
+    const SlabInfo* slab_info;               // [slab_start[256]]
     unsigned slab;                           // tiles per slab
 };
 
 template <int TAG>
-__global__ void radix_slab_bucket_kernel(const unsigned long long* __restrict__ slab_start, unsigned total_slabs, uint16_t* __restrict__ slab_bucket) {
+__global__ void radix_slab_info_kernel(const unsigned long long* __restrict__ bucket_off, const unsigned long long* __restrict__ slab_start,
+                                       unsigned total_slabs, unsigned slab_records, SlabInfo* __restrict__ slab_info) {
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= total_slabs) return;
     unsigned lo = 0, hi = RADIX;            // the last b with slab_start[b] <= s (buckets without records own no slab)
     while (hi - lo > 1) { const unsigned mid = (lo + hi) >> 1; if (slab_start[mid] <= s) lo = mid; else hi = mid; }
-    slab_bucket[s] = (uint16_t)lo;
+    SlabInfo si;
+    si.bucket = lo; si.slab0 = (unsigned)slab_start[lo];
+    si.first = bucket_off[lo] + (unsigned long long)(s - si.slab0) * slab_records;
+    si.end = bucket_off[lo + 1];
+    si.pad[0] = si.pad[1] = 0;
+    slab_info[s] = si;
 }
 
 template <int BLOCK, int ITEMS>
@@ -639,18 +651,17 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int PER = 2;
     const unsigned vt = blockIdx.x;
-    const unsigned b = tb.slab_bucket[vt / tb.slab];
-    const unsigned t = vt - (unsigned)tb.slab_start[b] * tb.slab;
-    const uint64_t off = tb.bucket_off[b], n = tb.bucket_off[b + 1] - off;
-    if ((uint64_t)t * TILE >= n) return;
+    const unsigned gs = vt / tb.slab;
+    const SlabInfo si = tb.slab_info[gs];
+    const uint64_t g0 = si.first + (uint64_t)(vt - gs * tb.slab) * TILE;      // global index of the tile's first record
+    if (g0 >= si.end) return;
+    const uint64_t g1 = si.end - g0 < (uint64_t)TILE ? si.end : g0 + TILE;
     __shared__ unsigned lh[4][RADIX];
     for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
     __syncthreads();
     unsigned* my = lh[(threadIdx.x / WAVE) & 3];
     // a bucket starts anywhere: 16-byte loads at even global indices; the first pair of a tile that starts at an odd index
     // holds a record of the tile before (left out), the last record of such a tile is picked up by itself
-    const uint64_t g0 = off + (uint64_t)t * TILE;                      // global index of the tile's first record
-    const uint64_t g1 = off + (n - (uint64_t)t * TILE < (uint64_t)TILE ? n : (uint64_t)(t + 1) * TILE);
     const uint64_t a0 = g0 & ~1ull;
 #pragma unroll
     for (int v = 0; v < ITEMS / PER; ++v) {
@@ -677,10 +688,9 @@ template <int TAG>
 __global__ __launch_bounds__(RADIX) void radix_slab_scan1w_kernel(unsigned* __restrict__ tile_hist, OneWordTabs tb, unsigned tile_records,
                                                                   unsigned long long* __restrict__ slab_tot) {
     const unsigned gs = blockIdx.x;
-    const unsigned b = tb.slab_bucket[gs];
-    const uint64_t n = tb.bucket_off[b + 1] - tb.bucket_off[b];
-    const uint64_t ntiles = (n + tile_records - 1) / tile_records;
-    const uint64_t t0 = (uint64_t)(gs - (unsigned)tb.slab_start[b]) * tb.slab;
+    const SlabInfo si = tb.slab_info[gs];
+    const uint64_t ntiles = (si.end - si.first + tile_records - 1) / tile_records;       // tiles from the slab's first to the end of the bucket
+    const uint64_t t0 = 0;
     const unsigned d = threadIdx.x;
     unsigned* __restrict__ rows = tile_hist + (uint64_t)gs * tb.slab * RADIX;
     unsigned long long run = 0;
@@ -730,10 +740,11 @@ __global__ __launch_bounds__(BLOCK, 6) void radix_scatter1w_kernel(
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
     __syncthreads();
     const unsigned vt = sh.s_tile;
-    const unsigned b = tb.slab_bucket[vt / tb.slab];
-    const unsigned s0 = (unsigned)tb.slab_start[b];
+    const unsigned gs = vt / tb.slab;
+    const SlabInfo si = tb.slab_info[gs];
+    const unsigned b = si.bucket, s0 = si.slab0;
     const unsigned t = vt - s0 * tb.slab;
-    const uint64_t off = tb.bucket_off[b], n = tb.bucket_off[b + 1] - off;
+    const uint64_t off = si.first - (uint64_t)(gs - s0) * tb.slab * TILE, n = si.end - off;
     if ((uint64_t)t * TILE >= n) return;
     const uint64_t remain = n - (uint64_t)t * TILE;
     const unsigned* te = tile_excl + (uint64_t)s0 * tb.slab * RADIX;
