@@ -530,14 +530,16 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- first-round keys: the 2k-character window at every position, packed (kmer.hpp:119-177,
     //      shifting.hpp:33-122; see key_pairs_kernel for the packing)
-    {
+    // (the one-word prefix sort computes word 1 inside its pass on the top digit: no keys in memory unless it has to give up)
+    const bool fused_keys = one_word && !kn.no_fused_keys;
+    auto make_keys = [&](bool with_hist) -> int {
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
         uint64_t nb = (n + KB * KI - 1) / (KB * KI);
         if (gsa)
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, d_slen);
-        else if (hist_in_keys) {
+        else if (with_hist) {
             // tile shape of the stage-1 sort (ScatterCfg<T>::DEF2), pass-1 histograms written on the way
             constexpr int HB = 512, HI = sizeof(T) == 4 ? 12 : 8;
             static_assert(ScatterCfg<T>::DEF2 == (sizeof(T) == 4 ? 7 : 2), "key tile must match the scatter tile");
@@ -550,7 +552,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr);
         PSACX_HIP(c, hipGetLastError());
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
-    }
+        return PSACX_OK;
+    };
+    if (!fused_keys) PSACX_TRY(make_keys(hist_in_keys));
 
     std::memset(r0, 0, sizeof(*r0));
     if (two_stage) {
@@ -560,8 +564,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             if (one_word) {
                 uint64_t* s1 = nullptr;
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
-                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, ks.spec, n, r0, &s1);
-                if (rc1 == PSACX_RETRY_1W) one_word = false;          // (uneven top digit: nothing was touched)
+                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, ks.spec, n, r0, &s1,
+                                               fused_keys ? d_text : (const uint8_t*)nullptr, n, &tab, &ks);
+                if (rc1 == PSACX_RETRY_1W) {          // (no room for the bucket tables: nothing was touched)
+                    one_word = false;
+                    if (fused_keys) PSACX_TRY(make_keys(false));
+                }
                 else {
                     PSACX_TRY(rc1);
                     sorted.k1 = reinterpret_cast<T*>(s1); sorted.k2 = nullptr; sorted.v = d_sa;
@@ -571,7 +579,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         } else one_word = false;
         if (!one_word)
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
-                               ks.spec, n, /*summary_ready=*/true, lo1, (hist_in_keys && !hist_of_top_digit) ? (int)lo1 : -1, false, pf, false, &packed1));
+                               ks.spec, n, /*summary_ready=*/true, lo1, (hist_in_keys && !hist_of_top_digit && !fused_keys) ? (int)lo1 : -1, false, pf, false, &packed1));
         if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
             PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         T* const S1 = sorted.k1;

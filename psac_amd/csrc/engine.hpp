@@ -133,6 +133,7 @@ struct Knobs {
     bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
     bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
+    bool no_fused_keys;     // PSACX_NO_FUSED_KEYS: one-word prefix sort with word 1 written by key_pairs_kernel and read back by the pass on the top digit
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
     unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
     bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
@@ -153,6 +154,7 @@ inline Knobs read_knobs() {
     k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
     k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
     k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
+    k.no_fused_keys = getenv("PSACX_NO_FUSED_KEYS") != nullptr;
     k.one_word_min = getenv("PSACX_ONE_WORD_MIN") ? (unsigned)std::max(16, atoi(getenv("PSACX_ONE_WORD_MIN"))) : 24u;
     e = getenv("PSACX_LEAD_SLACK");
     k.lead_slack = e ? (unsigned)atoi(e) : 2u;
@@ -841,8 +843,11 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 // suffixes.  The tile histograms of the top digit (shift lo1 + lead - 8) must be in the scratch (key_pairs_kernel<..., HIST>).
 // Returns PSACX_RETRY_1W without having touched k0 when the scratch has no room for the bucket tables.
 constexpr int PSACX_RETRY_1W = 1001;
+// text != nullptr (fused front end, sa_kernels.hpp: key_scatter1w_kernel): k0 holds nothing yet -- the histograms of the top digit come
+// from the text and pass 0 computes word 1 of its tile in registers (no key_pairs_kernel launch, 16 bytes per record less).
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
-                          uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1) {
+                          uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1, const uint8_t* text = nullptr, uint64_t n_text = 0,
+                          const CodeTable* tab = nullptr, const KeyShape* ks = nullptr) {
     constexpr int BLOCK = 512, ITEMS = 8, TILE = BLOCK * ITEMS;
     const unsigned low = lead - RADIX_BITS;            // prefix bits that stay in the word
     const uint64_t ntiles = (n + TILE - 1) / TILE;
@@ -853,6 +858,11 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     unsigned* tile_hist0 = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot0 = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     unsigned long long* base0 = sc.d_base;
+    if (text) {
+        ProfScope ps(c, TC_KMER);
+        hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, tile_hist0);
+        PSACX_HIP(c, hipGetLastError());
+    }
     {
         ProfScope ps(c, TC_SORT_TILEHIST);
         hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs0), dim3(RADIX), 0, c->stream, tile_hist0, ntiles, slab_tot0, slab0);
@@ -886,7 +896,13 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     const size_t tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + 64 + total_slabs * sizeof(SlabInfo) + 255) & ~(size_t)255;
     const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + tabs_bytes;
     if (need > sc.desc_bytes || vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
-    {
+    if (text) {
+        ProfScope ps(c, TC_SORT_SCATTER2);
+        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+        hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, a, (int)(lo1 + low),
+                           base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1);
+        PSACX_HIP(c, hipGetLastError());
+    } else {
         ProfScope ps(c, TC_SORT_SCATTER2);
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
         hipLaunchKernelGGL((radix_scatter3_kernel<uint64_t, BLOCK, ITEMS, false, 6, true, 7>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream,
@@ -895,7 +911,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
                            reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1);
         PSACX_HIP(c, hipGetLastError());
     }
-    c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n;
+    c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += (text ? 9ull : 16ull) * n;      // (fused: a character in, a word out)
     // the buckets (the tables of pass 0 in the scratch are dead once its scatter has run: same stream)
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes);

@@ -182,8 +182,10 @@ __device__ __forceinline__ void radix_scatter_tile(
     //    digit) << 32 | payload (pack = lo1, the bits of word 1 below the prefix); 8: one-word records in and out (a digit of the
     //    upper half; the records of one top digit only: the caller offsets the arrays); 9: one-word records in, word 1
     //    (prefix << lo1, top digit = voff, pack = lo1 | (prefix bits without the top digit) << 8) and the 64-bit payload out.
+    // 10: as 7, with word 1 of the tile's records waiting in LDS (the stage, a wave's 64 * ITEMS records in its own part, element
+    //     e at e ^ ((e >> 3) & 7): sa_kernels.hpp: key_scatter1w_kernel computes them there instead of reading them from memory)
     constexpr bool ONEW_IN = VN == 8 || VN == 9;
-    constexpr bool ONEW_OUT = VN == 7 || VN == 8;
+    constexpr bool ONEW_OUT = VN == 7 || VN == 8 || VN == 10;
     const T pmask = PK ? (T)((((uint64_t)1 << pack) - 1)) : (T)0;
     T* const stage = sh.stage;
     uint8_t* const sdig = sh.sdig;
@@ -233,10 +235,17 @@ __device__ __forceinline__ void radix_scatter_tile(
     // (lane pointer + constant: the loads of a thread differ in their immediate offsets only -- with the 32-bit sum wbase + i * 64
     //  as the index every load had its own address register)
     const T* __restrict__ pkd_l = pkd + wbase;
+    if (VN == 10) {
+        const T* pre = stage + wave * (WAVE * ITEMS);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { const unsigned e = (unsigned)i * WAVE + lane; kd[i] = pre[e ^ ((e >> 3) & 7u)]; }
+        // (the stage is written again two barriers further down: every wave has its records in registers by then)
+    } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = wbase + i * WAVE;
         kd[i] = (FULL || loc < count) ? pkd_l[i * WAVE] : (T)0;
+    }
     }
     if (!NOKO) {
 #pragma unroll
@@ -345,7 +354,7 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
-        const T staged = VN == 7 ? (T)((((uint64_t)kd[i] >> pack) << 32) | (uint64_t)(uint32_t)vv[i]) : kd[i];
+        const T staged = (VN == 7 || VN == 10) ? (T)((((uint64_t)kd[i] >> pack) << 32) | (uint64_t)(uint32_t)vv[i]) : kd[i];
         if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = staged; sdig[rank[i]] = (uint8_t)d; }
     }
     __syncthreads();

@@ -261,6 +261,162 @@ __global__ __launch_bounds__(BLOCK) void key_pairs_kernel(const uint8_t* __restr
 #undef SW
 }
 
+// ------------------------------------------------------------------ keys straight into the one-word prefix sort
+// (engine.hpp: prefix_sort_1w, fused front end).  key_pairs_kernel writes word 1 of every record and the pass on the top digit
+// reads it back: 16 bytes per record that carry no information the text does not hold.  Here the tile histograms of the top
+// digit come from the text itself (the top digit of word 1 is the first ceil(8 / lc) characters of the window) and the pass on
+// the top digit computes word 1 of its tile in registers.
+// top_digit_hist_kernel: tile_hist[tile][256] of the top eight bits of word 1 of the records of every tile of BLOCK * ITEMS records.
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void top_digit_hist_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_text, CodeTable tab, KeyShape ks,
+                                                               unsigned* __restrict__ tile_hist) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint16_t ctab[256];
+    __shared__ unsigned lh[4][RADIX];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned lc = ks.lc;
+    const unsigned nch = (8 + lc - 1) / lc < ks.c1 ? (8 + lc - 1) / lc : ks.c1;     // characters that reach into the top digit
+    const unsigned down = nch * lc > 8 ? nch * lc - 8 : 0, up = nch * lc < 8 ? 8 - nch * lc : 0;
+    unsigned* my = lh[(threadIdx.x / WAVE) & 3];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    static_assert(ITEMS == 8, "a thread takes eight consecutive records: their characters lie in three aligned 8-byte words");
+    const uint64_t rec0 = base + (uint64_t)threadIdx.x * ITEMS;
+    unsigned dig[ITEMS];
+    const uint64_t i0 = rec0 - ks.spec;                          // (meaningful when rec0 >= spec)
+    if (rec0 >= ks.spec && rec0 + ITEMS <= n && (i0 & ~7ull) + 24 <= n_text && (reinterpret_cast<uintptr_t>(text) & 7u) == 0) {
+        const uint64_t* __restrict__ tw = reinterpret_cast<const uint64_t*>(text + (i0 & ~7ull));
+        const uint64_t w0 = tw[0], w1 = tw[1], w2 = tw[2];
+        const unsigned sh8 = (unsigned)(i0 & 7ull) * 8;
+        // bytes i0 .. i0 + 15 in two words
+        const uint64_t lo = sh8 ? (w0 >> sh8) | (w1 << (64 - sh8)) : w0, hi = sh8 ? (w1 >> sh8) | (w2 << (64 - sh8)) : w1;
+        const unsigned tmask = nch * lc >= 32 ? ~0u : ((1u << (nch * lc)) - 1u);
+        unsigned t = 0;
+        for (unsigned q = 0; q + 1 < nch; ++q) t = (t << lc) | (unsigned)ctab[(lo >> (8 * q)) & 255u];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned k = (unsigned)j + nch - 1;                // the character that enters the window of record j
+            const unsigned ch = (unsigned)((k < 8 ? lo >> (8 * k) : hi >> (8 * (k - 8))) & 255u);
+            t = ((t << lc) | (unsigned)ctab[ch]) & tmask;
+            dig[j] = ((t >> down) << up) & 255u;
+        }
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t rec = rec0 + j;
+            unsigned t = 0;
+            if (rec < n) {
+                const uint64_t i = record_suffix(rec, ks.spec, n);
+                for (unsigned q = 0; q < nch; ++q) t = (t << lc) | (unsigned)((i + q < n_text) ? ctab[text[i + q]] : (uint16_t)0);
+            }
+            dig[j] = ((t >> down) << up) & 255u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) wave_hist_add(my, dig[j], rec0 + j < n);
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX; d += BLOCK) tile_hist[(uint64_t)blockIdx.x * RADIX + d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
+}
+
+// key_scatter1w_kernel: the pass on the top digit with word 1 computed on the spot (key_pairs_kernel's staging of the text window
+// and rolling pack; the words go to the wave's part of the stage in record order and radix_scatter_tile<..., VN = 10> takes them
+// from there in the order it ranks in, which keeps the pass stable: the short suffixes at the head of the input stay in front).
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_text, CodeTable tab, KeyShape ks,
+                                                                 uint64_t* __restrict__ out, int shift, const unsigned long long* __restrict__ digit_base,
+                                                                 const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
+                                                                 unsigned* __restrict__ tile_counter, unsigned chunk, unsigned slab_tiles, unsigned lo1) {
+    typedef uint64_t T;
+    constexpr int TILE = BLOCK * ITEMS;
+    constexpr int NW = BLOCK / WAVE;
+    constexpr int HALO = 2 * 64 + 8;
+#define SW(i) ((i) + (((i) >> 3) << 1))
+    __shared__ ScatterShared<T, TILE, NW> sh;
+    __shared__ uint16_t ctab[256];
+    static_assert(sizeof(uint16_t) * (SW(TILE + HALO) + 8) <= sizeof(sh.stage), "the codes of the tile live in the stage until the words are packed");
+    uint16_t* const codes = reinterpret_cast<uint16_t*>(sh.stage);
+    if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
+    for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    __syncthreads();
+    const unsigned tile = sh.s_tile;
+    const unsigned two_k = ks.c1 + ks.c2;
+    const uint64_t base = (uint64_t)tile * TILE;
+    const uint64_t i_lo = (base > ks.spec ? base : ks.spec) - ks.spec;
+    const unsigned need = TILE + two_k;
+    {
+        const uint64_t a_lo = i_lo & ~15ull;
+        const unsigned lead = (unsigned)(i_lo - a_lo);
+        const bool aligned_ptr = (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
+        for (unsigned v = threadIdx.x * 16u; v < need + lead; v += BLOCK * 16u) {
+            const uint64_t g0 = a_lo + v;
+            if (aligned_ptr && g0 + 16 <= n_text) {
+                const uint4 x = *reinterpret_cast<const uint4*>(text + g0);
+                const unsigned wds[4] = {x.x, x.y, x.z, x.w};
+                uint16_t cd[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) cd[b] = ctab[(wds[b >> 2] >> ((b & 3) * 8)) & 255u];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int i = (int)v + b - (int)lead;
+                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = cd[b];
+                }
+            } else {
+#pragma unroll 1
+                for (int b = 0; b < 16; ++b) {
+                    const int i = (int)v + b - (int)lead;
+                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = (g0 + b) < n_text ? ctab[text[g0 + b]] : (uint16_t)0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned lc = ks.lc;
+    const T mask1 = (ks.c1 * lc >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (ks.c1 * lc)) - 1);
+    const uint64_t j0 = base + (uint64_t)threadIdx.x * ITEMS;
+    T o1[ITEMS];
+    if (j0 >= ks.spec) {
+        const unsigned q = (unsigned)(j0 - ks.spec - i_lo);
+        T w1 = 0;
+        for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[SW(q + t)];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            w1 = ((T)(w1 << lc) | (T)codes[SW(q + j + ks.c1 - 1)]) & mask1;
+            o1[j] = j0 + j < n ? w1 : (T)0;
+        }
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t rec = j0 + j;
+            T w1 = 0;
+            if (rec < n) {
+                const uint64_t i = record_suffix(rec, ks.spec, n);
+                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i + t < n_text) ? tab.c[text[i + t]] : 0);
+            }
+            o1[j] = w1;
+        }
+    }
+    __syncthreads();                        // every thread has read its codes: the stage takes the words now
+    {
+        T* const pre = sh.stage + (threadIdx.x / WAVE) * (WAVE * ITEMS);
+        const unsigned lane = lane_id();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const unsigned e = lane * ITEMS + j; pre[e ^ ((e >> 3) & 7u)] = o1[j]; }
+        xrun_order();
+    }
+#undef SW
+    const uint64_t remain = n - base;
+    if (remain >= (uint64_t)TILE)
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, false, true, 10>(sh, tile, (unsigned)TILE, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
+                                                                                   digit_base, nullptr, nullptr, nullptr, ks.spec, n, tile_excl, slab_excl, nullptr,
+                                                                                   slab_tiles, (uint64_t)0, lo1);
+    else
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, false, true, 10>(sh, tile, (unsigned)remain, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
+                                                                                    digit_base, nullptr, nullptr, nullptr, ks.spec, n, tile_excl, slab_excl, nullptr,
+                                                                                    slab_tiles, (uint64_t)0, lo1);
+}
+
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
 template <typename T>
 __device__ __forceinline__ unsigned window_lcp(T x1, T x2, T y1, T y2, const KeyShape& ks) {

@@ -790,6 +790,11 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
     same_as_oracle(ctx, five, bits=64)
     monkeypatch.delenv("PSACX_FORCE_DIET")
+    # word 1 written by key_pairs_kernel and read back by the pass on the top digit (the default computes it inside that pass)
+    monkeypatch.setenv("PSACX_NO_FUSED_KEYS", "1")
+    same_as_oracle(ctx, five, bits=64)
+    same_as_oracle(ctx, inputs.dna((1 << 21) + 100, 17), bits=64, k=12)
+    monkeypatch.delenv("PSACX_NO_FUSED_KEYS")
     monkeypatch.setenv("PSACX_NO_ONE_WORD", "1")
     same_as_oracle(ctx, five, bits=64)
 
