@@ -848,9 +848,15 @@ constexpr int PSACX_RETRY_1W = 1001;
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
                           uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1, const uint8_t* text = nullptr, uint64_t n_text = 0,
                           const CodeTable* tab = nullptr, const KeyShape* ks = nullptr) {
-    constexpr int BLOCK = 512, ITEMS = 8, TILE = BLOCK * ITEMS;
+    constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // pass 0 (the tile key_pairs_kernel / key_scatter1w_kernel use)
+#ifndef PSACX_1W_ITEMS
+#define PSACX_1W_ITEMS 8
+#endif
+    // (bucket passes with other tiles, measured at 2^32 records: 512 x 6 -- 62 VGPRs, four workgroups per CU -- 106 ms for the five
+    //  passes against 89 ms; 512 x 12 -- two workgroups per CU -- 89 ms: the run length gained is the occupancy lost)
+    constexpr int ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;        // bucket passes
     const unsigned low = lead - RADIX_BITS;            // prefix bits that stay in the word
-    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t ntiles = (n + TILE0 - 1) / TILE0;
     char* const scratch = sc.d_desc;
     // pass 0: offsets from the histograms key_pairs_kernel left, top digit
     const unsigned slab0 = slab_tiles_for(ntiles);
@@ -933,7 +939,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         const int shift = 32 + j * RADIX_BITS;
         {
             ProfScope ps(c, TC_SORT_TILEHIST);
-            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
+            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS_B>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
             hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3((unsigned)total_slabs), dim3(RADIX), 0, c->stream, tile_hist, tb, (unsigned)TILE, slab_tot);
             hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, tb, base2);
             PSACX_HIP(c, hipGetLastError());
@@ -941,11 +947,11 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         ProfScope ps(c, TC_SORT_SCATTER2);
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
         if (!last)
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), 0u);
         else {
             // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), lo1 | (low << 8));
         }
         PSACX_HIP(c, hipGetLastError());

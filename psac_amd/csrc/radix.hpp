@@ -737,7 +737,7 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan1w_kernel(unsigned long l
 
 // one workgroup per (bucket, tile), handed out in order through the per-XCD queues
 template <int BLOCK, int ITEMS, int VN>
-__global__ __launch_bounds__(BLOCK, 6) void radix_scatter1w_kernel(
+__global__ __launch_bounds__(BLOCK, ITEMS <= 6 ? 8 : ITEMS <= 8 ? 6 : 4) void radix_scatter1w_kernel(
     const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift, OneWordTabs tb,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack) {
