@@ -47,8 +47,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # ... the prefix sort in one-word records (form 3), profiles/r04v_pmc_*.txt: top-digit pass (2 x 17320582.1 + 36377016.7) KiB, bucket passes
 #     (2 x 17323107.6 + 34451517.1) KiB x 3, widening pass (2 x 17328677.1 + 76887497.3) KiB; mean over the five = 79842555904 bytes
 #     (1.056 x the algorithmic 17.6 bytes per record and pass)
+# ... with the fused front end (the pass on the top digit no longer counted here), profiles/r04y_pmc_*.txt: bucket passes
+#     (2 x 17324186.8 + 34509922.4) KiB x 3, widening pass (2 x 17330780.3 + 78369040.8) KiB; mean over the four = 82049404928 bytes
+#     (1.061 x the algorithmic 18 bytes per record and pass)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 79842555904}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 82049404928}
 
 
 def parse():
@@ -129,7 +132,7 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
         # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the pass on the top digit (radix_scatter3_kernel<..., 7>:
         # word 1 in, one word out), the passes inside the buckets (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the
         # last one (radix_scatter1w_kernel<..., 9>: one word in, word 1 + suffix out); the figures below are their mean
-        kname = "radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records; mean over the top-digit pass, the bucket passes and the widening pass)"
+        kname = "radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records: the three passes inside the buckets, 8 + 8 bytes per record, and the widening pass, 8 + 16; the pass on the top digit computes its keys from the text and is timed with them)"
         tkey = 3
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",

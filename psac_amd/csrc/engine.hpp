@@ -903,7 +903,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + tabs_bytes;
     if (need > sc.desc_bytes || vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
     if (text) {
-        ProfScope ps(c, TC_SORT_SCATTER2);
+        ProfScope ps(c, TC_KMER);           // (key generation and the partition by the top digit in one kernel: timed with the keys)
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
         hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, a, (int)(lo1 + low),
                            base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1);
@@ -917,7 +917,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
                            reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1);
         PSACX_HIP(c, hipGetLastError());
     }
-    c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += (text ? 9ull : 16ull) * n;      // (fused: a character in, a word out)
+    if (!text) { c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n; }
     // the buckets (the tables of pass 0 in the scratch are dead once its scatter has run: same stream)
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes);

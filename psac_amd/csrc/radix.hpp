@@ -672,6 +672,20 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t
     // a bucket starts anywhere: 16-byte loads at even global indices; the first pair of a tile that starts at an odd index
     // holds a record of the tile before (left out), the last record of such a tile is picked up by itself
     const uint64_t a0 = g0 & ~1ull;
+    if (a0 + TILE <= si.end) {
+        // every pair lies inside the bucket: all loads of a thread issued together
+        uint4 q[ITEMS / PER];
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(in + a0) + threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < ITEMS / PER; ++v) q[v] = src[v * BLOCK];
+#pragma unroll
+        for (int v = 0; v < ITEMS / PER; ++v) {
+            const uint64_t e0 = a0 + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
+            const uint64_t x0 = ((uint64_t)q[v].y << 32) | q[v].x, x1 = ((uint64_t)q[v].w << 32) | q[v].z;
+            wave_hist_add(my, (unsigned)(x0 >> shift) & (RADIX - 1), e0 >= g0);
+            wave_hist_add(my, (unsigned)(x1 >> shift) & (RADIX - 1), e0 + 1 < g1);
+        }
+    } else
 #pragma unroll
     for (int v = 0; v < ITEMS / PER; ++v) {
         const uint64_t e0 = a0 + ((uint64_t)v * BLOCK + threadIdx.x) * PER;
