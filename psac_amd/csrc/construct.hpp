@@ -148,7 +148,7 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
                 uint64_t* active, uint64_t* unf_buckets, uint64_t capacity, unsigned shift = 0,
-                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0) {
+                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0, bool fill_lazy_ids = false) {
     // pos_off: SA position of ids[0] when pos_in is null (a slab of the reduced-memory layout)
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -163,6 +163,13 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     *active = h_cnt[0];
     *unf_buckets = h_cnt[1];
+    if (fill_lazy_ids && *active > 0) {
+        // (rebucket_first_kernel left the ids of the tiles without unresolved suffixes unwritten: somebody is going to read them now)
+        ProfScope ps(c, TC_COMPACT);
+        hipLaunchKernelGGL((fill_resolved_ids_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream,
+                           const_cast<T*>(ids), cnt, (const uint64_t*)w.d_nact, (const uint64_t*)w.d_totals);
+        PSACX_HIP(c, hipGetLastError());
+    }
     if (*active > 0 && *active <= capacity) {
         ProfScope ps(c, TC_COMPACT);
         if (payload)
@@ -373,16 +380,16 @@ int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n, co
 template <typename T, bool WITH_LCP>
 inline void launch_rebucket_first_fused(psacx_ctx* c, unsigned ntiles, const T* s1, const T* s2, const T* sa, uint64_t n, KeyShape ks,
                                         T* bsa, T* lcp, uint64_t* carry, uint64_t* nact, uint64_t* nunf, T* pyr1,
-                                        uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors) {
+                                        uint32_t* pk, uint32_t* pv, unsigned shift, unsigned* cursors, int lazy_ids = 0) {
     // pv == nullptr: packed pairs (64-bit words: one array of (position | rank << 32) entries at pk)
     if (pv)
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB>), dim3(ntiles),
                            dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
-                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
+                           (unsigned*)nullptr, 0, pk, pv, shift, cursors, (T*)nullptr, lazy_ids);
     else
         hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB, true>), dim3(ntiles),
                            dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, s2, sa, n, ks, bsa, lcp, carry, nact, nunf, n, Boundary<T>(), pyr1,
-                           (unsigned*)nullptr, 0, pk, pv, shift, cursors);
+                           (unsigned*)nullptr, 0, pk, pv, shift, cursors, (T*)nullptr, lazy_ids);
 }
 
 // d_slen != nullptr: generalized suffix array of a string set (construct_ss, suffix_array.hpp:267-363);
@@ -667,6 +674,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     bool isa_hist_ready = false;
     const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n, kn) > 0 && !kn.no_fused_l1;
+    bool lazy_ids = false;          // the rebucket kernel left out the ids of tiles without unresolved suffixes (filled in by run_compact if needed)
     // 32-bit words, normal layout: the same fusion; the pairs use two payload scratch arrays of the sort, the second level
     // the two position lists (all idle between the sort and the first compaction)
     const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0 && !kn.no_fused_l1 && !kn.isa_partition;
@@ -695,9 +703,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
             uint32_t* const pk = reinterpret_cast<uint32_t*>(w.x.v);
+            lazy_ids = n >= (1ull << 22) && !kn.no_lazy_ids;
             launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
                                                      w.d_nunf, pyr1, pk, kn.isa_two_arrays ? pk + n : (uint32_t*)nullptr,
-                                                     isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors);
+                                                     isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors, lazy_ids ? 1 : 0);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP>), dim3((unsigned)ntiles),
@@ -729,7 +738,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- which suffixes still share a bucket (suffix_array.hpp:925-965)
     uint64_t active = 0, unf_b = 0;
-    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active));
+    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active, 0, nullptr, nullptr, nullptr, 0, lazy_ids));
     r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;
     st.n_rounds = 1;
     // The list of unresolved SA positions exists only while it fits the workspace.  In the reduced-memory layout a

@@ -133,6 +133,7 @@ struct Knobs {
     bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
     bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
+    bool no_lazy_ids;       // PSACX_NO_LAZY_IDS: rebucket_first_kernel writes the bucket ids of every tile, resolved or not
     bool no_fused_keys;     // PSACX_NO_FUSED_KEYS: one-word prefix sort with word 1 written by key_pairs_kernel and read back by the pass on the top digit
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
     unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
@@ -155,6 +156,7 @@ inline Knobs read_knobs() {
     k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
     k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
     k.no_fused_keys = getenv("PSACX_NO_FUSED_KEYS") != nullptr;
+    k.no_lazy_ids = getenv("PSACX_NO_LAZY_IDS") != nullptr;
     k.one_word_min = getenv("PSACX_ONE_WORD_MIN") ? (unsigned)std::max(16, atoi(getenv("PSACX_ONE_WORD_MIN"))) : 24u;
     e = getenv("PSACX_LEAD_SLACK");
     k.lead_slack = e ? (unsigned)atoi(e) : 2u;

@@ -594,7 +594,9 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
     T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0,
     uint32_t* __restrict__ part_key = nullptr, uint32_t* __restrict__ part_val = nullptr, unsigned part_shift = 0,
-    unsigned* __restrict__ part_cursors = nullptr, T* __restrict__ sa_out = nullptr) {
+    unsigned* __restrict__ part_cursors = nullptr, T* __restrict__ sa_out = nullptr, int lazy_ids = 0) {
+    // lazy_ids: a tile without a single unresolved suffix does not write its bucket ids (they are e + 1 and nobody reads them
+    // unless some OTHER tile has unresolved suffixes: the caller then fills them in, fill_resolved_ids_kernel)
     // sa_out (optional): the suffixes are written there as well (the multi-GPU engine's records end in scratch arrays; the
     // copy into the rank's SA block rides along instead of reading them again)
     // sa_hist (optional): per-tile histogram of the digit of SA at sa_hist_shift, for the first level of the
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     for (int j = 0; j < ITEMS; ++j) {
         if (id[j] == 0) id[j] = carry; else carry = id[j];
     }
-    store_run_x<T, ITEMS>(Bsa, e0, n, id, xw);
+    if (!(lazy_ids && tact == 0)) store_run_x<T, ITEMS>(Bsa, e0, n, id, xw);
     if (WITH_LCP) store_run_x<T, ITEMS>(LCP, e0, n, lc, xw);
     if (sa_out) store_run_x<T, ITEMS>(sa_out, e0, n, sa, xw);
     if (sa_hist) {
@@ -1021,6 +1023,22 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_packed_kernel(const uint
 // pos_in == nullptr means list entry j sits at SA position j.  offset[tile] is the
 // exclusive scan of the per-tile active counts the rebucket kernels produced.
 // EMIT: also writes ids[e] and payload[e] of every active entry to out_id / out_payload (list order).
+// Bucket ids of the tiles rebucket_first_kernel left out (lazy_ids): a tile without unresolved suffixes holds singleton buckets only,
+// id = position + 1.  offset[]: exclusive scan of the per-tile counts of unresolved suffixes, *total: their sum.
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void fill_resolved_ids_kernel(T* __restrict__ ids, uint64_t n, const uint64_t* __restrict__ offset, const uint64_t* __restrict__ total) {
+    constexpr int TILE = BLOCK * ITEMS;
+    const unsigned tile = blockIdx.x;
+    const uint64_t cnt = (tile + 1 < gridDim.x ? offset[tile + 1] : *total) - offset[tile];
+    if (cnt != 0) return;
+    const uint64_t base = (uint64_t)tile * TILE;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint64_t e = base + (uint64_t)i * BLOCK + threadIdx.x;
+        if (e < n) ids[e] = (T)(e + 1);
+    }
+}
+
 template <typename T, int BLOCK, int ITEMS, bool EMIT = false>
 __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
