@@ -867,7 +867,22 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     unsigned long long* slab_tot0 = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     unsigned long long* base0 = sc.d_base;
     if (text) {
+        // a text that repeats itself massively (every sampled prefix seen before) keeps the two-array passes: see prefix_dup_probe_kernel
         ProfScope ps(c, TC_KMER);
+        const uint64_t stride = std::max<uint64_t>(64, n >> 20), samples = n / stride;
+        uint64_t slots = 1; while (slots < 4 * samples) slots <<= 1;
+        unsigned long long* table = reinterpret_cast<unsigned long long*>(scratch + 256);
+        unsigned long long* d_dups = reinterpret_cast<unsigned long long*>(scratch + 128);
+        if (256 + slots * 8 <= sc.desc_bytes && samples >= 1024 && !getenv("PSACX_ONE_WORD_ALWAYS")) {      // (the switch: tests of the tie paths)
+            PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256 + slots * 8, c->stream));
+            hipLaunchKernelGGL((prefix_dup_probe_kernel<uint64_t>), dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, c->stream, text, n_text, *tab, *ks, lo1,
+                               stride, samples, table, slots, d_dups);
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_HIP(c, hipMemcpyAsync(sc.h_base, d_dups, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            if (getenv("PSACX_SORT_DEBUG")) fprintf(stderr, "[psacx 1w] %llu of %llu sampled prefixes seen before\n", (unsigned long long)sc.h_base[0], (unsigned long long)samples);
+            if (sc.h_base[0] * 8 > samples) return PSACX_RETRY_1W;
+        }
         hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, tile_hist0);
         PSACX_HIP(c, hipGetLastError());
     }

@@ -319,6 +319,27 @@ __global__ __launch_bounds__(BLOCK) void top_digit_hist_kernel(const uint8_t* __
     for (int d = threadIdx.x; d < RADIX; d += BLOCK) tile_hist[(uint64_t)blockIdx.x * RADIX + d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
+// prefix_dup_probe_kernel: does the text repeat itself massively?  Every `stride`-th suffix puts the sorted prefix of its word 1
+// into an open-addressing table (zeroed, `slots` a power of two); dups counts the samples that met their own prefix there.
+// Random text: none.  A tandem repeat: nearly all.  (The one-word prefix sort drops the bits of word 1 below the prefix; when
+// most suffixes tie on the prefix they all read their windows from the text again, which costs more than it saves.)
+template <typename T>
+__global__ void prefix_dup_probe_kernel(const uint8_t* __restrict__ text, uint64_t n_text, CodeTable tab, KeyShape ks, unsigned lo1, uint64_t stride,
+                                        uint64_t samples, unsigned long long* __restrict__ table, uint64_t slots, unsigned long long* __restrict__ dups) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= samples) return;
+    const uint64_t i = s * stride;
+    T w1 = 0;
+    for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << ks.lc) | (T)((i + t < n_text) ? tab.c[text[i + t]] : 0);
+    const unsigned long long key = ((unsigned long long)w1 >> lo1) + 1ull;
+    uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
+    for (int probe = 0; probe < 16; ++probe, ++h) {
+        const unsigned long long old = atomicCAS(&table[h & (slots - 1)], 0ull, key);
+        if (old == 0ull) return;
+        if (old == key) { atomicAdd(dups, 1ull); return; }
+    }
+}
+
 // key_scatter1w_kernel: the pass on the top digit with word 1 computed on the spot (key_pairs_kernel's staging of the text window
 // and rolling pack; the words go to the wave's part of the stage in record order and radix_scatter_tile<..., VN = 10> takes them
 // from there in the order it ranks in, which keeps the pass stable: the short suffixes at the head of the input stay in front).

@@ -786,6 +786,11 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     for text, kw in cases:
         got, ref = same_as_oracle(ctx, text, bits=64, **kw)
         assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    # (texts whose sampled prefixes repeat -- the last two above -- keep the two-array passes: prefix_dup_probe_kernel; forced here)
+    monkeypatch.setenv("PSACX_ONE_WORD_ALWAYS", "1")
+    same_as_oracle(ctx, rep, bits=64)
+    same_as_oracle(ctx, np.full((1 << 21) + 3, 65, np.uint8), bits=64)
+    monkeypatch.delenv("PSACX_ONE_WORD_ALWAYS")
     monkeypatch.setenv("PSACX_FORCE_DIET", "1")
     same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
     same_as_oracle(ctx, five, bits=64)
