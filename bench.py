@@ -172,6 +172,11 @@ def main_distributed(a, rank, world, local_rank):
     as grouped ncclSend / ncclRecv over xGMI on a second stream.  torch.distributed only carries the communicator
     id to the ranks and brackets the timed region."""
     import ctypes as C
+    # RCCL prints a version banner on the C stdout of every process: while the libraries run, file descriptor 1 is the
+    # process's stderr, and it is the JSON line alone that goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import psac_amd
@@ -284,11 +289,20 @@ def main_distributed(a, rank, world, local_rank):
                 one.close()
             except Exception as e:          # never let the side measurement break the bench line
                 out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
-        print(json.dumps(out))
     for p in (d_text, d_sa, d_isa, d_lcp):
         lib.psacx_dev_free(ctx, C.c_void_p(p))
     mg.close()
     dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)           # what the libraries left in the C buffer goes to stderr too
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
