@@ -49,7 +49,7 @@ def make_text(n):
         base = (lo + rng.randint(0, sigma, size=max(1, n // 7))).astype(np.uint8)
         t = np.tile(base, 8)[:n].copy()
         if n > 10:
-            mut = rng.randint(0, n, size=max(1, n // 500))
+            mut = rng.randint(0, t.size, size=max(1, n // 500))
             t[mut] = (lo + rng.randint(0, sigma, size=mut.size)).astype(np.uint8)
         return t, "mutated repeats s=%d" % sigma
     if kind == 4:
