@@ -804,6 +804,21 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     same_as_oracle(ctx, five, bits=64)
 
 
+def test_bucket_ids_of_resolved_tiles_are_filled_in_on_demand(ctx, monkeypatch):
+    # rebucket_first_kernel (fused one-GPU form, from 2^22 characters on) does not write the bucket ids of a tile without
+    # unresolved suffixes; when some OTHER tile has unresolved suffixes, run_compact fills them in before anybody reads them
+    # (fill_resolved_ids_kernel).  Random DNA with one long repeat: two stretches of SA stay unresolved for several rounds, the
+    # rest of the tiles are resolved after the first.  Both word sizes, the per-round log included, and the eager form.
+    text = inputs.dna((1 << 22) + 1000, 23)
+    text[3000000:3050000] = text[100000:150000]
+    for bits in (64, 32):
+        got, ref = same_as_oracle(ctx, text, bits=bits)
+        assert len(ref["trace"]) > 3
+        assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    monkeypatch.setenv("PSACX_NO_LAZY_IDS", "1")
+    same_as_oracle(ctx, text, bits=64)
+
+
 @pytest.mark.parametrize("env", [{}, {"PSACX_NO_WHOLE_ROUNDS": "1"}, {"PSACX_WIDE_REFINE": "1"}, {"PSACX_NO_WHOLE_ROUNDS": "1", "PSACX_WIDE_REFINE": "1"}])
 def test_refinement_round_forms(ctx, monkeypatch, env):
     # rounds with at least 7/8 of the suffixes unresolved take all n records in text order and rebuild ISA by inverting SA
