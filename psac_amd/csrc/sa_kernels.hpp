@@ -355,6 +355,7 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
 #define SW(i) ((i) + (((i) >> 3) << 1))
     __shared__ ScatterShared<T, TILE, NW> sh;
     __shared__ uint16_t ctab[256];
+    __shared__ T grp[TILE / 8 + HALO / 8 + 1];
     static_assert(sizeof(uint16_t) * (SW(TILE + HALO) + 8) <= sizeof(sh.stage), "the codes of the tile live in the stage until the words are packed");
     uint16_t* const codes = reinterpret_cast<uint16_t*>(sh.stage);
     if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
@@ -397,7 +398,34 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
     const T mask1 = (ks.c1 * lc >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (ks.c1 * lc)) - 1);
     const uint64_t j0 = base + (uint64_t)threadIdx.x * ITEMS;
     T o1[ITEMS];
-    if (j0 >= ks.spec) {
+    // Tiles behind the short suffixes: a thread's windows start at code 8 t of the staged text, so the codes are first packed
+    // eight at a time (grp[m] = codes 8 m .. 8 m + 7, first code on top) and a thread puts its first window together from
+    // whole groups instead of reading c1 - 1 codes one by one (31 for DNA); the eight codes that roll in come from two groups.
+    const bool grouped = base >= ks.spec && 8 * lc <= 56 && ITEMS == 8;
+    if (grouped) {
+        constexpr int NG = TILE / 8 + HALO / 8 + 1;
+        for (int m = threadIdx.x; m < NG; m += BLOCK) {
+            T g = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g = (T)(g << lc) | (T)((unsigned)(8 * m + r) < need ? codes[SW(8 * m + r)] : (uint16_t)0);
+            grp[m] = g;
+        }
+        __syncthreads();
+        const unsigned t8 = threadIdx.x;                              // the thread's first window starts at code 8 * t8
+        const unsigned F = (ks.c1 - 1) / 8, R = (ks.c1 - 1) % 8;
+        T w1 = 0;
+        for (unsigned f = 0; f < F; ++f) w1 = (T)(w1 << (8 * lc)) | grp[t8 + f];
+        T ga = grp[t8 + F], gb = grp[t8 + F + 1];
+        if (R) w1 = (T)(w1 << (R * lc)) | (T)(ga >> ((8 - R) * lc));
+        const T cmask = (T)(((T)1 << lc) - 1);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned pos = R + (unsigned)j;                      // place of the code that rolls in, counted from the start of group F
+            const T code = pos < 8 ? (T)(ga >> ((7 - pos) * lc)) & cmask : (T)(gb >> ((15 - pos) * lc)) & cmask;
+            w1 = ((T)(w1 << lc) | code) & mask1;
+            o1[j] = j0 + j < n ? w1 : (T)0;
+        }
+    } else if (j0 >= ks.spec) {
         const unsigned q = (unsigned)(j0 - ks.spec - i_lo);
         T w1 = 0;
         for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[SW(q + t)];
