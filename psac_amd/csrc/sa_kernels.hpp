@@ -1194,6 +1194,20 @@ __device__ __forceinline__ T window_word1(const uint8_t* __restrict__ text, uint
     }
     return w1;
 }
+// word 1 of suffix `sa` when its bits above lo1 are known (have): only the characters that reach below bit lo1 come from the text
+template <typename T>
+__device__ __forceinline__ T window_word1_low(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
+                                              const KeyShape& ks, uint64_t sa, T have, unsigned lo1) {
+    const unsigned nlow = (lo1 + ks.lc - 1) / ks.lc < ks.c1 ? (lo1 + ks.lc - 1) / ks.lc : ks.c1;      // characters with a bit below lo1
+    const unsigned lowbits = nlow * ks.lc;
+    T w = 0;
+    for (unsigned t = ks.c1 - nlow; t < ks.c1; ++t) {
+        const uint64_t q = sa + t;
+        w = (T)(w << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
+    }
+    if (lowbits >= sizeof(T) * 8) return w;
+    return (T)(((have >> lowbits) << lowbits) | w);
+}
 template <typename T>
 __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
                                           const KeyShape& ks, uint64_t sa) {
@@ -1285,7 +1299,8 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
             if ((unsigned)i < len) {
                 k2[i] = FROM_ARRAY ? S2[e + i] : window_word2<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
                 // packed payload (radix.hpp: VN 3 .. 6): the bits of word 1 below the sorted prefix went to the payload
-                if (!FROM_ARRAY && packed) k1[i] = window_word1<T>(text, n_text, ctab, ks, (uint64_t)sa[i]);
+                // (the bits above lo1 are all there: only the characters that reach below the prefix are read)
+                if (!FROM_ARRAY && packed) k1[i] = window_word1_low<T>(text, n_text, ctab, ks, (uint64_t)sa[i], k1[i], lo1);
             } else { k1[i] = ~(T)0; k2[i] = ~(T)0; }
         }
         // adjacent exchanges of strictly descending neighbours only: stable
