@@ -257,7 +257,8 @@ int psacx_multi_get_phases(const psacx_multi* mg, char* buf, uint64_t cap);
 /* which forms the last construction took: bit 0 = first round in two-word form (records (B1, idx), ties repaired from the
  * text owners; idxsort.hpp:23-83 moves (B1, B2, idx)), bit 1 = reduced-memory layout, bit 2 = SA -> ISA slice by slice
  * through the destination-partition levels (bulk_permute.hpp:14-73), bit 3 = the suffixes of the two-word records travelled
- * packed into the unsorted low bits of B1 + one or two bytes (9 or 10 bytes per record on the wire and per sort pass) */
+ * packed into the unsorted low bits of B1 + one or two bytes (9 or 10 bytes per record on the wire and per sort pass),
+ * bit 4 = first round in one-word records dealt to the ranks by the top digit of the prefix (8 bytes per record on the wire) */
 int psacx_multi_last_form(const psacx_multi* mg);
 const char* psacx_multi_last_error(const psacx_multi* mg);
 psacx_ctx* psacx_multi_ctx(psacx_multi* mg, int local_rank);

@@ -845,19 +845,91 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 // suffixes.  The tile histograms of the top digit (shift lo1 + lead - 8) must be in the scratch (key_pairs_kernel<..., HIST>).
 // Returns PSACX_RETRY_1W without having touched k0 when the scratch has no room for the bucket tables.
 constexpr int PSACX_RETRY_1W = 1001;
+#ifndef PSACX_1W_ITEMS
+#define PSACX_1W_ITEMS 8
+#endif
+// Scratch layout of the bucket passes over one-word records.  h_tabs: bucket_off[0 .. 256] filled in (start of every bucket's records;
+// buckets without records own nothing), slab_start[0 .. 256] behind it is written here.
+struct OneWordLayout { unsigned slab; uint64_t total_slabs, vtiles; size_t hist_bytes, slab_bytes, tabs_bytes, need; };
+template <int TILE>
+inline OneWordLayout onew_layout(unsigned long long* h_tabs, uint64_t ntiles_hint) {
+    OneWordLayout lay;
+    lay.slab = ntiles_hint >= (1u << 16) ? 64u : 16u;
+    uint64_t total_slabs = 0;
+    for (int d = 0; d < RADIX; ++d) {
+        const uint64_t cnt = h_tabs[d + 1] - h_tabs[d];
+        h_tabs[RADIX + 1 + d] = total_slabs;
+        total_slabs += ((cnt + TILE - 1) / TILE + lay.slab - 1) / lay.slab;
+    }
+    h_tabs[2 * RADIX + 1] = total_slabs;
+    lay.total_slabs = total_slabs;
+    lay.vtiles = total_slabs * lay.slab;
+    lay.hist_bytes = ((size_t)lay.vtiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
+    lay.slab_bytes = ((size_t)total_slabs * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    lay.tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + 64 + total_slabs * sizeof(SlabInfo) + 255) & ~(size_t)255;
+    lay.need = 256 + lay.hist_bytes + lay.slab_bytes + (size_t)RADIX * RADIX * 8 + lay.tabs_bytes;
+    return lay;
+}
+// The LSD passes inside the buckets: one-word records (rest of the prefix << sfield | suffix) of bucket b at [bucket_off[b], bucket_off[b + 1]) of `cur`,
+// `low` prefix bits in the word.  All but the last pass ping-pong between cur and oth; the last one writes word 1 ((b << low | rest) << lo1) into the
+// array it does not read (*s1 tells which) and the suffixes as words into sa_out.  h_tabs must stay untouched until the stream has passed the copy.
+inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long long* h_tabs, const OneWordLayout& lay, uint64_t* cur, uint64_t* oth, uint64_t* sa_out,
+                              unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1) {
+    constexpr int BLOCK = 512, ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;
+    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
+    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + lay.hist_bytes);
+    unsigned long long* base2 = reinterpret_cast<unsigned long long*>(scratch + 256 + lay.hist_bytes + lay.slab_bytes);
+    unsigned long long* d_tabs = base2 + (size_t)RADIX * RADIX;
+    OneWordTabs tb;
+    tb.bucket_off = d_tabs; tb.slab_start = d_tabs + RADIX + 1; tb.slab = lay.slab;
+    SlabInfo* slab_info = reinterpret_cast<SlabInfo*>((reinterpret_cast<uintptr_t>(d_tabs + 2 * (RADIX + 1)) + 31) & ~(uintptr_t)31);
+    tb.slab_info = slab_info;
+    *s1 = cur;
+    if (lay.total_slabs == 0) return PSACX_OK;
+    const uint64_t total_slabs = lay.total_slabs, vtiles = lay.vtiles;
+    PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(radix_slab_info_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.bucket_off, tb.slab_start,
+                       (unsigned)total_slabs, (unsigned)(lay.slab * TILE), slab_info);
+    PSACX_HIP(c, hipGetLastError());
+    const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
+    for (int j = 0; j < npass; ++j) {
+        const bool last = j + 1 == npass;
+        const int shift = (int)sfield + j * RADIX_BITS;
+        {
+            ProfScope ps(c, TC_SORT_TILEHIST);
+            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS_B>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
+            hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3((unsigned)total_slabs), dim3(RADIX), 0, c->stream, tile_hist, tb, (unsigned)TILE, slab_tot);
+            hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, tb, base2);
+            PSACX_HIP(c, hipGetLastError());
+        }
+        ProfScope ps(c, TC_SORT_SCATTER2);
+        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
+        if (!last)
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
+                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), 0u);
+        else {
+            // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
+            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
+                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), lo1 | (low << 8) | (sfield << 16));
+        }
+        PSACX_HIP(c, hipGetLastError());
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * nrec;
+        std::swap(cur, oth);
+    }
+    *s1 = cur;
+    return PSACX_OK;
+}
 // text != nullptr (fused front end, sa_kernels.hpp: key_scatter1w_kernel): k0 holds nothing yet -- the histograms of the top digit come
 // from the text and pass 0 computes word 1 of its tile in registers (no key_pairs_kernel launch, 16 bytes per record less).
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
                           uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1, const uint8_t* text = nullptr, uint64_t n_text = 0,
                           const CodeTable* tab = nullptr, const KeyShape* ks = nullptr) {
     constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // pass 0 (the tile key_pairs_kernel / key_scatter1w_kernel use)
-#ifndef PSACX_1W_ITEMS
-#define PSACX_1W_ITEMS 8
-#endif
     // (bucket passes with other tiles, measured at 2^32 records: 512 x 6 -- 62 VGPRs, four workgroups per CU -- 106 ms for the five
     //  passes against 89 ms; 512 x 12 -- two workgroups per CU -- 89 ms: the run length gained is the occupancy lost)
     constexpr int ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;        // bucket passes
     const unsigned low = lead - RADIX_BITS;            // prefix bits that stay in the word
+    const unsigned sfield = 64 - low;                  // the payload field takes the rest (32 bits when lead = 40)
     const uint64_t ntiles = (n + TILE0 - 1) / TILE0;
     char* const scratch = sc.d_desc;
     // pass 0: offsets from the histograms key_pairs_kernel left, top digit
@@ -895,35 +967,19 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     PSACX_HIP(c, hipMemcpyAsync(sc.h_base, base0, RADIX * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSACX_HIP(c, hipStreamSynchronize(c->stream));
     // tables of the buckets: every bucket owns whole slabs of tiles (radix.hpp: OneWordTabs)
-    const unsigned slab = ntiles >= (1u << 16) ? 64u : 16u;
     unsigned long long* h_tabs = sc.h_base + RADIX;             // pinned: bucket_off[257], slab_start[257]
-    uint64_t maxcnt = 0, total_slabs = 0;
-    int used = 0;
-    for (int d = 0; d < RADIX; ++d) {
-        const uint64_t end = d + 1 < RADIX ? sc.h_base[d + 1] : n;
-        const uint64_t cnt = end - sc.h_base[d];
-        h_tabs[d] = sc.h_base[d];
-        h_tabs[RADIX + 1 + d] = total_slabs;
-        total_slabs += ((cnt + TILE - 1) / TILE + slab - 1) / slab;
-        maxcnt = std::max<uint64_t>(maxcnt, cnt);
-        used += cnt != 0;
-    }
+    for (int d = 0; d < RADIX; ++d) h_tabs[d] = sc.h_base[d];
     h_tabs[RADIX] = n;
-    h_tabs[2 * RADIX + 1] = total_slabs;
+    const OneWordLayout lay = onew_layout<TILE>(h_tabs, ntiles);
     if (getenv("PSACX_SORT_DEBUG"))
-        fprintf(stderr, "[psacx 1w] n=%llu lead=%u lo1=%u: %d buckets in use, largest %llu (mean %llu), %llu slabs of %u tiles for %llu tiles\n", (unsigned long long)n, lead,
-                lo1, used, (unsigned long long)maxcnt, (unsigned long long)(n / RADIX), (unsigned long long)total_slabs, slab, (unsigned long long)ntiles);
-    const uint64_t vtiles = total_slabs * slab;
-    const size_t hist_bytes = ((size_t)vtiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255;
-    const size_t slab_bytes = ((size_t)total_slabs * RADIX * sizeof(unsigned long long) + 255) & ~(size_t)255;
-    const size_t tabs_bytes = (2 * (RADIX + 1) * sizeof(unsigned long long) + 64 + total_slabs * sizeof(SlabInfo) + 255) & ~(size_t)255;
-    const size_t need = 256 + hist_bytes + slab_bytes + (size_t)RADIX * RADIX * 8 + tabs_bytes;
-    if (need > sc.desc_bytes || vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
+        fprintf(stderr, "[psacx 1w] n=%llu lead=%u lo1=%u: %llu slabs of %u tiles for %llu tiles\n", (unsigned long long)n, lead, lo1,
+                (unsigned long long)lay.total_slabs, lay.slab, (unsigned long long)ntiles);
+    if (lay.need > sc.desc_bytes || lay.vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
     if (text) {
         ProfScope ps(c, TC_KMER);           // (key generation and the partition by the top digit in one kernel: timed with the keys)
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
         hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, a, (int)(lo1 + low),
-                           base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1);
+                           base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1 | (sfield << 16), (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
     } else {
         ProfScope ps(c, TC_SORT_SCATTER2);
@@ -931,52 +987,15 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         hipLaunchKernelGGL((radix_scatter3_kernel<uint64_t, BLOCK, ITEMS, false, 6, true, 7>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream,
                            (const uint64_t*)k0, (const uint64_t*)nullptr, (const uint64_t*)nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, n,
                            (int)(lo1 + low), base0, tile_hist0, slab_tot0, (unsigned long long*)nullptr, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1);
+                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1 | (sfield << 16));
         PSACX_HIP(c, hipGetLastError());
     }
     if (!text) { c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n; }
     // the buckets (the tables of pass 0 in the scratch are dead once its scatter has run: same stream)
-    unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
-    unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes);
-    unsigned long long* base2 = reinterpret_cast<unsigned long long*>(scratch + 256 + hist_bytes + slab_bytes);
-    unsigned long long* d_tabs = base2 + (size_t)RADIX * RADIX;
-    OneWordTabs tb;
-    tb.bucket_off = d_tabs; tb.slab_start = d_tabs + RADIX + 1; tb.slab = slab;
-    SlabInfo* slab_info = reinterpret_cast<SlabInfo*>((reinterpret_cast<uintptr_t>(d_tabs + 2 * (RADIX + 1)) + 31) & ~(uintptr_t)31);
-    tb.slab_info = slab_info;
-    PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(radix_slab_info_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.bucket_off, tb.slab_start,
-                       (unsigned)total_slabs, (unsigned)(slab * TILE), slab_info);
-    PSACX_HIP(c, hipGetLastError());
-    const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
-    uint64_t* cur = a;
-    uint64_t* oth = k0;
-    for (int j = 0; j < npass; ++j) {
-        const bool last = j + 1 == npass;
-        const int shift = 32 + j * RADIX_BITS;
-        {
-            ProfScope ps(c, TC_SORT_TILEHIST);
-            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS_B>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
-            hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3((unsigned)total_slabs), dim3(RADIX), 0, c->stream, tile_hist, tb, (unsigned)TILE, slab_tot);
-            hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, tb, base2);
-            PSACX_HIP(c, hipGetLastError());
-        }
-        ProfScope ps(c, TC_SORT_SCATTER2);
-        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        if (!last)
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
-                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), 0u);
-        else {
-            // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
-            hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
-                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), lo1 | (low << 8));
-        }
-        PSACX_HIP(c, hipGetLastError());
-        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * n;
-        std::swap(cur, oth);
-    }
+    uint64_t* cur = nullptr;
+    PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur));
     *s1 = cur;          // (k0 after an odd number of bucket passes, `a` after an even number)
-    if (rs) { rs->sort_passes = (uint32_t)(npass + 1); rs->sort_passes_skipped = 0; }
+    if (rs) { rs->sort_passes = (uint32_t)((low + RADIX_BITS - 1) / RADIX_BITS + 1); rs->sort_passes_skipped = 0; }
     return PSACX_OK;
 }
 

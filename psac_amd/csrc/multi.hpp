@@ -163,6 +163,7 @@ struct psacx_multi {
     bool last_reduced = false;        // layout the last construction ran in
     bool last_two_word = false;       // the first round ran in two-word form (sort_first_two_word)
     bool last_packed = false;         // ... with the suffixes packed into the low bits of word 1 + one or two bytes
+    bool last_one_word = false;       // the first round ran in one-word records dealt by top digit (sort_first_one_word)
     bool last_slice_inversion = false;   // SA -> ISA ran slice by slice through the partition levels + window scatter
     uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
 };
@@ -1654,8 +1655,6 @@ struct MultiRun {
             }
         }
         // prefix sort of (word 1, suffix) on the leading bits, then the ties
-        std::vector<uint64_t> ties(L, 0);
-        bool general_ties = !solo_;
         bool solo_packed = false;        // one rank: the sort ran packed, word 1 of a tied record is read from the text again
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
@@ -1672,6 +1671,22 @@ struct MultiRun {
                 if (where) swap3(rec[i], alt);
                 drop3(i, alt);
             }
+            return PSACX_OK;
+        }));
+        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, solo_packed);
+    }
+
+    // Stage 2 of a first round that sorted (word 1, suffix) on the leading bits of word 1 only (rec[i]: k1, v sorted; word 1 may have lost the
+    // bits below the prefix: word1_gone): the suffixes that still tie are ordered by their full windows -- one rank with the text at hand: in
+    // place (tie_resolve_kernel); else compacted, their windows fetched from the ranks that own the text (dist_windows), ordered and written
+    // back -- and the records re-balanced to the block sizes.
+    int first_sort_ties(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1,
+                        const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool word1_gone) {
+        std::vector<uint64_t> ties(L, 0);
+        bool general_ties = !solo_;
+        const bool solo_packed = word1_gone;
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
             PSACX_TRY(need_k2(i, rec[i]));
             if (solo_ && rec[i].cnt) {
                 // one rank: the text is here, every tie group of at most 8 suffixes is ordered in place (tie_resolve_kernel, construct.hpp)
@@ -1737,6 +1752,299 @@ struct MultiRun {
         }));
         mark("    sort: ties");
         return rebalance(rec, targets);
+    }
+
+    // The first sort in ONE-word records (the one-GPU engine's prefix_sort_1w, engine.hpp, spread over the ranks).  A record is
+    // (prefix of word 1 without its top digit) << sfield | suffix; the top digit is known from the record's place:
+    //   1. every rank counts the top digits of its block straight from the text (top_digit_hist_kernel); one all-gather of the 256 counts
+    //      gives every rank the exact size of every bucket on every rank -- no samples, no splitters;
+    //   2. the 256 buckets are dealt to the ranks in order, whole, so that every rank's share is as close to its block as whole buckets
+    //      allow (equal prefixes never part; the text's own distribution decides the balance: a text whose buckets cannot be dealt
+    //      within the slack of the record arrays takes the two-word path with its sampled splitters);
+    //   3. the pass on the top digit computes word 1 in registers and writes the one-word records bucket by bucket
+    //      (key_scatter1w_kernel): 1 byte read + 8 written per record, nothing else is ever written on the sender;
+    //   4. the buckets travel in QR groups per destination, each bucket's pieces from all senders landing back to back; a group is
+    //      complete when it has landed and its LSD passes (8 + 8 bytes per record and pass, radix_scatter1w_kernel) run on the compute
+    //      stream while the later groups are still in flight; the last pass writes word 1 and the suffixes as words.
+    // The suffixes shorter than 2k (the last 2k - 1 positions of the text) are made on the host -- every rank knows the tail of the text
+    // from the gather -- and placed at the head of their buckets, where the stable passes keep them in front of equal prefixes.
+    // Needs 64-bit words and n <= 2^34 (the payload field takes bits_for(n - 1) bits, the prefix the rest + 8: fewer than 1/16 of the suffixes
+    // of a random text tie).  Returns PSACX_RETRY_ before anything has moved.  *lo1_out: bits of word 1 below the sorted prefix.
+    int sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2,
+                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec,
+                            unsigned* lo1_out) {
+        if constexpr (sizeof(T) != 8) { return PSACX_RETRY_; }
+        else {
+        constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS, TILE = BLOCK * PSACX_1W_ITEMS;
+        constexpr int TAILB = 128;                                   // bytes of every block's end that travel with the counts (2k <= 128)
+        const unsigned nbits = bits_for(n - 1);
+        if (bits1 < 24 || nbits > 40) return PSACX_RETRY_;
+        // prefix bits that stay in the word: what the one-GPU rule asks for (bits_for(n - 1) + 3 leading bits, whole digits) as far as the word has room
+        const unsigned want_lead = (nbits + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
+        const unsigned low = std::min(std::min(64u - nbits, bits1 - (unsigned)RADIX_BITS), want_lead - (unsigned)RADIX_BITS);
+        const unsigned lead = low + RADIX_BITS, sfield = 64 - low, lo1 = bits1 - lead;
+        if (lead < nbits + 3 && !trust) return PSACX_RETRY_;        // (too many suffixes would tie on the prefix)
+        if (lead < nbits + 1) return PSACX_RETRY_;
+        uint64_t min_m = sizes[0];
+        for (int r = 1; r < P; ++r) min_m = std::min(min_m, sizes[r]);
+        if (min_m < (uint64_t)TAILB || min_m < 2ull * two_k) return PSACX_RETRY_;
+        ++sort_calls_;
+        KeyShape ks0 = ks; ks0.spec = solo_ ? spec : 0;               // (one rank without the wire: the short suffixes are records of the kernel, as on one GPU)
+        // ---- 1. top digits of every block
+        std::vector<uint64_t> nrec(L), short_n(L);
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(RADIX + 2 + TAILB / 8, 0));
+        struct Scr { unsigned long long* base0; char* desc; unsigned* tile_hist0; unsigned long long* slab_tot0; uint64_t ntiles; unsigned slab0; size_t desc_bytes; };
+        std::vector<Scr> scr(L);
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            const uint64_t m = S[i].m, end = S[i].off + m, first_short = n - spec;
+            short_n[i] = solo_ ? 0 : std::min<uint64_t>(m, end > first_short ? end - first_short : 0);
+            nrec[i] = m - short_n[i];
+            Scr& q = scr[i];
+            q.ntiles = (nrec[i] + TILE0 - 1) / TILE0;
+            q.slab0 = slab_tiles_for(q.ntiles);
+            // the scratch of the bucket passes on the receiving side lives in the same slab: sized now for the largest share a rank may accept
+            const uint64_t cap_rec = m + m / 8 + 256 + (uint64_t)TILE;
+            const uint64_t vt_ub = (cap_rec + TILE - 1) / TILE + (uint64_t)RADIX * 64 + 64;
+            const size_t need_b = 256 + (((size_t)vt_ub * RADIX * sizeof(unsigned) + 255) & ~(size_t)255) + (((size_t)(vt_ub / 16 + RADIX) * RADIX * 8 + 255) & ~(size_t)255) +
+                                  (size_t)RADIX * RADIX * 8 + 2 * (RADIX + 1) * 8 + 64 + (size_t)(vt_ub / 16 + RADIX) * sizeof(SlabInfo) + 4096;
+            const uint64_t stride = std::max<uint64_t>(64, m >> 20), samples = m / stride;
+            uint64_t slots = 1; while (slots < 4 * samples) slots <<= 1;
+            const size_t need_a = 256 + std::max<size_t>((((size_t)q.ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255) + (q.ntiles / q.slab0 + 2) * RADIX * 8, slots * 8) + 4096;
+            q.desc_bytes = std::max(need_a, need_b);
+            MG_OP(g, c, ensure_slab(c, q.desc_bytes + (size_t)RADIX * 8 + 8192));
+            MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
+            Arena ar(c->slab);
+            q.base0 = ar.take<unsigned long long>((size_t)RADIX);
+            q.desc = ar.take<char>(q.desc_bytes);
+            q.tile_hist0 = reinterpret_cast<unsigned*>(q.desc + 256);
+            q.slab_tot0 = reinterpret_cast<unsigned long long*>(q.desc + 256 + (((size_t)q.ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
+            MG_HIP(g, hipSetDevice(c->device));
+            unsigned long long* h = reinterpret_cast<unsigned long long*>(c->pinned + 32768);
+            h[RADIX] = 0; h[RADIX + 1] = 0;
+            if (samples >= 1024 && !trust) {
+                // does the block repeat itself massively?  (prefix_dup_probe_kernel, sa_kernels.hpp: such a text keeps the two-word path)
+                unsigned long long* table = reinterpret_cast<unsigned long long*>(q.desc + 256);
+                unsigned long long* d_dups = reinterpret_cast<unsigned long long*>(q.desc + 128);
+                MG_HIP(g, hipMemsetAsync(q.desc, 0, 256 + slots * 8, c->stream));
+                hipLaunchKernelGGL((prefix_dup_probe_kernel<uint64_t>), dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t*)tbuf[i].p, m + two_k, tab, ks0, lo1,
+                                   stride, samples, table, slots, d_dups);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipMemcpyAsync(h + RADIX, d_dups, 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                h[RADIX + 1] = samples;
+            }
+            if (q.ntiles) {
+                hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)q.ntiles), dim3(BLOCK), 0, c->stream, (const uint8_t*)tbuf[i].p, solo_ ? m : nrec[i],
+                                   m + two_k, tab, ks0, q.tile_hist0);
+                const uint64_t nslabs0 = (q.ntiles + q.slab0 - 1) / q.slab0;
+                hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs0), dim3(RADIX), 0, c->stream, q.tile_hist0, q.ntiles, q.slab_tot0, q.slab0);
+                hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, q.slab_tot0, nslabs0, q.base0);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipMemcpyAsync(h, q.base0, RADIX * 8, hipMemcpyDeviceToHost, c->stream));
+            } else std::memset(h, 0, RADIX * 8);
+            MG_HIP(g, hipMemcpyAsync(h + RADIX + 2, tbuf[i].p + m - TAILB, TAILB, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            const uint64_t total = solo_ ? m : nrec[i];
+            for (int d = 0; d < RADIX; ++d) mine[i][d] = (d + 1 < RADIX ? h[d + 1] : total) - h[d];       // bucket sizes (the starts are their prefix sums)
+            for (int w = RADIX; w < RADIX + 2 + TAILB / 8; ++w) mine[i][w] = h[w];
+            return PSACX_OK;
+        }));
+        std::vector<uint64_t> table;                                 // table[r * W + b]
+        const int W = RADIX + 2 + TAILB / 8;
+        PSACX_TRY(gather(W, mine, table));
+        // ---- 2. the short suffixes (host), the buckets' sizes, their owners
+        {
+            uint64_t dups = 0, smp = 0;
+            for (int r = 0; r < P; ++r) { dups += table[(size_t)r * W + RADIX]; smp += table[(size_t)r * W + RADIX + 1]; }
+            if (!trust && smp && dups * 8 > smp) return PSACX_RETRY_;
+        }
+        std::vector<std::vector<uint64_t>> short_words(RADIX);
+        if (!solo_ && spec) {
+            const uint8_t* tail = reinterpret_cast<const uint8_t*>(&table[(size_t)(P - 1) * W + RADIX + 2]);       // text[n - TAILB .. n)
+            for (uint64_t j = 0; j < spec; ++j) {                    // suffix n - 1 - j, j + 1 characters long: shortest first
+                const uint64_t pos = n - 1 - j;
+                uint64_t w1 = 0;
+                for (unsigned t = 0; t < ks.c1; ++t) {
+                    const uint64_t code = pos + t < n ? (uint64_t)tab.c[tail[(size_t)TAILB - 1 - j + t]] : 0ull;
+                    w1 = (ks.lc >= 64 ? 0ull : (w1 << ks.lc)) | code;
+                }
+                const uint64_t prefix = lo1 >= 64 ? 0ull : (w1 >> lo1);
+                short_words[(size_t)((prefix >> low) & (RADIX - 1))].push_back((prefix << sfield) | pos);
+            }
+        }
+        std::vector<uint64_t> tot(RADIX, 0), PT(RADIX + 1, 0);
+        for (int b = 0; b < RADIX; ++b) {
+            tot[b] = short_words[b].size();
+            for (int r = 0; r < P; ++r) tot[b] += table[(size_t)r * W + b];
+            PT[b + 1] = PT[b] + tot[b];
+        }
+        if (PT[RADIX] != n) { mg_set_err(g, "one-word first sort: the top-digit counts do not add up to the text"); return PSACX_EDEVICE; }
+        const std::vector<uint64_t> TP = prefix_of(targets);
+        std::vector<int> cut(P + 1, 0);                              // rank d owns the buckets cut[d] .. cut[d + 1] - 1
+        cut[P] = RADIX;
+        for (int d = 1; d < P; ++d) {
+            int b = cut[d - 1];
+            while (b < RADIX && PT[b + 1] <= TP[d]) ++b;             // PT[b] <= TP[d] < PT[b + 1]
+            if (b < RADIX && TP[d] - PT[b] > PT[b + 1] - TP[d]) ++b; // the nearer bucket boundary
+            cut[d] = std::max(b, cut[d - 1]);
+        }
+        for (int d = 0; d < P; ++d) {
+            const uint64_t share = PT[cut[d + 1]] - PT[cut[d]];
+            if (!trust && share > sizes[d] + sizes[d] / 8) return PSACX_RETRY_;        // (the slack of the reduced-memory layout's record arrays)
+        }
+        *lo1_out = lo1;
+        // ---- 3. arrays: the partitioned block (grp), two record arrays of the rank's share (A, B) and the suffixes of the last pass (vout).
+        //      Reduced-memory layout: grp, the array that does not end up with word 1 and the suffixes are the rank's three output arrays.
+        const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
+        std::vector<DBuf<T>> grp(L), A(L), B(L), vout(L);
+        std::vector<uint64_t> share(L);
+        int rc_alloc = PSACX_OK;
+        for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
+            psacx_ctx* c = ctx(i);
+            const int me = rank(i);
+            drop3(i, rec[i]);
+            share[i] = PT[cut[me + 1]] - PT[cut[me]];
+            const uint64_t ng = solo_ ? S[i].m : nrec[i];
+            const bool lend = diet && !S[i].out_busy && std::max(share[i], ng) <= S[i].out_cap;
+            DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];          // the array the last pass writes word 1 into
+            DBuf<T>& other = (npass & 1) ? A[i] : B[i];
+            if (lend) {
+                S[i].out_busy = true;
+                other.borrow(c, S[i].ISA, share[i]);
+                vout[i].borrow(c, S[i].SA, share[i]);
+                if (S[i].LCP && !solo_) grp[i].borrow(c, S[i].LCP, ng);
+            } else {
+                rc_alloc = other.alloc(c, share[i], reserve_of(i));
+                if (rc_alloc == PSACX_OK) rc_alloc = vout[i].alloc(c, share[i], reserve_of(i));
+            }
+            if (rc_alloc == PSACX_OK) rc_alloc = k1_final.alloc(c, share[i], reserve_of(i));
+            if (rc_alloc == PSACX_OK && !solo_ && !grp[i].p) rc_alloc = grp[i].alloc(c, ng, reserve_of(i));
+            if (rc_alloc != PSACX_OK) mg_set_err(g, "one-word first sort: record arrays: " + c->hip_err);
+        }
+        PSACX_TRY(agree(rc_alloc));
+        // ---- 4. the pass on the top digit, word 1 computed on the spot (one rank without the wire: straight into A)
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            Scr& q = scr[i];
+            if (!q.ntiles) return PSACX_OK;
+            MG_HIP(g, hipSetDevice(c->device));
+            MG_HIP(g, hipMemsetAsync(q.desc, 0, 256, c->stream));
+            const uint64_t cnt = solo_ ? S[i].m : nrec[i];
+            hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)q.ntiles), dim3(BLOCK), 0, c->stream, (const uint8_t*)tbuf[i].p, cnt, S[i].m + two_k, tab, ks0,
+                               reinterpret_cast<uint64_t*>(solo_ ? A[i].p : grp[i].p), (int)(lo1 + low), q.base0, q.tile_hist0, q.slab_tot0, reinterpret_cast<unsigned*>(q.desc),
+                               sort_chunk_for(cnt, true), q.slab0, lo1 | (sfield << 16), solo_ ? (uint64_t)0 : S[i].off);
+            MG_HIP(g, hipGetLastError());
+            return PSACX_OK;
+        }));
+        mark("    sort: keys + partition by the top digit");
+        // ---- 5. where everything lands: bucket b of rank `me` = [short suffixes][sender 0] .. [sender P - 1]
+        int QR = solo_ ? 1 : 4;
+        if (const char* e = getenv("PSACX_MULTI_PIECES")) QR = std::max(1, std::min(16, atoi(e)));
+        std::vector<std::vector<uint64_t>> boff(L, std::vector<uint64_t>(RADIX + 1, 0));       // start of bucket b in the rank's arrays
+        std::vector<std::vector<uint64_t>> sstart(L, std::vector<uint64_t>(RADIX + 1, 0));     // start of bucket b in the sender's partitioned block
+        for (int i = 0; i < L; ++i) {
+            const int me = rank(i);
+            uint64_t at = 0;
+            for (int b = 0; b <= RADIX; ++b) { boff[i][b] = at; if (b < RADIX && b >= cut[me] && b < cut[me + 1]) at += tot[b]; }
+            for (int b = 0; b < RADIX; ++b) sstart[i][b + 1] = sstart[i][b] + mine[i][b];
+        }
+        // the buckets of a destination in QR ranges of about equal size (the same cuts on every rank: a sender must know the ranges of its destinations)
+        auto range_cuts = [&](int d) -> std::vector<int> {
+            const int nb = cut[d + 1] - cut[d];
+            const int qr = std::max(1, std::min(QR, nb));
+            const uint64_t sh = PT[cut[d + 1]] - PT[cut[d]];
+            std::vector<int> rc(QR + 1, cut[d + 1]);
+            rc[0] = cut[d];
+            for (int q = 1; q < qr; ++q) {
+                int b = rc[q - 1];
+                const uint64_t want = PT[cut[d]] + (uint64_t)(((unsigned __int128)sh * q) / qr);
+                while (b < cut[d + 1] && PT[b + 1] <= want) ++b;
+                rc[q] = std::max(b, rc[q - 1]);
+            }
+            return rc;
+        };
+        std::vector<std::vector<int>> rcuts(P);
+        for (int d = 0; d < P; ++d) rcuts[d] = range_cuts(d);
+        std::vector<std::vector<hipEvent_t>> done(QR, std::vector<hipEvent_t>(L, nullptr));
+        auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
+        int rc = PSACX_OK;
+        if (!solo_) {
+            for (int q = 0; q < QR && rc == PSACX_OK; ++q) for (int i = 0; i < L && rc == PSACX_OK; ++i) {
+                if (hipSetDevice(ctx(i)->device) != hipSuccess || hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming) != hipSuccess) { mg_set_err(g, "one-word first sort: event creation failed"); rc = PSACX_EHIP; }
+            }
+            // the short suffixes at the head of their buckets (before the first exchange is issued: the copies are ordered on the compute streams,
+            // which the range sorts wait on anyway)
+            for (int i = 0; i < L && rc == PSACX_OK; ++i) {
+                const int me = rank(i);
+                (void)hipSetDevice(ctx(i)->device);
+                for (int b = cut[me]; b < cut[me + 1] && rc == PSACX_OK; ++b)
+                    if (!short_words[b].empty() && hipMemcpyAsync(A[i].p + boff[i][b], short_words[b].data(), short_words[b].size() * 8, hipMemcpyHostToDevice, ctx(i)->stream) != hipSuccess) {
+                        mg_set_err(g, "one-word first sort: copy of the short suffixes failed"); rc = PSACX_EHIP;
+                    }
+            }
+            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
+                std::vector<std::vector<Msg>> sends(L), recvs(L);
+                std::vector<std::vector<const void*>> in(L);
+                std::vector<std::vector<void*>> out(L);
+                for (int i = 0; i < L; ++i) {
+                    const int me = rank(i);
+                    for (int d = 0; d < P; ++d)
+                        for (int b = rcuts[d][q]; b < rcuts[d][q + 1]; ++b) sends[i].push_back(Msg{d, sstart[i][b], mine[i][b]});
+                    for (int b = rcuts[me][q]; b < rcuts[me][q + 1]; ++b) {
+                        uint64_t at = boff[i][b] + short_words[b].size();
+                        for (int r = 0; r < P; ++r) { const uint64_t cn = table[(size_t)r * W + b]; recvs[i].push_back(Msg{r, at, cn}); at += cn; }
+                    }
+                    in[i] = {grp[i].p}; out[i] = {A[i].p};
+                }
+                rc = transfer(in, out, {sizeof(T)}, sends, recvs, &done[q]);
+            }
+        }
+        // ---- 6. the LSD passes inside the buckets of a range as soon as it has landed
+        std::vector<std::vector<std::vector<unsigned long long>>> tabs(L, std::vector<std::vector<unsigned long long>>(QR));
+        std::vector<uint64_t*> s1(L, nullptr);
+        for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
+            rc = par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_HIP(g, hipSetDevice(c->device));
+                if (!solo_) for (int s2 = 0; s2 < L; ++s2) MG_HIP(g, hipStreamWaitEvent(c->stream, done[q][s2], 0));
+                std::vector<unsigned long long>& ht = tabs[i][q];
+                ht.assign(2 * (RADIX + 1), 0);
+                const int b0 = rcuts[rank(i)][q], b1 = rcuts[rank(i)][q + 1];
+                uint64_t cntq = 0;
+                for (int b = 0; b <= RADIX; ++b) ht[b] = boff[i][std::min(std::max(b, b0), b1)];
+                cntq = ht[RADIX] - ht[0];
+                if (!cntq) { if (!s1[i]) s1[i] = reinterpret_cast<uint64_t*>(((npass & 1) ? B[i] : A[i]).p); return PSACX_OK; }
+                const OneWordLayout lay = onew_layout<TILE>(ht.data(), (share[i] + TILE - 1) / TILE);
+                if (lay.need > scr[i].desc_bytes || lay.vtiles >= (1ull << 31)) { mg_set_err(g, "one-word first sort: scratch of the bucket passes too small"); return PSACX_EDEVICE; }
+                uint64_t* res = nullptr;
+                MG_OP(g, c, onew_bucket_passes(c, scr[i].desc, ht.data(), lay, reinterpret_cast<uint64_t*>(A[i].p), reinterpret_cast<uint64_t*>(B[i].p),
+                                               reinterpret_cast<uint64_t*>(vout[i].p), sfield, low, lo1, cntq, &res));
+                s1[i] = res;
+                return PSACX_OK;
+            });
+        }
+        // everything has arrived and every pass has run before the partitioned blocks and the tables go away
+        for (int i = 0; i < L; ++i) {
+            (void)hipSetDevice(ctx(i)->device);
+            if (!solo_) for (int q = 0; q < QR; ++q) for (int s2 = 0; s2 < L; ++s2) if (done[q][s2]) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
+        }
+        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
+        drop_events();
+        PSACX_TRY(agree(rc));
+        for (int i = 0; i < L; ++i) {
+            DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];
+            if (s1[i] && reinterpret_cast<T*>(s1[i]) != k1_final.p) { mg_set_err(g, "one-word first sort: word 1 ended in the wrong array"); return PSACX_EDEVICE; }
+            grp[i].release();
+            ((npass & 1) ? A[i] : B[i]).release();
+            rec[i] = Rec<T>();
+            rec[i].k1 = std::move(k1_final); rec[i].v = std::move(vout[i]); rec[i].cnt = share[i];
+            rec[i].k1.n = share[i]; rec[i].v.n = share[i];
+        }
+        g->last_one_word = true;
+        mark("    sort: shuffle by buckets + bucket passes");
+        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, true);
+        }
     }
 
     // Stable partition of global positions `gidx` and one payload array by owner rank: the owner of every position
@@ -2643,11 +2951,24 @@ struct MultiRun {
         const int tw_mode = env_tw ? atoi(env_tw) : -1;
         bool two_word = !gsa && tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
                         !getenv("PSACX_ONE_STAGE");
+        // One-word records dealt by the top digit of the prefix (sort_first_one_word): 64-bit words, blocks of at least 2^21 characters
+        // (PSACX_MULTI_ONE_WORD: 0 = never, 1 = also for small blocks: tests)
+        CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
+        KeyShape ks; ks.lc = lc; ks.c1 = c1; ks.c2 = c2; ks.spec = 0;
+        const char* env_ow = getenv("PSACX_MULTI_ONE_WORD");
+        const int ow_mode = env_ow ? atoi(env_ow) : -1;
+        bool one_word = two_word && sizeof(T) == 8 && ow_mode != 0 && !tiny_blocks && (ow_mode >= 1 || min_local >= (1ull << 21));
+        unsigned lo1_first = bits_w1 - lead;
+        g->last_one_word = false;
+        if (one_word) {
+            const int rc1 = sort_first_one_word(rec, sizes, bits_w1, bits_w2, tbuf, two_k, tab, ks, tw_mode == 2, spec, &lo1_first);
+            if (rc1 == PSACX_RETRY_) one_word = false; else PSACX_TRY(rc1);
+        }
+        if (!one_word) {
         PSACX_TRY(make_records(!two_word));
         mark("keys");
-        if (two_word) {
-            CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
-            KeyShape ks; ks.lc = lc; ks.c1 = c1; ks.c2 = c2; ks.spec = 0;
+        }
+        if (two_word && !one_word) {
             const int rc2 = sort_first_two_word(rec, sizes, bits_w1, bits_w2, bits_w1 - lead, tbuf, two_k, tab, ks, tw_mode == 2, spec);
             if (rc2 == PSACX_RETRY_) {
                 two_word = false;
@@ -2658,7 +2979,7 @@ struct MultiRun {
         if (!two_word) PSACX_TRY(dist_sort(rec, sizes, bits_w1, bits_w2, true));
         tbuf.clear();
         g->last_two_word = two_word;
-        if (!two_word) g->last_packed = false;
+        if (!two_word || one_word) g->last_packed = false;
         PSACX_TRY(par([&](int i) -> int { return own3(i, rec[i]); }));
         mark("first sort");
 

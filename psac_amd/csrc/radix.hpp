@@ -184,8 +184,12 @@ __device__ __forceinline__ void radix_scatter_tile(
     //    (prefix << lo1, top digit = voff, pack = lo1 | (prefix bits without the top digit) << 8) and the 64-bit payload out.
     // 10: as 7, with word 1 of the tile's records waiting in LDS (the stage, a wave's 64 * ITEMS records in its own part, element
     //     e at e ^ ((e >> 3) & 7): sa_kernels.hpp: key_scatter1w_kernel computes them there instead of reading them from memory)
+    // Width of the payload field of a one-word record: bits 16 .. 23 of `pack` (0 = 32).  A text of up to 2^S characters keeps
+    // 64 - S prefix bits in the word (the multi-GPU engine: 2^34 characters -> 34 + 30).
     constexpr bool ONEW_IN = VN == 8 || VN == 9;
     constexpr bool ONEW_OUT = VN == 7 || VN == 8 || VN == 10;
+    constexpr bool ONEW_MAKE = VN == 7 || VN == 10;
+    const unsigned sfield = (ONEW_MAKE || VN == 9) ? (((pack >> 16) & 255u) ? ((pack >> 16) & 255u) : 32u) : 0u;
     const T pmask = PK ? (T)((((uint64_t)1 << pack) - 1)) : (T)0;
     T* const stage = sh.stage;
     uint8_t* const sdig = sh.sdig;
@@ -267,7 +271,7 @@ __device__ __forceinline__ void radix_scatter_tile(
             else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint16_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
             else vv[i] = (FULL || loc < count) ? (PV)(pv + wbase)[i * WAVE] : (PV)0;
         }
-    } else {
+    } else if (!ONEW_MAKE) {         // (one-word records out: the payload is put together when the word is staged)
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             // implicit payload: the record index, or the suffix the first-round record stands for
@@ -354,7 +358,12 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned d = EXT ? (unsigned)cls[EXT ? i : 0] : ((unsigned)(kd[i] >> shift) & (RADIX - 1));
         rank[i] += bstart[d] + mycnt[d];
-        const T staged = (VN == 7 || VN == 10) ? (T)((((uint64_t)kd[i] >> pack) << 32) | (uint64_t)(uint32_t)vv[i]) : kd[i];
+        T staged = kd[i];
+        if (ONEW_MAKE) {
+            const uint64_t g = base + wbase + i * WAVE;
+            const uint64_t made = (spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff;
+            staged = (T)((((uint64_t)kd[i] >> (pack & 255u)) << sfield) | made);
+        }
         if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = staged; sdig[rank[i]] = (uint8_t)d; }
     }
     __syncthreads();
@@ -367,8 +376,8 @@ __device__ __forceinline__ void radix_scatter_tile(
             if (PK_OUT_FULL) xlow[PK_OUT_FULL ? j : 0] = (T)(x & pmask);
             const T at = (T)(goff[sdig[p]] + (T)p);
             if (VN == 9) {
-                kd_out[at] = (T)(((voff << (pack >> 8)) | ((uint64_t)x >> 32)) << (pack & 255u));
-                v_out[at] = (T)((uint64_t)x & 0xFFFFFFFFull);
+                kd_out[at] = (T)(((voff << ((pack >> 8) & 255u)) | ((uint64_t)x >> sfield)) << (pack & 255u));
+                v_out[at] = (T)((uint64_t)x & ((1ull << sfield) - 1ull));
             } else kd_out[at] = x;
         }
     }

@@ -347,7 +347,10 @@ template <int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_text, CodeTable tab, KeyShape ks,
                                                                  uint64_t* __restrict__ out, int shift, const unsigned long long* __restrict__ digit_base,
                                                                  const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
-                                                                 unsigned* __restrict__ tile_counter, unsigned chunk, unsigned slab_tiles, unsigned lo1) {
+                                                                 unsigned* __restrict__ tile_counter, unsigned chunk, unsigned slab_tiles, unsigned lo1,
+                                                                 uint64_t voff = 0) {
+    // lo1: bits of word 1 below the sorted prefix | width of the payload field << 16 (radix.hpp: ONEW_MAKE; 0 = 32)
+    // voff: added to the suffix a record stands for (a rank's block of a distributed text)
     typedef uint64_t T;
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
@@ -458,12 +461,12 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
     const uint64_t remain = n - base;
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, false, true, 10>(sh, tile, (unsigned)TILE, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
-                                                                                   digit_base, nullptr, nullptr, nullptr, ks.spec, n, tile_excl, slab_excl, nullptr,
-                                                                                   slab_tiles, (uint64_t)0, lo1);
+                                                                                   digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
+                                                                                   slab_tiles, voff, lo1);
     else
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, false, true, 10>(sh, tile, (unsigned)remain, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
-                                                                                    digit_base, nullptr, nullptr, nullptr, ks.spec, n, tile_excl, slab_excl, nullptr,
-                                                                                    slab_tiles, (uint64_t)0, lo1);
+                                                                                    digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
+                                                                                    slab_tiles, voff, lo1);
 }
 
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)

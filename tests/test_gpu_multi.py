@@ -685,6 +685,39 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_first_round_one_word_form(P, monkeypatch):
+    # sort_first_one_word (multi.hpp): the 256 buckets of the top digit of the prefix are dealt whole to the ranks from exact counts,
+    # the sender writes one-word records (rest of the prefix | suffix) straight from the text, the buckets travel in groups and are
+    # sorted as they land (radix_scatter1w_kernel), the short suffixes are made on the host.  Forced below its size threshold
+    # (PSACX_MULTI_ONE_WORD=1); PSACX_MULTI_TWO_WORD=2 also sends repetitive and badly balanced texts through it (long tie groups,
+    # buckets of one rank only, empty ranks).
+    cases = [(O.rand_dna(70001, 7), 64), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
+             (np.full(5003, 65, np.uint8), 64), (inputs.cyclic(20011, "abc"), 64), (O.as_text("mississippi" * 40), 64),
+             (O.rand_dna(70001, 7), 32)]
+    monkeypatch.setenv("PSACX_MULTI_ONE_WORD", "1")
+    for mode, env in (("1", {}), ("2", {}), ("2", {"PSACX_MULTI_PIECES": "7"}), ("1", {"PSACX_MULTI_PIECES": "1"}), ("1", {"PSACX_MULTI_FORCE_WIRE": "1"})):
+        if env.get("PSACX_MULTI_FORCE_WIRE") and P != 1:
+            continue
+        monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
+        for k_ in ("PSACX_MULTI_FORCE_WIRE", "PSACX_MULTI_PIECES"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        mg = multi(P)
+        try:
+            used = 0
+            for text, bits in cases:
+                SA, ISA, LCP, rounds = same(mg, text, bits)
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, env, bits, text.size)
+                assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
+                used += mg.last_form()["one_word"]
+            assert used >= (len(cases) - 1 if mode == "2" else 2), (used, P, mode)      # (32-bit words never take the form)
+        finally:
+            mg.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
 def test_multi_string_sets(P):
     # construct_ss on p ranks (suffix_array.hpp:267-363; psacx_multi_construct_gsa_*): the reference's expected arrays
     # (test/test_gsa.cpp:35-105), random sets against the oracle's restatement, deep ties (equal strings, prefixes of each
