@@ -183,29 +183,33 @@ template <typename E> struct DBuf {
     E* p = nullptr; uint64_t n = 0; psacx_ctx* c = nullptr;
     DBuf() {}
     DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
-    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c), cap_(o.cap_), own_(o.own_) { o.p = nullptr; o.n = 0; }
-    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; cap_ = o.cap_; own_ = o.own_; o.p = nullptr; o.n = 0; } return *this; }
+    DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), c(o.c), cap_(o.cap_), lead_(o.lead_), own_(o.own_) { o.p = nullptr; o.n = 0; o.lead_ = 0; }
+    DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; c = o.c; cap_ = o.cap_; lead_ = o.lead_; own_ = o.own_; o.p = nullptr; o.n = 0; o.lead_ = 0; } return *this; }
     ~DBuf() { release(); }
     // `count` elements; the block is sized for max(count, reserve) so that arrays of slightly different lengths reuse
     // one cached block (reduced-memory layout)
     int alloc(psacx_ctx* ctx, uint64_t count, uint64_t reserve = 0) {
         release();
-        c = ctx; n = count; own_ = true;
+        c = ctx; n = count; own_ = true; lead_ = 0;
         if (hipSetDevice(c->device) != hipSuccess) return PSACX_EHIP;
         p = static_cast<E*>(pool_alloc(c, (size_t)std::max(count, reserve) * sizeof(E), &cap_));
         if (!p) { c->hip_err = "device allocation failed"; n = 0; return PSACX_ENOMEM; }
         return PSACX_OK;
     }
     // a view of memory somebody else owns (an output array used as scratch)
-    void borrow(psacx_ctx* ctx, E* ptr, uint64_t count) { release(); c = ctx; p = ptr; n = count; own_ = false; cap_ = 0; }
+    void borrow(psacx_ctx* ctx, E* ptr, uint64_t count) { release(); c = ctx; p = ptr; n = count; own_ = false; cap_ = 0; lead_ = 0; }
     bool owned() const { return own_; }
+    // the array starts k elements further into its block (records that were placed behind a headroom)
+    void advance(uint64_t k) { p += k; lead_ += k; }
+    void rewind(uint64_t k) { p -= k; lead_ -= k; }
     void release() {
         if (!p) return;
-        if (own_) pool_free(c, p, cap_);
-        p = nullptr; n = 0;
+        if (own_) pool_free(c, p - lead_, cap_);
+        p = nullptr; n = 0; lead_ = 0;
     }
 private:
     size_t cap_ = 0;
+    uint64_t lead_ = 0;
     bool own_ = true;
 };
 
@@ -558,9 +562,15 @@ struct MultiRun {
     // the second key array of a two-word record set, when word 2 of the tied records is about to be written
     int need_k2(int i, Rec<T>& r) {
         if (r.k2.p) return PSACX_OK;
-        MG_OP(g, ctx(i), r.k2.alloc(ctx(i), r.cnt, reserve_of(i)));
+        // (records behind a headroom, to be re-balanced in place: word 2 lies the same way)
+        const uint64_t head = i < (int)head_.size() ? head_[i] : 0, room = i < (int)room_.size() ? room_[i] : 0;
+        MG_OP(g, ctx(i), r.k2.alloc(ctx(i), std::max(r.cnt + head, room), reserve_of(i)));
+        r.k2.advance(head); r.k2.n = r.cnt;
         return PSACX_OK;
     }
+    // sort_first_one_word: the sorted records of local rank i lie head_[i] elements into arrays of room_[i] elements, so that the pieces of
+    // its block that other ranks hold can be received in front of / behind them (rebalance_in_place); empty = no such layout
+    std::vector<uint64_t> head_, room_;
     void drop3(int i, Rec<T>& r) {
         if (r.k1.p && !r.k1.owned()) S[i].out_busy = false;
         r = Rec<T>();
@@ -1268,6 +1278,42 @@ struct MultiRun {
         return PSACX_OK;
     }
 
+    // Re-balance without a copy (after sort_first_one_word): local rank i holds the globally sorted records held_from_[r] .. + held_cnt_[r]
+    // (r its rank) head_[i] elements into arrays of room_[i] elements, and its block starts at most head_[i] records before them: the pieces
+    // other ranks hold of it are received in front of and behind its own records, where the arrays have room, and the block then begins
+    // at the start of the arrays.  All three arrays of a record set travel in one group of messages.
+    std::vector<uint64_t> held_from_, held_cnt_;
+    int rebalance_in_place(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets) {
+        const std::vector<uint64_t> TP = prefix_of(targets);
+        std::vector<std::vector<Msg>> sends(L), recvs(L);
+        std::vector<std::vector<const void*>> in(L);
+        std::vector<std::vector<void*>> out(L);
+        for (int i = 0; i < L; ++i) {
+            const int me = rank(i);
+            const uint64_t g0 = held_from_[me], g1 = g0 + held_cnt_[me];
+            if (g0 < TP[me] || g0 - TP[me] != head_[i] || g1 < TP[me + 1]) { mg_set_err(g, "re-balance in place: a rank does not hold the tail of its block"); return PSACX_EINVAL; }
+            for (int d = 0; d < P; ++d) {
+                if (d == me) continue;
+                const uint64_t lo = std::max(g0, TP[d]), hi = std::min(g1, TP[d + 1]);
+                if (lo < hi) sends[i].push_back(Msg{d, head_[i] + (lo - g0), hi - lo});
+            }
+            for (int r = 0; r < P; ++r) {
+                if (r == me) continue;
+                const uint64_t lo = std::max(held_from_[r], TP[me]), hi = std::min(held_from_[r] + held_cnt_[r], TP[me + 1]);
+                if (lo < hi) recvs[i].push_back(Msg{r, lo - TP[me], hi - lo});
+            }
+            T* b1 = rec[i].k1.p - head_[i]; T* b2 = rec[i].k2.p - head_[i]; T* b3 = rec[i].v.p - head_[i];
+            in[i] = {b1, b2, b3}; out[i] = {b1, b2, b3};
+        }
+        PSACX_TRY(transfer(in, out, {sizeof(T), sizeof(T), sizeof(T)}, sends, recvs));
+        for (int i = 0; i < L; ++i) {
+            rec[i].k1.rewind(head_[i]); rec[i].k2.rewind(head_[i]); rec[i].v.rewind(head_[i]);
+            rec[i].cnt = targets[rank(i)];
+            rec[i].k1.n = rec[i].k2.n = rec[i].v.n = rec[i].cnt;
+        }
+        return PSACX_OK;
+    }
+
     // Both words of the packed 2k-character window of the suffixes gidx[i][0 .. cnt[i]) (global positions), computed by the
     // ranks that own those positions from their text blocks + halos (tbuf: block + 2k characters) and sent back in query
     // order: the remote form of window_word2() for the suffixes that tie on the leading bits of word 1.
@@ -1706,7 +1752,7 @@ struct MultiRun {
             return PSACX_OK;
         }));
         mark("    sort: local prefix sort");
-        if (!general_ties) { mark("    sort: ties"); return rebalance(rec, targets); }
+        if (!general_ties) { mark("    sort: ties"); return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets); }
         std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
@@ -1751,7 +1797,7 @@ struct MultiRun {
             return PSACX_OK;
         }));
         mark("    sort: ties");
-        return rebalance(rec, targets);
+        return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets);
     }
 
     // The first sort in ONE-word records (the one-GPU engine's prefix_sort_1w, engine.hpp, spread over the ranks).  A record is
@@ -1883,16 +1929,25 @@ struct MultiRun {
         const std::vector<uint64_t> TP = prefix_of(targets);
         std::vector<int> cut(P + 1, 0);                              // rank d owns the buckets cut[d] .. cut[d + 1] - 1
         cut[P] = RADIX;
+        // rank d starts at the first bucket boundary at or behind the start of its block: every rank then holds a little more than the tail
+        // of its own block -- the head, at most one bucket, sits at the end of the rank before it and is received in front of the rank's own
+        // records, for which the arrays leave room (head_ / room_; rebalance_in_place): no copy of the record arrays to re-balance them
         for (int d = 1; d < P; ++d) {
             int b = cut[d - 1];
-            while (b < RADIX && PT[b + 1] <= TP[d]) ++b;             // PT[b] <= TP[d] < PT[b + 1]
-            if (b < RADIX && TP[d] - PT[b] > PT[b + 1] - TP[d]) ++b; // the nearer bucket boundary
-            cut[d] = std::max(b, cut[d - 1]);
+            while (b < RADIX && PT[b] < TP[d]) ++b;
+            cut[d] = b;
         }
+        std::vector<uint64_t> Gs(P), cs(P), Hs(P), rooms(P);
+        bool inplace = !solo_;
         for (int d = 0; d < P; ++d) {
-            const uint64_t share = PT[cut[d + 1]] - PT[cut[d]];
-            if (!trust && share > sizes[d] + sizes[d] / 8) return PSACX_RETRY_;        // (the slack of the reduced-memory layout's record arrays)
+            Gs[d] = PT[cut[d]]; cs[d] = PT[cut[d + 1]] - PT[cut[d]];
+            Hs[d] = Gs[d] - TP[d]; rooms[d] = std::max(Hs[d] + cs[d], sizes[d]);
+            if (rooms[d] > sizes[d] + sizes[d] / 8) {                 // (the slack of the reduced-memory layout's record arrays)
+                if (!trust) return PSACX_RETRY_;
+                inplace = false;
+            }
         }
+        if (!inplace) for (int d = 0; d < P; ++d) { Hs[d] = 0; rooms[d] = cs[d]; }
         *lo1_out = lo1;
         // ---- 3. arrays: the partitioned block (grp), two record arrays of the rank's share (A, B) and the suffixes of the last pass (vout).
         //      Reduced-memory layout: grp, the array that does not end up with word 1 and the suffixes are the rank's three output arrays.
@@ -1904,21 +1959,21 @@ struct MultiRun {
             psacx_ctx* c = ctx(i);
             const int me = rank(i);
             drop3(i, rec[i]);
-            share[i] = PT[cut[me + 1]] - PT[cut[me]];
-            const uint64_t ng = solo_ ? S[i].m : nrec[i];
-            const bool lend = diet && !S[i].out_busy && std::max(share[i], ng) <= S[i].out_cap;
+            share[i] = cs[me];
+            const uint64_t ng = solo_ ? S[i].m : nrec[i], room = rooms[me];
+            const bool lend = diet && !S[i].out_busy && std::max(room, ng) <= S[i].out_cap;
             DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];          // the array the last pass writes word 1 into
             DBuf<T>& other = (npass & 1) ? A[i] : B[i];
             if (lend) {
                 S[i].out_busy = true;
-                other.borrow(c, S[i].ISA, share[i]);
-                vout[i].borrow(c, S[i].SA, share[i]);
+                other.borrow(c, S[i].ISA, room);
+                vout[i].borrow(c, S[i].SA, room);
                 if (S[i].LCP && !solo_) grp[i].borrow(c, S[i].LCP, ng);
             } else {
-                rc_alloc = other.alloc(c, share[i], reserve_of(i));
-                if (rc_alloc == PSACX_OK) rc_alloc = vout[i].alloc(c, share[i], reserve_of(i));
+                rc_alloc = other.alloc(c, room, reserve_of(i));
+                if (rc_alloc == PSACX_OK) rc_alloc = vout[i].alloc(c, room, reserve_of(i));
             }
-            if (rc_alloc == PSACX_OK) rc_alloc = k1_final.alloc(c, share[i], reserve_of(i));
+            if (rc_alloc == PSACX_OK) rc_alloc = k1_final.alloc(c, room, reserve_of(i));
             if (rc_alloc == PSACX_OK && !solo_ && !grp[i].p) rc_alloc = grp[i].alloc(c, ng, reserve_of(i));
             if (rc_alloc != PSACX_OK) mg_set_err(g, "one-word first sort: record arrays: " + c->hip_err);
         }
@@ -1945,7 +2000,7 @@ struct MultiRun {
         std::vector<std::vector<uint64_t>> sstart(L, std::vector<uint64_t>(RADIX + 1, 0));     // start of bucket b in the sender's partitioned block
         for (int i = 0; i < L; ++i) {
             const int me = rank(i);
-            uint64_t at = 0;
+            uint64_t at = Hs[me];
             for (int b = 0; b <= RADIX; ++b) { boff[i][b] = at; if (b < RADIX && b >= cut[me] && b < cut[me + 1]) at += tot[b]; }
             for (int b = 0; b < RADIX; ++b) sstart[i][b + 1] = sstart[i][b] + mine[i][b];
         }
@@ -2039,11 +2094,19 @@ struct MultiRun {
             ((npass & 1) ? A[i] : B[i]).release();
             rec[i] = Rec<T>();
             rec[i].k1 = std::move(k1_final); rec[i].v = std::move(vout[i]); rec[i].cnt = share[i];
+            rec[i].k1.advance(Hs[rank(i)]); rec[i].v.advance(Hs[rank(i)]);
             rec[i].k1.n = share[i]; rec[i].v.n = share[i];
+        }
+        if (inplace) {
+            head_.assign(L, 0); room_.assign(L, 0);
+            for (int i = 0; i < L; ++i) { head_[i] = Hs[rank(i)]; room_[i] = rooms[rank(i)]; }
+            held_from_ = Gs; held_cnt_ = cs;
         }
         g->last_one_word = true;
         mark("    sort: shuffle by buckets + bucket passes");
-        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, true);
+        const int rct = first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, true);
+        head_.clear(); room_.clear();
+        return rct;
         }
     }
 

@@ -36,6 +36,7 @@ for it in range(int(os.environ.get("BIGRUN_ITERS", "1"))):      # the last one i
     t0 = time.perf_counter()
     st, sent, ex, ga = mg.construct_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
     dt = time.perf_counter() - t0
+phases, form, wire = mg.phases(), mg.last_form(), mg.wire()
 peak, reduced, slab_rounds = mg.memory()
 words = max(peak) / float(m * w)
 own = 3.0 * (m + slack) / m + 1.0 / w
@@ -45,6 +46,8 @@ print("  engine allocations at their peak: %.2f words per character (max over ra
       % (words, (m + slack) / float(m), words + own))
 print("  a block of 2^32 characters with 64-bit words would hold %.1f GB of the 288 GB of an MI355X" % ((words + own) * 8 * 2.0 ** 32 / 1e9))
 err = mg.check_device(d["text"], sizes, d["sa"], d["isa"], d["lcp"], bits)
+print("  phases (host wall ms):", ", ".join("%s %.1f" % (k.strip(), v) for k, v in phases))
+print("  forms:", form, " wire:", wire)
 print("  distributed check errors:", err)
 mg.close()
 sys.exit(0 if err == [0, 0, 0, 0] else 1)
