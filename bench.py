@@ -118,7 +118,7 @@ def cpu_baseline(kind, sample, seed, bits):
     return out
 
 
-def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism):
+def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism, onew_passes=0):
     w = bits // 8
     ms_per_step = dt / a.steps * 1e3
     value = world * n * a.steps / dt / 1e6
@@ -128,10 +128,10 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
              "radix_scatter3_kernel<two-word> (one 8-bit digit pass of the first round's (B1,idx) prefix sort)")[dom]
     achieved = scat_bytes[dom] / (scat_ms[dom] * 1e-3) / 1e9 if scat_ms[dom] > 0 else 0.0
     tkey = dom
-    if dom == 2 and scat_launches[dom] and scat_bytes[dom] / float(scat_launches[dom]) / n < 20.0:
-        # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the pass on the top digit (radix_scatter3_kernel<..., 7>:
-        # word 1 in, one word out), the passes inside the buckets (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the
-        # last one (radix_scatter1w_kernel<..., 9>: one word in, word 1 + suffix out); the figures below are their mean
+    if dom == 2 and onew_passes > 0:         # (psacx_stats.onew_passes: bucket passes over one-word records ran)
+        # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the passes inside the buckets
+        # (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the last one (radix_scatter1w_kernel<..., 9>: one word in,
+        # word 1 + suffix out); the figures below are their mean
         kname = "radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records: the three passes inside the buckets, 8 + 8 bytes per record, and the widening pass, 8 + 16; the pass on the top digit computes its keys from the text and is timed with them)"
         tkey = 3
     out = {
@@ -407,10 +407,11 @@ def main():
     # dominant kernel: the scatter kernel of a radix pass.  Large sorts use
     # radix_scatter3_kernel (index 1, or 2 for two-word records), small ones radix_scatter_kernel (index 0); the
     # roofline is quoted on whichever moved more bytes in the timed region.
-    scat_ms = [0.0, 0.0, 0.0]; scat_bytes = [0, 0, 0]; scat_launches = [0, 0, 0]
+    scat_ms = [0.0, 0.0, 0.0]; scat_bytes = [0, 0, 0]; scat_launches = [0, 0, 0]; onew = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         s = step(True)
+        onew += s.onew_passes
         scat_ms[0] += s.ms_sort_scatter; scat_ms[1] += s.ms_sort_scatter3; scat_ms[2] += s.ms_sort_scatter2
         for q in (0, 1, 2):
             scat_bytes[q] += s.scatter_bytes[q]; scat_launches[q] += s.scatter_launches[q]
@@ -423,7 +424,7 @@ def main():
               "isa_scatter": round(s.ms_isa_scatter, 3), "gather": round(s.ms_gather, 3), "compact": round(s.ms_compact, 3),
               "rmq_build": round(s.ms_rmq_build, 3)}
     out = report(a, 1, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, int(s.k), int(s.bits_per_char),
-                 int(s.n_rounds), "1 process per GPU")
+                 int(s.n_rounds), "1 process per GPU", onew)
     out["config"]["workspace_GiB"] = round(s.workspace_bytes / 2.0 ** 30, 1)
     # the result of the last timed step, verified where it lies (psacx_check_dev_*: SA a permutation inverse to ISA,
     # suffix order, every LCP entry against a direct character comparison)

@@ -78,6 +78,8 @@ typedef struct psacx_stats {
     uint64_t scatter_bytes[3];     /* algorithmic bytes: read + write of the record, 2 * 3w ([2]: 2 * 2w) per record */
     uint64_t hist_bytes;           /* algorithmic bytes of the histogram kernels: 2w per record */
     uint64_t workspace_bytes;      /* HBM held by the ctx */
+    uint64_t onew_passes;          /* bucket passes run over one-word records (the MSD-first prefix sort of the first round); 0: that sort ran
+                                      in the two-array form, whose passes are counted in scatter_*[2] alone */
 } psacx_stats;
 
 /* life cycle ------------------------------------------------------------- */
@@ -256,8 +258,7 @@ int psacx_multi_get_wire(const psacx_multi* mg, uint64_t* sends, uint64_t* recvs
 int psacx_multi_get_phases(const psacx_multi* mg, char* buf, uint64_t cap);
 /* which forms the last construction took: bit 0 = first round in two-word form (records (B1, idx), ties repaired from the
  * text owners; idxsort.hpp:23-83 moves (B1, B2, idx)), bit 1 = reduced-memory layout, bit 2 = SA -> ISA slice by slice
- * through the destination-partition levels (bulk_permute.hpp:14-73), bit 3 = the suffixes of the two-word records travelled
- * packed into the unsorted low bits of B1 + one or two bytes (9 or 10 bytes per record on the wire and per sort pass),
+ * through the destination-partition levels (bulk_permute.hpp:14-73),
  * bit 4 = first round in one-word records dealt to the ranks by the top digit of the prefix (8 bytes per record on the wire) */
 int psacx_multi_last_form(const psacx_multi* mg);
 const char* psacx_multi_last_error(const psacx_multi* mg);

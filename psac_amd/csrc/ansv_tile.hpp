@@ -532,7 +532,7 @@ template <typename T>
 inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
     constexpr uint64_t TILE = (uint64_t)AnsvTile<T>::TB * 64;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
-    const unsigned dbg = getenv("PSACX_ANSV_DBG") ? (unsigned)atoi(getenv("PSACX_ANSV_DBG")) : 0u;      // (tuning aid: parts of the kernel left out, results wrong)
+    const unsigned dbg = 0u;
     // exactly as many workgroups as fit on the chip at once: every workgroup then walks an equal, contiguous share of the tiles
 #define PSACX_ANSV(LF, RF)                                                                                                       \
     do {                                                                                                                         \

@@ -90,7 +90,6 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.sc.d_err = a.take<unsigned>(64);
     w.sc.d_summary = a.take<unsigned long long>(8);
     w.sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
-    w.sc.d_dbg = kn.sort_debug ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     return a.off;
 }
 
@@ -101,7 +100,7 @@ inline int ensure_pinned(psacx_ctx* c, size_t bytes) {
     PSACX_HIP(c, hipHostMalloc((void**)&c->pinned, bytes, hipHostMallocDefault));
     c->pinned_bytes = bytes;
     void* dp = nullptr;
-    if (!getenv("PSACX_NO_HOST_STORES") && hipHostGetDevicePointer(&dp, c->pinned, 0) == hipSuccess) c->pinned_dev = static_cast<char*>(dp);
+    if (hipHostGetDevicePointer(&dp, c->pinned, 0) == hipSuccess) c->pinned_dev = static_cast<char*>(dp);
     else (void)hipGetLastError();
     return PSACX_OK;
 }
@@ -188,7 +187,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
 // whether the inversion of n records of T runs its partition levels as radix passes (see invert_permutation)
 template <typename T>
 inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
-    return sizeof(T) == 4 && n >= (1ull << 22) && n <= (1ull << 30) && !kn.isa_partition;
+    return sizeof(T) == 4 && n >= (1ull << 22) && n <= (1ull << 30);
 }
 
 // ISA[SA[i]] = val[i] - 1 for a full permutation SA (bulk_permute.hpp:14-73).  Large inputs go
@@ -206,7 +205,7 @@ inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
 constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;
 template <typename T>
 inline int isa_narrow_levels(uint64_t n, const Knobs& kn) {
-    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32) || kn.isa_wide) return 0;
+    if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32)) return 0;
     const unsigned idx_bits = bits_for(n - 1);
     return (int)((idx_bits - ISA_NARROW_WB + ISA_NARROW_CB - 1) / ISA_NARROW_CB);
 }
@@ -260,67 +259,40 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     for (int lv = 0; radix_levels && lv < levels; ++lv) {
         SortBufs<T> o = bufs[lv & 1];
         PSACX_HIP(c, hipMemsetAsync(sc->d_desc, 0, 256, c->stream));
-        dispatch_pass3<T>(c, ScatterCfg<T>::DEF2, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
-                          sc->d_base + (size_t)lv * RADIX, sc->d_desc, (unsigned long long*)nullptr, 0, 0,
-                          lv == 0 && have_hist0);
+        dispatch_pass3<T>(c, kin, (const T*)nullptr, vin, o.k1, (T*)nullptr, o.k2, n, (int)(INV_WINDOW_BITS + 8 * lv),
+                          sc->d_base + (size_t)lv * RADIX, sc->d_desc, 0, 0, lv == 0 && have_hist0);
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 4ull * sizeof(T) * n;
         kin = o.k1; vin = o.k2;
     }
     // 64-bit words, at most 2^32 positions: the pairs are narrowed to 32 bits by the first partition level (sa_kernels.hpp)
-    const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1 && !kn.isa_wide;
+    const bool narrow = !radix_levels && sizeof(T) == 8 && n <= (1ull << 32) && levels >= 1;
     if (fused_l1 && !(narrow && isa_narrow_levels<T>(n, kn) > 0)) { c->hip_err = "inversion: fused first level without the narrow form"; return PSACX_EINVAL; }
     if (narrow && isa_narrow_levels<T>(n, kn) > 0) {
         // 2^14-entry windows (64 KiB of 32-bit values in LDS) and 512-way levels: 2^32 positions need two partition
         // levels instead of three (24 + 16 + 16 = 56 instead of 72 bytes per record)
         constexpr int WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
-        uint32_t* nb[2][2] = {{reinterpret_cast<uint32_t*>(t1.k1), reinterpret_cast<uint32_t*>(t1.k1) + n},
-                              {reinterpret_cast<uint32_t*>(t2.k1), reinterpret_cast<uint32_t*>(t2.k1) + n}};
         const uint64_t ntiles = (n + PB * PI - 1) / (PB * PI);
         const int lv9 = isa_narrow_levels<T>(n, kn);
-        if (!kn.isa_two_arrays) {
-            // packed pairs: one array of (position | rank << 32) entries per level (sa_kernels.hpp: partition_packed_kernel)
-            uint64_t* pb[2] = {reinterpret_cast<uint64_t*>(t1.k1), reinterpret_cast<uint64_t*>(t2.k1)};
-            const uint64_t* cur = fused_l1 ? pb[0] : nullptr;
-            for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
-                const unsigned shift = isa_narrow_shift(lv9, lv);
-                PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ((size_t)(n >> shift) + 1) * sizeof(unsigned), c->stream));
-                uint64_t* o = pb[lv & 1];
-                if (lv == 0)
-                    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
-                                       (const uint64_t*)nullptr, o, n, shift, d_cursors, koff);
-                else
-                    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, (const T*)nullptr,
-                                       (const T*)nullptr, cur, o, n, shift, d_cursors, (uint64_t)0);
-                PSACX_HIP(c, hipGetLastError());
-                cur = o;
-            }
-            if (!cur) { c->hip_err = "inversion: no partition level"; return PSACX_EINVAL; }
-            const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
-            hipLaunchKernelGGL((window_scatter_packed_kernel<T, 1024, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, cur, n, d_isa);
-            PSACX_HIP(c, hipGetLastError());
-            return PSACX_OK;
-        }
-        const uint32_t* k32 = fused_l1 ? nb[0][0] : nullptr; const uint32_t* v32 = fused_l1 ? nb[0][1] : nullptr;
+        // packed pairs: one array of (position | rank << 32) entries per level (sa_kernels.hpp: partition_packed_kernel)
+        uint64_t* pb[2] = {reinterpret_cast<uint64_t*>(t1.k1), reinterpret_cast<uint64_t*>(t2.k1)};
+        const uint64_t* cur = fused_l1 ? pb[0] : nullptr;
         for (int lv = fused_l1 ? 1 : 0; lv < lv9; ++lv) {
             const unsigned shift = isa_narrow_shift(lv9, lv);
-            const size_t ncur = (size_t)(n >> shift) + 1;
-            PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ncur * sizeof(unsigned), c->stream));
-            uint32_t* ko = nb[lv & 1][0]; uint32_t* vo = nb[lv & 1][1];
+            PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ((size_t)(n >> shift) + 1) * sizeof(unsigned), c->stream));
+            uint64_t* o = pb[lv & 1];
             if (lv == 0)
-                hipLaunchKernelGGL((partition_pairs_kernel<T, uint32_t, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
-                                   ko, vo, n, shift, d_cursors, koff);
+                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
+                                   (const uint64_t*)nullptr, o, n, shift, d_cursors, koff);
             else
-                hipLaunchKernelGGL((partition_pairs_kernel<uint32_t, uint32_t, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, k32, v32,
-                                   ko, vo, n, shift, d_cursors, (uint64_t)0);
+                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, (const T*)nullptr,
+                                   (const T*)nullptr, cur, o, n, shift, d_cursors, (uint64_t)0);
             PSACX_HIP(c, hipGetLastError());
-            k32 = ko; v32 = vo;
+            cur = o;
         }
-        if (lv9 == 0) {     // (not reached: the narrow form starts at 2^22 positions)
-            c->hip_err = "inversion: no partition level"; return PSACX_EINVAL;
-        }
+        if (!cur) { c->hip_err = "inversion: no partition level"; return PSACX_EINVAL; }
         const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
-        hipLaunchKernelGGL((window_scatter_kernel<uint32_t, T, 1024, false, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, k32, v32, n, d_isa);
+        hipLaunchKernelGGL((window_scatter_packed_kernel<T, 1024, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, cur, n, d_isa);
         PSACX_HIP(c, hipGetLastError());
         return PSACX_OK;
     }
@@ -349,7 +321,7 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
 template <typename T>
 int prepare_range_min(psacx_ctx* c, Work<T>& w, uint64_t queries, uint64_t n, const Knobs& kn) {
     for (int L = 0; L < PYR_MAX; ++L) { w.pyr.pre[L] = nullptr; w.pyr.suf[L] = nullptr; }
-    if (queries < (1u << 16) || kn.no_rmq_aux) return PSACX_OK;
+    if (queries < (1u << 16)) return PSACX_OK;
     ProfScope ps(c, TC_RMQ_BUILD);
     for (int L = 1; L + 1 < w.pyr.nlev; ++L) {
         hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, w.pyr.len[L], 256, 8)), dim3(256), 0, c->stream,
@@ -501,7 +473,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     lead = (lead + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
     // word 1 slightly too short for that (DNA, 32-bit words, 2^29 < n <= 2^30): all of word 1 still leaves
     // fewer than a quarter of the suffixes tied, which is cheaper than carrying word 2 through five passes
-    const unsigned slack = kn.lead_slack;
+    const unsigned slack = 2;
     if (lead > bits_w1 && bits_for(n - 1) + slack <= bits_w1 && bits_w1 % RADIX_BITS == 0) lead = bits_w1;
     bool two_stage = !gsa && n >= (1ull << 21) && !kn.one_stage && lead <= bits_w1 &&
                      lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
@@ -511,15 +483,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     for (int attempt = 0; attempt < 2; ++attempt) {
     bool retry_one_stage = false;
     const unsigned lo1 = two_stage ? bits_w1 - lead : 0;
-    // the suffix a record stands for travels in the unsorted low bits of word 1 + one or two bytes (radix.hpp: VN 3 .. 6)
-    // (measured slower than 32-bit payload entries on one GPU, engine.hpp: packed_form_for -- off unless PSACX_PACKED=1)
-    const PackedForm pf = two_stage ? packed_form_for(n, lo1, sizeof(T), false) : PackedForm();
-    const bool hist_in_keys = two_stage && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.no_key_hist;
+    const bool hist_in_keys = two_stage;
     // one-word records, most significant digit first (engine.hpp: prefix_sort_1w): 64-bit words, suffixes below 2^32, the
     // prefix without its top digit in 32 bits
     bool one_word = two_stage && hist_in_keys && !gsa && sizeof(T) == 8 && n <= (1ull << 32) && n >= (1ull << kn.one_word_min) && lead >= 3 * RADIX_BITS &&
-                    lead <= 32 + RADIX_BITS && lead % RADIX_BITS == 0 && !pf.on() && !kn.no_one_word && attempt == 0;
-    const bool hist_of_top_digit = one_word;      // (what key_pairs_kernel leaves in the scratch)
+                    lead <= 32 + RADIX_BITS && lead % RADIX_BITS == 0 && !kn.no_one_word && attempt == 0;
 
     // In the diet layout the second record set is the output buffers (y = ISA, LCP, SA).  One stage: both sorted key
     // words must end up in the workspace set x (word 2 in the LCP buffer would be overwritten while its neighbours are
@@ -538,7 +506,6 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // ---- first-round keys: the 2k-character window at every position, packed (kmer.hpp:119-177,
     //      shifting.hpp:33-122; see key_pairs_kernel for the packing)
     // (the one-word prefix sort computes word 1 inside its pass on the top digit: no keys in memory unless it has to give up)
-    const bool fused_keys = one_word && !kn.no_fused_keys;
     auto make_keys = [&](bool with_hist) -> int {
         ProfScope ps(c, TC_KMER);
         constexpr int KB = 256, KI = 8;
@@ -547,13 +514,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI, true>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, d_slen);
         else if (with_hist) {
-            // tile shape of the stage-1 sort (ScatterCfg<T>::DEF2), pass-1 histograms written on the way
-            constexpr int HB = 512, HI = sizeof(T) == 4 ? 12 : 8;
-            static_assert(ScatterCfg<T>::DEF2 == (sizeof(T) == 4 ? 7 : 2), "key tile must match the scatter tile");
+            // tile shape of the stage-1 sort, pass-1 histograms written on the way
+            constexpr int HB = ScatterCfg<T>::BLOCK, HI = ScatterCfg<T>::ITEMS;
             nb = (n + HB * HI - 1) / (HB * HI);
             hipLaunchKernelGGL((key_pairs_kernel<T, HB, HI, false, true>), dim3((unsigned)nb), dim3(HB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr,
-                               reinterpret_cast<unsigned*>(w.sc.d_desc + 256), (int)(one_word ? lo1 + lead - RADIX_BITS : lo1));
+                               reinterpret_cast<unsigned*>(w.sc.d_desc + 256), (int)lo1);
         } else
             hipLaunchKernelGGL((key_pairs_kernel<T, KB, KI>), dim3((unsigned)nb), dim3(KB), 0, c->stream, d_text, n, n,
                                tab, ks, first_in.k1, k2rec, w.sc.d_partials, (const T*)nullptr);
@@ -561,21 +527,20 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_TRY(summary_finish(c, w.sc, (unsigned)nb));
         return PSACX_OK;
     };
-    if (!fused_keys) PSACX_TRY(make_keys(hist_in_keys));
+    if (!one_word) PSACX_TRY(make_keys(hist_in_keys));
 
     std::memset(r0, 0, sizeof(*r0));
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
-        bool packed1 = false;            // the sort ran in the packed form: word 1 comes back with payload bits in its low end
+        bool packed1 = false;            // the one-word sort ran: word 1 comes back without its bits below the prefix
         if constexpr (sizeof(T) == 8) {
             if (one_word) {
                 uint64_t* s1 = nullptr;
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
-                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, ks.spec, n, r0, &s1,
-                                               fused_keys ? d_text : (const uint8_t*)nullptr, n, &tab, &ks);
-                if (rc1 == PSACX_RETRY_1W) {          // (no room for the bucket tables: nothing was touched)
+                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always);
+                if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
                     one_word = false;
-                    if (fused_keys) PSACX_TRY(make_keys(false));
+                    PSACX_TRY(make_keys(hist_in_keys));
                 }
                 else {
                     PSACX_TRY(rc1);
@@ -586,7 +551,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         } else one_word = false;
         if (!one_word)
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
-                               ks.spec, n, /*summary_ready=*/true, lo1, (hist_in_keys && !hist_of_top_digit && !fused_keys) ? (int)lo1 : -1, false, pf, false, &packed1));
+                               ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
         if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
             PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         T* const S1 = sorted.k1;
@@ -673,18 +638,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- LCP of the 2k-mers + new bucket ids (suffix_array.hpp:1353-1396, bucketing.hpp:57-123)
     bool isa_hist_ready = false;
-    const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n, kn) > 0 && !kn.no_fused_l1;
+    const bool fuse_l1 = !gsa && isa_narrow_levels<T>(n, kn) > 0;
     bool lazy_ids = false;          // the rebucket kernel left out the ids of tiles without unresolved suffixes (filled in by run_compact if needed)
     // 32-bit words, normal layout: the same fusion; the pairs use two payload scratch arrays of the sort, the second level
     // the two position lists (all idle between the sort and the first compaction)
-    const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0 && !kn.no_fused_l1 && !kn.isa_partition;
+    const bool fuse32 = sizeof(T) == 4 && !gsa && !w.diet && isa_levels32(n) > 0;
     {
         ProfScope ps(c, TC_REBUCKET);
         const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
         T* const pyr1 = (WITH_LCP && w.pyr.nlev > 1) ? w.pyr.lvl[1] : (T*)nullptr;   // level 1 comes out of the rebucket kernel
         // ... and so do the tile histograms of the inversion's first radix level when the tiles agree
-        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n, kn) && (uint64_t)ScanCfg<T>::TILE == cfg_tile(ScatterCfg<T>::DEF2) && sort_cfg_env() < 0 &&
-                         !kn.no_key_hist;
+        isa_hist_ready = !fuse32 && isa_radix_levels<T>(n, kn) && (uint64_t)ScanCfg<T>::TILE == (uint64_t)ScatterCfg<T>::TILE;
         unsigned* const sa_hist = isa_hist_ready ? reinterpret_cast<unsigned*>(w.sc.d_desc + 256) : (unsigned*)nullptr;
         if (gsa) {
             PSACX_TRY((run_carries<T, false, true>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
@@ -703,9 +667,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
             PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
             uint32_t* const pk = reinterpret_cast<uint32_t*>(w.x.v);
-            lazy_ids = n >= (1ull << 22) && !kn.no_lazy_ids;
+            lazy_ids = n >= (1ull << 22);
             launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
-                                                     w.d_nunf, pyr1, pk, kn.isa_two_arrays ? pk + n : (uint32_t*)nullptr,
+                                                     w.d_nunf, pyr1, pk, (uint32_t*)nullptr,
                                                      isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors, lazy_ids ? 1 : 0);
         } else {
             PSACX_TRY((run_carries<T, false>(c, w, sorted.k1, sorted.k2, nullptr, n, d_sa, ks)));
@@ -755,7 +719,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false) -> int {
         // 64-bit words, fewer than 2^32 characters: bucket id and rank h further share one word, the suffix is a 32-bit entry --
         // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass
-        const bool both = sizeof(T) == 8 && n < (1ull << 32) && cnt >= SMALL_SORT_MAX && sort_cfg_env() < 0 && sort_mode_env() < 0 && !kn.wide_refine;
+        const bool both = sizeof(T) == 8 && n < (1ull << 32) && cnt >= SMALL_SORT_MAX;
         T* const key2 = both ? (T*)nullptr : w.x.k2;
         {
             ProfScope ps(c, TC_GATHER);
@@ -819,7 +783,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         // rounds in which at least 7/8 of the suffixes are unresolved (repetitive texts) take all n in text order, as psac's
         // doubling rounds do: the random fetch of the ranks h further and the random ISA stores turn into streams
         bool whole = !no_fast && !w.diet && have_list && w.cap_active >= n && n >= (1ull << 16) &&
-                     active >= n - n / 8 && !kn.no_whole_rounds;
+                     active >= n - n / 8;
         if (whole) {
             // ... unless SA order is nearly text order (sa_locality_kernel): 2^27 equal characters take 9.2 ms per round through
             // the list and 12.0 ms as whole rounds, a period-1024 tandem repeat 18.0 against 14.7 (profiles/r03g_*)
@@ -1053,7 +1017,6 @@ int pair_sort_dev(psacx_ctx* c, T* d_b1, T* d_b2, T* d_idx, uint64_t n, uint32_t
         sc.d_err = a.take<unsigned>(64);
         sc.d_summary = a.take<unsigned long long>(8);
         sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
-        sc.d_dbg = read_knobs().sort_debug ? a.take<unsigned long long>((n / SORT_TILE_MIN / 64 + 2) * 8) : nullptr;
     };
     SortBufs<T> alt; SortScratch sc; T* vtmp;
     layout(dry, alt, sc, vtmp);

@@ -193,14 +193,12 @@ int op_make_keys(psacx_ctx* c, const uint8_t* text, uint64_t m, uint64_t text_le
 
 template <typename T>
 int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t n, uint32_t bits1, uint32_t bits2,
-                 int32_t* where, uint32_t lo1 = 0, bool iota = false, uint64_t spec = 0, uint64_t spec_n = 0, bool v32_in = false,
-                 PackedForm pf = PackedForm(), bool packed_in = false, bool* ran_packed = nullptr) {
-    // pf / packed_in / ran_packed: the packed payload form of the first round's prefix sort (pair_sort, radix.hpp: VN 3 .. 6)
+                 int32_t* where, uint32_t lo1 = 0, bool iota = false, uint64_t spec = 0, uint64_t spec_n = 0, bool v32_in = false) {
     // lo1: the low lo1 bits of word 1 are not sorted on (prefix sort by its leading bits; bits2 is then 0)
     // iota / spec / spec_n: the first pass makes up the payload (pair_sort); v32_in: v holds 32-bit entries (two-word records)
     OP_PROLOGUE(c);
     *where = 0;
-    if (n < 2 && !iota && !v32_in && !packed_in) return PSACX_OK;      // (a made-up or 32-bit payload still has to be written out in full words)
+    if (n < 2 && !iota && !v32_in) return PSACX_OK;      // (a made-up or 32-bit payload still has to be written out in full words)
     if (n == 0) return PSACX_OK;
     PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
     SortScratch sc;
@@ -212,7 +210,6 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t
         sc.d_err = a.take<unsigned>(64);
         sc.d_summary = a.take<unsigned long long>(8);
         sc.d_partials = a.take<unsigned long long>(((size_t)(n / 2048) + 8192) * 4);
-        sc.d_dbg = nullptr;
     };
     { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_slab(c, dry.off + 4096)); }
     Arena ar(c->slab);
@@ -224,7 +221,7 @@ int op_pair_sort(psacx_ctx* c, T* k1, T* k2, T* v, T* a1, T* a2, T* av, uint64_t
     c->profile = c->profile_ops; c->ev_used = 0;
     SortBufs<T> in{k1, k2, v}, alt{a1, a2, av}, res;
     // a word with zero significant bits takes no pass
-    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, iota, bits1, bits2, nullptr, &res, nullptr, spec, spec_n, false, lo1, -1, v32_in, pf, packed_in, ran_packed));
+    PSACX_TRY(pair_sort<T>(c, sc, in, alt, n, iota, bits1, bits2, nullptr, &res, nullptr, spec, spec_n, false, lo1, -1, v32_in));
     *where = (res.k1 == k1) ? 0 : 1;
     if (res.v != (*where ? av : v))       // cannot happen without final_v, kept as a guard
         PSACX_HIP(c, hipMemcpyAsync(*where ? av : v, res.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

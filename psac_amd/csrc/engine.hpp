@@ -123,28 +123,17 @@ inline void prof_collect(psacx_ctx* c) {
     s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
 }
 
-// Tuning and test switches of a construction, read from the environment in ONE place at the start of every call (the
-// tests flip them between calls of one process, so they are not cached).  Each selects an earlier or fallback form of a
-// step that the parity suite keeps covered; none changes the result.
+// Test switches of a construction, read from the environment in ONE place at the start of every call (the tests flip them
+// between calls of one process, so they are not cached).  Each selects the fallback form of a stage that the parity suite keeps
+// covered; none changes the result.
 struct Knobs {
     bool force_diet;        // PSACX_FORCE_DIET: reduced-memory layout although the normal one fits
     uint64_t diet_cap;      // PSACX_DIET_CAP: at most this many records of room for the refinement rounds (0 = no limit)
     bool one_stage;         // PSACX_ONE_STAGE: first round as one sort over both key words
     bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
-    bool no_key_hist;       // PSACX_NO_KEY_HIST: no tile histograms out of the key / rebucket kernels
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
-    bool no_lazy_ids;       // PSACX_NO_LAZY_IDS: rebucket_first_kernel writes the bucket ids of every tile, resolved or not
-    bool no_fused_keys;     // PSACX_NO_FUSED_KEYS: one-word prefix sort with word 1 written by key_pairs_kernel and read back by the pass on the top digit
+    bool one_word_always;   // PSACX_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
-    unsigned lead_slack;    // PSACX_LEAD_SLACK (default 2)
-    bool isa_partition;     // PSACX_ISA_PARTITION: 32-bit words: reservation levels instead of radix levels / the fused form
-    bool isa_wide;          // PSACX_ISA_WIDE: 64-bit words: pairs stay 64-bit
-    bool no_fused_l1;       // PSACX_NO_FUSED_L1: first inversion level as its own kernel
-    bool no_rmq_aux;        // PSACX_NO_RMQ_AUX: range minima without the running-minimum tables
-    bool isa_two_arrays;    // PSACX_ISA_TWO_ARRAYS: the 32-bit pairs of the SA -> ISA levels in two arrays instead of one of packed entries
-    bool wide_refine;       // PSACX_WIDE_REFINE: refinement records of 64-bit words keep their three words below 2^32 characters too
-    bool no_whole_rounds;   // PSACX_NO_WHOLE_ROUNDS: rounds with almost every suffix unresolved still go through the list of unresolved positions
-    bool sort_debug;        // PSACX_SORT_DEBUG: phase stamps of sampled scatter tiles
 };
 inline Knobs read_knobs() {
     Knobs k;
@@ -153,21 +142,10 @@ inline Knobs read_knobs() {
     k.diet_cap = e ? strtoull(e, nullptr, 10) : 0;
     k.one_stage = getenv("PSACX_ONE_STAGE") != nullptr;
     k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
-    k.no_key_hist = getenv("PSACX_NO_KEY_HIST") != nullptr;
     k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
-    k.no_fused_keys = getenv("PSACX_NO_FUSED_KEYS") != nullptr;
-    k.no_lazy_ids = getenv("PSACX_NO_LAZY_IDS") != nullptr;
-    k.one_word_min = getenv("PSACX_ONE_WORD_MIN") ? (unsigned)std::max(16, atoi(getenv("PSACX_ONE_WORD_MIN"))) : 24u;
-    e = getenv("PSACX_LEAD_SLACK");
-    k.lead_slack = e ? (unsigned)atoi(e) : 2u;
-    k.isa_partition = getenv("PSACX_ISA_PARTITION") != nullptr;
-    k.isa_wide = getenv("PSACX_ISA_WIDE") != nullptr;
-    k.no_fused_l1 = getenv("PSACX_NO_FUSED_L1") != nullptr;
-    k.no_rmq_aux = getenv("PSACX_NO_RMQ_AUX") != nullptr;
-    k.no_whole_rounds = getenv("PSACX_NO_WHOLE_ROUNDS") != nullptr;
-    k.isa_two_arrays = getenv("PSACX_ISA_TWO_ARRAYS") != nullptr;
-    k.wide_refine = getenv("PSACX_WIDE_REFINE") != nullptr;
-    k.sort_debug = getenv("PSACX_SORT_DEBUG") != nullptr;
+    k.one_word_always = getenv("PSACX_ONE_WORD_ALWAYS") != nullptr;
+    e = getenv("PSACX_ONE_WORD_MIN");
+    k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     return k;
 }
 
@@ -352,7 +330,6 @@ struct SortScratch {
     unsigned* d_err;
     unsigned long long* h_hist;    // pinned
     unsigned long long* h_base;    // pinned
-    unsigned long long* d_dbg;     // phase stamps of sampled tiles (PSACX_SORT_DEBUG), may be null
     unsigned long long* d_summary; // OR/AND of the keys (see key_summary_add), 4 words
     unsigned long long* h_summary; // pinned, 4 words
     unsigned long long* d_partials;// per-workgroup key summaries of the producer kernel
@@ -370,16 +347,8 @@ inline size_t sort_desc_bytes(uint64_t n) {
     return b;
 }
 
-inline bool sort_host_scan_env() { static const bool on = getenv("PSACX_SORT_HOST_SCAN") != nullptr; return on; }
-
-inline unsigned sort_chunk_env() {   // tiles per XCD-local chunk (0 = plain ticket order)
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("PSACX_SORT_CHUNK"); v = e ? atoi(e) : -1; }
-    return (unsigned)v;
-}
+// tiles per XCD-local chunk of the tile queue (dev_common.hpp: claim_tile; 0 = plain ticket order)
 inline unsigned sort_chunk_for(uint64_t n, bool three) {
-    const unsigned e = sort_chunk_env();
-    if (e != (unsigned)-1) return e;
     if (n < (1ull << 21)) return 0;          // few tiles: plain start order
     return three ? 64u : 16u;
 }
@@ -396,90 +365,25 @@ inline void launch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
                        sort_chunk_for(n, false));
 }
 
-template <typename T> struct ScatterCfg;
-// DEF: three-word records, DEF2: two-word records.  Measured per word size: uint32 512 x 12; uint64 512 x 8
-// (two-word: 3.8 ms per 2^29-record pass against 5.2 ms with 256 x 8; three-word: 2.35 against 2.60 ms at 2^28,
-// 22 against 32 ms at 2^31, 47 against 78 ms at 2^32 where the smaller tiles hit a stride artefact)
-template <> struct ScatterCfg<uint32_t> { static constexpr int DEF = 7; static constexpr int DEF2 = 7; };
-template <> struct ScatterCfg<uint64_t> { static constexpr int DEF = 2; static constexpr int DEF2 = 2; };
-
-inline int sort_cfg_env() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("PSACX_SORT_CFG"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
-// Packed payload of the first round's prefix sort (radix.hpp: VN 3 .. 6): the low `bits` bits of word 1 lie below the sorted
-// prefix and carry the low bits of the suffix a record stands for, `bytes` (1 or 2) = size of the entries that hold the rest.
-// bytes == 0: not packed.
-struct PackedForm {
-    unsigned bits = 0, bytes = 0;
-    bool local = true;      // records that arrive packed stay packed between the passes of the local sort (else its first pass widens them)
-    bool on() const { return bytes != 0; }
-};
-// the form for payloads below `count` when the low lo1 bits of a 64-bit word 1 are free; none when more than 16 bits remain.
-// Measured on one GPU (4 GiB DNA, uint64, profiles/r03c_*): a pass over (8-byte word, 1-byte entry) records takes 32.4 ms
-// against 28.0 ms for (8-byte word, 32-bit entry) records although it moves 18 instead of 24 bytes per record, and 33.5 ms
-// with 2-byte entries (profiles/r03d_*): entries narrower than 32 bits cost more than they save in this scatter pattern --
-// so the one-GPU engine keeps its 32-bit payloads and the packed form is for the multi-GPU shuffle of texts beyond 2^32
-// characters, where the alternative is a 64-bit payload on the wire; there the first pass of the local sort widens the
-// entries again (two ranks of 2^31 + 2^20 characters: local sort 214 ms packed throughout against 184 ms)
-// (PSACX_PACKED=1 / 0 forces the form on / off wherever it applies, PSACX_PACKED_LOCAL=1 keeps the local passes packed).
-inline PackedForm packed_form_for(uint64_t count, unsigned lo1, size_t word_bytes, bool by_default) {
-    PackedForm pf;
-    const char* e = getenv("PSACX_PACKED");
-    const bool on = e ? atoi(e) != 0 : by_default;
-    if (!on || word_bytes != 8 || lo1 == 0) return pf;
-    const unsigned need = bits_for(count > 1 ? count - 1 : 1);
-    const unsigned rest = need > lo1 ? need - lo1 : 0;
-    if (rest > 16) return pf;
-    pf.bits = lo1 < 63 ? lo1 : 63; pf.bytes = rest > 8 ? 2 : 1;
-    if (const char* b = getenv("PSACX_PACKED_BYTES")) if (atoi(b) == 2) pf.bytes = 2;      // (measurements: 16-bit entries where 8 would do)
-    pf.local = getenv("PSACX_PACKED_LOCAL") != nullptr;
-    return pf;
-}
-
-struct ScatterShape { int block, items; };
-// scatter configurations selectable with PSACX_SORT_CFG (tuning aid)
-static const ScatterShape kShapes[] = {{256, 8}, {256, 16}, {512, 8}, {512, 16}, {256, 12}, {1024, 4}, {1024, 8}, {512, 12}};
-constexpr int N_SHAPES = 8;   // (register caps through __launch_bounds__ were measured: spills cost 1.6-3x)
-
-inline uint64_t cfg_tile(int cfg) {
-    if (cfg < 0 || cfg >= N_SHAPES) cfg = 1;
-    return (uint64_t)kShapes[cfg].block * kShapes[cfg].items;
-}
+// Tile shape of the scatter passes, measured per word size: uint32 512 x 12; uint64 512 x 8 (two-word: 3.8 ms per 2^29-record
+// pass against 5.2 ms with 256 x 8; three-word: 2.35 against 2.60 ms at 2^28, 22 against 32 ms at 2^31, 47 against 78 ms at 2^32
+// where the smaller tiles hit a stride artefact; register caps through __launch_bounds__ were measured: spills cost 1.6-3x)
+template <typename T> struct ScatterCfg { static constexpr int BLOCK = 512, ITEMS = sizeof(T) == 4 ? 12 : 8, TILE = BLOCK * ITEMS; };
 
 template <typename T, typename D>
-inline void dispatch_scatter(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in,
-                             T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
-                             const unsigned long long* base, char* desc, unsigned* err, unsigned long long* dbg,
-                             uint64_t spec, uint64_t spec_n) {
-#define PSACX_SC(B, I) launch_scatter<T, D, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, dbg, spec, spec_n)
-    switch (cfg) {
-        case 0: PSACX_SC(256, 8); break;
-        case 2: PSACX_SC(512, 8); break;
-        case 3: PSACX_SC(512, 16); break;
-        case 4: PSACX_SC(256, 12); break;
-        case 5: PSACX_SC(1024, 4); break;
-        case 6: PSACX_SC(1024, 8); break;
-        case 7: PSACX_SC(512, 12); break;
-        case 1:
-        default: PSACX_SC(256, 16); break;
-    }
-#undef PSACX_SC
+inline void dispatch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
+                             const unsigned long long* base, char* desc, unsigned* err) {
+    launch_scatter<T, D, ScatterCfg<T>::BLOCK, ScatterCfg<T>::ITEMS>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, nullptr, 0, 0);
 }
 
-inline int sort_mode_env() {     // 0 = single-sweep with look-back, 1 = three kernels per pass
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("PSACX_SORT_MODE"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
-template <typename T, int BLOCK, int ITEMS, int MINW = 1>
-inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
-                         uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                         unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0, unsigned pack = 0) {
-    constexpr int TILE = BLOCK * ITEMS;
+// One pass of the three-kernel form: tile histograms (unless the producer of the keys left them), slab / top scans, scatter.
+// vn (64-bit words, two-word records): 0 = word payloads, 1 = 32-bit payload entries on both sides, 2 = 32-bit entries in and
+// words out (radix.hpp: VN).
+template <typename T>
+inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
+                           uint64_t n, int shift, const unsigned long long* base, char* scratch, uint64_t spec, uint64_t spec_n,
+                           bool have_hist = false, int vn = 0) {
+    constexpr int BLOCK = ScatterCfg<T>::BLOCK, ITEMS = ScatterCfg<T>::ITEMS, TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const unsigned slab_tiles = slab_tiles_for(ntiles);
     const uint64_t nslabs = (ntiles + slab_tiles - 1) / slab_tiles;
@@ -495,54 +399,30 @@ inline void launch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* 
                            const_cast<unsigned long long*>(base));
     }
     ProfScope ps(c, ko_in ? TC_SORT_SCATTER3 : TC_SORT_SCATTER2);
-    constexpr bool DEF_SHAPE = BLOCK == 512 && ITEMS == (sizeof(T) == 4 ? 12 : 8);
-    constexpr bool NARROW_OK = DEF_SHAPE && sizeof(T) == 8;       // 32-bit payload arrays (radix.hpp: VN), default shape only (8192-record tiles measured: 33.6-34.9 against 28.1 ms per pass)
-    if (NARROW_OK && vn && !ko_in) {
-        // (radix.hpp: VN -- 1 / 2: 32-bit payload entries; 3 .. 6: payload packed into the low bits of the key word + 8- or 16-bit entries)
-        // registers capped for six waves per SIMD = three workgroups per CU: the narrow forms need 82, the cap costs them a
-        // few spilled registers and gains a third tile in flight (the pass is bound by the latency chain of a tile)
-#define PSACX_VN(V)                                                                                                                          \
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, (NARROW_OK ? 6 : MINW), true, NARROW_OK ? V : 0>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, \
-                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,                    \
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles, (uint64_t)0, pack)
-        switch (vn) {
-            case 1: PSACX_VN(1); break;
-            case 2: PSACX_VN(2); break;
-            case 3: PSACX_VN(3); break;
-            case 4: PSACX_VN(4); break;
-            case 5: PSACX_VN(5); break;
-            default: PSACX_VN(6); break;
+    unsigned* const counter = reinterpret_cast<unsigned*>(scratch);
+    const unsigned chunk = sort_chunk_for(n, true);
+    if constexpr (sizeof(T) == 8) {
+        // 32-bit payload arrays: registers capped for six waves per SIMD = three workgroups per CU: the narrow forms need 82, the cap
+        // costs them a few spilled registers and gains a third tile in flight (the pass is bound by the latency chain of a tile)
+        if (vn == 1 && !ko_in) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 6, true, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, ko_in, v_in, kd_out,
+                               ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n, counter, chunk, (const T*)nullptr, slab_tiles);
+            return;
         }
-#undef PSACX_VN
-        return;
+        if (vn == 2 && !ko_in) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 6, true, 2>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, ko_in, v_in, kd_out,
+                               ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n, counter, chunk, (const T*)nullptr, slab_tiles);
+            return;
+        }
     }
     if (ko_in)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
+                           counter, chunk, (const T*)nullptr, slab_tiles);
     else            // two-word records (k1, v): the prefix sort of the first round
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, MINW, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
-                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, dbg, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const T*)nullptr, slab_tiles);
-}
-
-template <typename T>
-inline void dispatch_pass3(psacx_ctx* c, int cfg, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out,
-                           T* v_out, uint64_t n, int shift, const unsigned long long* base, char* scratch,
-                           unsigned long long* dbg, uint64_t spec, uint64_t spec_n, bool have_hist = false, int vn = 0, unsigned pack = 0) {
-#define PSACX_P3(B, I) launch_pass3<T, B, I>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, scratch, dbg, spec, spec_n, have_hist, vn, pack)
-    switch (cfg) {
-        case 0: PSACX_P3(256, 8); break;
-        case 2: PSACX_P3(512, 8); break;
-        case 3: PSACX_P3(512, 16); break;
-        case 4: PSACX_P3(256, 12); break;
-        case 5: PSACX_P3(1024, 4); break;
-        case 6: PSACX_P3(1024, 8); break;
-        case 7: PSACX_P3(512, 12); break;
-        case 1:
-        default: PSACX_P3(256, 16); break;
-    }
-#undef PSACX_P3
+        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1, true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                           ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
+                           counter, chunk, (const T*)nullptr, slab_tiles);
 }
 
 // One pass that groups records by an externally supplied 8-bit class (cls[i] < 256), stable.
@@ -578,14 +458,14 @@ int class_partition(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> o
     return PSACX_OK;
 }
 
-// The shuffle pass of the two-word first round (multi.hpp: sort_first_two_word): the records k1[0 .. n) of one piece of a
-// rank's block are grouped by the destination in the byte array cls (stable), their payload -- the suffix a record stands
-// for -- is made up on the way (spec / spec_n / voff as in radix_scatter_tile) and leaves as 32-bit entries when v32.
-// The per-class totals of the piece are known already (classify_prefix_kernel), so nothing comes back to the host.
+// The shuffle pass of the two-word first round (multi.hpp: sort_first_two_word): the records k1[0 .. n) of a rank's block are
+// grouped by the destination in the byte array cls (stable), their payload -- the suffix a record stands for -- is made up on the
+// way (spec / spec_n / voff as in radix_scatter_tile) and leaves as 32-bit entries when v32.
+// The per-class totals are known already (classify_prefix_kernel), so nothing comes back to the host.
 template <typename T>
 int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, const T* k1, const uint8_t* cls, uint64_t n, T* k1_out, void* v_out,
-                    bool v32, uint64_t spec, uint64_t spec_n, uint64_t voff, PackedForm pf = PackedForm()) {
-    constexpr int BLOCK = 512, ITEMS = sizeof(T) == 4 ? 12 : 8, TILE = BLOCK * ITEMS;
+                    bool v32, uint64_t spec, uint64_t spec_n, uint64_t voff) {
+    constexpr int BLOCK = ScatterCfg<T>::BLOCK, ITEMS = ScatterCfg<T>::ITEMS, TILE = BLOCK * ITEMS;
     if (n == 0) return PSACX_OK;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const unsigned slab_tiles = slab_tiles_for(ntiles);
@@ -597,15 +477,7 @@ int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, con
     hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
     hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, slab_tot, nslabs, d_base);
     const T* dsrc = reinterpret_cast<const T*>(cls);
-    if (sizeof(T) == 8 && pf.bytes == 1)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 3 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
-                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
-                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
-    else if (sizeof(T) == 8 && pf.bytes == 2)
-        hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 5 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
-                           (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
-                           (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff, pf.bits);
-    else if (sizeof(T) == 8 && v32)
+    if (sizeof(T) == 8 && v32)
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, true, 1, true, (sizeof(T) == 8 ? 1 : 0), 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, k1,
                            (const T*)nullptr, (const T*)nullptr, k1_out, (T*)nullptr, static_cast<T*>(v_out), n, 0, d_base, tile_hist, slab_tot,
                            (unsigned long long*)nullptr, spec, spec_n, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), dsrc, slab_tiles, voff);
@@ -621,7 +493,7 @@ int piece_partition(psacx_ctx* c, char* scratch, unsigned long long* d_base, con
 // Default: three kernels for large inputs (no workgroup ever waits on another), look-back for small ones where the
 // launch count matters more; records without a second key word exist only in the three-kernel form.
 inline bool sort_is_three(uint64_t n, bool has_k2) {
-    return !has_k2 || (sort_mode_env() >= 0 ? sort_mode_env() == 1 : n >= SMALL_SORT_MAX);
+    return !has_k2 || n >= SMALL_SORT_MAX;
 }
 
 // folds the per-workgroup key summaries a producer kernel left in sc.d_partials into sc.d_summary
@@ -636,39 +508,34 @@ inline int summary_finish(psacx_ctx* c, SortScratch& sc, unsigned nblocks) {
 // set, the suffix start the first-round record stands for (in.v is only scratch).  The sorted arrays end up in
 // *res (the `in` or the `alt` set); when final_v is given the payload of the last
 // executed pass is written there instead and res->v == final_v.
+// v32_in (64-bit words, two-word records): in.v holds 32-bit entries (payloads below 2^32: the suffixes of a text of at most 2^32
+// characters after the multi-GPU shuffle, the suffixes of refinement records); they stay 32-bit between the passes and the last
+// pass widens them, as for a payload the first pass makes up.
+// ready_hist_shift >= 0: the tile histograms of word 1 at that bit position are already in the scratch (written by
+// key_pairs_kernel<..., HIST> with the tile shape of this sort).
 template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
               uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0,
-              int ready_hist_shift = -1, bool v32_in = false, PackedForm pf = PackedForm(), bool packed_in = false, bool* ran_packed = nullptr) {
-    // pf.on(): two-word records of 64-bit words whose payload travels packed (radix.hpp: VN 3 .. 6): made up and packed by
-    // the first pass (iota), or arriving that way in in.k1 / in.v (packed_in: after the multi-GPU shuffle); put together
-    // again by the last pass
-    // v32_in (64-bit words, two-word records): in.v holds 32-bit entries (payloads below 2^32 that arrived that way, the
-    // suffixes of a text of at most 2^32 characters after the multi-GPU shuffle); they stay 32-bit between the passes and the
-    // last pass widens them, as for a payload the first pass makes up
-    // ready_hist_shift >= 0: the tile histograms of word 1 at that bit position are already in the scratch
-    // (written by key_pairs_kernel<..., HIST> with the tile shape of this sort)
+              int ready_hist_shift = -1, bool v32_in = false) {
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
     if (!in.k2) bits2 = 0;
     const PassPlan plan = make_plan((int)bits1, (int)bits2, (int)lo1);
-    // default: three-kernel passes (no workgroup ever waits on another) for large inputs, the
-    // single-sweep look-back form for small ones where launch count matters more
-    // (records without a second key word exist only in the three-kernel form)
+    // three-kernel passes (no workgroup ever waits on another) for large inputs, the single-sweep look-back form for small ones
+    // where the launch count matters more (records without a second key word exist only in the three-kernel form)
     const bool three = sort_is_three(n, in.k2 != nullptr);
     bool skip[MAX_PASSES];
     int n_exec = 0;
     // look-back form: digit starts scanned on the device, one descriptor region per pass (zeroed by one memset together
     // with the histograms); the host only learns which passes have a constant digit (flags the scan kernel stores into
     // pinned host memory).  Needs the scratch laid out as carve() lays it out.
-    int cfg = sort_cfg_env();
-    if (cfg < 0) cfg = in.k2 ? ScatterCfg<T>::DEF : ScatterCfg<T>::DEF2;
     // (2048-record tiles for the small sorts were measured: three times the look-back chain, 0.27 -> 0.29 ms per round at 2^20)
+    constexpr uint64_t TILE = ScatterCfg<T>::TILE;
     const bool small_desc = n < (1ull << 30);
     const size_t hist_bytes = sizeof(unsigned long long) * MAX_PASSES * RADIX;
-    const size_t desc_stride = (256 + ((n + cfg_tile(cfg) - 1) / cfg_tile(cfg)) * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t)) + 255) & ~(size_t)255;
-    const bool dev_scan = !three && !sort_host_scan_env() && !sc.d_dbg && c->pinned_dev && c->pinned_bytes >= 512 &&
+    const size_t desc_stride = (256 + ((n + TILE - 1) / TILE) * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t)) + 255) & ~(size_t)255;
+    const bool dev_scan = !three && c->pinned_dev && c->pinned_bytes >= 512 &&
                           reinterpret_cast<char*>(sc.d_base) == reinterpret_cast<char*>(sc.d_hist) + hist_bytes &&
                           sc.d_desc == reinterpret_cast<char*>(sc.d_base) + hist_bytes &&
                           (size_t)plan.n_pass * desc_stride <= sc.desc_bytes;
@@ -689,65 +556,55 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             skip[p] = ((diff >> plan.shift[p]) & (RADIX - 1)) == 0;
             if (!skip[p]) ++n_exec;
         }
-    } else if (dev_scan) {
-        HistArgs ha;
-        ha.n_pass = plan.n_pass;
-        for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
-        {
-            ProfScope ps(c, TC_SORT_HIST);
-            PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, 2 * hist_bytes + (size_t)plan.n_pass * desc_stride, c->stream));
-            const int grid = grid_for(c, (n + 3) / 4, 256, 8);
-            hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n, ha, sc.d_hist);
-            hipLaunchKernelGGL(radix_hist_scan_kernel<0>, dim3(plan.n_pass), dim3(RADIX), 0, c->stream, sc.d_hist, sc.d_base,
-                               (unsigned long long)n, reinterpret_cast<unsigned*>(c->pinned_dev + 384));
-            PSACX_HIP(c, hipGetLastError());
-        }
-        PSACX_HIP(c, hipStreamSynchronize(c->stream));
-        const unsigned* constant = reinterpret_cast<const unsigned*>(c->pinned + 384);
-        for (int p = 0; p < plan.n_pass; ++p) { skip[p] = constant[p] != 0; if (!skip[p]) ++n_exec; }
-        c->stats.hist_bytes += 2ull * sizeof(T) * n;
     } else {
         HistArgs ha;
         ha.n_pass = plan.n_pass;
         for (int p = 0; p < plan.n_pass; ++p) { ha.word[p] = plan.word[p]; ha.shift[p] = plan.shift[p]; }
-        {
-            ProfScope ps(c, TC_SORT_HIST);
-            PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
-            const int grid = grid_for(c, (n + 3) / 4, 256, 8);
-            hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n,
-                               ha, sc.d_hist);
-            PSACX_HIP(c, hipGetLastError());
-        }
-        PSACX_HIP(c, hipMemcpyAsync(sc.h_hist, sc.d_hist, sizeof(unsigned long long) * plan.n_pass * RADIX,
-                                    hipMemcpyDeviceToHost, c->stream));
-        PSACX_HIP(c, hipStreamSynchronize(c->stream));
-        c->stats.hist_bytes += 2ull * sizeof(T) * n;
-        for (int p = 0; p < plan.n_pass; ++p) {
-            const unsigned long long* h = sc.h_hist + (size_t)p * RADIX;
-            unsigned long long run = 0;
-            skip[p] = false;
-            for (int d = 0; d < RADIX; ++d) {
-                if (h[d] == n) skip[p] = true;
-                sc.h_base[(size_t)p * RADIX + d] = run;
-                run += h[d];
+        if (dev_scan) {
+            {
+                ProfScope ps(c, TC_SORT_HIST);
+                PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, 2 * hist_bytes + (size_t)plan.n_pass * desc_stride, c->stream));
+                const int grid = grid_for(c, (n + 3) / 4, 256, 8);
+                hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n, ha, sc.d_hist);
+                hipLaunchKernelGGL(radix_hist_scan_kernel<0>, dim3(plan.n_pass), dim3(RADIX), 0, c->stream, sc.d_hist, sc.d_base,
+                                   (unsigned long long)n, reinterpret_cast<unsigned*>(c->pinned_dev + 384));
+                PSACX_HIP(c, hipGetLastError());
             }
-            if (!skip[p]) ++n_exec;
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            const unsigned* constant = reinterpret_cast<const unsigned*>(c->pinned + 384);
+            for (int p = 0; p < plan.n_pass; ++p) { skip[p] = constant[p] != 0; if (!skip[p]) ++n_exec; }
+        } else {
+            // (the scratch is not laid out for the device-side scan, or the device cannot store into the pinned words: digit starts on the host)
+            {
+                ProfScope ps(c, TC_SORT_HIST);
+                PSACX_HIP(c, hipMemsetAsync(sc.d_hist, 0, sizeof(unsigned long long) * MAX_PASSES * RADIX, c->stream));
+                const int grid = grid_for(c, (n + 3) / 4, 256, 8);
+                hipLaunchKernelGGL((radix_hist_kernel<T, 256>), dim3(grid), dim3(256), 0, c->stream, in.k1, in.k2, n, ha, sc.d_hist);
+                PSACX_HIP(c, hipGetLastError());
+            }
+            PSACX_HIP(c, hipMemcpyAsync(sc.h_hist, sc.d_hist, sizeof(unsigned long long) * plan.n_pass * RADIX, hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipStreamSynchronize(c->stream));
+            for (int p = 0; p < plan.n_pass; ++p) {
+                const unsigned long long* h = sc.h_hist + (size_t)p * RADIX;
+                unsigned long long run = 0;
+                skip[p] = false;
+                for (int d = 0; d < RADIX; ++d) {
+                    if (h[d] == n) skip[p] = true;
+                    sc.h_base[(size_t)p * RADIX + d] = run;
+                    run += h[d];
+                }
+                if (!skip[p]) ++n_exec;
+            }
+            if (n_exec) PSACX_HIP(c, hipMemcpyAsync(sc.d_base, sc.h_base, sizeof(unsigned long long) * plan.n_pass * RADIX, hipMemcpyHostToDevice, c->stream));
         }
-        if (n_exec) {
-            PSACX_HIP(c, hipMemcpyAsync(sc.d_base, sc.h_base, sizeof(unsigned long long) * plan.n_pass * RADIX,
-                                        hipMemcpyHostToDevice, c->stream));
-        }
+        c->stats.hist_bytes += 2ull * sizeof(T) * n;
     }
     if (rs) { rs->sort_passes = (uint32_t)n_exec; rs->sort_passes_skipped = (uint32_t)(plan.n_pass - n_exec); }
 
     // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
-    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in) && cfg == ScatterCfg<T>::DEF2;
+    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in);
     if (v32_in && !narrow) return PSACX_EINVAL;
-    const bool packed = pf.on() && three && sizeof(T) == 8 && !in.k2 && (iota || packed_in) && cfg == ScatterCfg<T>::DEF2 && pf.bits <= lo1;
-    if (packed_in && !packed) return PSACX_EINVAL;
-    // (a sort of one executed pass makes its payload up in full and leaves word 1 as it is)
-    if (ran_packed) *ran_packed = packed && (packed_in || n_exec > 1);
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
     for (int p = 0; p < plan.n_pass; ++p) {
@@ -761,48 +618,27 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         T* kd_out = plan.word[p] ? oth.k2 : oth.k1;
         T* ko_out = plan.word[p] ? oth.k1 : oth.k2;
         T* v_out = (last && final_v) ? final_v : oth.v;
-        const uint64_t tile = cfg_tile(cfg);
-        const uint64_t ntiles = (n + tile - 1) / tile;
+        const uint64_t ntiles = (n + TILE - 1) / TILE;
         const size_t dbytes = 256 + ntiles * RADIX * (small_desc ? sizeof(uint32_t) : sizeof(uint64_t));
         char* const desc = dev_scan ? sc.d_desc + (size_t)(done - 1) * desc_stride : sc.d_desc;
         if (!dev_scan) PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
+        const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
         if (three) {
-            const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
-            const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift && sort_cfg_env() < 0;
-            int vn = narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
-            const bool widen_first = packed && packed_in && !pf.local;      // packed on the wire only
-            if (widen_first) vn = first ? (pf.bytes == 1 ? 4 : 6) : 0;
-            else if (packed) vn = last ? ((first && !packed_in) ? 0 : (pf.bytes == 1 ? 4 : 6)) : (pf.bytes == 1 ? 3 : 5);
-            dispatch_pass3<T>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, sc.d_dbg, spec, spec_n,
-                              have_hist, vn, pf.bits);
+            const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift;
+            const int vn = narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
+            dispatch_pass3<T>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, spec, spec_n, have_hist, vn);
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
-            const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
-            if (small_desc)
-                dispatch_scatter<T, uint32_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, sc.d_dbg, spec, spec_n);
-            else
-                dispatch_scatter<T, uint64_t>(c, cfg, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, sc.d_dbg, spec, spec_n);
+            if (small_desc) dispatch_scatter<T, uint32_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err);
+            else dispatch_scatter<T, uint64_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err);
             PSACX_HIP(c, hipGetLastError());
-        }
-        if (sc.d_dbg && ntiles >= 64) {
-            // tuning aid: average shader-clock span of each phase over the sampled tiles
-            const size_t ns = (size_t)(ntiles / 64);
-            std::vector<unsigned long long> h(ns * 8);
-            PSACX_HIP(c, hipMemcpyAsync(h.data(), sc.d_dbg, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
-            PSACX_HIP(c, hipStreamSynchronize(c->stream));
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (size_t i = 0; i < ns; ++i) for (int q = 0; q < 6; ++q) acc[q] += (double)(h[i * 8 + q + 1] - h[i * 8 + q]);
-            fprintf(stderr, "[psacx sort dbg] pass %d n=%llu tiles=%llu cycles/tile: load+rank %.0f scan %.0f lookback %.0f key %.0f key2 %.0f val %.0f\n",
-                    p, (unsigned long long)n, (unsigned long long)ntiles, acc[0] / ns, acc[1] / ns, acc[2] / ns, acc[3] / ns, acc[4] / ns, acc[5] / ns);
         }
         const int form = !in.k2 ? 2 : (three ? 1 : 0);
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        if (packed && packed_in && !pf.local) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (first ? (uint64_t)pf.bytes : sizeof(T)) + sizeof(T)) * n;
-        else if (packed) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? (uint64_t)pf.bytes : 0ull) + (last ? sizeof(T) : (uint64_t)pf.bytes)) * n;
-        else if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
         else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;
@@ -813,11 +649,6 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         if (iota) {
             hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
-        } else if (packed_in) {
-            T* const w = (dst == cur.v) ? oth.v : dst;
-            hipLaunchKernelGGL((unpack_payload_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const T*)cur.k1, (const void*)cur.v, n, pf.bits, pf.bytes, w);
-            PSACX_HIP(c, hipGetLastError());
-            if (w != dst) PSACX_HIP(c, hipMemcpyAsync(dst, w, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         } else if (v32_in) {
             // (32-bit entries in, words out: through the other payload array when the widening would run in place)
             T* const w = (dst == cur.v) ? oth.v : dst;
@@ -834,16 +665,17 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 }
 
 // ----------------------------------------------------------------------------
-// Prefix sort of the first round in one-word records, most significant digit first (radix.hpp: VN 7 .. 9, *1w kernels).
+// Prefix sort of the first round in one-word records, most significant digit first (radix.hpp: VN 8 .. 10, *1w kernels).
 // The two-stage first round sorts (word 1, suffix) on the `lead` bits of word 1 above bit lo1 and reads nothing below them
 // afterwards (ties get their windows from the text again).  With lead - 8 <= 32 and suffixes below 2^32 a record fits ONE
-// 64-bit word once the top digit of the prefix is known from the record's place: pass 0 partitions k1 by the top digit and writes
-// (rest of the prefix) << 32 | suffix; the remaining digits are LSD passes inside the 256 buckets, all buckets in one launch; the
-// last of them writes word 1 (prefix << lo1, low bits zero: the packed form of the ties machinery) and the suffixes as words.
-// Bytes per record: 16 + (lead / 8 - 2) x 16 + 24 instead of (lead / 8 - 1) x 24 + 28 (and 8 per pass for the histograms as before).
-// k0: word 1 of every record in record order (destroyed); a: scratch of n words; *s1: whichever of the two holds the sorted word 1; sa_out: sorted
-// suffixes.  The tile histograms of the top digit (shift lo1 + lead - 8) must be in the scratch (key_pairs_kernel<..., HIST>).
-// Returns PSACX_RETRY_1W without having touched k0 when the scratch has no room for the bucket tables.
+// 64-bit word once the top digit of the prefix is known from the record's place: the pass on the top digit computes word 1 of its
+// tile in registers straight from the text (sa_kernels.hpp: key_scatter1w_kernel; the tile histograms of that digit come from the
+// text too, top_digit_hist_kernel) and writes (rest of the prefix) << sfield | suffix; the remaining digits are LSD passes inside the
+// 256 buckets, all buckets in one launch; the last of them writes word 1 (prefix << lo1, low bits zero) and the suffixes as words.
+// Bytes per record: 1 + 8, then (lead / 8 - 2) x 16 + 24, and 8 per bucket pass for its histograms.
+// k0, a: two scratch arrays of n words; *s1: whichever holds the sorted word 1; sa_out: sorted suffixes.
+// Returns PSACX_RETRY_1W without having written anything when the text repeats itself massively (probe) or the scratch has no room
+// for the bucket tables.
 constexpr int PSACX_RETRY_1W = 1001;
 #ifndef PSACX_1W_ITEMS
 #define PSACX_1W_ITEMS 8
@@ -914,6 +746,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
         }
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * nrec;
+        c->stats.onew_passes += 1;
         std::swap(cur, oth);
     }
     *s1 = cur;
@@ -922,40 +755,37 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
 // text != nullptr (fused front end, sa_kernels.hpp: key_scatter1w_kernel): k0 holds nothing yet -- the histograms of the top digit come
 // from the text and pass 0 computes word 1 of its tile in registers (no key_pairs_kernel launch, 16 bytes per record less).
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
-                          uint64_t spec, uint64_t spec_n, psacx_round* rs, uint64_t** s1, const uint8_t* text = nullptr, uint64_t n_text = 0,
-                          const CodeTable* tab = nullptr, const KeyShape* ks = nullptr) {
-    constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // pass 0 (the tile key_pairs_kernel / key_scatter1w_kernel use)
+                          psacx_round* rs, uint64_t** s1, const uint8_t* text, uint64_t n_text, const CodeTable& tab, const KeyShape& ks, bool probe) {
+    constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // the pass on the top digit
     // (bucket passes with other tiles, measured at 2^32 records: 512 x 6 -- 62 VGPRs, four workgroups per CU -- 106 ms for the five
     //  passes against 89 ms; 512 x 12 -- two workgroups per CU -- 89 ms: the run length gained is the occupancy lost)
-    constexpr int ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;        // bucket passes
+    constexpr int TILE = BLOCK * PSACX_1W_ITEMS;        // bucket passes
     const unsigned low = lead - RADIX_BITS;            // prefix bits that stay in the word
     const unsigned sfield = 64 - low;                  // the payload field takes the rest (32 bits when lead = 40)
     const uint64_t ntiles = (n + TILE0 - 1) / TILE0;
     char* const scratch = sc.d_desc;
-    // pass 0: offsets from the histograms key_pairs_kernel left, top digit
     const unsigned slab0 = slab_tiles_for(ntiles);
     const uint64_t nslabs0 = (ntiles + slab0 - 1) / slab0;
     unsigned* tile_hist0 = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot0 = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     unsigned long long* base0 = sc.d_base;
-    if (text) {
+    {
         // a text that repeats itself massively (every sampled prefix seen before) keeps the two-array passes: see prefix_dup_probe_kernel
         ProfScope ps(c, TC_KMER);
         const uint64_t stride = std::max<uint64_t>(64, n >> 20), samples = n / stride;
         uint64_t slots = 1; while (slots < 4 * samples) slots <<= 1;
         unsigned long long* table = reinterpret_cast<unsigned long long*>(scratch + 256);
         unsigned long long* d_dups = reinterpret_cast<unsigned long long*>(scratch + 128);
-        if (256 + slots * 8 <= sc.desc_bytes && samples >= 1024 && !getenv("PSACX_ONE_WORD_ALWAYS")) {      // (the switch: tests of the tie paths)
+        if (256 + slots * 8 <= sc.desc_bytes && samples >= 1024 && probe) {
             PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256 + slots * 8, c->stream));
-            hipLaunchKernelGGL((prefix_dup_probe_kernel<uint64_t>), dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, c->stream, text, n_text, *tab, *ks, lo1,
+            hipLaunchKernelGGL((prefix_dup_probe_kernel<uint64_t>), dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, c->stream, text, n_text, tab, ks, lo1,
                                stride, samples, table, slots, d_dups);
             PSACX_HIP(c, hipGetLastError());
             PSACX_HIP(c, hipMemcpyAsync(sc.h_base, d_dups, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             PSACX_HIP(c, hipStreamSynchronize(c->stream));
-            if (getenv("PSACX_SORT_DEBUG")) fprintf(stderr, "[psacx 1w] %llu of %llu sampled prefixes seen before\n", (unsigned long long)sc.h_base[0], (unsigned long long)samples);
             if (sc.h_base[0] * 8 > samples) return PSACX_RETRY_1W;
         }
-        hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, tile_hist0);
+        hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, tab, ks, tile_hist0);
         PSACX_HIP(c, hipGetLastError());
     }
     {
@@ -971,27 +801,15 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     for (int d = 0; d < RADIX; ++d) h_tabs[d] = sc.h_base[d];
     h_tabs[RADIX] = n;
     const OneWordLayout lay = onew_layout<TILE>(h_tabs, ntiles);
-    if (getenv("PSACX_SORT_DEBUG"))
-        fprintf(stderr, "[psacx 1w] n=%llu lead=%u lo1=%u: %llu slabs of %u tiles for %llu tiles\n", (unsigned long long)n, lead, lo1,
-                (unsigned long long)lay.total_slabs, lay.slab, (unsigned long long)ntiles);
     if (lay.need > sc.desc_bytes || lay.vtiles >= (1ull << 31)) return PSACX_RETRY_1W;
-    if (text) {
+    {
         ProfScope ps(c, TC_KMER);           // (key generation and the partition by the top digit in one kernel: timed with the keys)
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, *tab, *ks, a, (int)(lo1 + low),
+        hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, tab, ks, a, (int)(lo1 + low),
                            base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1 | (sfield << 16), (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
-    } else {
-        ProfScope ps(c, TC_SORT_SCATTER2);
-        PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        hipLaunchKernelGGL((radix_scatter3_kernel<uint64_t, BLOCK, ITEMS, false, 6, true, 7>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream,
-                           (const uint64_t*)k0, (const uint64_t*)nullptr, (const uint64_t*)nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, n,
-                           (int)(lo1 + low), base0, tile_hist0, slab_tot0, (unsigned long long*)nullptr, spec, spec_n,
-                           reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), (const uint64_t*)nullptr, slab0, (uint64_t)0, lo1 | (sfield << 16));
-        PSACX_HIP(c, hipGetLastError());
     }
-    if (!text) { c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += n; c->stats.scatter_bytes[2] += 16ull * n; }
-    // the buckets (the tables of pass 0 in the scratch are dead once its scatter has run: same stream)
+    // the buckets (the tables of the first pass in the scratch are dead once its scatter has run: same stream)
     uint64_t* cur = nullptr;
     PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur));
     *s1 = cur;          // (k0 after an odd number of bucket passes, `a` after an even number)

@@ -4,6 +4,8 @@
 using namespace psacx;
 
 namespace {
+// PSACX_MULTI_FORCE_WIRE: no shortcut for data a rank sends to itself or for scalars already on this host (psacx_multi: force_wire)
+bool force_wire_env() { return getenv("PSACX_MULTI_FORCE_WIRE") != nullptr; }
 
 int make_rank(psacx_multi* g, int i, int grank, int device) {
     MRank& R = g->R[i];
@@ -196,7 +198,7 @@ int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) {
     // one RCCL communicator over the devices; ranks that share a device (and a single rank) exchange by copies.
     // A communicator that cannot be built is an error, not a silent change of transport (PSACX_MULTI_NO_RCCL=1 asks
     // for peer copies between distinct devices explicitly).
-    g->force_wire = getenv("PSACX_MULTI_FORCE_WIRE") != nullptr;
+    g->force_wire = force_wire_env();
     g->use_rccl = distinct && (ndev > 1 || g->force_wire) && !getenv("PSACX_MULTI_NO_RCCL");
     if (g->use_rccl) {
         std::string err;
@@ -236,7 +238,7 @@ int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device,
     g->R.resize(1);
     int rc = make_rank(g, 0, rank, device);
     if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
-    g->force_wire = getenv("PSACX_MULTI_FORCE_WIRE") != nullptr;
+    g->force_wire = force_wire_env();
     const char* tr = getenv("PSACX_MULTI_TRANSPORT");
     if (id128 && tr && std::string(tr) == "shm") {
         // one process per rank on one host, exchanges staged through shared memory (shm_link.hpp): ranks may share a device
@@ -294,7 +296,7 @@ int psacx_multi_get_stats(const psacx_multi* g, psacx_stats* out, uint64_t* byte
 }
 
 int psacx_multi_transport(const psacx_multi* g) { return g ? g->transport : -1; }
-int psacx_multi_last_form(const psacx_multi* g) { return g ? (g->last_two_word ? 1 : 0) | (g->last_reduced ? 2 : 0) | (g->last_slice_inversion ? 4 : 0) | (g->last_packed ? 8 : 0) | (g->last_one_word ? 16 : 0) : 0; }
+int psacx_multi_last_form(const psacx_multi* g) { return g ? (g->last_two_word ? 1 : 0) | (g->last_reduced ? 2 : 0) | (g->last_slice_inversion ? 4 : 0) | (g->last_one_word ? 16 : 0) : 0; }
 
 int psacx_multi_get_wire(const psacx_multi* g, uint64_t* sends, uint64_t* recvs, uint64_t* allgathers, double* exchange_ms) {
     if (!g) return PSACX_EINVAL;

@@ -162,7 +162,6 @@ struct psacx_multi {
     uint64_t out_slack = 0;           // the output arrays given to construct_dev hold this many elements beyond the block
     bool last_reduced = false;        // layout the last construction ran in
     bool last_two_word = false;       // the first round ran in two-word form (sort_first_two_word)
-    bool last_packed = false;         // ... with the suffixes packed into the low bits of word 1 + one or two bytes
     bool last_one_word = false;       // the first round ran in one-word records dealt by top digit (sort_first_one_word)
     bool last_slice_inversion = false;   // SA -> ISA ran slice by slice through the partition levels + window scatter
     uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
@@ -598,6 +597,12 @@ struct MultiRun {
 
     explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
         if (const char* e = getenv("PSACX_MULTI_WIRE_PIECE")) wire_piece_ = std::max<size_t>(256, strtoull(e, nullptr, 10));
+        if (const char* e = getenv("PSACX_MULTI_PIECES")) pieces_env_ = std::max(1, atoi(e));      // ranges per destination of the first round's shuffle (tests)
+        one_stage_env_ = getenv("PSACX_ONE_STAGE") != nullptr;                                      // first round as one sort over both key words
+        if (const char* e = getenv("PSACX_MULTI_SLAB")) slab_env_ = strtoull(e, nullptr, 10);       // unresolved suffixes per refinement slab (reduced-memory layout)
+        if (const char* e = getenv("PSACX_MULTI_CHECK_CHUNKS")) check_chunks_env_ = strtoull(e, nullptr, 10);
+        // PSACX_SLICE_SHAPE=wb,s1,step (tests: the levels of the slice inversion on small inputs): window bits, slice bits, slices per step; 0 = default
+        if (const char* e = getenv("PSACX_SLICE_SHAPE")) { unsigned a = 0, b = 0; unsigned long long st = 0; if (sscanf(e, "%u,%u,%llu", &a, &b, &st) >= 1) { slice_wb_env_ = a; slice_s1_env_ = b; slice_step_env_ = st; } }
         solo_ = P == 1 && !mg->force_wire;
         t_last_ = t_phase_ = std::chrono::steady_clock::now();
     }
@@ -744,6 +749,10 @@ struct MultiRun {
     // arrived damaged in this stack (seen with a rank's message to itself: half the entries wrong at 2^28 64-bit records;
     // profiles/r04k: 2^30-byte pieces arrive whole, 2^31 - 1 do not), and pieces keep the channels' staging independent of the message length.  PSACX_MULTI_WIRE_PIECE: bytes.
     size_t wire_piece_ = (size_t)1 << 28;
+    int pieces_env_ = 0;
+    bool one_stage_env_ = false;
+    uint64_t slab_env_ = 0, check_chunks_env_ = 0, slice_step_env_ = 0;
+    unsigned slice_wb_env_ = 0, slice_s1_env_ = 0;
     ncclResult_t wire_send(RcclApi& nc, MRank& R, const void* p, size_t bytes, int peer) {
         for (size_t o = 0; o < bytes; o += wire_piece_) {
             const ncclResult_t r = nc.Send(static_cast<const char*>(p) + o, std::min(wire_piece_, bytes - o), ncclUint8, peer, R.comm, R.comm_stream);
@@ -1102,7 +1111,7 @@ struct MultiRun {
     int local_sort_first(int i, Rec<T>& rec, unsigned bits1, unsigned bits2) {
         psacx_ctx* c = ctx(i);
         unsigned lead = (bits_for(n - 1) + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
-        const bool two_stage = rec.cnt >= (1ull << 21) && lead <= bits1 && lead + RADIX_BITS <= bits1 + bits2 && !getenv("PSACX_ONE_STAGE");
+        const bool two_stage = rec.cnt >= (1ull << 21) && lead <= bits1 && lead + RADIX_BITS <= bits1 + bits2 && !one_stage_env_;
         if (!two_stage) return local_sort(i, rec, bits1, bits2);
         const unsigned lo1 = bits1 - lead;
         {
@@ -1392,9 +1401,9 @@ struct MultiRun {
         // q + 1 .. are still in flight on the second stream: the local sort runs under the shuffle (idxsort.hpp:58-62 sorts after
         // its Alltoallv has returned).  PSACX_MULTI_SHUFFLE_BY_POSITION=1: the earlier form (pieces of the block by position,
         // piece q + 1 partitioned while piece q travels, one local sort at the end).
-        const bool by_range = !solo_ && !getenv("PSACX_MULTI_SHUFFLE_BY_POSITION");
+        const bool by_range = !solo_;
         int QR = 1;
-        if (by_range) { QR = std::max(1, std::min(4, 64 / P)); if (const char* e = getenv("PSACX_MULTI_PIECES")) QR = std::max(1, std::min(64 / P, atoi(e))); }
+        if (by_range) { QR = std::max(1, std::min(4, 64 / P)); if (pieces_env_ > 0) QR = std::max(1, std::min(64 / P, pieces_env_)); }
         std::vector<uint64_t> spl;
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + SAMPLES, 0));
@@ -1443,13 +1452,9 @@ struct MultiRun {
                 for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
             }
         }
-        // The suffix a record stands for travels in the low bits of word 1 that lie below the sorted prefix + one or two bytes
-        // (radix.hpp: VN 3 .. 6; 9 or 10 bytes per record on the wire and in every pass of the local sort); else as 32-bit
-        // entries while the text has at most 2^32 characters; else as words.
-        const PackedForm pf = packed_form_for(n, lo1, sizeof(T), n > (1ull << 32));
-        const bool v32 = !pf.on() && sizeof(T) == 8 && n <= (1ull << 32);
-        const size_t vb = pf.on() ? pf.bytes : (v32 ? 4 : sizeof(T));
-        g->last_packed = pf.on();
+        // The suffix a record stands for travels as a 32-bit entry while the text has at most 2^32 characters, else as a word.
+        const bool v32 = sizeof(T) == 8 && n <= (1ull << 32);
+        const size_t vb = v32 ? 4 : sizeof(T);
         // record j of local rank i stands for suffix: the spec short suffixes first on rank 0 (n - 1 - j), then the block in order
         auto payload_of = [&](int i, uint64_t a, uint64_t* spec_q, uint64_t* specn_q, uint64_t* voff_q) {
             const uint64_t front = rank(i) == 0 ? spec_front : 0;
@@ -1512,7 +1517,7 @@ struct MultiRun {
                 uint64_t sq, snq, vq;
                 payload_of(i, 0, &sq, &snq, &vq);
                 MG_HIP(g, hipSetDevice(c->device));
-                MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p, cls[i].p, cn, grp[i].k1.p, grp[i].v.p, v32, sq, snq, vq, pf));
+                MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p, cls[i].p, cn, grp[i].k1.p, grp[i].v.p, v32, sq, snq, vq));
                 return PSACX_OK;
             }));
             // the unpartitioned records are not needed any more: in the reduced-memory layout they sat in the rank's output arrays,
@@ -1561,7 +1566,7 @@ struct MultiRun {
                     const uint64_t b0 = rbase[i][q], tq = rbase[i][q + 1] - b0;
                     if (!tq) return PSACX_OK;
                     MG_OP(g, c, op_pair_sort<T>(c, rcv[i].k1.p + b0, (T*)nullptr, rcv[i].v.p + b0, alt[i].k1.p + b0, (T*)nullptr, alt[i].v.p + b0, tq, bits1, 0, &where[i][q], lo1,
-                                                false, 0, 0, v32, pf, pf.on()));
+                                                false, 0, 0, v32));
                     return PSACX_OK;
                 }));
             }
@@ -1594,114 +1599,8 @@ struct MultiRun {
             }));
             sorted_already = true;
             mark("    sort: shuffle by ranges + range sorts");
-        } else if (!solo_) {
-            const uint32_t ns = (uint32_t)spl.size();
-            Splitters sp; std::memset(&sp, 0, sizeof(sp));
-            sp.n = ns;
-            for (uint32_t s2 = 0; s2 < ns; ++s2) sp.k1[s2] = spl[s2];
-            // The shuffle in Q pieces: piece q + 1 is partitioned by destination on the compute stream while piece q travels on
-            // the second stream (idxsort.hpp:58-62 hands the whole tuple array to MPI_Alltoallv at once).
-            int Q = 4;
-            if (const char* e = getenv("PSACX_MULTI_PIECES")) Q = std::max(1, std::min(16, atoi(e)));
-            constexpr uint64_t SPAN = 256 * 32;
-            std::vector<uint64_t> piece(L);
-            std::vector<std::vector<uint64_t>> cnt_q(L, std::vector<uint64_t>((size_t)Q * P, 0));
-            std::vector<DBuf<uint8_t>> cls(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                const uint64_t cn = rec[i].cnt;
-                piece[i] = std::max<uint64_t>(SPAN, ((cn + Q - 1) / Q + SPAN - 1) / SPAN * SPAN);
-                MG_OP(g, c, cls[i].alloc(c, cn + 16));
-                DBuf<unsigned long long> d_counts; MG_OP(g, c, d_counts.alloc(c, (size_t)Q * 64));
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_HIP(g, hipMemsetAsync(d_counts.p, 0, (size_t)Q * 64 * 8, c->stream));
-                if (cn) {
-                    const uint64_t per_piece = (piece[i] + SPAN - 1) / SPAN, nq = (cn + piece[i] - 1) / piece[i];
-                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3((unsigned)(per_piece * nq)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, cn, lo1, sp, cls[i].p,
-                                       piece[i], d_counts.p);
-                    MG_HIP(g, hipGetLastError());
-                }
-                MG_OP(g, c, ensure_pinned(c, (size_t)Q * 64 * 8 + 65536 + 32768));
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d_counts.p, (size_t)Q * 64 * 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                const unsigned long long* h = reinterpret_cast<const unsigned long long*>(c->pinned + 32768);
-                for (int q = 0; q < Q; ++q) for (int d = 0; d < P; ++d) cnt_q[i][(size_t)q * P + d] = h[(size_t)q * 64 + d];
-                return PSACX_OK;
-            }));
-            std::vector<uint64_t> table;                       // table[(r * Q + q) * P + d]
-            PSACX_TRY(gather(Q * P, cnt_q, table));
-            // receive arrays: a whole record set (the third array becomes word 2 of the tied records later)
-            std::vector<Rec<T>> grp(L), rcv(L);
-            std::vector<std::vector<uint64_t>> roff(L);
-            int rc_alloc = PSACX_OK;
-            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
-                roff[i].assign(P + 1, 0);
-                for (int r = 0; r < P; ++r) { uint64_t t = 0; for (int q = 0; q < Q; ++q) t += table[((size_t)r * Q + q) * P + rank(i)]; roff[i][r + 1] = roff[i][r] + t; }
-                rc_alloc = take3(i, grp[i], rec[i].cnt, false);
-            }
-            PSACX_TRY(agree(rc_alloc));
-            std::vector<std::vector<hipEvent_t>> done(Q, std::vector<hipEvent_t>(L, nullptr));
-            auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
-            for (int q = 0; q < Q; ++q) for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming)); }
-            // (the receive arrays come after the senders' second record set exists: in the reduced-memory layout a rank's records
-            //  sit in its output arrays, the partitioned copy in its one allocated set, and the received records need a third
-            //  place -- taken from the cache like any other array)
-            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, rcv[i], roff[i][P], false);
-            PSACX_TRY(agree(rc_alloc));
-            int rc = PSACX_OK;
-            for (int q = 0; q < Q && rc == PSACX_OK; ++q) {
-                rc = par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    const uint64_t cn = rec[i].cnt, a = std::min<uint64_t>((uint64_t)q * piece[i], cn), b = std::min<uint64_t>(a + piece[i], cn);
-                    if (b <= a) return PSACX_OK;
-                    SortScratch sc;
-                    auto layout = [&](Arena& ar) { sc.d_base = ar.take<unsigned long long>((size_t)RADIX); sc.desc_bytes = sort_desc_bytes(b - a); sc.d_desc = ar.take<char>(sc.desc_bytes); };
-                    { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
-                    Arena ar(c->slab);
-                    layout(ar);
-                    uint64_t sq, snq, vq;
-                    payload_of(i, a, &sq, &snq, &vq);
-                    MG_HIP(g, hipSetDevice(c->device));
-                    MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p + a, cls[i].p + a, b - a, grp[i].k1.p + a,
-                                                  reinterpret_cast<char*>(grp[i].v.p) + a * vb, v32, sq, snq, vq, pf));
-                    return PSACX_OK;
-                });
-                if (rc != PSACX_OK) break;
-                std::vector<std::vector<Msg>> sends(L), recvs(L);
-                std::vector<std::vector<const void*>> in(L);
-                std::vector<std::vector<void*>> out(L);
-                for (int i = 0; i < L; ++i) {
-                    const int me = rank(i);
-                    uint64_t at = std::min<uint64_t>((uint64_t)q * piece[i], rec[i].cnt);
-                    for (int d = 0; d < P; ++d) { const uint64_t cn = cnt_q[i][(size_t)q * P + d]; sends[i].push_back(Msg{d, at, cn}); at += cn; }
-                    for (int r = 0; r < P; ++r) {
-                        uint64_t before = 0;
-                        for (int q2 = 0; q2 < q; ++q2) before += table[((size_t)r * Q + q2) * P + me];
-                        recvs[i].push_back(Msg{r, roff[i][r] + before, table[((size_t)r * Q + q) * P + me]});
-                    }
-                    in[i] = {grp[i].k1.p, grp[i].v.p};
-                    out[i] = {rcv[i].k1.p, rcv[i].v.p};
-                }
-                rc = transfer(in, out, {sizeof(T), vb}, sends, recvs, &done[q]);
-            }
-            // everything has arrived (and, with ranks in one process, has been pulled) before the sorted copies go away
-            for (int i = 0; i < L; ++i) {
-                (void)hipSetDevice(ctx(i)->device);
-                for (int q = 0; q < Q; ++q) for (int s2 = 0; s2 < L; ++s2) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
-            }
-            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
-            drop_events();
-            if (rc != PSACX_OK) return rc;
-            mark("    sort: partition + shuffle");
-            for (int i = 0; i < L; ++i) {
-                drop3(i, grp[i]);
-                drop3(i, rec[i]);
-                rec[i] = std::move(rcv[i]);
-                rec[i].cnt = roff[i][P];
-            }
         }
         // prefix sort of (word 1, suffix) on the leading bits, then the ties
-        bool solo_packed = false;        // one rank: the sort ran packed, word 1 of a tied record is read from the text again
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             if (rec[i].cnt >= 1 && !sorted_already) {
@@ -1710,16 +1609,14 @@ struct MultiRun {
                 int32_t where = 0;
                 if (solo_) {
                     // the first pass makes up the payload (the suffix a record stands for), as on one GPU
-                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n,
-                                                false, pf, false, &solo_packed));
-                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32,
-                                                   pf, pf.on()));
+                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n));
+                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32));
                 if (where) swap3(rec[i], alt);
                 drop3(i, alt);
             }
             return PSACX_OK;
         }));
-        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, solo_packed);
+        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, false);
     }
 
     // Stage 2 of a first round that sorted (word 1, suffix) on the leading bits of word 1 only (rec[i]: k1, v sorted; word 1 may have lost the
@@ -1995,7 +1892,7 @@ struct MultiRun {
         mark("    sort: keys + partition by the top digit");
         // ---- 5. where everything lands: bucket b of rank `me` = [short suffixes][sender 0] .. [sender P - 1]
         int QR = solo_ ? 1 : 4;
-        if (const char* e = getenv("PSACX_MULTI_PIECES")) QR = std::max(1, std::min(16, atoi(e)));
+        if (pieces_env_ > 0) QR = std::max(1, std::min(16, pieces_env_));
         std::vector<std::vector<uint64_t>> boff(L, std::vector<uint64_t>(RADIX + 1, 0));       // start of bucket b in the rank's arrays
         std::vector<std::vector<uint64_t>> sstart(L, std::vector<uint64_t>(RADIX + 1, 0));     // start of bucket b in the sender's partitioned block
         for (int i = 0; i < L; ++i) {
@@ -2038,18 +1935,36 @@ struct MultiRun {
                         mg_set_err(g, "one-word first sort: copy of the short suffixes failed"); rc = PSACX_EHIP;
                     }
             }
+            // the messages from sender r to destination d in range q: one per bucket, neighbours joined where they are contiguous on both
+            // sides (always on the sender's; on the receiver's when no other sender's records and no short suffix lie between them).  Sender
+            // and receiver derive their lists from this one function.
+            struct Piece { uint64_t soff, roff, cnt; };
+            std::vector<std::vector<uint64_t>> bstart(P, std::vector<uint64_t>(RADIX + 1, 0));   // start of bucket b in rank d's arrays (as boff, for every rank)
+            for (int d = 0; d < P; ++d) { uint64_t at = Hs[d]; for (int b = 0; b <= RADIX; ++b) { bstart[d][b] = at; if (b < RADIX && b >= cut[d] && b < cut[d + 1]) at += tot[b]; } }
+            auto pieces = [&](int r, int d, int q) -> std::vector<Piece> {
+                std::vector<Piece> out;
+                uint64_t so = 0;
+                for (int b = 0; b < rcuts[d][q]; ++b) so += table[(size_t)r * W + b];
+                for (int b = rcuts[d][q]; b < rcuts[d][q + 1]; ++b) {
+                    const uint64_t cn = table[(size_t)r * W + b];
+                    uint64_t ro = bstart[d][b] + short_words[b].size();
+                    for (int r2 = 0; r2 < r; ++r2) ro += table[(size_t)r2 * W + b];
+                    if (cn) {
+                        if (!out.empty() && out.back().soff + out.back().cnt == so && out.back().roff + out.back().cnt == ro) out.back().cnt += cn;
+                        else out.push_back(Piece{so, ro, cn});
+                    }
+                    so += cn;
+                }
+                return out;
+            };
             for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
                 std::vector<std::vector<Msg>> sends(L), recvs(L);
                 std::vector<std::vector<const void*>> in(L);
                 std::vector<std::vector<void*>> out(L);
                 for (int i = 0; i < L; ++i) {
                     const int me = rank(i);
-                    for (int d = 0; d < P; ++d)
-                        for (int b = rcuts[d][q]; b < rcuts[d][q + 1]; ++b) sends[i].push_back(Msg{d, sstart[i][b], mine[i][b]});
-                    for (int b = rcuts[me][q]; b < rcuts[me][q + 1]; ++b) {
-                        uint64_t at = boff[i][b] + short_words[b].size();
-                        for (int r = 0; r < P; ++r) { const uint64_t cn = table[(size_t)r * W + b]; recvs[i].push_back(Msg{r, at, cn}); at += cn; }
-                    }
+                    for (int d = 0; d < P; ++d) for (const Piece& pc : pieces(me, d, q)) sends[i].push_back(Msg{d, pc.soff, pc.cnt});
+                    for (int r = 0; r < P; ++r) for (const Piece& pc : pieces(r, me, q)) recvs[i].push_back(Msg{r, pc.roff, pc.cnt});
                     in[i] = {grp[i].p}; out[i] = {A[i].p};
                 }
                 rc = transfer(in, out, {sizeof(T)}, sends, recvs, &done[q]);
@@ -2214,8 +2129,8 @@ struct MultiRun {
         unsigned cap_bits = 0;
         while ((2u << cap_bits) * (unsigned)P <= (unsigned)SLICE_MAX_CLASSES) ++cap_bits;        // most slice bits with P * 2^bits classes
         unsigned wbmax = WBMAX;
-        if (const char* e = getenv("PSACX_SLICE_WB")) wbmax = std::min<unsigned>(WBMAX, std::max(4, atoi(e)));     // (tests: levels on small inputs)
-        if (const char* e = getenv("PSACX_SLICE_S1")) cap_bits = std::min<unsigned>(cap_bits, (unsigned)atoi(e));
+        if (slice_wb_env_) wbmax = std::min<unsigned>(WBMAX, std::max(4u, slice_wb_env_));     // (tests: levels on small inputs)
+        if (slice_s1_env_) cap_bits = std::min<unsigned>(cap_bits, slice_s1_env_);
         unsigned s1 = std::min<unsigned>(cap_bits, kb > wbmax ? kb - wbmax : 0);
         // a further level walks tiles of 2^13 pairs that must not straddle slices
         if (kb - s1 > wbmax && kb - s1 < (unsigned)TILE_BITS) s1 = kb > (unsigned)TILE_BITS ? kb - TILE_BITS : 0;
@@ -2247,12 +2162,12 @@ struct MultiRun {
         const uint64_t slice = 1ull << sb;
         // ranks below 2^32: a pair is one 64-bit entry (position | rank << 32) on the wire and in every level (slice_inv.hpp:
         // *_packed_kernel; PSACX_SLICE_TWO_ARRAYS=1 keeps the two-array form)
-        const bool pack = sizeof(V) == 4 && !getenv("PSACX_SLICE_TWO_ARRAYS");
+        const bool pack = sizeof(V) == 4;
         // ranks beyond 2^32: on the wire as 32 bits relative to the end of the sender's block, packed with the position (8 instead
         // of 12 bytes per pair; slice_inv.hpp: SliceDecode), when no bucket of unresolved suffixes reaches further back than 2^32
         // positions from the end of its rank's block; the first owner-side kernel widens them.  PSACX_SLICE_ABS=1: 64-bit ranks.
         bool wpack = false;
-        if (sizeof(V) == 8 && !getenv("PSACX_SLICE_ABS")) {
+        if (sizeof(V) == 8) {
             std::vector<uint64_t> okv(L, 1), all;
             PSACX_TRY(par([&](int i) -> int {
                 if (!S[i].m) return PSACX_OK;
@@ -2306,7 +2221,7 @@ struct MultiRun {
         std::vector<unsigned*> cur(L, nullptr);
         uint64_t G = spo;
         if (diet && !solo_) G = std::max<uint64_t>(1, std::max<uint64_t>(slice, max_m / 8) >> sb);
-        if (const char* e = getenv("PSACX_SLICE_STEP")) G = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        if (slice_step_env_) G = slice_step_env_;
         G = std::min<uint64_t>(G, spo);
         const uint64_t nsteps = (spo + G - 1) / G;
         const uint64_t step_cap = G << sb;
@@ -2335,6 +2250,18 @@ struct MultiRun {
             };
             pair(pk_[i], m, wpack && !solo_);        // (one rank: the levels write back into this set, so it keeps both arrays; the packed entries go to its value array)
             const uint64_t cap = std::min<uint64_t>(step_cap, std::max<uint64_t>(m, 1));
+            if (diet && rc_a == PSACX_OK && cap * 4 <= m) {
+                // the step arrays are small beside the block: one block of exactly their size (a block of the usual size for them
+                // would count a whole array against the rank's memory)
+                const size_t per = (pack ? (size_t)cap * 8 : (size_t)cap * (4 + sizeof(V))) + 512;
+                const size_t small = per * ((solo_ ? 0 : 1) + ((!solo_ && nsteps > 1) ? 1 : 0) + (levels2 ? 1 : 0)) + (levels2 ? ((cap >> wb) + 2) * sizeof(unsigned) + 256 : 0) + 256;
+                auto& v = blocks[i];
+                v.emplace_back();
+                Cut& ct = v.back();
+                rc_a = ct.b.alloc(c, small, 0);
+                if (rc_a != PSACX_OK) mg_set_err(g, "SA -> ISA step arrays: " + c->hip_err);
+                ct.cap = small; ct.used = 0;
+            }
             if (rc_a == PSACX_OK && !solo_) pair(A0[i], cap);
             if (rc_a == PSACX_OK && !solo_ && nsteps > 1) pair(A1[i], cap);
             if (rc_a == PSACX_OK && levels2) { pair(Bb[i], cap); if (rc_a == PSACX_OK) cur[i] = (unsigned*)arr(((cap >> wb) + 2) * sizeof(unsigned)); }
@@ -2833,8 +2760,7 @@ struct MultiRun {
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
             if (diet) {
-                const char* env_slab = getenv("PSACX_MULTI_SLAB");
-                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
                 // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
                 //  device only when an allocation does not fit: pool_alloc)
@@ -3013,7 +2939,7 @@ struct MultiRun {
         const char* env_tw = getenv("PSACX_MULTI_TWO_WORD");
         const int tw_mode = env_tw ? atoi(env_tw) : -1;
         bool two_word = !gsa && tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
-                        !getenv("PSACX_ONE_STAGE");
+                        !one_stage_env_;
         // One-word records dealt by the top digit of the prefix (sort_first_one_word): 64-bit words, blocks of at least 2^21 characters
         // (PSACX_MULTI_ONE_WORD: 0 = never, 1 = also for small blocks: tests)
         CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
@@ -3042,7 +2968,6 @@ struct MultiRun {
         if (!two_word) PSACX_TRY(dist_sort(rec, sizes, bits_w1, bits_w2, true));
         tbuf.clear();
         g->last_two_word = two_word;
-        if (!two_word || one_word) g->last_packed = false;
         PSACX_TRY(par([&](int i) -> int { return own3(i, rec[i]); }));
         mark("first sort");
 
@@ -3163,7 +3088,6 @@ struct MultiRun {
                     PSACX_TRY(par([&](int i) -> int {
                         const uint64_t j = (t + (uint64_t)rank(i)) % steps;
                         kept_n[i][j] = kept[i].n;
-                        if (getenv("PSACX_MULTI_DEBUG")) fprintf(stderr, "[slab] h=%llu step %llu rank %d piece %llu [%llu,%llu) of %llu kept %llu\n", (unsigned long long)h, (unsigned long long)t, rank(i), (unsigned long long)j, (unsigned long long)e[i][j], (unsigned long long)e[i][j+1], (unsigned long long)S[i].pos.n, (unsigned long long)kept[i].n);
                         if (kept[i].n) {
                             MG_HIP(g, hipSetDevice(ctx(i)->device));
                             MG_HIP(g, hipMemcpyAsync(S[i].pos.p + e[i][j], kept[i].p, kept[i].n * sizeof(T), hipMemcpyDeviceToDevice, ctx(i)->stream));
@@ -3355,8 +3279,7 @@ struct MultiRun {
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
             if (diet) {
-                const char* env_slab = getenv("PSACX_MULTI_SLAB");
-                slab_cap = g->opt_slab ? g->opt_slab : env_slab ? strtoull(env_slab, nullptr, 10) : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
                 // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
                 //  device only when an allocation does not fit: pool_alloc)
@@ -3453,7 +3376,6 @@ struct MultiRun {
         uint64_t chunks = 1;
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
-            const char* env = getenv("PSACX_MULTI_CHECK_CHUNKS");
             for (int i = 0; i < L; ++i) {
                 int same = 0;
                 for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
@@ -3463,7 +3385,7 @@ struct MultiRun {
                 // the widened text (1 word per character) stays; a piece wants about 12 words per entry
                 const double avail = 0.8 * (double)fr / same - (double)m_local[i] * sizeof(T), need = 12.0 * (double)m_local[i] * sizeof(T);
                 mine[i][0] = m_local[i];
-                mine[i][1] = env ? strtoull(env, nullptr, 10) : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
+                mine[i][1] = check_chunks_env_ ? check_chunks_env_ : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
             }
             std::vector<uint64_t> all;
             PSACX_TRY(gather(2, mine, all));
@@ -3696,7 +3618,6 @@ struct MultiRun {
         uint64_t chunks = 1;
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
-            const char* env = getenv("PSACX_MULTI_CHECK_CHUNKS");
             for (int i = 0; i < L; ++i) {
                 int same = 0;
                 for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
@@ -3705,7 +3626,7 @@ struct MultiRun {
                 MG_HIP(g, hipMemGetInfo(&fr, &tot));
                 const double avail = 0.8 * (double)fr / same, need = 24.0 * (double)m_local[i] * sizeof(T);
                 mine[i][0] = m_local[i];
-                mine[i][1] = env ? strtoull(env, nullptr, 10) : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
+                mine[i][1] = check_chunks_env_ ? check_chunks_env_ : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
             }
             std::vector<uint64_t> all;
             PSACX_TRY(gather(2, mine, all));

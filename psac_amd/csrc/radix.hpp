@@ -156,12 +156,6 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 // VN (64-bit words, payloads below 2^32 -- the suffix indices of a text of at most 2^32 characters): 1 = the payload arrays
 // hold 32-bit entries on both sides, 2 = 32-bit entries in, full words out (the last pass of a sort).  The first round's
 // prefix sort then moves 12 instead of 16 bytes per record and pass.
-// VN 3 / 5 (packed payload, the prefix sort of the first round): the low `pack` bits of the key word are not part of the
-// sorted prefix (pack <= lo1) and nothing reads them after the sort (the records that tie on the prefix get their window
-// from the text again), so they carry the low `pack` bits of the payload; the payload array holds the rest as 8-bit (3) or
-// 16-bit (5) entries: 9 or 10 instead of 12 (16) bytes per record and pass.  A pass without v_in makes the payload up and
-// packs it.  VN 4 / 6: packed 8- / 16-bit entries in, full words out (the last pass of a sort puts the payload together again;
-// the key word leaves with the payload bits still in its low end).
 // CLSB (EXT only): bytes per entry of the class array dsrc (sizeof(T), or 1 for a byte array).
 // voff: added to the payload a pass makes up itself (v_in == nullptr): the records of a rank's block, or of a piece of it.
 template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int VN = 0, int CLSB = sizeof(T)>
@@ -175,8 +169,6 @@ __device__ __forceinline__ void radix_scatter_tile(
     const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
-    constexpr bool PK = VN >= 3 && VN <= 6;            // packed payload
-    constexpr bool PK_OUT_FULL = VN == 4 || VN == 6;   // ... put together again on the way out
     // VN 7 / 8 / 9: one-word records (the prefix sort of the first round, most significant digit first; engine.hpp: prefix_sort_1w).
     // 7: the pass on the TOP digit of the prefix; it makes the payload up and writes ONE word per record, (prefix without its top
     //    digit) << 32 | payload (pack = lo1, the bits of word 1 below the prefix); 8: one-word records in and out (a digit of the
@@ -190,7 +182,6 @@ __device__ __forceinline__ void radix_scatter_tile(
     constexpr bool ONEW_OUT = VN == 7 || VN == 8 || VN == 10;
     constexpr bool ONEW_MAKE = VN == 7 || VN == 10;
     const unsigned sfield = (ONEW_MAKE || VN == 9) ? (((pack >> 16) & 255u) ? ((pack >> 16) & 255u) : 32u) : 0u;
-    const T pmask = PK ? (T)((((uint64_t)1 << pack) - 1)) : (T)0;
     T* const stage = sh.stage;
     uint8_t* const sdig = sh.sdig;
     unsigned* const wcnt = sh.wcnt;
@@ -267,8 +258,6 @@ __device__ __forceinline__ void radix_scatter_tile(
         for (int i = 0; i < ITEMS; ++i) {
             const unsigned loc = wbase + i * WAVE;
             if (VN == 1 || VN == 2) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint32_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
-            else if (VN == 3 || VN == 4) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint8_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
-            else if (VN == 5 || VN == 6) vv[i] = (FULL || loc < count) ? (PV)(reinterpret_cast<const uint16_t*>(v_in) + base + wbase)[i * WAVE] : (PV)0;
             else vv[i] = (FULL || loc < count) ? (PV)(pv + wbase)[i * WAVE] : (PV)0;
         }
     } else if (!ONEW_MAKE) {         // (one-word records out: the payload is put together when the word is staged)
@@ -277,8 +266,7 @@ __device__ __forceinline__ void radix_scatter_tile(
             // implicit payload: the record index, or the suffix the first-round record stands for
             const uint64_t g = base + wbase + i * WAVE;
             const uint64_t made = (spec_n ? (g < spec ? spec_n - 1 - g : g - spec) : g) + voff;
-            if (PK) { kd[i] = (T)((kd[i] & ~pmask) | ((T)made & pmask)); vv[i] = (PV)(made >> pack); }
-            else vv[i] = (PV)made;
+            vv[i] = (PV)made;
         }
     }
 
@@ -367,13 +355,11 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (FULL || (wbase + i * WAVE) < count) { stage[rank[i]] = staged; sdig[rank[i]] = (uint8_t)d; }
     }
     __syncthreads();
-    T xlow[PK_OUT_FULL ? ITEMS : 1];    // packed payload on its way out: the bits the key word of output slot tid + j * BLOCK carries
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned p = tid + j * BLOCK;
         if (FULL || p < count) {
             const T x = stage[p];
-            if (PK_OUT_FULL) xlow[PK_OUT_FULL ? j : 0] = (T)(x & pmask);
             const T at = (T)(goff[sdig[p]] + (T)p);
             if (VN == 9) {
                 kd_out[at] = (T)(((voff << ((pack >> 8) & 255u)) | ((uint64_t)x >> sfield)) << (pack & 255u));
@@ -409,9 +395,6 @@ __device__ __forceinline__ void radix_scatter_tile(
         if (FULL || p < count) {
             const T at = (T)(goff[sdig[p]] + (T)p);
             if (VN == 1) reinterpret_cast<uint32_t*>(v_out)[at] = (uint32_t)pstage[p];
-            else if (VN == 3) reinterpret_cast<uint8_t*>(v_out)[at] = (uint8_t)pstage[p];
-            else if (VN == 5) reinterpret_cast<uint16_t*>(v_out)[at] = (uint16_t)pstage[p];
-            else if (PK_OUT_FULL) v_out[at] = (T)(xlow[PK_OUT_FULL ? j : 0] | (T)((uint64_t)pstage[p] << pack));
             else v_out[at] = (T)pstage[p];
         }
     }

@@ -662,11 +662,11 @@ def test_multi_first_round_two_word_form(P, monkeypatch):
     # mode 2 also sends repetitive texts through it (long tie groups -> radix sort of the compacted ties).
     cases = [(O.rand_dna(70001, 7), 64), (O.rand_dna(70001, 7), 32), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
              (np.full(5003, 65, np.uint8), 64), (inputs.cyclic(20011, "abc"), 32), (O.as_text("mississippi" * 40), 64)]
-    # shuffle by key ranges with one sort per range under the exchanges (default), by position with one sort at the end
-    # (PSACX_MULTI_SHUFFLE_BY_POSITION=1), and with other numbers of ranges / pieces
-    for mode, env in (("1", {}), ("2", {}), ("1", {"PSACX_MULTI_SHUFFLE_BY_POSITION": "1"}), ("2", {"PSACX_MULTI_PIECES": "7"}), ("1", {"PSACX_MULTI_PIECES": "1"})):
+    # shuffle by key ranges with one sort per range under the exchanges, also with other numbers of ranges
+    monkeypatch.setenv("PSACX_MULTI_ONE_WORD", "0")
+    for mode, env in (("1", {}), ("2", {}), ("2", {"PSACX_MULTI_PIECES": "7"}), ("1", {"PSACX_MULTI_PIECES": "1"})):
         monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
-        for k_ in ("PSACX_MULTI_SHUFFLE_BY_POSITION", "PSACX_MULTI_PIECES"):
+        for k_ in ("PSACX_MULTI_PIECES",):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -811,54 +811,18 @@ def test_multi_suffix_tree_node_table(P):
         mg.close()
 
 
-@pytest.mark.parametrize("P,entry_bytes,local", [(1, 1, 0), (2, 2, 0), (3, 1, 1), (7, 2, 1), (4, 1, 0)])
-def test_multi_packed_payload_on_the_wire(P, entry_bytes, local, monkeypatch):
-    # The form a text beyond 2^32 characters takes by default, forced on small inputs (PSACX_PACKED=1): the suffix of a
-    # two-word record travels in the unsorted low bits of word 1 + a one- or two-byte entry (9 or 10 bytes per record on the
-    # wire and in the passes of the local sort, radix.hpp: VN 3 .. 6); ties fetch both words from the text owners.
-    monkeypatch.setenv("PSACX_PACKED", "1")
-    monkeypatch.setenv("PSACX_PACKED_BYTES", str(entry_bytes))
-    if local:                # the local sort keeps the entries packed between its passes (else its first pass widens them)
-        monkeypatch.setenv("PSACX_PACKED_LOCAL", "1")
-    cases = [(O.rand_dna(70001, 7), 64), (inputs.ascii128(50000, 3), 64), (inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64),
-             (O.rand_dna((1 << 21) + 11, 8), 64), (O.rand_dna(70001, 7), 32)]
-    for mode in ("1", "2"):
-        monkeypatch.setenv("PSACX_MULTI_TWO_WORD", mode)
-        mg = multi(P)
-        try:
-            packed = 0
-            for text, bits in cases:
-                SA, ISA, LCP, rounds = same(mg, text, bits)
-                ref = O.construct(text, bits=bits)
-                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, mode, bits, text.size)
-                assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
-                f = mg.last_form()
-                assert not f["packed"] or (f["two_word"] and bits == 64)
-                packed += f["packed"]
-            assert packed >= 3, packed
-        finally:
-            mg.close()
-
-
 @pytest.mark.parametrize("P,wb,s1,step", [(1, 6, 9, 0), (2, 5, 2, 1), (3, 14, 9, 0), (7, 4, 1, 1), (4, 6, 3, 2)])
 def test_multi_isa_by_destination_slices(P, wb, s1, step, monkeypatch):
     # SA -> ISA of the first round slice by slice (slice_inv.hpp): first level by (owner, slice) on the senders, the slices
     # travel in steps (double-buffered), further reservation levels + the LDS window scatter on the owners.  Small windows
     # and few slice bits force the deeper levels on test-sized inputs.
-    monkeypatch.setenv("PSACX_SLICE_WB", str(wb))
-    monkeypatch.setenv("PSACX_SLICE_S1", str(s1))
-    if step:
-        monkeypatch.setenv("PSACX_SLICE_STEP", str(step))
-    # (the pairs travel and are partitioned as packed 64-bit entries; PSACX_SLICE_TWO_ARRAYS=1: as two 32-bit arrays;
-    #  PSACX_SLICE_WIDE=1: the 64-bit rank form of texts beyond 2^32 characters, whose ranks travel as 32 bits relative to the
-    #  end of the sender's block and are widened by the first owner-side kernel; PSACX_SLICE_ABS=1: as 64-bit words)
-    for two in (False, True, "wide", "wide_abs"):
-        if two is True:
-            monkeypatch.setenv("PSACX_SLICE_TWO_ARRAYS", "1")
-        if two in ("wide", "wide_abs"):
+    monkeypatch.setenv("PSACX_SLICE_SHAPE", "%d,%d,%d" % (wb, s1, step))
+    # (the pairs travel and are partitioned as packed 64-bit entries; PSACX_SLICE_WIDE=1: the 64-bit rank form of texts beyond
+    #  2^32 characters, whose ranks travel as 32 bits relative to the end of the sender's block and are widened by the first
+    #  owner-side kernel)
+    for two in (False, "wide"):
+        if two == "wide":
             monkeypatch.setenv("PSACX_SLICE_WIDE", "1")
-        if two == "wide_abs":
-            monkeypatch.setenv("PSACX_SLICE_ABS", "1")
         mg = multi(P)
         try:
             for text, bits in ((O.rand_dna(300007, 7), 64), (O.rand_dna(131072 * P, 9), 32), (inputs.tandem(90001, 256, O.rand_dna(256, 3)), 32),

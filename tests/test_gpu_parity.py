@@ -161,193 +161,28 @@ def test_isa_inversion_partition_path(ctx):
         assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
 
 
-@pytest.mark.parametrize("env", ["PSACX_NO_FUSED_L1", "PSACX_ISA_WIDE", "PSACX_ISA_PARTITION", "PSACX_ISA_TWO_ARRAYS"])
-def test_isa_inversion_earlier_forms(ctx, monkeypatch, env):
-    # The default SA -> ISA inversion (first level fused into rebucket_first_kernel, 512-way levels, 2^14-entry windows)
-    # against its earlier forms, which stay selectable: the results must be identical (and are checked on their own).
+def test_isa_inversion_forms(ctx, monkeypatch):
+    # The SA -> ISA inversion by destination-partition levels + LDS window scatter: 64-bit words with the first level fused into
+    # rebucket_first_kernel and packed (position | rank) pairs, 32-bit words with the fused two-array first level (normal layout) and
+    # with radix levels (reduced-memory layout): property check + Kasai, and the two layouts give identical arrays.
     cases = (((1 << 22) + 4097, 64, 5), ((1 << 23) + 77, 32, 6), ((1 << 22) + 1, 32, 7))
     base = []
     for n, bits, seed in cases:
         text = inputs.dna(n, seed)
         sa = run(ctx, text, bits=bits)
         assert O.check_sa(text, sa.local_SA, sa.local_B) == 0
+        assert np.array_equal(O.kasai(text, sa.local_SA, sa.local_B), sa.local_LCP)
         base.append((sa.local_SA.copy(), sa.local_B.copy(), sa.local_LCP.copy()))
-    monkeypatch.setenv(env, "1")
+    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
     for (n, bits, seed), (SA, B, LCP) in zip(cases, base):
         sa = run(ctx, inputs.dna(n, seed), bits=bits)
         assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_B, B) and np.array_equal(sa.local_LCP, LCP)
 
 
-def test_small_sort_host_scan_form():
-    # The small (look-back) sorts scan their digit histograms on the device and receive the round counters through
-    # pinned host memory; PSACX_SORT_HOST_SCAN / PSACX_NO_HOST_STORES select the earlier host-side forms (read once per
-    # process, hence the child processes).  A tandem repeat keeps 2^18 suffixes unresolved for 15 rounds.
-    prog = ("import sys, zlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import inputs, psac_amd;"
-            "t = inputs.tandem(1 << 18, 256, inputs.dna(256, 3));"
-            "sa = psac_amd.SuffixArray(index_bits=32, lcp=True); sa.construct(t);"
-            "print(zlib.crc32(sa.local_SA.tobytes()), zlib.crc32(sa.local_B.tobytes()), zlib.crc32(sa.local_LCP.tobytes()), len(sa.rounds))"
-            % (os.path.dirname(HERE), HERE))
-    import subprocess
-    import zlib
-    outs = []
-    for extra in ({}, {"PSACX_SORT_HOST_SCAN": "1"}, {"PSACX_NO_HOST_STORES": "1"}):
-        env = dict(os.environ); env.update(extra)
-        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] == outs[2], outs
-    t = inputs.tandem(1 << 18, 256, inputs.dna(256, 3))
-    ref = O.construct(t, bits=32)
-    assert outs[0].split()[0] == str(zlib.crc32(np.asarray(ref["SA"], np.uint32).tobytes()))
-
-
-def test_pair_sort_standalone(ctx):
-    # idxsort.hpp:23-83: records (b1, b2, i) sorted by (b1, b2)
-    import ctypes as C
-    rng = np.random.default_rng(1)
-    for bits, dt in ((32, np.uint32), (64, np.uint64)):
-        for n in (1, 2, 1000, 4096, 4097, 300001):
-            hi = 1 << 20
-            b1 = rng.integers(0, 50, n).astype(dt)
-            b2 = rng.integers(0, hi, n).astype(dt)
-            d1 = ctx.alloc(b1.nbytes); d2 = ctx.alloc(b2.nbytes); di = ctx.alloc(b1.nbytes)
-            ctx.h2d(d1, b1); ctx.h2d(d2, b2)
-            fn = getattr(ctx._lib, "psacx_pair_sort_dev_u%d" % bits)
-            ctx.check(fn(ctx.handle, C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(di), n, 21))
-            o1 = np.empty(n, dt); o2 = np.empty(n, dt); oi = np.empty(n, dt)
-            ctx.d2h(o1, d1); ctx.d2h(o2, d2); ctx.d2h(oi, di)
-            for p in (d1, d2, di):
-                ctx.free(p)
-            order = np.lexsort((b2, b1))          # stable, so ties keep index order
-            assert np.array_equal(oi, order.astype(dt))
-            assert np.array_equal(o1, b1[order]) and np.array_equal(o2, b2[order])
-
-
-def test_errors(ctx):
-    import psac_amd
-    sa = psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
-    with pytest.raises(ValueError):
-        sa.construct(b"")
-    import ctypes as C
-    rc = ctx._lib.psacx_construct_u32(ctx.handle, None, 5, 0, 0, None, None, None)
-    assert rc == -1
-
-
-def test_ansv_all_type_combinations(ctx):
-    # test/test_ansv.cpp:232-252, 270-282: every (left_type, right_type) on rand() % 100 inputs,
-    # n in {13, 137, 1000, 26666}; plus an LCP array (suffix_tree.hpp:62 uses furthest_eq / nearest_sm)
-    import psac_amd
-    rng = np.random.default_rng(17)
-    NO = 2**64 - 1
-    cases = [rng.integers(0, 100, n).astype(np.uint32) for n in (1, 2, 13, 137, 1000, 26666)]
-    cases.append(rng.integers(0, 3, 70000).astype(np.uint64))
-    cases.append(np.zeros(5000, np.uint32))
-    cases.append(np.arange(5000, dtype=np.uint32))
-    cases.append(np.arange(5000, dtype=np.uint64)[::-1].copy())
-    text = O.rand_dna(200000, 5)
-    cases.append(O.construct(text, bits=32)["LCP"])
-    for v in cases:
-        for lt in (0, 1, 2):
-            for rt in (0, 1, 2):
-                if v.size > 30000 and (lt, rt) not in ((0, 0), (2, 0), (1, 2)):
-                    continue
-                left, right = psac_amd.ansv(v, lt, rt, nonsv=NO, ctx=ctx)
-                assert np.array_equal(left, O.ansv(v, True, lt, NO)), (v.size, lt, rt)
-                assert np.array_equal(right, O.ansv(v, False, rt, NO)), (v.size, lt, rt)
-
-
-def test_cli_and_cpp_header(ctx, tmp_path):
-    # psac CLI parity (src/psac.cpp:65-128): -f/-l/-c/-o, .sa64/.lcp64 as raw uint64, print64 listing
-    # of README.md:88-100
-    import subprocess
-    root = os.path.dirname(HERE)
-    psac = os.path.join(root, "psac_amd", "bin", "psac")
-    p64 = os.path.join(root, "psac_amd", "bin", "print64")
-    if not (os.path.exists(psac) and os.path.exists(p64)):
-        pytest.skip("CLI not built")
-    f = tmp_path / "miss.txt"
-    f.write_bytes(b"mississippi")
-    r = subprocess.run([psac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "out")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    assert "PSAC time:" in r.stderr and "[SUCCESS]" in r.stderr
-    sa = np.fromfile(str(tmp_path / "out.sa64"), dtype=np.uint64)
-    lcp = np.fromfile(str(tmp_path / "out.lcp64"), dtype=np.uint64)
-    assert sa.tolist() == KAT["mississippi"]["SA"] and lcp.tolist() == KAT["mississippi"]["LCP"]
-    listing = subprocess.run([p64, str(tmp_path / "out.sa64")], capture_output=True, text=True).stdout.split()
-    assert [int(x) for x in listing] == KAT["mississippi"]["SA"]
-    # random input through -r, checked by the CLI's own -c, then the -t path (ANSV over LCP)
-    r = subprocess.run([psac, "-r", "300000", "-s", "3", "-l", "-c"], capture_output=True, text=True)
-    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr
-    r = subprocess.run([psac, "-r", "100000", "-t", "-c"], capture_output=True, text=True)
-    assert r.returncode == 0 and "ST time:" in r.stderr and "ST edges:" in r.stderr, r.stderr
-    # argument errors exit non-zero like TCLAP (src/psac.cpp:147-150)
-    assert subprocess.run([psac], capture_output=True).returncode != 0
-    assert subprocess.run([psac, "-f", str(f), "-r", "5"], capture_output=True).returncode != 0
-
-
-def _dist_loopback_gpu(text, P, bits, k=0):
-    import torch
-    from dist_harness import dist as D
-    from dist_harness.comm import LoopbackWorld
-    from dist_harness.dist_ops import HipOps
-    sizes = D.blk_sizes(text.size, P)
-    offs = D.prefix(sizes)
-    ops = [HipOps(bits, 0) for _ in range(P)]
-    blocks = [torch.from_numpy(text[o:o + s].copy()).cuda() for o, s in zip(offs, sizes)]
-
-    def fn(comm, op, blk):
-        return (yield from D.construct(comm, op, blk, want_lcp=True, k_req=k))
-    res = LoopbackWorld(P).run(fn, [(ops[r], blocks[r]) for r in range(P)])
-    udt = np.uint32 if bits == 32 else np.uint64
-    cat = lambda key: np.concatenate([r[key].cpu().numpy().view(udt) for r in res])
-    out = cat("SA"), cat("ISA"), cat("LCP"), res[0]["rounds"]
-    for o in ops:
-        o.close()
-    return out
-
-
-@pytest.mark.parametrize("P", [1, 2, 3, 4])
-def test_distributed_ops_on_one_gpu(ctx, P):
-    # the block-distributed choreography with the HIP step ops, P virtual ranks sharing this GPU
-    for bits in (32, 64):
-        text = O.rand_dna(60011, 7)
-        sa, isa, lcp, _ = _dist_loopback_gpu(text, P, bits)
-        ref = O.construct(text, bits=bits)
-        assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
-    unit = O.rand_dna(256, 3)
-    text = inputs.tandem(40000, 256, unit)
-    sa, isa, lcp, rounds = _dist_loopback_gpu(text, P, 32)
-    ref = O.construct(text, bits=32)
-    assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
-    text = O.rand_dna(30011, 23)
-    sa, isa, lcp, _ = _dist_loopback_gpu(text, P, 64, k=3)
-    assert np.array_equal(sa, O.naive_sa(text, 64))
-    assert np.array_equal(O.kasai(text, sa, isa), lcp)
-
-
-def test_distributed_shift_saturates(ctx):
-    # psacx_op_add_scalar: SA + h in 64 bits, clamped to n (see tests/test_dist_cpu.py for the CPU twin)
-    import torch
-    from dist_harness.dist_ops import HipOps
-    ops = HipOps(32, 0)
-    n = 0xFFFFFF00
-    sa = torch.from_numpy(np.array([5, 0x80000000, 0xFFFFFE00, 0xFFFFFEFF], np.uint32).view(np.int32)).cuda()
-    q = ops.add_scalar(sa, 0x200, n)
-    assert q.cpu().numpy().view(np.uint32).tolist() == [0x205, 0x80000200, n, n]
-    ops.close()
-
-
-def test_distributed_ops_larger(ctx):
-    text = inputs.dna((1 << 22) + 1234, 9)
-    sa, isa, lcp, _ = _dist_loopback_gpu(text, 3, 32)
-    assert O.check_sa(text, sa, isa) == 0
-    assert np.array_equal(O.kasai(text, sa, isa), lcp)
-
-
 def test_low_entropy_text_many_range_minima(ctx):
     # 2^21 characters with geometric symbol frequencies: most suffixes stay unresolved after the first round, so
     # the refinement issues ~10^6 range minima per round and the running-minimum tables (levels 0 and up) are in
-    # use -- on the single-GPU engine and in the distributed range_min op; PSACX_NO_RMQ_AUX covers the plain scans
+    # use -- on the single-GPU engine and in the distributed range_min op
     rng = np.random.RandomState(5)
     p = 0.5 ** np.arange(1, 21); p /= p.sum()
     text = (97 + rng.choice(20, size=(1 << 21) + 77, p=p)).astype(np.uint8)
@@ -355,12 +190,8 @@ def test_low_entropy_text_many_range_minima(ctx):
     got = run(ctx, text, bits=32)
     assert np.array_equal(got.local_SA, ref["SA"]) and np.array_equal(got.local_B, ref["ISA"]) and np.array_equal(got.local_LCP, ref["LCP"])
     assert [(h, b, e) for h, b, e, *_ in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
-    os.environ["PSACX_NO_RMQ_AUX"] = "1"
-    try:
-        plain = run(ctx, text, bits=64)
-    finally:
-        del os.environ["PSACX_NO_RMQ_AUX"]
-    assert np.array_equal(plain.local_LCP, ref["LCP"].astype(np.uint64))
+    wide = run(ctx, text, bits=64)
+    assert np.array_equal(wide.local_LCP, ref["LCP"].astype(np.uint64))
     sa, isa, lcp, _ = _dist_loopback_gpu(text, 2, 32)
     assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
 
@@ -749,25 +580,6 @@ def test_degenerate_texts_above_the_two_stage_threshold(ctx):
         same_as_oracle(ctx, text, bits=bits)
 
 
-@pytest.mark.parametrize("entry_bytes", [1, 2])
-def test_packed_payload_form_of_the_prefix_sort(ctx, monkeypatch, entry_bytes):
-    # PSACX_PACKED=1: the suffix of a first-round record travels in the unsorted low bits of word 1 + a one- or
-    # two-byte entry (radix.hpp: VN 3 .. 6), word 1 of the tied suffixes is read from the text again.  64-bit words
-    # only; random DNA (tiny tie groups), ASCII (63-bit word 1, 16-bit entries anyway), a text whose tie groups are
-    # long (the radix fallback for the ties), and the reduced-memory layout.
-    monkeypatch.setenv("PSACX_PACKED", "1")
-    monkeypatch.setenv("PSACX_PACKED_BYTES", str(entry_bytes))
-    same_as_oracle(ctx, inputs.dna((1 << 22) + 77, 5), bits=64)
-    same_as_oracle(ctx, inputs.ascii128((1 << 21) + 5, 4), bits=64)
-    rep = np.tile(inputs.dna(1 << 12, 9), 1 << 10)
-    rep[::4099] = 84
-    same_as_oracle(ctx, rep, bits=64)
-    monkeypatch.setenv("PSACX_FORCE_DIET", "1")
-    same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
-    monkeypatch.setenv("PSACX_TIES_RADIX", "1")
-    same_as_oracle(ctx, inputs.dna((1 << 21) + 9, 7), bits=64)
-
-
 def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     # 64-bit words, at most 2^32 characters: the prefix sort of the first round partitions word 1 by the TOP digit of the prefix
     # and moves one 64-bit word per record (rest of the prefix | suffix) through LSD passes inside the 256 buckets
@@ -795,11 +607,6 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     same_as_oracle(ctx, inputs.dna((1 << 22) + 1, 6), bits=64)
     same_as_oracle(ctx, five, bits=64)
     monkeypatch.delenv("PSACX_FORCE_DIET")
-    # word 1 written by key_pairs_kernel and read back by the pass on the top digit (the default computes it inside that pass)
-    monkeypatch.setenv("PSACX_NO_FUSED_KEYS", "1")
-    same_as_oracle(ctx, five, bits=64)
-    same_as_oracle(ctx, inputs.dna((1 << 21) + 100, 17), bits=64, k=12)
-    monkeypatch.delenv("PSACX_NO_FUSED_KEYS")
     monkeypatch.setenv("PSACX_NO_ONE_WORD", "1")
     same_as_oracle(ctx, five, bits=64)
 
@@ -808,25 +615,21 @@ def test_bucket_ids_of_resolved_tiles_are_filled_in_on_demand(ctx, monkeypatch):
     # rebucket_first_kernel (fused one-GPU form, from 2^22 characters on) does not write the bucket ids of a tile without
     # unresolved suffixes; when some OTHER tile has unresolved suffixes, run_compact fills them in before anybody reads them
     # (fill_resolved_ids_kernel).  Random DNA with one long repeat: two stretches of SA stay unresolved for several rounds, the
-    # rest of the tiles are resolved after the first.  Both word sizes, the per-round log included, and the eager form.
+    # rest of the tiles are resolved after the first.  Both word sizes, the per-round log included.
     text = inputs.dna((1 << 22) + 1000, 23)
     text[3000000:3050000] = text[100000:150000]
     for bits in (64, 32):
         got, ref = same_as_oracle(ctx, text, bits=bits)
         assert len(ref["trace"]) > 3
         assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
-    monkeypatch.setenv("PSACX_NO_LAZY_IDS", "1")
-    same_as_oracle(ctx, text, bits=64)
 
 
-@pytest.mark.parametrize("env", [{}, {"PSACX_NO_WHOLE_ROUNDS": "1"}, {"PSACX_WIDE_REFINE": "1"}, {"PSACX_NO_WHOLE_ROUNDS": "1", "PSACX_WIDE_REFINE": "1"}])
-def test_refinement_round_forms(ctx, monkeypatch, env):
+def test_refinement_round_forms(ctx):
     # rounds with at least 7/8 of the suffixes unresolved take all n records in text order and rebuild ISA by inverting SA
     # (shift_keys_kernel; not when SA order is nearly text order: sa_locality_kernel); 64-bit words below 2^32 characters
     # sort two-word records (bucket id and rank h further in one word, 32-bit suffix) from 2^21 records on.  Every form
-    # must give the arrays and the per-round log of the list form with three-word records.
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
+    # must give the oracle's arrays and per-round log (the single symbol takes the list form, the repeats the whole rounds; 32-bit
+    # words and the texts below 2^21 unresolved suffixes the three-word records).
     texts = [inputs.tandem((1 << 21) + 3000, 512, inputs.dna(512, 3)), np.full((1 << 21) + 17, 67, np.uint8),
              np.tile(inputs.dna(1 << 11, 9), (1 << 10) + 1)]
     texts[2][::4099] = 84

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the stand-alone rank-pair sort (psacx_pair_sort_dev) on round-1-like keys:
 (B1,B2) = (10-mer at i, 10-mer at i+10) of random DNA, 3 bits per character.
-PSACX_SORT_CFG selects the scatter shape, PSACX_SORT_DEBUG=1 prints per-phase clocks."""
+"""
 import ctypes as C
 import os
 import sys
@@ -38,7 +38,7 @@ for r in range(reps):
     per = ms / max(s.scatter_launches[q], 1)
     gbs = s.scatter_bytes[q] / (ms * 1e-3) / 1e9
     print("cfg=%s n=2^%d u%d: hist %.3f ms, tile-hist %.3f ms, scatter %.3f ms over %d passes (%.3f ms/pass) -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s)"
-          % (os.environ.get("PSACX_SORT_CFG", "def"), logn, bits, s.ms_sort_hist, s.ms_sort_tilehist, ms, s.scatter_launches[q], per, gbs, gbs / 80.0))
+          % ("def", logn, bits, s.ms_sort_hist, s.ms_sort_tilehist, ms, s.scatter_launches[q], per, gbs, gbs / 80.0))
 if logn <= 24:
     o1 = np.empty(n, dt); o2 = np.empty(n, dt); oi = np.empty(n, dt)
     ctx.d2h(o1, d1); ctx.d2h(o2, d2); ctx.d2h(oi, di)
