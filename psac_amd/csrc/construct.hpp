@@ -993,9 +993,9 @@ int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, ui
     PSACX_TRY(staged_h2d(c, d_text, text, n));
     int rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_lc);
     if (rc != PSACX_OK) return rc;
-    PSACX_TRY(staged_d2h(c, sa, d_sa, n * sizeof(T)));
-    PSACX_TRY(staged_d2h(c, isa, d_isa, n * sizeof(T)));
-    if (d_lcp) PSACX_TRY(staged_d2h(c, lcp, d_lcp, n * sizeof(T)));
+    PSACX_TRY(staged_d2h_entries<T>(c, sa, d_sa, n, n - 1));
+    PSACX_TRY(staged_d2h_entries<T>(c, isa, d_isa, n, n - 1));
+    if (d_lcp) PSACX_TRY(staged_d2h_entries<T>(c, lcp, d_lcp, n, ~0ull));
     if (d_lc) PSACX_TRY(staged_d2h(c, lc, d_lc, n));
     return PSACX_OK;
 }

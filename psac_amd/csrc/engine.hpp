@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,6 +29,8 @@ enum TimerCat {
 
 } // namespace psacx
 
+namespace psacx { struct HostPool; }
+
 struct psacx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -39,9 +44,14 @@ struct psacx_ctx {
     size_t pinned_bytes = 0;
     char* io = nullptr;              // device copies of text / SA / ISA / LCP for the host-pointer entry points (kept between calls)
     size_t io_bytes = 0;
-    char* stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points
+    // host-pointer entry points: a ring of pinned staging buffers, device-side bounce buffers of the same size (results leave the device
+    // in the narrowest entries that hold them) and a pool of host threads that moves the staged chunks to / from the caller's memory
+    static constexpr int STAGE_SLOTS = 4;
+    char* stage[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    char* dstage = nullptr;          // STAGE_SLOTS chunks of device memory
     size_t stage_bytes = 0;
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    psacx::HostPool* hpool = nullptr;
     // Freed device blocks of the multi-GPU path, kept for reuse (size -> pointer).  Every use of such a block is
     // ordered on this ctx's stream (its second stream joins it through events), so a block handed out again is
     // only touched after everything that used it before.  (hipMallocAsync was measured first: its pool stalls for
@@ -182,7 +192,7 @@ inline int ensure_slab(psacx_ctx* c, size_t bytes) {
 }
 
 inline int ensure_io(psacx_ctx* c, size_t bytes) {
-    if (c->io_bytes >= bytes && c->io_bytes / 4 <= bytes) return PSACX_OK;      // a much smaller request gives the rest back
+    if (c->io_bytes >= bytes) return PSACX_OK;      // (kept between calls; it goes back to the device when a construction needs the room, construct_dev, or with psacx_trim)
     if (c->io) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->io); c->io = nullptr; c->io_bytes = 0; }
     hipError_t e = hipMalloc((void**)&c->io, bytes);
     if (e != hipSuccess) {
@@ -195,14 +205,57 @@ inline int ensure_io(psacx_ctx* c, size_t bytes) {
 }
 
 // Host <-> device copies of the host-pointer entry points.  hipMemcpy on pageable memory stages through the
-// runtime's own bounce buffer with one copying thread (measured 9.5 GB/s device -> host); here the DMA engine
-// fills one pinned buffer while a few host threads empty the other into the caller's memory.
+// runtime's own bounce buffer with one copying thread (measured 9.5 GB/s device -> host); here the DMA engine works through a
+// ring of pinned buffers while a pool of host threads moves the chunks between them and the caller's memory.  Results leave the
+// device narrowed to the fewest bytes per entry that hold their largest value (a suffix array of 2^32 positions: 4 of its 8 bytes;
+// the LCP array of random text: 1) and are widened again by the host threads: PCIe carries 36 instead of 96 GiB for the headline
+// workload, the caller sees the same arrays.
 constexpr size_t STAGE_CHUNK = (size_t)64 << 20;
-constexpr int STAGE_THREADS = 8;
+inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu);
+
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(int, int)>* job = nullptr;
+    uint64_t gen = 0;
+    int pending = 0, n = 0;
+    bool stop = false;
+    explicit HostPool(int threads) : n(threads) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this, i]() { work(i); });
+    }
+    void work(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&]() { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job;
+            }
+            (*f)(i, n);
+            std::unique_lock<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    // f(t, n) on every thread t of the pool; returns when all are done
+    void run(const std::function<void(int, int)>& f) {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &f; pending = n; ++gen;
+        cv_job.notify_all();
+        cv_done.wait(lk, [this]() { return pending == 0; });
+    }
+    ~HostPool() {
+        { std::unique_lock<std::mutex> lk(mu); stop = true; cv_job.notify_all(); }
+        for (auto& t : th) t.join();
+    }
+};
 
 inline int ensure_stage(psacx_ctx* c) {
-    if (c->stage[0]) return PSACX_OK;
-    for (int i = 0; i < 2; ++i) {
+    if (c->stage[0] && c->hpool) return PSACX_OK;
+    for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) {
+        if (c->stage[i]) continue;
         if (hipHostMalloc((void**)&c->stage[i], STAGE_CHUNK, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
@@ -211,51 +264,120 @@ inline int ensure_stage(psacx_ctx* c) {
         }
     }
     c->stage_bytes = STAGE_CHUNK;
+    if (!c->hpool) {
+        // (a chunk of 64 MiB is a few MiB per thread: more threads than memory channels gain nothing)
+        const unsigned hw = std::thread::hardware_concurrency();
+        c->hpool = new HostPool((int)std::max(1u, std::min(32u, hw ? hw : 8u)));
+    }
     return PSACX_OK;
 }
 
-inline void parallel_memcpy(char* dst, const char* src, size_t bytes) {
-    const size_t min_per_thread = (size_t)4 << 20;
-    int nt = (int)std::min<size_t>(STAGE_THREADS, (bytes + min_per_thread - 1) / min_per_thread);
-    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
-    const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) {
-        const size_t o = per * t;
-        if (o >= bytes) break;
-        th.emplace_back([=]() { std::memcpy(dst + o, src + o, std::min(per, bytes - o)); });
-    }
-    std::memcpy(dst, src, std::min(per, bytes));
-    for (auto& x : th) x.join();
+// bytes [0, bytes) of src to dst by all threads of the pool (pieces of whole pages)
+inline void pool_memcpy(HostPool* hp, char* dst, const char* src, size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) { std::memcpy(dst, src, bytes); return; }
+    hp->run([=](int t, int nt) {
+        const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095, o = per * (size_t)t;
+        if (o < bytes) std::memcpy(dst + o, src + o, std::min(per, bytes - o));
+    });
 }
 
 inline int staged_d2h(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) {
     PSACX_TRY(ensure_stage(c));
+    constexpr int NS = psacx_ctx::STAGE_SLOTS;
     char* dst = static_cast<char*>(dst_); const char* src = static_cast<const char*>(src_);
-    size_t issued = 0, drained = 0; int qi = 0, qd = 0;
-    size_t len[2] = {0, 0};
+    size_t issued = 0, drained = 0; int qi = 0, qd = 0, inflight = 0;
+    size_t len[NS] = {0, 0, 0, 0};
     while (drained < bytes) {
-        while (issued < bytes && len[qi] == 0) {
+        while (issued < bytes && inflight < NS) {
             const size_t m = std::min(STAGE_CHUNK, bytes - issued);
             PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], src + issued, m, hipMemcpyDeviceToHost, c->stream));
             PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], c->stream));
-            len[qi] = m; issued += m; qi ^= 1;
+            len[qi] = m; issued += m; qi = (qi + 1) % NS; ++inflight;
         }
         PSACX_HIP(c, hipEventSynchronize(c->stage_ev[qd]));
-        parallel_memcpy(dst + drained, c->stage[qd], len[qd]);
-        drained += len[qd]; len[qd] = 0; qd ^= 1;
+        pool_memcpy(c->hpool, dst + drained, c->stage[qd], len[qd]);
+        drained += len[qd]; len[qd] = 0; qd = (qd + 1) % NS; --inflight;
+    }
+    return PSACX_OK;
+}
+
+template <typename T, typename E>
+__global__ void narrow_entries_kernel(const T* __restrict__ in, uint64_t cnt, E* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (E)in[i];
+}
+template <typename T>
+__global__ void max_entry_kernel(const T* __restrict__ in, uint64_t cnt, unsigned long long* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    T m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) { const T x = in[i]; m = x > m ? x : m; }
+    for (int d = 32; d > 0; d >>= 1) { const T o = (T)__shfl_xor((unsigned long long)m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+
+// `count` entries of T from device memory into the caller's array, travelling as the narrowest of 1 / 2 / 4-byte entries that hold
+// max_value (UINT64_MAX: found here with one pass over the array; wide values travel as they are)
+template <typename T>
+int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint64_t max_value) {
+    if (count == 0) return PSACX_OK;
+    PSACX_TRY(ensure_stage(c));
+    constexpr int NS = psacx_ctx::STAGE_SLOTS;
+    if (count * sizeof(T) < 4 * STAGE_CHUNK) return staged_d2h(c, dst, src, count * sizeof(T));
+    if (!c->dstage && hipMalloc((void**)&c->dstage, NS * STAGE_CHUNK) != hipSuccess) { (void)hipGetLastError(); c->dstage = nullptr; return staged_d2h(c, dst, src, count * sizeof(T)); }
+    if (max_value == ~0ull) {
+        unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->dstage);
+        PSACX_HIP(c, hipMemsetAsync(d_max, 0, 8, c->stream));
+        hipLaunchKernelGGL((max_entry_kernel<T>), dim3(grid_for(c, count, 256, 8)), dim3(256), 0, c->stream, src, count, d_max);
+        PSACX_HIP(c, hipGetLastError());
+        PSACX_HIP(c, hipMemcpyAsync(c->stage[0], d_max, 8, hipMemcpyDeviceToHost, c->stream));
+        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        max_value = *reinterpret_cast<unsigned long long*>(c->stage[0]);
+    }
+    const size_t e = max_value < (1ull << 8) ? 1 : max_value < (1ull << 16) ? 2 : max_value < (1ull << 32) ? 4 : 8;
+    if (e >= sizeof(T)) return staged_d2h(c, dst, src, count * sizeof(T));
+    const uint64_t per = STAGE_CHUNK / e;
+    uint64_t issued = 0, drained = 0; int qi = 0, qd = 0, inflight = 0;
+    uint64_t len[NS] = {0, 0, 0, 0};
+    HostPool* hp = c->hpool;
+    while (drained < count) {
+        while (issued < count && inflight < NS) {
+            const uint64_t m = std::min(per, count - issued);
+            char* const bounce = c->dstage + (size_t)qi * STAGE_CHUNK;
+            const int grid = grid_for(c, m, 256, 8);
+            if (e == 1) hipLaunchKernelGGL((narrow_entries_kernel<T, uint8_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint8_t*>(bounce));
+            else if (e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint16_t*>(bounce));
+            else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint32_t*>(bounce));
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * e, hipMemcpyDeviceToHost, c->stream));
+            PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], c->stream));
+            len[qi] = m; issued += m; qi = (qi + 1) % NS; ++inflight;
+        }
+        PSACX_HIP(c, hipEventSynchronize(c->stage_ev[qd]));
+        {
+            const uint64_t m = len[qd];
+            T* const out = dst + drained;
+            const char* const in = c->stage[qd];
+            hp->run([=](int t, int nt) {
+                const uint64_t a = m * (uint64_t)t / nt, b = m * (uint64_t)(t + 1) / nt;
+                if (e == 1) { const uint8_t* p = reinterpret_cast<const uint8_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
+                else if (e == 2) { const uint16_t* p = reinterpret_cast<const uint16_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
+                else { const uint32_t* p = reinterpret_cast<const uint32_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
+            });
+        }
+        drained += len[qd]; len[qd] = 0; qd = (qd + 1) % NS; --inflight;
     }
     return PSACX_OK;
 }
 
 inline int staged_h2d(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) {
     PSACX_TRY(ensure_stage(c));
+    constexpr int NS = psacx_ctx::STAGE_SLOTS;
     char* dst = static_cast<char*>(dst_); const char* src = static_cast<const char*>(src_);
-    int q = 0; bool used[2] = {false, false};
-    for (size_t off = 0; off < bytes; off += STAGE_CHUNK, q ^= 1) {
+    int q = 0; bool used[NS] = {false, false, false, false};
+    for (size_t off = 0; off < bytes; off += STAGE_CHUNK, q = (q + 1) % NS) {
         const size_t m = std::min(STAGE_CHUNK, bytes - off);
         if (used[q]) PSACX_HIP(c, hipEventSynchronize(c->stage_ev[q]));       // the DMA out of this buffer is over
-        parallel_memcpy(c->stage[q], src + off, m);
+        pool_memcpy(c->hpool, c->stage[q], src + off, m);
         PSACX_HIP(c, hipMemcpyAsync(dst + off, c->stage[q], m, hipMemcpyHostToDevice, c->stream));
         PSACX_HIP(c, hipEventRecord(c->stage_ev[q], c->stream));
         used[q] = true;
@@ -304,7 +426,8 @@ inline void pool_free(psacx_ctx* c, void* p, size_t cap) {
     c->pool_live -= std::min(c->pool_live, cap);
 }
 
-inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8) {
+inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu = 8);
+inline int grid_for(const psacx_ctx* c, uint64_t work_items, int block, int per_cu) {
     uint64_t want = (work_items + block - 1) / block;
     uint64_t cap = (uint64_t)c->n_cu * per_cu;
     if (want < 1) want = 1;
@@ -372,8 +495,8 @@ template <typename T> struct ScatterCfg { static constexpr int BLOCK = 512, ITEM
 
 template <typename T, typename D>
 inline void dispatch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out, uint64_t n, int shift,
-                             const unsigned long long* base, char* desc, unsigned* err) {
-    launch_scatter<T, D, ScatterCfg<T>::BLOCK, ScatterCfg<T>::ITEMS>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, nullptr, 0, 0);
+                             const unsigned long long* base, char* desc, unsigned* err, uint64_t spec, uint64_t spec_n) {
+    launch_scatter<T, D, ScatterCfg<T>::BLOCK, ScatterCfg<T>::ITEMS>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, desc, err, nullptr, spec, spec_n);
 }
 
 // One pass of the three-kernel form: tile histograms (unless the producer of the keys left them), slab / top scans, scatter.
@@ -630,8 +753,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
-            if (small_desc) dispatch_scatter<T, uint32_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err);
-            else dispatch_scatter<T, uint64_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err);
+            if (small_desc) dispatch_scatter<T, uint32_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, spec, spec_n);
+            else dispatch_scatter<T, uint64_t>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, desc, sc.d_err, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
         }
         const int form = !in.k2 ? 2 : (three ? 1 : 0);

@@ -63,10 +63,12 @@ void psacx_destroy(psacx_ctx* c) {
     if (c->io) (void)hipFree(c->io);
     pool_flush(c);
     delete c->pool;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     }
+    if (c->dstage) (void)hipFree(c->dstage);
+    delete c->hpool;
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -94,6 +96,7 @@ int psacx_trim(psacx_ctx* c) {
     if (c->slab) { PSACX_HIP(c, hipFree(c->slab)); c->slab = nullptr; c->slab_bytes = 0; }
     if (c->aux) { PSACX_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
     if (c->io) { PSACX_HIP(c, hipFree(c->io)); c->io = nullptr; c->io_bytes = 0; }
+    if (c->dstage) { PSACX_HIP(c, hipFree(c->dstage)); c->dstage = nullptr; }
     pool_flush(c);
     return PSACX_OK;
 }

@@ -139,3 +139,41 @@ def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     # the same with room for only a quarter of the unresolved suffixes per slab of a refinement round
     text2, sb = _tandem_twin(ctx, monkeypatch, 1 << 25)
     assert np.array_equal(sb.local_SA, SA) and np.array_equal(sb.local_LCP, LCP) and np.array_equal(sb.local_B, sa.local_B)
+
+
+def test_host_pointer_path_narrow_transfers(ctx):
+    # psacx_construct_u64 on host pointers (SURVEY 8(d) Metric 1: what psac's construct() spans): the results leave the device in the
+    # narrowest entries that hold them (engine.hpp: staged_d2h_entries -- SA / ISA of fewer than 2^32 positions in 4 of their 8 bytes, LCP
+    # in 1, 2 or 4 according to its largest value) and are widened on the host.  Against the arrays of the device-pointer path copied
+    # as they are: random DNA (LCP < 256), one repeat of 300 characters (LCP < 65536), one of 100000 characters (4-byte entries), and
+    # 2^30 characters.
+    import psac_amd
+    def both(text):
+        n = text.size
+        hs = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+        hs.construct(text)
+        d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+        d = [ctx.alloc(n * 8) for _ in range(3)]
+        try:
+            ds = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+            ds.construct_device(d_text, n, d[0], d[1], d[2])
+            tmp = np.empty(n, np.uint64)
+            for arr, p in ((hs.local_SA, d[0]), (hs.local_B, d[1]), (hs.local_LCP, d[2])):
+                ctx.d2h(tmp, p)
+                assert np.array_equal(arr, tmp)
+        finally:
+            for p in [d_text] + d:
+                ctx.free(p)
+        return hs
+    n = (1 << 27) + 12345
+    t = inputs.dna(n, 21)
+    hs = both(t)
+    assert int(hs.local_LCP.max()) < 256
+    t2 = t.copy(); t2[90000000:90000300] = t2[1000:1300]
+    hs = both(t2)
+    assert 300 <= int(hs.local_LCP.max()) < 65536
+    t3 = t.copy(); t3[90000000:90100000] = t3[5000:105000]
+    hs = both(t3)
+    assert int(hs.local_LCP.max()) >= 100000
+    del hs, t2, t3
+    both(inputs.dna(1 << 30, 4))

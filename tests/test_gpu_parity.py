@@ -179,6 +179,149 @@ def test_isa_inversion_forms(ctx, monkeypatch):
         assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_B, B) and np.array_equal(sa.local_LCP, LCP)
 
 
+def test_pair_sort_standalone(ctx):
+    # idxsort.hpp:23-83: records (b1, b2, i) sorted by (b1, b2)
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    for bits, dt in ((32, np.uint32), (64, np.uint64)):
+        for n in (1, 2, 1000, 4096, 4097, 300001):
+            hi = 1 << 20
+            b1 = rng.integers(0, 50, n).astype(dt)
+            b2 = rng.integers(0, hi, n).astype(dt)
+            d1 = ctx.alloc(b1.nbytes); d2 = ctx.alloc(b2.nbytes); di = ctx.alloc(b1.nbytes)
+            ctx.h2d(d1, b1); ctx.h2d(d2, b2)
+            fn = getattr(ctx._lib, "psacx_pair_sort_dev_u%d" % bits)
+            ctx.check(fn(ctx.handle, C.c_void_p(d1), C.c_void_p(d2), C.c_void_p(di), n, 21))
+            o1 = np.empty(n, dt); o2 = np.empty(n, dt); oi = np.empty(n, dt)
+            ctx.d2h(o1, d1); ctx.d2h(o2, d2); ctx.d2h(oi, di)
+            for p in (d1, d2, di):
+                ctx.free(p)
+            order = np.lexsort((b2, b1))          # stable, so ties keep index order
+            assert np.array_equal(oi, order.astype(dt))
+            assert np.array_equal(o1, b1[order]) and np.array_equal(o2, b2[order])
+
+
+def test_errors(ctx):
+    import psac_amd
+    sa = psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
+    with pytest.raises(ValueError):
+        sa.construct(b"")
+    import ctypes as C
+    rc = ctx._lib.psacx_construct_u32(ctx.handle, None, 5, 0, 0, None, None, None)
+    assert rc == -1
+
+
+def test_ansv_all_type_combinations(ctx):
+    # test/test_ansv.cpp:232-252, 270-282: every (left_type, right_type) on rand() % 100 inputs,
+    # n in {13, 137, 1000, 26666}; plus an LCP array (suffix_tree.hpp:62 uses furthest_eq / nearest_sm)
+    import psac_amd
+    rng = np.random.default_rng(17)
+    NO = 2**64 - 1
+    cases = [rng.integers(0, 100, n).astype(np.uint32) for n in (1, 2, 13, 137, 1000, 26666)]
+    cases.append(rng.integers(0, 3, 70000).astype(np.uint64))
+    cases.append(np.zeros(5000, np.uint32))
+    cases.append(np.arange(5000, dtype=np.uint32))
+    cases.append(np.arange(5000, dtype=np.uint64)[::-1].copy())
+    text = O.rand_dna(200000, 5)
+    cases.append(O.construct(text, bits=32)["LCP"])
+    for v in cases:
+        for lt in (0, 1, 2):
+            for rt in (0, 1, 2):
+                if v.size > 30000 and (lt, rt) not in ((0, 0), (2, 0), (1, 2)):
+                    continue
+                left, right = psac_amd.ansv(v, lt, rt, nonsv=NO, ctx=ctx)
+                assert np.array_equal(left, O.ansv(v, True, lt, NO)), (v.size, lt, rt)
+                assert np.array_equal(right, O.ansv(v, False, rt, NO)), (v.size, lt, rt)
+
+
+def test_cli_and_cpp_header(ctx, tmp_path):
+    # psac CLI parity (src/psac.cpp:65-128): -f/-l/-c/-o, .sa64/.lcp64 as raw uint64, print64 listing
+    # of README.md:88-100
+    import subprocess
+    root = os.path.dirname(HERE)
+    psac = os.path.join(root, "psac_amd", "bin", "psac")
+    p64 = os.path.join(root, "psac_amd", "bin", "print64")
+    if not (os.path.exists(psac) and os.path.exists(p64)):
+        pytest.skip("CLI not built")
+    f = tmp_path / "miss.txt"
+    f.write_bytes(b"mississippi")
+    r = subprocess.run([psac, "-f", str(f), "-l", "-c", "-o", str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "PSAC time:" in r.stderr and "[SUCCESS]" in r.stderr
+    sa = np.fromfile(str(tmp_path / "out.sa64"), dtype=np.uint64)
+    lcp = np.fromfile(str(tmp_path / "out.lcp64"), dtype=np.uint64)
+    assert sa.tolist() == KAT["mississippi"]["SA"] and lcp.tolist() == KAT["mississippi"]["LCP"]
+    listing = subprocess.run([p64, str(tmp_path / "out.sa64")], capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in listing] == KAT["mississippi"]["SA"]
+    # random input through -r, checked by the CLI's own -c, then the -t path (ANSV over LCP)
+    r = subprocess.run([psac, "-r", "300000", "-s", "3", "-l", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[SUCCESS]" in r.stderr, r.stderr
+    r = subprocess.run([psac, "-r", "100000", "-t", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ST time:" in r.stderr and "ST edges:" in r.stderr, r.stderr
+    # argument errors exit non-zero like TCLAP (src/psac.cpp:147-150)
+    assert subprocess.run([psac], capture_output=True).returncode != 0
+    assert subprocess.run([psac, "-f", str(f), "-r", "5"], capture_output=True).returncode != 0
+
+
+def _dist_loopback_gpu(text, P, bits, k=0):
+    import torch
+    from dist_harness import dist as D
+    from dist_harness.comm import LoopbackWorld
+    from dist_harness.dist_ops import HipOps
+    sizes = D.blk_sizes(text.size, P)
+    offs = D.prefix(sizes)
+    ops = [HipOps(bits, 0) for _ in range(P)]
+    blocks = [torch.from_numpy(text[o:o + s].copy()).cuda() for o, s in zip(offs, sizes)]
+
+    def fn(comm, op, blk):
+        return (yield from D.construct(comm, op, blk, want_lcp=True, k_req=k))
+    res = LoopbackWorld(P).run(fn, [(ops[r], blocks[r]) for r in range(P)])
+    udt = np.uint32 if bits == 32 else np.uint64
+    cat = lambda key: np.concatenate([r[key].cpu().numpy().view(udt) for r in res])
+    out = cat("SA"), cat("ISA"), cat("LCP"), res[0]["rounds"]
+    for o in ops:
+        o.close()
+    return out
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_distributed_ops_on_one_gpu(ctx, P):
+    # the block-distributed choreography with the HIP step ops, P virtual ranks sharing this GPU
+    for bits in (32, 64):
+        text = O.rand_dna(60011, 7)
+        sa, isa, lcp, _ = _dist_loopback_gpu(text, P, bits)
+        ref = O.construct(text, bits=bits)
+        assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+    unit = O.rand_dna(256, 3)
+    text = inputs.tandem(40000, 256, unit)
+    sa, isa, lcp, rounds = _dist_loopback_gpu(text, P, 32)
+    ref = O.construct(text, bits=32)
+    assert np.array_equal(sa, ref["SA"]) and np.array_equal(isa, ref["ISA"]) and np.array_equal(lcp, ref["LCP"])
+    text = O.rand_dna(30011, 23)
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, P, 64, k=3)
+    assert np.array_equal(sa, O.naive_sa(text, 64))
+    assert np.array_equal(O.kasai(text, sa, isa), lcp)
+
+
+def test_distributed_shift_saturates(ctx):
+    # psacx_op_add_scalar: SA + h in 64 bits, clamped to n (see tests/test_dist_cpu.py for the CPU twin)
+    import torch
+    from dist_harness.dist_ops import HipOps
+    ops = HipOps(32, 0)
+    n = 0xFFFFFF00
+    sa = torch.from_numpy(np.array([5, 0x80000000, 0xFFFFFE00, 0xFFFFFEFF], np.uint32).view(np.int32)).cuda()
+    q = ops.add_scalar(sa, 0x200, n)
+    assert q.cpu().numpy().view(np.uint32).tolist() == [0x205, 0x80000200, n, n]
+    ops.close()
+
+
+def test_distributed_ops_larger(ctx):
+    text = inputs.dna((1 << 22) + 1234, 9)
+    sa, isa, lcp, _ = _dist_loopback_gpu(text, 3, 32)
+    assert O.check_sa(text, sa, isa) == 0
+    assert np.array_equal(O.kasai(text, sa, isa), lcp)
+
+
 def test_low_entropy_text_many_range_minima(ctx):
     # 2^21 characters with geometric symbol frequencies: most suffixes stay unresolved after the first round, so
     # the refinement issues ~10^6 range minima per round and the running-minimum tables (levels 0 and up) are in
