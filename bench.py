@@ -118,7 +118,7 @@ def cpu_baseline(kind, sample, seed, bits):
     return out
 
 
-def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism, onew_passes=0):
+def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k, l, rounds, parallelism, onew_passes=0, scat_records=None):
     w = bits // 8
     ms_per_step = dt / a.steps * 1e3
     value = world * n * a.steps / dt / 1e6
@@ -156,7 +156,9 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                      "avg_launch_ms": round(scat_ms[dom] / max(scat_launches[dom], 1), 4),
                      "launches_per_step": scat_launches[dom] // max(a.steps, 1),
                      "algorithmic_bytes_per_launch": scat_bytes[dom] // max(scat_launches[dom], 1),
-                     "bytes_per_record_per_pass": round(scat_bytes[dom] / max(scat_launches[dom], 1) / float(n), 2),
+                     "records_per_launch": (scat_records[dom] // max(scat_launches[dom], 1)) if scat_records else n,
+                     "bytes_per_record_per_pass": round(scat_bytes[dom] / float(max(scat_records[dom], 1)), 2) if scat_records
+                                                  else round(scat_bytes[dom] / max(scat_launches[dom], 1) / float(n), 2),
                      "traffic": TRAFFIC.get((tkey, n, bits)) if world == 1 else None,
                      "traffic_source": "PMC counters of the committed profile of this workload (profiles/), not measured in this run"},
     }
@@ -186,20 +188,28 @@ def main_distributed(a, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if a.n is None:
-        # The largest block of 2^32, 2^31 (configs[3]: 16 GiB over 8 GPUs), 2^30, 2^28 characters per GPU that fits every GPU.
-        # With more than one rank the reduced-memory layout peaks at 4.75 words per character for the engine (the shuffle holds
-        # the partitioned records, the receive arrays and the second record set at once; measured with two ranks of 2^31,
-        # profiles/r04b_*) + 3.375 for the result arrays with their slack + the text = 8.25 words of 8 bytes: 264 GiB at 2^32
-        # characters.  That does not leave room for the block cache's fragmentation and RCCL's buffers on a 288 GiB part (tried:
-        # out of memory in the first exchange, profiles/r04d_*), so a full GPU takes 2^31.  Asked for: 9.5 words + 8 GiB.
+        # The largest block of 2^32 (BASELINE.json configs[4]: 32 GiB over 8 GPUs) or 2^31 (configs[3]: 16 GiB over 8 GPUs) characters per
+        # GPU that fits every GPU.  The reduced-memory layout of the multi-GPU engine peaks at 2.63 words per character for the engine
+        # (profiles/r4d_*: the one-word first round keeps its records in the rank's result arrays, the re-balance runs in place) + 3.375
+        # for the result arrays with their slack + the text = 6.13 words of 8 bytes: 196 GiB at 2^32 characters.  Asked for: 7 words + 8 GiB
+        # (RCCL's buffers, the block cache's odd sizes).  A GPU that cannot hold 2^31 is not the machine this benchmark is defined on:
+        # the run stops with a reason instead of quoting a smaller workload as if it were the configured one (--n overrides).
         free_b = torch.cuda.mem_get_info(local_rank)[0]
-        fit = 28
-        for lg in (32, 31, 30):
-            if free_b >= int(9.5 * 8 * (1 << lg)) + (8 << 30):
+        fit = 0
+        for lg in (32, 31):
+            if free_b >= int(7.0 * 8 * (1 << lg)) + (8 << 30):
                 fit = lg
                 break
         t_fit = torch.tensor([fit], dtype=torch.int32, device="cuda")
         dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+        if int(t_fit.item()) == 0:
+            if rank == 0:
+                sys.stderr.write("bench.py --gpus %d: a rank has %.1f GiB of free device memory, fewer than the %.1f GiB a block of 2^31 characters "
+                                 "needs (7 words of 8 bytes per character + 8 GiB); pass --n to run a smaller block\n"
+                                 % (world, free_b / 2.0 ** 30, (7.0 * 8 * (1 << 31) + (8 << 30)) / 2.0 ** 30))
+            dist.destroy_process_group()
+            os.dup2(real_stdout, 1)
+            sys.exit(3)
         a.n = 1 << int(t_fit.item())
     n = a.n
     bits = a.index if a.index else (32 if world * n <= (1 << 31) else 64)
@@ -253,42 +263,48 @@ def main_distributed(a, rank, world, local_rank):
     lib.psacx_get_stats(ctx, C.byref(s))
     # what every rank saw in its last step: the wire calls it issued, the time its exchanges held its second stream and the
     # host wall time of its phases
-    mine = {"rank": rank, "wire": mg.wire(), "phases_ms": dict((k, round(v, 3)) for k, v in mg.phases()), "payload_bytes_sent": sent}
+    peak_r, reduced_r, slab_rounds_r = mg.memory()
+    mine = {"rank": rank, "wire": mg.wire(), "phases_ms": dict((k, round(v, 3)) for k, v in mg.phases()), "payload_bytes_sent": sent,
+            "ranks_seen_by_rccl": mg.nranks, "transport": mg.transport, "forms": mg.last_form(),
+            "engine_words_per_char_at_peak": round(peak_r[0] / float(n * w), 2),
+            "wire_piece_bytes": int(os.environ.get("PSACX_MULTI_WIRE_PIECE", str(1 << 28)))}
     per_rank = [None] * world
     dist.all_gather_object(per_rank, mine)
     if rank == 0:
         out = report(a, world, n, bits, dt, [s.ms_sort_scatter, s.ms_sort_scatter3, s.ms_sort_scatter2], list(s.scatter_bytes),
                      list(s.scatter_launches), None, int(st.k), int(st.bits_per_char), int(st.n_rounds),
                      "block-partitioned text, 1 rank per GPU, C++ host over RCCL (grouped ncclSend/ncclRecv: sort shuffle, "
-                     "ISA scatter, B2 fetch, range minima) on a second stream per GPU")
+                     "ISA scatter, B2 fetch, range minima) on a second stream per GPU", int(s.onew_passes), list(s.scatter_records))
         out["exchange"] = {"payload_bytes_sent_by_rank0_per_step": sent, "all_to_all_exchanges_per_step": nex,
                            "scalar_all_gathers_per_step": nga, "uses_rccl": mg.uses_rccl, "transport": mg.transport,
-                           "ranks_seen_by_rccl": mg.nranks,
+                           "ranks_seen_by_rccl": [p["ranks_seen_by_rccl"] for p in per_rank],
+                           "wire_piece_bytes": mine["wire_piece_bytes"], "forms_per_rank": [p["forms"] for p in per_rank],
                            "exchange_ms_on_second_stream_per_rank": [p["wire"]["exchange_ms"][0] for p in per_rank],
                            "nccl_calls_last_step_rank0": {k: mine["wire"][k] for k in ("sends", "recvs", "allgathers")}}
         out["phase_ms_last_step_per_rank"] = [p["phases_ms"] for p in per_rank]
         peak, reduced, slab_rounds = mg.memory()
         out["config"]["layout"] = {"reduced_memory": reduced, "refinement_rounds_in_slabs": slab_rounds,
                                    "engine_words_per_char_at_peak": round(peak[0] / float(n * w), 2),
+                                   "engine_words_per_char_at_peak_per_rank": [p["engine_words_per_char_at_peak"] for p in per_rank],
                                    "result_arrays_words_per_char": round(3.0 * (n + slack) / n, 3)}
-        # for a like-for-like scaling figure: the one-GPU engine on rank 0's block alone (same size, same index width),
-        # timed after the measured region.  With 2^32 characters per GPU that is the N = 1 bench line itself.
-        if n >= (1 << 32):
-            out["config"]["one_gpu_engine_same_block"] = "the N = 1 line of this bench (same block, same index width)"
-        else:
-            try:
-                lib.psacx_trim(ctx)              # the multi-GPU engine's cached blocks go back to the device first
-                one = psac_amd.Context(local_rank)
-                sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
+        # for a like-for-like scaling figure: the one-GPU engine on rank 0's block alone (same size, same index width, the same
+        # buffers), timed after the measured region; weak_scaling_efficiency = value / (N x that rate)
+        try:
+            lib.psacx_trim(ctx)              # the multi-GPU engine's cached blocks go back to the device first
+            one = psac_amd.Context(local_rank)
+            sa1 = psac_amd.SuffixArray(index_bits=bits, lcp=not a.no_lcp, ctx=one)
+            sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
+            t1 = time.perf_counter()
+            for _ in range(3):
                 sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    sa1.construct_device(d_text, n, d_sa, d_isa, None if a.no_lcp else d_lcp)
-                t1 = (time.perf_counter() - t1) / 3
-                out["config"]["one_gpu_engine_same_block"] = {"ms": round(t1 * 1e3, 3), "MChars_per_s": round(n / t1 / 1e6, 1)}
-                one.close()
-            except Exception as e:          # never let the side measurement break the bench line
-                out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
+            t1 = (time.perf_counter() - t1) / 3
+            one_rate = n / t1 / 1e6
+            out["config"]["one_gpu_engine_same_block"] = {"ms": round(t1 * 1e3, 3), "MChars_per_s": round(one_rate, 1)}
+            out["weak_scaling_efficiency"] = round(out["value"] / (world * one_rate), 4)
+            one.close()
+        except Exception as e:          # never let the side measurement break the bench line
+            out["config"]["one_gpu_engine_same_block"] = {"error": str(e)[:200]}
+            out["weak_scaling_efficiency"] = None
     for p in (d_text, d_sa, d_isa, d_lcp):
         lib.psacx_dev_free(ctx, C.c_void_p(p))
     mg.close()
@@ -465,9 +481,11 @@ def main():
         hs.local_SA, hs.local_B, hs.local_LCP = hs.construct_into(text, hs.local_SA, hs.local_B, hs.local_LCP)
         ht = time.perf_counter() - t1
         out["construct_host"] = {"ms": round(ht * 1e3, 1), "MChars_per_s": round(hn / ht / 1e6, 1), "n": hn,
-                                 "note": "psacx_construct_u%d on host pointers (SURVEY 8(d) Metric 1): H2D %d MiB + D2H %d MiB through "
-                                         "pinned staging buffers, second call on touched pageable memory"
-                                         % (bits, hn >> 20, (hn * w * (2 if a.no_lcp else 3)) >> 20)}
+                                 "note": "psacx_construct_u%d on host pointers (SURVEY 8(d) Metric 1): H2D of %d MiB of text, %d MiB of results "
+                                         "written into the caller's arrays; they cross PCIe narrowed to the fewest bytes per entry that hold "
+                                         "their largest value (SA / ISA 4 of %d bytes at this size, LCP 1 on random text) through a ring of pinned "
+                                         "buffers and are widened by host threads; second call on touched pageable memory"
+                                         % (bits, hn >> 20, (hn * w * (2 if a.no_lcp else 3)) >> 20, w)}
         del text, hs
     if a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)

@@ -51,6 +51,8 @@ struct psacx_ctx {
     char* dstage = nullptr;          // STAGE_SLOTS chunks of device memory
     size_t stage_bytes = 0;
     hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream[2] = {nullptr, nullptr};     // the device -> host copies of the narrowed chunks alternate between two streams (two DMA engines)
+    hipEvent_t narrow_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     psacx::HostPool* hpool = nullptr;
     // Freed device blocks of the multi-GPU path, kept for reuse (size -> pointer).  Every use of such a block is
     // ordered on this ctx's stream (its second stream joins it through events), so a block handed out again is
@@ -264,10 +266,15 @@ inline int ensure_stage(psacx_ctx* c) {
         }
     }
     c->stage_bytes = STAGE_CHUNK;
+    for (int i = 0; i < 2; ++i)
+        if (!c->copy_stream[i] && hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream[i] = nullptr; }
+    for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i)
+        if (!c->narrow_ev[i] && hipEventCreateWithFlags(&c->narrow_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->narrow_ev[i] = nullptr; }
     if (!c->hpool) {
-        // (a chunk of 64 MiB is a few MiB per thread: more threads than memory channels gain nothing)
+        // (tools/ubench_pcie.hip on the GPU box: 8 - 16 threads with streaming stores widen at 280 - 300 GB/s, 48 threads at 98 -- more
+        //  threads than memory channels lose; the DMA engine delivers 51 - 57 GB/s)
         const unsigned hw = std::thread::hardware_concurrency();
-        c->hpool = new HostPool((int)std::max(1u, std::min(32u, hw ? hw : 8u)));
+        c->hpool = new HostPool((int)std::max(1u, std::min(16u, hw ? hw : 8u)));
     }
     return PSACX_OK;
 }
@@ -348,8 +355,14 @@ int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint6
             else if (e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint16_t*>(bounce));
             else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint32_t*>(bounce));
             PSACX_HIP(c, hipGetLastError());
-            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * e, hipMemcpyDeviceToHost, c->stream));
-            PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], c->stream));
+            hipStream_t cs = c->stream;
+            if (c->copy_stream[qi & 1] && c->narrow_ev[qi]) {
+                cs = c->copy_stream[qi & 1];
+                PSACX_HIP(c, hipEventRecord(c->narrow_ev[qi], c->stream));
+                PSACX_HIP(c, hipStreamWaitEvent(cs, c->narrow_ev[qi], 0));
+            }
+            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * e, hipMemcpyDeviceToHost, cs));
+            PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], cs));
             len[qi] = m; issued += m; qi = (qi + 1) % NS; ++inflight;
         }
         PSACX_HIP(c, hipEventSynchronize(c->stage_ev[qd]));
@@ -359,9 +372,11 @@ int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint6
             const char* const in = c->stage[qd];
             hp->run([=](int t, int nt) {
                 const uint64_t a = m * (uint64_t)t / nt, b = m * (uint64_t)(t + 1) / nt;
-                if (e == 1) { const uint8_t* p = reinterpret_cast<const uint8_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
-                else if (e == 2) { const uint16_t* p = reinterpret_cast<const uint16_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
-                else { const uint32_t* p = reinterpret_cast<const uint32_t*>(in); for (uint64_t i = a; i < b; ++i) out[i] = (T)p[i]; }
+                // (streaming stores: the caller's array is written once and not read here -- no read-for-ownership traffic on the host side,
+                //  which is what bounds this path: 128 MiB written per 64 MiB chunk that PCIe delivers)
+                if (e == 1) { const uint8_t* p = reinterpret_cast<const uint8_t*>(in); for (uint64_t i = a; i < b; ++i) __builtin_nontemporal_store((T)p[i], out + i); }
+                else if (e == 2) { const uint16_t* p = reinterpret_cast<const uint16_t*>(in); for (uint64_t i = a; i < b; ++i) __builtin_nontemporal_store((T)p[i], out + i); }
+                else { const uint32_t* p = reinterpret_cast<const uint32_t*>(in); for (uint64_t i = a; i < b; ++i) __builtin_nontemporal_store((T)p[i], out + i); }
             });
         }
         drained += len[qd]; len[qd] = 0; qd = (qd + 1) % NS; --inflight;

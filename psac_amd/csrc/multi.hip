@@ -127,9 +127,10 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
         psacx_ctx* cx = g->R[r].ctx;
         MG_HIP(g, hipSetDevice(cx->device));
         if (!m[r]) continue;
-        MG_OP(g, cx, staged_d2h(cx, sa + off[r], dsa[r].p, m[r] * sizeof(T)));
-        MG_OP(g, cx, staged_d2h(cx, isa + off[r], disa[r].p, m[r] * sizeof(T)));
-        if (want_lcp) MG_OP(g, cx, staged_d2h(cx, lcp + off[r], dlcp[r].p, m[r] * sizeof(T)));
+        // (narrowed on the device, widened on the host: engine.hpp: staged_d2h_entries)
+        MG_OP(g, cx, staged_d2h_entries<T>(cx, sa + off[r], dsa[r].p, m[r], n - 1));
+        MG_OP(g, cx, staged_d2h_entries<T>(cx, isa + off[r], disa[r].p, m[r], n - 1));
+        if (want_lcp) MG_OP(g, cx, staged_d2h_entries<T>(cx, lcp + off[r], dlcp[r].p, m[r], ~0ull));
     }
     return PSACX_OK;
 }

@@ -68,6 +68,8 @@ void psacx_destroy(psacx_ctx* c) {
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     }
     if (c->dstage) (void)hipFree(c->dstage);
+    for (int i = 0; i < 2; ++i) if (c->copy_stream[i]) (void)hipStreamDestroy(c->copy_stream[i]);
+    for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) if (c->narrow_ev[i]) (void)hipEventDestroy(c->narrow_ev[i]);
     delete c->hpool;
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);

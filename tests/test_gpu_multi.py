@@ -291,6 +291,21 @@ def test_bench_and_cli_process_per_gpu_path(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and "roofline" in out and out["config"]["rounds"] >= 1
+    # what makes the N > 1 line readable: the one-GPU engine on the same block and the efficiency against it, what RCCL saw, the memory
+    # peak per rank, the piece size of the wire, the forms the construction took -- and, with the wire forced and the one-word first round
+    # at this size, a roofline entry quoted on the bucket passes (16 or 24 bytes per record) with every send matched by a receive
+    env2 = dict(env, PSACX_MULTI_FORCE_WIRE="1", PSACX_MULTI_TWO_WORD="1", PSACX_MULTI_ONE_WORD="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29579", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", str(1 << 24), "--index", "64"],
+                       capture_output=True, text=True, env=env2, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["one_gpu_engine_same_block"]["ms"] > 0 and 0 < out["weak_scaling_efficiency"] < 2
+    ex = out["exchange"]
+    assert ex["ranks_seen_by_rccl"] == [1] and ex["transport"] == "rccl" and ex["wire_piece_bytes"] == 1 << 28
+    assert ex["forms_per_rank"][0]["one_word"] and ex["nccl_calls_last_step_rank0"]["sends"] == ex["nccl_calls_last_step_rank0"]["recvs"] > 0
+    assert out["config"]["layout"]["engine_words_per_char_at_peak_per_rank"][0] > 0
+    assert 16 <= out["roofline"]["bytes_per_record_per_pass"] <= 24 and out["roofline"]["records_per_launch"] > 0
     env = dict(os.environ, PSACX_CLI_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29578", "-m", "psac_amd", "-r", "300000", "-s", "2", "-l", "-c"], capture_output=True, text=True, env=env,
