@@ -55,6 +55,11 @@ struct blk_dist {
     int rank_of(std::size_t) const { return 0; }
 };
 
+// characters compare by their unsigned value (alphabet.hpp:205-236)
+template <typename char_t> struct unsigned_less {
+    bool operator()(char_t a, char_t b) const { typedef typename std::make_unsigned<char_t>::type u; return (u)a < (u)b; }
+};
+
 // the part of alphabet<char> callers read (alphabet.hpp:147-164, :224-262, :296-300)
 template <typename char_t> class alphabet {
 public:
@@ -212,11 +217,33 @@ public:
     // suffix_array.hpp:469-486
     template <typename Iterator>
     void construct(Iterator begin, Iterator end, bool fast_resolval = true, unsigned int k = 0) {
+        construct_with(begin, end, fast_resolval, k, nullptr);
+    }
+    // suffix_array.hpp:365-366: the alphabet and k come from the caller (an alphabet that covers more characters than occur is
+    // fine: SA, ISA and LCP do not depend on the coding, which only has to keep the order of the characters; a character
+    // outside it is an error).  `alpha` is the caller's afterwards, as in the reference.
+    template <typename Iterator>
+    void construct(Iterator begin, Iterator end, bool fast_resolval, const alphabet_type& a, unsigned int k) {
+        construct_with(begin, end, fast_resolval, k, &a);
+    }
+
+private:
+    template <typename Iterator>
+    void construct_with(Iterator begin, Iterator end, bool fast_resolval, unsigned int k, const alphabet_type* given) {
         init_size((std::size_t)std::distance(begin, end));
         if (n == 0) throw std::runtime_error("psacx: empty input");
         std::vector<uint8_t> bytes(n);
         std::vector<char_t> chars;
         densify(begin, end, bytes, chars);
+        if (given) {
+            const std::vector<char_t>& have = given->unique_chars();
+            for (std::size_t i = 0; i < chars.size(); ++i)
+                if (!std::binary_search(have.begin(), have.end(), chars[i], psacx::unsigned_less<char_t>()))
+                    throw std::runtime_error("psacx: the text holds a character that is not in the given alphabet");
+            if (k == 0) throw std::runtime_error("psacx: construct with an explicit alphabet needs k > 0");
+            const unsigned int kmax = given->template chars_per_word<index_t>();
+            if (k > kmax) k = kmax;
+        }
         local_SA.assign(n, 0); local_B.assign(n, 0);
         if (_CONSTRUCT_LCP) local_LCP.assign(n, 0); else local_LCP.clear();
         uint32_t flags = (_CONSTRUCT_LCP ? PSACX_LCP : 0u) | (fast_resolval ? 0u : PSACX_NO_FAST);
@@ -247,7 +274,7 @@ public:
         psacx_stats st;
         if (multi_) psacx::check(nullptr, psacx_multi_get_stats(multi_, &st, nullptr, nullptr, nullptr));
         else psacx::check(ctx_, psacx_get_stats(ctx_, &st));
-        alpha.set(chars);
+        if (given) alpha = *given; else alpha.set(chars);
         if (verbose) {
             PSACX_INFO("Alphabet: " << alpha);                       // suffix_array.hpp:481
             for (uint32_t r = 0; r < st.n_rounds; ++r)                // suffix_array.hpp:416
@@ -256,6 +283,7 @@ public:
         }
     }
 
+public:
     // suffix_array.hpp:267-363: generalized suffix array of a string set.  local_SA counts positions
     // in the strings laid back to back without separators; equal suffixes come in that order.
     void construct_ss(simple_dstringset& ss, const alphabet_type& a) {

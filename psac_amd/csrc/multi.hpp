@@ -1532,9 +1532,10 @@ struct MultiRun {
             // so that the sort of an earlier range, which widens its entries in place, never touches a later range's input.
             std::vector<std::vector<hipEvent_t>> done(2 * QR, std::vector<hipEvent_t>(L, nullptr));
             auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
-            for (int q = 0; q < 2 * QR; ++q) for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming)); }
-            const uint64_t wide = sizeof(T) / vb;                // narrow entries per word
             int rc = PSACX_OK;
+            for (int q = 0; q < 2 * QR && rc == PSACX_OK; ++q) for (int i = 0; i < L && rc == PSACX_OK; ++i)
+                if (hipSetDevice(ctx(i)->device) != hipSuccess || hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming) != hipSuccess) { mg_set_err(g, "two-word first sort: event creation failed"); rc = PSACX_EHIP; }
+            const uint64_t wide = sizeof(T) / vb;                // narrow entries per word
             for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
                 for (int arr = 0; arr < 2 && rc == PSACX_OK; ++arr) {
                     std::vector<std::vector<Msg>> sends(L), recvs(L);
@@ -1555,11 +1556,11 @@ struct MultiRun {
                     rc = transfer(in, out, {arr == 0 ? sizeof(T) : vb}, sends, recvs, &done[2 * q + arr]);
                 }
             }
-            if (rc != PSACX_OK) { drop_events(); return rc; }
-            // the ranges, one after the other, as they arrive
+            // the ranges, one after the other, as they arrive (a rank whose sort fails still waits for its messages and tells its peers:
+            // every path below runs the waits, drops the events and agrees on the outcome)
             std::vector<std::vector<int32_t>> where(L, std::vector<int32_t>(QR, 0));
-            for (int q = 0; q < QR; ++q) {
-                PSACX_TRY(par([&](int i) -> int {
+            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
+                rc = (par([&](int i) -> int {
                     psacx_ctx* c = ctx(i);
                     MG_HIP(g, hipSetDevice(c->device));
                     for (int s2 = 0; s2 < L; ++s2) { MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q][s2], 0)); MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q + 1][s2], 0)); }
@@ -1573,10 +1574,11 @@ struct MultiRun {
             // everything has arrived (and, with ranks in one process, has been pulled) before the partitioned copies go away
             for (int i = 0; i < L; ++i) {
                 (void)hipSetDevice(ctx(i)->device);
-                for (int q = 0; q < 2 * QR; ++q) for (int s2 = 0; s2 < L; ++s2) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
+                for (int q = 0; q < 2 * QR; ++q) for (int s2 = 0; s2 < L; ++s2) if (done[q][s2]) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
             }
             for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
             drop_events();
+            PSACX_TRY(agree(rc));
             // the sorted ranges into one record set (a sort's result lies in the set its last executed pass wrote)
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);

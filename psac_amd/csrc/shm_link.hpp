@@ -55,8 +55,12 @@ struct ShmLink {
         return buf;
     }
 
+    // id128 must be unique per communicator (an RCCL unique id is).  A segment of the same name that a crashed run left behind, or that
+    // rank 0 has not yet replaced, is recognised and dropped: a rank that is not rank 0 only stays on a segment whose name still leads to
+    // the inode it mapped, waits there until all P ranks have attached, and refuses one that P ranks hold already.
     bool open(int rank_, int nranks, const void* id128, std::string& err) {
         rank = rank_; P = nranks; name = name_of(id128);
+        opened = false;
         const char* e = getenv("PSACX_SHM_BOX");
         slot_bytes = (size_t)1 << 20;
         box_bytes = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32 << 20;
@@ -64,39 +68,74 @@ struct ShmLink {
         if (box_bytes < 4096) box_bytes = 4096;
         bytes = 4096 + (size_t)P * (slot_bytes + box_bytes);
         const auto t0 = std::chrono::steady_clock::now();
-        int fd = -1;
+        auto late = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
         if (rank == 0) {
             (void)shm_unlink(name.c_str());
-            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { err = "shm_open / ftruncate of " + name + " failed"; if (fd >= 0) close(fd); return false; }
+            base = static_cast<char*>(mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+            close(fd);
+            if (base == MAP_FAILED) { base = nullptr; err = "mmap of " + name + " failed"; return false; }
+            Header* h = hdr();
+            h->arrived.store(0); h->sense.store(0); h->attached.store(1);
+            h->nranks = (uint32_t)P; h->slot_bytes = slot_bytes; h->box_bytes = box_bytes;
+            h->magic.store(MAGIC, std::memory_order_release);
+            while (h->attached.load(std::memory_order_acquire) < (uint32_t)P) {
+                if (late()) { err = "timed out waiting for the peers of " + name; munmap(base, bytes); base = nullptr; (void)shm_unlink(name.c_str()); return false; }
+                usleep(200);
+            }
         } else {
             for (;;) {
-                fd = shm_open(name.c_str(), O_RDWR, 0600);
+                int fd = -1;
                 struct stat st;
-                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
-                if (fd >= 0) { close(fd); fd = -1; }
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { err = "timed out waiting for " + name; return false; }
+                for (;;) {
+                    fd = shm_open(name.c_str(), O_RDWR, 0600);
+                    if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+                    if (fd >= 0) { close(fd); fd = -1; }
+                    if (late()) { err = "timed out waiting for " + name; return false; }
+                    usleep(1000);
+                }
+                const ino_t ino = st.st_ino;
+                base = static_cast<char*>(mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+                close(fd);
+                if (base == MAP_FAILED) { base = nullptr; err = "mmap of " + name + " failed"; return false; }
+                Header* h = hdr();
+                // the name must still lead to this inode while we wait on it (rank 0 unlinks whatever was there and makes its own)
+                auto stale = [&]() {
+                    const int f2 = shm_open(name.c_str(), O_RDWR, 0600);
+                    struct stat s2;
+                    const bool gone = f2 < 0 || fstat(f2, &s2) != 0 || s2.st_ino != ino;
+                    if (f2 >= 0) close(f2);
+                    return gone;
+                };
+                // (a segment that looks wrong -- another shape, P ranks on it already -- may be one a crashed run left behind and rank 0 is
+                //  about to replace: it is only an error if the name still leads to it when the time is up)
+                bool retry = false, joined = false;
+                const char* wrong = nullptr;
+                for (unsigned spin = 0;; ++spin) {
+                    if (!joined && !wrong && h->magic.load(std::memory_order_acquire) == MAGIC) {
+                        if (h->nranks != (uint32_t)P || h->box_bytes != box_bytes) wrong = " was made for another communicator shape";
+                        else if (h->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)P) wrong = " is held by all its ranks already: the communicator id must be unique";
+                        else joined = true;
+                    }
+                    if (joined && h->attached.load(std::memory_order_acquire) >= (uint32_t)P) break;
+                    if ((wrong || (spin & 63u) == 63u) && stale()) { retry = true; break; }
+                    if (late()) {
+                        err = wrong ? "shared segment " + name + wrong : "timed out waiting for the peers of " + name;
+                        munmap(base, bytes); base = nullptr; return false;
+                    }
+                    usleep(wrong ? 2000 : 200);
+                }
+                if (!retry) break;
+                munmap(base, bytes); base = nullptr;           // a segment somebody left behind: look again
                 usleep(1000);
             }
         }
-        base = static_cast<char*>(mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
-        close(fd);
-        if (base == MAP_FAILED) { base = nullptr; err = "mmap of " + name + " failed"; return false; }
-        Header* h = hdr();
-        if (rank == 0) {
-            h->arrived.store(0); h->sense.store(0); h->attached.store(0);
-            h->nranks = (uint32_t)P; h->slot_bytes = slot_bytes; h->box_bytes = box_bytes;
-            h->magic.store(MAGIC, std::memory_order_release);
-        } else {
-            while (h->magic.load(std::memory_order_acquire) != MAGIC) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { err = "timed out waiting for the header of " + name; return false; }
-                usleep(200);
-            }
-            if (h->nranks != (uint32_t)P || h->box_bytes != box_bytes) { err = "shared segment " + name + " was made for another communicator shape"; return false; }
-        }
-        h->attached.fetch_add(1);
-        return barrier(err);
+        if (!barrier(err)) { munmap(base, bytes); base = nullptr; if (rank == 0) (void)shm_unlink(name.c_str()); return false; }
+        opened = true;
+        return true;
     }
+    bool opened = false;           // open() went through: the closing barrier has peers
 
     // false on timeout (a peer died): the caller turns it into an error instead of hanging
     bool barrier(std::string& err) {
@@ -122,10 +161,11 @@ struct ShmLink {
     void close_link() {
         if (!base) return;
         std::string err;
-        (void)barrier(err);                               // nobody unmaps while a peer still reads
+        if (opened) (void)barrier(err);                   // nobody unmaps while a peer still reads (a link whose open() failed has no peers to wait for)
         munmap(base, bytes);
         base = nullptr;
-        if (rank == 0) (void)shm_unlink(name.c_str());
+        if (rank == 0 && opened) (void)shm_unlink(name.c_str());
+        opened = false;
     }
 };
 

@@ -28,6 +28,20 @@ int main(int argc, char** argv) {
         CHECK(sa.local_SA == exp);
         sa.construct(s.begin(), s.end(), false, 2);
         CHECK(sa.local_SA == exp);
+        // the alphabet and k given by the caller (suffix_array.hpp:365-366); an alphabet that covers more characters than occur
+        suffix_array<char, uint32_t, true> sb((psacx::comm(0)));
+        sb.verbose = false;
+        sb.construct(s.begin(), s.end());
+        const std::vector<uint32_t> lcp = sb.local_LCP, isa = sb.local_B;
+        const psacx::alphabet<char> wide = psacx::alphabet<char>::from_string(std::string("abcimpswxyz"));
+        sb.construct(s.begin(), s.end(), true, wide, 2);
+        CHECK(sb.local_SA == exp && sb.local_LCP == lcp && sb.local_B == isa);
+        CHECK(sb.alpha == wide && sb.alpha.sigma() == 11);
+        sb.construct(s.begin(), s.end(), true, psacx::alphabet<char>::from_string(s), 3);
+        CHECK(sb.local_SA == exp && sb.local_LCP == lcp && sb.alpha.sigma() == 4);
+        bool threw = false;
+        try { sb.construct(s.begin(), s.end(), true, psacx::alphabet<char>::from_string(std::string("ims")), 2); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw);
     }
     {
         // int alphabet: i = 3, m = 128, p = 66000, s = 12345678

@@ -50,6 +50,24 @@ int main(int argc, char** argv) {
     unsigned char id[128];
     for (int i = 0; i < 128; ++i) id[i] = (unsigned char)(i * 37 + getpid());
     setenv("PSACX_SHM_BOX", "65536", 1);
+    {
+        // what a crashed run with the same id leaves behind: a complete-looking segment that all its P ranks had attached to.  The ranks
+        // below must not settle on it (rank 0 replaces it; a rank that mapped the old one sees the name lead elsewhere and looks again)
+        const std::string nm = ShmLink::name_of(id);
+        const size_t bytes = 4096 + (size_t)P * (((size_t)1 << 20) + 65536);
+        const int fd = shm_open(nm.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)bytes) == 0) {
+            void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                ShmLink::Header* h = static_cast<ShmLink::Header*>(m);
+                h->arrived.store(1); h->sense.store(1); h->attached.store((uint32_t)P);
+                h->nranks = (uint32_t)P; h->slot_bytes = (size_t)1 << 20; h->box_bytes = 65536;
+                h->magic.store(ShmLink::MAGIC);
+                munmap(m, bytes);
+            }
+        }
+        if (fd >= 0) close(fd);
+    }
     std::vector<pid_t> kids;
     for (int r = 1; r < P; ++r) {
         pid_t p = fork();
