@@ -527,6 +527,9 @@ __global__ __launch_bounds__(AnsvWaves<T>::N * WAVE, (sizeof(T) == 4 && !LF && !
     }
 }
 
+template <typename T>
+void launch_ansv_seq(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r);
+
 // grid: a few workgroups per CU, each with a contiguous share of the tiles
 template <typename T>
 inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
@@ -541,6 +544,7 @@ inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int
         const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)c->n_cu * occ);                                     \
         hipLaunchKernelGGL((ansv_tile_kernel<T, LF, RF>), dim3(grid), dim3(AnsvWaves<T>::N * WAVE), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles, dbg); \
     } while (0)
+    if (lt != 2 && rt != 2) { launch_ansv_seq<T>(c, P, n, lt, rt, nonsv, d_l, d_r); return; }      // (ansv_seq.hpp: stack walk inside the blocks)
     if (lt == 2 && rt == 2) PSACX_ANSV(true, true);
     else if (lt == 2) PSACX_ANSV(true, false);
     else if (rt == 2) PSACX_ANSV(false, true);
