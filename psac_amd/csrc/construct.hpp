@@ -717,9 +717,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // whole: the round takes all n suffixes in TEXT order (shift_keys_kernel) and ISA is rebuilt by inverting the new SA
     // (the destination-partition levels of the first round) instead of one random store per record
     auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false) -> int {
-        // 64-bit words, fewer than 2^32 characters: bucket id and rank h further share one word, the suffix is a 32-bit entry --
-        // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass
-        const bool both = sizeof(T) == 8 && n < (1ull << 32) && cnt >= SMALL_SORT_MAX;
+        // 64-bit words, at most 2^32 characters: bucket number and rank h further share one word, the suffix is a 32-bit entry --
+        // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass.  With a list
+        // of unresolved positions the bucket numbers are dense (gather_keys_kernel: list index of the head, halved): 31 bits beside a
+        // 33-bit rank at n = 2^32, and fewer digits to sort on whenever few suffixes are left.
+        const bool dense = plist != nullptr && !whole;
+        const unsigned kb2 = dense ? id_bits : 32u;
+        const bool both = sizeof(T) == 8 && cnt >= SMALL_SORT_MAX && (n < (1ull << 32) || (n == (1ull << 32) && dense));
+        const unsigned num_bits = dense ? bits_for(cnt > 2 ? (cnt - 1) >> 1 : 1) : id_bits;
         T* const key2 = both ? (T*)nullptr : w.x.k2;
         {
             ProfScope ps(c, TC_GATHER);
@@ -728,7 +733,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 hipLaunchKernelGGL((shift_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
             else
                 hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
-                                   plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
+                                   plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen, kb2);
             PSACX_HIP(c, hipGetLastError());
             // (only the three-kernel form of the sort reads the key summary)
             if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
@@ -736,7 +741,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         psacx_round rs; std::memset(&rs, 0, sizeof(rs));
         if (both) {
             SortBufs<T> in2{w.x.k1, nullptr, w.x.v}, alt2{w.ry.k1, nullptr, w.ry.v};
-            PSACX_TRY(pair_sort<T>(c, w.sc, in2, alt2, cnt, /*iota=*/false, 32 + id_bits, 0, nullptr, &sorted, &rs, 0, 0,
+            PSACX_TRY(pair_sort<T>(c, w.sc, in2, alt2, cnt, /*iota=*/false, kb2 + num_bits, 0, nullptr, &sorted, &rs, 0, 0,
                                    /*summary_ready=*/true, 0, -1, /*v32_in=*/true));
             sorted.k2 = nullptr;
         } else
@@ -748,11 +753,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, KeyShape())));
+            KeyShape split; split.lc = kb2; split.c1 = split.c2 = 0; split.spec = 0;       // (last_head_kernel: where a one-word key divides)
+            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, split)));
             hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
                                d_sa, w.bsa, whole ? (T*)nullptr : d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
-                               (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr);
+                               (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr, kb2);
             PSACX_HIP(c, hipGetLastError());
         }
         PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active));

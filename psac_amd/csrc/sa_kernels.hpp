@@ -540,9 +540,10 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
         if (e < wend) {
             if (e == 0 && !bd.has_prev) head = true;
             else {
-                // (A2 == nullptr: 64-bit words holding both 32-bit keys of a refinement record, K1 << 32 | K2)
-                const T x1 = A1[e], x2 = A2 ? A2[e] : (T)((uint64_t)x1 & 0xFFFFFFFFull);
-                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = A2 ? (e ? A2[e - 1] : bd.prev2) : (T)((uint64_t)y1 & 0xFFFFFFFFull);
+                // (A2 == nullptr: 64-bit words holding both keys of a refinement record, K1 << kb2 | K2, kb2 = ks.lc bits for K2)
+                const uint64_t m2 = (~0ull) >> (64 - (REFINE ? ks.lc : 32u));
+                const T x1 = A1[e], x2 = A2 ? A2[e] : (T)((uint64_t)x1 & m2);
+                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = A2 ? (e ? A2[e - 1] : bd.prev2) : (T)((uint64_t)y1 & m2);
                 head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
                 if (!REFINE && !head) {
                     // equal packed windows: still a boundary if either suffix is shorter than 2k
@@ -1371,7 +1372,11 @@ template <typename T>
 __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ SA,
                                    const T* __restrict__ Bsa, const T* __restrict__ ISA, uint64_t n,
                                    uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V,
-                                   unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr) {
+                                   unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr, unsigned kb2 = 32) {
+    // kb2 (K2 == nullptr): bits of the rank h further in the one-word key; above them the bucket's number.  With a list of positions
+    // the number is DENSE: the list index of the bucket's head halved -- the members of a bucket are consecutive in SA and all of them
+    // are in the list, so the head's index is j - (p - head position); buckets have at least two members, so halving keeps the numbers
+    // apart and in order.  31 bits for 2^32 list entries: together with a 33-bit rank that is one 64-bit word at n = 2^32 too.
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
@@ -1384,8 +1389,9 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
         const T b2 = inside ? (T)(ISA[q] + 1) : (T)0;
         if (K2) { K1[j] = b1; K2[j] = b2; V[j] = sa; o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2; }
         else {
-            // both keys in one 64-bit word, the suffix as a 32-bit entry (texts below 2^32 characters): two-word records
-            const T kk = (T)(((uint64_t)b1 << 32) | (uint64_t)b2);
+            // both keys in one 64-bit word, the suffix as a 32-bit entry (texts of at most 2^32 characters): two-word records
+            const uint64_t num = pos ? ((j - (p - ((uint64_t)b1 - 1))) >> 1) : (uint64_t)b1;
+            const T kk = (T)((num << kb2) | (uint64_t)b2);
             K1[j] = kk; reinterpret_cast<uint32_t*>(V)[j] = (uint32_t)sa; o1 |= kk; a1 &= kk;
         }
     }
@@ -1550,15 +1556,17 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
     const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf,
     Boundary<T> bd, T* __restrict__ q_at, T* __restrict__ q_lo, T* __restrict__ q_hi,
-    unsigned long long* __restrict__ q_count) {
+    unsigned long long* __restrict__ q_count, unsigned kb2 = 32) {
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
     const unsigned tile = blockIdx.x;
     const uint64_t e0 = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * ITEMS;
 
-    // K2 == nullptr: both keys of a record in one 64-bit word (K1 << 32 | K2; texts below 2^32 characters, one GPU)
+    // K2 == nullptr: both keys of a record in one 64-bit word (K1 << kb2 | K2; texts of at most 2^32 characters, one GPU); only
+    // equality of K1 matters here (a bucket's number), K2 is the rank of the suffix h further
     const bool both = K2 == nullptr;
+    const uint64_t m2 = (~0ull) >> (64 - kb2);
     __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
@@ -1566,7 +1574,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if (!both) load_run_x<T, ITEMS>(K2, e0, cnt, a2, (T)0, xw);
     else {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { a2[j] = (T)((uint64_t)a1[j] & 0xFFFFFFFFull); a1[j] = (T)((uint64_t)a1[j] >> 32); }
+        for (int j = 0; j < ITEMS; ++j) { a2[j] = (T)((uint64_t)a1[j] & m2); a1[j] = (T)((uint64_t)a1[j] >> kb2); }
     }
     if (pos) load_run_x<T, ITEMS>(pos, e0, cnt, ps, (T)0, xw);
     else {
@@ -1576,14 +1584,14 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) {
         p1 = K1[e0 - 1];
-        if (both) { p2 = (T)((uint64_t)p1 & 0xFFFFFFFFull); p1 = (T)((uint64_t)p1 >> 32); } else p2 = K2[e0 - 1];
+        if (both) { p2 = (T)((uint64_t)p1 & m2); p1 = (T)((uint64_t)p1 >> kb2); } else p2 = K2[e0 - 1];
     }
     else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; }
     bool next_head = true;
     if (e0 + ITEMS <= cnt && (e0 + ITEMS < cnt || bd.has_next)) {
         const bool in = e0 + ITEMS < cnt;
         T q1 = in ? K1[e0 + ITEMS] : bd.next1, q2 = in ? (both ? (T)0 : K2[e0 + ITEMS]) : bd.next2;
-        if (in && both) { q2 = (T)((uint64_t)q1 & 0xFFFFFFFFull); q1 = (T)((uint64_t)q1 >> 32); }
+        if (in && both) { q2 = (T)((uint64_t)q1 & m2); q1 = (T)((uint64_t)q1 >> kb2); }
         next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
     }
 

@@ -535,6 +535,45 @@ def test_multi_reduced_memory_twin_of_config_c5_and_its_footprint():
         mg.close()
 
 
+def test_multi_first_round_memory_in_the_reduced_layout():
+    # psacx_multi_get_memory after a construction of random DNA in the reduced-memory layout (8 ranks x 2^25 characters, uint64, the
+    # ranks sharing device 0): the one-word first round keeps the partitioned block, the receive array and the suffixes in the rank's three
+    # result arrays and re-balances in place, so the engine's own allocations peak below 3 words per character (round 3: 4.75 with more
+    # than one rank; psac plans 6 for its sort, idxsort.hpp:41-45).  With the result arrays (3 x 1.125) and the text that is the 6.5 words
+    # a block of 2^32 characters is allowed on a 288 GiB part.  Verified by the distributed checker.
+    import ctypes as C
+    P, m, bits = 8, 1 << 25, 64
+    mg = multi(P)
+    try:
+        lib = mg._lib
+        sizes = [m] * P
+        slack = m // 8 + 256
+        ctxs = [mg.rank_ctx(i) for i in range(P)]
+        def alloc(ctx, nbytes):
+            p = C.c_void_p()
+            assert lib.psacx_dev_alloc(ctx, C.byref(p), nbytes) == 0
+            return p.value
+        d_text = [alloc(c, m) for c in ctxs]
+        for i, c in enumerate(ctxs):
+            assert lib.psacx_synth_text_dev(c, C.c_void_p(d_text[i]), m, i * m, 0, 1, 1024) == 0
+        outs = [[alloc(c, (m + slack) * 8) for c in ctxs] for _ in range(3)]
+        mg.configure(layout=mg.LAYOUT_REDUCED, output_slack=slack)
+        mg.construct_device(d_text, sizes, outs[0], outs[1], outs[2], bits)
+        peak, reduced, _ = mg.memory()
+        form = mg.last_form()
+        assert reduced and form["one_word"] and form["slice_inversion"]
+        words = max(peak) / (m * 8.0)
+        print("engine allocations at their peak: %.2f words per character" % words)
+        assert words <= 3.0, words
+        assert words + 3.0 * (m + slack) / m + 2.0 / 8 <= 6.5
+        assert mg.check_device(d_text, sizes, outs[0], outs[1], outs[2], bits) == [0, 0, 0, 0]
+        for c, ps in zip(ctxs, zip(d_text, *outs)):
+            for p_ in ps:
+                lib.psacx_dev_free(c, C.c_void_p(p_))
+    finally:
+        mg.close()
+
+
 def test_multi_rccl_wire_forced_at_world_size_one(monkeypatch):
     # PSACX_MULTI_FORCE_WIRE=1: the shortcuts for data a rank addresses to itself and for scalars already on this host are
     # off, so ncclAllGather and ncclSend / ncclRecv (to self) are really issued at world size 1 -- the calls the driver's
