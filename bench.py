@@ -50,8 +50,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # ... with the fused front end (the pass on the top digit no longer counted here), profiles/r04y_pmc_*.txt: bucket passes
 #     (2 x 17324186.8 + 34509922.4) KiB x 3, widening pass (2 x 17330780.3 + 78369040.8) KiB; mean over the four = 82049404928 bytes
 #     (1.061 x the algorithmic 18 bytes per record and pass)
+# ... round 4, profiles/r4b_bench_{fetch,write}_4gib_u64.txt: bucket passes (2 x 17324028 + 34444799) KiB x 3, widening pass
+#     (2 x 17328092 + 76522428) KiB; mean over the four = 81525037312 bytes (1.054 x the algorithmic 18 bytes per record and pass)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 82049404928}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 81525037312}
 
 
 def parse():

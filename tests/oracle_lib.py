@@ -61,6 +61,31 @@ def construct_all_cores(text, bits=32):
     return SA, LCP
 
 
+def construct_all_cores_cached(tag, text, bits=32):
+    """construct_all_cores for a text several test modules check against (the 2^27-character tandem twin of configs[4]): the first
+    caller of a session leaves SA and LCP under the system's temporary directory, keyed by the tag and a checksum of the text."""
+    import tempfile
+    import zlib
+    t = as_text(text)
+    key = "%s_%d_%08x_u%d" % (tag, t.size, zlib.crc32(t[:: max(1, t.size // (1 << 20))].tobytes()), bits)
+    d = os.path.join(tempfile.gettempdir(), "psacx_oracle_cache")
+    fa, fl = os.path.join(d, key + ".sa.npy"), os.path.join(d, key + ".lcp.npy")
+    if os.path.exists(fa) and os.path.exists(fl):
+        try:
+            SA, LCP = np.load(fa), np.load(fl)
+            if SA.size == t.size and LCP.size == t.size:
+                return SA, LCP
+        except Exception:
+            pass
+    SA, LCP = construct_all_cores(t, bits=bits)
+    try:
+        os.makedirs(d, exist_ok=True)
+        np.save(fa, SA); np.save(fl, LCP)
+    except Exception:
+        pass
+    return SA, LCP
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

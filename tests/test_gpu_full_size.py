@@ -128,7 +128,7 @@ def _tandem_twin(ctx, monkeypatch, cap):
 
 def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     text, sa = _tandem_twin(ctx, monkeypatch, 0)
-    SA, LCP = O.construct_all_cores(text, bits=64)
+    SA, LCP = O.construct_all_cores_cached("tandem_1024_3", text, bits=64)
     assert np.array_equal(sa.local_SA, SA) and np.array_equal(sa.local_LCP, LCP)
     if O.have_divsufsort():
         assert np.array_equal(SA, O.divsufsort(text, 64))

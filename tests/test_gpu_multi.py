@@ -112,7 +112,7 @@ def test_multi_twins_of_the_eight_gpu_configs():
         del rSA, rLCP
         text = inputs.tandem(1 << 27, 1024, inputs.dna(1024, 3))
         SA, ISA, LCP, rounds = same(mg, text, 64)
-        rSA, rLCP = O.construct_all_cores(text, bits=64)
+        rSA, rLCP = O.construct_all_cores_cached("tandem_1024_3", text, bits=64)
         assert np.array_equal(SA, rSA) and np.array_equal(LCP, rLCP)
         assert np.array_equal(ISA[SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
         assert [r[0] for r in rounds] == [21 << i for i in range(len(rounds))] and len(rounds) >= 20
@@ -536,13 +536,13 @@ def test_multi_reduced_memory_twin_of_config_c5_and_its_footprint():
 
 
 def test_multi_first_round_memory_in_the_reduced_layout():
-    # psacx_multi_get_memory after a construction of random DNA in the reduced-memory layout (8 ranks x 2^25 characters, uint64, the
+    # psacx_multi_get_memory after a construction of random DNA in the reduced-memory layout (8 ranks x 2^26 characters, uint64, the
     # ranks sharing device 0): the one-word first round keeps the partitioned block, the receive array and the suffixes in the rank's three
     # result arrays and re-balances in place, so the engine's own allocations peak below 3 words per character (round 3: 4.75 with more
     # than one rank; psac plans 6 for its sort, idxsort.hpp:41-45).  With the result arrays (3 x 1.125) and the text that is the 6.5 words
     # a block of 2^32 characters is allowed on a 288 GiB part.  Verified by the distributed checker.
     import ctypes as C
-    P, m, bits = 8, 1 << 25, 64
+    P, m, bits = 8, 1 << 26, 64
     mg = multi(P)
     try:
         lib = mg._lib
