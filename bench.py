@@ -196,9 +196,15 @@ def main_distributed(a, rank, world, local_rank):
         # for the result arrays with their slack + the text = 6.13 words of 8 bytes: 196 GiB at 2^32 characters.  Asked for: 7 words + 8 GiB
         # (RCCL's buffers, the block cache's odd sizes).  A GPU that cannot hold 2^31 is not the machine this benchmark is defined on:
         # the run stops with a reason instead of quoting a smaller workload as if it were the configured one (--n overrides).
+        # 2^32 per GPU only while the whole text has at most 2^34 characters (N <= 4): the one-word records of the first round keep
+        # 64 - bits_for(n - 1) bits of prefix beside the suffix, and beyond 2^34 characters too many suffixes would tie on them
+        # (multi.hpp: sort_first_one_word refuses, and the two-word form it falls back to peaks at 8.25 words per character).  Eight
+        # GPUs take 2^31 each: BASELINE.json configs[3], 16 GiB of DNA over 8 GPUs.
         free_b = torch.cuda.mem_get_info(local_rank)[0]
         fit = 0
         for lg in (32, 31):
+            if world * (1 << lg) > (1 << 34):
+                continue
             if free_b >= int(7.0 * 8 * (1 << lg)) + (8 << 30):
                 fit = lg
                 break
