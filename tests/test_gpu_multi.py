@@ -112,7 +112,7 @@ def test_multi_twins_of_the_eight_gpu_configs():
         del rSA, rLCP
         text = inputs.tandem(1 << 27, 1024, inputs.dna(1024, 3))
         SA, ISA, LCP, rounds = same(mg, text, 64)
-        rSA, rLCP = O.construct_all_cores_cached("tandem_1024_3", text, bits=64)
+        rSA, rLCP = O.reference_sa_lcp_cached("tandem_1024_3", text, bits=64)
         assert np.array_equal(SA, rSA) and np.array_equal(LCP, rLCP)
         assert np.array_equal(ISA[SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
         assert [r[0] for r in rounds] == [21 << i for i in range(len(rounds))] and len(rounds) >= 20
