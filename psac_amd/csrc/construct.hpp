@@ -479,6 +479,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                      lead + RADIX_BITS <= bits_w1 + bits_w2;     // at least one pass less
     psacx_round* r0 = &st.rounds[0];
     SortBufs<T> sorted;
+    bool onew_recs = false;          // the sorted records of the first round are still one-word (sa_kernels.hpp: OneWordView); sorted.k1 holds them
+    OneWordView onew_view = OneWordView();
+    T* onew_w1 = nullptr;            // ... and word 1 of the suffixes that tie on the leading bits is here
     // (second attempt: only when the two-stage form met more ties than the reduced-memory layout has room for)
     for (int attempt = 0; attempt < 2; ++attempt) {
     bool retry_one_stage = false;
@@ -533,11 +536,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         bool packed1 = false;            // the one-word sort ran: word 1 comes back without its bits below the prefix
+        onew_recs = false;
         if constexpr (sizeof(T) == 8) {
             if (one_word) {
                 uint64_t* s1 = nullptr;
+                // the records stay one-word through the tie stage and the rebucket kernel when that kernel runs in its fused form
+                const bool keep = !kn.widen_last && !kn.ties_radix && isa_narrow_levels<T>(n, kn) > 0;
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
-                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always);
+                                               reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
+                                               keep ? &onew_view : nullptr);
                 if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
                     one_word = false;
                     PSACX_TRY(make_keys(hist_in_keys));
@@ -546,6 +553,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                     PSACX_TRY(rc1);
                     sorted.k1 = reinterpret_cast<T*>(s1); sorted.k2 = nullptr; sorted.v = d_sa;
                     packed1 = true;          // (the bits of word 1 below the prefix are gone: ties read word 1 from the text)
+                    onew_recs = keep;
                 }
             }
         } else one_word = false;
@@ -554,9 +562,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
         if (w.diet && sorted.v != d_sa)          // (a skipped pass changed the parity)
             PSACX_HIP(c, hipMemcpyAsync(d_sa, sorted.v, n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-        T* const S1 = sorted.k1;
+        T* S1 = sorted.k1;
         T* const S2 = w.diet ? w.x.k2 : first_alt.k2;        // word 2 in sorted order, filled for the ties only
-        T* const free_k1 = (S1 == w.x.k1) ? w.y.k1 : w.x.k1;
+        T* free_k1 = (S1 == w.x.k1) ? w.y.k1 : w.x.k1;
         // stage 2, common case: all tie groups are tiny and get ordered in place
         // (tile shapes measured: 64-bit words 256 x 32: 10.7 ms at 2^32, 128 x 32: 11.1, 256 x 16: 13.0, 512 x 8: 16.6;
         //  32-bit words 256 x 16: 1.2-1.3 ms at 2^28, 128 x 32: 1.4)
@@ -567,13 +575,30 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_GATHER);
             PSACX_HIP(c, hipMemsetAsync(d_big, 0, sizeof(unsigned long long), c->stream));
             const uint64_t nb = (n + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
-            if (!kn.ties_radix)
+            if constexpr (sizeof(T) == 8) {
+                if (onew_recs)          // S1: the one-word records; the array the last pass did not write takes word 1 of the tied suffixes
+                    hipLaunchKernelGGL((tie_resolve_1w_kernel<TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, reinterpret_cast<uint64_t*>(S1),
+                                       reinterpret_cast<uint64_t*>(free_k1), reinterpret_cast<uint64_t*>(S2), n, onew_view, d_text, n, tab, ks, d_big);
+            }
+            if (!kn.ties_radix && !onew_recs)
                 hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, S1, d_sa, S2, n, lo1,
                                    d_text, n, tab, ks, d_big, packed1);
             PSACX_HIP(c, hipGetLastError());
         }
         PSACX_HIP(c, hipMemcpyAsync(h_big, d_big, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        if constexpr (sizeof(T) == 8) {
+            if (onew_recs && *h_big) {
+                // a long group: the radix path below works on word 1 and the suffixes as arrays -- written now, as the last pass would have
+                ProfScope ps(c, TC_GATHER);
+                hipLaunchKernelGGL(onew_widen_kernel<0>, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, reinterpret_cast<const uint64_t*>(S1), n, onew_view,
+                                   reinterpret_cast<uint64_t*>(free_k1), reinterpret_cast<uint64_t*>(d_sa));
+                PSACX_HIP(c, hipGetLastError());
+                std::swap(S1, free_k1);
+                sorted.k1 = S1;
+                onew_recs = false;
+            }
+        }
         if (*h_big || kn.ties_radix) {
             // some group is long (repetitive text): compact all ties and radix-sort them by the full window
             const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -618,6 +643,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             }
         }
         sorted.k2 = S2; sorted.v = d_sa;
+        onew_w1 = onew_recs ? free_k1 : (T*)nullptr;
         if (retry_one_stage) continue;
     } else {
         PSACX_TRY(pair_sort<T>(c, w.sc, first_in, first_alt, n, /*iota=*/true, bits_w1, bits_w2, w.diet ? (T*)nullptr : d_sa,
@@ -661,6 +687,21 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             launch_rebucket_first_fused<T, WITH_LCP>(c, (unsigned)ntiles, sorted.k1, sorted.k2, d_sa, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact,
                                                      w.d_nunf, pyr1, reinterpret_cast<uint32_t*>(w.x.v), reinterpret_cast<uint32_t*>(w.y.v),
                                                      isa_narrow_shift(isa_levels32(n), 0), w.d_cursors);
+        } else if (fuse_l1 && onew_recs) {
+            // ... on the one-word records of the prefix sort: the kernel takes word 1 and the suffixes out of them and writes the suffix array
+            if constexpr (sizeof(T) == 8) {
+                hipLaunchKernelGGL(last_head_1w_kernel<0>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, c->stream, reinterpret_cast<const uint64_t*>(sorted.k1),
+                                   reinterpret_cast<const uint64_t*>(onew_w1), reinterpret_cast<const uint64_t*>(sorted.k2), n, (unsigned)ScanCfg<T>::TILE, ntiles,
+                                   w.d_carry, ks, onew_view);
+                PSACX_HIP(c, hipGetLastError());
+                hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(), (uint64_t)0, (uint64_t*)nullptr);
+                PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
+                lazy_ids = n >= (1ull << 22);
+                hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB, true, true>), dim3((unsigned)ntiles),
+                                   dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, (const T*)nullptr, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact, w.d_nunf, n,
+                                   Boundary<T>(), pyr1, (unsigned*)nullptr, 0, reinterpret_cast<uint32_t*>(w.x.v), (uint32_t*)nullptr,
+                                   isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors, d_sa, lazy_ids ? 1 : 0, onew_view, (const T*)onew_w1);
+            }
         } else if (fuse_l1) {
             // the first level of the SA -> ISA inversion rides along: its (position, rank) pairs go to the payload scratch
             // array of the sort, which nobody reads any more (word 1 / word 2 / SA are read from other arrays)

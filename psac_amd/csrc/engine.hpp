@@ -146,6 +146,8 @@ struct Knobs {
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
     bool one_word_always;   // PSACX_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
+    bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
+                            // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
 inline Knobs read_knobs() {
     Knobs k;
@@ -158,6 +160,7 @@ inline Knobs read_knobs() {
     k.one_word_always = getenv("PSACX_ONE_WORD_ALWAYS") != nullptr;
     e = getenv("PSACX_ONE_WORD_MIN");
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
+    k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
     return k;
 }
 
@@ -843,8 +846,10 @@ inline OneWordLayout onew_layout(unsigned long long* h_tabs, uint64_t ntiles_hin
 // The LSD passes inside the buckets: one-word records (rest of the prefix << sfield | suffix) of bucket b at [bucket_off[b], bucket_off[b + 1]) of `cur`,
 // `low` prefix bits in the word.  All but the last pass ping-pong between cur and oth; the last one writes word 1 ((b << low | rest) << lo1) into the
 // array it does not read (*s1 tells which) and the suffixes as words into sa_out.  h_tabs must stay untouched until the stream has passed the copy.
+// view_out != nullptr: the last pass leaves one-word records like the others (*s1: where) and *view_out describes them (sa_kernels.hpp: OneWordView;
+// its table lives in the scratch until the next sort) -- the kernels after the sort read them where they lie.
 inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long long* h_tabs, const OneWordLayout& lay, uint64_t* cur, uint64_t* oth, uint64_t* sa_out,
-                              unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1) {
+                              unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1, OneWordView* view_out = nullptr) {
     constexpr int BLOCK = 512, ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + lay.hist_bytes);
@@ -855,9 +860,10 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
     SlabInfo* slab_info = reinterpret_cast<SlabInfo*>((reinterpret_cast<uintptr_t>(d_tabs + 2 * (RADIX + 1)) + 31) & ~(uintptr_t)31);
     tb.slab_info = slab_info;
     *s1 = cur;
+    if (view_out) { view_out->off = d_tabs; view_out->low = low; view_out->sfield = sfield; view_out->lo1 = lo1; }
+    PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (lay.total_slabs == 0) return PSACX_OK;
     const uint64_t total_slabs = lay.total_slabs, vtiles = lay.vtiles;
-    PSACX_HIP(c, hipMemcpyAsync(d_tabs, h_tabs, 2 * (RADIX + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(radix_slab_info_kernel<0>, dim3((unsigned)((total_slabs + 255) / 256)), dim3(256), 0, c->stream, tb.bucket_off, tb.slab_start,
                        (unsigned)total_slabs, (unsigned)(lay.slab * TILE), slab_info);
     PSACX_HIP(c, hipGetLastError());
@@ -874,7 +880,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
         }
         ProfScope ps(c, TC_SORT_SCATTER2);
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        if (!last)
+        if (!last || view_out)
             hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), 0u);
         else {
@@ -883,7 +889,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), lo1 | (low << 8) | (sfield << 16));
         }
         PSACX_HIP(c, hipGetLastError());
-        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += (last ? 24ull : 16ull) * nrec;
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += (last && !view_out ? 24ull : 16ull) * nrec;
         c->stats.onew_passes += 1;
         std::swap(cur, oth);
     }
@@ -893,7 +899,8 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
 // text != nullptr (fused front end, sa_kernels.hpp: key_scatter1w_kernel): k0 holds nothing yet -- the histograms of the top digit come
 // from the text and pass 0 computes word 1 of its tile in registers (no key_pairs_kernel launch, 16 bytes per record less).
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
-                          psacx_round* rs, uint64_t** s1, const uint8_t* text, uint64_t n_text, const CodeTable& tab, const KeyShape& ks, bool probe) {
+                          psacx_round* rs, uint64_t** s1, const uint8_t* text, uint64_t n_text, const CodeTable& tab, const KeyShape& ks, bool probe,
+                          OneWordView* view_out = nullptr) {
     constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // the pass on the top digit
     // (bucket passes with other tiles, measured at 2^32 records: 512 x 6 -- 62 VGPRs, four workgroups per CU -- 106 ms for the five
     //  passes against 89 ms; 512 x 12 -- two workgroups per CU -- 89 ms: the run length gained is the occupancy lost)
@@ -949,7 +956,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     }
     // the buckets (the tables of the first pass in the scratch are dead once its scatter has run: same stream)
     uint64_t* cur = nullptr;
-    PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur));
+    PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur, view_out));
     *s1 = cur;          // (k0 after an odd number of bucket passes, `a` after an even number)
     if (rs) { rs->sort_passes = (uint32_t)((low + RADIX_BITS - 1) / RADIX_BITS + 1); rs->sort_passes_skipped = 0; }
     return PSACX_OK;

@@ -574,6 +574,85 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
     }
 }
 
+// ------------------------------------------------------------------ one-word records read where they lie
+// The prefix sort of the first round (engine.hpp: prefix_sort_1w) leaves the records of bucket b -- the top digit of the sorted prefix --
+// at [off[b], off[b + 1]) as ONE word each: (rest of the prefix) << sfield | suffix.  The kernels that follow the sort (tie_resolve_1w_kernel,
+// last_head_1w_kernel, rebucket_first_kernel<.., ONEW>) read them in that form -- the top digit is known from a record's place -- instead of
+// having the last pass write word 1 and the suffix as two arrays (8 bytes per record less written by the pass and 8 less read by the tie
+// stage; the suffix array itself is written by the rebucket kernel, which holds the suffixes anyway).
+struct OneWordView {
+    const unsigned long long* off;      // off[0 .. 256], off[256] = number of records
+    unsigned low, sfield, lo1;          // prefix bits in the word, width of the suffix field, bits of word 1 below the sorted prefix
+};
+// the bucket of record e: the largest b with off[b] <= e (empty buckets are skipped)
+__device__ __forceinline__ unsigned onew_bucket(const OneWordView& ow, uint64_t e) {
+    unsigned b = 0;
+#pragma unroll
+    for (int s = 128; s; s >>= 1) if (ow.off[b + s] <= e) b += s;
+    return b;
+}
+// the leading bits of word 1 (top digit | rest of the prefix), and word 1 with zeros below them
+__device__ __forceinline__ uint64_t onew_lead(const OneWordView& ow, unsigned b, uint64_t rec) { return ((uint64_t)b << ow.low) | (rec >> ow.sfield); }
+__device__ __forceinline__ uint64_t onew_word1(const OneWordView& ow, unsigned b, uint64_t rec) { return onew_lead(ow, b, rec) << ow.lo1; }
+__device__ __forceinline__ uint64_t onew_suffix(const OneWordView& ow, uint64_t rec) { return rec & ((1ull << ow.sfield) - 1); }
+// a thread that walks records in ascending order keeps its bucket and the end of that bucket in registers
+struct OneWordCursor {
+    unsigned b; uint64_t end;
+    __device__ __forceinline__ void start(const OneWordView& ow, uint64_t e) { b = onew_bucket(ow, e); end = ow.off[b + 1]; }
+    __device__ __forceinline__ unsigned at(const OneWordView& ow, uint64_t e) {
+        while (b < 255u && e >= end) { ++b; end = ow.off[b + 1]; }
+        return b;
+    }
+};
+
+// last_head_kernel (first round) on one-word records: W1 / S2 hold both words of the suffixes that tie on the leading bits
+// (tie_resolve_1w_kernel filled them), nothing elsewhere.  One wave per tile, four tiles per workgroup.
+template <int TAG>
+__global__ __launch_bounds__(256) void last_head_1w_kernel(const uint64_t* __restrict__ R, const uint64_t* __restrict__ W1, const uint64_t* __restrict__ S2,
+                                                           uint64_t cnt, unsigned tile_size, uint64_t ntiles, uint64_t* __restrict__ agg, KeyShape ks,
+                                                           OneWordView ow) {
+    constexpr unsigned NW = 256 / WAVE;
+    const unsigned lane = lane_id(), wv = threadIdx.x / WAVE;
+    const uint64_t tile = (uint64_t)blockIdx.x * NW + wv;
+    if (tile >= ntiles) return;
+    const uint64_t lo = tile * tile_size;
+    uint64_t hi = lo + tile_size;
+    if (hi > cnt) hi = cnt;
+    const uint64_t two_k = ks.c1 + ks.c2;
+    uint64_t found = 0;
+    for (uint64_t wend = hi; wend > lo; ) {
+        const uint64_t w0 = wend >= lo + WAVE ? wend - WAVE : lo;
+        const uint64_t e = w0 + lane;
+        bool head = false;
+        if (e < wend) {
+            if (e == 0) head = true;
+            else {
+                const uint64_t x = R[e], y = R[e - 1];
+                const unsigned bx = onew_bucket(ow, e), by = onew_bucket(ow, e - 1);
+                head = onew_lead(ow, bx, x) != onew_lead(ow, by, y);
+                if (!head) head = W1[e] != W1[e - 1] || S2[e] != S2[e - 1];
+                if (!head) head = (cnt - onew_suffix(ow, x) < two_k) || (cnt - onew_suffix(ow, y) < two_k);
+            }
+        }
+        const uint64_t m = __ballot(head);
+        if (m) { found = w0 + (63u - (unsigned)__builtin_clzll(m)) + 1; break; }
+        wend = w0;
+    }
+    if (lane == 0) agg[tile] = found;
+}
+
+// one-word records -> word 1 (zeros below the sorted prefix) and the suffixes as words: what the last pass of the prefix sort writes when the
+// records are not read where they lie (the tie stage met a long group and takes its radix path)
+template <int TAG>
+__global__ void onew_widen_kernel(const uint64_t* __restrict__ R, uint64_t n, OneWordView ow, uint64_t* __restrict__ S1, uint64_t* __restrict__ SA) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint64_t x = R[e];
+        S1[e] = onew_word1(ow, onew_bucket(ow, e), x);
+        SA[e] = onew_suffix(ow, x);
+    }
+}
+
 // Exclusive scan of `len` uint64 values by one workgroup (len is the number of tiles, at
 // most a few tens of thousands).  total[0] receives the reduction of everything.
 template <int BLOCK, typename Op>
@@ -640,14 +719,17 @@ __global__ __launch_bounds__(BLOCK) void tile_scan2_kernel(uint64_t* __restrict_
 // replaces: its 16 bytes per record of reads are saved).  part_key / part_val: the pair arrays, part_cursors: zeroed.
 // PPK (with PCB): the pairs leave as ONE array of 64-bit entries (position | rank << 32, part_key viewed as uint64_t*,
 // part_val unused): a class's run of a tile is one 64-byte piece instead of two of 32 bytes, and is staged through LDS once.
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0, bool PPK = false>
+// ONEW (one GPU, 64-bit words): S1 holds the one-word records of the prefix sort (OneWordView), S1t word 1 of the suffixes that tie on the
+// leading bits (S2 their word 2), SA is not read: the suffixes come out of the records and leave through sa_out.
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0, bool PPK = false, bool ONEW = false>
 __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
     T* __restrict__ pyr1 = nullptr, unsigned* __restrict__ sa_hist = nullptr, int sa_hist_shift = 0,
     uint32_t* __restrict__ part_key = nullptr, uint32_t* __restrict__ part_val = nullptr, unsigned part_shift = 0,
-    unsigned* __restrict__ part_cursors = nullptr, T* __restrict__ sa_out = nullptr, int lazy_ids = 0) {
+    unsigned* __restrict__ part_cursors = nullptr, T* __restrict__ sa_out = nullptr, int lazy_ids = 0,
+    OneWordView ow = OneWordView(), const T* __restrict__ S1t = nullptr) {
     // lazy_ids: a tile without a single unresolved suffix does not write its bucket ids (they are e + 1 and nobody reads them
     // unless some OTHER tile has unresolved suffixes: the caller then fills them in, fill_resolved_ids_kernel)
     // sa_out (optional): the suffixes are written there as well (the multi-GPU engine's records end in scratch arrays; the
@@ -678,33 +760,68 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
     T* const xp = reinterpret_cast<T*>(xp_raw);
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], sa[ITEMS];
+    // (ONEW: the table of the bucket starts is asked for before the records, so that its way from memory is not waited for on its own)
+    static_assert(!ONEW || BLOCK >= 257, "one thread per table entry");
+    const unsigned long long my_off = (ONEW && threadIdx.x < 257) ? ow.off[threadIdx.x] : 0ull;
     load_run_x<T, ITEMS>(S1, e0, n, a1, (T)0, xw);
     if (!LAZY2) load_run_x<T, ITEMS>(S2, e0, n, a2, (T)0, xw);
-    load_run_x<T, ITEMS>(SA, e0, n, sa, (T)0, xw);
+    if constexpr (!ONEW) load_run_x<T, ITEMS>(SA, e0, n, sa, (T)0, xw);
     T p1 = 0, p2 = 0, psa = 0;
     bool have_p = false;
-    if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; psa = SA[e0 - 1]; have_p = true; if (!LAZY2) p2 = S2[e0 - 1]; }
-    else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; psa = bd.prev3; }
     const bool have_q = e0 + ITEMS <= n && (e0 + ITEMS < n || bd.has_next);
     const bool q_in = e0 + ITEMS < n;
-    const T q1v = have_q ? (q_in ? S1[e0 + ITEMS] : bd.next1) : (T)0;
+    T q1v = 0, qsav = 0;
+    __shared__ unsigned long long s_off[ONEW ? 257 : 1];
+    if constexpr (ONEW) {
+        // word 1 (zeros below the sorted prefix) and the suffix out of every record; the top digit from the record's place
+        // (the table of the bucket starts in LDS: a thread's search is eight dependent reads)
+        static_assert(!ONEW || (sizeof(T) == 8 && LAZY2), "one-word records: 64-bit words, no string sets");
+        if (threadIdx.x < 257) s_off[threadIdx.x] = my_off;
+        __syncthreads();
+        ow.off = s_off;
+        OneWordCursor cu;
+        cu.start(ow, e0 ? (e0 - 1 < n ? e0 - 1 : (n ? n - 1 : 0)) : 0);
+        if (e0 > 0 && e0 - 1 < n) { const uint64_t x = S1[e0 - 1]; p1 = (T)onew_word1(ow, cu.b, x); psa = (T)onew_suffix(ow, x); have_p = true; }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t x = a1[j];
+            sa[j] = (T)onew_suffix(ow, x);
+            a1[j] = e0 + j < n ? (T)onew_word1(ow, cu.at(ow, e0 + j), x) : (T)0;
+        }
+        if (have_q && q_in) { const uint64_t x = S1[e0 + ITEMS]; q1v = (T)onew_word1(ow, cu.at(ow, e0 + ITEMS), x); qsav = (T)onew_suffix(ow, x); }
+    } else {
+        if (e0 > 0 && e0 - 1 < n) { p1 = S1[e0 - 1]; psa = SA[e0 - 1]; have_p = true; if (!LAZY2) p2 = S2[e0 - 1]; }
+        else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; psa = bd.prev3; }
+        q1v = have_q ? (q_in ? S1[e0 + ITEMS] : bd.next1) : (T)0;
+    }
+    bool q_tied = false;            // (ONEW) the record after this run ties with the run's last one on the leading bits
     if (LAZY2) {
-        if (have_p && p1 == a1[0] && e0 < n) p2 = S2[e0 - 1];
+        const bool p_tied = have_p && p1 == a1[0] && e0 < n;
+        if (ONEW) q_tied = have_q && q_in && q1v == a1[ITEMS - 1];
+        unsigned tied = 0;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const bool eq_prev = j ? a1[j] == a1[j - 1] : ((have_p || (e0 == 0 && bd.has_prev)) && a1[0] == p1);
             const bool eq_next = (e0 + j + 1 == n) ? (bd.has_next && a1[j] == bd.next1)          // last record of the block
                                                    : (j + 1 < ITEMS ? a1[j] == a1[j + 1] : (have_q && a1[j] == q1v));
-            a2[j] = ((eq_prev || eq_next) && e0 + j < n) ? S2[e0 + j] : (T)0;
+            if ((eq_prev || eq_next) && e0 + j < n) tied |= 1u << j;
         }
+        if (p_tied) { p2 = S2[e0 - 1]; if (ONEW) p1 = S1t[e0 - 1]; }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool t = (tied >> j) & 1u;
+            a2[j] = t ? S2[e0 + j] : (T)0;
+            if (ONEW && t) a1[j] = S1t[e0 + j];          // (the bits of word 1 below the sorted prefix matter between tied suffixes only)
+        }
+        if (ONEW && q_tied) q1v = S1t[e0 + ITEMS];
     }
     // head flag of the first record after this run (for the activity test)
     bool next_head = true;
     if (have_q) {
         const bool in = q_in;
         const T q1 = q1v;
-        const T q2 = in ? ((!LAZY2 || q1 == a1[ITEMS - 1]) ? S2[e0 + ITEMS] : (T)0) : bd.next2;
-        const T qsa = in ? SA[e0 + ITEMS] : bd.next3;
+        const T q2 = in ? ((ONEW ? q_tied : (!LAZY2 || q1 == a1[ITEMS - 1])) ? S2[e0 + ITEMS] : (T)0) : bd.next2;
+        const T qsa = in ? (ONEW ? qsav : SA[e0 + ITEMS]) : bd.next3;
         uint64_t c = window_lcp<T>(a1[ITEMS - 1], a2[ITEMS - 1], q1, q2, ks);
         const uint64_t la = first_round_len<GSA, T>(ng, sa[ITEMS - 1], a1[ITEMS - 1], a2[ITEMS - 1], ks);
         const uint64_t lb = first_round_len<GSA, T>(ng, qsa, q1, q2, ks);
@@ -1328,6 +1445,113 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
                 if (!FROM_ARRAY || moved) S2[e + i] = k2[i];
                 if (moved) SA[e + i] = sa[i];
             }
+        }
+    }
+}
+
+// tie_resolve_kernel on one-word records (OneWordView): the groups are found on (top digit, rest of the prefix); the members of a group share
+// their prefix bits, so a group is put in order by rewriting the suffix fields of its records.  W1 / S2 receive both words of the window of
+// every tied suffix (word 1 with the characters below the sorted prefix read from the text): rebucket_first_kernel<.., ONEW> reads them for
+// exactly those records.
+template <int BLOCK, int ITEMS, int G>
+__global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __restrict__ R, uint64_t* __restrict__ W1, uint64_t* __restrict__ S2,
+                                                               uint64_t n, OneWordView ow, const uint8_t* __restrict__ text, uint64_t n_text,
+                                                               CodeTable tab, KeyShape ks, unsigned long long* __restrict__ big) {
+    typedef uint64_t T;
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ uint16_t ctab[256];
+    __shared__ unsigned leaders[TILE / 2 + 1];
+    __shared__ unsigned n_leaders;
+    __shared__ unsigned long long s_off[257];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
+    for (int i = threadIdx.x; i < 257; i += BLOCK) s_off[i] = ow.off[i];
+    if (threadIdx.x == 0) n_leaders = 0;
+    __syncthreads();
+    ow.off = s_off;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t e0 = t0 + (uint64_t)threadIdx.x * ITEMS;
+    if (e0 < n) {
+        // (top digit, rest of the prefix) of records e0 - 1 .. e0 + ITEMS, three at a time
+        T mid[ITEMS];
+        load_run<T, ITEMS>(R, e0, n, mid, (T)0);
+        const T before = e0 ? R[e0 - 1] : (T)0, after = e0 + ITEMS < n ? R[e0 + ITEMS] : (T)0;
+        OneWordCursor cu;
+        cu.start(ow, e0 ? e0 - 1 : 0);
+        T vp = e0 ? onew_lead(ow, cu.b, before) : (T)0;
+        T vc = onew_lead(ow, cu.at(ow, e0), mid[0]);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t e = e0 + j;
+            const T x = j + 1 < ITEMS ? mid[j + 1 < ITEMS ? j + 1 : 0] : after;
+            const T vn = e + 1 < n ? onew_lead(ow, cu.at(ow, e + 1), x) : ~(T)0;
+            const bool start = (e == 0) || vp != vc;
+            if (e + 1 < n && start && vn == vc) leaders[atomicAdd(&n_leaders, 1u)] = (unsigned)(e - t0);
+            vp = vc; vc = vn;
+        }
+    }
+    __syncthreads();
+    // pass 2: eight lanes per group, one member each -- the members' windows come from the text side by side, a member's place in its group
+    // is the number of members that sort before it (the lanes of a group ask each other), and every lane writes its own member there
+    const unsigned ng = n_leaders;
+    const T smask = (1ull << ow.sfield) - 1;
+    const unsigned lane = lane_id(), m = lane & (G - 1), seg0 = lane & ~(unsigned)(G - 1);
+    static_assert(G == 8, "eight lanes per group");
+    const unsigned nlow = (ow.lo1 + ks.lc - 1) / ks.lc < ks.c1 ? (ow.lo1 + ks.lc - 1) / ks.lc : ks.c1;      // characters of word 1 with a bit below lo1
+    const unsigned lowbits = nlow * ks.lc;
+    for (unsigned g0 = 0; g0 < ng; g0 += BLOCK / G) {            // (the same trips for every lane of the workgroup: the lane moves below need whole waves)
+        const unsigned g = g0 + threadIdx.x / G;
+        const bool live = g < ng;
+        const uint64_t e = t0 + (live ? leaders[g] : 0u);
+        const unsigned b = onew_bucket(ow, e);
+        const uint64_t bend = ow.off[b + 1];              // a group does not reach over the end of its bucket
+        const T rec = (live && e + m < bend) ? R[e + m] : (T)0;
+        const T beyond = (live && e + G < bend) ? R[e + G] : (T)0;
+        const T key = shfl<T>(rec >> ow.sfield, (int)seg0);
+        const bool same = live && e + m < bend && (rec >> ow.sfield) == key;
+        const unsigned mine = (unsigned)(__ballot(same) >> seg0) & ((1u << G) - 1u);
+        const unsigned len = (unsigned)__builtin_ctz(~mine);                // members: the leading run of equal prefixes
+        const bool too_long = len == (unsigned)G && e + G < bend && (beyond >> ow.sfield) == key;
+        const bool member = live && !too_long && m < len;
+        if (live && too_long && m == 0) atomicAdd(big, 1ull);
+        const T sa = rec & smask;
+        T k1 = ~(T)0, k2 = ~(T)0;
+        if (member) {
+            const T have = onew_word1(ow, b, rec);
+            const uint64_t q0 = sa + ks.c1 - nlow;
+            const unsigned L = nlow + ks.c2;                      // characters [q0, q0 + L): the tail of word 1, then word 2
+            if (L <= 32 && q0 + 32 <= n_text) {
+                // four 8-byte pieces asked for together instead of L single characters one after the other
+                uint64_t x[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { x[c] = 0; if ((unsigned)(8 * c) < L) __builtin_memcpy(&x[c], text + q0 + 8 * c, 8); }
+                T lo = 0, w2 = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned at = 8 * c + i;
+                        const T code = (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
+                        if (at < nlow) lo = (T)(lo << ks.lc) | code;
+                        else if (at < L) w2 = (T)(w2 << ks.lc) | code;
+                    }
+                }
+                k1 = lowbits >= 64 ? lo : (T)(((have >> lowbits) << lowbits) | lo);
+                k2 = w2;
+            } else {
+                k2 = window_word2<T>(text, n_text, ctab, ks, sa);
+                k1 = window_word1_low<T>(text, n_text, ctab, ks, sa, have, ow.lo1);
+            }
+        }
+        unsigned rank = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const T o1 = shfl<T>(k1, (int)(seg0 + j)), o2 = shfl<T>(k2, (int)(seg0 + j));
+            if (o1 < k1 || (o1 == k1 && (o2 < k2 || (o2 == k2 && (unsigned)j < m)))) ++rank;          // (equal windows keep their order: stable)
+        }
+        const bool moved = ((unsigned)(__ballot(member && rank != m) >> seg0) & ((1u << G) - 1u)) != 0;
+        if (member) {
+            W1[e + rank] = k1; S2[e + rank] = k2;
+            if (moved) R[e + rank] = (key << ow.sfield) | sa;
         }
     }
 }

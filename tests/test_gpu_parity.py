@@ -752,6 +752,13 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     monkeypatch.delenv("PSACX_FORCE_DIET")
     monkeypatch.setenv("PSACX_NO_ONE_WORD", "1")
     same_as_oracle(ctx, five, bits=64)
+    monkeypatch.delenv("PSACX_NO_ONE_WORD")
+    # from 2^22 characters on the tie stage and the rebucket kernel read the one-word records where the sort left them (the cases of
+    # 2^22 characters and more above; `rep` with the probe off meets a long tie group and widens them after all); the same with the
+    # last pass writing word 1 and the suffixes as arrays
+    monkeypatch.setenv("PSACX_WIDEN_LAST", "1")
+    same_as_oracle(ctx, cases[0][0], bits=64)
+    same_as_oracle(ctx, three, bits=64)
 
 
 def test_bucket_ids_of_resolved_tiles_are_filled_in_on_demand(ctx, monkeypatch):

@@ -20,5 +20,5 @@ for rep in range(3):
         if on: os.environ[env] = os.environ.get("AB_VALUE", "1")
         else: os.environ.pop(env, None)
         s = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp, profile=True)
-        print("%s=%d: keys %.1f, tile hist %.1f, scatter %.1f, rebucket %.2f, isa %.1f, total %.1f"
-              % (env, on, s.ms_kmer, s.ms_sort_tilehist, s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, s.ms_rebucket, s.ms_isa_scatter, s.ms_total))
+        print("%s=%d: keys %.1f, tile hist %.1f, scatter %.1f, ties %.2f, rebucket %.2f, isa %.1f, total %.1f"
+              % (env, on, s.ms_kmer, s.ms_sort_tilehist, s.ms_sort_scatter + s.ms_sort_scatter3 + s.ms_sort_scatter2, s.ms_gather, s.ms_rebucket, s.ms_isa_scatter, s.ms_total))
