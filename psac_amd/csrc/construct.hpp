@@ -313,6 +313,46 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
     return PSACX_OK;
 }
 
+// The ISA entries of a refinement round -- (suffix | value << 32) pairs in list order, a subset of the positions -- taken to their
+// places like the pairs of the whole inversion: 512-way partition levels by destination (the class regions of a level are filled as far
+// as its cursors say), then stores that stay inside windows of 2^14 entries.  64-bit words, 2^22 .. 2^32 characters.  A round that is
+// worked off in slabs runs the first level per slab (the class regions fill up slab by slab) and the rest once at its end: the ranks every
+// slab reads are those of the round's start, as in psac's rounds, and every line of ISA is written once.
+// lvl_a, lvl_b: two arrays of n entries (lvl_a must survive from the first slab to the end of the round); cursors: d_cursors
+// (1024 + (n >> 14) + 1 entries).  One random 8-byte store per record instead: 217 ms per round of 2^32 records.
+template <typename T> struct IsaLevels {
+    static constexpr int PB = 512, PI = 16, WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
+    psacx_ctx* c; unsigned* cursors; uint64_t n; int lv9; uint64_t* lvl_a; bool open;
+    unsigned* c0() const { return cursors; }
+    unsigned* c1() const { return cursors + 1024; }
+    int begin(psacx_ctx* ctx, unsigned* d_cursors, uint64_t n_, uint64_t* a, const Knobs& kn) {
+        c = ctx; cursors = d_cursors; n = n_; lvl_a = a; open = true;
+        lv9 = isa_narrow_levels<T>(n, kn);
+        if (lv9 < 1 || lv9 > 2) { c->hip_err = "ISA update by levels: text size out of range"; return PSACX_EINVAL; }
+        PSACX_HIP(c, hipMemsetAsync(cursors, 0, (1024 + (size_t)(n >> WB) + 1) * sizeof(unsigned), c->stream));
+        return PSACX_OK;
+    }
+    int add(const uint64_t* pairs, uint64_t cnt) {
+        hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+                           (const T*)nullptr, pairs, lvl_a, cnt, isa_narrow_shift(lv9, 0), lv9 == 1 ? c1() : c0(), (uint64_t)0);
+        PSACX_HIP(c, hipGetLastError());
+        return PSACX_OK;
+    }
+    int finish(T* d_isa, uint64_t* lvl_b) {
+        open = false;
+        const uint64_t* last = lvl_a;
+        if (lv9 == 2) {
+            hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)((n + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+                               (const T*)nullptr, (const uint64_t*)lvl_a, lvl_b, n, (unsigned)WB, c1(), (uint64_t)0, (const unsigned*)c0(), isa_narrow_shift(lv9, 0));
+            PSACX_HIP(c, hipGetLastError());
+            last = lvl_b;
+        }
+        hipLaunchKernelGGL((window_store_sparse_kernel<T, 1024, WB>), dim3((unsigned)((n + (1ull << WB) - 1) >> WB)), dim3(1024), 0, c->stream, last, (const unsigned*)c1(), n, d_isa);
+        PSACX_HIP(c, hipGetLastError());
+        return PSACX_OK;
+    }
+};
+
 // Range minima of a refinement round (suffix_array.hpp:1457-1476 issues one per freshly split boundary)
 // read LCP values set in earlier rounds only, so per-group running minima can be tabulated once per
 // round: a query then costs two loads per level instead of up to 126.  Levels >= 1 are tiny and always
@@ -757,6 +797,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // B2 = rank of the suffix h further, sort by (bucket, B2), new ids / LCP / ISA written in place
     // whole: the round takes all n suffixes in TEXT order (shift_keys_kernel) and ISA is rebuilt by inverting the new SA
     // (the destination-partition levels of the first round) instead of one random store per record
+    IsaLevels<T> isa_lv; isa_lv.open = false;
     auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false) -> int {
         // 64-bit words, at most 2^32 characters: bucket number and rank h further share one word, the suffix is a 32-bit entry --
         // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass.  With a list
@@ -790,6 +831,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                /*summary_ready=*/true));
         if (rr) { rr->sort_passes += rs.sort_passes; rr->sort_passes_skipped += rs.sort_passes_skipped; }
         T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
+        // large rounds of the two-word form: the ISA entries leave the rebucket kernel as pairs (in the idle second key array of the round's
+        // second record set) and reach ISA through partition levels once the compaction has read the ids (x.k2 and x.k1 are idle then)
+        uint64_t* const isa_pairs = (both && !whole && (cnt >= (1ull << 22) || isa_lv.open) && isa_narrow_levels<T>(n, kn) > 0 && !kn.isa_stores)
+                                        ? reinterpret_cast<uint64_t*>(w.ry.k2) : (uint64_t*)nullptr;
         if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n, kn));
         {
             ProfScope ps(c, TC_REBUCKET);
@@ -799,10 +844,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
                                d_sa, w.bsa, whole ? (T*)nullptr : d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
-                               (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr, kb2);
+                               (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr, kb2, isa_pairs);
             PSACX_HIP(c, hipGetLastError());
         }
         PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active));
+        if (isa_pairs) {
+            ProfScope ps(c, TC_ISA_SCATTER);
+            const bool mine = !isa_lv.open;          // (a round in slabs opens the levels itself and closes them after its last slab)
+            if (mine) PSACX_TRY(isa_lv.begin(c, w.d_cursors, n, reinterpret_cast<uint64_t*>(w.x.k2), kn));
+            PSACX_TRY(isa_lv.add(isa_pairs, cnt));
+            if (mine) PSACX_TRY(isa_lv.finish(d_isa, reinterpret_cast<uint64_t*>(w.x.k1)));
+        }
         if (whole) {
             ProfScope ps(c, TC_ISA_SCATTER);
             PSACX_TRY(invert_permutation<T>(c, w.d_cursors, d_sa, w.bsa, n, d_isa, w.x, w.ry, kn, 0, &w.sc, false, false));
@@ -866,6 +918,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             const uint64_t room = w.cap_active > 2ull * ScanCfg<T>::TILE ? w.cap_active - 2ull * ScanCfg<T>::TILE : 0;
             uint64_t sum_act = 0, sum_unf = 0, s0 = 0;
             T* h_id = reinterpret_cast<T*>(c->pinned + 128);
+            // (64-bit words, at most 2^32 characters: the slabs' ISA entries are collected by destination class and stored at the end of the round)
+            const bool collect = sizeof(T) == 8 && n <= (1ull << 32) && isa_narrow_levels<T>(n, kn) > 0 && !kn.isa_stores && room >= SMALL_SORT_MAX;
             while (s0 < n) {
                 // furthest tile boundary whose tiles (from the one holding s0) hold at most `room` unresolved positions
                 uint64_t t = s0 / ScanCfg<T>::TILE, acc = 0;
@@ -891,10 +945,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 if (cnt > w.cap_active) { c->hip_err = "slab larger than planned"; return PSACX_EDEVICE; }
                 if (cnt) {
                     uint64_t na = 0, nu = 0;
+                    // (a slab too small for the two-word records sorts through x.k2, where the collected pairs live: they go to ISA first)
+                    if (isa_lv.open && cnt < SMALL_SORT_MAX) PSACX_TRY(isa_lv.finish(d_isa, reinterpret_cast<uint64_t*>(w.x.k1)));
+                    else if (collect && !isa_lv.open && cnt >= SMALL_SORT_MAX) PSACX_TRY(isa_lv.begin(c, w.d_cursors, n, reinterpret_cast<uint64_t*>(w.x.k2), kn));
                     PSACX_TRY(refine(pos, cnt, h, rr, pos_next, &na, &nu));
                     sum_act += na; sum_unf += nu;
                 }
                 s0 = e;
+            }
+            if (isa_lv.open) {
+                ProfScope ps(c, TC_ISA_SCATTER);
+                PSACX_TRY(isa_lv.finish(d_isa, reinterpret_cast<uint64_t*>(w.x.k1)));
             }
             nactive = sum_act; unf_b = sum_unf;
         }

@@ -146,6 +146,7 @@ struct Knobs {
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
     bool one_word_always;   // PSACX_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
+    bool isa_stores;        // PSACX_ISA_STORES: refinement rounds update ISA by one random store per record even where the partition levels apply
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -161,6 +162,7 @@ inline Knobs read_knobs() {
     e = getenv("PSACX_ONE_WORD_MIN");
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
+    k.isa_stores = getenv("PSACX_ISA_STORES") != nullptr;
     return k;
 }
 

@@ -1113,7 +1113,10 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const TI* __restr
 template <typename TI, int BLOCK, int ITEMS, bool FIRST, int CB>
 __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __restrict__ key_in, const TI* __restrict__ val_in,
                                                                  const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n,
-                                                                 unsigned shift, unsigned* __restrict__ cursors, uint64_t koff) {
+                                                                 unsigned shift, unsigned* __restrict__ cursors, uint64_t koff,
+                                                                 const unsigned* __restrict__ in_counts = nullptr, unsigned in_shift = 0) {
+    // in_counts (levels after the first, pairs of a SUBSET of the positions: the ISA update of a refinement round): the class regions of
+    // the level before are filled to in_counts[class] only (class = index >> in_shift; a tile lies inside one region)
     constexpr int NCLS = 1 << CB;
     static_assert(BLOCK >= NCLS, "one thread per class");
     constexpr int TILE = BLOCK * ITEMS;
@@ -1124,7 +1127,12 @@ __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __res
     __shared__ unsigned scan_tmp[BLOCK / WAVE + 1];
     const unsigned tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    const uint64_t remain = n - base;
+    uint64_t remain = n - base;
+    if (in_counts) {
+        const uint64_t filled = in_counts[base >> in_shift], into = base & ((1ull << in_shift) - 1);
+        if (filled <= into) return;                  // (the same for every thread of the workgroup)
+        remain = filled - into < remain ? filled - into : remain;
+    }
     const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
     for (int i = tid; i < NCLS; i += BLOCK) cnt[i] = 0;
     __syncthreads();
@@ -1185,6 +1193,29 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_packed_kernel(const uint
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) { const uint64_t x = pairs[base + p]; win[(uint32_t)x & (W - 1)] = (uint32_t)(x >> 32); }
     __syncthreads();
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) out[base + p] = (TO)win[p];
+}
+
+// The last step of the ISA update of a refinement round: window w holds counts[w] (position | value << 32) pairs at pairs[w << WB ...].
+// The window of `out` is brought into LDS unless every entry of it has a pair, the pairs are applied there, and the window goes back in
+// whole lines (values below 2^32: texts of at most 2^32 characters).  (Storing the pairs straight into `out` -- random 8-byte stores
+// inside 128 KiB -- took 4 x as long.)
+template <typename TO, int BLOCK, int WB>
+__global__ __launch_bounds__(BLOCK) void window_store_sparse_kernel(const uint64_t* __restrict__ pairs, const unsigned* __restrict__ counts, uint64_t n,
+                                                                    TO* __restrict__ out) {
+    constexpr unsigned W = 1u << WB;
+    __shared__ uint32_t win[W];
+    const uint64_t base = (uint64_t)blockIdx.x << WB;
+    const unsigned count = counts[blockIdx.x];
+    if (count == 0) return;
+    const uint64_t remain = n - base;
+    const unsigned wn = remain < (uint64_t)W ? (unsigned)remain : W;
+    if (count < wn) {
+        for (unsigned p = threadIdx.x; p < wn; p += BLOCK) win[p] = (uint32_t)out[base + p];
+        __syncthreads();
+    }
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) { const uint64_t x = pairs[base + p]; win[(uint32_t)x & (W - 1)] = (uint32_t)(x >> 32); }
+    __syncthreads();
+    for (unsigned p = threadIdx.x; p < wn; p += BLOCK) out[base + p] = (TO)win[p];
 }
 
 // ------------------------------------------------------------------ K12
@@ -1780,7 +1811,9 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
     const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf,
     Boundary<T> bd, T* __restrict__ q_at, T* __restrict__ q_lo, T* __restrict__ q_hi,
-    unsigned long long* __restrict__ q_count, unsigned kb2 = 32) {
+    unsigned long long* __restrict__ q_count, unsigned kb2 = 32, uint64_t* __restrict__ pairs_out = nullptr) {
+    // pairs_out (one GPU, at most 2^32 characters): the ISA entries of the round leave as (suffix | new id - 1 << 32) pairs in list order
+    // instead of one random store each; the caller takes them to their places through partition levels (construct.hpp: isa_update_by_levels)
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ T scan_tmp[BLOCK / WAVE + 1];
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
@@ -1882,10 +1915,17 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         if (e < cnt) {
             SA[(uint64_t)ps[j] - bd.off] = sa[j];
             Bsa[(uint64_t)ps[j] - bd.off] = id[j];
-            if (!DIST && ISA) ISA[sa[j]] = id[j] - 1;
+            if (!DIST && ISA && !pairs_out) ISA[sa[j]] = id[j] - 1;
         }
     }
     store_run_x<T, ITEMS>(ids_out, e0, cnt, id, xw);
+    if constexpr (!DIST && sizeof(T) == 8) {
+        if (pairs_out) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sa[j] = (T)((uint64_t)(uint32_t)sa[j] | ((uint64_t)(uint32_t)(id[j] - 1) << 32));
+            store_run_x<T, ITEMS>(reinterpret_cast<T*>(pairs_out), e0, cnt, sa, xw);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ K14
