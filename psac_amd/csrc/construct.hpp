@@ -147,7 +147,9 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
 template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
                 uint64_t* active, uint64_t* unf_buckets, uint64_t capacity, unsigned shift = 0,
-                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0, bool fill_lazy_ids = false) {
+                const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0, bool fill_lazy_ids = false,
+                uint32_t* ord_out = nullptr) {
+    // ord_out: the list entries' bucket numbers counted from 0 (needs the per-tile counts of unfinished buckets in w.d_nunf)
     // pos_off: SA position of ids[0] when pos_in is null (a slab of the reduced-memory layout)
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -178,7 +180,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
         else
             hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
-                               (const T*)nullptr, (T*)nullptr, (T*)nullptr);
+                               (const T*)nullptr, (T*)nullptr, (T*)nullptr, (const uint64_t*)w.d_nunf, ord_out);
         PSACX_HIP(c, hipGetLastError());
     }
     return PSACX_OK;
@@ -783,7 +785,10 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
 
     // ---- which suffixes still share a bucket (suffix_array.hpp:925-965)
     uint64_t active = 0, unf_b = 0;
-    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active, 0, nullptr, nullptr, nullptr, 0, lazy_ids));
+    // (64-bit words, at most 2^32 characters: the list comes with its entries' bucket numbers counted from 0, in the idle upper half of the
+    //  payload array -- the one-word sort keys of the refinement rounds then need only as many bits as there are buckets)
+    uint32_t* const ord_arr = (sizeof(T) == 8 && n <= (1ull << 32)) ? reinterpret_cast<uint32_t*>(w.x.v) + n : (uint32_t*)nullptr;
+    PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active, 0, nullptr, nullptr, nullptr, 0, lazy_ids, ord_arr));
     r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;
     st.n_rounds = 1;
     // The list of unresolved SA positions exists only while it fits the workspace.  In the reduced-memory layout a
@@ -798,7 +803,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     // whole: the round takes all n suffixes in TEXT order (shift_keys_kernel) and ISA is rebuilt by inverting the new SA
     // (the destination-partition levels of the first round) instead of one random store per record
     IsaLevels<T> isa_lv; isa_lv.open = false;
-    auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false) -> int {
+    // nb_in: buckets in the list (0: not known, or the list has no bucket numbers beside it); list_out == nullptr: only the counters
+    auto refine = [&](const T* plist, uint64_t cnt, uint64_t h, psacx_round* rr, T* list_out, uint64_t* nactive, uint64_t* nunf, bool whole = false,
+                      uint64_t nb_in = 0) -> int {
         // 64-bit words, at most 2^32 characters: bucket number and rank h further share one word, the suffix is a 32-bit entry --
         // two-word records with a narrow payload (radix.hpp: NOKO, VN 1 / 2), 24 instead of 48 bytes per record and pass.  With a list
         // of unresolved positions the bucket numbers are dense (gather_keys_kernel: list index of the head, halved): 31 bits beside a
@@ -806,7 +813,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         const bool dense = plist != nullptr && !whole;
         const unsigned kb2 = dense ? id_bits : 32u;
         const bool both = sizeof(T) == 8 && cnt >= SMALL_SORT_MAX && (n < (1ull << 32) || (n == (1ull << 32) && dense));
-        const unsigned num_bits = dense ? bits_for(cnt > 2 ? (cnt - 1) >> 1 : 1) : id_bits;
+        const bool by_ord = dense && both && ord_arr && nb_in > 0;
+        const unsigned num_bits = by_ord ? bits_for(nb_in > 1 ? nb_in - 1 : 1) : dense ? bits_for(cnt > 2 ? (cnt - 1) >> 1 : 1) : id_bits;
         T* const key2 = both ? (T*)nullptr : w.x.k2;
         {
             ProfScope ps(c, TC_GATHER);
@@ -815,7 +823,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 hipLaunchKernelGGL((shift_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
             else
                 hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
-                                   plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen, kb2);
+                                   plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen, kb2,
+                                   by_ord ? (const uint32_t*)ord_arr : (const uint32_t*)nullptr);
             PSACX_HIP(c, hipGetLastError());
             // (only the three-kernel form of the sort reads the key summary)
             if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
@@ -847,7 +856,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr, kb2, isa_pairs);
             PSACX_HIP(c, hipGetLastError());
         }
-        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, w.cap_active));
+        PSACX_TRY(run_compact<T>(c, w, ids, plist, cnt, list_out, nactive, nunf, list_out ? w.cap_active : 0, 0, nullptr, nullptr, nullptr, 0, false,
+                                 list_out ? ord_arr : (uint32_t*)nullptr));
         if (isa_pairs) {
             ProfScope ps(c, TC_ISA_SCATTER);
             const bool mine = !isa_lv.open;          // (a round in slabs opens the levels itself and closes them after its last slab)
@@ -871,12 +881,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             // back under the capacity: rebuild the list of unresolved positions from the bucket ids
             const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
             hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                               c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u);
+                               c->stream, w.bsa, n, (T)0, (T)0, w.d_nact, 0u, w.d_nunf);
             PSACX_HIP(c, hipGetLastError());
-            PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
             uint64_t a2 = 0, u2 = 0;
-            PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, pos, &a2, &u2, w.cap_active));
-            if (a2 != active) { c->hip_err = "active list rebuild disagrees with the round counters"; return PSACX_EDEVICE; }
+            PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, pos, &a2, &u2, w.cap_active, 0, nullptr, nullptr, nullptr, 0, false, ord_arr));
+            if (a2 != active || u2 != unf_b) { c->hip_err = "active list rebuild disagrees with the round counters"; return PSACX_EDEVICE; }
             have_list = true;
         }
         // rounds in which at least 7/8 of the suffixes are unresolved (repetitive texts) take all n in text order, as psac's
@@ -900,7 +909,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_TRY(refine((const T*)nullptr, n, h, rr, pos_next, &nactive, &unf_b, true));
             std::swap(pos, pos_next);
         } else if (no_fast || have_list) {
-            PSACX_TRY(refine(no_fast ? (const T*)nullptr : pos, round_cnt, h, rr, pos_next, &nactive, &unf_b));
+            PSACX_TRY(refine(no_fast ? (const T*)nullptr : pos, round_cnt, h, rr, pos_next, &nactive, &unf_b, false, no_fast ? 0 : unf_b));
             std::swap(pos, pos_next);
         } else {
             // Slabs.  Buckets are contiguous in SA order and a refinement only permutes inside buckets, so any range
@@ -937,18 +946,17 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 }
                 const uint64_t len = e - s0, lt = (len + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
                 hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)lt), dim3(ScanCfg<T>::BLOCK), 0,
-                                   c->stream, w.bsa + s0, len, (T)0, (T)0, w.d_nact, 0u);
+                                   c->stream, w.bsa + s0, len, (T)0, (T)0, w.d_nact, 0u, w.d_nunf);
                 PSACX_HIP(c, hipGetLastError());
-                PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, lt * sizeof(uint64_t), c->stream));
-                uint64_t cnt = 0, unused = 0;
-                PSACX_TRY(run_compact<T>(c, w, w.bsa + s0, nullptr, len, pos, &cnt, &unused, w.cap_active, 0, nullptr, nullptr, nullptr, s0));
+                uint64_t cnt = 0, slab_buckets = 0;
+                PSACX_TRY(run_compact<T>(c, w, w.bsa + s0, nullptr, len, pos, &cnt, &slab_buckets, w.cap_active, 0, nullptr, nullptr, nullptr, s0, false, ord_arr));
                 if (cnt > w.cap_active) { c->hip_err = "slab larger than planned"; return PSACX_EDEVICE; }
                 if (cnt) {
                     uint64_t na = 0, nu = 0;
                     // (a slab too small for the two-word records sorts through x.k2, where the collected pairs live: they go to ISA first)
                     if (isa_lv.open && cnt < SMALL_SORT_MAX) PSACX_TRY(isa_lv.finish(d_isa, reinterpret_cast<uint64_t*>(w.x.k1)));
                     else if (collect && !isa_lv.open && cnt >= SMALL_SORT_MAX) PSACX_TRY(isa_lv.begin(c, w.d_cursors, n, reinterpret_cast<uint64_t*>(w.x.k2), kn));
-                    PSACX_TRY(refine(pos, cnt, h, rr, pos_next, &na, &nu));
+                    PSACX_TRY(refine(pos, cnt, h, rr, (T*)nullptr, &na, &nu, false, slab_buckets));
                     sum_act += na; sum_unf += nu;
                 }
                 s0 = e;

@@ -1244,7 +1244,10 @@ template <typename T, int BLOCK, int ITEMS, bool EMIT = false>
 __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
     const uint64_t* __restrict__ offset, uint64_t pos_off, T prev_id, T next_id, unsigned shift = 0,
-    const T* __restrict__ payload = nullptr, T* __restrict__ out_id = nullptr, T* __restrict__ out_payload = nullptr) {
+    const T* __restrict__ payload = nullptr, T* __restrict__ out_id = nullptr, T* __restrict__ out_payload = nullptr,
+    const uint64_t* __restrict__ unf_offset = nullptr, uint32_t* __restrict__ ord_out = nullptr) {
+    // ord_out (with unf_offset = exclusive scan of the per-tile counts of buckets with more than one member): every list entry's bucket
+    // counted from 0 in list order -- the bucket's number in the one-word sort keys of the next round (gather_keys_kernel)
     // shift: only the bits above `shift` of an id count (ties of a prefix sort by the leading bits)
     // prev_id / next_id: bucket id of the list entry just before / after this block (0 = none);
     // pos_off: SA position of entry 0 when pos_in is null
@@ -1270,16 +1273,19 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
             for (int j = 0; j < ITEMS + 2; ++j) v[j] >>= shift;
         }
     }
-    unsigned act = 0, nact = 0;
+    unsigned act = 0, nact = 0, uh = 0;          // uh: active entries that open their bucket
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool in = (e0 + j) < cnt;
-        if (in && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) { act |= 1u << j; ++nact; }
+        if (in && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) { act |= 1u << j; ++nact; if (v[j + 1] != v[j]) uh |= 1u << j; }
     }
     unsigned agg;
-    const unsigned excl = block_scan_exclusive<BLOCK, unsigned>(nact, OpSum(), 0u, scan_tmp, &agg);
-    if (agg == 0) return;
+    static_assert(TILE < (1 << 16), "active entries and bucket heads of a tile scanned in one word");
+    const unsigned both_excl = block_scan_exclusive<BLOCK, unsigned>(nact | ((unsigned)__builtin_popcount(uh) << 16), OpSum(), 0u, scan_tmp, &agg);
+    const unsigned excl = both_excl & 0xFFFFu;
+    if ((agg & 0xFFFFu) == 0) return;
     uint64_t o = offset[tile] + excl;
+    uint64_t ord = ord_out ? unf_offset[tile] + (both_excl >> 16) : 0;          // buckets opened before this thread's first entry
     T ps[ITEMS];
     if (pos_in) load_run_x<T, ITEMS>(pos_in, e0, cnt, ps, (T)0, xw);
     T pl[EMIT ? ITEMS : 1];
@@ -1293,6 +1299,8 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     for (int j = 0; j < ITEMS; ++j) {
         if (act & (1u << j)) {
             if (EMIT) { out_id[o] = raw[EMIT ? j : 0]; out_payload[o] = pl[EMIT ? j : 0]; }
+            if (uh & (1u << j)) ++ord;
+            if (ord_out) ord_out[o] = (uint32_t)(ord - 1);
             pos_out[o++] = pos_in ? ps[j] : (T)(pos_off + e0 + j);
         }
     }
@@ -1302,7 +1310,8 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
 // do not get the counts from a rebucket kernel
 template <typename T, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict__ ids, uint64_t cnt, T prev_id, T next_id,
-                                                             uint64_t* __restrict__ n_active, unsigned shift = 0) {
+                                                             uint64_t* __restrict__ n_active, unsigned shift = 0, uint64_t* __restrict__ n_unf = nullptr) {
+    // n_unf (optional): per tile, the buckets with more than one member that start in it
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ unsigned red_tmp[BLOCK / WAVE + 1];
     __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];
@@ -1325,9 +1334,9 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
     unsigned nact = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
-        if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) ++nact;
+        if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) nact += 1u + ((v[j + 1] != v[j]) ? (1u << 16) : 0u);
     const unsigned t = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
-    if (threadIdx.x == 0) n_active[blockIdx.x] = t;
+    if (threadIdx.x == 0) { n_active[blockIdx.x] = t & 0xFFFFu; if (n_unf) n_unf[blockIdx.x] = t >> 16; }
 }
 
 // ------------------------------------------------------------------ first round in two stages
@@ -1627,7 +1636,10 @@ template <typename T>
 __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ SA,
                                    const T* __restrict__ Bsa, const T* __restrict__ ISA, uint64_t n,
                                    uint64_t h, T* __restrict__ K1, T* __restrict__ K2, T* __restrict__ V,
-                                   unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr, unsigned kb2 = 32) {
+                                   unsigned long long* __restrict__ summary, const T* __restrict__ slen = nullptr, unsigned kb2 = 32,
+                                   const uint32_t* __restrict__ ord = nullptr) {
+    // ord (with pos, K2 == nullptr): the bucket numbers of the list entries counted from 0 (compact_active_kernel) -- as many bits as the
+    // buckets of the list need, so the sort runs fewer digit passes when few large buckets are left (a tandem repeat)
     // kb2 (K2 == nullptr): bits of the rank h further in the one-word key; above them the bucket's number.  With a list of positions
     // the number is DENSE: the list index of the bucket's head halved -- the members of a bucket are consecutive in SA and all of them
     // are in the list, so the head's index is j - (p - head position); buckets have at least two members, so halving keeps the numbers
@@ -1645,7 +1657,7 @@ __global__ void gather_keys_kernel(const T* __restrict__ pos, uint64_t cnt, cons
         if (K2) { K1[j] = b1; K2[j] = b2; V[j] = sa; o1 |= b1; a1 &= b1; o2 |= b2; a2 &= b2; }
         else {
             // both keys in one 64-bit word, the suffix as a 32-bit entry (texts of at most 2^32 characters): two-word records
-            const uint64_t num = pos ? ((j - (p - ((uint64_t)b1 - 1))) >> 1) : (uint64_t)b1;
+            const uint64_t num = ord ? (uint64_t)ord[j] : (pos ? ((j - (p - ((uint64_t)b1 - 1))) >> 1) : (uint64_t)b1);
             const T kk = (T)((num << kb2) | (uint64_t)b2);
             K1[j] = kk; reinterpret_cast<uint32_t*>(V)[j] = (uint32_t)sa; o1 |= kk; a1 &= kk;
         }
