@@ -536,13 +536,14 @@ def test_multi_reduced_memory_twin_of_config_c5_and_its_footprint():
 
 
 def test_multi_first_round_memory_in_the_reduced_layout():
-    # psacx_multi_get_memory after a construction of random DNA in the reduced-memory layout (8 ranks x 2^26 characters, uint64, the
+    # psacx_multi_get_memory after a construction of random DNA in the reduced-memory layout (8 ranks x 2^28 characters, uint64, the
     # ranks sharing device 0): the one-word first round keeps the partitioned block, the receive array and the suffixes in the rank's three
     # result arrays and re-balances in place, so the engine's own allocations peak below 3 words per character (round 3: 4.75 with more
     # than one rank; psac plans 6 for its sort, idxsort.hpp:41-45).  With the result arrays (3 x 1.125) and the text that is the 6.5 words
-    # a block of 2^32 characters is allowed on a 288 GiB part.  Verified by the distributed checker.
+    # a block of 2^32 characters is allowed on a 288 GiB part.  Verified by the distributed checker.  (Blocks of 2^28 characters: the
+    # allocations that do not grow with the block -- wire pieces, sort tables, about 0.6 GB a rank -- are 1.2 words of a 2^26 block.)
     import ctypes as C
-    P, m, bits = 8, 1 << 26, 64
+    P, m, bits = 8, 1 << 28, 64
     mg = multi(P)
     try:
         lib = mg._lib
