@@ -52,8 +52,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 #     (1.061 x the algorithmic 18 bytes per record and pass)
 # ... round 4, profiles/r4b_bench_{fetch,write}_4gib_u64.txt: bucket passes (2 x 17324028 + 34444799) KiB x 3, widening pass
 #     (2 x 17328092 + 76522428) KiB; mean over the four = 81525037312 bytes (1.054 x the algorithmic 18 bytes per record and pass)
+# ... round 4, later (no widening pass any more), profiles/r4d_bench_{fetch,write}_4gib_u64.txt: four bucket passes of
+#     (2 x 17323970 + 34463887) KiB = 70770510848 bytes each (1.030 x the algorithmic 16 bytes per record and pass)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 81525037312}
+TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 70770510848}
 
 
 def parse():
@@ -134,7 +136,9 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
         # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the passes inside the buckets
         # (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the last one (radix_scatter1w_kernel<..., 9>: one word in,
         # word 1 + suffix out); the figures below are their mean
-        kname = "radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records: the three passes inside the buckets, 8 + 8 bytes per record, and the widening pass, 8 + 16; the pass on the top digit computes its keys from the text and is timed with them)"
+        kname = ("radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records, 8 + 8 bytes per record: the "
+                 "passes inside the buckets; the tie stage and the rebucket kernel read the records where the last pass leaves them; the pass on "
+                 "the top digit computes its keys from the text and is timed with them)")
         tkey = 3
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
