@@ -140,6 +140,11 @@ def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     # the same with room for only a quarter of the unresolved suffixes per slab of a refinement round
     text2, sb = _tandem_twin(ctx, monkeypatch, 1 << 25)
     assert np.array_equal(sb.local_SA, SA) and np.array_equal(sb.local_LCP, LCP) and np.array_equal(sb.local_B, sa.local_B)
+    # (both runs above take the ISA entries of a round to their places through partition levels, the second collecting them over the
+    #  slabs of a round: construct.hpp: IsaLevels) -- the same with one random store per entry
+    monkeypatch.setenv("PSACX_ISA_STORES", "1")
+    text3, sc = _tandem_twin(ctx, monkeypatch, 1 << 25)
+    assert np.array_equal(sc.local_SA, SA) and np.array_equal(sc.local_LCP, LCP) and np.array_equal(sc.local_B, sa.local_B)
 
 
 def test_host_pointer_path_narrow_transfers(ctx):
