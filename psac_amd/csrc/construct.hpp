@@ -587,7 +587,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
                                                reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
                                                keep ? &onew_view : nullptr);
-                if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
+                if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
+                    two_stage = false; retry_one_stage = true; one_word = false;
+                } else if (rc1 == PSACX_RETRY_1W || rc1 == PSACX_RETRY_1STAGE) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
                     one_word = false;
                     PSACX_TRY(make_keys(hist_in_keys));
                 }
@@ -599,6 +601,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 }
             }
         } else one_word = false;
+        if (retry_one_stage) continue;
         if (!one_word)
         PSACX_TRY(pair_sort<T>(c, w.sc, in1, alt1, n, /*iota=*/true, bits_w1, 0, w.diet ? (T*)nullptr : d_sa, &sorted, r0,
                                ks.spec, n, /*summary_ready=*/true, lo1, hist_in_keys ? (int)lo1 : -1));
