@@ -1772,15 +1772,63 @@ __device__ __forceinline__ T pyramid_edge_min(const T* __restrict__ a, uint64_t 
 template <typename T>
 __device__ __forceinline__ T pyramid_min(const Pyramid<T>& P, uint64_t l, uint64_t r) {
     T m = ~(T)0;
+    // Every level below the top has its running minima (the rounds with many queries on one GPU in the normal layout): a level costs
+    // at most two loads whose addresses follow from l and r alone, so the loads of ALL levels are asked for before the first is used --
+    // one wait per query instead of one per level (a thread evaluates the queries of its records one after the other: 2^30 characters
+    // of repeated reads spent two thirds of rebucket_refine_kernel in these waits).  Only a range inside one group that does not touch
+    // either end of it, and what reaches the top level, is walked.
+    bool all_tables = P.nlev >= 2;
+#pragma unroll
+    for (int L = 0; L < PYR_MAX - 1; ++L) if (L < P.nlev - 1 && P.pre[L] == nullptr) all_tables = false;
+    if (all_tables) {
+        T x[PYR_MAX - 1], y[PYR_MAX - 1];
+        bool done = false;
+        int wlev = -1; uint64_t wa = 0, wb = 0;
+#pragma unroll
+        for (int L = 0; L < PYR_MAX - 1; ++L) {
+            x[L] = ~(T)0; y[L] = ~(T)0;
+            if (!done && L < P.nlev - 1) {
+                if ((l >> 6) == ((r - 1) >> 6)) {
+                    if ((l & 63) == 0) x[L] = P.pre[L][r - 1];
+                    else if ((r & 63) == 0) x[L] = P.suf[L][l];
+                    else { wlev = L; wa = l; wb = r; }
+                    done = true;
+                } else {
+                    if (l & 63) x[L] = P.suf[L][l];
+                    if (r & 63) y[L] = P.pre[L][r - 1];
+                    l = (l + 63) >> 6; r >>= 6;
+                    if (l >= r) done = true;
+                }
+            }
+        }
+        if (!done) { wlev = P.nlev - 1; wa = l; wb = r; }
+#pragma unroll
+        for (int L = 0; L < PYR_MAX - 1; ++L) { m = x[L] < m ? x[L] : m; m = y[L] < m ? y[L] : m; }
+        if (wlev >= 0) {
+            const T* a = P.lvl[0];
+#pragma unroll
+            for (int L = 1; L < PYR_MAX; ++L) if (wlev == L) a = P.lvl[L];
+            m = pyramid_edge_min<T>(a, wa, wb, m);
+        }
+        return m;
+    }
     for (int L = 0; L < P.nlev; ++L) {
         const T* a = P.lvl[L];
-        if (r - l <= 128 || L == P.nlev - 1) return pyramid_edge_min<T>(a, l, r, m);
+        if (L == P.nlev - 1) return pyramid_edge_min<T>(a, l, r, m);
         const uint64_t lb = (l + 63) >> 6, rb = r >> 6;
         if (P.pre[L]) {
-            // lb <= rb here (the range is longer than 128): both partial groups are whole prefixes / suffixes
+            // with the running minima of the groups a range that reaches into two groups or more costs two loads on this level however
+            // short it is (a range of 100 entries used to be read entry by entry); only a range inside one group is walked
+            if ((l >> 6) == ((r - 1) >> 6)) {
+                if ((l & 63) == 0) { const T x = P.pre[L][r - 1]; return x < m ? x : m; }
+                if ((r & 63) == 0) { const T x = P.suf[L][l]; return x < m ? x : m; }
+                return pyramid_edge_min<T>(a, l, r, m);
+            }
+            // lb <= rb here: both partial groups are whole prefixes / suffixes of their groups
             if (l & 63) { const T x = P.suf[L][l]; m = x < m ? x : m; }
             if (r & 63) { const T x = P.pre[L][r - 1]; m = x < m ? x : m; }
         } else {
+            if (r - l <= 128) return pyramid_edge_min<T>(a, l, r, m);
             m = pyramid_edge_min<T>(a, l, lb << 6, m);
             m = pyramid_edge_min<T>(a, rb << 6, r, m);
         }
