@@ -845,7 +845,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
         // large rounds of the two-word form: the ISA entries leave the rebucket kernel as pairs (in the idle second key array of the round's
         // second record set) and reach ISA through partition levels once the compaction has read the ids (x.k2 and x.k1 are idle then)
-        uint64_t* const isa_pairs = (both && !whole && (cnt >= (1ull << 22) || isa_lv.open) && isa_narrow_levels<T>(n, kn) > 0 && !kn.isa_stores)
+        const bool levels_pay = kn.isa_update == 2 || (kn.isa_update == 0 && n >= (1ull << 31) && cnt >= n / 8);
+        uint64_t* const isa_pairs = (both && !whole && ((cnt >= (1ull << 22) && levels_pay) || isa_lv.open) && isa_narrow_levels<T>(n, kn) > 0)
                                         ? reinterpret_cast<uint64_t*>(w.ry.k2) : (uint64_t*)nullptr;
         if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n, kn));
         {
@@ -931,7 +932,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             uint64_t sum_act = 0, sum_unf = 0, s0 = 0;
             T* h_id = reinterpret_cast<T*>(c->pinned + 128);
             // (64-bit words, at most 2^32 characters: the slabs' ISA entries are collected by destination class and stored at the end of the round)
-            const bool collect = sizeof(T) == 8 && n <= (1ull << 32) && isa_narrow_levels<T>(n, kn) > 0 && !kn.isa_stores && room >= SMALL_SORT_MAX;
+            const bool collect = sizeof(T) == 8 && n <= (1ull << 32) && isa_narrow_levels<T>(n, kn) > 0 && room >= SMALL_SORT_MAX &&
+                                 (kn.isa_update == 2 || (kn.isa_update == 0 && n >= (1ull << 31)));
             while (s0 < n) {
                 // furthest tile boundary whose tiles (from the one holding s0) hold at most `room` unresolved positions
                 uint64_t t = s0 / ScanCfg<T>::TILE, acc = 0;

@@ -146,7 +146,9 @@ struct Knobs {
     bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
     bool one_word_always;   // PSACX_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
     unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
-    bool isa_stores;        // PSACX_ISA_STORES: refinement rounds update ISA by one random store per record even where the partition levels apply
+    int isa_update;         // PSACX_ISA_UPDATE=stores | levels: how large refinement rounds update ISA -- one random store per record, or pairs through
+                            // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
+                            // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -162,7 +164,8 @@ inline Knobs read_knobs() {
     e = getenv("PSACX_ONE_WORD_MIN");
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
-    k.isa_stores = getenv("PSACX_ISA_STORES") != nullptr;
+    e = getenv("PSACX_ISA_UPDATE");
+    k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
     return k;
 }
 

@@ -130,6 +130,7 @@ def _tandem_twin(ctx, monkeypatch, cap):
 def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     if not O.have_divsufsort():
         pytest.skip("oracle/_ref/libdivsufsort*.so not built")
+    monkeypatch.setenv("PSACX_ISA_UPDATE", "levels")          # (the default from 2^31 characters on)
     text, sa = _tandem_twin(ctx, monkeypatch, 0)
     assert np.array_equal(sa.local_B[sa.local_SA.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
     SA, LCP = O.reference_sa_lcp_cached("tandem_1024_3", text, bits=64, isa=sa.local_B)
@@ -142,7 +143,7 @@ def test_config_c5_twin_tandem_reduced_memory(ctx, monkeypatch):
     assert np.array_equal(sb.local_SA, SA) and np.array_equal(sb.local_LCP, LCP) and np.array_equal(sb.local_B, sa.local_B)
     # (both runs above take the ISA entries of a round to their places through partition levels, the second collecting them over the
     #  slabs of a round: construct.hpp: IsaLevels) -- the same with one random store per entry
-    monkeypatch.setenv("PSACX_ISA_STORES", "1")
+    monkeypatch.setenv("PSACX_ISA_UPDATE", "stores")
     text3, sc = _tandem_twin(ctx, monkeypatch, 1 << 25)
     assert np.array_equal(sc.local_SA, SA) and np.array_equal(sc.local_LCP, LCP) and np.array_equal(sc.local_B, sa.local_B)
 
