@@ -1916,6 +1916,15 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     T id[ITEMS];
     unsigned heads = 0;
     T run = 0;
+    // One GPU, at most 2^32 characters: the range minima of the new boundaries are not evaluated by the thread that finds them (a
+    // thread's eight records one after the other, a few lanes of the wave busy each time, every query two dependent waits) but put
+    // into a queue of the wave in LDS, four records of every lane at a time, and taken from there one per lane: all lanes busy, a
+    // lane's queries a quarter as many (2^30 characters of repeated reads with mutations: rebucket_refine_kernel 208 -> ... ms).
+    constexpr int RQ_PER = 4, RQ_CAP = WAVE * RQ_PER;
+    __shared__ uint32_t rq_buf[(WITH_LCP && !DIST) ? (BLOCK / WAVE) * RQ_CAP * 3 : 1];
+    const bool rq_queue = WITH_LCP && !DIST && n <= (1ull << 32);
+    const T p2_first = p2;
+    unsigned rq = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
@@ -1935,6 +1944,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             } else if (DIST) {
                 const unsigned long long slot = atomicAdd(q_count, 1ull);
                 q_at[slot] = ps[j]; q_lo[slot] = lo; q_hi[slot] = hi;
+            } else if (rq_queue) {
+                rq |= 1u << j;
             } else {
                 const T m = pyramid_min<T>(pyr, (uint64_t)lo, (uint64_t)hi);
                 pyramid_set<T>(pyr, at, (T)(h + m));
@@ -1942,6 +1953,39 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         }
         p1 = a1[j]; p2 = a2[j];
         if (id[j] > run) run = id[j];
+    }
+    if constexpr (WITH_LCP && !DIST) {
+        if (rq_queue && __ballot(rq != 0)) {
+            uint32_t* const qb = rq_buf + (threadIdx.x / WAVE) * (RQ_CAP * 3);
+            const unsigned lane = lane_id();
+#pragma unroll
+            for (int part = 0; part < ITEMS / RQ_PER; ++part) {
+                unsigned qn = 0;
+#pragma unroll
+                for (int jj = 0; jj < RQ_PER; ++jj) {
+                    const int j = part * RQ_PER + jj;
+                    const bool has = (rq >> j) & 1u;
+                    const uint64_t mo = __ballot(has);
+                    if (has) {
+                        const T pv = j ? a2[j ? j - 1 : 0] : p2_first;
+                        const T lo = pv < a2[j] ? pv : a2[j], hi = pv < a2[j] ? a2[j] : pv;
+                        const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0u));
+                        qb[slot * 3 + 0] = (uint32_t)((uint64_t)ps[j] - bd.off);
+                        qb[slot * 3 + 1] = (uint32_t)((uint64_t)lo - 1);
+                        qb[slot * 3 + 2] = (uint32_t)((uint64_t)hi - 1);
+                    }
+                    qn += (unsigned)__builtin_popcountll(mo);
+                }
+                xrun_order();
+                for (unsigned i = lane; i < qn; i += WAVE) {
+                    const uint64_t at = qb[i * 3 + 0];
+                    const uint64_t lo = (uint64_t)qb[i * 3 + 1] + 1, hi = (uint64_t)qb[i * 3 + 2] + 1;
+                    const T m = pyramid_min<T>(pyr, lo, hi);
+                    pyramid_set<T>(pyr, at, (T)(h + m));
+                }
+                xrun_order();
+            }
+        }
     }
     if (next_head) heads |= 1u << ITEMS;
     if (e0 < cnt && e0 + ITEMS > cnt) {
