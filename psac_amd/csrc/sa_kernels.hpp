@@ -1919,7 +1919,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     // One GPU, at most 2^32 characters: the range minima of the new boundaries are not evaluated by the thread that finds them (a
     // thread's eight records one after the other, a few lanes of the wave busy each time, every query two dependent waits) but put
     // into a queue of the wave in LDS, four records of every lane at a time, and taken from there one per lane: all lanes busy, a
-    // lane's queries a quarter as many (2^30 characters of repeated reads with mutations: rebucket_refine_kernel 208 -> ... ms).
+    // lane's queries a quarter as many (2^30 characters of repeated reads with mutations: rebucket_refine_kernel 246 -> 212 ms).
     constexpr int RQ_PER = 4, RQ_CAP = WAVE * RQ_PER;
     __shared__ uint32_t rq_buf[(WITH_LCP && !DIST) ? (BLOCK / WAVE) * RQ_CAP * 3 : 1];
     const bool rq_queue = WITH_LCP && !DIST && n <= (1ull << 32);
