@@ -561,6 +561,22 @@ inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
             return;
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // three-word records whose payload stays below 2^32 (the suffixes of a text of at most 2^32 characters): 32-bit payload entries
+        // between the passes here too -- 40 instead of 48 bytes per record and pass (the one-stage first round of repetitive texts)
+        if (ko_in && vn == 1) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1, false, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
+                               counter, chunk, (const T*)nullptr, slab_tiles);
+            return;
+        }
+        if (ko_in && vn == 2) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1, false, 2>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
+                               counter, chunk, (const T*)nullptr, slab_tiles);
+            return;
+        }
+    }
     if (ko_in)
         hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                            ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
@@ -749,7 +765,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
 
     // two-word records of 64-bit words whose payload is made up by the first pass (suffix indices < n <= 2^32): the payload
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
-    const bool narrow = three && sizeof(T) == 8 && !in.k2 && ((iota && n <= (1ull << 32)) || v32_in);
+    const bool narrow = three && sizeof(T) == 8 && ((iota && n <= (1ull << 32)) || v32_in);
     if (v32_in && !narrow) return PSACX_EINVAL;
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
@@ -784,7 +800,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        if (narrow) c->stats.scatter_bytes[form] += (2ull * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        if (narrow) c->stats.scatter_bytes[form] += ((in.k2 ? 4ull : 2ull) * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
         else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(BLOCK >= RADIX, "one thread per digit needed");
-    static_assert(VN == 0 || (sizeof(T) == 8 && NOKO), "narrow payloads exist for two-word records of 64-bit words");
+    static_assert(VN == 0 || sizeof(T) == 8, "narrow payloads exist for records of 64-bit words");
     __shared__ ScatterShared<T, TILE, NW> sh;
     // tiles are handed out in start order so that neighbouring runs of a digit are written
     // close in time (they share cache lines); nothing ever waits on another workgroup
