@@ -1346,15 +1346,37 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
 // full window afterwards.  K2rec holds word 2 in RECORD order (see record_suffix).
 // word 2 of the packed window of suffix `sa`, straight from the text (same packing as key_pairs_kernel)
 // word 1 of the packed window of suffix `sa`
+// cnt characters of the text from position q0 on as codes of lc bits each, the first on top (cnt * lc <= 64; zeros beyond the end of the
+// text).  Away from the end the characters are read as 8-byte pieces, four asked for at a time, instead of one dependent byte load
+// after the other (a text with interspersed repeats sends a quarter of its suffixes through gather_prefix_ties_kernel: 42 byte loads
+// per suffix were 179 ms at 2^30 characters).
+template <typename T>
+__device__ __forceinline__ T packed_chars(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab, unsigned lc, uint64_t q0, unsigned cnt) {
+    T w = 0;
+    if (q0 + cnt + 32 <= n_text) {
+        for (unsigned t0 = 0; t0 < cnt; t0 += 32) {
+            uint64_t x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { x[c] = 0; if (t0 + 8u * c < cnt) __builtin_memcpy(&x[c], text + q0 + t0 + 8u * c, 8); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (t0 + 8u * c + i < cnt) w = (T)(w << lc) | (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
+            }
+        }
+        return w;
+    }
+    for (unsigned t = 0; t < cnt; ++t) {
+        const uint64_t q = q0 + t;
+        w = (T)(w << lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
+    }
+    return w;
+}
 template <typename T>
 __device__ __forceinline__ T window_word1(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
                                           const KeyShape& ks, uint64_t sa) {
-    T w1 = 0;
-    for (unsigned t = 0; t < ks.c1; ++t) {
-        const uint64_t q = sa + t;
-        w1 = (T)(w1 << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
-    }
-    return w1;
+    return packed_chars<T>(text, n_text, ctab, ks.lc, sa, ks.c1);
 }
 // word 1 of suffix `sa` when its bits above lo1 are known (have): only the characters that reach below bit lo1 come from the text
 template <typename T>
@@ -1362,23 +1384,14 @@ __device__ __forceinline__ T window_word1_low(const uint8_t* __restrict__ text, 
                                               const KeyShape& ks, uint64_t sa, T have, unsigned lo1) {
     const unsigned nlow = (lo1 + ks.lc - 1) / ks.lc < ks.c1 ? (lo1 + ks.lc - 1) / ks.lc : ks.c1;      // characters with a bit below lo1
     const unsigned lowbits = nlow * ks.lc;
-    T w = 0;
-    for (unsigned t = ks.c1 - nlow; t < ks.c1; ++t) {
-        const uint64_t q = sa + t;
-        w = (T)(w << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
-    }
+    const T w = packed_chars<T>(text, n_text, ctab, ks.lc, sa + (ks.c1 - nlow), nlow);
     if (lowbits >= sizeof(T) * 8) return w;
     return (T)(((have >> lowbits) << lowbits) | w);
 }
 template <typename T>
 __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
                                           const KeyShape& ks, uint64_t sa) {
-    T w2 = 0;
-    for (unsigned t = 0; t < ks.c2; ++t) {
-        const uint64_t q = sa + ks.c1 + t;
-        w2 = (T)(w2 << ks.lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
-    }
-    return w2;
+    return packed_chars<T>(text, n_text, ctab, ks.lc, sa + ks.c1, ks.c2);
 }
 
 // Both words of the packed window of the suffixes q[j] (global positions) out of a rank's text block with its halo
