@@ -644,12 +644,22 @@ __global__ __launch_bounds__(256) void last_head_1w_kernel(const uint64_t* __res
 // one-word records -> word 1 (zeros below the sorted prefix) and the suffixes as words: what the last pass of the prefix sort writes when the
 // records are not read where they lie (the tie stage met a long group and takes its radix path)
 template <int TAG>
-__global__ void onew_widen_kernel(const uint64_t* __restrict__ R, uint64_t n, OneWordView ow, uint64_t* __restrict__ S1, uint64_t* __restrict__ SA) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const uint64_t x = R[e];
-        S1[e] = onew_word1(ow, onew_bucket(ow, e), x);
-        SA[e] = onew_suffix(ow, x);
+__global__ __launch_bounds__(256) void onew_widen_kernel(const uint64_t* __restrict__ R, uint64_t n, OneWordView ow, uint64_t* __restrict__ S1, uint64_t* __restrict__ SA) {
+    __shared__ unsigned long long s_off[257];
+    for (int i = threadIdx.x; i < 257; i += 256) s_off[i] = ow.off[i];
+    __syncthreads();
+    ow.off = s_off;
+    constexpr int ITEMS = 8;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * ITEMS;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS; e0 < n; e0 += stride) {
+        uint64_t x[ITEMS], w1[ITEMS], sa[ITEMS];
+        load_run<uint64_t, ITEMS>(R, e0, n, x, 0ull);
+        OneWordCursor cu;
+        cu.start(ow, e0);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { w1[j] = e0 + j < n ? onew_word1(ow, cu.at(ow, e0 + j), x[j]) : 0ull; sa[j] = onew_suffix(ow, x[j]); }
+        store_run<uint64_t, ITEMS>(S1, e0, n, w1);
+        store_run<uint64_t, ITEMS>(SA, e0, n, sa);
     }
 }
 
@@ -1455,7 +1465,8 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
     }
     __syncthreads();
     // pass 2: one thread per group, all loads of a step issued together
-    const unsigned ng = n_leaders;
+    // (a long group met by anybody sends ALL ties through the caller's radix path: what this kernel would still order is thrown away)
+    const unsigned ng = __hip_atomic_load(big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : n_leaders;
     for (unsigned g = threadIdx.x; g < ng; g += BLOCK) {
         const uint64_t e = t0 + leaders[g];
         T k1[G + 1], sa[G];
@@ -1546,7 +1557,8 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
     __syncthreads();
     // pass 2: eight lanes per group, one member each -- the members' windows come from the text side by side, a member's place in its group
     // is the number of members that sort before it (the lanes of a group ask each other), and every lane writes its own member there
-    const unsigned ng = n_leaders;
+    // (a long group met by anybody sends ALL ties through the caller's radix path: what this kernel would still order is thrown away)
+    const unsigned ng = __hip_atomic_load(big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : n_leaders;
     const T smask = (1ull << ow.sfield) - 1;
     const unsigned lane = lane_id(), m = lane & (G - 1), seg0 = lane & ~(unsigned)(G - 1);
     static_assert(G == 8, "eight lanes per group");
