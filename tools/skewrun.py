@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Non-uniform inputs at scale: tools/skewrun.py <log2 n> <bits>.  Builds (a) a low-entropy text (geometric
-symbol frequencies over 20 symbols), (b) a text of repeated reads with mutations (long shared prefixes),
+symbol frequencies over 20 symbols), (b) a text of repeated reads with mutations (long shared prefixes), (c) random DNA with
+40 % interspersed repeats (1000 families of 300 bp, 5 % divergence),
 constructs SA+ISA+LCP on the GPU, verifies on the device, prints timings."""
 import json
 import os
@@ -32,8 +33,27 @@ def mutated_reads(n):
     return t
 
 
+def interspersed_repeats(n, frac=0.4):
+    """random DNA of which `frac` is covered by copies of 1000 repeat families of 300 bp, 5 % mutations per copy (a genome's
+    interspersed repeats: a quarter of the suffixes tie on the sorted prefix, in groups of up to 10^5)"""
+    r = np.random.RandomState(11)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    t = acgt[r.randint(0, 4, size=n)].copy()
+    fam = acgt[r.randint(0, 4, size=(1000, 300))]
+    copies = int(n * frac / 300)
+    pos = r.randint(0, max(1, n - 300), size=copies)
+    which = r.randint(0, 1000, size=copies)
+    for a in range(0, copies, 1 << 16):
+        blk = fam[which[a:a + (1 << 16)]].copy()
+        mut = r.rand(*blk.shape) < 0.05
+        blk[mut] = acgt[r.randint(0, 4, size=int(mut.sum()))]
+        idx = pos[a:a + (1 << 16), None] + np.arange(300)[None, :]
+        t[idx.ravel()] = blk.ravel()
+    return t
+
+
 ctx = psac_amd.Context(0)
-for name, gen in (("geometric20", geometric_text), ("mutated_repeats", mutated_reads)):
+for name, gen in (("geometric20", geometric_text), ("mutated_repeats", mutated_reads), ("interspersed_repeats_40", interspersed_repeats)):
     text = gen(n)
     d_text = ctx.alloc(n); ctx.h2d(d_text, text)
     d_sa, d_isa, d_lcp = ctx.alloc(n * w), ctx.alloc(n * w), ctx.alloc(n * w)
