@@ -1416,9 +1416,7 @@ __global__ __launch_bounds__(BLOCK) void window_at_kernel(const uint8_t* __restr
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
         const uint64_t i = (uint64_t)q[j] - off;
-        T w1 = 0;
-        for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << ks.lc) | (T)(i + t < text_len ? ctab[text[i + t]] : (uint16_t)0);
-        W1[j] = w1;
+        W1[j] = window_word1<T>(text, text_len, ctab, ks, i);
         W2[j] = window_word2<T>(text, text_len, ctab, ks, i);
     }
 }
