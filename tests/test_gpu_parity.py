@@ -741,7 +741,13 @@ def test_one_word_form_of_the_prefix_sort(ctx, monkeypatch):
     for text, kw in cases:
         got, ref = same_as_oracle(ctx, text, bits=64, **kw)
         assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
-    # (texts whose sampled prefixes repeat -- the last two above -- keep the two-array passes: prefix_dup_probe_kernel; forced here)
+    # (texts whose sampled prefixes nearly all repeat -- `rep` and the single symbol above -- take one sort over both words instead:
+    #  prefix_dup_probe_kernel, PSACX_RETRY_1STAGE; a text of which a third repeats keeps two stages in two-array passes, PSACX_RETRY_1W)
+    third = inputs.dna((1 << 22) + 9, 31)
+    third[: (1 << 22) // 3] = np.tile(inputs.dna(1 << 11, 33), (1 << 22) // 3 // (1 << 11) + 1)[: (1 << 22) // 3]
+    got, ref = same_as_oracle(ctx, third, bits=64)
+    assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    # ... and the one-word form forced on the repetitive ones
     monkeypatch.setenv("PSACX_ONE_WORD_ALWAYS", "1")
     same_as_oracle(ctx, rep, bits=64)
     same_as_oracle(ctx, np.full((1 << 21) + 3, 65, np.uint8), bits=64)
