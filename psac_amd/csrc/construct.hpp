@@ -176,7 +176,7 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
         if (payload)
             hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
-                               payload, out_id, out_payload);
+                               payload, out_id, out_payload, (const uint64_t*)w.d_nunf, ord_out);
         else
             hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
@@ -650,17 +650,21 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             {
                 ProfScope ps(c, TC_COMPACT);
                 hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
-                                   c->stream, S1, n, (T)0, (T)0, w.d_nact, lo1);
+                                   c->stream, S1, n, (T)0, (T)0, w.d_nact, lo1, w.d_nunf);
                 PSACX_HIP(c, hipGetLastError());
-                PSACX_HIP(c, hipMemsetAsync(w.d_nunf, 0, ntiles * sizeof(uint64_t), c->stream));
             }
             // two record sets for the ties out of buffers that are idle until the rebucket step; the
             // compaction already fills word 1 and the suffix of set a
             SortBufs<T> a, b, s2;
             if (w.diet) { a = w.ry; b.k1 = w.bsa; b.k2 = w.x.v; b.v = free_k1; }
             else { a.k1 = free_k1; a.k2 = first_alt.v; a.v = first_in.v; b.k1 = w.bsa; b.k2 = w.pos_b; b.v = d_isa; }
-            uint64_t ties = 0, unused = 0;
-            PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &unused, w.cap_active, lo1, d_sa, a.k1, a.v));
+            // (the tie groups counted from 0 beside the list, in the idle second key array of set b: the sort below takes the group's
+            //  number in place of the sorted prefix)
+            uint32_t* const tie_ord = reinterpret_cast<uint32_t*>(b.k2);
+            uint64_t ties = 0, tie_groups = 0;
+            PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &tie_groups, w.cap_active, lo1, d_sa, a.k1, a.v, 0, false, tie_ord));
+            const unsigned ord_bits = bits_for(tie_groups > 1 ? tie_groups - 1 : 1);
+            const bool by_ord = lo1 > 0 && ties > 0 && tie_groups > 0 && tie_groups < (1ull << 32) && lo1 + ord_bits + RADIX_BITS <= bits_w1;
             if (ties > w.cap_active) {
                 // repetitive text in the reduced-memory layout: there is no room to sort all ties at once, so the
                 // first round is run again as one sort over both words (the keys were sorted in place: rebuilt)
@@ -672,18 +676,18 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                     ProfScope ps(c, TC_GATHER);
                     const int gg = grid_for(c, ties, 256, 16);
                     hipLaunchKernelGGL((gather_prefix_ties_kernel<T, 256>), dim3(gg), dim3(256), 0, c->stream, ties, a.k1, a.v,
-                                       d_text, n, tab, ks, a.k2, w.sc.d_partials, packed1);
+                                       d_text, n, tab, ks, a.k2, w.sc.d_partials, packed1, by_ord ? (const uint32_t*)tie_ord : (const uint32_t*)nullptr, lo1);
                     PSACX_HIP(c, hipGetLastError());
                     PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
                 }
                 psacx_round r1;
                 std::memset(&r1, 0, sizeof(r1));
-                PSACX_TRY(pair_sort<T>(c, w.sc, a, b, ties, /*iota=*/false, bits_w1, bits_w2, nullptr, &s2, &r1, 0, 0,
+                PSACX_TRY(pair_sort<T>(c, w.sc, a, b, ties, /*iota=*/false, by_ord ? lo1 + ord_bits : bits_w1, bits_w2, nullptr, &s2, &r1, 0, 0,
                                        /*summary_ready=*/true));
                 r0->sort_passes += r1.sort_passes; r0->sort_passes_skipped += r1.sort_passes_skipped;
                 ProfScope ps(c, TC_GATHER);
                 hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, ties, 256, 16)), dim3(256), 0, c->stream,
-                                   w.pos_a, ties, lo1 ? s2.k1 : (const T*)nullptr, s2.k2, s2.v, S1, S2, d_sa);
+                                   w.pos_a, ties, lo1 ? s2.k1 : (const T*)nullptr, s2.k2, s2.v, S1, S2, d_sa, by_ord ? lo1 : 0u);
                 PSACX_HIP(c, hipGetLastError());
             }
         }

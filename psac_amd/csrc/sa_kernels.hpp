@@ -1288,7 +1288,8 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool in = (e0 + j) < cnt;
-        if (in && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) { act |= 1u << j; ++nact; if (v[j + 1] != v[j]) uh |= 1u << j; }
+        // (the very first entry opens its bucket whatever stands before it: ids of a prefix sort may be 0, like the "none" before them)
+        if (in && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) { act |= 1u << j; ++nact; if (v[j + 1] != v[j] || (e0 + j == 0 && prev_id == 0)) uh |= 1u << j; }
     }
     unsigned agg;
     static_assert(TILE < (1 << 16), "active entries and bucket heads of a tile scanned in one word");
@@ -1345,7 +1346,7 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
     unsigned nact = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
-        if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) nact += 1u + ((v[j + 1] != v[j]) ? (1u << 16) : 0u);
+        if ((e0 + j) < cnt && (v[j + 1] == v[j] || v[j + 1] == v[j + 2])) nact += 1u + ((v[j + 1] != v[j] || (e0 + j == 0 && prev_id == 0)) ? (1u << 16) : 0u);
     const unsigned t = block_reduce<BLOCK, unsigned>(nact, OpSum(), red_tmp);
     if (threadIdx.x == 0) { n_active[blockIdx.x] = t & 0xFFFFu; if (n_unf) n_unf[blockIdx.x] = t >> 16; }
 }
@@ -1625,16 +1626,25 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt, T* __restrict__ K1, const T* __restrict__ V,
                                           const uint8_t* __restrict__ text, uint64_t n_text, CodeTable tab, KeyShape ks,
-                                          T* __restrict__ K2, unsigned long long* __restrict__ summary, bool packed = false) {
+                                          T* __restrict__ K2, unsigned long long* __restrict__ summary, bool packed = false,
+                                          const uint32_t* __restrict__ ord = nullptr, unsigned lo1 = 0) {
+    // ord (with lo1): the tie groups counted from 0 in list order (compact_active_kernel).  The records are in the order of their
+    // sorted prefixes already, so the sort that follows only needs the group's number above the bits of word 1 below the prefix:
+    // K1 = ord << lo1 | low bits (fewer digits than the 64 bits of word 1; scatter_prefix_ties_kernel puts the low bits back under
+    // the prefix that stands in S1).
     __shared__ uint16_t ctab[256];
     for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const T lowmask = lo1 ? (T)(((T)1 << lo1) - 1) : (T)0;
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
         T k1 = K1[j];
         const T k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
-        if (packed) { k1 = window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]); K1[j] = k1; }      // (its low bits carried the payload)
+        if (packed) k1 = ord ? window_word1_low<T>(text, n_text, ctab, ks, (uint64_t)V[j], k1, lo1)       // (its low bits are not in the record)
+                             : window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        if (ord) k1 = (T)(((T)ord[j] << lo1) | (k1 & lowmask));
+        if (packed || ord) K1[j] = k1;
         K2[j] = k2;
         o1 |= k1; a1 &= k1; o2 |= k2; a2 &= k2;
     }
@@ -1646,11 +1656,14 @@ __global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt,
 template <typename T>
 __global__ void scatter_prefix_ties_kernel(const T* __restrict__ pos, uint64_t cnt, const T* __restrict__ K1s,
                                            const T* __restrict__ K2s, const T* __restrict__ Vs, T* __restrict__ S1,
-                                           T* __restrict__ S2, T* __restrict__ SA) {
+                                           T* __restrict__ S2, T* __restrict__ SA, unsigned merge_lo = 0) {
+    // merge_lo: only the low merge_lo bits of K1s are word 1's (above them the sort key held the group's number): they go under the
+    // prefix S1[p] holds -- a record comes back into its own group, whose prefix is the same at every place of it
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const T lowmask = merge_lo ? (T)(((T)1 << merge_lo) - 1) : ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
         const uint64_t p = pos[j];
-        if (K1s) S1[p] = K1s[j];
+        if (K1s) S1[p] = merge_lo ? (T)((S1[p] & ~lowmask) | (K1s[j] & lowmask)) : K1s[j];
         S2[p] = K2s[j]; SA[p] = Vs[j];
     }
 }
