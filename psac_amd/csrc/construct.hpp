@@ -23,6 +23,7 @@ template <typename T> struct ScanCfg {
 };
 constexpr int SCAN_TILE_MIN = 512 * SCAN_ITEMS;      // sizes per-tile arrays where the word type is not known
 
+constexpr unsigned SCAN_CHUNKS = 4096, SCAN_CHUNK = 1024 * 4;      // (chunks of 4096 tiles; up to 2^24 tiles)
 template <typename T> struct Work {
     T *bsa;
     SortBufs<T> x, y;                  // record sets of the first sort (y may alias the output buffers)
@@ -37,6 +38,7 @@ template <typename T> struct Work {
     uint64_t* d_nact;                  // per scan tile: active positions (then exclusive sum-scan)
     uint64_t* d_nunf;                  // per scan tile: buckets with > 1 member
     uint64_t* d_totals;                // [0] active, [1] unfinished buckets
+    uint64_t* d_chunks;                // 2 x SCAN_CHUNKS chunk totals of the long tile scans
     unsigned* d_cursors;               // fill cursors of the destination buckets (ISA inversion)
     size_t n_cursors;
     SortScratch sc;
@@ -81,6 +83,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.d_nact = a.take<uint64_t>(nt);
     w.d_nunf = a.take<uint64_t>(nt);
     w.d_totals = a.take<uint64_t>(4);
+    w.d_chunks = a.take<uint64_t>(2 * SCAN_CHUNKS);
     w.n_cursors = (size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P;
     w.d_cursors = a.take<unsigned>(w.n_cursors);
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
@@ -129,6 +132,20 @@ inline uint32_t choose_k(uint32_t word_bits, uint32_t l, uint64_t n, uint32_t k)
     return k;
 }
 
+// exclusive max-scan of the per-tile carries (in chunks when there are many tiles: sa_kernels.hpp: chunk_scan_kernel)
+template <typename T>
+int scan_carries(psacx_ctx* c, Work<T>& w, uint64_t ntiles) {
+    const uint64_t nch = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (ntiles >= 8 * SCAN_CHUNK && nch <= SCAN_CHUNKS) {
+        hipLaunchKernelGGL((chunk_scan_kernel<1024, OpMax>), dim3((unsigned)nch, 1), dim3(1024), 0, c->stream, w.d_carry, w.d_carry, ntiles, OpMax(), (uint64_t)0, w.d_chunks, SCAN_CHUNKS);
+        hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_chunks, nch, OpMax(), (uint64_t)0, (uint64_t*)nullptr);
+        hipLaunchKernelGGL((chunk_add_kernel<1024, OpMax>), dim3((unsigned)nch, 1), dim3(1024), 0, c->stream, w.d_carry, w.d_carry, ntiles, OpMax(), (const uint64_t*)w.d_chunks, SCAN_CHUNKS);
+    } else
+        hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(), (uint64_t)0, (uint64_t*)nullptr);
+    PSACX_HIP(c, hipGetLastError());
+    return PSACX_OK;
+}
+
 // per-tile carries of the prefix-max: last head of every tile, then an exclusive max-scan
 template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
@@ -137,9 +154,7 @@ int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos
     hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)(REFINE ? ntiles : (ntiles + 3) / 4)), dim3(256), 0, c->stream,
                        a1, a2, pos, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(),
-                       (uint64_t)0, (uint64_t*)nullptr);
-    PSACX_HIP(c, hipGetLastError());
+    PSACX_TRY(scan_carries<T>(c, w, ntiles));
     return PSACX_OK;
 }
 
@@ -156,8 +171,14 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     {
         ProfScope ps(c, TC_COMPACT);
         // the kernel stores the two totals into the pinned host words itself when the device can address them
-        hipLaunchKernelGGL((tile_scan2_kernel<1024>), dim3(2), dim3(1024), 0, c->stream, w.d_nact, w.d_nunf, ntiles, w.d_totals,
-                           c->pinned_dev ? reinterpret_cast<uint64_t*>(c->pinned_dev) : (uint64_t*)nullptr);
+        const uint64_t nch = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        uint64_t* const host_tot = c->pinned_dev ? reinterpret_cast<uint64_t*>(c->pinned_dev) : (uint64_t*)nullptr;
+        if (ntiles >= 8 * SCAN_CHUNK && nch <= SCAN_CHUNKS) {
+            hipLaunchKernelGGL((chunk_scan_kernel<1024, OpSum>), dim3((unsigned)nch, 2), dim3(1024), 0, c->stream, w.d_nact, w.d_nunf, ntiles, OpSum(), (uint64_t)0, w.d_chunks, SCAN_CHUNKS);
+            hipLaunchKernelGGL((tile_scan2_kernel<1024>), dim3(2), dim3(1024), 0, c->stream, w.d_chunks, w.d_chunks + SCAN_CHUNKS, nch, w.d_totals, host_tot);
+            hipLaunchKernelGGL((chunk_add_kernel<1024, OpSum>), dim3((unsigned)nch, 2), dim3(1024), 0, c->stream, w.d_nact, w.d_nunf, ntiles, OpSum(), (const uint64_t*)w.d_chunks, SCAN_CHUNKS);
+        } else
+        hipLaunchKernelGGL((tile_scan2_kernel<1024>), dim3(2), dim3(1024), 0, c->stream, w.d_nact, w.d_nunf, ntiles, w.d_totals, host_tot);
         PSACX_HIP(c, hipGetLastError());
     }
     if (!c->pinned_dev) PSACX_HIP(c, hipMemcpyAsync(h_cnt, w.d_totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -743,7 +764,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                    reinterpret_cast<const uint64_t*>(onew_w1), reinterpret_cast<const uint64_t*>(sorted.k2), n, (unsigned)ScanCfg<T>::TILE, ntiles,
                                    w.d_carry, ks, onew_view);
                 PSACX_HIP(c, hipGetLastError());
-                hipLaunchKernelGGL((tile_scan_kernel<1024, OpMax>), dim3(1), dim3(1024), 0, c->stream, w.d_carry, ntiles, OpMax(), (uint64_t)0, (uint64_t*)nullptr);
+                PSACX_TRY(scan_carries<T>(c, w, ntiles));
                 PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
                 lazy_ids = n >= (1ull << 22);
                 hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB, true, true>), dim3((unsigned)ntiles),

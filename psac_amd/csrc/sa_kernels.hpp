@@ -687,6 +687,37 @@ __global__ __launch_bounds__(BLOCK) void tile_scan_kernel(uint64_t* __restrict__
     if (threadIdx.x == 0 && total) total[0] = carry;
 }
 
+// Long arrays (2^20 tiles at 2^32 records: one workgroup took 0.75 ms): every workgroup scans a chunk of BLOCK * 4 entries in place and
+// leaves the chunk's total (blockIdx.y picks the array: a0 / a1, totals at tot and tot + tot_stride), one workgroup scans the totals
+// (tile_scan_kernel / tile_scan2_kernel on them), chunk_add_kernel puts every chunk's offset onto its entries.
+template <int BLOCK, typename Op>
+__global__ __launch_bounds__(BLOCK) void chunk_scan_kernel(uint64_t* __restrict__ a0, uint64_t* __restrict__ a1, uint64_t len, Op op, uint64_t identity,
+                                                           uint64_t* __restrict__ tot, unsigned tot_stride) {
+    constexpr int PER = 4;
+    __shared__ uint64_t tmp[BLOCK / WAVE + 1];
+    uint64_t* const a = blockIdx.y ? a1 : a0;
+    const uint64_t e0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * PER;
+    uint64_t v[PER];
+    uint64_t run = identity;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { v[j] = (e0 + j < len) ? a[e0 + j] : identity; run = op(run, v[j]); }
+    uint64_t total;
+    uint64_t ex = block_scan_exclusive<BLOCK, uint64_t>(run, op, identity, tmp, &total);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { if (e0 + j < len) a[e0 + j] = ex; ex = op(ex, v[j]); }
+    if (threadIdx.x == 0) tot[(size_t)blockIdx.y * tot_stride + blockIdx.x] = total;
+}
+template <int BLOCK, typename Op>
+__global__ __launch_bounds__(BLOCK) void chunk_add_kernel(uint64_t* __restrict__ a0, uint64_t* __restrict__ a1, uint64_t len, Op op,
+                                                          const uint64_t* __restrict__ off, unsigned off_stride) {
+    constexpr int PER = 4;
+    uint64_t* const a = blockIdx.y ? a1 : a0;
+    const uint64_t o = off[(size_t)blockIdx.y * off_stride + blockIdx.x];
+    const uint64_t e0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * PER;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (e0 + j < len) a[e0 + j] = op(o, a[e0 + j]);
+}
+
 // The two sum scans that follow a rebucket step (active positions, buckets with more than one member) in one launch:
 // block 0 scans a0, block 1 scans a1.  totals[b] receives block b's sum; host_totals (optional) is the same pair in
 // host-pinned memory the device can write, so that the host reads the counters after a stream synchronisation without
