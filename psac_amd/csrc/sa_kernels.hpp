@@ -628,8 +628,9 @@ __global__ __launch_bounds__(256) void last_head_1w_kernel(const uint64_t* __res
             if (e == 0) head = true;
             else {
                 const uint64_t x = R[e], y = R[e - 1];
-                const unsigned bx = onew_bucket(ow, e), by = onew_bucket(ow, e - 1);
-                head = onew_lead(ow, bx, x) != onew_lead(ow, by, y);
+                // (the buckets are looked up only when the rest of the prefix agrees: eight dependent loads each)
+                head = (x >> ow.sfield) != (y >> ow.sfield);
+                if (!head) head = onew_bucket(ow, e) != onew_bucket(ow, e - 1);
                 if (!head) head = W1[e] != W1[e - 1] || S2[e] != S2[e - 1];
                 if (!head) head = (cnt - onew_suffix(ow, x) < two_k) || (cnt - onew_suffix(ow, y) < two_k);
             }
