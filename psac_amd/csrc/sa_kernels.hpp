@@ -313,12 +313,41 @@ __global__ __launch_bounds__(BLOCK) void top_digit_hist_kernel(const uint8_t* __
             dig[j] = ((t >> down) << up) & 255u;
         }
     }
+    // (plain LDS atomics: the digits of a text that reaches this kernel vary -- a text whose prefixes repeat was turned away by the probe --
+    //  and wave_hist_add's two ballots per record were a fifth of it: keys phase 24.5 -> 23.8 ms at 2^32)
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) wave_hist_add(my, dig[j], rec0 + j < n);
+    for (int j = 0; j < ITEMS; ++j) if (rec0 + j < n) atomicAdd(&my[dig[j]], 1u);
     __syncthreads();
     for (int d = threadIdx.x; d < RADIX; d += BLOCK) tile_hist[(uint64_t)blockIdx.x * RADIX + d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
+// cnt characters of the text from position q0 on as codes of lc bits each, the first on top (cnt * lc <= 64; zeros beyond the end of the
+// text).  Away from the end the characters are read as 8-byte pieces, four asked for at a time, instead of one dependent byte load
+// after the other (a text with interspersed repeats sends a quarter of its suffixes through gather_prefix_ties_kernel: 42 byte loads
+// per suffix were 179 ms at 2^30 characters).
+template <typename T>
+__device__ __forceinline__ T packed_chars(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab, unsigned lc, uint64_t q0, unsigned cnt) {
+    T w = 0;
+    if (q0 + cnt + 32 <= n_text) {
+        for (unsigned t0 = 0; t0 < cnt; t0 += 32) {
+            uint64_t x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { x[c] = 0; if (t0 + 8u * c < cnt) __builtin_memcpy(&x[c], text + q0 + t0 + 8u * c, 8); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (t0 + 8u * c + i < cnt) w = (T)(w << lc) | (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
+            }
+        }
+        return w;
+    }
+    for (unsigned t = 0; t < cnt; ++t) {
+        const uint64_t q = q0 + t;
+        w = (T)(w << lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
+    }
+    return w;
+}
 // prefix_dup_probe_kernel: does the text repeat itself massively?  Every `stride`-th suffix puts the sorted prefix of its word 1
 // into an open-addressing table (zeroed, `slots` a power of two); dups counts the samples that met their own prefix there.
 // Random text: none.  A tandem repeat: nearly all.  (The one-word prefix sort drops the bits of word 1 below the prefix; when
@@ -329,8 +358,7 @@ __global__ void prefix_dup_probe_kernel(const uint8_t* __restrict__ text, uint64
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= samples) return;
     const uint64_t i = s * stride;
-    T w1 = 0;
-    for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << ks.lc) | (T)((i + t < n_text) ? tab.c[text[i + t]] : 0);
+    const T w1 = packed_chars<T>(text, n_text, tab.c, ks.lc, i, ks.c1);
     const unsigned long long key = ((unsigned long long)w1 >> lo1) + 1ull;
     uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
     for (int probe = 0; probe < 16; ++probe, ++h) {
@@ -1389,33 +1417,6 @@ __global__ __launch_bounds__(BLOCK) void count_active_kernel(const T* __restrict
 // full window afterwards.  K2rec holds word 2 in RECORD order (see record_suffix).
 // word 2 of the packed window of suffix `sa`, straight from the text (same packing as key_pairs_kernel)
 // word 1 of the packed window of suffix `sa`
-// cnt characters of the text from position q0 on as codes of lc bits each, the first on top (cnt * lc <= 64; zeros beyond the end of the
-// text).  Away from the end the characters are read as 8-byte pieces, four asked for at a time, instead of one dependent byte load
-// after the other (a text with interspersed repeats sends a quarter of its suffixes through gather_prefix_ties_kernel: 42 byte loads
-// per suffix were 179 ms at 2^30 characters).
-template <typename T>
-__device__ __forceinline__ T packed_chars(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab, unsigned lc, uint64_t q0, unsigned cnt) {
-    T w = 0;
-    if (q0 + cnt + 32 <= n_text) {
-        for (unsigned t0 = 0; t0 < cnt; t0 += 32) {
-            uint64_t x[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { x[c] = 0; if (t0 + 8u * c < cnt) __builtin_memcpy(&x[c], text + q0 + t0 + 8u * c, 8); }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (t0 + 8u * c + i < cnt) w = (T)(w << lc) | (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
-            }
-        }
-        return w;
-    }
-    for (unsigned t = 0; t < cnt; ++t) {
-        const uint64_t q = q0 + t;
-        w = (T)(w << lc) | (T)(q < n_text ? ctab[text[q]] : (uint16_t)0);
-    }
-    return w;
-}
 template <typename T>
 __device__ __forceinline__ T window_word1(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab,
                                           const KeyShape& ks, uint64_t sa) {
