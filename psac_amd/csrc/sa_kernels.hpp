@@ -1438,6 +1438,39 @@ __device__ __forceinline__ T window_word2(const uint8_t* __restrict__ text, uint
     return packed_chars<T>(text, n_text, ctab, ks.lc, sa + ks.c1, ks.c2);
 }
 
+// The characters of word 1 that reach below bit lo1 and all of word 2 -- one stretch of the text -- read together (at most 32
+// characters: four 8-byte pieces in flight; longer stretches take the two words one after the other).  k1: `have` with its low
+// characters filled in, k2: word 2.
+template <typename T>
+__device__ __forceinline__ void window_low_and_word2(const uint8_t* __restrict__ text, uint64_t n_text, const uint16_t* ctab, const KeyShape& ks,
+                                                     uint64_t sa, T have, unsigned lo1, T& k1, T& k2) {
+    const unsigned nlow = (lo1 + ks.lc - 1) / ks.lc < ks.c1 ? (lo1 + ks.lc - 1) / ks.lc : ks.c1;
+    const unsigned lowbits = nlow * ks.lc;
+    const uint64_t q0 = sa + ks.c1 - nlow;
+    const unsigned L = nlow + ks.c2;
+    if (L <= 32 && q0 + 32 <= n_text) {
+        uint64_t x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { x[c] = 0; if ((unsigned)(8 * c) < L) __builtin_memcpy(&x[c], text + q0 + 8 * c, 8); }
+        T lo = 0, w2 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned at = 8 * c + i;
+                const T code = (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
+                if (at < nlow) lo = (T)(lo << ks.lc) | code;
+                else if (at < L) w2 = (T)(w2 << ks.lc) | code;
+            }
+        }
+        k1 = lowbits >= sizeof(T) * 8 ? lo : (T)(((have >> lowbits) << lowbits) | lo);
+        k2 = w2;
+    } else {
+        k2 = window_word2<T>(text, n_text, ctab, ks, sa);
+        k1 = window_word1_low<T>(text, n_text, ctab, ks, sa, have, lo1);
+    }
+}
+
 // Both words of the packed window of the suffixes q[j] (global positions) out of a rank's text block with its halo
 // (text[0] = position off, text_len = block + 2k characters, zero beyond the end of the whole text): what the owner of a
 // position answers when another rank asks for the window of a suffix that ties on the leading bits (multi.hpp).
@@ -1594,8 +1627,6 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
     const T smask = (1ull << ow.sfield) - 1;
     const unsigned lane = lane_id(), m = lane & (G - 1), seg0 = lane & ~(unsigned)(G - 1);
     static_assert(G == 8, "eight lanes per group");
-    const unsigned nlow = (ow.lo1 + ks.lc - 1) / ks.lc < ks.c1 ? (ow.lo1 + ks.lc - 1) / ks.lc : ks.c1;      // characters of word 1 with a bit below lo1
-    const unsigned lowbits = nlow * ks.lc;
     for (unsigned g0 = 0; g0 < ng; g0 += BLOCK / G) {            // (the same trips for every lane of the workgroup: the lane moves below need whole waves)
         const unsigned g = g0 + threadIdx.x / G;
         const bool live = g < ng;
@@ -1614,31 +1645,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
         const T sa = rec & smask;
         T k1 = ~(T)0, k2 = ~(T)0;
         if (member) {
-            const T have = onew_word1(ow, b, rec);
-            const uint64_t q0 = sa + ks.c1 - nlow;
-            const unsigned L = nlow + ks.c2;                      // characters [q0, q0 + L): the tail of word 1, then word 2
-            if (L <= 32 && q0 + 32 <= n_text) {
-                // four 8-byte pieces asked for together instead of L single characters one after the other
-                uint64_t x[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { x[c] = 0; if ((unsigned)(8 * c) < L) __builtin_memcpy(&x[c], text + q0 + 8 * c, 8); }
-                T lo = 0, w2 = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const unsigned at = 8 * c + i;
-                        const T code = (T)ctab[(unsigned)(x[c] >> (8 * i)) & 255u];
-                        if (at < nlow) lo = (T)(lo << ks.lc) | code;
-                        else if (at < L) w2 = (T)(w2 << ks.lc) | code;
-                    }
-                }
-                k1 = lowbits >= 64 ? lo : (T)(((have >> lowbits) << lowbits) | lo);
-                k2 = w2;
-            } else {
-                k2 = window_word2<T>(text, n_text, ctab, ks, sa);
-                k1 = window_word1_low<T>(text, n_text, ctab, ks, sa, have, ow.lo1);
-            }
+            window_low_and_word2<T>(text, n_text, ctab, ks, sa, (T)onew_word1(ow, b, rec), ow.lo1, k1, k2);
         }
         unsigned rank = 0;
 #pragma unroll
@@ -1672,10 +1679,12 @@ __global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt,
     const T lowmask = lo1 ? (T)(((T)1 << lo1) - 1) : (T)0;
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        T k1 = K1[j];
-        const T k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
-        if (packed) k1 = ord ? window_word1_low<T>(text, n_text, ctab, ks, (uint64_t)V[j], k1, lo1)       // (its low bits are not in the record)
-                             : window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        T k1 = K1[j], k2;
+        if (packed && ord) window_low_and_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j], k1, lo1, k1, k2);       // (its low bits are not in the record)
+        else {
+            k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+            if (packed) k1 = window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+        }
         if (ord) k1 = (T)(((T)ord[j] << lo1) | (k1 & lowmask));
         if (packed || ord) K1[j] = k1;
         K2[j] = k2;
