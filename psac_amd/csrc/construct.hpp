@@ -163,8 +163,9 @@ template <typename T>
 int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_t cnt, T* pos_out,
                 uint64_t* active, uint64_t* unf_buckets, uint64_t capacity, unsigned shift = 0,
                 const T* payload = nullptr, T* out_id = nullptr, T* out_payload = nullptr, uint64_t pos_off = 0, bool fill_lazy_ids = false,
-                uint32_t* ord_out = nullptr) {
+                uint32_t* ord_out = nullptr, bool* payload32 = nullptr) {
     // ord_out: the list entries' bucket numbers counted from 0 (needs the per-tile counts of unfinished buckets in w.d_nunf)
+    // payload32 (in: allowed; out: done): the emitted payloads as 32-bit entries when the list is long enough for the three-kernel sort
     // pos_off: SA position of ids[0] when pos_in is null (a slab of the reduced-memory layout)
     uint64_t* h_cnt = reinterpret_cast<uint64_t*>(c->pinned);   // [2]
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -194,16 +195,19 @@ int run_compact(psacx_ctx* c, Work<T>& w, const T* ids, const T* pos_in, uint64_
     }
     if (*active > 0 && *active <= capacity) {
         ProfScope ps(c, TC_COMPACT);
+        const bool p32 = payload32 && *payload32 && sizeof(T) == 8 && *active >= SMALL_SORT_MAX;
+        if (payload32) *payload32 = p32;
         if (payload)
             hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
-                               payload, out_id, out_payload, (const uint64_t*)w.d_nunf, ord_out);
+                               payload, out_id, out_payload, (const uint64_t*)w.d_nunf, ord_out, p32 ? 1 : 0);
         else
             hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, ids, pos_in, cnt, pos_out, w.d_nact, pos_off, (T)0, (T)0, shift,
                                (const T*)nullptr, (T*)nullptr, (T*)nullptr, (const uint64_t*)w.d_nunf, ord_out);
         PSACX_HIP(c, hipGetLastError());
     }
+    else if (payload32) *payload32 = false;
     return PSACX_OK;
 }
 
@@ -683,7 +687,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             //  number in place of the sorted prefix)
             uint32_t* const tie_ord = reinterpret_cast<uint32_t*>(b.k2);
             uint64_t ties = 0, tie_groups = 0;
-            PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &tie_groups, w.cap_active, lo1, d_sa, a.k1, a.v, 0, false, tie_ord));
+            bool tie_v32 = sizeof(T) == 8 && n <= (1ull << 32);         // (the suffixes of the ties as 32-bit entries through the sort)
+            PSACX_TRY(run_compact<T>(c, w, S1, nullptr, n, w.pos_a, &ties, &tie_groups, w.cap_active, lo1, d_sa, a.k1, a.v, 0, false, tie_ord, &tie_v32));
             const unsigned ord_bits = bits_for(tie_groups > 1 ? tie_groups - 1 : 1);
             const bool by_ord = lo1 > 0 && ties > 0 && tie_groups > 0 && tie_groups < (1ull << 32) && lo1 + ord_bits + RADIX_BITS <= bits_w1;
             if (ties > w.cap_active) {
@@ -697,14 +702,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                     ProfScope ps(c, TC_GATHER);
                     const int gg = grid_for(c, ties, 256, 16);
                     hipLaunchKernelGGL((gather_prefix_ties_kernel<T, 256>), dim3(gg), dim3(256), 0, c->stream, ties, a.k1, a.v,
-                                       d_text, n, tab, ks, a.k2, w.sc.d_partials, packed1, by_ord ? (const uint32_t*)tie_ord : (const uint32_t*)nullptr, lo1);
+                                       d_text, n, tab, ks, a.k2, w.sc.d_partials, packed1, by_ord ? (const uint32_t*)tie_ord : (const uint32_t*)nullptr, lo1, tie_v32 ? 1 : 0);
                     PSACX_HIP(c, hipGetLastError());
                     PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
                 }
                 psacx_round r1;
                 std::memset(&r1, 0, sizeof(r1));
                 PSACX_TRY(pair_sort<T>(c, w.sc, a, b, ties, /*iota=*/false, by_ord ? lo1 + ord_bits : bits_w1, bits_w2, nullptr, &s2, &r1, 0, 0,
-                                       /*summary_ready=*/true));
+                                       /*summary_ready=*/true, 0, -1, /*v32_in=*/tie_v32));
                 r0->sort_passes += r1.sort_passes; r0->sort_passes_skipped += r1.sort_passes_skipped;
                 ProfScope ps(c, TC_GATHER);
                 hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, ties, 256, 16)), dim3(256), 0, c->stream,

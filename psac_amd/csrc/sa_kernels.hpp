@@ -1316,7 +1316,8 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
     const T* __restrict__ ids, const T* __restrict__ pos_in, uint64_t cnt, T* __restrict__ pos_out,
     const uint64_t* __restrict__ offset, uint64_t pos_off, T prev_id, T next_id, unsigned shift = 0,
     const T* __restrict__ payload = nullptr, T* __restrict__ out_id = nullptr, T* __restrict__ out_payload = nullptr,
-    const uint64_t* __restrict__ unf_offset = nullptr, uint32_t* __restrict__ ord_out = nullptr) {
+    const uint64_t* __restrict__ unf_offset = nullptr, uint32_t* __restrict__ ord_out = nullptr, int payload32 = 0) {
+    // payload32 (EMIT, 64-bit words): the payloads leave as 32-bit entries (suffixes of a text of at most 2^32 characters)
     // ord_out (with unf_offset = exclusive scan of the per-tile counts of buckets with more than one member): every list entry's bucket
     // counted from 0 in list order -- the bucket's number in the one-word sort keys of the next round (gather_keys_kernel)
     // shift: only the bits above `shift` of an id count (ties of a prefix sort by the leading bits)
@@ -1370,7 +1371,10 @@ __global__ __launch_bounds__(BLOCK) void compact_active_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (act & (1u << j)) {
-            if (EMIT) { out_id[o] = raw[EMIT ? j : 0]; out_payload[o] = pl[EMIT ? j : 0]; }
+            if (EMIT) {
+                out_id[o] = raw[EMIT ? j : 0];
+                if (payload32) reinterpret_cast<uint32_t*>(out_payload)[o] = (uint32_t)pl[EMIT ? j : 0]; else out_payload[o] = pl[EMIT ? j : 0];
+            }
             if (uh & (1u << j)) ++ord;
             if (ord_out) ord_out[o] = (uint32_t)(ord - 1);
             pos_out[o++] = pos_in ? ps[j] : (T)(pos_off + e0 + j);
@@ -1667,7 +1671,8 @@ template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt, T* __restrict__ K1, const T* __restrict__ V,
                                           const uint8_t* __restrict__ text, uint64_t n_text, CodeTable tab, KeyShape ks,
                                           T* __restrict__ K2, unsigned long long* __restrict__ summary, bool packed = false,
-                                          const uint32_t* __restrict__ ord = nullptr, unsigned lo1 = 0) {
+                                          const uint32_t* __restrict__ ord = nullptr, unsigned lo1 = 0, int v32 = 0) {
+    // v32: V holds 32-bit entries
     // ord (with lo1): the tie groups counted from 0 in list order (compact_active_kernel).  The records are in the order of their
     // sorted prefixes already, so the sort that follows only needs the group's number above the bits of word 1 below the prefix:
     // K1 = ord << lo1 | low bits (fewer digits than the 64 bits of word 1; scatter_prefix_ties_kernel puts the low bits back under
@@ -1680,10 +1685,11 @@ __global__ __launch_bounds__(BLOCK) void gather_prefix_ties_kernel(uint64_t cnt,
     T o1 = 0, a1 = ~(T)0, o2 = 0, a2 = ~(T)0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
         T k1 = K1[j], k2;
-        if (packed && ord) window_low_and_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j], k1, lo1, k1, k2);       // (its low bits are not in the record)
+        const uint64_t sa = v32 ? (uint64_t)reinterpret_cast<const uint32_t*>(V)[j] : (uint64_t)V[j];
+        if (packed && ord) window_low_and_word2<T>(text, n_text, ctab, ks, sa, k1, lo1, k1, k2);       // (its low bits are not in the record)
         else {
-            k2 = window_word2<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
-            if (packed) k1 = window_word1<T>(text, n_text, ctab, ks, (uint64_t)V[j]);
+            k2 = window_word2<T>(text, n_text, ctab, ks, sa);
+            if (packed) k1 = window_word1<T>(text, n_text, ctab, ks, sa);
         }
         if (ord) k1 = (T)(((T)ord[j] << lo1) | (k1 & lowmask));
         if (packed || ord) K1[j] = k1;
