@@ -1605,22 +1605,21 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
     const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
     const uint64_t e0 = t0 + (uint64_t)threadIdx.x * ITEMS;
     if (e0 < n) {
-        // (top digit, rest of the prefix) of records e0 - 1 .. e0 + ITEMS, three at a time
+        // two neighbours tie when the rest of their prefixes agree and no bucket starts between them; the bucket table is asked only
+        // where the rests agree (one record in 250 on random text), not walked along with every record
         T mid[ITEMS];
         load_run<T, ITEMS>(R, e0, n, mid, (T)0);
         const T before = e0 ? R[e0 - 1] : (T)0, after = e0 + ITEMS < n ? R[e0 + ITEMS] : (T)0;
-        OneWordCursor cu;
-        cu.start(ow, e0 ? e0 - 1 : 0);
-        T vp = e0 ? onew_lead(ow, cu.b, before) : (T)0;
-        T vc = onew_lead(ow, cu.at(ow, e0), mid[0]);
+        auto starts_bucket = [&](uint64_t e) -> bool { return ow.off[onew_bucket(ow, e)] == e; };
+        bool eq_prev = e0 != 0 && (before >> ow.sfield) == (mid[0] >> ow.sfield) && !starts_bucket(e0);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const uint64_t e = e0 + j;
             const T x = j + 1 < ITEMS ? mid[j + 1 < ITEMS ? j + 1 : 0] : after;
-            const T vn = e + 1 < n ? onew_lead(ow, cu.at(ow, e + 1), x) : ~(T)0;
-            const bool start = (e == 0) || vp != vc;
-            if (e + 1 < n && start && vn == vc) leaders[atomicAdd(&n_leaders, 1u)] = (unsigned)(e - t0);
-            vp = vc; vc = vn;
+            bool eq_next = e + 1 < n && (x >> ow.sfield) == (mid[j] >> ow.sfield);
+            if (eq_next) eq_next = !starts_bucket(e + 1);
+            if (e < n && !eq_prev && eq_next) leaders[atomicAdd(&n_leaders, 1u)] = (unsigned)(e - t0);
+            eq_prev = eq_next;
         }
     }
     __syncthreads();
