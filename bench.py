@@ -200,14 +200,16 @@ def main_distributed(a, rank, world, local_rank):
         # for the result arrays with their slack + the text = 6.13 words of 8 bytes: 196 GiB at 2^32 characters.  Asked for: 7 words + 8 GiB
         # (RCCL's buffers, the block cache's odd sizes).  A GPU that cannot hold 2^31 is not the machine this benchmark is defined on:
         # the run stops with a reason instead of quoting a smaller workload as if it were the configured one (--n overrides).
-        # 2^32 per GPU only while the whole text has at most 2^34 characters (N <= 4): the one-word records of the first round keep
-        # 64 - bits_for(n - 1) bits of prefix beside the suffix, and beyond 2^34 characters too many suffixes would tie on them
-        # (multi.hpp: sort_first_one_word refuses, and the two-word form it falls back to peaks at 8.25 words per character).  Eight
-        # GPUs take 2^31 each: BASELINE.json configs[3], 16 GiB of DNA over 8 GPUs.
+        # Random text: 2^32 per GPU only while the whole text has at most 2^34 characters (N <= 4) -- the one-word records of the first
+        # round keep 64 - bits_for(n - 1) bits of prefix beside the suffix, and beyond 2^34 characters a quarter of the suffixes of a random
+        # text tie on them and take the slower tie stage; eight GPUs take 2^31 each: BASELINE.json configs[3], 16 GiB of DNA over 8 GPUs.
+        # The tandem repeat (configs[4]: 32 GiB over 8 GPUs) takes 2^32 per GPU at every N: all its suffixes tie on any prefix anyway, the
+        # reduced-memory layout orders them slab by slab (multi.hpp: first_sort_ties) and peaks below 3 engine words per character
+        # (profiles/r5a_multi_tandem_*: one rank x 2^32 2.48, 8 x 2^28 2.92; 8.25 and "does not fit" in round 4).
         free_b = torch.cuda.mem_get_info(local_rank)[0]
         fit = 0
         for lg in (32, 31):
-            if world * (1 << lg) > (1 << 34):
+            if world * (1 << lg) > (1 << 34) and a.alphabet != "tandem":
                 continue
             if free_b >= int(7.0 * 8 * (1 << lg)) + (8 << 30):
                 fit = lg

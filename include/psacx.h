@@ -259,7 +259,9 @@ int psacx_multi_get_phases(const psacx_multi* mg, char* buf, uint64_t cap);
 /* which forms the last construction took: bit 0 = first round in two-word form (records (B1, idx), ties repaired from the
  * text owners; idxsort.hpp:23-83 moves (B1, B2, idx)), bit 1 = reduced-memory layout, bit 2 = SA -> ISA slice by slice
  * through the destination-partition levels (bulk_permute.hpp:14-73),
- * bit 4 = first round in one-word records dealt to the ranks by the top digit of the prefix (8 bytes per record on the wire) */
+ * bit 4 = first round in one-word records dealt to the ranks by the top digit of the prefix (8 bytes per record on the wire),
+ * bits 8..15 = slabs beyond the first in which the ties of that round were ordered (reduced-memory layout, repetitive text: the
+ * records of one slab at a time take the place of idxsort.hpp:41-45's whole second record set) */
 int psacx_multi_last_form(const psacx_multi* mg);
 const char* psacx_multi_last_error(const psacx_multi* mg);
 psacx_ctx* psacx_multi_ctx(psacx_multi* mg, int local_rank);

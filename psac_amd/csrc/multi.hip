@@ -297,7 +297,7 @@ int psacx_multi_get_stats(const psacx_multi* g, psacx_stats* out, uint64_t* byte
 }
 
 int psacx_multi_transport(const psacx_multi* g) { return g ? g->transport : -1; }
-int psacx_multi_last_form(const psacx_multi* g) { return g ? (g->last_two_word ? 1 : 0) | (g->last_reduced ? 2 : 0) | (g->last_slice_inversion ? 4 : 0) | (g->last_one_word ? 16 : 0) : 0; }
+int psacx_multi_last_form(const psacx_multi* g) { return g ? (g->last_two_word ? 1 : 0) | (g->last_reduced ? 2 : 0) | (g->last_slice_inversion ? 4 : 0) | (g->last_one_word ? 16 : 0) | ((int)std::min<uint32_t>(g->last_tie_slabs, 255u) << 8) : 0; }
 
 int psacx_multi_get_wire(const psacx_multi* g, uint64_t* sends, uint64_t* recvs, uint64_t* allgathers, double* exchange_ms) {
     if (!g) return PSACX_EINVAL;

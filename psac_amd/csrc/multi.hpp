@@ -165,6 +165,7 @@ struct psacx_multi {
     bool last_one_word = false;       // the first round ran in one-word records dealt by top digit (sort_first_one_word)
     bool last_slice_inversion = false;   // SA -> ISA ran slice by slice through the partition levels + window scatter
     uint32_t last_slab_rounds = 0;    // refinement rounds it worked off in more than one slab
+    uint32_t last_tie_slabs = 0;      // slabs beyond the first in which the tie stage of the first round ran (reduced-memory layout, repetitive text)
 };
 
 namespace psacx {
@@ -227,6 +228,21 @@ template <typename T> __global__ void gather_at_kernel(const T* __restrict__ a, 
 template <typename T> __global__ void reverse_copy_kernel(const T* __restrict__ in, uint64_t cnt, T* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) out[i] = in[cnt - 1 - i];
+}
+
+// positions j of [lo, hi) at which a new group of equal prefixes (k1 >> lo1) starts (j >= 1): the last of them into *last (0 = none), the
+// first into *first (~0 = none) -- where the tie stage of the reduced-memory layout may cut its slabs (MultiRun::first_sort_ties)
+template <typename T> __global__ void prefix_cut_kernel(const T* __restrict__ k1, uint64_t lo, uint64_t hi, unsigned lo1, unsigned long long* __restrict__ last,
+                                                        unsigned long long* __restrict__ first) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mx = 0, mn = ~0ull;
+    for (uint64_t j = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < hi; j += stride)
+        if (j >= 1 && (k1[j] >> lo1) != (k1[j - 1] >> lo1)) { mx = j > mx ? j : mx; mn = j < mn ? j : mn; }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long ox = __shfl_xor(mx, d, 64), on = __shfl_xor(mn, d, 64);
+        mx = ox > mx ? ox : mx; mn = on < mn ? on : mn;
+    }
+    if ((threadIdx.x & 63) == 0) { if (mx) atomicMax(last, mx); if (mn != ~0ull) atomicMin(first, mn); }
 }
 
 template <typename T> __global__ void widen_text_kernel(const uint8_t* __restrict__ t, uint64_t cnt, T* __restrict__ out) {
@@ -1652,49 +1668,101 @@ struct MultiRun {
         }));
         mark("    sort: local prefix sort");
         if (!general_ties) { mark("    sort: ties"); return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets); }
-        std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, tpos[i].alloc(c, ties[i])); MG_OP(g, c, tk1[i].alloc(c, ties[i])); MG_OP(g, c, tv[i].alloc(c, ties[i]));
-            if (ties[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk)); }
-            return PSACX_OK;
-        }));
-        {
-            std::vector<const T*> q(L);
-            for (int i = 0; i < L; ++i) q[i] = tv[i].p;
-            PSACX_TRY(dist_windows(tbuf, two_k, tab, ks, q, ties, w1, w2));
+        // Reduced-memory layout: the compacted ties, their windows and the second record set of their sort are eight arrays of as many
+        // entries as there are ties -- on a repetitive text every suffix ties.  The records are then worked off in slabs of at most
+        // `cap` records that end where a group of equal prefixes ends (groups are independent of each other; a group longer than a
+        // slab is taken whole): the same steps on fewer records, every rank as many slabs as the one with the most.
+        uint64_t cap = 0;
+        if (diet && slab_cap) {
+            std::vector<uint64_t> all;
+            PSACX_TRY(gather1(ties, all));
+            const uint64_t tcap = std::max<uint64_t>(slab_cap / 2, 64);
+            for (uint64_t t : all) if (t > tcap) cap = tcap;
         }
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            const uint64_t tn = ties[i];
-            if (!tn) return PSACX_OK;
-            MG_HIP(g, hipSetDevice(c->device));
-            // every group is at most TG long: ordered in registers (tie_resolve_kernel reading both words from the arrays)
-            constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
-            DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
-            MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
-            const uint64_t nb = (tn + (uint64_t)TB_ * TI_ - 1) / ((uint64_t)TB_ * TI_);
-            hipLaunchKernelGGL((tie_resolve_kernel<T, TB_, TI_, TG_, true>), dim3((unsigned)nb), dim3(TB_), 0, c->stream, w1[i].p, tv[i].p, w2[i].p, tn, lo1,
-                               (const uint8_t*)nullptr, (uint64_t)0, tab, ks, big.p);
-            MG_HIP(g, hipGetLastError());
-            MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
-            MG_HIP(g, hipStreamSynchronize(c->stream));
-            const T *s1 = w1[i].p, *s2 = w2[i].p, *sv = tv[i].p;
-            DBuf<T> b1, b2, bv;
-            if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) {
-                // some group is long (repetitive text): a stable sort of all tied records by the full window; the groups come in
-                // ascending order of their prefix, so the sorted records go back to the same positions in order
-                MG_OP(g, c, b1.alloc(c, tn)); MG_OP(g, c, b2.alloc(c, tn)); MG_OP(g, c, bv.alloc(c, tn));
-                int32_t where = 0;
-                MG_OP(g, c, op_pair_sort<T>(c, w1[i].p, w2[i].p, tv[i].p, b1.p, b2.p, bv.p, tn, bits1, bits2, &where));
-                if (where) { s1 = b1.p; s2 = b2.p; sv = bv.p; }
+        std::vector<uint64_t> at(L, 0), end(L, 0), tn(L, 0);
+        for (;;) {
+            if (!cap) for (int i = 0; i < L; ++i) { end[i] = rec[i].cnt; tn[i] = ties[i]; }
+            else PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                const uint64_t cnt = rec[i].cnt;
+                end[i] = cnt; tn[i] = 0;
+                if (at[i] >= cnt) return PSACX_OK;
+                if (cnt - at[i] > cap) {
+                    DBuf<unsigned long long> cut; MG_OP(g, c, cut.alloc(c, 2));
+                    unsigned long long* h = reinterpret_cast<unsigned long long*>(c->pinned + 32768);
+                    MG_HIP(g, hipSetDevice(c->device));
+                    auto ask = [&](uint64_t lo, uint64_t hi) -> int {
+                        h[0] = 0; h[1] = ~0ull;
+                        MG_HIP(g, hipMemcpyAsync(cut.p, h, 16, hipMemcpyHostToDevice, c->stream));
+                        hipLaunchKernelGGL((prefix_cut_kernel<T>), dim3(grid_for(c, hi - lo, 256, 8)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, lo, hi, lo1, cut.p, cut.p + 1);
+                        MG_HIP(g, hipGetLastError());
+                        MG_HIP(g, hipMemcpyAsync(h, cut.p, 16, hipMemcpyDeviceToHost, c->stream));
+                        MG_HIP(g, hipStreamSynchronize(c->stream));
+                        return PSACX_OK;
+                    };
+                    PSACX_TRY(ask(at[i] + 1, at[i] + cap + 1));              // the last group start inside the slab ...
+                    if (h[0]) end[i] = h[0];
+                    else {                                                   // ... or, a group longer than the slab, the end of that group
+                        PSACX_TRY(ask(at[i] + cap + 1, cnt));
+                        if (h[1] != ~0ull) end[i] = h[1];
+                    }
+                }
+                MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &tn[i]));
+                return PSACX_OK;
+            }));
+            std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                MG_OP(g, c, tpos[i].alloc(c, tn[i])); MG_OP(g, c, tk1[i].alloc(c, tn[i])); MG_OP(g, c, tv[i].alloc(c, tn[i]));
+                if (tn[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk)); }
+                return PSACX_OK;
+            }));
+            {
+                std::vector<const T*> q(L);
+                for (int i = 0; i < L; ++i) q[i] = tv[i].p;
+                PSACX_TRY(dist_windows(tbuf, two_k, tab, ks, q, tn, w1, w2));
             }
-            hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, tn, 256, 16)), dim3(256), 0, c->stream, (const T*)tpos[i].p, tn, s1, s2, sv,
-                               rec[i].k1.p, rec[i].k2.p, rec[i].v.p);
-            MG_HIP(g, hipGetLastError());
-            MG_HIP(g, hipStreamSynchronize(c->stream));          // (the compacted arrays go back to the cache when this scope ends)
-            return PSACX_OK;
-        }));
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                const uint64_t n_t = tn[i];
+                if (!n_t) return PSACX_OK;
+                MG_HIP(g, hipSetDevice(c->device));
+                // every group is at most TG long: ordered in registers (tie_resolve_kernel reading both words from the arrays)
+                constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
+                DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
+                MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
+                const uint64_t nb = (n_t + (uint64_t)TB_ * TI_ - 1) / ((uint64_t)TB_ * TI_);
+                hipLaunchKernelGGL((tie_resolve_kernel<T, TB_, TI_, TG_, true>), dim3((unsigned)nb), dim3(TB_), 0, c->stream, w1[i].p, tv[i].p, w2[i].p, n_t, lo1,
+                                   (const uint8_t*)nullptr, (uint64_t)0, tab, ks, big.p);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+                const T *s1 = w1[i].p, *s2 = w2[i].p, *sv = tv[i].p;
+                DBuf<T> b1, b2, bv;
+                if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) {
+                    // some group is long (repetitive text): a stable sort of all tied records by the full window; the groups come in
+                    // ascending order of their prefix, so the sorted records go back to the same positions in order
+                    tk1[i].release();                                    // (word 1 of the ties came back with the windows)
+                    MG_OP(g, c, b1.alloc(c, n_t)); MG_OP(g, c, b2.alloc(c, n_t)); MG_OP(g, c, bv.alloc(c, n_t));
+                    int32_t where = 0;
+                    MG_OP(g, c, op_pair_sort<T>(c, w1[i].p, w2[i].p, tv[i].p, b1.p, b2.p, bv.p, n_t, bits1, bits2, &where));
+                    if (where) { s1 = b1.p; s2 = b2.p; sv = bv.p; }
+                }
+                hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, n_t, 256, 16)), dim3(256), 0, c->stream, (const T*)tpos[i].p, n_t, s1, s2, sv,
+                                   rec[i].k1.p + at[i], rec[i].k2.p + at[i], rec[i].v.p + at[i]);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipStreamSynchronize(c->stream));          // (the compacted arrays go back to the cache when this scope ends)
+                return PSACX_OK;
+            }));
+            if (!cap) break;
+            std::vector<uint64_t> left(L), left_all;
+            for (int i = 0; i < L; ++i) { at[i] = end[i]; left[i] = rec[i].cnt - at[i]; }
+            PSACX_TRY(gather1(left, left_all));
+            bool more = false;
+            for (uint64_t x : left_all) more |= x != 0;
+            if (!more) break;
+            ++g->last_tie_slabs;
+        }
         mark("    sort: ties");
         return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets);
     }
@@ -1728,7 +1796,11 @@ struct MultiRun {
         const unsigned want_lead = (nbits + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
         const unsigned low = std::min(std::min(64u - nbits, bits1 - (unsigned)RADIX_BITS), want_lead - (unsigned)RADIX_BITS);
         const unsigned lead = low + RADIX_BITS, sfield = 64 - low, lo1 = bits1 - lead;
-        if (lead < nbits + 3 && !trust) return PSACX_RETRY_;        // (too many suffixes would tie on the prefix)
+        // Reduced-memory layout: a text that repeats itself, or one so long that few prefix bits fit beside the suffix (beyond 2^34 characters),
+        // stays in one-word records -- its many ties are ordered slab by slab (first_sort_ties), while the three-word records of the
+        // other forms would not fit the device at all (8.25 words per character against 3)
+        const bool ties_ok = trust || diet;
+        if (lead < nbits + 3 && !ties_ok) return PSACX_RETRY_;      // (too many suffixes would tie on the prefix)
         if (lead < nbits + 1) return PSACX_RETRY_;
         uint64_t min_m = sizes[0];
         for (int r = 1; r < P; ++r) min_m = std::min(min_m, sizes[r]);
@@ -1767,7 +1839,7 @@ struct MultiRun {
             MG_HIP(g, hipSetDevice(c->device));
             unsigned long long* h = reinterpret_cast<unsigned long long*>(c->pinned + 32768);
             h[RADIX] = 0; h[RADIX + 1] = 0;
-            if (samples >= 1024 && !trust) {
+            if (samples >= 1024 && !ties_ok) {
                 // does the block repeat itself massively?  (prefix_dup_probe_kernel, sa_kernels.hpp: such a text keeps the two-word path)
                 unsigned long long* table = reinterpret_cast<unsigned long long*>(q.desc + 256);
                 unsigned long long* d_dups = reinterpret_cast<unsigned long long*>(q.desc + 128);
@@ -1802,7 +1874,7 @@ struct MultiRun {
         {
             uint64_t dups = 0, smp = 0;
             for (int r = 0; r < P; ++r) { dups += table[(size_t)r * W + RADIX]; smp += table[(size_t)r * W + RADIX + 1]; }
-            if (!trust && smp && dups * 8 > smp) return PSACX_RETRY_;
+            if (!ties_ok && smp && dups * 8 > smp) return PSACX_RETRY_;
         }
         std::vector<std::vector<uint64_t>> short_words(RADIX);
         if (!solo_ && spec) {
@@ -2222,7 +2294,7 @@ struct MultiRun {
         std::vector<Ptrs> pk_(L), A0(L), A1(L), Bb(L);
         std::vector<unsigned*> cur(L, nullptr);
         uint64_t G = spo;
-        if (diet && !solo_) G = std::max<uint64_t>(1, std::max<uint64_t>(slice, max_m / 8) >> sb);
+        if (diet) G = std::max<uint64_t>(1, std::max<uint64_t>(slice, max_m / 8) >> sb);     // (one rank without the wire: the levels work on a step's part of the class array)
         if (slice_step_env_) G = slice_step_env_;
         G = std::min<uint64_t>(G, spo);
         const uint64_t nsteps = (spo + G - 1) / G;
@@ -2330,8 +2402,10 @@ struct MultiRun {
                 if (!solo_) MG_HIP(g, hipStreamWaitEvent(c->stream, done[t & 1][i], 0));
                 if (!len) return PSACX_OK;
                 Ptrs& A = (t & 1) ? A1[i] : A0[i];
-                const uint32_t* ks = solo_ ? pk_[i].k : A.k; const V* vs = solo_ ? pk_[i].v : A.v;
-                uint32_t* ka = solo_ ? pk_[i].k : A.k; V* va = solo_ ? pk_[i].v : A.v;
+                // (one rank without the wire: the classes of the first level ARE the slices, in place: the step's part of them)
+                const uint64_t so = solo_ ? lo : 0;
+                const uint32_t* ks = solo_ ? pk_[i].k + ((pack || !pk_[i].v) ? 2 * so : so) : A.k; const V* vs = solo_ ? (pk_[i].v ? pk_[i].v + so : nullptr) : A.v;
+                uint32_t* ka = const_cast<uint32_t*>(ks); V* va = const_cast<V*>(vs);
                 unsigned below = rbits;                        // bits still to partition on beneath the current level
                 if (pack) {
                     const uint64_t* cur_in = reinterpret_cast<const uint64_t*>(ks);
@@ -2366,7 +2440,7 @@ struct MultiRun {
                     MG_HIP(g, hipMemcpy(d.p, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
                     dec.seg = d.p; dec.base = d.p + (size_t)(s1e - s0) * (P + 1);
                     keep_dec[i].push_back(std::move(d));
-                    ks = solo_ ? reinterpret_cast<const uint32_t*>(pk_[i].v) : reinterpret_cast<const uint32_t*>(A.v);     // the packed entries as they arrived
+                    ks = solo_ ? reinterpret_cast<const uint32_t*>(pk_[i].v + so) : reinterpret_cast<const uint32_t*>(A.v);     // the packed entries as they arrived
                 }
                 for (unsigned j = 0; j < levels2; ++j) {
                     below -= cbs[j];
@@ -2493,11 +2567,14 @@ struct MultiRun {
                 std::vector<uint64_t> bnd2;
                 PSACX_TRY(route_by(i, parts[i][3 * half].p, a, b, cnt[i], ra[i], bounds[i]));
                 PSACX_TRY(route_by(i, parts[i][3 * half].p, a, slot.p, cnt[i], rb[i], bnd2));
+                rb[i].k2.release();                       // (only the slots of the second pass are read again)
+                for (int q3 = 0; q3 < 3; ++q3) parts[i][3 * half + q3].release();      // this half's sub-queries are on their way
                 in[i] = {ra[i].k2.p, ra[i].v.p};
                 return PSACX_OK;
             }));
             std::vector<std::vector<DBuf<T>>> q, got;
             PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
+            ra.clear(); ra.resize(L);                     // (blocks go back to the rank's cache in stream order: engine.hpp pool)
             std::vector<DBuf<T>> res(L);
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
@@ -2509,6 +2586,7 @@ struct MultiRun {
                 return PSACX_OK;
             }));
             PSACX_TRY(exchange<T>(1, in, b2, got, rc2));
+            q.clear(); res.clear();
             answers[half].resize(L);
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
@@ -2639,6 +2717,7 @@ struct MultiRun {
             PSACX_TRY(dist_put(blk, gi, va, cnt, -1, false));
         }
         mark("  refine + ISA");
+        rec.clear(); rec.resize(L);                       // (the sorted records are not read again: their room serves the range minima)
         if (want_lcp) {
             std::vector<const T*> lo(L), hi(L);
             for (int i = 0; i < L; ++i) { lo[i] = ql[i].p; hi[i] = qh[i].p; }
@@ -2652,7 +2731,6 @@ struct MultiRun {
             }));
         }
         mark("  range minima");
-        rec.clear(); rec.resize(L);
         PSACX_TRY(next_active(&ids, &plist, nact, nunf, kept, unf_b, unf_e));
         return PSACX_OK;
     }
@@ -2719,7 +2797,7 @@ struct MultiRun {
             return PSACX_OK;
         }));
         diet = false; slab_cap = 0; first_round_ = true;
-        g->last_reduced = false; g->last_slab_rounds = 0;
+        g->last_reduced = false; g->last_slab_rounds = 0; g->last_tie_slabs = 0;
         // sizes + alphabet (alphabet.hpp:98: allreduce of the character histograms)
         {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(258, 0));
@@ -2762,7 +2840,10 @@ struct MultiRun {
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
             if (diet) {
-                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                // (a refinement step holds up to seventeen arrays of a slab's length at once -- its records, their new ids and the queries and
+                //  answers of the range minima on both sides of an exchange -- beside the bucket ids and the list of unresolved positions:
+                //  with 1/32 of a block per step that stays below three words per character, BASELINE.json configs[4])
+                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 32, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
                 // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
                 //  device only when an allocation does not fit: pool_alloc)
@@ -3281,7 +3362,10 @@ struct MultiRun {
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
             if (diet) {
-                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 16, 1u << 16);
+                // (a refinement step holds up to seventeen arrays of a slab's length at once -- its records, their new ids and the queries and
+                //  answers of the range minima on both sides of an exchange -- beside the bucket ids and the list of unresolved positions:
+                //  with 1/32 of a block per step that stays below three words per character, BASELINE.json configs[4])
+                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 32, 1u << 16);
                 if (slab_cap < 64) slab_cap = 64;
                 // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
                 //  device only when an allocation does not fit: pool_alloc)

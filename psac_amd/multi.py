@@ -77,9 +77,10 @@ class MultiContext(object):
         return {"sends": a.value, "recvs": b.value, "allgathers": c.value, "exchange_ms": [round(x, 3) for x in ms]}
 
     def last_form(self):
-        """{"two_word", "reduced_memory", "slice_inversion", "one_word"}: the forms the last construction took (psacx_multi_last_form)."""
+        """{"two_word", "reduced_memory", "slice_inversion", "one_word", "tie_slabs"}: the forms the last construction took
+        (psacx_multi_last_form); tie_slabs = slabs beyond the first in which the tie stage of the first round ran."""
         f = self._lib.psacx_multi_last_form(self.handle)
-        return {"two_word": bool(f & 1), "reduced_memory": bool(f & 2), "slice_inversion": bool(f & 4), "one_word": bool(f & 16)}
+        return {"two_word": bool(f & 1), "reduced_memory": bool(f & 2), "slice_inversion": bool(f & 4), "one_word": bool(f & 16), "tie_slabs": (f >> 8) & 255}
 
     def phases(self):
         """Host wall time (ms) of the phases of the last construction, in order of first appearance."""

@@ -575,6 +575,47 @@ def test_multi_first_round_memory_in_the_reduced_layout():
         mg.close()
 
 
+@pytest.mark.parametrize("P,lg", [(8, 28), (1, 30)])
+def test_multi_repetitive_text_memory_in_the_reduced_layout(P, lg):
+    # BASELINE.json configs[4] at reduced scale: a period-1024 tandem repeat (every suffix ties on the sorted prefix of the first round and
+    # stays unresolved for ~27 rounds) in the reduced-memory layout, 8 ranks x 2^28 characters and one rank x 2^30, uint64.  The text keeps
+    # the one-word first round (its ties are ordered slab by slab), the slice inversion of one rank runs in steps, a refinement step
+    # releases what it no longer reads before the range minima: the engine's own allocations stay below 3 words per character (round 4:
+    # the three-word fallback took 8.25 and a block of 2^32 characters did not fit the device; psac plans 6 words for the sort alone,
+    # idxsort.hpp:41-45, and runs the same loop for any text, suffix_array.hpp:381-450).  Verified by the distributed checker.
+    import ctypes as C
+    m, bits = 1 << lg, 64
+    mg = multi(P)
+    try:
+        lib = mg._lib
+        sizes = [m] * P
+        slack = m // 8 + 256
+        ctxs = [mg.rank_ctx(i) for i in range(P)]
+        def alloc(ctx, nbytes):
+            p = C.c_void_p()
+            assert lib.psacx_dev_alloc(ctx, C.byref(p), nbytes) == 0
+            return p.value
+        d_text = [alloc(c, m) for c in ctxs]
+        for i, c in enumerate(ctxs):
+            assert lib.psacx_synth_text_dev(c, C.c_void_p(d_text[i]), m, i * m, 2, 3, 1024) == 0
+        outs = [[alloc(c, (m + slack) * 8) for c in ctxs] for _ in range(3)]
+        mg.configure(layout=mg.LAYOUT_REDUCED, output_slack=slack)
+        st = mg.construct_device(d_text, sizes, outs[0], outs[1], outs[2], bits)[0]
+        peak, reduced, slab_rounds = mg.memory()
+        form = mg.last_form()
+        assert reduced and form["one_word"] and form["slice_inversion"] and form["tie_slabs"] >= 8 and slab_rounds >= 20 and st.n_rounds >= 24
+        words = max(peak) / (m * 8.0)
+        print("engine allocations at their peak: %.2f words per character" % words)
+        assert words <= 3.0, words
+        assert words + 3.0 * (m + slack) / m + 1.0 / 8 <= 6.5
+        assert mg.check_device(d_text, sizes, outs[0], outs[1], outs[2], bits) == [0, 0, 0, 0]
+        for c, ps in zip(ctxs, zip(d_text, *outs)):
+            for p_ in ps:
+                lib.psacx_dev_free(c, C.c_void_p(p_))
+    finally:
+        mg.close()
+
+
 def test_multi_rccl_wire_forced_at_world_size_one(monkeypatch):
     # PSACX_MULTI_FORCE_WIRE=1: the shortcuts for data a rank addresses to itself and for scalars already on this host are
     # off, so ncclAllGather and ncclSend / ncclRecv (to self) are really issued at world size 1 -- the calls the driver's
@@ -768,6 +809,41 @@ def test_multi_first_round_one_word_form(P, monkeypatch):
                 assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
                 used += mg.last_form()["one_word"]
             assert used >= (len(cases) - 2 if mode == "2" else 2), (used, P, mode)      # (32-bit words never take the form, nor do blocks shorter than 128 characters)
+        finally:
+            mg.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_multi_first_round_ties_in_slabs(P, monkeypatch):
+    # Reduced-memory layout: a repetitive text stays in one-word records (sort_first_one_word does not turn it away) and its ties --
+    # every suffix of a tandem repeat -- are ordered slab by slab (first_sort_ties): slabs end where a group of equal prefixes ends, a
+    # group longer than a slab (one symbol, a period of three) is taken whole, ranks without ties left run empty slabs along.
+    # BASELINE.json configs[4] at reduced scale; idxsort.hpp:41-45 plans the whole second record set instead.
+    cases = [(inputs.tandem(30000, 256, O.rand_dna(256, 3)), 64), (O.rand_dna(70001, 7), 64), (np.full(5003, 65, np.uint8), 64),
+             (inputs.cyclic(20011, "abc"), 64), (O.as_text("mississippi" * 40), 64), (inputs.tandem(50021, 1024, O.rand_dna(1024, 5)), 64)]
+    monkeypatch.setenv("PSACX_MULTI_ONE_WORD", "1")
+    monkeypatch.setenv("PSACX_MULTI_TWO_WORD", "1")
+    for slab, env in ((700, {}), (4000, {"PSACX_MULTI_PIECES": "3"}), (700, {"PSACX_MULTI_FORCE_WIRE": "1"})):
+        if env.get("PSACX_MULTI_FORCE_WIRE") and P != 1:
+            continue
+        for k_ in ("PSACX_MULTI_FORCE_WIRE", "PSACX_MULTI_PIECES"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        mg = multi(P)
+        try:
+            mg.configure(layout=mg.LAYOUT_REDUCED, slab=slab)
+            slabs = []
+            for text, bits in cases:
+                SA, ISA, LCP, rounds = same(mg, text, bits)
+                ref = O.construct(text, bits=bits)
+                assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"]), (P, slab, env, text.size)
+                form = mg.last_form()
+                assert form["reduced_memory"]
+                slabs.append((form["one_word"], form["tie_slabs"]))
+            # the tandem repeats took the one-word form although every suffix ties, and their ties needed several slabs
+            assert slabs[0][0] and slabs[0][1] >= 1 and slabs[5][0] and slabs[5][1] >= 1, slabs
+            assert slabs[1][1] == 0, slabs              # random text: a handful of ties, one slab
         finally:
             mg.close()
 
