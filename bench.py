@@ -55,7 +55,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # ... round 4, later (no widening pass any more), profiles/r4d_bench_{fetch,write}_4gib_u64.txt: four bucket passes of
 #     (2 x 17323970 + 34463887) KiB = 70770510848 bytes each (1.030 x the algorithmic 16 bytes per record and pass)
 # Keyed by (scatter form, records per launch, index bits).
-TRAFFIC = {(1, 1 << 28, 32): 6553287372, (2, 1 << 28, 32): 4184907503, (2, 1 << 32, 64): 117173345280, (3, 1 << 32, 64): 70770510848}
+# ... round 4, last code, profiles/r4f_bench_{fetch,write}_4gib_u64.txt: (2 x 17324001 + 34476460) KiB = 70783449088 bytes (1.030 x)
+# Every entry names the committed profile it was read from (roofline.traffic_profile).
+TRAFFIC = {(1, 1 << 28, 32): (6553287372, "profiles/r01_pmc_fetch_size.txt + r01_pmc_write_size.txt"),
+           (2, 1 << 28, 32): (4184907503, "profiles/r01d_pmc_fetch_size.txt + r01d_pmc_write_size.txt"),
+           (2, 1 << 32, 64): (117173345280, "profiles/r04s_pmc_fetch_size_4gib_u64.txt + r04s_pmc_write_size_4gib_u64.txt"),
+           (3, 1 << 32, 64): (70783449088, "profiles/r4f_bench_fetch_4gib_u64.txt + r4f_bench_write_4gib_u64.txt")}
 
 
 def parse():
@@ -107,6 +112,21 @@ def cpu_baseline(kind, sample, seed, bits):
     out = {"value": round(sample / dt / 1e6, 3), "unit": "MChars/s", "cores": cores, "kind": "port",
            "sample": "%d chars of the same generator (%s, seed %d), SA+LCP, uint%d, %.1f s on %d threads"
                      % (sample, kind, seed, bits, dt, cores)}
+    # the port's single-core throughput beside the survey's figure for psac itself on one core of its VM
+    # (16 MiB random DNA, uint64, k = 21: 6631 ms = 2.53 MChars/s; uint32: 4.06) -- the same 2^24 characters
+    try:
+        ps = min(sample, 1 << 24)
+        t0 = time.perf_counter()
+        O.construct(make_text("dna", ps, seed), bits=bits)
+        t1 = time.perf_counter() - t0
+        ref = 2.53 if bits == 64 else 4.06
+        out["port_1_thread"] = {"value": round(ps / t1 / 1e6, 3), "unit": "MChars/s", "cores": 1, "kind": "port",
+                                "sample": "%d chars of random DNA (seed %d), SA+ISA+LCP, uint%d, %.1f s on 1 thread" % (ps, seed, bits, t1),
+                                "survey_psac_1_core_MChars_per_s": ref, "ratio_to_survey_psac": round(ps / t1 / 1e6 / ref, 2),
+                                "note": "BASELINE.md section 2 timed psac's own headers on one core of the survey VM (Xeon 2.1 GHz) on the same "
+                                        "generator family and size; this is the oracle's restatement on one core of this box"}
+    except Exception as e:          # a side measurement never breaks the bench line
+        out["port_1_thread"] = {"error": str(e)[:200]}
     # SURVEY 8(d) CPU baseline leg (1): libdivsufsort (the reference's own CPU comparison, src/psac_vs_dss.cpp:
     # 87-119; oracle/_ref build of /root/reference/ext/libdivsufsort) + Kasai LCP, one thread, bounded sample
     if O.have_divsufsort():
@@ -165,8 +185,10 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
                      "records_per_launch": (scat_records[dom] // max(scat_launches[dom], 1)) if scat_records else n,
                      "bytes_per_record_per_pass": round(scat_bytes[dom] / float(max(scat_records[dom], 1)), 2) if scat_records
                                                   else round(scat_bytes[dom] / max(scat_launches[dom], 1) / float(n), 2),
-                     "traffic": TRAFFIC.get((tkey, n, bits)) if world == 1 else None,
-                     "traffic_source": "PMC counters of the committed profile of this workload (profiles/), not measured in this run"},
+                     "traffic": TRAFFIC.get((tkey, n, bits), (None, None))[0] if world == 1 else None,
+                     "traffic_profile": TRAFFIC.get((tkey, n, bits), (None, None))[1] if world == 1 else None,
+                     "traffic_source": "PMC counters (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes) of the committed "
+                                       "profile named in traffic_profile, per launch of this kernel on this workload; not measured in this run"},
     }
     if phases:
         out["phase_ms_last_step"] = phases
@@ -343,12 +365,14 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
     lib = ctx._lib
     res = {}
 
-    def run(tag, kind, n, bits, steps, env=None):
+    def run(tag, kind, n, bits, steps, env=None, seed=None, period=1024, recurrence_check=False):
+        # recurrence_check: verified by the distributed checker with one rank (every LCP entry through its recurrence) -- the device
+        # checker compares characters, sum(LCP) of them: hours on a long repeat
         try:
             old = {}
             for k_, v_ in (env or {}).items():
                 old[k_] = os.environ.get(k_); os.environ[k_] = v_
-            ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID[kind], a.seed, 1024))
+            ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID[kind], a.seed if seed is None else seed, period))
             s_ = sa64 if bits == 64 else psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
             s_.construct_device(d_text, n, d_sa, d_isa, d_lcp)
             ctx.check(lib.psacx_sync(ctx.handle))
@@ -363,8 +387,17 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
             dt = (time.perf_counter() - t0) / steps
             q = max((0, 1, 2), key=lambda j: by[j])
             gbs = by[q] / (ms[q] * 1e-3) / 1e9 if ms[q] > 0 else 0.0
-            err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, bits)
+            if recurrence_check:
+                ctx.check(lib.psacx_trim(ctx.handle))          # (the workspace of the construction goes back to the device: the checker brings its own)
+                mgc = psac_amd.MultiContext([ctx.device])
+                try:
+                    err = mgc.check_device([d_text], [n], [d_sa], [d_isa], [d_lcp], bits)
+                finally:
+                    mgc.close()
+            else:
+                err = psac_amd.check_device(ctx, d_text, n, d_sa, d_isa, d_lcp, bits)
             res[tag] = {"n": n, "index_bits": bits, "ms_per_construction": round(dt * 1e3, 3), "MChars_per_s": round(n / dt / 1e6, 1),
+                        "timing": "host wall clock over %d constructions after one warm-up call, text and results resident in HBM" % steps,
                         "rounds": int(st.n_rounds), "verified": list(err) == [0, 0, 0, 0],
                         "scatter_pass": {"form": ("look-back", "three-word (B1,B2,idx)", "two-word (B1,idx)")[q],
                                          "launches_per_construction": la[q] // steps, "avg_launch_ms": round(ms[q] / max(la[q], 1), 4),
@@ -381,11 +414,59 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
 
     run("configs[2]: 4096 MiB random ASCII (sigma 128), uint64", "ascii128", 1 << 32, 64, 3)
     run("configs[1]: 256 MiB random DNA, uint32", "dna", 1 << 28, 32, 5)
+    # ANSV over the LCP array that run left in HBM (the pass psac -t makes, suffix_tree.hpp:62: left furthest_eq, right nearest_sm)
+    res["ansv psac -t pair (furthest_eq, nearest_sm), LCP of 2^28 DNA, uint32"] = ansv_leg(ctx, d_lcp, 1 << 28, 32, d_sa, d_isa)
+    # texts that are not random (the reference's own benchmark input is a genome, pbs_run.sh:36): the twin of configs[4] and repeated
+    # reads with mutations; host wall time per construction after a warm-up call
+    run("configs[4] twin (/256): 128 MiB period-1024 tandem repeat of DNA, uint64", "tandem", 1 << 27, 64, 2, seed=3, recurrence_check=True)
+    run("repeated reads with mutations: 1024 MiB (period 65536, one substitution in 200), uint64", "mutated", 1 << 30, 64, 2, seed=7, period=1 << 16,
+        recurrence_check=True)
     # the (B1,B2,idx) records of idxsort.hpp:58-62 through every digit of both words (PSACX_ONE_STAGE=1 switches the
     # two-stage first round off): 6w = 48 bytes per record and pass, SURVEY 8(d)'s per-unit figure
     run("three-word scatter form: 2048 MiB random DNA, uint64, one-stage first round", "dna", 1 << 31, 64, 2, {"PSACX_ONE_STAGE": "1"})
     ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), 1 << 32, 0, KIND_ID[a.alphabet], a.seed, 1024))
     return res
+
+
+def ansv_leg(ctx, d_in, n, bits, d_l, d_r):
+    """psacx_ansv_dev_* on an array resident in HBM (left furthest_eq, right nearest_sm), timed over three calls after a warm-up;
+    a window of 2^22 elements in the middle is compared with the oracle's ansv (ansv.hpp:48-65 restated) wherever the oracle's
+    answer lies inside the window.  d_l, d_r: room for n uint64 results each (buffers of the workload before it, idle by now)."""
+    import numpy as np
+    import psac_amd
+    import oracle_lib as O
+    try:
+        w = bits // 8
+        NONSV = (1 << 64) - 1
+        lt, rt = psac_amd.FURTHEST_EQ, psac_amd.NEAREST_SM
+        psac_amd.ansv_device(ctx, d_in, n, d_l, d_r, bits, lt, rt, NONSV)
+        ctx.check(ctx._lib.psacx_sync(ctx.handle))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            psac_amd.ansv_device(ctx, d_in, n, d_l, d_r, bits, lt, rt, NONSV)
+        ctx.check(ctx._lib.psacx_sync(ctx.handle))
+        dt = (time.perf_counter() - t0) / 3
+        # the window: values and both results back to the host
+        W = min(n, 1 << 22); off = (n - W) // 2
+        v = np.empty(W, np.uint32 if bits == 32 else np.uint64); gl = np.empty(W, np.uint64); gr = np.empty(W, np.uint64)
+        ctx.d2h(v, d_in + off * w); ctx.d2h(gl, d_l + off * 8); ctx.d2h(gr, d_r + off * 8)
+        sm_l = O.ansv(v, True, 0, NONSV); fe_l = O.ansv(v, True, 2, NONSV); sm_r = O.ansv(v, False, 0, NONSV)
+        # left (furthest_eq: from the nearest value <= in[i] on through the values equal to THAT one while nothing smaller lies between,
+        # ansv_common.hpp:20-22): the window's answer is the global one where something smaller than the answer's value precedes it
+        # inside the window, so that the walk ends there
+        has = fe_l != np.uint64(NONSV)
+        okl = np.zeros(W, bool)
+        okl[has] = sm_l[fe_l[has].astype(np.int64)] != np.uint64(NONSV)
+        want_l = fe_l + np.uint64(off)
+        okr = sm_r != np.uint64(NONSV)
+        bad = int(np.count_nonzero(gl[okl] != want_l[okl])) + int(np.count_nonzero(gr[okr] != (sm_r[okr] + np.uint64(off))))
+        gbs = n * (w + 16) / dt / 1e9
+        return {"n": n, "index_bits": bits, "ms": round(dt * 1e3, 3), "G_elements_per_s": round(n / dt / 1e9, 2),
+                "algorithmic_bytes_per_element": w + 16, "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+                "timing": "host wall clock over 3 calls after one warm-up call, input and results resident in HBM",
+                "verified": bad == 0, "checked": "%d left and %d right answers of a 2^22-element window against the oracle" % (int(okl.sum()), int(okr.sum()))}
+    except Exception as e:              # a side measurement never breaks the bench line
+        return {"error": str(e)[:200]}
 
 
 def mem_available_bytes():
@@ -398,7 +479,7 @@ def mem_available_bytes():
     return 0
 
 
-KIND_ID = {"dna": 0, "ascii128": 1, "tandem": 2}
+KIND_ID = {"dna": 0, "ascii128": 1, "tandem": 2, "mutated": 3}
 
 
 def main():
@@ -494,12 +575,18 @@ def main():
         t1 = time.perf_counter()
         hs.local_SA, hs.local_B, hs.local_LCP = hs.construct_into(text, hs.local_SA, hs.local_B, hs.local_LCP)
         ht = time.perf_counter() - t1
+        sa_bytes = 1 if hn <= (1 << 8) else 2 if hn <= (1 << 16) else 4 if hn <= (1 << 32) else 8
+        narrowed = ("they cross PCIe narrowed to the fewest bytes per entry that hold their largest value (SA / ISA %d of %d bytes at this size, "
+                    "LCP as few as 1 on random text)" % (sa_bytes, w)) if sa_bytes < w else "entries of SA / ISA cross PCIe in full (nothing to narrow at this size and width)"
         out["construct_host"] = {"ms": round(ht * 1e3, 1), "MChars_per_s": round(hn / ht / 1e6, 1), "n": hn,
                                  "note": "psacx_construct_u%d on host pointers (SURVEY 8(d) Metric 1): H2D of %d MiB of text, %d MiB of results "
-                                         "written into the caller's arrays; they cross PCIe narrowed to the fewest bytes per entry that hold "
-                                         "their largest value (SA / ISA 4 of %d bytes at this size, LCP 1 on random text) through a ring of pinned "
+                                         "written into the caller's arrays; %s through a ring of pinned "
                                          "buffers and are widened by host threads; second call on touched pageable memory"
-                                         % (bits, hn >> 20, (hn * w * (2 if a.no_lcp else 3)) >> 20, w)}
+                                         % (bits, hn >> 20, (hn * w * (2 if a.no_lcp else 3)) >> 20, narrowed)}
+        # BASELINE's metric in its own sense (SURVEY 8(d) Metric 1 = n / construct() wall time with H2D of the text and D2H of SA / ISA / LCP)
+        out["value_metric1"] = out["construct_host"]["MChars_per_s"]
+        out["value_metric1_definition"] = ("MChars/s of construct() on host pointers, PCIe copies included (SURVEY 8(d) Metric 1, what psac's own timer "
+                                           "spans, src/psac.cpp:95-121), n = %d; `value` is the device-resident rate" % hn)
         del text, hs
     if a.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(a.alphabet, min(a.cpu_sample, n), a.seed, bits)

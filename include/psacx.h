@@ -174,7 +174,8 @@ int psacx_check_dev_u64(psacx_ctx* ctx, const uint8_t* d_text, uint64_t n, const
  * src/psac.cpp:89-93): srand(1337 * seed), then "ACGT"[rand() % 4] per character (glibc rand; host memory).
  * psacx_synth_text_dev: the synthetic texts of the benchmark configurations written straight
  * into HBM: characters first .. first + n of kind 0 = DNA(seed), 1 = ASCII128(seed) (splitmix64 streams, the same
- * definition as tests/inputs.py), 2 = TANDEM: DNA(seed) repeated with `period`. */
+ * definition as tests/inputs.py), 2 = TANDEM: DNA(seed) repeated with `period`, 3 = MUTATED: that repeat with one position in
+ * 200 replaced (long shared prefixes that end somewhere: the repeated reads of a sequencing run, the human genome of pbs_run.sh:36). */
 int psacx_rand_dna(uint8_t* out, uint64_t n, int seed);
 int psacx_synth_text_dev(psacx_ctx* ctx, uint8_t* d_text, uint64_t n, uint64_t first, int kind, uint64_t seed,
                          uint64_t period);

@@ -56,7 +56,8 @@ int check_dev(psacx_ctx* c, const uint8_t* text, uint64_t n, const T* sa, const 
 
 // Synthetic benchmark texts of SURVEY.md section 8(d), generated where they are used: character g of
 // DNA(n, seed) is "ACGT"[z & 3], of ASCII128(n, seed) z & 127, with z the g-th output (counting from 1) of
-// splitmix64 started at `seed`; TANDEM repeats the first `period` characters of DNA(period, seed).
+// splitmix64 started at `seed`; TANDEM repeats the first `period` characters of DNA(period, seed); MUTATED is that repeat with one
+// position in 200 (chosen by a second stream over the absolute position) given a character of its own: repeated reads with mutations.
 // tests/inputs.py defines the same streams on the host.
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t g) {
     uint64_t z = seed + (g + 1) * 0x9E3779B97F4A7C15ull;
@@ -72,8 +73,13 @@ __global__ void synth_text_kernel(uint8_t* __restrict__ out, uint64_t n, uint64_
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             uint64_t g = first + i0 + j;
-            if (kind == 2) g %= period;
-            const uint64_t z = splitmix64_at(seed, g);
+            const uint64_t g_abs = g;
+            if (kind == 2 || kind == 3) g %= period;
+            uint64_t z = splitmix64_at(seed, g);
+            if (kind == 3) {           // one position in 200 carries its own character instead of the repeat's
+                const uint64_t m = splitmix64_at(seed ^ 0xA5A5A5A5A5A5A5A5ull, g_abs);
+                if (m % 200 == 0) z = m >> 8;
+            }
             b[j] = kind == 1 ? (uint8_t)(z & 127) : (uint8_t)"ACGT"[z & 3];
         }
         if (i0 + 16 <= n && ((uintptr_t)(out + i0) & 15) == 0) {
@@ -90,7 +96,7 @@ __global__ void synth_text_kernel(uint8_t* __restrict__ out, uint64_t n, uint64_
 }
 
 int synth_text_dev(psacx_ctx* c, uint8_t* d_text, uint64_t n, uint64_t first, int kind, uint64_t seed, uint64_t period) {
-    if (!c || !d_text || kind < 0 || kind > 2 || (kind == 2 && period == 0)) return PSACX_EINVAL;
+    if (!c || !d_text || kind < 0 || kind > 3 || (kind >= 2 && period == 0)) return PSACX_EINVAL;
     if (n == 0) return PSACX_OK;
     PSACX_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(synth_text_kernel, dim3(grid_for(c, n / 16 + 1, 256, 16)), dim3(256), 0, c->stream, d_text, n, first, kind, seed, period);

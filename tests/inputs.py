@@ -38,3 +38,14 @@ def tandem(n, period, unit):
 def cyclic(n, word):
     w = np.frombuffer(word.encode(), dtype=np.uint8)
     return np.tile(w, (n + w.size - 1) // w.size)[:n].copy()
+
+
+def mutated(n, period, seed):
+    """TANDEM(n, period, seed) with one position in 200 given a character of its own (psacx_synth_text_dev kind 3):
+    position g is mutated when the g-th output of the stream seeded seed ^ 0xA5A5A5A5A5A5A5A5 is a multiple of 200."""
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = tandem(n, period, dna(period, seed))
+    m = splitmix64_stream(n, seed ^ 0xA5A5A5A5A5A5A5A5)
+    hit = (m % np.uint64(200)) == 0
+    t[hit] = lut[((m[hit] >> np.uint64(8)) & np.uint64(3)).astype(np.int64)]
+    return t

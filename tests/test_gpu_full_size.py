@@ -20,7 +20,7 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-KIND = {"dna": 0, "ascii128": 1, "tandem": 2}
+KIND = {"dna": 0, "ascii128": 1, "tandem": 2, "mutated": 3}
 
 
 @pytest.fixture(scope="module")
@@ -56,8 +56,8 @@ def test_synthetic_text_generator_matches_the_host_definition(ctx):
     # the device generator against tests/inputs.py (the definition of SURVEY 8(d)), ragged length and offsets
     n = (1 << 20) + 13
     for kind, ref in (("dna", inputs.dna(n, 5)), ("ascii128", inputs.ascii128(n, 42)),
-                      ("tandem", inputs.tandem(n, 1024, inputs.dna(1024, 3)))):
-        seed = {"dna": 5, "ascii128": 42, "tandem": 3}[kind]
+                      ("tandem", inputs.tandem(n, 1024, inputs.dna(1024, 3))), ("mutated", inputs.mutated(n, 1024, 11))):
+        seed = {"dna": 5, "ascii128": 42, "tandem": 3, "mutated": 11}[kind]
         d = device_text(ctx, n, kind, seed)
         got = np.empty(n, np.uint8)
         ctx.d2h(got, d)
