@@ -5,6 +5,7 @@
 #include "../../include/psacx_ops.h"
 #include "construct.hpp"
 #include "nsv.hpp"
+#include "multi_plan.hpp"      // BlkDist (mxx::blk_dist) and the host-side plans
 
 namespace psacx {
 
@@ -14,18 +15,6 @@ __global__ void iota_from_kernel(T* __restrict__ out, uint64_t m, uint64_t start
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) out[i] = (T)(start + i);
 }
-
-struct BlkDist {       // mxx::blk_dist
-    uint64_t n, div, mod; unsigned P;
-    __host__ __device__ unsigned rank_of(uint64_t g) const {
-        const uint64_t big = (div + 1) * mod;
-        if (g < big) return (unsigned)(g / (div + 1));
-        return (unsigned)(mod + (g - big) / (div ? div : 1));
-    }
-    __host__ __device__ uint64_t off(unsigned r) const { return div * r + (r < mod ? r : mod); }
-    __host__ __device__ uint64_t size(unsigned r) const { return div + (r < mod ? 1 : 0); }
-};
-inline BlkDist make_dist(uint64_t n, unsigned P) { BlkDist d; d.n = n; d.P = P; d.div = n / P; d.mod = n % P; return d; }
 
 template <typename T>
 __global__ void owners_kernel(const T* __restrict__ g, uint64_t cnt, BlkDist d, T* __restrict__ out) {

@@ -1,5 +1,7 @@
 // multi.hip -- extern "C" surface of the multi-GPU construction (include/psacx.h, psacx_multi_*) over multi.hpp.
 #include "multi.hpp"
+#include "multi_first_round.hpp"     // members of MultiRun: the first round in two-word / one-word records
+#include "multi_queries.hpp"         // members of MultiRun: ANSV, left-branching characters, suffix-tree table, checker
 
 using namespace psacx;
 

@@ -37,6 +37,7 @@
 #include "ansv_seq.hpp"
 #include "shm_link.hpp"
 #include "slice_inv.hpp"
+#include "multi_kernels.hpp"
 
 namespace psacx {
 
@@ -215,11 +216,7 @@ private:
 
 template <typename T> struct Rec { DBuf<T> k1, k2, v; uint64_t cnt = 0; };
 
-inline std::vector<uint64_t> prefix_of(const std::vector<uint64_t>& x) {
-    std::vector<uint64_t> o(x.size() + 1, 0);
-    for (size_t i = 0; i < x.size(); ++i) o[i + 1] = o[i] + x[i];
-    return o;
-}
+using plan::prefix_of;
 
 template <typename T> __global__ void gather_at_kernel(const T* __restrict__ a, const uint64_t* __restrict__ idx, unsigned cnt, uint64_t* __restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,282 +245,6 @@ template <typename T> __global__ void prefix_cut_kernel(const T* __restrict__ k1
 template <typename T> __global__ void widen_text_kernel(const uint8_t* __restrict__ t, uint64_t cnt, T* __restrict__ out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)t[i];
-}
-
-// ---- kernels of the distributed left-branching characters (MultiRun::left_chars): the text position SA[i-1] + LCP[i] of
-//      every entry of a piece (prev_sa: SA of the entry before the piece; has_prev = 0 at global position 0 -> n = "none"),
-//      then the fetched characters narrowed to bytes ('\0' where the position is past the end, alphabet.hpp:168)
-template <typename T>
-__global__ void lc_queries_kernel(const T* __restrict__ SA, const T* __restrict__ LCP, uint64_t cnt, uint64_t n, int has_prev, T prev_sa,
-                                  T* __restrict__ q) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
-        uint64_t p = n;
-        if (i || has_prev) {
-            p = (uint64_t)(i ? SA[i - 1] : prev_sa) + (uint64_t)LCP[i];
-            if (p > n) p = n;
-        }
-        q[i] = (T)p;
-    }
-}
-template <typename T>
-__global__ void lc_narrow_kernel(const T* __restrict__ ch, const T* __restrict__ q, uint64_t cnt, uint64_t n, uint8_t* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
-        out[i] = (uint64_t)q[i] < n ? (uint8_t)ch[i] : (uint8_t)0;
-}
-
-// ---- kernels of the distributed ANSV (MultiRun::ansv).  Start positions travel as T with one added (0 = before
-//      position 0, n + 1 = past the end), "none" as all ones.
-template <typename T>
-__global__ void ansv_owner_kernel(const T* __restrict__ start1, uint64_t cnt, BlkDist d, T* __restrict__ cls) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        uint64_t s = (uint64_t)start1[j];
-        s = s ? s - 1 : 0;
-        if (s >= d.n) s = d.n - 1;
-        cls[j] = (T)d.rank_of(s);
-    }
-}
-// nearest element of this block strictly beyond start (left: below it) with value < thr (strict) or <= thr
-template <typename T>
-__global__ void nsv_from_enc_kernel(Pyramid<T> P, uint64_t m, uint64_t off, const T* __restrict__ start1, const T* __restrict__ thr,
-                                    uint64_t cnt, int strict, int left, T* __restrict__ out_idx, T* __restrict__ out_val) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const long long s = (long long)(uint64_t)start1[j] - 1 - (long long)off;          // block-relative, may be < 0 or >= m
-        const T v = thr[j];
-        uint64_t r = NSV_NONE;
-        if (m) {
-            if (left) {
-                if (s > 0) {
-                    if ((uint64_t)s >= m) {
-                        const T x = P.lvl[0][m - 1];
-                        r = (strict ? x < v : x <= v) ? m - 1 : (m > 1 ? nsv_search<T, true>(P, m - 1, v, strict != 0) : NSV_NONE);
-                    } else r = nsv_search<T, true>(P, (uint64_t)s, v, strict != 0);
-                }
-            } else if (s < (long long)m - 1) {
-                if (s < 0) {
-                    const T x = P.lvl[0][0];
-                    r = (strict ? x < v : x <= v) ? 0 : (m > 1 ? nsv_search<T, false>(P, 0, v, strict != 0) : NSV_NONE);
-                } else r = nsv_search<T, false>(P, (uint64_t)s, v, strict != 0);
-            }
-        }
-        out_idx[j] = r == NSV_NONE ? ~(T)0 : (T)(off + r);
-        out_val[j] = r == NSV_NONE ? (T)0 : P.lvl[0][r];
-    }
-}
-// open queries (idx == none): the nearest rank beyond the start's owner whose block minimum qualifies, P = none
-template <typename T>
-__global__ void ansv_target_kernel(const T* __restrict__ own, const T* __restrict__ thr, const T* __restrict__ idx, uint64_t cnt, RankMins mins,
-                                   RankMins sizes, int P, int strict, int left, T* __restrict__ target) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        int t = P;
-        if (idx[j] == ~(T)0) {
-            const unsigned long long v = (unsigned long long)thr[j];
-            const int o = (int)own[j];
-            if (left) { for (int b = o - 1; b >= 0; --b) if (sizes.v[b] && (strict ? mins.v[b] < v : mins.v[b] <= v)) { t = b; break; } }
-            else { for (int b = o + 1; b < P; ++b) if (sizes.v[b] && (strict ? mins.v[b] < v : mins.v[b] <= v)) { t = b; break; } }
-        }
-        target[j] = (T)t;
-    }
-}
-template <typename T>
-__global__ void ansv_merge_kernel(T* __restrict__ idx, T* __restrict__ val, const T* __restrict__ idx2, const T* __restrict__ val2,
-                                  const T* __restrict__ target, uint64_t cnt, int P) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
-        if ((int)target[j] < P) { idx[j] = idx2[j]; val[j] = val2[j]; }
-}
-template <typename T>
-__global__ void fill_t_kernel(T* __restrict__ a, uint64_t cnt, T v) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) a[j] = v;
-}
-// local tile ANSV results (block-relative uint64, NSV_NONE = not inside the block) -> idx (global T, all ones = open) and value found
-template <typename T>
-__global__ void ansv_local_to_idx_kernel(const uint64_t* __restrict__ loc, const T* __restrict__ block, uint64_t cnt, uint64_t off,
-                                         T* __restrict__ idx, T* __restrict__ val) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const uint64_t r = loc[j];
-        idx[j] = r == NSV_NONE ? ~(T)0 : (T)(off + r);
-        val[j] = r == NSV_NONE ? (T)0 : block[r];
-    }
-}
-// start positions (plus one) for the follow-up searches of furthest_eq
-template <typename T>
-__global__ void ansv_next_start_kernel(const T* __restrict__ idx, uint64_t cnt, T when_none1, T* __restrict__ start1) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
-        start1[j] = idx[j] == ~(T)0 ? when_none1 : (T)(idx[j] + 1);
-}
-template <typename T>
-__global__ void ansv_finish_kernel(const T* __restrict__ first, const T* __restrict__ far, int use_far, uint64_t cnt, uint64_t nonsv,
-                                   uint64_t* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const T a = first[j];
-        const T r = (use_far && a != ~(T)0) ? far[j] : a;
-        out[j] = r == ~(T)0 ? nonsv : (uint64_t)r;
-    }
-}
-
-// Distributed check, per block (see MultiRun::check).  For SA position p = off + i:
-//   back[i] = ISA[SA[p]] (must be p), ch[i] = S[SA[p]], nx[i] = ISA[SA[p] + 1] (undefined when SA[p] + 1 == n).
-// Queries of the LCP recurrence: LCP[p] = 0 if the first characters differ, 1 if the smaller suffix is one character
-// long, else 1 + min(LCP[ISA[SA[p-1]+1] + 1 .. ISA[SA[p]+1]]).
-template <typename T>
-__global__ void check_queries_kernel(const T* __restrict__ SA, const T* __restrict__ ch, const T* __restrict__ nx, uint64_t cnt, uint64_t n,
-                                     int has_prev, T prev_sa, T prev_ch, T prev_nx, T* __restrict__ qlo, T* __restrict__ qhi) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
-        T lo = 0, hi = 1;                                   // a harmless query where none is needed
-        if (i > 0 || has_prev) {
-            const uint64_t a = i ? (uint64_t)SA[i - 1] : (uint64_t)prev_sa, b = SA[i];
-            const T ca = i ? ch[i - 1] : prev_ch, na = i ? nx[i - 1] : prev_nx;
-            if (a < n && b < n && ca == ch[i] && a + 1 < n && b + 1 < n && na < nx[i]) { lo = (T)(na + 1); hi = (T)(nx[i] + 1); }
-        }
-        qlo[i] = lo; qhi[i] = hi;
-    }
-}
-template <typename T>
-__global__ void check_verdict_kernel(const T* __restrict__ SA, const T* __restrict__ back, const T* __restrict__ ch, const T* __restrict__ nx,
-                                     const T* __restrict__ LCP, const T* __restrict__ mins, uint64_t cnt, uint64_t off, uint64_t n,
-                                     int has_prev, T prev_sa, T prev_ch, T prev_nx, unsigned long long* __restrict__ err) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned e0 = 0, e1 = 0, e2 = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
-        const uint64_t b = SA[i], p = off + i;
-        if (b >= n || (uint64_t)back[i] != p) { ++e0; continue; }
-        if (p == 0) { if (LCP && LCP[0] != 0) atomicAdd(&err[3], 1ull); continue; }
-        if (i == 0 && !has_prev) continue;
-        const uint64_t a = i ? (uint64_t)SA[i - 1] : (uint64_t)prev_sa;
-        if (a >= n) continue;                               // counted where it lives
-        const T ca = i ? ch[i - 1] : prev_ch, cb = ch[i];
-        const T na = i ? nx[i - 1] : prev_nx, nb = nx[i];
-        bool ok = ca < cb;
-        if (ca == cb) ok = (a + 1 == n) || (b + 1 < n && na < nb);
-        if (!ok) { ++e1; continue; }
-        if (LCP) {
-            uint64_t want;
-            if (ca != cb) want = 0;
-            else if (a + 1 == n) want = 1;
-            else want = 1 + (uint64_t)mins[i];
-            if ((uint64_t)LCP[i] != want) ++e2;
-        }
-    }
-    e0 = wave_reduce<uint32_t>(e0, OpSum()); e1 = wave_reduce<uint32_t>(e1, OpSum()); e2 = wave_reduce<uint32_t>(e2, OpSum());
-    if (lane_id() == 0) {
-        if (e0) atomicAdd(&err[0], (unsigned long long)e0);
-        if (e1) atomicAdd(&err[1], (unsigned long long)e1);
-        if (e2) atomicAdd(&err[2], (unsigned long long)e2);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// number of leading entries <= key of a non-decreasing array (one thread)
-// ---- string sets (construct_ss on p ranks, suffix_array.hpp:267-363): for the positions base .. base + cnt of the text,
-// slen = characters to the end of the string holding the position, soff = characters from its start (off: the nstr + 1
-// global string offsets).  Positions past the end of the text count as strings of one character.
-template <typename T>
-__global__ void string_pos_kernel(const uint64_t* __restrict__ off, uint64_t nstr, uint64_t n, uint64_t base, uint64_t cnt, T* __restrict__ slen,
-                                  T* __restrict__ soff) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const uint64_t i = base + j;
-        if (i >= n) { if (slen) slen[j] = (T)1; if (soff) soff[j] = (T)0; continue; }
-        uint64_t lo = 0, hi = nstr;              // largest t with off[t] <= i
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
-        if (slen) slen[j] = (T)(off[lo + 1] - i);
-        if (soff) soff[j] = (T)(i - off[lo]);
-    }
-}
-// the ranks a rank answers for "the suffix h further" in a string set: none (all ones) when that suffix starts in another
-// string, i.e. when the position lies fewer than h characters into its own string (shifting.hpp:374-418)
-template <typename T>
-__global__ void mask_by_string_kernel(const T* __restrict__ isa, const T* __restrict__ soff, uint64_t m, uint64_t h, T* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = (uint64_t)soff[j] >= h ? isa[j] : ~(T)0;
-}
-template <typename T>
-__global__ void finish_b2_masked_kernel(const T* __restrict__ ans, const T* __restrict__ q, uint64_t cnt, uint64_t n, T* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride)
-        out[j] = ((uint64_t)q[j] < n && ans[j] != ~(T)0) ? (T)(ans[j] + 1) : (T)0;
-}
-
-// ---- suffix-tree node table over block-distributed SA / LCP (suffix_tree.hpp:43-223 for_each_parent, :440-499)
-// For the LCP index i = off + j: the parent of leaf n + i and (when there is one) of internal node i, from the ANSV of LCP
-// (left furthest_eq, right nearest_sm, suffix_tree.hpp:62) and the LCP values found there; q = the text position whose
-// character labels the edge.  An index without an internal-node record gets parent = i and q2 = ST_NOREC.
-constexpr uint64_t ST_NOREC = ~0ull;
-template <typename T>
-__global__ void st_parents_kernel(const T* __restrict__ LCP, const T* __restrict__ SA, uint64_t m, uint64_t off, uint64_t n,
-                                  const uint64_t* __restrict__ lnsv, const uint64_t* __restrict__ rnsv, const T* __restrict__ lcp_l,
-                                  const T* __restrict__ lcp_r, int has_next, T next_lcp, T* __restrict__ p1, uint64_t* __restrict__ q1,
-                                  T* __restrict__ p2, uint64_t* __restrict__ q2) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-        const uint64_t i = off + j, ln = lnsv[j], rn = rnsv[j], sa = SA[j], li = LCP[j];
-        const uint64_t lnext = j + 1 < m ? (uint64_t)LCP[j + 1] : (has_next ? (uint64_t)next_lcp : 0);
-        const uint64_t lv = ln != NSV_NONE ? (uint64_t)lcp_l[j] : 0, rv = rn != NSV_NONE ? (uint64_t)lcp_r[j] : 0;
-        uint64_t parent, lcp_val;
-        if (i == 0) { lcp_val = n > 1 ? lnext : 0; parent = lcp_val > 0 ? 1 : 0; }
-        else if (i == n - 1 || li >= lnext) {
-            lcp_val = lv;
-            if (ln != NSV_NONE && lcp_val == li) parent = ln; else { parent = i; lcp_val = li; }
-        } else { parent = i + 1; lcp_val = lnext; }
-        p1[j] = (T)parent; q1[j] = sa + lcp_val;
-        bool rec = !(i == 0 || li == 0);
-        if (rec) {
-            if (rn == NSV_NONE) { if (lv == li) rec = false; else { parent = ln; lcp_val = lv; } }
-            else if (lv >= rv) { if (lv == li) rec = false; else { parent = ln; lcp_val = lv; } }
-            else { parent = rn; lcp_val = rv; }
-        }
-        p2[j] = rec ? (T)parent : (T)i;
-        q2[j] = rec ? sa + lcp_val : ST_NOREC;
-    }
-}
-// the positions as index words for the bulk fetch (past the end / no record: position 0, the answer is not used)
-template <typename T>
-__global__ void st_positions_kernel(const uint64_t* __restrict__ q, uint64_t m, uint64_t n, T* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = q[j] < n ? (T)q[j] : (T)0;
-}
-template <typename T>
-__global__ void st_nsv_positions_kernel(const uint64_t* __restrict__ q, uint64_t m, T* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = q[j] != NSV_NONE ? (T)q[j] : (T)0;
-}
-// what travels to the owner of the parent's row: x = the LCP index the child stands for, y = column | leaf flag << 16
-// (0xFFFF: no record)
-template <typename T>
-__global__ void st_payload_kernel(const uint64_t* __restrict__ q, const T* __restrict__ ch, uint64_t m, uint64_t off, uint64_t n, CodeTable tab,
-                                  int leaf, T* __restrict__ x, T* __restrict__ y) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-        x[j] = (T)(off + j);
-        if (q[j] == ST_NOREC) y[j] = (T)0xFFFFu;
-        else y[j] = (T)((q[j] < n ? (unsigned)tab.c[(unsigned)ch[j] & 255u] : 0u) | ((unsigned)leaf << 16));
-    }
-}
-template <typename T>
-__global__ void st_put_kernel(unsigned long long* __restrict__ nodes, uint64_t off, uint64_t row, const T* __restrict__ pos, const T* __restrict__ x,
-                              const T* __restrict__ y, uint64_t cnt, uint64_t n) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += stride) {
-        const unsigned yy = (unsigned)y[j];
-        if ((yy & 0xFFFFu) == 0xFFFFu) continue;
-        nodes[((uint64_t)pos[j] - off) * row + (yy & 0xFFFFu)] = (yy >> 16) ? n + (uint64_t)x[j] : (uint64_t)x[j];
-    }
-}
-
-template <typename T> __global__ void upper_bound_kernel(const T* __restrict__ a, uint64_t n, uint64_t key, uint64_t* __restrict__ out) {
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)a[mid] <= key) lo = mid + 1; else hi = mid; }
-    *out = lo;
 }
 
 template <typename T>
@@ -929,7 +650,7 @@ struct MultiRun {
     // receive arrays exist already.  done (optional): one event per local rank that is recorded on its second stream when its
     // messages have arrived; the compute streams are then NOT made to wait (the caller waits on the events when it needs the
     // data, so that later exchanges run under earlier local work).
-    struct Msg { int peer; uint64_t off, cnt; };
+    typedef plan::Msg Msg;          // (cnt elements at element offset off of the local array, to / from rank peer)
     int transfer(const std::vector<std::vector<const void*>>& in, const std::vector<std::vector<void*>>& out, const std::vector<size_t>& esz,
                  const std::vector<std::vector<Msg>>& sends, const std::vector<std::vector<Msg>>& recvs, std::vector<hipEvent_t>* done = nullptr) {
         const int na = (int)esz.size();
@@ -1195,16 +916,7 @@ struct MultiRun {
         // period divides the spacing every sample of every rank carries the same key, and one rank received 2.8 blocks.)
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + 3 * SAMPLES, 0));
         PSACX_TRY(par([&](int i) -> int {
-            const uint64_t c = rec[i].cnt;
-            std::vector<uint64_t> pos;
-            for (int s = 0; s < SAMPLES && c; ++s) {
-                const uint64_t lo = (uint64_t)(((unsigned __int128)c * s) / SAMPLES), hi = (uint64_t)(((unsigned __int128)c * (s + 1)) / SAMPLES);
-                if (hi <= lo) continue;
-                uint64_t z = ((uint64_t)rank(i) << 32 | (uint64_t)s) + 0x9E3779B97F4A7C15ull * (sort_calls_ + 1);      // splitmix64
-                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-                const uint64_t p = lo + z % (hi - lo);
-                if (pos.empty() || pos.back() != p) pos.push_back(p);
-            }
+            const std::vector<uint64_t> pos = plan::sample_positions(rec[i].cnt, rank(i), sort_calls_, SAMPLES);
             std::vector<uint64_t> a, b;
             PSACX_TRY(fetch(i, rec[i].k1.p, pos, a));
             PSACX_TRY(fetch(i, rec[i].k2.p, pos, b));
@@ -1214,18 +926,13 @@ struct MultiRun {
         }));
         std::vector<uint64_t> all;
         PSACX_TRY(gather(1 + 3 * SAMPLES, mine, all));
-        struct Smp { uint64_t k1, k2, r, p; bool operator<(const Smp& o) const { return k1 != o.k1 ? k1 < o.k1 : k2 != o.k2 ? k2 < o.k2 : r != o.r ? r < o.r : p < o.p; }
-                     bool operator==(const Smp& o) const { return k1 == o.k1 && k2 == o.k2 && r == o.r && p == o.p; } };
+        typedef plan::Smp Smp;
         std::vector<Smp> flat;
         for (int r = 0; r < P; ++r) {
             const uint64_t* row = &all[(size_t)r * (1 + 3 * SAMPLES)];
             for (uint64_t s = 0; s < row[0]; ++s) flat.push_back(Smp{row[1 + 3 * s], row[2 + 3 * s], (uint64_t)r, row[3 + 3 * s]});
         }
-        std::sort(flat.begin(), flat.end());
-        std::vector<Smp> spl;
-        for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
-        std::sort(spl.begin(), spl.end());
-        spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
+        const std::vector<Smp> spl = plan::choose_splitters(std::move(flat), P);
         const uint32_t ns = (uint32_t)spl.size();
         std::vector<uint64_t> s1(ns + 1), s2(ns + 1), sr(ns + 1), sp(ns + 1);
         for (uint32_t s = 0; s < ns; ++s) { s1[s] = spl[s].k1; s2[s] = spl[s].k2; sr[s] = spl[s].r; sp[s] = spl[s].p; }
@@ -1289,9 +996,7 @@ struct MultiRun {
             return PSACX_OK;
         };
         for (int i = 0; i < L; ++i) {
-            const uint64_t gr = G[rank(i)];
-            bounds[i].assign(P + 1, c2[i]);
-            for (int d = 0; d < P; ++d) bounds[i][d] = std::min<uint64_t>(TP[d] > gr ? TP[d] - gr : 0, c2[i]);
+            bounds[i] = plan::rebalance_bounds(G[rank(i)], c2[i], TP);
             in[i] = {rec[i].k1.p, rec[i].k2.p, rec[i].v.p};
         }
         PSACX_TRY(exchange<T>(3, in, bounds, got, rc, recv3));
@@ -1314,18 +1019,8 @@ struct MultiRun {
         std::vector<std::vector<const void*>> in(L);
         std::vector<std::vector<void*>> out(L);
         for (int i = 0; i < L; ++i) {
-            const int me = rank(i);
-            const uint64_t g0 = held_from_[me], g1 = g0 + held_cnt_[me];
-            if (g0 < TP[me] || g0 - TP[me] != head_[i] || g1 < TP[me + 1]) { mg_set_err(g, "re-balance in place: a rank does not hold the tail of its block"); return PSACX_EINVAL; }
-            for (int d = 0; d < P; ++d) {
-                if (d == me) continue;
-                const uint64_t lo = std::max(g0, TP[d]), hi = std::min(g1, TP[d + 1]);
-                if (lo < hi) sends[i].push_back(Msg{d, head_[i] + (lo - g0), hi - lo});
-            }
-            for (int r = 0; r < P; ++r) {
-                if (r == me) continue;
-                const uint64_t lo = std::max(held_from_[r], TP[me]), hi = std::min(held_from_[r] + held_cnt_[r], TP[me + 1]);
-                if (lo < hi) recvs[i].push_back(Msg{r, lo - TP[me], hi - lo});
+            if (!plan::in_place_messages(rank(i), P, held_from_, held_cnt_, TP, head_[i], sends[i], recvs[i])) {
+                mg_set_err(g, "re-balance in place: a rank does not hold the tail of its block"); return PSACX_EINVAL;
             }
             T* b1 = rec[i].k1.p - head_[i]; T* b2 = rec[i].k2.p - head_[i]; T* b3 = rec[i].v.p - head_[i];
             in[i] = {b1, b2, b3}; out[i] = {b1, b2, b3};
@@ -1339,765 +1034,12 @@ struct MultiRun {
         return PSACX_OK;
     }
 
-    // Both words of the packed 2k-character window of the suffixes gidx[i][0 .. cnt[i]) (global positions), computed by the
-    // ranks that own those positions from their text blocks + halos (tbuf: block + 2k characters) and sent back in query
-    // order: the remote form of window_word2() for the suffixes that tie on the leading bits of word 1.
-    int dist_windows(const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, const std::vector<const T*>& gidx,
-                     const std::vector<uint64_t>& cnt, std::vector<DBuf<T>>& w1, std::vector<DBuf<T>>& w2) {
-        w1.clear(); w1.resize(L); w2.clear(); w2.resize(L);
-        auto answer = [&](int i, const T* q, uint64_t qn, T* o1, T* o2) -> int {
-            psacx_ctx* c = ctx(i);
-            OP_PROLOGUE(c);
-            if (qn) {
-                hipLaunchKernelGGL((window_at_kernel<T, 256>), dim3(grid_for(c, qn, 256, 16)), dim3(256), 0, c->stream, tbuf[i].p, S[i].m + two_k, S[i].off, q, qn,
-                                   tab, ks, o1, o2);
-                PSACX_HIP(c, hipGetLastError());
-            }
-            return PSACX_OK;
-        };
-        if (solo_) {
-            MG_OP(g, ctx(0), w1[0].alloc(ctx(0), cnt[0])); MG_OP(g, ctx(0), w2[0].alloc(ctx(0), cnt[0]));
-            MG_OP(g, ctx(0), answer(0, gidx[0], cnt[0], w1[0].p, w2[0].p));
-            return PSACX_OK;
-        }
-        std::vector<Rec<T>> routed(L);
-        std::vector<std::vector<uint64_t>> bounds(L), rc, rc2;
-        std::vector<std::vector<const T*>> in(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            DBuf<T> idx; MG_OP(g, c, idx.alloc(c, cnt[i]));
-            MG_OP(g, c, psacx_op_iota(c, idx.p, cnt[i], 0));
-            PSACX_TRY(route(i, gidx[i], idx.p, cnt[i], routed[i], bounds[i]));
-            in[i] = {routed[i].k2.p};
-            return PSACX_OK;
-        }));
-        std::vector<std::vector<DBuf<T>>> q, got;
-        PSACX_TRY(exchange<T>(1, in, bounds, q, rc));
-        std::vector<DBuf<T>> a1(L), a2(L);
-        std::vector<std::vector<uint64_t>> back_bounds(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, a1[i].alloc(c, q[i][0].n)); MG_OP(g, c, a2[i].alloc(c, q[i][0].n));
-            MG_OP(g, c, answer(i, q[i][0].p, q[i][0].n, a1[i].p, a2[i].p));
-            back_bounds[i] = prefix_of(rc[i]);
-            in[i] = {a1[i].p, a2[i].p};
-            return PSACX_OK;
-        }));
-        PSACX_TRY(exchange<T>(2, in, back_bounds, got, rc2));
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, w1[i].alloc(c, cnt[i])); MG_OP(g, c, w2[i].alloc(c, cnt[i]));
-            MG_OP(g, c, op_put(c, w1[i].p, routed[i].v.p, cnt[i], 0, got[i][0].p, 0));      // undo the routing permutation
-            MG_OP(g, c, op_put(c, w2[i].p, routed[i].v.p, cnt[i], 0, got[i][1].p, 0));
-            return PSACX_OK;
-        }));
-        return PSACX_OK;
-    }
-
-    // The first sort in two-word form (what the one-GPU engine does, construct.hpp "two stages"): the records are (word 1,
-    // suffix) only.  When the leading `lead` = bits1 - lo1 bits of word 1 separate almost every suffix of the whole text,
-    //   1. the shuffle goes by those leading bits alone -- splitters are prefix values and equal prefixes never part, so a
-    //      group of suffixes that tie on them is whole on one rank -- and moves two words per record instead of three;
-    //   2. the local sort is a prefix sort of two-word records on the leading bits (lead / 8 passes of 4w bytes per record
-    //      instead of all digits of both words at 6w);
-    //   3. the few suffixes that still tie are compacted, the full window of each is fetched from the rank that owns its text
-    //      (dist_windows), the groups are ordered by it (in registers when every group is tiny, else by a radix sort of the
-    //      compacted records) and written back; word 2 exists for those records only, which is all rebucket_first_kernel reads.
-    // rec[i]: k1 and v filled, k2 allocated but unused until step 3.  Returns PSACX_RETRY_ before anything has moved when the
-    // samples say the text is repetitive (many equal prefixes) or the prefixes cannot balance the ranks: the caller then runs
-    // the three-word path.
+    // ---------------------------------------------------------------- the first round in two-word / one-word records: multi_first_round.hpp
     static constexpr int PSACX_RETRY_ = 1;
-    int sort_first_two_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1,
-                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec_front) {
-        ++sort_calls_;
-        constexpr int SAMPLES = 8192;
-        // Shuffle by key ranges (default with more than one rank): every destination's share of the prefix space is cut into QR
-        // ranges, the block is partitioned once by (destination, range), range q of every destination travels in exchange q, and
-        // the receiver sorts range q -- complete and final as soon as it has landed -- on its compute stream while ranges
-        // q + 1 .. are still in flight on the second stream: the local sort runs under the shuffle (idxsort.hpp:58-62 sorts after
-        // its Alltoallv has returned).  PSACX_MULTI_SHUFFLE_BY_POSITION=1: the earlier form (pieces of the block by position,
-        // piece q + 1 partitioned while piece q travels, one local sort at the end).
-        const bool by_range = !solo_;
-        int QR = 1;
-        if (by_range) { QR = std::max(1, std::min(4, 64 / P)); if (pieces_env_ > 0) QR = std::max(1, std::min(64 / P, pieces_env_)); }
-        std::vector<uint64_t> spl;
-        {
-            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(1 + SAMPLES, 0));
-            PSACX_TRY(par([&](int i) -> int {
-                const uint64_t c = rec[i].cnt;
-                std::vector<uint64_t> pos;
-                for (int s = 0; s < SAMPLES && c; ++s) {
-                    const uint64_t lo = (uint64_t)(((unsigned __int128)c * s) / SAMPLES), hi = (uint64_t)(((unsigned __int128)c * (s + 1)) / SAMPLES);
-                    if (hi <= lo) continue;
-                    uint64_t z = ((uint64_t)rank(i) << 32 | (uint64_t)s) + 0x9E3779B97F4A7C15ull * (sort_calls_ + 1);      // splitmix64
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-                    const uint64_t p = lo + z % (hi - lo);
-                    if (pos.empty() || pos.back() != p) pos.push_back(p);
-                }
-                std::vector<uint64_t> a;
-                PSACX_TRY(fetch(i, rec[i].k1.p, pos, a));
-                mine[i][0] = pos.size();
-                for (size_t s = 0; s < pos.size(); ++s) mine[i][1 + s] = a[s] >> lo1;
-                return PSACX_OK;
-            }));
-            std::vector<uint64_t> all, flat;
-            PSACX_TRY(gather(1 + SAMPLES, mine, all));
-            for (int r = 0; r < P; ++r) {
-                const uint64_t* row = &all[(size_t)r * (1 + SAMPLES)];
-                flat.insert(flat.end(), row + 1, row + 1 + row[0]);
-            }
-            std::sort(flat.begin(), flat.end());
-            if (!trust && !flat.empty()) {
-                // equal prefixes among a few thousand samples of a 2^lead space: a repetitive text, whose tie groups are long
-                size_t dup = 0;
-                for (size_t j = 1; j < flat.size(); ++j) dup += flat[j] == flat[j - 1];
-                if (dup * 64 > flat.size()) return PSACX_RETRY_;
-            }
-            if (by_range) {
-                // P * QR key ranges, QR consecutive ones per destination (equal splitters leave a range empty: the class numbers
-                // must stay destination * QR + range)
-                for (int cc = 1; cc < P * QR && !flat.empty(); ++cc) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * cc / (size_t)(P * QR))]);
-            } else {
-                for (int d = 1; d < P && !flat.empty(); ++d) spl.push_back(flat[std::min(flat.size() - 1, flat.size() * d / P)]);
-                spl.erase(std::unique(spl.begin(), spl.end()), spl.end());
-            }
-            if (!trust && !flat.empty() && P > 1) {
-                // the share of the samples each destination would receive (destination = splitters <= prefix)
-                std::vector<size_t> share(P, 0);
-                for (uint64_t x : flat) share[std::min<size_t>((size_t)(std::upper_bound(spl.begin(), spl.end(), x) - spl.begin()) / (by_range ? QR : 1), P - 1)]++;
-                for (int d = 0; d < P; ++d) if ((double)share[d] * P > 1.06 * (double)flat.size()) return PSACX_RETRY_;
-            }
-        }
-        // The suffix a record stands for travels as a 32-bit entry while the text has at most 2^32 characters, else as a word.
-        const bool v32 = sizeof(T) == 8 && n <= (1ull << 32);
-        const size_t vb = v32 ? 4 : sizeof(T);
-        // record j of local rank i stands for suffix: the spec short suffixes first on rank 0 (n - 1 - j), then the block in order
-        auto payload_of = [&](int i, uint64_t a, uint64_t* spec_q, uint64_t* specn_q, uint64_t* voff_q) {
-            const uint64_t front = rank(i) == 0 ? spec_front : 0;
-            if (a == 0 && front) { *spec_q = front; *specn_q = n; *voff_q = 0; }          // (rank 0's block starts at position 0)
-            else { *spec_q = 0; *specn_q = 0; *voff_q = S[i].off + a - front; }
-        };
-        bool sorted_already = false;
-        if (by_range) {
-            const int NC = P * QR;
-            Splitters sp; std::memset(&sp, 0, sizeof(sp));
-            sp.n = (uint32_t)spl.size();
-            for (uint32_t s2 = 0; s2 < sp.n; ++s2) sp.k1[s2] = spl[s2];
-            constexpr uint64_t SPAN = 256 * 32;
-            std::vector<std::vector<uint64_t>> cnt_c(L, std::vector<uint64_t>((size_t)NC, 0));
-            std::vector<DBuf<uint8_t>> cls(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                const uint64_t cn = rec[i].cnt;
-                MG_OP(g, c, cls[i].alloc(c, cn + 16));
-                DBuf<unsigned long long> d_counts; MG_OP(g, c, d_counts.alloc(c, 64));
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_HIP(g, hipMemsetAsync(d_counts.p, 0, 64 * 8, c->stream));
-                if (cn) {
-                    const uint64_t one = (cn + SPAN - 1) / SPAN * SPAN;           // the whole block as one "piece"
-                    hipLaunchKernelGGL((classify_prefix_kernel<T>), dim3((unsigned)(one / SPAN)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, cn, lo1, sp, cls[i].p, one, d_counts.p);
-                    MG_HIP(g, hipGetLastError());
-                }
-                MG_OP(g, c, ensure_pinned(c, 64 * 8 + 65536 + 32768));
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d_counts.p, 64 * 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                const unsigned long long* h = reinterpret_cast<const unsigned long long*>(c->pinned + 32768);
-                for (int cc = 0; cc < NC; ++cc) cnt_c[i][cc] = h[cc];
-                return PSACX_OK;
-            }));
-            std::vector<uint64_t> table;                       // table[r * NC + destination * QR + range]
-            PSACX_TRY(gather(NC, cnt_c, table));
-            std::vector<Rec<T>> grp(L), rcv(L);
-            std::vector<std::vector<uint64_t>> rbase(L), soff(L);          // start of range q in the receive arrays; start of class c in the partitioned block
-            int rc_alloc = PSACX_OK;
-            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
-                const int me = rank(i);
-                rbase[i].assign(QR + 1, 0);
-                for (int q = 0; q < QR; ++q) { uint64_t t = 0; for (int r = 0; r < P; ++r) t += table[(size_t)r * NC + me * QR + q]; rbase[i][q + 1] = rbase[i][q] + t; }
-                soff[i] = prefix_of(cnt_c[i]);
-                rc_alloc = take3(i, grp[i], rec[i].cnt, false);
-            }
-            PSACX_TRY(agree(rc_alloc));
-            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, rcv[i], rbase[i][QR], false);
-            PSACX_TRY(agree(rc_alloc));
-            // one stable partition of the block by class; the suffix a record stands for is made up on the way
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                const uint64_t cn = rec[i].cnt;
-                if (!cn) return PSACX_OK;
-                SortScratch sc;
-                auto layout = [&](Arena& ar) { sc.d_base = ar.take<unsigned long long>((size_t)RADIX); sc.desc_bytes = sort_desc_bytes(cn); sc.d_desc = ar.take<char>(sc.desc_bytes); };
-                { Arena dry(nullptr); layout(dry); MG_OP(g, c, ensure_slab(c, dry.off + 4096)); }
-                Arena ar(c->slab);
-                layout(ar);
-                uint64_t sq, snq, vq;
-                payload_of(i, 0, &sq, &snq, &vq);
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_OP(g, c, piece_partition<T>(c, sc.d_desc, sc.d_base, rec[i].k1.p, cls[i].p, cn, grp[i].k1.p, grp[i].v.p, v32, sq, snq, vq));
-                return PSACX_OK;
-            }));
-            // the unpartitioned records are not needed any more: in the reduced-memory layout they sat in the rank's output arrays,
-            // which now serve as the second record set of the range sorts
-            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); drop3(i, rec[i]); cls[i].release(); }
-            std::vector<Rec<T>> alt(L);
-            for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) rc_alloc = take3(i, alt[i], rbase[i][QR], false);
-            PSACX_TRY(agree(rc_alloc));
-            mark("    sort: classify + partition");
-            // range q of every destination travels in exchanges 2 q (word 1) and 2 q + 1 (suffixes): all issued now, in order, on
-            // the second streams.  The narrow suffix entries of range q land at the start of the range's own word-sized region,
-            // so that the sort of an earlier range, which widens its entries in place, never touches a later range's input.
-            std::vector<std::vector<hipEvent_t>> done(2 * QR, std::vector<hipEvent_t>(L, nullptr));
-            auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
-            int rc = PSACX_OK;
-            for (int q = 0; q < 2 * QR && rc == PSACX_OK; ++q) for (int i = 0; i < L && rc == PSACX_OK; ++i)
-                if (hipSetDevice(ctx(i)->device) != hipSuccess || hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming) != hipSuccess) { mg_set_err(g, "two-word first sort: event creation failed"); rc = PSACX_EHIP; }
-            const uint64_t wide = sizeof(T) / vb;                // narrow entries per word
-            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
-                for (int arr = 0; arr < 2 && rc == PSACX_OK; ++arr) {
-                    std::vector<std::vector<Msg>> sends(L), recvs(L);
-                    std::vector<std::vector<const void*>> in(L);
-                    std::vector<std::vector<void*>> out(L);
-                    for (int i = 0; i < L; ++i) {
-                        const int me = rank(i);
-                        for (int d = 0; d < P; ++d) sends[i].push_back(Msg{d, soff[i][(size_t)d * QR + q], cnt_c[i][(size_t)d * QR + q]});
-                        uint64_t within = 0;
-                        for (int r = 0; r < P; ++r) {
-                            const uint64_t cn = table[(size_t)r * NC + me * QR + q];
-                            recvs[i].push_back(Msg{r, (arr == 0 ? rbase[i][q] : rbase[i][q] * wide) + within, cn});
-                            within += cn;
-                        }
-                        if (arr == 0) { in[i] = {grp[i].k1.p}; out[i] = {rcv[i].k1.p}; }
-                        else { in[i] = {grp[i].v.p}; out[i] = {rcv[i].v.p}; }
-                    }
-                    rc = transfer(in, out, {arr == 0 ? sizeof(T) : vb}, sends, recvs, &done[2 * q + arr]);
-                }
-            }
-            // the ranges, one after the other, as they arrive (a rank whose sort fails still waits for its messages and tells its peers:
-            // every path below runs the waits, drops the events and agrees on the outcome)
-            std::vector<std::vector<int32_t>> where(L, std::vector<int32_t>(QR, 0));
-            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
-                rc = (par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    MG_HIP(g, hipSetDevice(c->device));
-                    for (int s2 = 0; s2 < L; ++s2) { MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q][s2], 0)); MG_HIP(g, hipStreamWaitEvent(c->stream, done[2 * q + 1][s2], 0)); }
-                    const uint64_t b0 = rbase[i][q], tq = rbase[i][q + 1] - b0;
-                    if (!tq) return PSACX_OK;
-                    MG_OP(g, c, op_pair_sort<T>(c, rcv[i].k1.p + b0, (T*)nullptr, rcv[i].v.p + b0, alt[i].k1.p + b0, (T*)nullptr, alt[i].v.p + b0, tq, bits1, 0, &where[i][q], lo1,
-                                                false, 0, 0, v32));
-                    return PSACX_OK;
-                }));
-            }
-            // everything has arrived (and, with ranks in one process, has been pulled) before the partitioned copies go away
-            for (int i = 0; i < L; ++i) {
-                (void)hipSetDevice(ctx(i)->device);
-                for (int q = 0; q < 2 * QR; ++q) for (int s2 = 0; s2 < L; ++s2) if (done[q][s2]) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
-            }
-            for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
-            drop_events();
-            PSACX_TRY(agree(rc));
-            // the sorted ranges into one record set (a sort's result lies in the set its last executed pass wrote)
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_HIP(g, hipSetDevice(c->device));
-                int in_alt = 0;
-                for (int q = 0; q < QR; ++q) in_alt += where[i][q] != 0;
-                const bool to_alt = in_alt * 2 > QR;
-                for (int q = 0; q < QR; ++q) {
-                    const uint64_t b0 = rbase[i][q], tq = rbase[i][q + 1] - b0;
-                    if (!tq || (where[i][q] != 0) == to_alt) continue;
-                    Rec<T>& from = to_alt ? rcv[i] : alt[i]; Rec<T>& to = to_alt ? alt[i] : rcv[i];
-                    MG_HIP(g, hipMemcpyAsync(to.k1.p + b0, from.k1.p + b0, tq * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                    MG_HIP(g, hipMemcpyAsync(to.v.p + b0, from.v.p + b0, tq * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
-                }
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                drop3(i, grp[i]);
-                if (to_alt) { drop3(i, rcv[i]); rec[i] = std::move(alt[i]); } else { drop3(i, alt[i]); rec[i] = std::move(rcv[i]); }
-                rec[i].cnt = rbase[i][QR];
-                return PSACX_OK;
-            }));
-            sorted_already = true;
-            mark("    sort: shuffle by ranges + range sorts");
-        }
-        // prefix sort of (word 1, suffix) on the leading bits, then the ties
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            if (rec[i].cnt >= 1 && !sorted_already) {
-                Rec<T> alt;
-                PSACX_TRY(take3(i, alt, rec[i].cnt, false));
-                int32_t where = 0;
-                if (solo_) {
-                    // the first pass makes up the payload (the suffix a record stands for), as on one GPU
-                    MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, true, spec_front, n));
-                } else MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p, (T*)nullptr, rec[i].v.p, alt.k1.p, (T*)nullptr, alt.v.p, rec[i].cnt, bits1, 0, &where, lo1, false, 0, 0, v32));
-                if (where) swap3(rec[i], alt);
-                drop3(i, alt);
-            }
-            return PSACX_OK;
-        }));
-        return first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, false);
-    }
-
-    // Stage 2 of a first round that sorted (word 1, suffix) on the leading bits of word 1 only (rec[i]: k1, v sorted; word 1 may have lost the
-    // bits below the prefix: word1_gone): the suffixes that still tie are ordered by their full windows -- one rank with the text at hand: in
-    // place (tie_resolve_kernel); else compacted, their windows fetched from the ranks that own the text (dist_windows), ordered and written
-    // back -- and the records re-balanced to the block sizes.
-    int first_sort_ties(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1,
-                        const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool word1_gone) {
-        std::vector<uint64_t> ties(L, 0);
-        bool general_ties = !solo_;
-        const bool solo_packed = word1_gone;
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            PSACX_TRY(need_k2(i, rec[i]));
-            if (solo_ && rec[i].cnt) {
-                // one rank: the text is here, every tie group of at most 8 suffixes is ordered in place (tie_resolve_kernel, construct.hpp)
-                constexpr int TB = 256, TI = sizeof(T) == 8 ? 32 : 16, TG = 8;
-                DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
-                const uint64_t nb = (rec[i].cnt + (uint64_t)TB * TI - 1) / ((uint64_t)TB * TI);
-                hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, rec[i].k1.p, rec[i].v.p, rec[i].k2.p, rec[i].cnt, lo1,
-                                   (const uint8_t*)tbuf[i].p, S[i].m + two_k, tab, ks, big.p, solo_packed);
-                MG_HIP(g, hipGetLastError());
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) general_ties = true;
-            }
-            if (general_ties) MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p, rec[i].v.p, rec[i].cnt, lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &ties[i]));
-            return PSACX_OK;
-        }));
-        mark("    sort: local prefix sort");
-        if (!general_ties) { mark("    sort: ties"); return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets); }
-        // Reduced-memory layout: the compacted ties, their windows and the second record set of their sort are eight arrays of as many
-        // entries as there are ties -- on a repetitive text every suffix ties.  The records are then worked off in slabs of at most
-        // `cap` records that end where a group of equal prefixes ends (groups are independent of each other; a group longer than a
-        // slab is taken whole): the same steps on fewer records, every rank as many slabs as the one with the most.
-        uint64_t cap = 0;
-        if (diet && slab_cap) {
-            std::vector<uint64_t> all;
-            PSACX_TRY(gather1(ties, all));
-            const uint64_t tcap = std::max<uint64_t>(slab_cap / 2, 64);
-            for (uint64_t t : all) if (t > tcap) cap = tcap;
-        }
-        std::vector<uint64_t> at(L, 0), end(L, 0), tn(L, 0);
-        for (;;) {
-            if (!cap) for (int i = 0; i < L; ++i) { end[i] = rec[i].cnt; tn[i] = ties[i]; }
-            else PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                const uint64_t cnt = rec[i].cnt;
-                end[i] = cnt; tn[i] = 0;
-                if (at[i] >= cnt) return PSACX_OK;
-                if (cnt - at[i] > cap) {
-                    DBuf<unsigned long long> cut; MG_OP(g, c, cut.alloc(c, 2));
-                    unsigned long long* h = reinterpret_cast<unsigned long long*>(c->pinned + 32768);
-                    MG_HIP(g, hipSetDevice(c->device));
-                    auto ask = [&](uint64_t lo, uint64_t hi) -> int {
-                        h[0] = 0; h[1] = ~0ull;
-                        MG_HIP(g, hipMemcpyAsync(cut.p, h, 16, hipMemcpyHostToDevice, c->stream));
-                        hipLaunchKernelGGL((prefix_cut_kernel<T>), dim3(grid_for(c, hi - lo, 256, 8)), dim3(256), 0, c->stream, (const T*)rec[i].k1.p, lo, hi, lo1, cut.p, cut.p + 1);
-                        MG_HIP(g, hipGetLastError());
-                        MG_HIP(g, hipMemcpyAsync(h, cut.p, 16, hipMemcpyDeviceToHost, c->stream));
-                        MG_HIP(g, hipStreamSynchronize(c->stream));
-                        return PSACX_OK;
-                    };
-                    PSACX_TRY(ask(at[i] + 1, at[i] + cap + 1));              // the last group start inside the slab ...
-                    if (h[0]) end[i] = h[0];
-                    else {                                                   // ... or, a group longer than the slab, the end of that group
-                        PSACX_TRY(ask(at[i] + cap + 1, cnt));
-                        if (h[1] != ~0ull) end[i] = h[1];
-                    }
-                }
-                MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, (T*)nullptr, (T*)nullptr, (T*)nullptr, &tn[i]));
-                return PSACX_OK;
-            }));
-            std::vector<DBuf<T>> tpos(L), tk1(L), tv(L), w1, w2;
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, tpos[i].alloc(c, tn[i])); MG_OP(g, c, tk1[i].alloc(c, tn[i])); MG_OP(g, c, tv[i].alloc(c, tn[i]));
-                if (tn[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk)); }
-                return PSACX_OK;
-            }));
-            {
-                std::vector<const T*> q(L);
-                for (int i = 0; i < L; ++i) q[i] = tv[i].p;
-                PSACX_TRY(dist_windows(tbuf, two_k, tab, ks, q, tn, w1, w2));
-            }
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                const uint64_t n_t = tn[i];
-                if (!n_t) return PSACX_OK;
-                MG_HIP(g, hipSetDevice(c->device));
-                // every group is at most TG long: ordered in registers (tie_resolve_kernel reading both words from the arrays)
-                constexpr int TB_ = 256, TI_ = 16, TG_ = 8;
-                DBuf<unsigned long long> big; MG_OP(g, c, big.alloc(c, 1));
-                MG_HIP(g, hipMemsetAsync(big.p, 0, 8, c->stream));
-                const uint64_t nb = (n_t + (uint64_t)TB_ * TI_ - 1) / ((uint64_t)TB_ * TI_);
-                hipLaunchKernelGGL((tie_resolve_kernel<T, TB_, TI_, TG_, true>), dim3((unsigned)nb), dim3(TB_), 0, c->stream, w1[i].p, tv[i].p, w2[i].p, n_t, lo1,
-                                   (const uint8_t*)nullptr, (uint64_t)0, tab, ks, big.p);
-                MG_HIP(g, hipGetLastError());
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, big.p, 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                const T *s1 = w1[i].p, *s2 = w2[i].p, *sv = tv[i].p;
-                DBuf<T> b1, b2, bv;
-                if (*reinterpret_cast<unsigned long long*>(c->pinned + 32768)) {
-                    // some group is long (repetitive text): a stable sort of all tied records by the full window; the groups come in
-                    // ascending order of their prefix, so the sorted records go back to the same positions in order
-                    tk1[i].release();                                    // (word 1 of the ties came back with the windows)
-                    MG_OP(g, c, b1.alloc(c, n_t)); MG_OP(g, c, b2.alloc(c, n_t)); MG_OP(g, c, bv.alloc(c, n_t));
-                    int32_t where = 0;
-                    MG_OP(g, c, op_pair_sort<T>(c, w1[i].p, w2[i].p, tv[i].p, b1.p, b2.p, bv.p, n_t, bits1, bits2, &where));
-                    if (where) { s1 = b1.p; s2 = b2.p; sv = bv.p; }
-                }
-                hipLaunchKernelGGL((scatter_prefix_ties_kernel<T>), dim3(grid_for(c, n_t, 256, 16)), dim3(256), 0, c->stream, (const T*)tpos[i].p, n_t, s1, s2, sv,
-                                   rec[i].k1.p + at[i], rec[i].k2.p + at[i], rec[i].v.p + at[i]);
-                MG_HIP(g, hipGetLastError());
-                MG_HIP(g, hipStreamSynchronize(c->stream));          // (the compacted arrays go back to the cache when this scope ends)
-                return PSACX_OK;
-            }));
-            if (!cap) break;
-            std::vector<uint64_t> left(L), left_all;
-            for (int i = 0; i < L; ++i) { at[i] = end[i]; left[i] = rec[i].cnt - at[i]; }
-            PSACX_TRY(gather1(left, left_all));
-            bool more = false;
-            for (uint64_t x : left_all) more |= x != 0;
-            if (!more) break;
-            ++g->last_tie_slabs;
-        }
-        mark("    sort: ties");
-        return head_.empty() ? rebalance(rec, targets) : rebalance_in_place(rec, targets);
-    }
-
-    // The first sort in ONE-word records (the one-GPU engine's prefix_sort_1w, engine.hpp, spread over the ranks).  A record is
-    // (prefix of word 1 without its top digit) << sfield | suffix; the top digit is known from the record's place:
-    //   1. every rank counts the top digits of its block straight from the text (top_digit_hist_kernel); one all-gather of the 256 counts
-    //      gives every rank the exact size of every bucket on every rank -- no samples, no splitters;
-    //   2. the 256 buckets are dealt to the ranks in order, whole, so that every rank's share is as close to its block as whole buckets
-    //      allow (equal prefixes never part; the text's own distribution decides the balance: a text whose buckets cannot be dealt
-    //      within the slack of the record arrays takes the two-word path with its sampled splitters);
-    //   3. the pass on the top digit computes word 1 in registers and writes the one-word records bucket by bucket
-    //      (key_scatter1w_kernel): 1 byte read + 8 written per record, nothing else is ever written on the sender;
-    //   4. the buckets travel in QR groups per destination, each bucket's pieces from all senders landing back to back; a group is
-    //      complete when it has landed and its LSD passes (8 + 8 bytes per record and pass, radix_scatter1w_kernel) run on the compute
-    //      stream while the later groups are still in flight; the last pass writes word 1 and the suffixes as words.
-    // The suffixes shorter than 2k (the last 2k - 1 positions of the text) are made on the host -- every rank knows the tail of the text
-    // from the gather -- and placed at the head of their buckets, where the stable passes keep them in front of equal prefixes.
-    // Needs 64-bit words and n <= 2^34 (the payload field takes bits_for(n - 1) bits, the prefix the rest + 8: fewer than 1/16 of the suffixes
-    // of a random text tie).  Returns PSACX_RETRY_ before anything has moved.  *lo1_out: bits of word 1 below the sorted prefix.
-    int sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2,
-                            const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec,
-                            unsigned* lo1_out) {
-        if constexpr (sizeof(T) != 8) { return PSACX_RETRY_; }
-        else {
-        constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS, TILE = BLOCK * PSACX_1W_ITEMS;
-        constexpr int TAILB = 128;                                   // bytes of every block's end that travel with the counts (2k <= 128)
-        const unsigned nbits = bits_for(n - 1);
-        if (bits1 < 24 || nbits > 40) return PSACX_RETRY_;
-        // prefix bits that stay in the word: what the one-GPU rule asks for (bits_for(n - 1) + 3 leading bits, whole digits) as far as the word has room
-        const unsigned want_lead = (nbits + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
-        const unsigned low = std::min(std::min(64u - nbits, bits1 - (unsigned)RADIX_BITS), want_lead - (unsigned)RADIX_BITS);
-        const unsigned lead = low + RADIX_BITS, sfield = 64 - low, lo1 = bits1 - lead;
-        // Reduced-memory layout: a text that repeats itself, or one so long that few prefix bits fit beside the suffix (beyond 2^34 characters),
-        // stays in one-word records -- its many ties are ordered slab by slab (first_sort_ties), while the three-word records of the
-        // other forms would not fit the device at all (8.25 words per character against 3)
-        const bool ties_ok = trust || diet;
-        if (lead < nbits + 3 && !ties_ok) return PSACX_RETRY_;      // (too many suffixes would tie on the prefix)
-        if (lead < nbits + 1) return PSACX_RETRY_;
-        uint64_t min_m = sizes[0];
-        for (int r = 1; r < P; ++r) min_m = std::min(min_m, sizes[r]);
-        if (min_m < (uint64_t)TAILB || min_m < 2ull * two_k) return PSACX_RETRY_;
-        ++sort_calls_;
-        KeyShape ks0 = ks; ks0.spec = solo_ ? spec : 0;               // (one rank without the wire: the short suffixes are records of the kernel, as on one GPU)
-        // ---- 1. top digits of every block
-        std::vector<uint64_t> nrec(L), short_n(L);
-        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(RADIX + 2 + TAILB / 8, 0));
-        struct Scr { unsigned long long* base0; char* desc; unsigned* tile_hist0; unsigned long long* slab_tot0; uint64_t ntiles; unsigned slab0; size_t desc_bytes; };
-        std::vector<Scr> scr(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            const uint64_t m = S[i].m, end = S[i].off + m, first_short = n - spec;
-            short_n[i] = solo_ ? 0 : std::min<uint64_t>(m, end > first_short ? end - first_short : 0);
-            nrec[i] = m - short_n[i];
-            Scr& q = scr[i];
-            q.ntiles = (nrec[i] + TILE0 - 1) / TILE0;
-            q.slab0 = slab_tiles_for(q.ntiles);
-            // the scratch of the bucket passes on the receiving side lives in the same slab: sized now for the largest share a rank may accept
-            const uint64_t cap_rec = m + m / 8 + 256 + (uint64_t)TILE;
-            const uint64_t vt_ub = (cap_rec + TILE - 1) / TILE + (uint64_t)RADIX * 64 + 64;
-            const size_t need_b = 256 + (((size_t)vt_ub * RADIX * sizeof(unsigned) + 255) & ~(size_t)255) + (((size_t)(vt_ub / 16 + RADIX) * RADIX * 8 + 255) & ~(size_t)255) +
-                                  (size_t)RADIX * RADIX * 8 + 2 * (RADIX + 1) * 8 + 64 + (size_t)(vt_ub / 16 + RADIX) * sizeof(SlabInfo) + 4096;
-            const uint64_t stride = std::max<uint64_t>(64, m >> 20), samples = m / stride;
-            uint64_t slots = 1; while (slots < 4 * samples) slots <<= 1;
-            const size_t need_a = 256 + std::max<size_t>((((size_t)q.ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255) + (q.ntiles / q.slab0 + 2) * RADIX * 8, slots * 8) + 4096;
-            q.desc_bytes = std::max(need_a, need_b);
-            MG_OP(g, c, ensure_slab(c, q.desc_bytes + (size_t)RADIX * 8 + 8192));
-            MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-            Arena ar(c->slab);
-            q.base0 = ar.take<unsigned long long>((size_t)RADIX);
-            q.desc = ar.take<char>(q.desc_bytes);
-            q.tile_hist0 = reinterpret_cast<unsigned*>(q.desc + 256);
-            q.slab_tot0 = reinterpret_cast<unsigned long long*>(q.desc + 256 + (((size_t)q.ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
-            MG_HIP(g, hipSetDevice(c->device));
-            unsigned long long* h = reinterpret_cast<unsigned long long*>(c->pinned + 32768);
-            h[RADIX] = 0; h[RADIX + 1] = 0;
-            if (samples >= 1024 && !ties_ok) {
-                // does the block repeat itself massively?  (prefix_dup_probe_kernel, sa_kernels.hpp: such a text keeps the two-word path)
-                unsigned long long* table = reinterpret_cast<unsigned long long*>(q.desc + 256);
-                unsigned long long* d_dups = reinterpret_cast<unsigned long long*>(q.desc + 128);
-                MG_HIP(g, hipMemsetAsync(q.desc, 0, 256 + slots * 8, c->stream));
-                hipLaunchKernelGGL((prefix_dup_probe_kernel<uint64_t>), dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t*)tbuf[i].p, m + two_k, tab, ks0, lo1,
-                                   stride, samples, table, slots, d_dups);
-                MG_HIP(g, hipGetLastError());
-                MG_HIP(g, hipMemcpyAsync(h + RADIX, d_dups, 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                h[RADIX + 1] = samples;
-            }
-            if (q.ntiles) {
-                hipLaunchKernelGGL((top_digit_hist_kernel<uint64_t, BLOCK, ITEMS>), dim3((unsigned)q.ntiles), dim3(BLOCK), 0, c->stream, (const uint8_t*)tbuf[i].p, solo_ ? m : nrec[i],
-                                   m + two_k, tab, ks0, q.tile_hist0);
-                const uint64_t nslabs0 = (q.ntiles + q.slab0 - 1) / q.slab0;
-                hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs0), dim3(RADIX), 0, c->stream, q.tile_hist0, q.ntiles, q.slab_tot0, q.slab0);
-                hipLaunchKernelGGL(radix_top_scan_kernel<0>, dim3(1), dim3(RADIX), 0, c->stream, q.slab_tot0, nslabs0, q.base0);
-                MG_HIP(g, hipGetLastError());
-                MG_HIP(g, hipMemcpyAsync(h, q.base0, RADIX * 8, hipMemcpyDeviceToHost, c->stream));
-            } else std::memset(h, 0, RADIX * 8);
-            MG_HIP(g, hipMemcpyAsync(h + RADIX + 2, tbuf[i].p + m - TAILB, TAILB, hipMemcpyDeviceToHost, c->stream));
-            MG_HIP(g, hipStreamSynchronize(c->stream));
-            const uint64_t total = solo_ ? m : nrec[i];
-            for (int d = 0; d < RADIX; ++d) mine[i][d] = (d + 1 < RADIX ? h[d + 1] : total) - h[d];       // bucket sizes (the starts are their prefix sums)
-            for (int w = RADIX; w < RADIX + 2 + TAILB / 8; ++w) mine[i][w] = h[w];
-            return PSACX_OK;
-        }));
-        std::vector<uint64_t> table;                                 // table[r * W + b]
-        const int W = RADIX + 2 + TAILB / 8;
-        PSACX_TRY(gather(W, mine, table));
-        // ---- 2. the short suffixes (host), the buckets' sizes, their owners
-        {
-            uint64_t dups = 0, smp = 0;
-            for (int r = 0; r < P; ++r) { dups += table[(size_t)r * W + RADIX]; smp += table[(size_t)r * W + RADIX + 1]; }
-            if (!ties_ok && smp && dups * 8 > smp) return PSACX_RETRY_;
-        }
-        std::vector<std::vector<uint64_t>> short_words(RADIX);
-        if (!solo_ && spec) {
-            const uint8_t* tail = reinterpret_cast<const uint8_t*>(&table[(size_t)(P - 1) * W + RADIX + 2]);       // text[n - TAILB .. n)
-            for (uint64_t j = 0; j < spec; ++j) {                    // suffix n - 1 - j, j + 1 characters long: shortest first
-                const uint64_t pos = n - 1 - j;
-                uint64_t w1 = 0;
-                for (unsigned t = 0; t < ks.c1; ++t) {
-                    const uint64_t code = pos + t < n ? (uint64_t)tab.c[tail[(size_t)TAILB - 1 - j + t]] : 0ull;
-                    w1 = (ks.lc >= 64 ? 0ull : (w1 << ks.lc)) | code;
-                }
-                const uint64_t prefix = lo1 >= 64 ? 0ull : (w1 >> lo1);
-                short_words[(size_t)((prefix >> low) & (RADIX - 1))].push_back((prefix << sfield) | pos);
-            }
-        }
-        std::vector<uint64_t> tot(RADIX, 0), PT(RADIX + 1, 0);
-        for (int b = 0; b < RADIX; ++b) {
-            tot[b] = short_words[b].size();
-            for (int r = 0; r < P; ++r) tot[b] += table[(size_t)r * W + b];
-            PT[b + 1] = PT[b] + tot[b];
-        }
-        if (PT[RADIX] != n) { mg_set_err(g, "one-word first sort: the top-digit counts do not add up to the text"); return PSACX_EDEVICE; }
-        const std::vector<uint64_t> TP = prefix_of(targets);
-        std::vector<int> cut(P + 1, 0);                              // rank d owns the buckets cut[d] .. cut[d + 1] - 1
-        cut[P] = RADIX;
-        // rank d starts at the first bucket boundary at or behind the start of its block: every rank then holds a little more than the tail
-        // of its own block -- the head, at most one bucket, sits at the end of the rank before it and is received in front of the rank's own
-        // records, for which the arrays leave room (head_ / room_; rebalance_in_place): no copy of the record arrays to re-balance them
-        for (int d = 1; d < P; ++d) {
-            int b = cut[d - 1];
-            while (b < RADIX && PT[b] < TP[d]) ++b;
-            cut[d] = b;
-        }
-        std::vector<uint64_t> Gs(P), cs(P), Hs(P), rooms(P);
-        bool inplace = !solo_;
-        for (int d = 0; d < P; ++d) {
-            Gs[d] = PT[cut[d]]; cs[d] = PT[cut[d + 1]] - PT[cut[d]];
-            Hs[d] = Gs[d] - TP[d]; rooms[d] = std::max(Hs[d] + cs[d], sizes[d]);
-            if (rooms[d] > sizes[d] + sizes[d] / 8) {                 // (the slack of the reduced-memory layout's record arrays)
-                if (!trust) return PSACX_RETRY_;
-                inplace = false;
-            }
-        }
-        if (!inplace) for (int d = 0; d < P; ++d) { Hs[d] = 0; rooms[d] = cs[d]; }
-        *lo1_out = lo1;
-        // ---- 3. arrays: the partitioned block (grp), two record arrays of the rank's share (A, B) and the suffixes of the last pass (vout).
-        //      Reduced-memory layout: grp, the array that does not end up with word 1 and the suffixes are the rank's three output arrays.
-        const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
-        std::vector<DBuf<T>> grp(L), A(L), B(L), vout(L);
-        std::vector<uint64_t> share(L);
-        int rc_alloc = PSACX_OK;
-        for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
-            psacx_ctx* c = ctx(i);
-            const int me = rank(i);
-            drop3(i, rec[i]);
-            share[i] = cs[me];
-            const uint64_t ng = solo_ ? S[i].m : nrec[i], room = rooms[me];
-            const bool lend = diet && !S[i].out_busy && std::max(room, ng) <= S[i].out_cap;
-            DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];          // the array the last pass writes word 1 into
-            DBuf<T>& other = (npass & 1) ? A[i] : B[i];
-            if (lend) {
-                S[i].out_busy = true;
-                other.borrow(c, S[i].ISA, room);
-                vout[i].borrow(c, S[i].SA, room);
-                if (S[i].LCP && !solo_) grp[i].borrow(c, S[i].LCP, ng);
-            } else {
-                rc_alloc = other.alloc(c, room, reserve_of(i));
-                if (rc_alloc == PSACX_OK) rc_alloc = vout[i].alloc(c, room, reserve_of(i));
-            }
-            if (rc_alloc == PSACX_OK) rc_alloc = k1_final.alloc(c, room, reserve_of(i));
-            if (rc_alloc == PSACX_OK && !solo_ && !grp[i].p) rc_alloc = grp[i].alloc(c, ng, reserve_of(i));
-            if (rc_alloc != PSACX_OK) mg_set_err(g, "one-word first sort: record arrays: " + c->hip_err);
-        }
-        PSACX_TRY(agree(rc_alloc));
-        // ---- 4. the pass on the top digit, word 1 computed on the spot (one rank without the wire: straight into A)
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            Scr& q = scr[i];
-            if (!q.ntiles) return PSACX_OK;
-            MG_HIP(g, hipSetDevice(c->device));
-            MG_HIP(g, hipMemsetAsync(q.desc, 0, 256, c->stream));
-            const uint64_t cnt = solo_ ? S[i].m : nrec[i];
-            hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)q.ntiles), dim3(BLOCK), 0, c->stream, (const uint8_t*)tbuf[i].p, cnt, S[i].m + two_k, tab, ks0,
-                               reinterpret_cast<uint64_t*>(solo_ ? A[i].p : grp[i].p), (int)(lo1 + low), q.base0, q.tile_hist0, q.slab_tot0, reinterpret_cast<unsigned*>(q.desc),
-                               sort_chunk_for(cnt, true), q.slab0, lo1 | (sfield << 16), solo_ ? (uint64_t)0 : S[i].off);
-            MG_HIP(g, hipGetLastError());
-            return PSACX_OK;
-        }));
-        mark("    sort: keys + partition by the top digit");
-        // ---- 5. where everything lands: bucket b of rank `me` = [short suffixes][sender 0] .. [sender P - 1]
-        int QR = solo_ ? 1 : 4;
-        if (pieces_env_ > 0) QR = std::max(1, std::min(16, pieces_env_));
-        std::vector<std::vector<uint64_t>> boff(L, std::vector<uint64_t>(RADIX + 1, 0));       // start of bucket b in the rank's arrays
-        std::vector<std::vector<uint64_t>> sstart(L, std::vector<uint64_t>(RADIX + 1, 0));     // start of bucket b in the sender's partitioned block
-        for (int i = 0; i < L; ++i) {
-            const int me = rank(i);
-            uint64_t at = Hs[me];
-            for (int b = 0; b <= RADIX; ++b) { boff[i][b] = at; if (b < RADIX && b >= cut[me] && b < cut[me + 1]) at += tot[b]; }
-            for (int b = 0; b < RADIX; ++b) sstart[i][b + 1] = sstart[i][b] + mine[i][b];
-        }
-        // the buckets of a destination in QR ranges of about equal size (the same cuts on every rank: a sender must know the ranges of its destinations)
-        auto range_cuts = [&](int d) -> std::vector<int> {
-            const int nb = cut[d + 1] - cut[d];
-            const int qr = std::max(1, std::min(QR, nb));
-            const uint64_t sh = PT[cut[d + 1]] - PT[cut[d]];
-            std::vector<int> rc(QR + 1, cut[d + 1]);
-            rc[0] = cut[d];
-            for (int q = 1; q < qr; ++q) {
-                int b = rc[q - 1];
-                const uint64_t want = PT[cut[d]] + (uint64_t)(((unsigned __int128)sh * q) / qr);
-                while (b < cut[d + 1] && PT[b + 1] <= want) ++b;
-                rc[q] = std::max(b, rc[q - 1]);
-            }
-            return rc;
-        };
-        std::vector<std::vector<int>> rcuts(P);
-        for (int d = 0; d < P; ++d) rcuts[d] = range_cuts(d);
-        std::vector<std::vector<hipEvent_t>> done(QR, std::vector<hipEvent_t>(L, nullptr));
-        auto drop_events = [&]() { for (auto& v : done) for (int i = 0; i < L; ++i) if (v[i]) { (void)hipSetDevice(ctx(i)->device); (void)hipEventDestroy(v[i]); v[i] = nullptr; } };
-        int rc = PSACX_OK;
-        if (!solo_) {
-            for (int q = 0; q < QR && rc == PSACX_OK; ++q) for (int i = 0; i < L && rc == PSACX_OK; ++i) {
-                if (hipSetDevice(ctx(i)->device) != hipSuccess || hipEventCreateWithFlags(&done[q][i], hipEventDisableTiming) != hipSuccess) { mg_set_err(g, "one-word first sort: event creation failed"); rc = PSACX_EHIP; }
-            }
-            // the short suffixes at the head of their buckets (before the first exchange is issued: the copies are ordered on the compute streams,
-            // which the range sorts wait on anyway)
-            for (int i = 0; i < L && rc == PSACX_OK; ++i) {
-                const int me = rank(i);
-                (void)hipSetDevice(ctx(i)->device);
-                for (int b = cut[me]; b < cut[me + 1] && rc == PSACX_OK; ++b)
-                    if (!short_words[b].empty() && hipMemcpyAsync(A[i].p + boff[i][b], short_words[b].data(), short_words[b].size() * 8, hipMemcpyHostToDevice, ctx(i)->stream) != hipSuccess) {
-                        mg_set_err(g, "one-word first sort: copy of the short suffixes failed"); rc = PSACX_EHIP;
-                    }
-            }
-            // the messages from sender r to destination d in range q: one per bucket, neighbours joined where they are contiguous on both
-            // sides (always on the sender's; on the receiver's when no other sender's records and no short suffix lie between them).  Sender
-            // and receiver derive their lists from this one function.
-            struct Piece { uint64_t soff, roff, cnt; };
-            std::vector<std::vector<uint64_t>> bstart(P, std::vector<uint64_t>(RADIX + 1, 0));   // start of bucket b in rank d's arrays (as boff, for every rank)
-            for (int d = 0; d < P; ++d) { uint64_t at = Hs[d]; for (int b = 0; b <= RADIX; ++b) { bstart[d][b] = at; if (b < RADIX && b >= cut[d] && b < cut[d + 1]) at += tot[b]; } }
-            auto pieces = [&](int r, int d, int q) -> std::vector<Piece> {
-                std::vector<Piece> out;
-                uint64_t so = 0;
-                for (int b = 0; b < rcuts[d][q]; ++b) so += table[(size_t)r * W + b];
-                for (int b = rcuts[d][q]; b < rcuts[d][q + 1]; ++b) {
-                    const uint64_t cn = table[(size_t)r * W + b];
-                    uint64_t ro = bstart[d][b] + short_words[b].size();
-                    for (int r2 = 0; r2 < r; ++r2) ro += table[(size_t)r2 * W + b];
-                    if (cn) {
-                        if (!out.empty() && out.back().soff + out.back().cnt == so && out.back().roff + out.back().cnt == ro) out.back().cnt += cn;
-                        else out.push_back(Piece{so, ro, cn});
-                    }
-                    so += cn;
-                }
-                return out;
-            };
-            for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
-                std::vector<std::vector<Msg>> sends(L), recvs(L);
-                std::vector<std::vector<const void*>> in(L);
-                std::vector<std::vector<void*>> out(L);
-                for (int i = 0; i < L; ++i) {
-                    const int me = rank(i);
-                    for (int d = 0; d < P; ++d) for (const Piece& pc : pieces(me, d, q)) sends[i].push_back(Msg{d, pc.soff, pc.cnt});
-                    for (int r = 0; r < P; ++r) for (const Piece& pc : pieces(r, me, q)) recvs[i].push_back(Msg{r, pc.roff, pc.cnt});
-                    in[i] = {grp[i].p}; out[i] = {A[i].p};
-                }
-                rc = transfer(in, out, {sizeof(T)}, sends, recvs, &done[q]);
-            }
-        }
-        // ---- 6. the LSD passes inside the buckets of a range as soon as it has landed
-        std::vector<std::vector<std::vector<unsigned long long>>> tabs(L, std::vector<std::vector<unsigned long long>>(QR));
-        std::vector<uint64_t*> s1(L, nullptr);
-        for (int q = 0; q < QR && rc == PSACX_OK; ++q) {
-            rc = par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_HIP(g, hipSetDevice(c->device));
-                if (!solo_) for (int s2 = 0; s2 < L; ++s2) MG_HIP(g, hipStreamWaitEvent(c->stream, done[q][s2], 0));
-                std::vector<unsigned long long>& ht = tabs[i][q];
-                ht.assign(2 * (RADIX + 1), 0);
-                const int b0 = rcuts[rank(i)][q], b1 = rcuts[rank(i)][q + 1];
-                uint64_t cntq = 0;
-                for (int b = 0; b <= RADIX; ++b) ht[b] = boff[i][std::min(std::max(b, b0), b1)];
-                cntq = ht[RADIX] - ht[0];
-                if (!cntq) { if (!s1[i]) s1[i] = reinterpret_cast<uint64_t*>(((npass & 1) ? B[i] : A[i]).p); return PSACX_OK; }
-                const OneWordLayout lay = onew_layout<TILE>(ht.data(), (share[i] + TILE - 1) / TILE);
-                if (lay.need > scr[i].desc_bytes || lay.vtiles >= (1ull << 31)) { mg_set_err(g, "one-word first sort: scratch of the bucket passes too small"); return PSACX_EDEVICE; }
-                uint64_t* res = nullptr;
-                MG_OP(g, c, onew_bucket_passes(c, scr[i].desc, ht.data(), lay, reinterpret_cast<uint64_t*>(A[i].p), reinterpret_cast<uint64_t*>(B[i].p),
-                                               reinterpret_cast<uint64_t*>(vout[i].p), sfield, low, lo1, cntq, &res));
-                s1[i] = res;
-                return PSACX_OK;
-            });
-        }
-        // everything has arrived and every pass has run before the partitioned blocks and the tables go away
-        for (int i = 0; i < L; ++i) {
-            (void)hipSetDevice(ctx(i)->device);
-            if (!solo_) for (int q = 0; q < QR; ++q) for (int s2 = 0; s2 < L; ++s2) if (done[q][s2]) (void)hipStreamWaitEvent(ctx(i)->stream, done[q][s2], 0);
-        }
-        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); (void)hipStreamSynchronize(ctx(i)->stream); }
-        drop_events();
-        PSACX_TRY(agree(rc));
-        for (int i = 0; i < L; ++i) {
-            DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];
-            if (s1[i] && reinterpret_cast<T*>(s1[i]) != k1_final.p) { mg_set_err(g, "one-word first sort: word 1 ended in the wrong array"); return PSACX_EDEVICE; }
-            grp[i].release();
-            ((npass & 1) ? A[i] : B[i]).release();
-            rec[i] = Rec<T>();
-            rec[i].k1 = std::move(k1_final); rec[i].v = std::move(vout[i]); rec[i].cnt = share[i];
-            rec[i].k1.advance(Hs[rank(i)]); rec[i].v.advance(Hs[rank(i)]);
-            rec[i].k1.n = share[i]; rec[i].v.n = share[i];
-        }
-        if (inplace) {
-            head_.assign(L, 0); room_.assign(L, 0);
-            for (int i = 0; i < L; ++i) { head_[i] = Hs[rank(i)]; room_[i] = rooms[rank(i)]; }
-            held_from_ = Gs; held_cnt_ = cs;
-        }
-        g->last_one_word = true;
-        mark("    sort: shuffle by buckets + bucket passes");
-        const int rct = first_sort_ties(rec, targets, bits1, bits2, lo1, tbuf, two_k, tab, ks, true);
-        head_.clear(); room_.clear();
-        return rct;
-        }
-    }
+    int dist_windows(const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, const std::vector<const T*>& gidx, const std::vector<uint64_t>& cnt, std::vector<DBuf<T>>& w1, std::vector<DBuf<T>>& w2);
+    int sort_first_two_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1, const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec_front);
+    int first_sort_ties(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, unsigned lo1, const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool word1_gone);
+    int sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector<uint64_t>& targets, unsigned bits1, unsigned bits2, const std::vector<DBuf<uint8_t>>& tbuf, uint32_t two_k, const CodeTable& tab, const KeyShape& ks, bool trust, uint64_t spec, unsigned* lo1_out);
 
     // Stable partition of global positions `gidx` and one payload array by owner rank: the owner of every position
     // is computed into a class array, one pass of the radix scatter kernel over two-word records (position, payload)
@@ -2196,40 +1138,13 @@ struct MultiRun {
     template <typename V>
     int isa_by_slices_t(bool ids_in_isa) {
         constexpr unsigned WBMAX = sizeof(V) == 4 ? 14 : 13;
-        constexpr int PB = 512, PI = 16, TILE_BITS = 13;
+        constexpr int PB = 512, PI = 16;
         uint64_t max_m = 0;
         for (int r = 0; r < P; ++r) max_m = std::max(max_m, sizes[r]);
-        const unsigned kb = bits_for(max_m > 1 ? max_m - 1 : 1);
-        unsigned cap_bits = 0;
-        while ((2u << cap_bits) * (unsigned)P <= (unsigned)SLICE_MAX_CLASSES) ++cap_bits;        // most slice bits with P * 2^bits classes
-        unsigned wbmax = WBMAX;
-        if (slice_wb_env_) wbmax = std::min<unsigned>(WBMAX, std::max(4u, slice_wb_env_));     // (tests: levels on small inputs)
-        if (slice_s1_env_) cap_bits = std::min<unsigned>(cap_bits, slice_s1_env_);
-        unsigned s1 = std::min<unsigned>(cap_bits, kb > wbmax ? kb - wbmax : 0);
-        // a further level walks tiles of 2^13 pairs that must not straddle slices
-        if (kb - s1 > wbmax && kb - s1 < (unsigned)TILE_BITS) s1 = kb > (unsigned)TILE_BITS ? kb - TILE_BITS : 0;
-        const unsigned sb = kb - s1;
-        const unsigned spo = (unsigned)((max_m + (1ull << sb) - 1) >> sb);
-        const unsigned wb = std::min(sb, wbmax);
-        const unsigned rbits = sb - wb;
-        // levels of at most 9 bits each; a level's parent buckets (2^(shift + cb) pairs) must hold whole tiles, which only
-        // binds the last level when a test shrinks the windows below a tile
-        std::vector<unsigned> cbs;
-        if (rbits) {
-            const unsigned last_min = wb >= (unsigned)TILE_BITS ? 1u : std::min(rbits, (unsigned)TILE_BITS - wb);
-            unsigned nl = (rbits + 8) / 9;
-            cbs.assign(nl, 0);
-            for (unsigned j = 0; j < nl; ++j) cbs[j] = rbits / nl + (j < rbits % nl ? 1 : 0);
-            if (cbs.back() < last_min) {
-                const unsigned rest = rbits - last_min;
-                nl = 1 + (rest + 8) / 9;
-                cbs.assign(nl, 0);
-                for (unsigned j = 0; j + 1 < nl; ++j) cbs[j] = rest / (nl - 1) + (j < rest % (nl - 1) ? 1 : 0);
-                cbs.back() = last_min;
-            }
-        }
-        const unsigned levels2 = (unsigned)cbs.size();
-        const unsigned C = (unsigned)P * spo;
+        // slice / window / level widths (multi_plan.hpp: slice_shape)
+        const plan::SliceShape shape = plan::slice_shape(max_m, (unsigned)P, WBMAX, (unsigned)SLICE_MAX_CLASSES, slice_wb_env_, slice_s1_env_);
+        const unsigned sb = shape.sb, spo = shape.spo, wb = shape.wb, rbits = shape.rbits, levels2 = shape.levels2, C = shape.C;
+        const std::vector<unsigned>& cbs = shape.cbs;
         SliceMap map;
         map.div = n / P; map.mod = n % P; map.P = (unsigned)P; map.sb = sb; map.spo = spo; map.dshift = -1;
         if (map.mod == 0 && map.div && (map.div & (map.div - 1)) == 0) { map.dshift = 0; while ((1ull << map.dshift) < map.div) ++map.dshift; }
@@ -2293,10 +1208,7 @@ struct MultiRun {
         std::vector<std::vector<Cut>> blocks(L);
         std::vector<Ptrs> pk_(L), A0(L), A1(L), Bb(L);
         std::vector<unsigned*> cur(L, nullptr);
-        uint64_t G = spo;
-        if (diet) G = std::max<uint64_t>(1, std::max<uint64_t>(slice, max_m / 8) >> sb);     // (one rank without the wire: the levels work on a step's part of the class array)
-        if (slice_step_env_) G = slice_step_env_;
-        G = std::min<uint64_t>(G, spo);
+        const uint64_t G = plan::slices_per_step(shape, max_m, diet, slice_step_env_);     // (one rank without the wire: the levels work on a step's part of the class array)
         const uint64_t nsteps = (spo + G - 1) / G;
         const uint64_t step_cap = G << sb;
         std::vector<std::vector<uint64_t>> cstart(L);
@@ -2835,8 +1747,7 @@ struct MultiRun {
             }
             offs = prefix_of(sizes);
             n = offs[P];
-            for (int r = 0; r < P; ++r)            // suffix_array.hpp:226-227
-                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
+            if (!plan::follows_blk_dist(sizes)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }      // suffix_array.hpp:226-227
             for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
             if (n == 0) return PSACX_EINVAL;
             if (diet) {
@@ -3215,613 +2126,16 @@ struct MultiRun {
         return PSACX_OK;
     }
 
-    // ---------------------------------------------------------------- all nearest smaller values over a block-distributed array
-    // ansv<T, left_type, right_type, global_indexing> (ansv.hpp:2042-2051; gansv_impl :1304-1740 keeps per-rank stacks
-    // and exchanges unmatched prefix minima).  Here every element first searches its own block (the tile kernel of
-    // ansv_tile.hpp); a search that leaves the block goes to the nearest further block whose all-gathered minimum
-    // qualifies and is answered from that block's edge.  furthest_eq = nearest <=, then the first strictly smaller value
-    // beyond it, then back to the first value <= (three searches, ansv_common.hpp:20-22).
+    // ---------------------------------------------------------------- queries on a finished result: defined in multi_queries.hpp
+    // (all nearest smaller values, left-branching characters, suffix-tree node table, distributed checker)
     struct AnsvState { std::vector<const T*> block; std::vector<uint64_t> m; std::vector<Pyramid<T>> pyr; std::vector<DBuf<T>> pyr_mem; std::vector<uint64_t> mins; };
-
-    int ansv_pyramid(int i, const T* block, uint64_t m, Pyramid<T>& Pm, DBuf<T>& mem, uint64_t* block_min) {
-        psacx_ctx* c = ctx(i);
-        Pm = Pyramid<T>();
-        *block_min = ~0ull;
-        if (m == 0) return PSACX_OK;
-        uint64_t total = 0, len = m;
-        while (len > 64) { len = (len + 63) / 64; total += (len + 63) & ~63ull; }
-        MG_OP(g, c, mem.alloc(c, total + 64));
-        Pm.lvl[0] = const_cast<T*>(block); Pm.len[0] = m; Pm.nlev = 1;
-        len = m;
-        uint64_t at = 0;
-        OP_PROLOGUE(c);
-        while (len > 64 && Pm.nlev < PYR_MAX) {
-            len = (len + 63) / 64;
-            Pm.lvl[Pm.nlev] = mem.p + at; Pm.len[Pm.nlev] = len; at += (len + 63) & ~63ull;
-            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, len * 64, 256, 8)), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1],
-                               Pm.len[Pm.nlev - 1], Pm.lvl[Pm.nlev], len);
-            MG_HIP(g, hipGetLastError());
-            Pm.nlev++;
-        }
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(mem.p + at);
-        hipLaunchKernelGGL((top_min_kernel<T>), dim3(1), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1], Pm.len[Pm.nlev - 1], d);
-        MG_HIP(g, hipGetLastError());
-        MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d, 8, hipMemcpyDeviceToHost, c->stream));
-        MG_HIP(g, hipStreamSynchronize(c->stream));
-        *block_min = *reinterpret_cast<uint64_t*>(c->pinned + 32768);
-        return PSACX_OK;
-    }
-
-    // queries (start1 = start + 1, thr) of every local rank sent to rank cls[j] (< P; P = nowhere), answered there from
-    // that rank's block, answers back in query order.  idx / val: all ones / 0 where nothing was found or asked.
-    int ansv_ask(AnsvState& A, const std::vector<const T*>& cls, const std::vector<const T*>& start1, const std::vector<const T*>& thr,
-                 const std::vector<uint64_t>& cnt, bool strict, bool left, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val) {
-        std::vector<Rec<T>> ra(L), rb(L);
-        std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
-        std::vector<std::vector<const T*>> in(L);
-        std::vector<DBuf<T>> slot(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, slot[i].alloc(c, cnt[i]));
-            MG_OP(g, c, psacx_op_iota(c, slot[i].p, cnt[i], 0));
-            std::vector<uint64_t> bnd2;
-            PSACX_TRY(route_by(i, cls[i], start1[i], thr[i], cnt[i], ra[i], bounds[i]));
-            PSACX_TRY(route_by(i, cls[i], start1[i], slot[i].p, cnt[i], rb[i], bnd2));
-            in[i] = {ra[i].k2.p, ra[i].v.p};
-            return PSACX_OK;
-        }));
-        // class P ("nowhere") is the tail of the routed arrays: it is simply not sent (bounds[P] = its start)
-        std::vector<std::vector<DBuf<T>>> q, got;
-        PSACX_TRY(exchange<T>(2, in, bounds, q, rc));
-        std::vector<DBuf<T>> ri(L), rv(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            const uint64_t qn = q[i][0].n;
-            MG_OP(g, c, ri[i].alloc(c, qn)); MG_OP(g, c, rv[i].alloc(c, qn));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (nsv_from_enc_kernel<T>), qn, A.pyr[i], A.m[i], S[i].off, q[i][0].p, q[i][1].p, qn, strict ? 1 : 0, left ? 1 : 0, ri[i].p, rv[i].p);
-            b2[i] = prefix_of(rc[i]);
-            in[i] = {ri[i].p, rv[i].p};
-            return PSACX_OK;
-        }));
-        PSACX_TRY(exchange<T>(2, in, b2, got, rc2));
-        idx.clear(); idx.resize(L); val.clear(); val.resize(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, idx[i].alloc(c, cnt[i])); MG_OP(g, c, val[i].alloc(c, cnt[i]));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], idx[i].p, cnt[i], (T)~(T)0);
-            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], val[i].p, cnt[i], (T)0);
-            const uint64_t back = got[i][0].n;            // answers come back for the queries that were sent, in routed order
-            MG_OP(g, c, op_put(c, idx[i].p, rb[i].v.p, back, 0, got[i][0].p, 0));
-            MG_OP(g, c, op_put(c, val[i].p, rb[i].v.p, back, 0, got[i][1].p, 0));
-            return PSACX_OK;
-        }));
-        return PSACX_OK;
-    }
-
-    // For every query the nearest element strictly beyond start (start1 - 1; -1 and n allowed) with value < thr (strict) or
-    // <= thr, towards lower positions if left.  have_local: idx / val already hold the answers of the block that owns the
-    // start (the tile kernel's pass); otherwise that block is asked first.
-    int ansv_search(AnsvState& A, const std::vector<const T*>& start1, const std::vector<const T*>& thr, const std::vector<uint64_t>& cnt,
-                    bool strict, bool left, bool have_local, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val) {
-        const BlkDist bd = make_dist(n, (unsigned)P);
-        std::vector<DBuf<T>> own(L);
-        std::vector<const T*> cls(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, own[i].alloc(c, cnt[i]));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (ansv_owner_kernel<T>), cnt[i], start1[i], cnt[i], bd, own[i].p);
-            cls[i] = own[i].p;
-            return PSACX_OK;
-        }));
-        if (!have_local) PSACX_TRY(ansv_ask(A, cls, start1, thr, cnt, strict, left, idx, val));
-        if (solo_) return PSACX_OK;
-        RankMins rm, rs;
-        for (int r = 0; r < 64; ++r) { rm.v[r] = r < P ? A.mins[r] : ~0ull; rs.v[r] = r < P ? sizes[r] : 0; }
-        std::vector<DBuf<T>> target(L), edge(L);
-        std::vector<const T*> tp(L), ep(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, target[i].alloc(c, cnt[i])); MG_OP(g, c, edge[i].alloc(c, cnt[i]));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (ansv_target_kernel<T>), cnt[i], own[i].p, thr[i], idx[i].p, cnt[i], rm, rs, P, strict ? 1 : 0, left ? 1 : 0, target[i].p);
-            SIMPLE_LAUNCH(c, (fill_t_kernel<T>), cnt[i], edge[i].p, cnt[i], (T)(left ? n + 1 : 0));     // beyond the target's far edge
-            tp[i] = target[i].p; ep[i] = edge[i].p;
-            return PSACX_OK;
-        }));
-        std::vector<DBuf<T>> i2, v2;
-        PSACX_TRY(ansv_ask(A, tp, ep, thr, cnt, strict, left, i2, v2));
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (ansv_merge_kernel<T>), cnt[i], idx[i].p, val[i].p, i2[i].p, v2[i].p, target[i].p, cnt[i], P);
-            return PSACX_OK;
-        }));
-        return PSACX_OK;
-    }
-
-    int ansv(const std::vector<const T*>& block, const std::vector<uint64_t>& m_local, int left_type, int right_type, uint64_t nonsv,
-             const std::vector<uint64_t*>& out_left, const std::vector<uint64_t*>& out_right) {
-        if (left_type < 0 || left_type > 2 || right_type < 0 || right_type > 2) return PSACX_EINVAL;
-        S.resize(L);
-        AnsvState A;
-        A.block = block; A.m = m_local; A.pyr.resize(L); A.pyr_mem.resize(L);
-        PSACX_TRY(par([&](int i) -> int {
-            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i];
-            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-            return PSACX_OK;
-        }));
-        {
-            std::vector<uint64_t> all;
-            PSACX_TRY(gather1(m_local, all));
-            sizes = all; offs = prefix_of(sizes); n = offs[P];
-            for (int r = 0; r < P; ++r)
-                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
-            for (int i = 0; i < L; ++i) S[i].off = offs[rank(i)];
-            if (n == 0) return PSACX_EINVAL;
-            if (diet) {
-                // (a refinement step holds up to seventeen arrays of a slab's length at once -- its records, their new ids and the queries and
-                //  answers of the range minima on both sides of an exchange -- beside the bucket ids and the list of unresolved positions:
-                //  with 1/32 of a block per step that stays below three words per character, BASELINE.json configs[4])
-                slab_cap = g->opt_slab ? g->opt_slab : slab_env_ ? slab_env_ : std::max<uint64_t>(sizes[0] / 32, 1u << 16);
-                if (slab_cap < 64) slab_cap = 64;
-                // (free blocks stay cached -- hipFree / hipMalloc of a 36 GB block cost about a second each -- and go back to the
-                //  device only when an allocation does not fit: pool_alloc)
-                for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = 0;
-                g->last_reduced = true;
-            } else for (int i = 0; i < L; ++i) ctx(i)->pool_cache_limit = std::max<size_t>((size_t)S[i].m * sizeof(T) * 16, (size_t)64 << 20);   // free blocks kept for reuse: at most sixteen block-sized arrays (a flush is hipFree + hipMalloc of everything: seconds with eight ranks)
-            if (sizeof(T) == 4 && n > 0xFFFFFFFDull) return PSACX_ERANGE;
-        }
-        std::vector<uint64_t> bm(L);
-        for (int i = 0; i < L; ++i) PSACX_TRY(ansv_pyramid(i, block[i], m_local[i], A.pyr[i], A.pyr_mem[i], &bm[i]));
-        PSACX_TRY(gather1(bm, A.mins));
-        // every element's own position (plus one) as the start of its first search
-        std::vector<DBuf<T>> here(L);
-        std::vector<const T*> herep(L);
-        PSACX_TRY(par([&](int i) -> int {
-            MG_OP(g, ctx(i), here[i].alloc(ctx(i), m_local[i]));
-            MG_OP(g, ctx(i), psacx_op_iota(ctx(i), here[i].p, m_local[i], S[i].off + 1));
-            herep[i] = here[i].p;
-            return PSACX_OK;
-        }));
-        for (int side = 0; side < 2; ++side) {
-            const bool left = side == 0;
-            const int typ = left ? left_type : right_type;
-            const std::vector<uint64_t*>& out = left ? out_left : out_right;
-            // first search inside the own block by the tile kernel (it fills both sides; the other side's array is scratch)
-            std::vector<DBuf<T>> idx(L), val(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, idx[i].alloc(c, m_local[i])); MG_OP(g, c, val[i].alloc(c, m_local[i]));
-                if (!m_local[i]) return PSACX_OK;
-                DBuf<uint64_t> other; MG_OP(g, c, other.alloc(c, m_local[i]));
-                const int t1 = typ == 0 ? 0 : 1;                       // strict, or nearest <=
-                MG_HIP(g, hipSetDevice(c->device));
-                if (left) launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], t1, 0, NSV_NONE, out[i], other.p);
-                else launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], 0, t1, NSV_NONE, other.p, out[i]);
-                MG_HIP(g, hipGetLastError());
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (ansv_local_to_idx_kernel<T>), m_local[i], out[i], block[i], m_local[i], S[i].off, idx[i].p, val[i].p);
-                return PSACX_OK;
-            }));
-            PSACX_TRY(ansv_search(A, herep, block, m_local, typ == 0, left, true, idx, val));
-            std::vector<DBuf<T>> far(L);
-            if (typ == 2) {
-                // s = first strictly smaller value beyond j (threshold: the value found at j), f = from s back towards i the first value <= it
-                std::vector<DBuf<T>> st2(L), st3(L), si, sv, fv;
-                std::vector<const T*> p2(L), p3(L), u(L);
-                PSACX_TRY(par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    MG_OP(g, c, st2[i].alloc(c, m_local[i]));
-                    OP_PROLOGUE(c);
-                    SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], idx[i].p, m_local[i], (T)(left ? n + 1 : 0), st2[i].p);
-                    p2[i] = st2[i].p; u[i] = val[i].p;
-                    return PSACX_OK;
-                }));
-                PSACX_TRY(ansv_search(A, p2, u, m_local, true, left, false, si, sv));
-                PSACX_TRY(par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    MG_OP(g, c, st3[i].alloc(c, m_local[i]));
-                    OP_PROLOGUE(c);
-                    SIMPLE_LAUNCH(c, (ansv_next_start_kernel<T>), m_local[i], si[i].p, m_local[i], (T)(left ? 0 : n + 1), st3[i].p);
-                    p3[i] = st3[i].p;
-                    return PSACX_OK;
-                }));
-                PSACX_TRY(ansv_search(A, p3, u, m_local, false, !left, false, far, fv));
-            }
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (ansv_finish_kernel<T>), m_local[i], idx[i].p, typ == 2 ? (const T*)far[i].p : (const T*)idx[i].p, typ == 2 ? 1 : 0,
-                              m_local[i], nonsv, out[i]);
-                return PSACX_OK;
-            }));
-        }
-        for (int i = 0; i < L; ++i) { MG_HIP(g, hipSetDevice(ctx(i)->device)); MG_HIP(g, hipStreamSynchronize(ctx(i)->stream)); }
-        return PSACX_OK;
-    }
-
-    // Left-branching characters of a block-distributed SA / LCP (suffix_array.hpp:211-212; the reference fills local_Lc
-    // inside its LCP code, :1365-1383 and par_rmq.hpp:334-481; the result is by definition Lc[i] = S[SA[i-1] + LCP[i]],
-    // desa.hpp:262-264, '\0' past the end and at i = 0): the last SA entry of every block goes to its right neighbour, the
-    // text positions are fetched from their owners through the engine's bulk-RMA exchange (dist_take), piece by piece so
-    // that a block that is a large share of its device fits.
-    int left_chars(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
-                   const std::vector<T*>& d_lcp, const std::vector<uint8_t*>& d_lc) {
-        want_lcp = true;
-        S.resize(L);
-        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); pool_flush(ctx(i)); }
-        PSACX_TRY(par([&](int i) -> int {
-            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
-            S[i].SA = d_sa[i]; S[i].ISA = nullptr; S[i].LCP = d_lcp[i];
-            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-            return PSACX_OK;
-        }));
-        uint64_t chunks = 1;
-        {
-            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
-            for (int i = 0; i < L; ++i) {
-                int same = 0;
-                for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
-                size_t fr = 0, tot = 0;
-                MG_HIP(g, hipSetDevice(ctx(i)->device));
-                MG_HIP(g, hipMemGetInfo(&fr, &tot));
-                // the widened text (1 word per character) stays; a piece wants about 12 words per entry
-                const double avail = 0.8 * (double)fr / same - (double)m_local[i] * sizeof(T), need = 12.0 * (double)m_local[i] * sizeof(T);
-                mine[i][0] = m_local[i];
-                mine[i][1] = check_chunks_env_ ? check_chunks_env_ : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
-            }
-            std::vector<uint64_t> all;
-            PSACX_TRY(gather(2, mine, all));
-            sizes.assign(P, 0);
-            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 2]; chunks = std::max(chunks, all[(size_t)r * 2 + 1]); }
-            chunks = std::min<uint64_t>(chunks, 4096);
-            offs = prefix_of(sizes); n = offs[P];
-            for (int r = 0; r < P; ++r)
-                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
-            for (int i = 0; i < L; ++i) { S[i].off = offs[rank(i)]; ctx(i)->pool_cache_limit = 0; }
-            if (n == 0) return PSACX_EINVAL;
-        }
-        std::vector<DBuf<T>> wide(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, wide[i].alloc(c, S[i].m));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
-            return PSACX_OK;
-        }));
-        // SA of the entry before every block
-        std::vector<psacx_boundary> edge;
-        {
-            std::vector<uint64_t> one(L);
-            std::vector<const T*> a1(L), a2(L), a3(L);
-            for (int i = 0; i < L; ++i) { one[i] = S[i].m ? 1 : 0; a1[i] = S[i].SA + (S[i].m ? S[i].m - 1 : 0); a2[i] = a1[i]; a3[i] = a1[i]; }
-            PSACX_TRY(neighbours(a1, a2, a3, one, 1, edge));
-        }
-        std::vector<uint64_t> carry(L, 0);                       // SA of the last entry of the previous piece
-        for (uint64_t q = 0; q < chunks; ++q) {
-            std::vector<uint64_t> from(L), cnt(L);
-            for (int i = 0; i < L; ++i) {
-                from[i] = (uint64_t)(((unsigned __int128)S[i].m * q) / chunks);
-                cnt[i] = (uint64_t)(((unsigned __int128)S[i].m * (q + 1)) / chunks) - from[i];
-            }
-            std::vector<DBuf<T>> qs(L), ch;
-            std::vector<const T*> blk(L), gi(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, qs[i].alloc(c, cnt[i]));
-                const int has_prev = from[i] ? 1 : edge[i].has_prev;
-                const uint64_t prev = from[i] ? carry[i] : edge[i].prev[0];
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (lc_queries_kernel<T>), cnt[i], S[i].SA + from[i], S[i].LCP + from[i], cnt[i], n, has_prev, (T)prev, qs[i].p);
-                if (cnt[i]) { std::vector<uint64_t> o; PSACX_TRY(fetch(i, S[i].SA + from[i], {cnt[i] - 1}, o)); carry[i] = o[0]; }
-                blk[i] = wide[i].p; gi[i] = qs[i].p;
-                return PSACX_OK;
-            }));
-            PSACX_TRY(dist_take(blk, gi, cnt, ch));
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (lc_narrow_kernel<T>), cnt[i], (const T*)ch[i].p, (const T*)qs[i].p, cnt[i], n, d_lc[i] + from[i]);
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                return PSACX_OK;
-            }));
-        }
-        return PSACX_OK;
-    }
-
-    // Suffix-tree node table of a block-distributed SA / LCP (construct_suffix_tree on p ranks, suffix_tree.hpp:413-499): rank r
-    // receives the rows of the LCP indices of its block, nodes[i][(sigma + 1) columns], column c = the child reached through
-    // the character with alphabet code c (0 = end of text), leaves numbered n + i, 0 = none.  Parents from the distributed
-    // ANSV of LCP (suffix_tree.hpp:62), the LCP values at the parents and the edge characters S[SA[i] + lcp] through the bulk
-    // fetch (dist_take), the cells to the owners of the parents' rows like bulk_permute's (index, value) pairs.
-    // d_nodes == nullptr: only *sigma is computed (the size query of psacx_suffix_tree_*).
-    int suffix_tree(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
-                    const std::vector<T*>& d_lcp, const std::vector<unsigned long long*>* d_nodes, uint32_t* sigma) {
-        want_lcp = true;
-        // ---- alphabet over all blocks (alphabet.hpp:147-164: codes 1 .. sigma in byte order)
-        CodeTable tab;
-        {
-            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(256, 0));
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-                DBuf<unsigned long long> h; MG_OP(g, c, h.alloc(c, 256));
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_HIP(g, hipMemsetAsync(h.p, 0, 256 * 8, c->stream));
-                if (m_local[i]) {
-                    hipLaunchKernelGGL((char_hist_kernel<256>), dim3(grid_for(c, m_local[i] / 16 + 1, 256, 8)), dim3(256), 0, c->stream, text[i], m_local[i], h.p);
-                    MG_HIP(g, hipGetLastError());
-                }
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, h.p, 256 * 8, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                std::memcpy(mine[i].data(), c->pinned + 32768, 256 * 8);
-                return PSACX_OK;
-            }));
-            std::vector<uint64_t> all;
-            PSACX_TRY(gather(256, mine, all));
-            uint16_t next = 1;
-            for (int ch = 0; ch < 256; ++ch) {
-                uint64_t tot = 0;
-                for (int r = 0; r < P; ++r) tot += all[(size_t)r * 256 + ch];
-                tab.c[ch] = tot ? next++ : (uint16_t)0;
-            }
-            *sigma = next - 1u;
-        }
-        if (!d_nodes) return PSACX_OK;
-        const uint64_t row = (uint64_t)*sigma + 1;
-        // ---- ANSV of LCP: left furthest_eq, right nearest_sm
-        std::vector<DBuf<uint64_t>> ln(L), rn(L);
-        {
-            std::vector<const T*> blk(L); std::vector<uint64_t*> ol(L), orr(L);
-            for (int i = 0; i < L; ++i) {
-                MG_OP(g, ctx(i), ln[i].alloc(ctx(i), m_local[i])); MG_OP(g, ctx(i), rn[i].alloc(ctx(i), m_local[i]));
-                blk[i] = d_lcp[i]; ol[i] = ln[i].p; orr[i] = rn[i].p;
-            }
-            PSACX_TRY(ansv(blk, m_local, 2, 0, NSV_NONE, ol, orr));          // (sets sizes / offs / n)
-        }
-        S.resize(L);
-        for (int i = 0; i < L; ++i) {
-            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i]; S[i].SA = d_sa[i]; S[i].ISA = nullptr; S[i].LCP = d_lcp[i];
-            S[i].off = offs[rank(i)];
-        }
-        // ---- LCP at the two parents; the first LCP entry of the next block
-        std::vector<DBuf<T>> lcp_l, lcp_r;
-        {
-            std::vector<DBuf<T>> pl(L), pr(L);
-            std::vector<const T*> blk(L), g1(L), g2(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, pl[i].alloc(c, S[i].m)); MG_OP(g, c, pr[i].alloc(c, S[i].m));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (st_nsv_positions_kernel<T>), S[i].m, (const uint64_t*)ln[i].p, S[i].m, pl[i].p);
-                SIMPLE_LAUNCH(c, (st_nsv_positions_kernel<T>), S[i].m, (const uint64_t*)rn[i].p, S[i].m, pr[i].p);
-                blk[i] = S[i].LCP; g1[i] = pl[i].p; g2[i] = pr[i].p;
-                return PSACX_OK;
-            }));
-            PSACX_TRY(dist_take(blk, g1, m_local, lcp_l));
-            PSACX_TRY(dist_take(blk, g2, m_local, lcp_r));
-        }
-        std::vector<psacx_boundary> edge;
-        {
-            std::vector<const T*> a1(L);
-            for (int i = 0; i < L; ++i) a1[i] = S[i].LCP;
-            PSACX_TRY(neighbours(a1, a1, a1, m_local, 1, edge));
-        }
-        // ---- parents and edge positions, edge characters
-        std::vector<DBuf<T>> p1(L), p2(L);
-        std::vector<DBuf<uint64_t>> q1(L), q2(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, p1[i].alloc(c, S[i].m)); MG_OP(g, c, p2[i].alloc(c, S[i].m)); MG_OP(g, c, q1[i].alloc(c, S[i].m)); MG_OP(g, c, q2[i].alloc(c, S[i].m));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (st_parents_kernel<T>), S[i].m, (const T*)S[i].LCP, (const T*)S[i].SA, S[i].m, S[i].off, n, (const uint64_t*)ln[i].p, (const uint64_t*)rn[i].p,
-                          (const T*)lcp_l[i].p, (const T*)lcp_r[i].p, (int)edge[i].has_next, (T)edge[i].next[0], p1[i].p, q1[i].p, p2[i].p, q2[i].p);
-            MG_HIP(g, hipStreamSynchronize(c->stream));
-            return PSACX_OK;
-        }));
-        for (int i = 0; i < L; ++i) { ln[i].release(); rn[i].release(); lcp_l[i].release(); lcp_r[i].release(); }
-        std::vector<DBuf<T>> wide(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, wide[i].alloc(c, S[i].m));
-            MG_HIP(g, hipSetDevice(c->device));
-            MG_HIP(g, hipMemsetAsync((*d_nodes)[i], 0, S[i].m * row * sizeof(unsigned long long), c->stream));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
-            return PSACX_OK;
-        }));
-        for (int which = 0; which < 2; ++which) {
-            std::vector<DBuf<uint64_t>>& q = which ? q2 : q1;
-            std::vector<DBuf<T>>& par_ = which ? p2 : p1;
-            std::vector<DBuf<T>> qs(L), ch, x(L), y(L);
-            std::vector<const T*> blk(L), gi(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, qs[i].alloc(c, S[i].m));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (st_positions_kernel<T>), S[i].m, (const uint64_t*)q[i].p, S[i].m, n, qs[i].p);
-                blk[i] = wide[i].p; gi[i] = qs[i].p;
-                return PSACX_OK;
-            }));
-            PSACX_TRY(dist_take(blk, gi, m_local, ch));
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, x[i].alloc(c, S[i].m)); MG_OP(g, c, y[i].alloc(c, S[i].m));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (st_payload_kernel<T>), S[i].m, (const uint64_t*)q[i].p, (const T*)ch[i].p, S[i].m, S[i].off, n, tab, which == 0 ? 1 : 0, x[i].p, y[i].p);
-                return PSACX_OK;
-            }));
-            // the cells to the owners of their rows: the same stable partition by owner for both payload words
-            std::vector<const T*> pos(L), xs(L), ys(L);
-            std::vector<uint64_t> tot(L);
-            std::vector<Rec<T>> r1(L), r2(L);
-            std::vector<std::vector<DBuf<T>>> got1, got2;
-            if (solo_) { for (int i = 0; i < L; ++i) { pos[i] = par_[i].p; xs[i] = x[i].p; ys[i] = y[i].p; tot[i] = S[i].m; } }
-            else {
-                std::vector<std::vector<uint64_t>> b1(L), b2(L), rc;
-                std::vector<std::vector<const T*>> in1(L), in2(L);
-                for (int i = 0; i < L; ++i) {
-                    PSACX_TRY(route(i, par_[i].p, x[i].p, S[i].m, r1[i], b1[i])); in1[i] = {r1[i].k2.p, r1[i].v.p};
-                    PSACX_TRY(route(i, par_[i].p, y[i].p, S[i].m, r2[i], b2[i])); in2[i] = {r2[i].v.p};
-                }
-                PSACX_TRY(exchange<T>(2, in1, b1, got1, rc));
-                PSACX_TRY(exchange<T>(1, in2, b2, got2, rc));
-                for (int i = 0; i < L; ++i) { pos[i] = got1[i][0].p; xs[i] = got1[i][1].p; ys[i] = got2[i][0].p; tot[i] = got1[i][0].n; }
-            }
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (st_put_kernel<T>), tot[i], (*d_nodes)[i], S[i].off, row, pos[i], xs[i], ys[i], tot[i], n);
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                return PSACX_OK;
-            }));
-        }
-        return PSACX_OK;
-    }
-
-    // Distributed verification of block-distributed SA / ISA / LCP without gathering anything on one rank: what
-    // d_check_sa does (check_suffix_array.hpp:207-267: SA a permutation whose inverse is ISA, S[SA[i-1]] <= S[SA[i]],
-    // ties decided by the ranks of the suffixes one further) with the engine's own exchanges (bulk_rma for
-    // ISA[SA[i]], S[SA[i]], ISA[SA[i]+1]), plus the LCP array through its recurrence
-    //   LCP[i] = 0 | 1 | 1 + min(LCP[ISA[SA[i-1]+1]+1 .. ISA[SA[i]+1]])      (range minima: bulk_rmq_v2)
-    // which has the true LCP array as its only solution.  errors[0..3] as psacx_check_dev_*, summed over all ranks.
-    int check(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa,
-              const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp, bool with_lcp, uint64_t errors[4]) {
-        want_lcp = with_lcp;
-        S.resize(L);
-        for (int i = 0; i < L; ++i) { (void)hipSetDevice(ctx(i)->device); pool_flush(ctx(i)); }     // the checker wants different sizes than the construction left cached
-        PSACX_TRY(par([&](int i) -> int {
-            S[i].c = ctx(i); S[i].r = rank(i); S[i].m = m_local[i]; S[i].text = text[i];
-            S[i].SA = d_sa[i]; S[i].ISA = d_isa[i]; S[i].LCP = with_lcp ? d_lcp[i] : nullptr;
-            MG_OP(g, S[i].c, ensure_pinned(S[i].c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 65536 + 32768));
-            return PSACX_OK;
-        }));
-        // The block is verified in `chunks` pieces of consecutive SA positions (every test is local to an entry and its
-        // predecessor): one piece needs about 24 words per entry, so a block that large a share of the device is cut.
-        uint64_t chunks = 1;
-        {
-            std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(2, 0));
-            for (int i = 0; i < L; ++i) {
-                int same = 0;
-                for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
-                size_t fr = 0, tot = 0;
-                MG_HIP(g, hipSetDevice(ctx(i)->device));
-                MG_HIP(g, hipMemGetInfo(&fr, &tot));
-                const double avail = 0.8 * (double)fr / same, need = 24.0 * (double)m_local[i] * sizeof(T);
-                mine[i][0] = m_local[i];
-                mine[i][1] = check_chunks_env_ ? check_chunks_env_ : need > avail ? (uint64_t)(need / std::max(avail, 1.0)) + 1 : 1;
-            }
-            std::vector<uint64_t> all;
-            PSACX_TRY(gather(2, mine, all));
-            sizes.assign(P, 0);
-            for (int r = 0; r < P; ++r) { sizes[r] = all[(size_t)r * 2]; chunks = std::max(chunks, all[(size_t)r * 2 + 1]); }
-            chunks = std::min<uint64_t>(chunks, 4096);
-            offs = prefix_of(sizes); n = offs[P];
-            for (int r = 0; r < P; ++r)
-                if (sizes[r] != n / P + ((uint64_t)r < n % P ? 1 : 0)) { g->err = "The input string must be equally block decomposed accross all MPI processes."; return PSACX_EINVAL; }
-            for (int i = 0; i < L; ++i) { S[i].off = offs[rank(i)]; ctx(i)->pool_cache_limit = 0; }
-            if (n == 0) return PSACX_EINVAL;
-        }
-        // the text as index words, once (S[SA[i]] travels through the same exchanges as the indices)
-        std::vector<DBuf<T>> wide(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            MG_OP(g, c, wide[i].alloc(c, S[i].m));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (widen_text_kernel<T>), S[i].m, text[i], S[i].m, wide[i].p);
-            return PSACX_OK;
-        }));
-        // (SA, S[SA], ISA[SA + 1]) of a range of SA positions of every rank
-        auto triple = [&](const std::vector<uint64_t>& from, const std::vector<uint64_t>& cnt, std::vector<DBuf<T>>* back, std::vector<DBuf<T>>& ch,
-                          std::vector<DBuf<T>>& nx) -> int {
-            std::vector<const T*> blk(L), gi(L);
-            std::vector<DBuf<T>> q1(L);
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                MG_OP(g, c, q1[i].alloc(c, cnt[i]));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (add_scalar_kernel<T>), cnt[i], S[i].SA + from[i], cnt[i], (uint64_t)1, n, q1[i].p);
-                return PSACX_OK;
-            }));
-            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = S[i].SA + from[i]; }
-            if (back) PSACX_TRY(dist_take(blk, gi, cnt, *back));
-            for (int i = 0; i < L; ++i) blk[i] = wide[i].p;
-            PSACX_TRY(dist_take(blk, gi, cnt, ch));
-            for (int i = 0; i < L; ++i) { blk[i] = S[i].ISA; gi[i] = q1[i].p; }
-            PSACX_TRY(dist_take(blk, gi, cnt, nx));
-            return PSACX_OK;
-        };
-        // the last entry of every block: the predecessor of the next non-empty block's first entry
-        std::vector<psacx_boundary> edge;
-        {
-            std::vector<uint64_t> from(L), one(L);
-            std::vector<DBuf<T>> ch, nx;
-            for (int i = 0; i < L; ++i) { one[i] = S[i].m ? 1 : 0; from[i] = S[i].m ? S[i].m - 1 : 0; }
-            PSACX_TRY(triple(from, one, nullptr, ch, nx));
-            std::vector<const T*> a1(L), a2(L), a3(L);
-            for (int i = 0; i < L; ++i) { a1[i] = S[i].SA + from[i]; a2[i] = ch[i].p; a3[i] = nx[i].p; }
-            PSACX_TRY(neighbours(a1, a2, a3, one, 3, edge));
-        }
-        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(4, 0));
-        std::vector<std::vector<uint64_t>> carry(L, std::vector<uint64_t>(3, 0));        // last entry of the previous piece
-        for (uint64_t q = 0; q < chunks; ++q) {
-            std::vector<uint64_t> from(L), cnt(L);
-            for (int i = 0; i < L; ++i) {
-                from[i] = (uint64_t)(((unsigned __int128)S[i].m * q) / chunks);
-                cnt[i] = (uint64_t)(((unsigned __int128)S[i].m * (q + 1)) / chunks) - from[i];
-            }
-            std::vector<DBuf<T>> back, ch, nx, mins;
-            PSACX_TRY(triple(from, cnt, &back, ch, nx));
-            std::vector<psacx_boundary> bd(L);
-            for (int i = 0; i < L; ++i) {
-                std::memset(&bd[i], 0, sizeof(psacx_boundary));
-                if (from[i] == 0) { bd[i].has_prev = edge[i].has_prev; for (int w = 0; w < 3; ++w) bd[i].prev[w] = edge[i].prev[w]; }
-                else { bd[i].has_prev = 1; for (int w = 0; w < 3; ++w) bd[i].prev[w] = carry[i][w]; }
-            }
-            PSACX_TRY(par([&](int i) -> int {                     // this piece's last entry, for the next one
-                if (!cnt[i]) return PSACX_OK;
-                const T* arr[3] = {S[i].SA + from[i], ch[i].p, nx[i].p};
-                for (int w = 0; w < 3; ++w) { std::vector<uint64_t> o; PSACX_TRY(fetch(i, arr[w], {cnt[i] - 1}, o)); carry[i][w] = o[0]; }
-                return PSACX_OK;
-            }));
-            if (with_lcp) {
-                std::vector<DBuf<T>> qlo(L), qhi(L);
-                std::vector<const T*> lo(L), hi(L);
-                PSACX_TRY(par([&](int i) -> int {
-                    psacx_ctx* c = ctx(i);
-                    MG_OP(g, c, qlo[i].alloc(c, cnt[i])); MG_OP(g, c, qhi[i].alloc(c, cnt[i]));
-                    OP_PROLOGUE(c);
-                    SIMPLE_LAUNCH(c, (check_queries_kernel<T>), cnt[i], S[i].SA + from[i], ch[i].p, nx[i].p, cnt[i], n, bd[i].has_prev, (T)bd[i].prev[0],
-                                  (T)bd[i].prev[1], (T)bd[i].prev[2], qlo[i].p, qhi[i].p);
-                    lo[i] = qlo[i].p; hi[i] = qhi[i].p;
-                    return PSACX_OK;
-                }));
-                PSACX_TRY(dist_range_min(lo, hi, cnt, mins));
-            }
-            PSACX_TRY(par([&](int i) -> int {
-                psacx_ctx* c = ctx(i);
-                DBuf<unsigned long long> e; MG_OP(g, c, e.alloc(c, 4));
-                MG_HIP(g, hipSetDevice(c->device));
-                MG_HIP(g, hipMemsetAsync(e.p, 0, 32, c->stream));
-                OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (check_verdict_kernel<T>), cnt[i], S[i].SA + from[i], back[i].p, ch[i].p, nx[i].p, with_lcp ? (const T*)(S[i].LCP + from[i]) : (const T*)nullptr,
-                              with_lcp ? (const T*)mins[i].p : (const T*)nullptr, cnt[i], S[i].off + from[i], n, bd[i].has_prev, (T)bd[i].prev[0], (T)bd[i].prev[1],
-                              (T)bd[i].prev[2], e.p);
-                MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, e.p, 32, hipMemcpyDeviceToHost, c->stream));
-                MG_HIP(g, hipStreamSynchronize(c->stream));
-                const uint64_t* h = reinterpret_cast<const uint64_t*>(c->pinned + 32768);
-                for (int w = 0; w < 4; ++w) mine[i][w] += h[w];
-                return PSACX_OK;
-            }));
-        }
-        std::vector<uint64_t> all;
-        PSACX_TRY(gather(4, mine, all));
-        for (int q = 0; q < 4; ++q) { errors[q] = 0; for (int r = 0; r < P; ++r) errors[q] += all[(size_t)r * 4 + q]; }
-        return PSACX_OK;
-    }
+    int ansv_pyramid(int i, const T* block, uint64_t m, Pyramid<T>& Pm, DBuf<T>& mem, uint64_t* block_min);
+    int ansv_ask(AnsvState& A, const std::vector<const T*>& cls, const std::vector<const T*>& start1, const std::vector<const T*>& thr, const std::vector<uint64_t>& cnt, bool strict, bool left, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val);
+    int ansv_search(AnsvState& A, const std::vector<const T*>& start1, const std::vector<const T*>& thr, const std::vector<uint64_t>& cnt, bool strict, bool left, bool have_local, std::vector<DBuf<T>>& idx, std::vector<DBuf<T>>& val);
+    int ansv(const std::vector<const T*>& block, const std::vector<uint64_t>& m_local, int left_type, int right_type, uint64_t nonsv, const std::vector<uint64_t*>& out_left, const std::vector<uint64_t*>& out_right);
+    int left_chars(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa, const std::vector<T*>& d_lcp, const std::vector<uint8_t*>& d_lc);
+    int suffix_tree(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa, const std::vector<T*>& d_lcp, const std::vector<unsigned long long*>* d_nodes, uint32_t* sigma);
+    int check(const std::vector<const uint8_t*>& text, const std::vector<uint64_t>& m_local, const std::vector<T*>& d_sa, const std::vector<T*>& d_isa, const std::vector<T*>& d_lcp, bool with_lcp, uint64_t errors[4]);
 
     // boundary bucket ids of every block, the list of positions that still share a bucket (suffix_array.hpp:925-965)
     // and the global counters.  ids == nullptr: first round (ids = Bsa, every position is a list entry).
