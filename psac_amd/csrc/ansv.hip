@@ -10,7 +10,7 @@
 // global 64-ary min-pyramid per distinct value (ansv_tile.hpp).
 #include "engine.hpp"
 #include "nsv.hpp"
-#include "ansv_seq.hpp"
+#include "ansv_wave.hpp"
 
 namespace psacx {
 

@@ -1,9 +1,10 @@
-// ansv_tile.hpp -- pieces the ANSV kernel (ansv_seq.hpp) is built from: window-minima tables over 64 lane-held values and the binary
+// ansv_tile.hpp -- pieces the ANSV kernel (ansv_wave.hpp) is built from: window-minima tables over 64 lane-held values and the binary
 // descent over them, and the answers of searches that leave a tile (one wave-cooperative walk of the global 64-ary min-pyramid per
 // distinct value, shared through a small LDS table that is carried from tile to tile).
 // Semantics: /root/reference/include/ansv.hpp:48-65 (ansv_sequential), tie rules ansv_common.hpp:20-22 (nearest_sm / nearest_eq /
 // furthest_eq), result contract ansv.hpp:2042-2051.  (Rounds 2-3 had a kernel of their own here: one element per lane, binary
-// descents inside every 64-block; the run-per-lane form replaced it in round 4.)
+// descents inside every 64-block; round 4 a run per lane in workgroup tiles of 4096 elements with seven barriers a tile; round 5 the
+// wave-owned tiles of ansv_wave.hpp.)
 #pragma once
 #include "nsv.hpp"
 
@@ -12,9 +13,6 @@ namespace psacx {
 constexpr unsigned ANSV_MEMO = 16;
 constexpr uint64_t ANSV_NOCONT = ~0ull - 1;      // a run of equal values does not continue beyond the tile edge
 
-// a search that starts at the edge of a tile of 64 x 64 elements finds nothing in the edge element's own 64-block nor in the 64 blocks
-// around it: the global walk may start two levels up
-template <typename T> struct ANSV_SKIP { static constexpr int LEVELS = 2; };
 
 template <typename T> struct AnsvMemo {
     T val[ANSV_MEMO];
@@ -129,9 +127,10 @@ __device__ __forceinline__ void ansv_memo_compact(AnsvMemo<T>& m) {
 // Answer of a search that leaves the tile (whole wave, wave-uniform arguments).  kind 0: the typed nearest
 // smaller value beyond the tile edge for value v; kind 1 (furthest_eq): the far end of the run of values equal
 // to v if the run continues beyond the edge, ANSV_NOCONT otherwise.
+// skip: levels of the pyramid on which the walk from the tile edge can find nothing (1 for a tile whose edges are multiples of 64)
 template <typename T, bool LEFT>
 __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
-                                                T v, int type, unsigned kind, AnsvMemo<T>& memo) {
+                                                T v, int type, unsigned kind, AnsvMemo<T>& memo, int skip) {
     uint64_t r;
     if (ansv_memo_find<T>(memo, v, kind, &r)) return r;
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
@@ -139,7 +138,7 @@ __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n,
     uint64_t j = NSV_NONE;
     r = kind == 0 ? NSV_NONE : ANSV_NOCONT;
     if (!edge) {
-        j = nsv_search_wave<T, LEFT>(P, start, v, kind == 0 && type == 0, ANSV_SKIP<T>::LEVELS);
+        j = nsv_search_wave<T, LEFT>(P, start, v, kind == 0 && type == 0, skip);
         if (kind == 0) {
             r = j;
             if (type == 2 && j != NSV_NONE) r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
@@ -156,12 +155,12 @@ __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n,
 template <typename T, bool LEFT>
 __device__ __forceinline__ void ansv_resolve_pending(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
                                                      bool pend, T myq, int type, unsigned kind, AnsvMemo<T>& memo, uint64_t nonsv,
-                                                     uint64_t* __restrict__ out, uint64_t g) {
+                                                     uint64_t* __restrict__ out, uint64_t g, int skip) {
     uint64_t m = __ballot(pend);
     while (m) {
         const int src = __builtin_ctzll(m);
         const T vq = shfl<T>(myq, src);
-        const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, kind, memo);
+        const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, kind, memo, skip);
         const bool mine = pend && myq == vq;
         if (mine) {
             if (kind == 0) out[g] = r == NSV_NONE ? nonsv : r;
@@ -172,12 +171,13 @@ __device__ __forceinline__ void ansv_resolve_pending(const Pyramid<T>& P, uint64
 }
 
 template <typename T>
-void launch_ansv_seq(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r);
+void launch_ansv_wave(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r);
 
-// left_type / right_type: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq; P: the 64-ary min-pyramid over the input (level 0 = the input)
+// left_type / right_type: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq; P: the 64-ary min-pyramid over the input (level 0 = the input);
+// d_l / d_r may be null: that side is not computed
 template <typename T>
 inline void launch_ansv_tiles(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
-    launch_ansv_seq<T>(c, P, n, lt, rt, nonsv, d_l, d_r);
+    launch_ansv_wave<T>(c, P, n, lt, rt, nonsv, d_l, d_r);
 }
 
 } // namespace psacx

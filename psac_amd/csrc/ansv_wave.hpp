@@ -1,0 +1,350 @@
+// ansv_wave.hpp -- all nearest smaller values, third tile form: every WAVE owns its tiles (64 runs of 16 elements: a run per lane) and
+// works through them on its own -- no workgroup barrier anywhere, so the 16 waves of a CU sit in different phases and their global loads,
+// register work and LDS traffic overlap instead of meeting at seven barriers per tile (the round-4 kernel: 71 % of the wave cycles waiting;
+// here 49 %).
+// Semantics: /root/reference/include/ansv.hpp:48-65 (ansv_sequential), tie rules ansv_common.hpp:20-22, contract ansv.hpp:2042-2051.
+//
+// One side of one tile is a pass:
+//   1. a lane loads its run (64 contiguous bytes), keeps it in registers and compares all pairs: every element gets the position of its
+//      answer inside the run, or stays open; the run goes to the wave's LDS area, its minimum stays in the lane;
+//   2. the open elements (a third on an LCP array) are compacted into a queue (popcounts + one scan over the lanes);
+//   3. the queue, 64 entries a step: binary descent over window minima of the 64 run minima (held one per lane: ansv_tile.hpp), the run
+//      found is read from LDS and searched in registers; what finds nothing in the tile asks the table of answers beyond the tile edge
+//      (one wave-cooperative walk of the global min-pyramid per distinct value);
+//   4. furthest_eq (the nearest <= element, then on through the values equal to IT while nothing smaller lies between): the nearest <=
+//      answers of the tile are links where the values agree; pointer doubling over the links gives every chain its far end -- a few
+//      rounds over a uint16 array in LDS instead of a second search per element;
+//   5. all answers of the tile leave as coalesced 512-byte stores;
+//   6. the table of answers beyond the edge is brought up to date against this tile, for the next one on the same side.
+// A wave walks its range of tiles from both ends at once: the left side upwards, the right side downwards, so that on either side the
+// tile just finished is the one the carried answers have to be checked against (in the round-4 kernel the right side lost its answers at
+// every tile and walked the pyramid again: 272 against 147 time units in its queue loop).  The input is read twice (8 of 24 bytes per
+// element); the all-pairs work is the same (one side per visit).
+#pragma once
+#include "ansv_tile.hpp"
+
+namespace psacx {
+
+constexpr unsigned AW_PEND = 0xFFFFu;       // the answer lies beyond the edge of the tile
+constexpr unsigned AW_DONE = 0xFFFEu;       // written by the search beyond the edge: the store pass leaves it alone
+
+template <typename T> struct AnsvWaveShared {
+    static constexpr int RUN = 16, TILE = 64 * RUN;
+    __attribute__((aligned(16))) T v[TILE];                   // the tile
+    __attribute__((aligned(16))) uint16_t ans[TILE];          // tile position of every element's answer (nearest types; nearest <= for furthest_eq)
+    __attribute__((aligned(16))) uint16_t q[TILE];            // queue of open elements; afterwards the far ends of the chains (furthest_eq)
+    AnsvMemo<T> memo[2];                                      // answers beyond the edge, left / right side
+};
+
+// rightmost (LEFT) / leftmost index of the 16 values that qualifies (-1: none)
+template <typename T, bool LEFT>
+__device__ __forceinline__ int answ_in_run(const T (&a)[16], T x, bool strict) {
+    int r = -1;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int i = LEFT ? s : 15 - s;
+        const bool ok = strict ? a[i] < x : a[i] <= x;
+        r = ok ? i : r;
+    }
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void answ_load_run(const T* __restrict__ p, T (&a)[16]) {       // p: 16-byte aligned, LDS or global
+    constexpr int PER = 16 / sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(PER)));
+    const vec* __restrict__ q = reinterpret_cast<const vec*>(p);
+#pragma unroll
+    for (int c = 0; c < 16 / PER; ++c) {
+        const vec w = q[c];
+#pragma unroll
+        for (int d = 0; d < PER; ++d) a[c * PER + d] = w[d];
+    }
+}
+
+// type: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq (FUR)
+template <typename T> __device__ __forceinline__ T answ_readlane(T v, unsigned src);      // src: wave-uniform
+template <> __device__ __forceinline__ uint32_t answ_readlane<uint32_t>(uint32_t v, unsigned src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+template <> __device__ __forceinline__ uint64_t answ_readlane<uint64_t>(uint64_t v, unsigned src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// the run of this lane in tile t (padding past the end of the array: all ones)
+template <typename T>
+__device__ __forceinline__ void answ_fetch(const T* __restrict__ in, uint64_t n, uint64_t t, T (&a)[16]) {
+    const uint64_t g0 = t * AnsvWaveShared<T>::TILE + (uint64_t)lane_id() * 16;
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && g0 + 16 <= n) answ_load_run<T>(in + g0, a);
+    else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = g0 + i < n ? in[g0 + i] : ~(T)0;
+    }
+}
+
+// (asking for the next pass's run as soon as the registers of this one are free was measured: 16 registers held through the pass, a few
+//  spills, nearest_sm pair 2.69 against 2.60 ms -- the pass is bound by its instruction count, not by the load at its head)
+template <typename T, bool LEFT, bool FUR>
+__device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyramid<T>& P, uint64_t n, uint64_t t, int type, uint64_t nonsv,
+                                               uint64_t* __restrict__ out) {
+    typedef AnsvWaveShared<T> SH;
+    constexpr unsigned TILE = SH::TILE, RUN = SH::RUN;
+    constexpr int SKIP = 1;                       // the tile edges are multiples of 64: nothing beyond them on level 0 of the pyramid
+    const T* __restrict__ in = P.lvl[0];
+    const unsigned lane = lane_id();
+    const bool strict = !FUR && type == 0;
+    AnsvMemo<T>& memo = sh.memo[LEFT ? 0 : 1];
+    const uint64_t tile_base = t * TILE;
+    const uint64_t tile_end = tile_base + TILE < n ? tile_base + TILE : n;
+    const unsigned n_rel = (unsigned)(tile_end - tile_base);          // elements of the tile that exist (the rest is padding)
+    // ---- 1. the run in registers and in LDS, all pairs
+    T mn;
+    unsigned total;
+    {
+        T a[16];
+        answ_fetch<T>(in, n, t, a);
+        {
+            constexpr int PER = 16 / sizeof(T);
+            typedef T vec __attribute__((ext_vector_type(PER)));
+            vec* __restrict__ q = reinterpret_cast<vec*>(sh.v + lane * RUN);
+            mn = a[0];
+#pragma unroll
+            for (int c = 0; c < 16 / PER; ++c) {
+                vec w;
+#pragma unroll
+                for (int d = 0; d < PER; ++d) { w[d] = a[c * PER + d]; mn = a[c * PER + d] < mn ? a[c * PER + d] : mn; }
+                q[c] = w;
+            }
+        }
+        unsigned open = 0;                        // bit j: element j finds nothing inside its run
+        uint32_t w16[8];                          // sixteen tile positions, two per word
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int al = -1;
+            if (LEFT) {
+#pragma unroll
+                for (int i = 0; i < j; ++i) al = (strict ? a[i] < a[j] : a[i] <= a[j]) ? i : al;
+            } else {
+#pragma unroll
+                for (int i = 15; i > j; --i) al = (strict ? a[i] < a[j] : a[i] <= a[j]) ? i : al;
+            }
+            // (an answer in the padding past the end of the array is none: the element goes on as open and ends beyond the edge)
+            const bool none = al < 0 || lane * RUN + (unsigned)(al < 0 ? 0 : al) >= n_rel;
+            if (none && lane * RUN + (unsigned)j < n_rel) open |= 1u << j;
+            const uint32_t code = none ? AW_PEND : lane * RUN + (unsigned)al;
+            if (j & 1) w16[j >> 1] |= code << 16; else w16[j >> 1] = code;
+        }
+        typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
+        vec4* __restrict__ qa = reinterpret_cast<vec4*>(sh.ans + lane * RUN);
+        vec4 x0, x1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { x0[d] = w16[d]; x1[d] = w16[4 + d]; }
+        qa[0] = x0; qa[1] = x1;
+        // ---- 2. the open elements into the queue
+        const unsigned mine = (unsigned)__builtin_popcount(open);
+        const unsigned incl = wave_scan_inclusive<uint32_t>(mine, OpSum());
+        total = shfl<uint32_t>(incl, 63);
+        unsigned o = incl - mine;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (open & (1u << j)) sh.q[o++] = (uint16_t)(lane * RUN + (unsigned)j);
+    }
+    xrun_order();
+    // ---- 3. the queue.  First the run next to the own one (five of six open elements of an LCP array end there): one run read and
+    //      searched, no descent; what is still open is compacted to the front of the queue.  Then the nearest run whose minimum
+    //      qualifies (descent over window minima of the 64 run minima) and the search inside it.
+    {
+        unsigned total2 = 0;
+#pragma unroll 1
+        for (unsigned i0 = 0; i0 < total; i0 += 64) {
+            const unsigned i = i0 + lane;
+            const bool valid = i < total;
+            const unsigned e = valid ? sh.q[i] : 0u;
+            const T x = sh.v[e];
+            const unsigned r = e >> 4;
+            const bool has_nb = LEFT ? r > 0 : r < 63;
+            const unsigned nb = has_nb ? (LEFT ? r - 1 : r + 1) : r;
+            T b[16];
+            answ_load_run<T>(sh.v + nb * RUN, b);
+            const int j = answ_in_run<T, LEFT>(b, x, strict);
+            const unsigned pos = nb * RUN + (unsigned)(j < 0 ? 0 : j);
+            const bool hit = valid && has_nb && j >= 0 && pos < n_rel;
+            if (hit) sh.ans[e] = (uint16_t)pos;
+            const bool rest = valid && !hit;
+            const uint64_t m = __ballot(rest);
+            if (rest) sh.q[total2 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)e;
+            total2 += (unsigned)__builtin_popcountll(m);
+        }
+        xrun_order();
+        T W[6];
+        if (LEFT) ansv_tables_left<T>(mn, W); else ansv_tables_right<T>(mn, W);
+#pragma unroll 1
+        for (unsigned i0 = 0; i0 < total2; i0 += 64) {
+            const unsigned i = i0 + lane;
+            const bool valid = i < total2;
+            const unsigned e = valid ? sh.q[i] : 0u;
+            const T x = sh.v[e];
+            const unsigned tr = ansv_descend<T, LEFT>(W, e >> 4, x, strict);
+            const bool found = valid && tr < 64;
+            unsigned pos = AW_PEND;
+            if (__ballot(found)) {
+                T b[16];
+                answ_load_run<T>(sh.v + (found ? tr : 0u) * RUN, b);
+                const int j = answ_in_run<T, LEFT>(b, x, strict);
+                if (found) { pos = tr * RUN + (unsigned)(j < 0 ? 0 : j); if (pos >= n_rel) pos = AW_PEND; }
+            }
+            if (!FUR) {
+                const bool pend = valid && pos == AW_PEND;
+                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, type, 0u, memo, nonsv, out, tile_base + e, SKIP);
+                if (pend) pos = AW_DONE;
+            }
+            if (valid) sh.ans[e] = (uint16_t)pos;
+        }
+    }
+    xrun_order();
+    if (!FUR) {
+        // ---- 5. the answers out, lane = element
+        uint64_t* __restrict__ o = out + tile_base + lane;
+#pragma unroll 4
+        for (unsigned k = 0; k < RUN; ++k) {
+            const unsigned e = k * 64 + lane;
+            const unsigned a = sh.ans[e];
+            if (e < n_rel && a != AW_DONE) o[k * 64] = tile_base + a;
+        }
+    } else {
+        // ---- 4. furthest_eq: links to the nearest <= element where it is EQUAL, pointer doubling to the far end of every chain
+#pragma unroll
+        for (unsigned h = 0; h < 2; ++h) {            // eight elements at a time: their loads travel together
+            unsigned ne[8]; T xe[8], xn[8];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) { ne[k] = sh.ans[(h * 8 + k) * 64 + lane]; xe[k] = sh.v[(h * 8 + k) * 64 + lane]; }
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) xn[k] = sh.v[ne[k] != AW_PEND ? ne[k] : 0u];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) sh.q[(h * 8 + k) * 64 + lane] = (uint16_t)((ne[k] != AW_PEND && xn[k] == xe[k]) ? ne[k] : (h * 8 + k) * 64 + lane);
+        }
+        xrun_order();
+        for (;;) {
+            bool changed = false;
+#pragma unroll
+            for (unsigned h = 0; h < 2; ++h) {            // eight elements at a time: their loads travel together
+                unsigned f[8], ff[8];
+#pragma unroll
+                for (unsigned k = 0; k < 8; ++k) f[k] = sh.q[(h * 8 + k) * 64 + lane];
+#pragma unroll
+                for (unsigned k = 0; k < 8; ++k) ff[k] = sh.q[f[k]];
+#pragma unroll
+                for (unsigned k = 0; k < 8; ++k) if (ff[k] != f[k]) { sh.q[(h * 8 + k) * 64 + lane] = (uint16_t)ff[k]; changed = true; }
+            }
+            xrun_order();
+            if (!__ballot(changed)) break;
+        }
+        // the answer of e: the far end of the chain of its nearest <= element; a chain whose far end inside the tile has ITS nearest <=
+        // element beyond the edge may go on there (asked per value); an element without a <= element in the tile asks for everything
+#pragma unroll 1
+        for (unsigned h = 0; h < 4; ++h) {            // four elements at a time
+            unsigned ne[4], r[4], ar[4]; T x[4], u[4];
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) { ne[k] = sh.ans[(h * 4 + k) * 64 + lane]; x[k] = sh.v[(h * 4 + k) * 64 + lane]; }
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) r[k] = ne[k] != AW_PEND ? sh.q[ne[k]] : 0u;
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) { ar[k] = sh.ans[r[k]]; u[k] = sh.v[r[k]]; }
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) {
+                const unsigned e = (h * 4 + k) * 64 + lane;
+                const uint64_t g = tile_base + e;
+                const bool in_range = e < n_rel;
+                const bool pend = in_range && ne[k] == AW_PEND;
+                const bool cont = in_range && ne[k] != AW_PEND && ar[k] == AW_PEND;
+                if (in_range && !pend) out[g] = tile_base + r[k];
+                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x[k], 2, 0u, memo, nonsv, out, g, SKIP);
+                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, u[k], 2, 1u, memo, nonsv, out, g, SKIP);
+            }
+        }
+    }
+    // ---- 6. the answers beyond the edge, for the next tile on this side.  An entry stays true unless this tile holds a qualifying element:
+    //      that element, the nearest one to the next tile, is then the new nearest answer.  furthest_eq: from that element j the chain
+    //      runs to its far end r inside the tile (sh.q, step 4); when r's own nearest <= element lies beyond this tile's edge the chain may
+    //      go on there, which the table may know (value u = in[j], kind 1).  Entries of kind 0 first: they read the OLD entries of kind 1.
+    {
+        const unsigned c = memo.cnt < ANSV_MEMO ? memo.cnt : ANSV_MEMO;
+        // (the entries in registers, one per lane: the loop below asks lanes, not LDS)
+        const T mval = lane < c ? memo.val[lane] : (T)0;
+        const unsigned mkind = lane < c ? memo.kind[lane] : 0u;
+        const bool mlive = lane < c && memo.ready[lane] != 0;
+#pragma unroll 1
+        for (int round = 0; round < (FUR ? 2 : 1); ++round) {
+        uint64_t todo = __ballot(mlive && (!FUR || mkind == (unsigned)round));
+        while (todo) {
+            const unsigned idx = (unsigned)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const unsigned kind = (unsigned)__builtin_amdgcn_readlane((int)mkind, (int)idx);
+            const T x = answ_readlane<T>(mval, idx);
+            const uint64_t bal = __ballot(strict ? mn < x : mn <= x);
+            if (!bal) continue;
+            const unsigned rr = LEFT ? 63u - (unsigned)__builtin_clzll(bal) : (unsigned)__builtin_ctzll(bal);
+            const T y = sh.v[rr * RUN + (lane & 15u)];
+            const uint64_t in_b = __ballot(lane < 16 && (strict ? y < x : y <= x));
+            const unsigned pl = LEFT ? 63u - (unsigned)__builtin_clzll(in_b) : (unsigned)__builtin_ctzll(in_b);
+            const unsigned j = rr * RUN + pl;
+            const uint64_t gp = tile_base + j;
+            const T u = answ_readlane<T>(y, pl);
+            if (j >= n_rel) { if (lane == 0) memo.ready[idx] = 0; continue; }           // (padding past the end of the array)
+            if (!FUR) { if (lane == 0) { memo.res[idx] = gp; memo.first[idx] = gp; } continue; }
+            if (kind == 1 && u < x) { if (lane == 0) { memo.res[idx] = ANSV_NOCONT; memo.first[idx] = gp; } continue; }
+            // the chain of value u from j: its far end inside the tile, and whether it may go on beyond the tile
+            const unsigned r = sh.q[j];
+            const bool at_edge = sh.ans[r] == AW_PEND;
+            uint64_t res = tile_base + r;
+            bool keep = true;
+            if (at_edge) {
+                if (kind == 1) { const uint64_t old = memo.res[idx]; if (old != ANSV_NOCONT) res = old; }      // (u == x: the entry itself tells)
+                else { uint64_t far; if (ansv_memo_find<T>(memo, u, 1u, &far)) { if (far != ANSV_NOCONT) res = far; } else keep = false; }
+            }
+            if (lane == 0) { if (keep) { memo.res[idx] = res; memo.first[idx] = gp; } else memo.ready[idx] = 0; }
+        }
+        }
+        if (lane == 0) ansv_memo_compact<T>(memo);
+    }
+    xrun_order();
+}
+
+template <typename T, bool LF, bool RF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, sizeof(T) == 4 ? 4 : 3) void ansv_wave_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type, uint64_t nonsv,
+                                                               uint64_t* __restrict__ left, uint64_t* __restrict__ right, uint64_t ntiles) {
+    // left / right may be null: that side is not computed (the distributed search asks for one side at a time)
+    __shared__ AnsvWaveShared<T> shw[WAVES];
+    const unsigned lane = lane_id();
+    const unsigned wave = threadIdx.x / WAVE;
+    AnsvWaveShared<T>& sh = shw[wave];
+    const uint64_t gw = (uint64_t)blockIdx.x * WAVES + wave, nw = (uint64_t)gridDim.x * WAVES;
+    const uint64_t per = (ntiles + nw - 1) / nw;
+    const uint64_t t_lo = gw * per;
+    const uint64_t t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+    if (lane < 2) sh.memo[lane].cnt = 0;
+    if (lane < 2 * ANSV_MEMO) sh.memo[lane / ANSV_MEMO].ready[lane % ANSV_MEMO] = 0;
+    xrun_order();
+    for (uint64_t k = 0; t_lo + k < t_hi; ++k) {
+        if (left) ansv_wave_pass<T, true, LF>(sh, P, n, t_lo + k, LF ? 2 : left_type, nonsv, left);
+        if (right) ansv_wave_pass<T, false, RF>(sh, P, n, t_hi - 1 - k, RF ? 2 : right_type, nonsv, right);
+    }
+}
+
+template <typename T>
+void launch_ansv_wave(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int rt, uint64_t nonsv, uint64_t* d_l, uint64_t* d_r) {
+    constexpr int WAVES = 4;
+    constexpr uint64_t TILE = AnsvWaveShared<T>::TILE;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+#define PSACX_ANSW(LF, RF)                                                                                                       \
+    do {                                                                                                                         \
+        int occ = 0;                                                                                                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_wave_kernel<T, LF, RF, WAVES>, 64 * WAVES, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; } \
+        const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + WAVES - 1) / WAVES, (uint64_t)c->n_cu * occ);               \
+        hipLaunchKernelGGL((ansv_wave_kernel<T, LF, RF, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles); \
+    } while (0)
+    if (lt == 2 && rt == 2) PSACX_ANSW(true, true);
+    else if (lt == 2) PSACX_ANSW(true, false);
+    else if (rt == 2) PSACX_ANSW(false, true);
+    else PSACX_ANSW(false, false);
+#undef PSACX_ANSW
+}
+
+} // namespace psacx

@@ -34,7 +34,7 @@
 #include <thread>
 
 #include "dist_ops.hpp"
-#include "ansv_seq.hpp"
+#include "ansv_wave.hpp"
 #include "shm_link.hpp"
 #include "slice_inv.hpp"
 #include "multi_kernels.hpp"

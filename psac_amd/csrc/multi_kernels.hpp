@@ -1,7 +1,7 @@
 // multi_kernels.hpp -- the small kernels of the multi-GPU engine's query side (multi_queries.hpp) and of its string-set path.
 #pragma once
 #include "dist_ops.hpp"
-#include "ansv_seq.hpp"
+#include "ansv_wave.hpp"
 
 namespace psacx {
 

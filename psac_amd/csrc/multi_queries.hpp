@@ -9,7 +9,7 @@ namespace psacx {
 // ---------------------------------------------------------------- all nearest smaller values over a block-distributed array
 // ansv<T, left_type, right_type, global_indexing> (ansv.hpp:2042-2051; gansv_impl :1304-1740 keeps per-rank stacks
 // and exchanges unmatched prefix minima).  Here every element first searches its own block (the tile kernel of
-// ansv_tile.hpp); a search that leaves the block goes to the nearest further block whose all-gathered minimum
+// ansv_wave.hpp); a search that leaves the block goes to the nearest further block whose all-gathered minimum
 // qualifies and is answered from that block's edge.  furthest_eq = nearest <=, then the first strictly smaller value
 // beyond it, then back to the first value <= (three searches, ansv_common.hpp:20-22).
 
@@ -184,17 +184,16 @@ int MultiRun<T>::ansv(const std::vector<const T*>& block, const std::vector<uint
         const bool left = side == 0;
         const int typ = left ? left_type : right_type;
         const std::vector<uint64_t*>& out = left ? out_left : out_right;
-        // first search inside the own block by the tile kernel (it fills both sides; the other side's array is scratch)
+        // first search inside the own block by the tile kernel (ansv_wave.hpp; a null array: that side is not computed)
         std::vector<DBuf<T>> idx(L), val(L);
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, idx[i].alloc(c, m_local[i])); MG_OP(g, c, val[i].alloc(c, m_local[i]));
             if (!m_local[i]) return PSACX_OK;
-            DBuf<uint64_t> other; MG_OP(g, c, other.alloc(c, m_local[i]));
             const int t1 = typ == 0 ? 0 : 1;                       // strict, or nearest <=
             MG_HIP(g, hipSetDevice(c->device));
-            if (left) launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], t1, 0, NSV_NONE, out[i], other.p);
-            else launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], 0, t1, NSV_NONE, other.p, out[i]);
+            if (left) launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], t1, 0, NSV_NONE, out[i], (uint64_t*)nullptr);
+            else launch_ansv_tiles<T>(c, A.pyr[i], m_local[i], 0, t1, NSV_NONE, (uint64_t*)nullptr, out[i]);
             MG_HIP(g, hipGetLastError());
             OP_PROLOGUE(c);
             SIMPLE_LAUNCH(c, (ansv_local_to_idx_kernel<T>), m_local[i], out[i], block[i], m_local[i], S[i].off, idx[i].p, val[i].p);

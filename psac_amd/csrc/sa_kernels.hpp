@@ -1821,17 +1821,34 @@ __global__ void pyramid_aux_kernel(const T* __restrict__ in, uint64_t len, T* __
     }
 }
 
+// out[c] = min(in[64 c .. 64 c + 63]).  A lane reads 16 bytes, so a wave covers 1 KiB = 4 (32-bit) or 2 (64-bit) groups per load, and a group's
+// minimum is folded over its 16 / 32 lanes (the form with one group per wave and one element per lane read a quarter of the bytes per
+// instruction and folded over all 64 lanes: level 1 over 2^28 32-bit values 0.37 ms, a third of an ANSV pass).
 template <typename T>
 __global__ void pyramid_level_kernel(const T* __restrict__ in, uint64_t len_in, T* __restrict__ out,
                                      uint64_t len_out) {
+    constexpr int PER = 16 / sizeof(T), LANES = 64 / PER, GPW = WAVE / LANES;       // elements per lane, lanes per group, groups per wave and step
+    typedef T vec __attribute__((ext_vector_type(PER)));
     const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) / WAVE;
     const unsigned lane = lane_id();
-    for (uint64_t c = wave_id; c < len_out; c += nwaves) {
-        const uint64_t i = c * 64 + lane;
-        T v = i < len_in ? in[i] : ~(T)0;
-        v = wave_reduce<T>(v, OpMin());
-        if (lane == 0) out[c] = v;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    const uint64_t steps = (len_out + GPW - 1) / GPW;
+    for (uint64_t s = wave_id; s < steps; s += nwaves) {
+        const uint64_t c = s * GPW + lane / LANES;              // this lane's group
+        const uint64_t i = c * 64 + (uint64_t)(lane % LANES) * PER;
+        T v = ~(T)0;
+        if (vec_ok && i + PER <= len_in) {
+            const vec w = *reinterpret_cast<const vec*>(in + i);
+#pragma unroll
+            for (int d = 0; d < PER; ++d) v = w[d] < v ? w[d] : v;
+        } else {
+#pragma unroll
+            for (int d = 0; d < PER; ++d) if (i + d < len_in) { const T x = in[i + d]; v = x < v ? x : v; }
+        }
+#pragma unroll
+        for (int m = LANES / 2; m >= 1; m >>= 1) { const T o = shfl_xor<T>(v, m); v = o < v ? o : v; }
+        if (lane % LANES == 0 && c < len_out) out[c] = v;
     }
 }
 
