@@ -120,14 +120,21 @@ __global__ __launch_bounds__(RADIX) void radix_hist_scan_kernel(const unsigned l
 
 // ------------------------------------------------------------ scatter pass
 __device__ __forceinline__ uint64_t match_any8(unsigned d, bool valid) {
-    uint64_t m = __ballot(valid);
+    // lanes whose digit equals this lane's: for every bit, the ballot of the bit XOR this lane's bit spread over a word (0 / all ones) marks the
+    // lanes that DIFFER there; OR over the bits, inverted.  Four vector instructions per bit: v_bfe_i32 (the bit as 0 / -1), the compare
+    // for the ballot, and one v_bitop3 (acc | (ballot ^ bit)) per half of the mask -- the form `m &= bit ? bal : ~bal` compiled to ten,
+    // and the scatter passes are bound by vector issue: 100 instructions per record at 4.4 SIMD cycles each were 12.1 of their 15.2 ms
+    // (tools/ubench_valu.hip; profiles/r4d_sq_counters_one_gpu_kernels.txt).
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int b = 0; b < RADIX_BITS; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        int x = __builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);            // 0 or -1
+        asm("" : "+v"(x));                   // (keeps the compare on x: the optimizer otherwise derives the ballot from d with a shift of its own)
+        const uint64_t bal = __ballot(x != 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, (uint32_t)x, 0xF6);        // lo | (bal ^ x)
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), (uint32_t)x, 0xF6);
     }
-    return m;
+    return ~(((uint64_t)hi << 32) | lo) & __ballot(valid);
 }
 
 // T: record word type.  D: look-back descriptor word (uint32_t when n < 2^30).
@@ -166,7 +173,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     const unsigned long long* __restrict__ digit_base, D* __restrict__ desc, unsigned* __restrict__ err,
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
-    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0) {
+    const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0,
+    const T (*kd_made)[ITEMS] = nullptr) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     // VN 7 / 8 / 9: one-word records (the prefix sort of the first round, most significant digit first; engine.hpp: prefix_sort_1w).
@@ -174,8 +182,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     //    digit) << 32 | payload (pack = lo1, the bits of word 1 below the prefix); 8: one-word records in and out (a digit of the
     //    upper half; the records of one top digit only: the caller offsets the arrays); 9: one-word records in, word 1
     //    (prefix << lo1, top digit = voff, pack = lo1 | (prefix bits without the top digit) << 8) and the 64-bit payload out.
-    // 10: as 7, with word 1 of the tile's records waiting in LDS (the stage, a wave's 64 * ITEMS records in its own part, element
-    //     e at e ^ ((e >> 3) & 7): sa_kernels.hpp: key_scatter1w_kernel computes them there instead of reading them from memory)
+    // 10: as 7, with word 1 of the thread's records handed over in registers (kd_made[i] = the record (wave, i, lane) of the striped order:
+    //     sa_kernels.hpp: key_scatter1w_kernel cuts them out of the tile's packed text instead of reading them from memory)
     // Width of the payload field of a one-word record: bits 16 .. 23 of `pack` (0 = 32).  A text of up to 2^S characters keeps
     // 64 - S prefix bits in the word (the multi-GPU engine: 2^34 characters -> 34 + 30).
     constexpr bool ONEW_IN = VN == 8 || VN == 9;
@@ -231,10 +239,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     //  as the index every load had its own address register)
     const T* __restrict__ pkd_l = pkd + wbase;
     if (VN == 10) {
-        const T* pre = stage + wave * (WAVE * ITEMS);
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) { const unsigned e = (unsigned)i * WAVE + lane; kd[i] = pre[e ^ ((e >> 3) & 7u)]; }
-        // (the stage is written again two barriers further down: every wave has its records in registers by then)
+        for (int i = 0; i < ITEMS; ++i) kd[i] = (*kd_made)[i];
     } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {

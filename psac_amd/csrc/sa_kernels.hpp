@@ -368,9 +368,14 @@ __global__ void prefix_dup_probe_kernel(const uint8_t* __restrict__ text, uint64
     }
 }
 
-// key_scatter1w_kernel: the pass on the top digit with word 1 computed on the spot (key_pairs_kernel's staging of the text window
-// and rolling pack; the words go to the wave's part of the stage in record order and radix_scatter_tile<..., VN = 10> takes them
-// from there in the order it ranks in, which keeps the pass stable: the short suffixes at the head of the input stay in front).
+// key_scatter1w_kernel: the pass on the top digit with word 1 computed on the spot.  The text window of the tile is staged ONCE as a
+// stream of packed codes (lc bits per character, first character on top, 32-bit words): a thread turns 16 bytes into 16 lc bits and
+// stores them as lc half-words.  Word 1 of any record of the tile is then 64 bits of that stream at bit offset lc x (its place): three
+// words read and two shifts -- every lane cuts out the records of its own places in the striped order radix_scatter_tile ranks in, so the
+// words never pass through LDS again.  (Until round 5 the codes were staged as 16-bit entries, packed eight at a time into groups, put
+// together per thread by a rolling window and handed to the ranking through the stage: 3.9 G of the kernel's 10.6 G vector
+// instructions at 2^32 records, and the kernel is bound by vector issue: profiles/r4d_sq_counters_one_gpu_kernels.txt, tools/ubench_valu.hip.)
+// The pass stays stable: the short suffixes at the head of the input keep their places in front.
 template <int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_text, CodeTable tab, KeyShape ks,
                                                                  uint64_t* __restrict__ out, int shift, const unsigned long long* __restrict__ digit_base,
@@ -382,119 +387,84 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
     typedef uint64_t T;
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
-    constexpr int HALO = 2 * 64 + 8;
-#define SW(i) ((i) + (((i) >> 3) << 1))
+    constexpr int HALO = 2 * 64 + 8 + 16;
     __shared__ ScatterShared<T, TILE, NW> sh;
     __shared__ uint16_t ctab[256];
-    __shared__ T grp[TILE / 8 + HALO / 8 + 1];
-    static_assert(sizeof(uint16_t) * (SW(TILE + HALO) + 8) <= sizeof(sh.stage), "the codes of the tile live in the stage until the words are packed");
-    uint16_t* const codes = reinterpret_cast<uint16_t*>(sh.stage);
+    static_assert(sizeof(uint32_t) * ((TILE + HALO) * 8 / 32 + 4) <= sizeof(sh.stage), "the packed codes of the tile live in the stage until the words are cut out");
+    uint32_t* const stream = reinterpret_cast<uint32_t*>(sh.stage);
+    uint16_t* const stream16 = reinterpret_cast<uint16_t*>(sh.stage);
     if (threadIdx.x == 0) sh.s_tile = tile_counter ? claim_tile(tile_counter, gridDim.x, chunk) : blockIdx.x;
     for (int i = threadIdx.x; i < NW * RADIX; i += BLOCK) sh.wcnt[i] = 0;
     for (int i = threadIdx.x; i < 256; i += BLOCK) ctab[i] = tab.c[i];
     __syncthreads();
     const unsigned tile = sh.s_tile;
-    const unsigned two_k = ks.c1 + ks.c2;
     const uint64_t base = (uint64_t)tile * TILE;
+    const unsigned lc = ks.lc;
+    // the text from the first regular suffix of the tile on (aligned down to 16 bytes): character q of the stream = text[a_lo + q]
     const uint64_t i_lo = (base > ks.spec ? base : ks.spec) - ks.spec;
-    const unsigned need = TILE + two_k;
+    const uint64_t a_lo = i_lo & ~15ull;
+    const unsigned need = TILE + ks.c1 + 16;                   // characters the windows of the tile reach over (lead included)
     {
-        const uint64_t a_lo = i_lo & ~15ull;
-        const unsigned lead = (unsigned)(i_lo - a_lo);
         const bool aligned_ptr = (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
-        for (unsigned v = threadIdx.x * 16u; v < need + lead; v += BLOCK * 16u) {
-            const uint64_t g0 = a_lo + v;
+        for (unsigned v = threadIdx.x; v * 16u < need; v += BLOCK) {
+            const uint64_t g0 = a_lo + (uint64_t)v * 16u;
+            uint16_t cd[16];
             if (aligned_ptr && g0 + 16 <= n_text) {
                 const uint4 x = *reinterpret_cast<const uint4*>(text + g0);
                 const unsigned wds[4] = {x.x, x.y, x.z, x.w};
-                uint16_t cd[16];
 #pragma unroll
                 for (int b = 0; b < 16; ++b) cd[b] = ctab[(wds[b >> 2] >> ((b & 3) * 8)) & 255u];
-#pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int i = (int)v + b - (int)lead;
-                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = cd[b];
-                }
             } else {
-#pragma unroll 1
-                for (int b = 0; b < 16; ++b) {
-                    const int i = (int)v + b - (int)lead;
-                    if (i >= 0 && (unsigned)i < need) codes[SW(i)] = (g0 + b) < n_text ? ctab[text[g0 + b]] : (uint16_t)0;
-                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) cd[b] = (g0 + b) < n_text ? ctab[text[g0 + b]] : (uint16_t)0;
+            }
+            // sixteen codes = lc half-words of the stream; half-word h of the stream is the upper half of word h / 2 when h is even
+            uint32_t acc = 0;
+            unsigned nb = 0, h = lc * v;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                acc = (acc << lc) | cd[b];
+                nb += lc;
+                if (nb >= 16) { nb -= 16; stream16[(h++) ^ 1u] = (uint16_t)(acc >> nb); }
             }
         }
     }
     __syncthreads();
-    const unsigned lc = ks.lc;
-    const T mask1 = (ks.c1 * lc >= sizeof(T) * 8) ? ~(T)0 : (T)(((T)1 << (ks.c1 * lc)) - 1);
-    const uint64_t j0 = base + (uint64_t)threadIdx.x * ITEMS;
-    T o1[ITEMS];
-    // Tiles behind the short suffixes: a thread's windows start at code 8 t of the staged text, so the codes are first packed
-    // eight at a time (grp[m] = codes 8 m .. 8 m + 7, first code on top) and a thread puts its first window together from
-    // whole groups instead of reading c1 - 1 codes one by one (31 for DNA); the eight codes that roll in come from two groups.
-    const bool grouped = base >= ks.spec && 8 * lc <= 56 && ITEMS == 8;
-    if (grouped) {
-        constexpr int NG = TILE / 8 + HALO / 8 + 1;
-        for (int m = threadIdx.x; m < NG; m += BLOCK) {
-            T g = 0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) g = (T)(g << lc) | (T)((unsigned)(8 * m + r) < need ? codes[SW(8 * m + r)] : (uint16_t)0);
-            grp[m] = g;
-        }
-        __syncthreads();
-        const unsigned t8 = threadIdx.x;                              // the thread's first window starts at code 8 * t8
-        const unsigned F = (ks.c1 - 1) / 8, R = (ks.c1 - 1) % 8;
-        T w1 = 0;
-        for (unsigned f = 0; f < F; ++f) w1 = (T)(w1 << (8 * lc)) | grp[t8 + f];
-        T ga = grp[t8 + F], gb = grp[t8 + F + 1];
-        if (R) w1 = (T)(w1 << (R * lc)) | (T)(ga >> ((8 - R) * lc));
-        const T cmask = (T)(((T)1 << lc) - 1);
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const unsigned pos = R + (unsigned)j;                      // place of the code that rolls in, counted from the start of group F
-            const T code = pos < 8 ? (T)(ga >> ((7 - pos) * lc)) & cmask : (T)(gb >> ((15 - pos) * lc)) & cmask;
-            w1 = ((T)(w1 << lc) | code) & mask1;
-            o1[j] = j0 + j < n ? w1 : (T)0;
-        }
-    } else if (j0 >= ks.spec) {
-        const unsigned q = (unsigned)(j0 - ks.spec - i_lo);
-        T w1 = 0;
-        for (unsigned t = 0; t + 1 < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)codes[SW(q + t)];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            w1 = ((T)(w1 << lc) | (T)codes[SW(q + j + ks.c1 - 1)]) & mask1;
-            o1[j] = j0 + j < n ? w1 : (T)0;
-        }
-    } else {
-#pragma unroll 1
-        for (int j = 0; j < ITEMS; ++j) {
-            const uint64_t rec = j0 + j;
-            T w1 = 0;
-            if (rec < n) {
-                const uint64_t i = record_suffix(rec, ks.spec, n);
-                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i + t < n_text) ? tab.c[text[i + t]] : 0);
-            }
-            o1[j] = w1;
-        }
-    }
-    __syncthreads();                        // every thread has read its codes: the stage takes the words now
+    // word 1 of the thread's records, in the order the ranking takes them: record (wave, i, lane) = base + wave * 64 * ITEMS + i * 64 + lane
+    T kd[ITEMS];
     {
-        T* const pre = sh.stage + (threadIdx.x / WAVE) * (WAVE * ITEMS);
-        const unsigned lane = lane_id();
+        const unsigned wbase = (threadIdx.x / WAVE) * (WAVE * ITEMS) + lane_id();
+        const unsigned wbits = ks.c1 * lc;                     // 1 .. 64
+        const long long rel = (long long)base - (long long)ks.spec - (long long)a_lo;      // stream character of record 0 of the tile (negative among the short suffixes)
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const unsigned e = lane * ITEMS + j; pre[e ^ ((e >> 3) & 7u)] = o1[j]; }
-        xrun_order();
+        for (int i = 0; i < ITEMS; ++i) {
+            const unsigned p = wbase + (unsigned)i * WAVE;
+            const uint64_t rec = base + p;
+            T w1 = 0;
+            if (rec >= ks.spec) {
+                const unsigned o = (unsigned)(rel + (long long)p) * lc;          // bit offset in the stream
+                const unsigned m = o >> 5, sft = o & 31u;
+                const uint64_t x = ((uint64_t)stream[m] << 32) | stream[m + 1];
+                const uint64_t r = (x << sft) | (((uint64_t)stream[m + 2] << sft) >> 32);
+                w1 = r >> (64u - wbits);
+            } else if (rec < n) {
+                // a suffix shorter than the window (the first records of the text): its characters one by one
+                const uint64_t i0 = record_suffix(rec, ks.spec, n);
+                for (unsigned t = 0; t < ks.c1; ++t) w1 = (T)(w1 << lc) | (T)((i0 + t < n_text) ? tab.c[text[i0 + t]] : 0);
+            }
+            kd[i] = rec < n ? w1 : (T)0;
+        }
     }
-#undef SW
+    __syncthreads();                        // every thread has cut out its words: the stage takes the records now
     const uint64_t remain = n - base;
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, false, true, 10>(sh, tile, (unsigned)TILE, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
                                                                                    digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
-                                                                                   slab_tiles, voff, lo1);
+                                                                                   slab_tiles, voff, lo1, &kd);
     else
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, false, true, 10>(sh, tile, (unsigned)remain, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
                                                                                     digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
-                                                                                    slab_tiles, voff, lo1);
+                                                                                    slab_tiles, voff, lo1, &kd);
 }
 
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
