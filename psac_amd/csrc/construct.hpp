@@ -609,9 +609,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 uint64_t* s1 = nullptr;
                 // the records stay one-word through the tie stage and the rebucket kernel when that kernel runs in its fused form
                 const bool keep = !kn.widen_last && !kn.ties_radix && isa_narrow_levels<T>(n, kn) > 0;
+                // (the digit bytes between the passes live in the array that takes word 2 of the tied suffixes after the sort: idle until then)
+                uint8_t* const dig = kn.no_digit_bytes ? (uint8_t*)nullptr : reinterpret_cast<uint8_t*>(w.diet ? w.x.k2 : first_alt.k2);
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
                                                reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
-                                               keep ? &onew_view : nullptr);
+                                               keep ? &onew_view : nullptr, dig);
                 if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
                     two_stage = false; retry_one_stage = true; one_word = false;
                 } else if (rc1 == PSACX_RETRY_1W || rc1 == PSACX_RETRY_1STAGE) {          // (a repetitive text, or no room for the bucket tables: nothing was written)

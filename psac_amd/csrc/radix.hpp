@@ -174,7 +174,9 @@ __device__ __forceinline__ void radix_scatter_tile(
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
     const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0,
-    const T (*kd_made)[ITEMS] = nullptr) {
+    const T (*kd_made)[ITEMS] = nullptr, uint8_t* __restrict__ dnext = nullptr, const int dnext_shift = 0) {
+    // dnext (one-word records out): byte `at` receives bits dnext_shift .. + 7 of the record written to place `at` -- the digit the NEXT pass
+    // sorts on, so that its tile histograms read one byte per record instead of the record (radix_tile_hist_bytes_kernel)
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     // VN 7 / 8 / 9: one-word records (the prefix sort of the first round, most significant digit first; engine.hpp: prefix_sort_1w).
@@ -370,7 +372,10 @@ __device__ __forceinline__ void radix_scatter_tile(
             if (VN == 9) {
                 kd_out[at] = (T)(((voff << ((pack >> 8) & 255u)) | ((uint64_t)x >> sfield)) << (pack & 255u));
                 v_out[at] = (T)((uint64_t)x & ((1ull << sfield) - 1ull));
-            } else kd_out[at] = x;
+            } else {
+                kd_out[at] = x;
+                if (ONEW_OUT && dnext) dnext[at] = (uint8_t)((uint64_t)x >> dnext_shift);
+            }
         }
     }
     if (ONEW_OUT || VN == 9) return;            // one word moved: nothing else to stage
@@ -704,6 +709,45 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t
     for (int d = threadIdx.x; d < RADIX; d += BLOCK) row[d] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
+// The same tile histograms from the digit bytes the pass before left beside its records (radix_scatter_tile: dnext): one byte read per
+// record instead of eight.  A WAVE takes a tile (TILE bytes = 64 per lane, read as four aligned 16-byte pieces; a tile's bytes start
+// anywhere: the bytes outside the tile are masked off, a lane-0 tail picks up what the shifted pieces miss) and counts into its own
+// 256 counters in LDS -- no barrier; eight tiles per workgroup.
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_kernel(const uint8_t* __restrict__ dig, OneWordTabs tb, unsigned vtiles, unsigned* __restrict__ tile_hist) {
+    constexpr int TILE = BLOCK * ITEMS, NW = BLOCK / WAVE;
+    static_assert(TILE == 64 * WAVE, "a lane takes 64 bytes of the tile");
+    __shared__ unsigned lh[NW][RADIX];
+    const unsigned wave = threadIdx.x / WAVE, lane = lane_id();
+    const unsigned vt = blockIdx.x * NW + wave;
+    if (vt >= vtiles) return;
+    const unsigned gs = vt / tb.slab;
+    const SlabInfo si = tb.slab_info[gs];
+    const uint64_t g0 = si.first + (uint64_t)(vt - gs * tb.slab) * TILE;      // global index of the tile's first record
+    if (g0 >= si.end) return;
+    const uint64_t g1 = si.end - g0 < (uint64_t)TILE ? si.end : g0 + TILE;
+    unsigned* const my = lh[wave];
+#pragma unroll
+    for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
+    xrun_order();
+    const uint64_t a0 = g0 & ~15ull;
+    // pieces a0 + 16 (i * 64 + lane), i = 0 .. 3, and one more piece (lane 0) when the tile does not start on a piece
+    auto piece = [&](uint64_t e0) {
+        if (e0 >= g1) return;
+        const uint4 q = *reinterpret_cast<const uint4*>(dig + e0);           // (the array is padded to whole pieces)
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (e0 + k >= g0 && e0 + k < g1) atomicAdd(&my[(w[k >> 2] >> (8 * (k & 3))) & 255u], 1u);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece(a0 + 16ull * (uint64_t)(i * WAVE + lane));
+    if (lane == 0 && a0 != g0) piece(a0 + 16ull * 4 * WAVE);
+    xrun_order();
+    unsigned* row = tile_hist + (uint64_t)vt * RADIX;
+#pragma unroll
+    for (int i = 0; i < RADIX / WAVE; ++i) row[i * WAVE + lane] = my[i * WAVE + lane];
+}
+
 // one workgroup per slab: exclusive scan of the tile counts of the slab per digit (in place), slab totals out
 template <int TAG>
 __global__ __launch_bounds__(RADIX) void radix_slab_scan1w_kernel(unsigned* __restrict__ tile_hist, OneWordTabs tb, unsigned tile_records,
@@ -752,7 +796,8 @@ template <int BLOCK, int ITEMS, int VN>
 __global__ __launch_bounds__(BLOCK, ITEMS <= 6 ? 8 : ITEMS <= 8 ? 6 : 4) void radix_scatter1w_kernel(
     const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift, OneWordTabs tb,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
-    const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack) {
+    const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack,
+    uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(VN == 8 || VN == 9, "one-word records in");
@@ -774,11 +819,11 @@ __global__ __launch_bounds__(BLOCK, ITEMS <= 6 ? 8 : ITEMS <= 8 ? 6 : 4) void ra
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, true, false, false, true, VN>(sh, t, (unsigned)TILE, in + off, nullptr, nullptr, out, nullptr, v_out,
                                                                                           shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, tb.slab,
-                                                                                          (uint64_t)b, pack);
+                                                                                          (uint64_t)b, pack, nullptr, dnext, dnext_shift);
     else
         radix_scatter_tile<uint64_t, unsigned, BLOCK, ITEMS, false, false, false, true, VN>(sh, t, (unsigned)remain, in + off, nullptr, nullptr, out, nullptr, v_out,
                                                                                            shift, db, nullptr, nullptr, nullptr, 0, 0, te, se, nullptr, tb.slab,
-                                                                                           (uint64_t)b, pack);
+                                                                                           (uint64_t)b, pack, nullptr, dnext, dnext_shift);
 }
 
 } // namespace psacx
