@@ -922,7 +922,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), lo1 | (low << 8) | (sfield << 16));
         }
         PSACX_HIP(c, hipGetLastError());
-        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += (last && !view_out ? 24ull : 16ull) * nrec;
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += ((last && !view_out ? 24ull : 16ull) + ((dig && !last) ? 1ull : 0ull)) * nrec;      // (+ the digit byte for the next pass's histograms)
         c->stats.onew_passes += 1;
         std::swap(cur, oth);
     }

@@ -582,6 +582,7 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
     //      Reduced-memory layout: grp, the array that does not end up with word 1 and the suffixes are the rank's three output arrays.
     const int npass = (int)((low + RADIX_BITS - 1) / RADIX_BITS);
     std::vector<DBuf<T>> grp(L), A(L), B(L), vout(L);
+    std::vector<DBuf<uint8_t>> dig(L);          // the digit the next bucket pass sorts on, a byte per record (engine.hpp: onew_bucket_passes)
     std::vector<uint64_t> share(L);
     int rc_alloc = PSACX_OK;
     for (int i = 0; i < L && rc_alloc == PSACX_OK; ++i) {
@@ -604,6 +605,7 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
         }
         if (rc_alloc == PSACX_OK) rc_alloc = k1_final.alloc(c, room, reserve_of(i));
         if (rc_alloc == PSACX_OK && !solo_ && !grp[i].p) rc_alloc = grp[i].alloc(c, ng, reserve_of(i));
+        if (rc_alloc == PSACX_OK && npass > 1) rc_alloc = dig[i].alloc(c, room + 64);
         if (rc_alloc != PSACX_OK) mg_set_err(g, "one-word first sort: record arrays: " + c->hip_err);
     }
     PSACX_TRY(agree(rc_alloc));
@@ -683,7 +685,7 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
             if (lay.need > scr[i].desc_bytes || lay.vtiles >= (1ull << 31)) { mg_set_err(g, "one-word first sort: scratch of the bucket passes too small"); return PSACX_EDEVICE; }
             uint64_t* res = nullptr;
             MG_OP(g, c, onew_bucket_passes(c, scr[i].desc, ht.data(), lay, reinterpret_cast<uint64_t*>(A[i].p), reinterpret_cast<uint64_t*>(B[i].p),
-                                           reinterpret_cast<uint64_t*>(vout[i].p), sfield, low, lo1, cntq, &res));
+                                           reinterpret_cast<uint64_t*>(vout[i].p), sfield, low, lo1, cntq, &res, nullptr, dig[i].p));
             s1[i] = res;
             return PSACX_OK;
         });
@@ -699,7 +701,7 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
     for (int i = 0; i < L; ++i) {
         DBuf<T>& k1_final = (npass & 1) ? B[i] : A[i];
         if (s1[i] && reinterpret_cast<T*>(s1[i]) != k1_final.p) { mg_set_err(g, "one-word first sort: word 1 ended in the wrong array"); return PSACX_EDEVICE; }
-        grp[i].release();
+        grp[i].release(); dig[i].release();
         ((npass & 1) ? A[i] : B[i]).release();
         rec[i] = Rec<T>();
         rec[i].k1 = std::move(k1_final); rec[i].v = std::move(vout[i]); rec[i].cnt = share[i];
