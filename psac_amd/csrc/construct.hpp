@@ -616,7 +616,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                                keep ? &onew_view : nullptr, dig);
                 if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
                     two_stage = false; retry_one_stage = true; one_word = false;
-                } else if (rc1 == PSACX_RETRY_1W || rc1 == PSACX_RETRY_1STAGE) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
+                } else if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
                     one_word = false;
                     PSACX_TRY(make_keys(hist_in_keys));
                 }
@@ -822,6 +822,9 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     uint64_t active = 0, unf_b = 0;
     // (64-bit words, at most 2^32 characters: the list comes with its entries' bucket numbers counted from 0, in the idle upper half of the
     //  payload array -- the one-word sort keys of the refinement rounds then need only as many bits as there are buckets)
+    // (ALIAS: ord_arr is the upper half of w.x.v.  x.v is also written in full by the last pass of a v32 sort, by shift_keys_kernel in whole
+    //  rounds at n = 2^32, by three-word sorts and as level-1 ISA pairs by the fused rebucket kernel.  Every reader of ord_arr --
+    //  gather_keys_kernel with by_ord -- runs directly after the run_compact that wrote it and before the round's sort touches x.v; keep it so.)
     uint32_t* const ord_arr = (sizeof(T) == 8 && n <= (1ull << 32)) ? reinterpret_cast<uint32_t*>(w.x.v) + n : (uint32_t*)nullptr;
     PSACX_TRY(run_compact<T>(c, w, w.bsa, nullptr, n, w.pos_a, &active, &unf_b, w.cap_active, 0, nullptr, nullptr, nullptr, 0, lazy_ids, ord_arr));
     r0->h = k; r0->active = n; r0->unfinished_buckets = unf_b; r0->unfinished_elements = active;

@@ -308,7 +308,8 @@ struct MultiRun {
     // its block that other ranks hold can be received in front of / behind them (rebalance_in_place); empty = no such layout
     std::vector<uint64_t> head_, room_;
     void drop3(int i, Rec<T>& r) {
-        if (r.k1.p && !r.k1.owned()) S[i].out_busy = false;
+        // (any member that lives in an output array: sort_first_one_word lends the SA array to the suffixes while word 1 is the engine's own)
+        if ((r.k1.p && !r.k1.owned()) || (r.k2.p && !r.k2.owned()) || (r.v.p && !r.v.owned())) S[i].out_busy = false;
         r = Rec<T>();
     }
     void swap3(Rec<T>& a, Rec<T>& b) { std::swap(a.k1, b.k1); std::swap(a.k2, b.k2); std::swap(a.v, b.v); }

@@ -118,7 +118,12 @@ struct ShmLink {
                         else if (h->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)P) wrong = " is held by all its ranks already: the communicator id must be unique";
                         else joined = true;
                     }
-                    if (joined && h->attached.load(std::memory_order_acquire) >= (uint32_t)P) break;
+                    if (joined && h->attached.load(std::memory_order_acquire) >= (uint32_t)P) {
+                        // (a segment a crashed run left behind can reach its count through late joiners like this one while rank 0 is
+                        //  replacing it: the name must still lead here before the count is believed -- ADVICE r4)
+                        if (stale()) { retry = true; }
+                        break;
+                    }
                     if ((wrong || (spin & 63u) == 63u) && stale()) { retry = true; break; }
                     if (late()) {
                         err = wrong ? "shared segment " + name + wrong : "timed out waiting for the peers of " + name;
