@@ -48,12 +48,16 @@ template <typename T> struct Work {
 // Diet layout (when that does not fit in HBM): the second record set of the first sort is the
 // output buffers themselves (ISA, LCP, SA are dead until the sort is over), and the refinement
 // rounds get `cap` records of room instead of n (4 n w + 5 cap w bytes).
+// slack of the first record array for the padded output of the pass on the top digit (engine.hpp: prefix_sort_1w)
+constexpr uint64_t ONEW_PAD = 20480;            // places per bucket: 160 KiB
+template <typename T> inline uint64_t onew_pad_total(uint64_t n) { return (sizeof(T) == 8 && n >= (1ull << 28)) ? (uint64_t)RADIX * ONEW_PAD : 0; }
+
 template <typename T>
 size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool diet, uint64_t cap, T* d_sa, T* d_isa, const Knobs& kn) {
     w.diet = diet;
     w.cap_active = diet ? cap : n;
     w.bsa = a.take<T>(n);
-    w.x.k1 = a.take<T>(n); w.x.k2 = a.take<T>(n); w.x.v = a.take<T>(n);
+    w.x.k1 = a.take<T>(n + onew_pad_total<T>(n)); w.x.k2 = a.take<T>(n); w.x.v = a.take<T>(n);
     if (!diet) {
         w.y.k1 = a.take<T>(n); w.y.k2 = a.take<T>(n); w.y.v = a.take<T>(n);
         w.ry = w.y;
@@ -613,7 +617,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 uint8_t* const dig = kn.no_digit_bytes ? (uint8_t*)nullptr : reinterpret_cast<uint8_t*>(w.diet ? w.x.k2 : first_alt.k2);
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
                                                reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
-                                               keep ? &onew_view : nullptr, dig);
+                                               keep ? &onew_view : nullptr, dig,
+                                               (in1.k1 == w.x.k1 && onew_pad_total<T>(n) && !kn.no_pad) ? ONEW_PAD : (uint64_t)0);
                 if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
                     two_stage = false; retry_one_stage = true; one_word = false;
                 } else if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)

@@ -150,6 +150,7 @@ struct Knobs {
                             // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
                             // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
     bool no_digit_bytes;    // PSACX_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
+    bool no_pad;            // PSACX_NO_PAD: the pass on the top digit writes its buckets back to back (A/B runs of the padded layout)
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -166,6 +167,7 @@ inline Knobs read_knobs() {
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
     k.no_digit_bytes = getenv("PSACX_NO_DIGIT_BYTES") != nullptr;
+    k.no_pad = getenv("PSACX_NO_PAD") != nullptr;
     e = getenv("PSACX_ISA_UPDATE");
     k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
     return k;
@@ -878,7 +880,9 @@ inline OneWordLayout onew_layout(unsigned long long* h_tabs, uint64_t ntiles_hin
 // dig != nullptr: one byte per record (the array padded to a multiple of 16) that holds, at every place, the digit of the record there that the NEXT pass sorts on
 // -- written by the pass on the top digit and by every bucket pass but the last; the tile histograms then read it instead of the records.
 inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long long* h_tabs, const OneWordLayout& lay, uint64_t* cur, uint64_t* oth, uint64_t* sa_out,
-                              unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1, OneWordView* view_out = nullptr, uint8_t* dig = nullptr) {
+                              unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1, OneWordView* view_out = nullptr, uint8_t* dig = nullptr,
+                              uint64_t in_pad = 0) {
+    // in_pad: in the input of the FIRST pass the records of bucket b lie b * in_pad places further than bucket_off says (prefix_sort_1w)
     constexpr int BLOCK = 512, ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + lay.hist_bytes);
@@ -905,7 +909,8 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
             if (dig && j > 0) hipLaunchKernelGGL((radix_tile_hist_bytes_kernel<BLOCK, ITEMS_B>), dim3((unsigned)((vtiles + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0, c->stream,
                                                  (const uint8_t*)dig, tb, (unsigned)vtiles, tile_hist);
             else
-            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS_B>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist);
+            hipLaunchKernelGGL((radix_tile_hist1w_kernel<BLOCK, ITEMS_B>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, tb, shift, tile_hist,
+                               j == 0 ? in_pad : (uint64_t)0);
             hipLaunchKernelGGL(radix_slab_scan1w_kernel<0>, dim3((unsigned)total_slabs), dim3(RADIX), 0, c->stream, tile_hist, tb, (unsigned)TILE, slab_tot);
             hipLaunchKernelGGL(radix_top_scan1w_kernel<0>, dim3(RADIX), dim3(RADIX), 0, c->stream, slab_tot, tb, base2);
             PSACX_HIP(c, hipGetLastError());
@@ -915,11 +920,12 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
         if (!last || view_out)
             hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), 0u,
-                               last ? (uint8_t*)nullptr : dig, shift + RADIX_BITS);
+                               last ? (uint8_t*)nullptr : dig, shift + RADIX_BITS, j == 0 ? in_pad : (uint64_t)0);
         else {
             // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
             hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
-                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), lo1 | (low << 8) | (sfield << 16));
+                               tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), lo1 | (low << 8) | (sfield << 16),
+                               (uint8_t*)nullptr, 0, j == 0 ? in_pad : (uint64_t)0);
         }
         PSACX_HIP(c, hipGetLastError());
         c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += ((last && !view_out ? 24ull : 16ull) + ((dig && !last) ? 1ull : 0ull)) * nrec;      // (+ the digit byte for the next pass's histograms)
@@ -934,7 +940,10 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
 // dig: n bytes (rounded up to 16) of scratch for the digit bytes between the passes (onew_bucket_passes), or null
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
                           psacx_round* rs, uint64_t** s1, const uint8_t* text, uint64_t n_text, const CodeTable& tab, const KeyShape& ks, bool probe,
-                          OneWordView* view_out = nullptr, uint8_t* dig = nullptr) {
+                          OneWordView* view_out = nullptr, uint8_t* dig = nullptr, uint64_t pad = 0) {
+    // pad (even; k0 must hold n + 256 * pad words): the pass on the top digit writes bucket b's records b * pad places further -- into k0, so that
+    // only the first bucket pass reads the padded layout -- because output fronts a multiple of 2^27 bytes apart (2^32 records of 8 bytes in 256
+    // equal buckets) alias in the memory channels (tools/ubench_fronts.hip)
     constexpr int BLOCK = 512, ITEMS = 8, TILE0 = BLOCK * ITEMS;          // the pass on the top digit
     // (bucket passes with other tiles, measured at 2^32 records: 512 x 6 -- 62 VGPRs, four workgroups per CU -- 106 ms for the five
     //  passes against 89 ms; 512 x 12 -- two workgroups per CU -- 89 ms: the run length gained is the occupancy lost)
@@ -985,15 +994,16 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     {
         ProfScope ps(c, TC_KMER);           // (key generation and the partition by the top digit in one kernel: timed with the keys)
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
-        hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, tab, ks, a, (int)(lo1 + low),
+        hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, tab, ks, pad ? k0 : a, (int)(lo1 + low),
                            base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1 | (sfield << 16), (uint64_t)0,
-                           (uint8_t*)nullptr, 0);       // (no digit bytes out of this pass: their stores cost it 4.5 ms, the record histogram of the first bucket pass 3.7)
+                           (uint8_t*)nullptr, 0, pad);  // (no digit bytes out of this pass: their stores cost it 4.5 ms, the record histogram of the first bucket pass 3.7)
         PSACX_HIP(c, hipGetLastError());
     }
     // the buckets (the tables of the first pass in the scratch are dead once its scatter has run: same stream)
     uint64_t* cur = nullptr;
-    PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur, view_out, dig));
-    *s1 = cur;          // (k0 after an odd number of bucket passes, `a` after an even number)
+    if (pad) PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, k0, a, sa_out, sfield, low, lo1, n, &cur, view_out, dig, pad));
+    else PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur, view_out, dig));
+    *s1 = cur;          // (without pad: k0 after an odd number of bucket passes, `a` after an even number; with pad the other way round)
     if (rs) { rs->sort_passes = (uint32_t)((low + RADIX_BITS - 1) / RADIX_BITS + 1); rs->sort_passes_skipped = 0; }
     return PSACX_OK;
 }

@@ -174,7 +174,9 @@ __device__ __forceinline__ void radix_scatter_tile(
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
     const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0,
-    const T (*kd_made)[ITEMS] = nullptr, uint8_t* __restrict__ dnext = nullptr, const int dnext_shift = 0) {
+    const T (*kd_made)[ITEMS] = nullptr, uint8_t* __restrict__ dnext = nullptr, const int dnext_shift = 0, const uint64_t out_pad = 0) {
+    // out_pad: the records of digit d land d * out_pad places further (the pass on the top digit: 256 output fronts that lie a multiple of
+    // 2^27 bytes apart alias in the memory channels -- 14.1 against 7.2 ms for the stores alone at 2^32 records, tools/ubench_fronts.hip)
     // dnext (one-word records out): byte `at` receives bits dnext_shift .. + 7 of the record written to place `at` -- the digit the NEXT pass
     // sorts on, so that its tile histograms read one byte per record instead of the record (radix_tile_hist_bytes_kernel)
     constexpr int TILE = BLOCK * ITEMS;
@@ -344,7 +346,7 @@ __device__ __forceinline__ void radix_scatter_tile(
             }
             desc_store<D>(desc + (uint64_t)tile * RADIX + tid, 2u, (D)(excl + tot));
         }
-        goff[tid] = (T)((LB ? (uint64_t)digit_base[tid] : 0ull) + excl - (uint64_t)bs);
+        goff[tid] = (T)((LB ? (uint64_t)digit_base[tid] : 0ull) + excl - (uint64_t)bs + (uint64_t)tid * out_pad);
     }
     __syncthreads();
     if (stamp) mydbg[3] = __builtin_amdgcn_s_memtime();
@@ -659,12 +661,15 @@ __global__ void radix_slab_info_kernel(const unsigned long long* __restrict__ bu
 }
 
 template <int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t* __restrict__ in, OneWordTabs tb, int shift, unsigned* __restrict__ tile_hist) {
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist1w_kernel(const uint64_t* __restrict__ in, OneWordTabs tb, int shift, unsigned* __restrict__ tile_hist,
+                                                                  uint64_t in_pad = 0) {
+    // in_pad (even): the records of bucket b lie b * in_pad places behind where the tables say (radix_scatter_tile: out_pad)
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int PER = 2;
     const unsigned vt = blockIdx.x;
     const unsigned gs = vt / tb.slab;
     const SlabInfo si = tb.slab_info[gs];
+    in += (uint64_t)si.bucket * in_pad;
     const uint64_t g0 = si.first + (uint64_t)(vt - gs * tb.slab) * TILE;      // global index of the tile's first record
     if (g0 >= si.end) return;
     const uint64_t g1 = si.end - g0 < (uint64_t)TILE ? si.end : g0 + TILE;
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(BLOCK, ITEMS <= 6 ? 8 : ITEMS <= 8 ? 6 : 4) void ra
     const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* __restrict__ v_out, int shift, OneWordTabs tb,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned* __restrict__ tile_counter, unsigned chunk, unsigned pack,
-    uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0) {
+    uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0, uint64_t in_pad = 0) {
     constexpr int TILE = BLOCK * ITEMS;
     constexpr int NW = BLOCK / WAVE;
     static_assert(VN == 8 || VN == 9, "one-word records in");
@@ -811,6 +816,7 @@ __global__ __launch_bounds__(BLOCK, ITEMS <= 6 ? 8 : ITEMS <= 8 ? 6 : 4) void ra
     const unsigned b = si.bucket, s0 = si.slab0;
     const unsigned t = vt - s0 * tb.slab;
     const uint64_t off = si.first - (uint64_t)(gs - s0) * tb.slab * TILE, n = si.end - off;
+    in += (uint64_t)b * in_pad;
     if ((uint64_t)t * TILE >= n) return;
     const uint64_t remain = n - (uint64_t)t * TILE;
     const unsigned* te = tile_excl + (uint64_t)s0 * tb.slab * RADIX;

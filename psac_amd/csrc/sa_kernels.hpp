@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
                                                                  uint64_t* __restrict__ out, int shift, const unsigned long long* __restrict__ digit_base,
                                                                  const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
                                                                  unsigned* __restrict__ tile_counter, unsigned chunk, unsigned slab_tiles, unsigned lo1,
-                                                                 uint64_t voff = 0, uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0) {
+                                                                 uint64_t voff = 0, uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0, uint64_t out_pad = 0) {
     // lo1: bits of word 1 below the sorted prefix | width of the payload field << 16 (radix.hpp: ONEW_MAKE; 0 = 32)
     // voff: added to the suffix a record stands for (a rank's block of a distributed text)
     // dnext: the digit the first bucket pass sorts on, one byte per record (radix.hpp: radix_scatter_tile)
@@ -461,11 +461,11 @@ __global__ __launch_bounds__(BLOCK, 6) void key_scatter1w_kernel(const uint8_t* 
     if (remain >= (uint64_t)TILE)
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, false, true, 10>(sh, tile, (unsigned)TILE, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
                                                                                    digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
-                                                                                   slab_tiles, voff, lo1, &kd, dnext, dnext_shift);
+                                                                                   slab_tiles, voff, lo1, &kd, dnext, dnext_shift, out_pad);
     else
         radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, false, true, 10>(sh, tile, (unsigned)remain, nullptr, nullptr, nullptr, out, nullptr, nullptr, shift,
                                                                                     digit_base, nullptr, nullptr, nullptr, ks.spec, ks.spec ? n : (uint64_t)0, tile_excl, slab_excl, nullptr,
-                                                                                    slab_tiles, voff, lo1, &kd, dnext, dnext_shift);
+                                                                                    slab_tiles, voff, lo1, &kd, dnext, dnext_shift, out_pad);
 }
 
 // characters two packed windows share from the left (bitops.hpp:170-183 on the packed form)
