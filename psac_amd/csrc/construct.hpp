@@ -618,7 +618,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
                                                reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
                                                keep ? &onew_view : nullptr, dig,
-                                               (in1.k1 == w.x.k1 && onew_pad_total<T>(n) && !kn.no_pad) ? ONEW_PAD : (uint64_t)0);
+                                               (in1.k1 == w.x.k1 && onew_pad_total<T>(n)) ? ONEW_PAD : (uint64_t)0);
                 if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
                     two_stage = false; retry_one_stage = true; one_word = false;
                 } else if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)

@@ -150,7 +150,6 @@ struct Knobs {
                             // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
                             // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
     bool no_digit_bytes;    // PSACX_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
-    bool no_pad;            // PSACX_NO_PAD: the pass on the top digit writes its buckets back to back (A/B runs of the padded layout)
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -167,7 +166,6 @@ inline Knobs read_knobs() {
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
     k.no_digit_bytes = getenv("PSACX_NO_DIGIT_BYTES") != nullptr;
-    k.no_pad = getenv("PSACX_NO_PAD") != nullptr;
     e = getenv("PSACX_ISA_UPDATE");
     k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
     return k;
