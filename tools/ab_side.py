@@ -1,0 +1,20 @@
+"""Wall time of construct_device on the side workloads of bench.py (for A/B runs of a knob): python tools/ab_side.py KIND LOG2N PERIOD [REPS]
+KIND: 0 random DNA, 2 tandem repeat, 3 repeated reads with mutations (psacx_synth_text_dev)."""
+import sys, time, ctypes as C, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import psac_amd
+kind, lg, period = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+n = 1 << lg
+ctx = psac_amd.Context(0)
+d_text = ctx.alloc(n)
+ctx.check(ctx._lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, kind, 7, period))
+d_sa, d_isa, d_lcp = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * 8)
+sa = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+ts = []
+for _ in range(reps):
+    t0 = time.perf_counter()
+    st = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("kind", kind, "n 2^%d" % lg, "knob", os.environ.get("PSACX_NO_DIGIT_BYTES"), "ms", " ".join("%.1f" % t for t in ts), "rounds", st.n_rounds)
