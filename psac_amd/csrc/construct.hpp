@@ -10,6 +10,7 @@
 // reference's because they are uniquely determined by the text.
 #pragma once
 #include "engine.hpp"
+#include "bucket_sort.hpp"
 
 namespace psacx {
 
@@ -38,6 +39,7 @@ template <typename T> struct Work {
     uint64_t* d_nact;                  // per scan tile: active positions (then exclusive sum-scan)
     uint64_t* d_nunf;                  // per scan tile: buckets with > 1 member
     uint64_t* d_totals;                // [0] active, [1] unfinished buckets
+    uint64_t* d_over;                  // [2] tasks too long for the sort in LDS (bucket_sort.hpp), wide / narrow windows
     uint64_t* d_chunks;                // 2 x SCAN_CHUNKS chunk totals of the long tile scans
     unsigned* d_cursors;               // fill cursors of the destination buckets (ISA inversion)
     size_t n_cursors;
@@ -87,6 +89,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.d_nact = a.take<uint64_t>(nt);
     w.d_nunf = a.take<uint64_t>(nt);
     w.d_totals = a.take<uint64_t>(4);
+    w.d_over = a.take<uint64_t>(2);
     w.d_chunks = a.take<uint64_t>(2 * SCAN_CHUNKS);
     w.n_cursors = (size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P;
     w.d_cursors = a.take<unsigned>(w.n_cursors);
@@ -873,7 +876,45 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
         psacx_round rs; std::memset(&rs, 0, sizeof(rs));
-        if (both) {
+        // no bucket longer than a workgroup holds in LDS (asked of the device first): every bucket is sorted there and the records cross
+        // memory once (bucket_sort.hpp); a text with a few huge buckets left -- a tandem repeat -- is not worth the question
+        bool sorted_in_lds = false;
+        if constexpr (sizeof(T) == 8) {
+            if (both && dense && !kn.no_bucket_sort && (by_ord ? cnt / nb_in : (uint64_t)0) <= BSORT_CAP / 4) {
+                // (wide windows first; both questions are asked before the one synchronisation)
+                const uint64_t nt_wide = (cnt + BSORT_W_WIDE - 1) / BSORT_W_WIDE, nt_narrow = (cnt + BSORT_W_NARROW - 1) / BSORT_W_NARROW;
+                uint64_t* const st_wide = reinterpret_cast<uint64_t*>(w.sc.d_desc + 256);
+                uint64_t* const st_narrow = st_wide + nt_wide + 1;
+                unsigned long long* d_over = reinterpret_cast<unsigned long long*>(w.d_over);
+                unsigned long long* h_over = reinterpret_cast<unsigned long long*>(c->pinned + 96);
+                {
+                    ProfScope ps(c, TC_SORT_HIST);
+                    PSACX_HIP(c, hipMemsetAsync(d_over, 0, 2 * sizeof(unsigned long long), c->stream));
+                    hipLaunchKernelGGL(bucket_task_starts_kernel<0>, dim3((unsigned)((nt_wide + 1 + 3) / 4)), dim3(256), 0, c->stream,
+                                       reinterpret_cast<const uint64_t*>(w.x.k1), cnt, kb2, nt_wide, BSORT_W_WIDE, st_wide, d_over);
+                    hipLaunchKernelGGL(bucket_task_starts_kernel<0>, dim3((unsigned)((nt_narrow + 1 + 3) / 4)), dim3(256), 0, c->stream,
+                                       reinterpret_cast<const uint64_t*>(w.x.k1), cnt, kb2, nt_narrow, BSORT_W_NARROW, st_narrow, d_over + 1);
+                    PSACX_HIP(c, hipGetLastError());
+                    PSACX_HIP(c, hipMemcpyAsync(h_over, d_over, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+                }
+                PSACX_HIP(c, hipStreamSynchronize(c->stream));
+                const bool wide = h_over[0] == 0;
+                const uint64_t ntasks = wide ? nt_wide : nt_narrow;
+                const uint64_t* const starts = wide ? st_wide : st_narrow;
+                if (wide || h_over[1] == 0) {
+                    ProfScope ps(c, TC_SORT_SCATTER);
+                    hipLaunchKernelGGL((bucket_sort_lds_kernel<BSORT_BLOCK, BSORT_ITEMS>), dim3((unsigned)ntasks), dim3(BSORT_BLOCK), 0, c->stream,
+                                       reinterpret_cast<const uint64_t*>(w.x.k1), reinterpret_cast<const uint32_t*>(w.x.v), starts, kb2,
+                                       reinterpret_cast<uint64_t*>(w.ry.k1), reinterpret_cast<uint64_t*>(w.ry.v));
+                    PSACX_HIP(c, hipGetLastError());
+                    sorted.k1 = w.ry.k1; sorted.k2 = nullptr; sorted.v = w.ry.v;
+                    rs.sort_passes = 1;
+                    sorted_in_lds = true;
+                }
+            }
+        }
+        if (sorted_in_lds) {
+        } else if (both) {
             SortBufs<T> in2{w.x.k1, nullptr, w.x.v}, alt2{w.ry.k1, nullptr, w.ry.v};
             PSACX_TRY(pair_sort<T>(c, w.sc, in2, alt2, cnt, /*iota=*/false, kb2 + num_bits, 0, nullptr, &sorted, &rs, 0, 0,
                                    /*summary_ready=*/true, 0, -1, /*v32_in=*/true));
@@ -949,6 +990,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             PSACX_HIP(c, hipStreamSynchronize(c->stream));
             if (*h_near * 2 > samples) whole = false;
         }
+        // (Tried: such a round through the list when its sort can stay in LDS -- 2^30 characters of repeated reads with mutations 682 -> 778 ms:
+        //  the random fetch of the ranks and the random ISA stores of nearly n suffixes cost more than the eight passes over three words.)
         if (whole) {
             PSACX_TRY(refine((const T*)nullptr, n, h, rr, pos_next, &nactive, &unf_b, true));
             std::swap(pos, pos_next);

@@ -150,6 +150,7 @@ struct Knobs {
                             // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
                             // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
     bool no_digit_bytes;    // PSACX_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
+    bool no_bucket_sort;    // PSACX_NO_BUCKET_SORT: the refinement rounds always take the global radix sort (A/B runs; bucket_sort.hpp)
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -165,6 +166,7 @@ inline Knobs read_knobs() {
     e = getenv("PSACX_ONE_WORD_MIN");
     k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
     k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
+    k.no_bucket_sort = getenv("PSACX_NO_BUCKET_SORT") != nullptr;
     k.no_digit_bytes = getenv("PSACX_NO_DIGIT_BYTES") != nullptr;
     e = getenv("PSACX_ISA_UPDATE");
     k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
