@@ -795,6 +795,21 @@ def test_refinement_round_forms(ctx):
             assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
 
 
+def test_refinement_sort_inside_lds(ctx, monkeypatch):
+    # bucket_sort.hpp: 64-bit words, a list round of at least 2^21 unresolved suffixes none of whose buckets is longer than a workgroup
+    # holds in LDS -- every bucket is sorted there (one pass reported for the round) instead of by the global radix passes.  Repeated reads
+    # with mutations: 2048 copies of 4096 characters, so no bucket outgrows 2048 suffixes.  Both forms must give the oracle's arrays and log.
+    text = inputs.mutated((1 << 23) + 1234, 4096, 5)
+    got, ref = same_as_oracle(ctx, text, bits=64)
+    assert [(h, b, e) for (h, b, e, *_rest) in got.rounds] == [(h, b, e) for h, b, e, _ in ref["trace"]]
+    in_lds = [r for r in got.rounds[1:] if r[3] >= (1 << 21) and r[4] == 1]
+    assert in_lds, got.rounds
+    monkeypatch.setenv("PSACX_NO_BUCKET_SORT", "1")
+    other, _ = same_as_oracle(ctx, text, bits=64)
+    assert not [r for r in other.rounds[1:] if r[3] >= (1 << 21) and r[4] == 1]
+    assert np.array_equal(other.local_SA, got.local_SA) and np.array_equal(other.local_LCP, got.local_LCP)
+
+
 def test_ansv_device_resident(ctx):
     # psacx_ansv_dev_*: LCP left in HBM by the construction -> ANSV without leaving the device (psac -t's
     # pair: left furthest_eq, right nearest_sm, suffix_tree.hpp:62); 2^24 characters, compared with the oracle
