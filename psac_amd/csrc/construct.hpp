@@ -610,6 +610,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
     if (two_stage) {
         SortBufs<T> in1{first_in.k1, nullptr, first_in.v}, alt1{first_alt.k1, nullptr, first_alt.v};
         bool packed1 = false;            // the one-word sort ran: word 1 comes back without its bits below the prefix
+        uint8_t* tie_bytes = nullptr;    // ... and left the lowest byte of every record's prefix bits here (engine.hpp: onew_bucket_passes)
         onew_recs = false;
         if constexpr (sizeof(T) == 8) {
             if (one_word) {
@@ -618,10 +619,12 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 const bool keep = !kn.widen_last && !kn.ties_radix && isa_narrow_levels<T>(n, kn) > 0;
                 // (the digit bytes between the passes live in the array that takes word 2 of the tied suffixes after the sort: idle until then)
                 uint8_t* const dig = kn.no_digit_bytes ? (uint8_t*)nullptr : reinterpret_cast<uint8_t*>(w.diet ? w.x.k2 : first_alt.k2);
+                // (... and the bytes the tie stage looks for its groups in live in the other second-word array, which nobody writes before the rebucket kernel)
+                tie_bytes = (keep && !kn.no_digit_bytes) ? reinterpret_cast<uint8_t*>(w.diet ? w.y.k2 : first_in.k2) : (uint8_t*)nullptr;
                 const int rc1 = prefix_sort_1w(c, w.sc, reinterpret_cast<uint64_t*>(in1.k1), reinterpret_cast<uint64_t*>(alt1.k1),
                                                reinterpret_cast<uint64_t*>(d_sa), n, lo1, lead, r0, &s1, d_text, n, tab, ks, !kn.one_word_always,
                                                keep ? &onew_view : nullptr, dig,
-                                               (in1.k1 == w.x.k1 && onew_pad_total<T>(n)) ? ONEW_PAD : (uint64_t)0);
+                                               (in1.k1 == w.x.k1 && onew_pad_total<T>(n)) ? ONEW_PAD : (uint64_t)0, tie_bytes);
                 if (rc1 == PSACX_RETRY_1STAGE) {          // (nearly every suffix ties on the prefix: one sort over both words; nothing was written)
                     two_stage = false; retry_one_stage = true; one_word = false;
                 } else if (rc1 == PSACX_RETRY_1W) {          // (a repetitive text, or no room for the bucket tables: nothing was written)
@@ -658,7 +661,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             if constexpr (sizeof(T) == 8) {
                 if (onew_recs)          // S1: the one-word records; the array the last pass did not write takes word 1 of the tied suffixes
                     hipLaunchKernelGGL((tie_resolve_1w_kernel<TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, reinterpret_cast<uint64_t*>(S1),
-                                       reinterpret_cast<uint64_t*>(free_k1), reinterpret_cast<uint64_t*>(S2), n, onew_view, d_text, n, tab, ks, d_big);
+                                       reinterpret_cast<uint64_t*>(free_k1), reinterpret_cast<uint64_t*>(S2), n, onew_view, d_text, n, tab, ks, d_big,
+                                       (const uint8_t*)tie_bytes);
             }
             if (!kn.ties_radix && !onew_recs)
                 hipLaunchKernelGGL((tie_resolve_kernel<T, TB, TI, TG>), dim3((unsigned)nb), dim3(TB), 0, c->stream, S1, d_sa, S2, n, lo1,

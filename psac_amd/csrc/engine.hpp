@@ -881,7 +881,9 @@ inline OneWordLayout onew_layout(unsigned long long* h_tabs, uint64_t ntiles_hin
 // -- written by the pass on the top digit and by every bucket pass but the last; the tile histograms then read it instead of the records.
 inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long long* h_tabs, const OneWordLayout& lay, uint64_t* cur, uint64_t* oth, uint64_t* sa_out,
                               unsigned sfield, unsigned low, unsigned lo1, uint64_t nrec, uint64_t** s1, OneWordView* view_out = nullptr, uint8_t* dig = nullptr,
-                              uint64_t in_pad = 0) {
+                              uint64_t in_pad = 0, uint8_t* tie_bytes = nullptr) {
+    // tie_bytes (with view_out): the last pass leaves the LOWEST byte of the prefix bits of the record at every place there: two neighbours that
+    // tie on the prefix agree in it, two that do not agree in it once in 256 -- the tie stage reads these bytes instead of the records
     // in_pad: in the input of the FIRST pass the records of bucket b lie b * in_pad places further than bucket_off says (prefix_sort_1w)
     constexpr int BLOCK = 512, ITEMS_B = PSACX_1W_ITEMS, TILE = BLOCK * ITEMS_B;
     unsigned* tile_hist = reinterpret_cast<unsigned*>(scratch + 256);
@@ -920,7 +922,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
         if (!last || view_out)
             hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 8>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, (uint64_t*)nullptr, shift,
                                tb, base2, tile_hist, slab_tot, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(nrec, true), 0u,
-                               last ? (uint8_t*)nullptr : dig, shift + RADIX_BITS, j == 0 ? in_pad : (uint64_t)0);
+                               last ? tie_bytes : dig, last ? (int)sfield : shift + RADIX_BITS, j == 0 ? in_pad : (uint64_t)0);
         else {
             // the last pass reads `cur` and writes word 1 into the other array and the suffixes into sa_out
             hipLaunchKernelGGL((radix_scatter1w_kernel<BLOCK, ITEMS_B, 9>), dim3((unsigned)vtiles), dim3(BLOCK), 0, c->stream, (const uint64_t*)cur, oth, sa_out, shift,
@@ -928,7 +930,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
                                (uint8_t*)nullptr, 0, j == 0 ? in_pad : (uint64_t)0);
         }
         PSACX_HIP(c, hipGetLastError());
-        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += ((last && !view_out ? 24ull : 16ull) + ((dig && !last) ? 1ull : 0ull)) * nrec;      // (+ the digit byte for the next pass's histograms)
+        c->stats.scatter_launches[2] += 1; c->stats.scatter_records[2] += nrec; c->stats.scatter_bytes[2] += ((last && !view_out ? 24ull : 16ull) + (((dig && !last) || (last && view_out && tie_bytes)) ? 1ull : 0ull)) * nrec;      // (+ the digit byte for the next pass's histograms)
         c->stats.onew_passes += 1;
         std::swap(cur, oth);
     }
@@ -940,7 +942,7 @@ inline int onew_bucket_passes(psacx_ctx* c, char* scratch, const unsigned long l
 // dig: n bytes (rounded up to 16) of scratch for the digit bytes between the passes (onew_bucket_passes), or null
 inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t* a, uint64_t* sa_out, uint64_t n, unsigned lo1, unsigned lead,
                           psacx_round* rs, uint64_t** s1, const uint8_t* text, uint64_t n_text, const CodeTable& tab, const KeyShape& ks, bool probe,
-                          OneWordView* view_out = nullptr, uint8_t* dig = nullptr, uint64_t pad = 0) {
+                          OneWordView* view_out = nullptr, uint8_t* dig = nullptr, uint64_t pad = 0, uint8_t* tie_bytes = nullptr) {
     // pad (even; k0 must hold n + 256 * pad words): the pass on the top digit writes bucket b's records b * pad places further -- into k0, so that
     // only the first bucket pass reads the padded layout -- because output fronts a multiple of 2^27 bytes apart (2^32 records of 8 bytes in 256
     // equal buckets) alias in the memory channels (tools/ubench_fronts.hip)
@@ -1001,8 +1003,8 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
     }
     // the buckets (the tables of the first pass in the scratch are dead once its scatter has run: same stream)
     uint64_t* cur = nullptr;
-    if (pad) PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, k0, a, sa_out, sfield, low, lo1, n, &cur, view_out, dig, pad));
-    else PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur, view_out, dig));
+    if (pad) PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, k0, a, sa_out, sfield, low, lo1, n, &cur, view_out, dig, pad, tie_bytes));
+    else PSACX_TRY(onew_bucket_passes(c, scratch, h_tabs, lay, a, k0, sa_out, sfield, low, lo1, n, &cur, view_out, dig, 0, tie_bytes));
     *s1 = cur;          // (without pad: k0 after an odd number of bucket passes, `a` after an even number; with pad the other way round)
     if (rs) { rs->sort_passes = (uint32_t)((low + RADIX_BITS - 1) / RADIX_BITS + 1); rs->sort_passes_skipped = 0; }
     return PSACX_OK;

@@ -1561,7 +1561,10 @@ __global__ __launch_bounds__(BLOCK) void tie_resolve_kernel(T* __restrict__ S1, 
 template <int BLOCK, int ITEMS, int G>
 __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __restrict__ R, uint64_t* __restrict__ W1, uint64_t* __restrict__ S2,
                                                                uint64_t n, OneWordView ow, const uint8_t* __restrict__ text, uint64_t n_text,
-                                                               CodeTable tab, KeyShape ks, unsigned long long* __restrict__ big) {
+                                                               CodeTable tab, KeyShape ks, unsigned long long* __restrict__ big,
+                                                               const uint8_t* __restrict__ tb = nullptr) {
+    // tb (optional): the lowest byte of the prefix bits of the record at every place (written by the last pass of the sort): the groups are
+    // looked for in these bytes -- neighbours that tie agree in them, others do once in 256 -- and only such neighbours' records are read
     typedef uint64_t T;
     constexpr int TILE = BLOCK * ITEMS;
     __shared__ uint16_t ctab[256];
@@ -1575,7 +1578,32 @@ __global__ __launch_bounds__(BLOCK, 4) void tie_resolve_1w_kernel(uint64_t* __re
     ow.off = s_off;
     const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
     const uint64_t e0 = t0 + (uint64_t)threadIdx.x * ITEMS;
-    if (e0 < n) {
+    if (tb && e0 < n) {
+        static_assert(ITEMS == 32, "a thread takes the 32 bytes of its places as two 16-byte pieces");
+        auto starts_bucket = [&](uint64_t e) -> bool { return ow.off[onew_bucket(ow, e)] == e; };
+        const uint4 q0 = *reinterpret_cast<const uint4*>(tb + e0), q1 = *reinterpret_cast<const uint4*>(tb + e0 + 16);
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        auto byte_at = [&](int j) -> unsigned { return (w[j >> 2] >> (8 * (j & 3))) & 255u; };
+        const unsigned before = e0 ? (unsigned)tb[e0 - 1] : 256u, after = e0 + ITEMS < n ? (unsigned)tb[e0 + ITEMS] : 256u;
+        // bit j + 1: the places e0 + j and e0 + j + 1 agree in their bytes (j = -1 .. 31)
+        uint64_t cand = before == byte_at(0) ? 1ull : 0ull;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned nx = j + 1 < ITEMS ? byte_at(j + 1 < ITEMS ? j + 1 : 0) : after;
+            if (byte_at(j) == nx && e0 + j + 1 < n) cand |= 1ull << (j + 1);
+        }
+        uint64_t tied = 0;                              // ... and their prefixes agree, inside one bucket
+        while (cand) {
+            const int jj = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const uint64_t e = e0 + (uint64_t)jj - 1;
+            const T x = R[e], y = R[e + 1];
+            if ((x >> ow.sfield) == (y >> ow.sfield) && !starts_bucket(e + 1)) tied |= 1ull << jj;
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (((tied >> (j + 1)) & 1ull) && !((tied >> j) & 1ull)) leaders[atomicAdd(&n_leaders, 1u)] = (unsigned)(e0 + j - t0);
+    } else if (e0 < n) {
         // two neighbours tie when the rest of their prefixes agree and no bucket starts between them; the bucket table is asked only
         // where the rests agree (one record in 250 on random text), not walked along with every record
         T mid[ITEMS];
