@@ -94,7 +94,7 @@ void psacx_destroy(psacx_ctx* ctx);
 const char* psacx_strerror(int code);
 /* text of the last HIP error seen by this ctx ("" if none) */
 const char* psacx_last_hip_error(const psacx_ctx* ctx);
-/* release the cached HBM workspace (it is re-grown on the next call) */
+/* release the cached HBM workspace and the host-side staging of the host-pointer path: pinned ring, widening threads (all re-made on the next call that needs them) */
 int psacx_trim(psacx_ctx* ctx);
 
 /* construction ------------------------------------------------------------

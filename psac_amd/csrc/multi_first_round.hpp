@@ -571,6 +571,9 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
     const plan::OneWordDeal deal = plan::deal_top_digit_buckets(table.data(), W, P, shorts, targets, trust, !solo_, QR);
     if (deal.PT[RADIX] != n) { mg_set_err(g, "one-word first sort: the top-digit counts do not add up to the text"); return PSACX_EDEVICE; }
     if (!deal.ok) return PSACX_RETRY_;
+    // (the scratch of the bucket passes was sized above for the tiles of a share of 9/8 of a block and 64 more per bucket: a deal forced beyond
+    //  that -- `trust` -- is turned away here, before anything has moved, instead of failing on the receiving side)
+    for (int r = 0; r < P; ++r) if (deal.cs[r] > sizes[r] + sizes[r] / 8 + 256 + (uint64_t)RADIX * 63 * TILE) return PSACX_RETRY_;
     const std::vector<uint64_t>& tot = deal.tot; const std::vector<uint64_t>& PT = deal.PT;
     const std::vector<int>& cut = deal.cut;
     const std::vector<uint64_t>& Gs = deal.Gs; const std::vector<uint64_t>& cs = deal.cs; const std::vector<uint64_t>& Hs = deal.Hs;

@@ -99,6 +99,13 @@ int psacx_trim(psacx_ctx* c) {
     if (c->aux) { PSACX_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_bytes = 0; }
     if (c->io) { PSACX_HIP(c, hipFree(c->io)); c->io = nullptr; c->io_bytes = 0; }
     if (c->dstage) { PSACX_HIP(c, hipFree(c->dstage)); c->dstage = nullptr; }
+    // ... and what the host-pointer path keeps on the host side: the ring of pinned buffers and the threads that widen the results
+    // (a process that drives several contexts one after the other would otherwise hold them for every context it ever used)
+    for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) {
+        if (c->stage[i]) { (void)hipHostFree(c->stage[i]); c->stage[i] = nullptr; }
+        if (c->stage_ev[i]) { (void)hipEventDestroy(c->stage_ev[i]); c->stage_ev[i] = nullptr; }
+    }
+    delete c->hpool; c->hpool = nullptr;
     pool_flush(c);
     return PSACX_OK;
 }
