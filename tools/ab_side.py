@@ -1,5 +1,6 @@
-"""Wall time of construct_device on the side workloads of bench.py (for A/B runs of a knob): python tools/ab_side.py KIND LOG2N PERIOD [REPS]
-KIND: 0 random DNA, 2 tandem repeat, 3 repeated reads with mutations (psacx_synth_text_dev)."""
+"""Wall time of construct_device on the side workloads of bench.py (for A/B runs of a knob): python tools/ab_side.py KIND LOG2N PERIOD [REPS] [check]
+KIND: 0 random DNA, 2 tandem repeat, 3 repeated reads with mutations (psacx_synth_text_dev).  check: the result of the last construction goes
+through the recurrence checker of the multi-GPU engine on one rank (LCP by ranks, not by characters: repetitive texts)."""
 import sys, time, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import psac_amd
@@ -17,4 +18,12 @@ for _ in range(reps):
     t0 = time.perf_counter()
     st = sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
     ts.append((time.perf_counter() - t0) * 1e3)
-print("kind", kind, "n 2^%d" % lg, "knob", os.environ.get("PSACX_NO_DIGIT_BYTES"), "ms", " ".join("%.1f" % t for t in ts), "rounds", st.n_rounds)
+err = None
+if len(sys.argv) > 5 and sys.argv[5] == "check":
+    ctx.check(ctx._lib.psacx_trim(ctx.handle))
+    mgc = psac_amd.MultiContext([ctx.device])
+    try:
+        err = list(mgc.check_device([d_text], [n], [d_sa], [d_isa], [d_lcp], 64))
+    finally:
+        mgc.close()
+print("kind", kind, "n 2^%d" % lg, "knob", os.environ.get("PSACX_NO_DIGIT_BYTES"), "ms", " ".join("%.1f" % t for t in ts), "rounds", st.n_rounds, "check", err)
