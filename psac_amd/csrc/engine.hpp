@@ -998,7 +998,7 @@ inline int prefix_sort_1w(psacx_ctx* c, SortScratch& sc, uint64_t* k0, uint64_t*
         PSACX_HIP(c, hipMemsetAsync(scratch, 0, 256, c->stream));
         hipLaunchKernelGGL((key_scatter1w_kernel<BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, text, n, n_text, tab, ks, pad ? k0 : a, (int)(lo1 + low),
                            base0, tile_hist0, slab_tot0, reinterpret_cast<unsigned*>(scratch), sort_chunk_for(n, true), slab0, lo1 | (sfield << 16), (uint64_t)0,
-                           (uint8_t*)nullptr, 0, pad);  // (no digit bytes out of this pass: their stores cost it 4.5 ms, the record histogram of the first bucket pass 3.7)
+                           (uint8_t*)nullptr, 0, pad);  // (no digit bytes out of this pass: their stores cost it 4.9 ms -- also at the padded places -- and save the first bucket pass's histogram 4.6)
         PSACX_HIP(c, hipGetLastError());
     }
     // the buckets (the tables of the first pass in the scratch are dead once its scatter has run: same stream)
