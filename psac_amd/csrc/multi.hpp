@@ -242,6 +242,32 @@ template <typename T> __global__ void prefix_cut_kernel(const T* __restrict__ k1
     if ((threadIdx.x & 63) == 0) { if (mx) atomicMax(last, mx); if (mn != ~0ull) atomicMin(first, mn); }
 }
 
+// out[q] = the number of entries of the ascending array a[0 .. cnt) that are below key[q] (one thread per question)
+template <typename T> __global__ void lower_bound_kernel(const T* __restrict__ a, uint64_t cnt, const uint64_t* __restrict__ key, unsigned nq, uint64_t* __restrict__ out) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint64_t lo = 0, hi = cnt;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if ((uint64_t)a[mid] < key[q]) lo = mid + 1; else hi = mid; }
+    out[q] = lo;
+}
+
+// The key of record j of a run of whole buckets in list order (pos[j]: SA position, k1[j]: bucket id = SA position of the bucket's head + 1,
+// k2[j]: rank h further, below 2^kb): (index of the bucket's head in the run, halved) << kb | k2[j], written over k2 -- the members of a
+// bucket are neighbours in the list, so the head's index is j - (pos[j] - head position); buckets have two members at least, so halving
+// keeps the numbers of different buckets apart (gather_keys_kernel's dense bucket numbers, sa_kernels.hpp)
+template <typename T> __global__ void refine_key_kernel(const T* __restrict__ pos, const T* __restrict__ k1, T* __restrict__ k2, uint64_t len, unsigned kb) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) {
+        const uint64_t hidx = j - ((uint64_t)pos[j] - ((uint64_t)k1[j] - 1));
+        k2[j] = (T)(((hidx >> 1) << kb) | (uint64_t)k2[j]);
+    }
+}
+template <typename T> __global__ void mask_low_kernel(T* __restrict__ a, uint64_t len, unsigned kb) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const T m = kb >= sizeof(T) * 8 ? ~(T)0 : (T)(((T)1 << kb) - 1);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += stride) a[j] &= m;
+}
+
 template <typename T> __global__ void widen_text_kernel(const uint8_t* __restrict__ t, uint64_t cnt, T* __restrict__ out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) out[i] = (T)t[i];
@@ -336,6 +362,7 @@ struct MultiRun {
     explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
         if (const char* e = getenv("PSACX_MULTI_WIRE_PIECE")) wire_piece_ = std::max<size_t>(256, strtoull(e, nullptr, 10));
         if (const char* e = getenv("PSACX_MULTI_PIECES")) pieces_env_ = std::max(1, atoi(e));      // ranges per destination of the first round's shuffle (tests)
+        global_refine_sort_env_ = getenv("PSACX_MULTI_GLOBAL_REFINE_SORT") != nullptr;               // refinement rounds sort all their records across the ranks (tests, A/B runs)
         one_stage_env_ = getenv("PSACX_ONE_STAGE") != nullptr;                                      // first round as one sort over both key words
         if (const char* e = getenv("PSACX_MULTI_SLAB")) slab_env_ = strtoull(e, nullptr, 10);       // unresolved suffixes per refinement slab (reduced-memory layout)
         if (const char* e = getenv("PSACX_MULTI_CHECK_CHUNKS")) check_chunks_env_ = strtoull(e, nullptr, 10);
@@ -489,6 +516,7 @@ struct MultiRun {
     size_t wire_piece_ = (size_t)1 << 28;
     int pieces_env_ = 0;
     bool one_stage_env_ = false;
+    bool global_refine_sort_env_ = false;
     uint64_t slab_env_ = 0, check_chunks_env_ = 0, slice_step_env_ = 0;
     unsigned slice_wb_env_ = 0, slice_s1_env_ = 0;
     ncclResult_t wire_send(RcclApi& nc, MRank& R, const void* p, size_t bytes, int peer) {
@@ -977,6 +1005,119 @@ struct MultiRun {
         }));
         mark("    sort: local sort");
         return rebalance(rec, targets);
+    }
+
+    // The sort of a refinement round: records (bucket id, rank h further, suffix) of the unresolved positions of every rank, in SA order.
+    // A bucket's records are neighbours before and after the sort, so only the buckets that reach over a rank boundary need their ranks
+    // to talk: those records (the first of a rank whose bucket started on a lower rank -- bucket id <= block offset --, the last of a rank
+    // whose bucket goes on on the next one) are sorted across the ranks (dist_sort on them alone: the per-rank counts are kept, and
+    // ascending bucket ids put every piece back in its place), all others by a local sort.  psac sorts its unresolved buckets the same
+    // way (suffix_array.hpp:1092-1157, the split buckets in two phases: stringset.hpp:323-375); a doubling round that sorts all records
+    // across the ranks (idxsort.hpp:23-83) moves three words per unresolved suffix over the links instead.
+    // The local part sorts two-word records: a bucket's records keep their places as a set, so the bucket ids (k1) stay where they are and
+    // only (rank h further, suffix) move, under the key (bucket's number in the run << bits2 | rank) -- as many digits as the run has
+    // buckets and the text has ranks, instead of both 64-bit words of a three-word record (a tandem repeat of 2^31 characters on
+    // 8 ranks: 40 key bits in 32-byte records instead of 66 in 48-byte ones).
+    int refine_sort(std::vector<Rec<T>>& rec, const std::vector<const T*>& plist, const std::vector<uint64_t>& counts, unsigned bits1, unsigned bits2) {
+        if (solo_ || global_refine_sort_env_) return dist_sort(rec, counts, bits1, bits2);
+        // first / last bucket id of every rank
+        std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(3, 0));
+        PSACX_TRY(par([&](int i) -> int {
+            if (!rec[i].cnt) return PSACX_OK;
+            std::vector<uint64_t> o;
+            PSACX_TRY(fetch(i, rec[i].k1.p, {0, rec[i].cnt - 1}, o));
+            mine[i][0] = 1; mine[i][1] = o[0]; mine[i][2] = o[1];
+            return PSACX_OK;
+        }));
+        std::vector<uint64_t> all;
+        PSACX_TRY(gather(3, mine, all));
+        std::vector<uint64_t> head(L, 0), tail(L, 0), ns(L, 0);
+        PSACX_TRY(par([&](int i) -> int {
+            const uint64_t cn = rec[i].cnt;
+            if (!cn) return PSACX_OK;
+            psacx_ctx* c = ctx(i);
+            uint64_t next_first = 0;
+            for (int r = rank(i) + 1; r < P; ++r) if (all[(size_t)r * 3]) { next_first = all[(size_t)r * 3 + 1]; break; }
+            // records with id <= offset: below (offset + 1); records with the last id, if the next rank starts with it: from lower_bound(last id) on
+            const bool goes_on = next_first != 0 && next_first == mine[i][2];
+            MG_HIP(g, hipSetDevice(c->device));
+            DBuf<uint64_t> d; MG_OP(g, c, d.alloc(c, 4));
+            uint64_t* h = reinterpret_cast<uint64_t*>(c->pinned + 32768);
+            h[0] = S[i].off + 1; h[1] = mine[i][2];
+            MG_HIP(g, hipMemcpyAsync(d.p, h, 16, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL((lower_bound_kernel<T>), dim3(1), dim3(64), 0, c->stream, (const T*)rec[i].k1.p, cn, (const uint64_t*)d.p, 2u, d.p + 2);
+            MG_HIP(g, hipGetLastError());
+            MG_HIP(g, hipMemcpyAsync(h, d.p + 2, 16, hipMemcpyDeviceToHost, c->stream));
+            MG_HIP(g, hipStreamSynchronize(c->stream));
+            head[i] = h[0];
+            tail[i] = goes_on ? cn - h[1] : 0;
+            if (head[i] + tail[i] >= cn) { head[i] = cn; tail[i] = 0; }          // (the whole rank lies in buckets shared with others)
+            ns[i] = head[i] + tail[i];
+            return PSACX_OK;
+        }));
+        std::vector<uint64_t> ns_all;
+        PSACX_TRY(gather1(ns, ns_all));
+        uint64_t any = 0;
+        for (uint64_t x : ns_all) any += x;
+        // the shared buckets' records across the ranks
+        std::vector<Rec<T>> sh(L);
+        if (any) {
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                sh[i].cnt = ns[i];
+                MG_OP(g, c, sh[i].k1.alloc(c, ns[i])); MG_OP(g, c, sh[i].k2.alloc(c, ns[i])); MG_OP(g, c, sh[i].v.alloc(c, ns[i]));
+                MG_HIP(g, hipSetDevice(c->device));
+                DBuf<T>* from[3] = {&rec[i].k1, &rec[i].k2, &rec[i].v};
+                DBuf<T>* to[3] = {&sh[i].k1, &sh[i].k2, &sh[i].v};
+                for (int q = 0; q < 3; ++q) {
+                    if (head[i]) MG_HIP(g, hipMemcpyAsync(to[q]->p, from[q]->p, head[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    if (tail[i]) MG_HIP(g, hipMemcpyAsync(to[q]->p + head[i], from[q]->p + (rec[i].cnt - tail[i]), tail[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                }
+                return PSACX_OK;
+            }));
+            PSACX_TRY(dist_sort(sh, ns_all, bits1, bits2));
+        }
+        // everything else where it lies
+        PSACX_TRY(par([&](int i) -> int {
+            psacx_ctx* c = ctx(i);
+            const uint64_t cn = rec[i].cnt, lo = head[i], len = cn - head[i] - tail[i];
+            MG_HIP(g, hipSetDevice(c->device));
+            const unsigned nb = bits_for(len > 2 ? (len - 1) >> 1 : 1);
+            if (len >= 2 && nb + bits2 <= sizeof(T) * 8 && sizeof(T) == 8) {
+                DBuf<T> ak, av;
+                MG_OP(g, c, ak.alloc(c, len)); MG_OP(g, c, av.alloc(c, len));
+                hipLaunchKernelGGL((refine_key_kernel<T>), dim3(grid_for(c, len, 256, 8)), dim3(256), 0, c->stream, plist[i] + lo, (const T*)(rec[i].k1.p + lo), rec[i].k2.p + lo, len, bits2);
+                MG_HIP(g, hipGetLastError());
+                int32_t where = 0;
+                MG_OP(g, c, op_pair_sort<T>(c, rec[i].k2.p + lo, (T*)nullptr, rec[i].v.p + lo, ak.p, (T*)nullptr, av.p, len, nb + bits2, 0, &where));
+                if (where) {
+                    MG_HIP(g, hipMemcpyAsync(rec[i].k2.p + lo, ak.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    MG_HIP(g, hipMemcpyAsync(rec[i].v.p + lo, av.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                }
+                hipLaunchKernelGGL((mask_low_kernel<T>), dim3(grid_for(c, len, 256, 8)), dim3(256), 0, c->stream, rec[i].k2.p + lo, len, bits2);
+                MG_HIP(g, hipGetLastError());
+                MG_HIP(g, hipStreamSynchronize(c->stream));          // (the second record set goes back to the cache when this scope ends)
+            } else if (len >= 2) {
+                Rec<T> alt;
+                PSACX_TRY(take3(i, alt, cn));
+                int32_t where = 0;
+                MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p + lo, rec[i].k2.p + lo, rec[i].v.p + lo, alt.k1.p + lo, alt.k2.p + lo, alt.v.p + lo, len, bits1, bits2, &where));
+                if (where) swap3(rec[i], alt);
+                drop3(i, alt);
+            }
+            if (any && ns[i]) {
+                if (sh[i].cnt != ns[i]) { mg_set_err(g, "refinement sort: the records of the shared buckets came back in other numbers"); return PSACX_EDEVICE; }
+                DBuf<T>* to[3] = {&rec[i].k1, &rec[i].k2, &rec[i].v};
+                DBuf<T>* from[3] = {&sh[i].k1, &sh[i].k2, &sh[i].v};
+                for (int q = 0; q < 3; ++q) {
+                    if (head[i]) MG_HIP(g, hipMemcpyAsync(to[q]->p, from[q]->p, head[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                    if (tail[i]) MG_HIP(g, hipMemcpyAsync(to[q]->p + (cn - tail[i]), from[q]->p + head[i], tail[i] * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                }
+                MG_HIP(g, hipStreamSynchronize(c->stream));          // (the small arrays go back to the cache when this scope ends)
+            }
+            return PSACX_OK;
+        }));
+        return PSACX_OK;
     }
 
     // exact re-balance of globally sorted records to the block sizes: the j-th record of rank r has global index G[r] + j
@@ -1598,7 +1739,7 @@ struct MultiRun {
         }
         q.clear();
         mark("  B2 fetch");
-        PSACX_TRY(dist_sort(rec, counts, id_bits, id_bits));
+        PSACX_TRY(refine_sort(rec, plist, counts, id_bits, id_bits));
         mark("  sort");
         {
             std::vector<const T*> a1(L), a2(L), a3(L);
