@@ -53,6 +53,27 @@ def test_multi_matches_oracle(P):
         mg.close()
 
 
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_multi_refinement_sort_forms(P, monkeypatch):
+    # refinement rounds on p ranks: the buckets that reach over a rank boundary are sorted across the ranks, all others where they lie
+    # (multi.hpp: refine_sort; two-word local records with 64-bit words, three-word ones with 32-bit words); PSACX_MULTI_GLOBAL_REFINE_SORT=1
+    # keeps the sort of all records across the ranks.  A tandem repeat (buckets longer than a block early on, every rank boundary inside a
+    # bucket), repeated reads with mutations (many small buckets, few of them on a boundary) and one symbol (one bucket over all ranks).
+    texts = [inputs.tandem(150001, 512, O.rand_dna(512, 3)), inputs.mutated(120007, 2048, 5), np.full(20011, 71, np.uint8)]
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("PSACX_MULTI_GLOBAL_REFINE_SORT", env)
+        mg = multi(P)
+        try:
+            for text in texts:
+                for bits in (64, 32):
+                    SA, ISA, LCP, rounds = same(mg, text, bits)
+                    ref = O.construct(text, bits=bits)
+                    assert np.array_equal(SA, ref["SA"]) and np.array_equal(ISA, ref["ISA"]) and np.array_equal(LCP, ref["LCP"])
+                    assert rounds == [(h, b, e) for h, b, e, _ in ref["trace"]]
+        finally:
+            mg.close()
+
+
 def test_multi_block_decomposition_is_enforced():
     # suffix_array.hpp:226-227: blocks that do not follow mxx::blk_dist are refused
     import ctypes as C
