@@ -66,6 +66,14 @@ __global__ void lcp_apply_kernel(T* __restrict__ block, const T* __restrict__ at
         block[(uint64_t)at[i] - off] = (T)(h + (uint64_t)mins[i]);
 }
 
+// the same through a min-pyramid over the block that somebody keeps (multi.hpp: block_pyramid): the upper levels follow
+template <typename T>
+__global__ void lcp_apply_pyr_kernel(Pyramid<T> P, const T* __restrict__ at, uint64_t cnt, uint64_t off, const T* __restrict__ mins, uint64_t h) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride)
+        pyramid_set<T>(P, (uint64_t)at[i] - off, (T)(h + (uint64_t)mins[i]));
+}
+
 // lower / upper bound of (q1,q2) in sorted pairs; use_second == 0 compares the first word only
 template <typename T>
 __global__ void pair_bounds_kernel(const T* __restrict__ s1, const T* __restrict__ s2, uint64_t n,
@@ -370,7 +378,8 @@ int op_rebucket_first(psacx_ctx* c, const T* s1, const T* s2, const T* sa, uint6
 template <typename T>
 int op_rebucket_refine(psacx_ctx* c, const T* t1, const T* t2, const T* tv, const T* pos, uint64_t cnt, uint64_t n, uint64_t h,
                        const psacx_boundary* b, T* sa_block, T* bsa_block, T* lcp_block, T* ids_out, T* q_at, T* q_lo, T* q_hi,
-                       uint64_t* nq, uint64_t* nact, uint64_t* nunf) {
+                       uint64_t* nq, uint64_t* nact, uint64_t* nunf, const Pyramid<T>* kept = nullptr) {
+    // kept: a min-pyramid over lcp_block that the caller keeps (level 0 = lcp_block): the entries this step lowers are lowered in its upper levels too
     OP_PROLOGUE(c);
     *nq = *nact = *nunf = 0;
     if (cnt == 0) return PSACX_OK;
@@ -385,6 +394,7 @@ int op_rebucket_refine(psacx_ctx* c, const T* t1, const T* t2, const T* tv, cons
     Pyramid<T> pyr;
     std::memset(&pyr, 0, sizeof(pyr));
     pyr.lvl[0] = lcp_block; pyr.nlev = lcp_block ? 1 : 0;
+    if (kept && lcp_block && kept->nlev > 0 && kept->lvl[0] == lcp_block) pyr = *kept;
     if (lcp_block)
         hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0,
                            c->stream, t1, t2, tv, pos, cnt, n, h, sa_block, bsa_block, (T*)nullptr, pyr, ids_out, ts.carry, ts.nact,

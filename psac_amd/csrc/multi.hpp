@@ -1586,15 +1586,45 @@ struct MultiRun {
                        std::vector<DBuf<T>>& out) {
         out.clear(); out.resize(L);
         if (solo_) {
-            MG_OP(g, ctx(0), out[0].alloc(ctx(0), cnt[0]));
-            MG_OP(g, ctx(0), op_range_min<T>(ctx(0), S[0].LCP, S[0].m, lo[0], hi[0], cnt[0], S[0].off, out[0].p));
+            psacx_ctx* c = ctx(0);
+            MG_OP(g, c, out[0].alloc(c, cnt[0]));
+            if (!cnt[0]) return PSACX_OK;
+            if (cnt[0] >= S[0].m / 32) {          // (a whole round at once: a pyramid with the running minima of every level pays for itself)
+                MG_OP(g, c, op_range_min<T>(c, S[0].LCP, S[0].m, lo[0], hi[0], cnt[0], S[0].off, out[0].p));
+                return PSACX_OK;
+            }
+            Pyramid<T> Pm; uint64_t bmin = 0;
+            PSACX_TRY(block_pyramid(0, Pm, &bmin));
+            // many questions: the running minima of the groups of the upper levels beside the kept pyramid (a level then costs two loads
+            // however short the range; the tables of level 0 -- two arrays of the block's length -- are not made: op_range_min makes them
+            // for m / 32 questions and more, a slab has fewer)
+            DBuf<T> aux;
+            if (cnt[0] >= (1u << 16) && Pm.nlev > 2) {
+                uint64_t tot = 0;
+                for (int Lv = 1; Lv + 1 < Pm.nlev; ++Lv) tot += 2 * ((Pm.len[Lv] + 63) & ~63ull);
+                MG_OP(g, c, aux.alloc(c, tot));
+                OP_PROLOGUE(c);
+                uint64_t at = 0;
+                for (int Lv = 1; Lv + 1 < Pm.nlev; ++Lv) {
+                    T* pre = aux.p + at; at += (Pm.len[Lv] + 63) & ~63ull;
+                    T* suf = aux.p + at; at += (Pm.len[Lv] + 63) & ~63ull;
+                    hipLaunchKernelGGL((pyramid_aux_kernel<T>), dim3(grid_for(c, Pm.len[Lv], 256, 8)), dim3(256), 0, c->stream, Pm.lvl[Lv], Pm.len[Lv], pre, suf);
+                    MG_HIP(g, hipGetLastError());
+                    Pm.pre[Lv] = pre; Pm.suf[Lv] = suf;
+                }
+            }
+            {
+                OP_PROLOGUE(c);
+                hipLaunchKernelGGL((range_min_kernel<T>), dim3(grid_for(c, cnt[0], 256, 16)), dim3(256), 0, c->stream, Pm, lo[0], hi[0], cnt[0], S[0].off, out[0].p);
+                MG_HIP(g, hipGetLastError());
+                if (aux.p) MG_HIP(g, hipStreamSynchronize(c->stream));          // (the tables go back to the cache when this scope ends)
+            }
             return PSACX_OK;
         }
         // one min-pyramid of every rank's LCP block serves its block minimum and both batches of sub-queries
         std::vector<uint64_t> bm(L), mins;
         std::vector<Pyramid<T>> pyr(L);
-        std::vector<DBuf<T>> pyr_mem(L);
-        for (int i = 0; i < L; ++i) PSACX_TRY(block_pyramid(i, pyr[i], pyr_mem[i], &bm[i]));
+        for (int i = 0; i < L; ++i) PSACX_TRY(block_pyramid(i, pyr[i], &bm[i]));
         PSACX_TRY(gather1(bm, mins));
         // own1/lo1/hi1: the part inside the rank of lo; own2/lo2/hi2: the part inside the rank of hi - 1; ra/rb: whole ranks between
         std::vector<std::vector<DBuf<T>>> parts(L);
@@ -1661,36 +1691,57 @@ struct MultiRun {
         return PSACX_OK;
     }
 
-    // 64-ary min-pyramid over this rank's LCP block in its own buffer (levels >= 1; level 0 is the block), and the block minimum
-    int block_pyramid(int i, Pyramid<T>& Pm, DBuf<T>& mem, uint64_t* block_min) {
+    // 64-ary min-pyramid over this rank's LCP block (levels >= 1 in a buffer of the run; level 0 is the block), and the block minimum.
+    // Built once, when the first range minimum of the run is asked for (the first round has written every LCP entry by then), and kept
+    // up to date by whoever lowers an entry afterwards (pyramid_set: rebucket_refine_kernel, lcp_apply_pyr_kernel) -- a refinement
+    // round in slabs asks for range minima once per slab, and a pyramid per question read the whole block every time (a 2^32 block:
+    // 34 GB, 1700 times per construction of a tandem repeat: 8.7 of its 33 s).
+    std::vector<Pyramid<T>> lcp_pyr_;
+    std::vector<DBuf<T>> lcp_pyr_mem_;
+    int block_pyramid(int i, Pyramid<T>& Pm, uint64_t* block_min) {
         psacx_ctx* c = ctx(i);
         const uint64_t m = S[i].m;
-        Pm = Pyramid<T>();
+        if ((int)lcp_pyr_.size() != L) { lcp_pyr_.assign(L, Pyramid<T>()); lcp_pyr_mem_.clear(); lcp_pyr_mem_.resize(L); }
         *block_min = (uint64_t)(T)~(T)0;
+        Pm = Pyramid<T>();
         if (m == 0) return PSACX_OK;
-        uint64_t total = 0, len = m;
-        int nlev = 1;
-        while (len > 128 && nlev < PYR_MAX) { len = (len + 63) / 64; total += (len + 63) & ~63ull; ++nlev; }
-        MG_OP(g, c, mem.alloc(c, total + 64));
-        Pm.lvl[0] = S[i].LCP; Pm.len[0] = m; Pm.nlev = 1;
-        len = m;
-        uint64_t at = 0;
         OP_PROLOGUE(c);
-        while (len > 128 && Pm.nlev < PYR_MAX) {
-            len = (len + 63) / 64;
-            Pm.lvl[Pm.nlev] = mem.p + at; Pm.len[Pm.nlev] = len; at += (len + 63) & ~63ull;
-            hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, len * 64, 256, 8)), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1],
-                               Pm.len[Pm.nlev - 1], Pm.lvl[Pm.nlev], len);
-            MG_HIP(g, hipGetLastError());
-            Pm.nlev++;
+        if (lcp_pyr_[i].nlev == 0 || lcp_pyr_[i].lvl[0] != S[i].LCP) {
+            Pyramid<T>& Q = lcp_pyr_[i];
+            DBuf<T>& mem = lcp_pyr_mem_[i];
+            Q = Pyramid<T>();
+            uint64_t total = 0, len = m;
+            int nlev = 1;
+            while (len > 128 && nlev < PYR_MAX) { len = (len + 63) / 64; total += (len + 63) & ~63ull; ++nlev; }
+            mem.release();
+            MG_OP(g, c, mem.alloc(c, total + 64));
+            Q.lvl[0] = S[i].LCP; Q.len[0] = m; Q.nlev = 1;
+            len = m;
+            uint64_t at = 0;
+            while (len > 128 && Q.nlev < PYR_MAX) {
+                len = (len + 63) / 64;
+                Q.lvl[Q.nlev] = mem.p + at; Q.len[Q.nlev] = len; at += (len + 63) & ~63ull;
+                hipLaunchKernelGGL((pyramid_level_kernel<T>), dim3(grid_for(c, len * 64, 256, 8)), dim3(256), 0, c->stream, Q.lvl[Q.nlev - 1],
+                                   Q.len[Q.nlev - 1], Q.lvl[Q.nlev], len);
+                MG_HIP(g, hipGetLastError());
+                Q.nlev++;
+            }
         }
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(mem.p + at);      // 64 spare entries at the end
+        Pm = lcp_pyr_[i];
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(lcp_pyr_mem_[i].p + (lcp_pyr_mem_[i].n - 64));      // 64 spare entries at the end
         hipLaunchKernelGGL((top_min_kernel<T>), dim3(1), dim3(256), 0, c->stream, Pm.lvl[Pm.nlev - 1], Pm.len[Pm.nlev - 1], d);
         MG_HIP(g, hipGetLastError());
         MG_HIP(g, hipMemcpyAsync(c->pinned + 32768, d, 8, hipMemcpyDeviceToHost, c->stream));
         MG_HIP(g, hipStreamSynchronize(c->stream));
         *block_min = *reinterpret_cast<uint64_t*>(c->pinned + 32768);
         return PSACX_OK;
+    }
+    // the pyramid of rank i's LCP block if the run keeps one (else one of level 0 only): for the kernels that lower LCP entries
+    Pyramid<T> lcp_pyramid_or_block(int i) const {
+        if (i < (int)lcp_pyr_.size() && lcp_pyr_[i].nlev > 0 && lcp_pyr_[i].lvl[0] == S[i].LCP) return lcp_pyr_[i];
+        Pyramid<T> Q = Pyramid<T>();
+        Q.lvl[0] = S[i].LCP; Q.len[0] = S[i].m; Q.nlev = S[i].LCP ? 1 : 0;
+        return Q;
     }
 
     // One refinement pass (suffix_array.hpp:1092-1157, :1181-1285) over the list entries plist[i][0 .. cnt[i]) of every local
@@ -1761,8 +1812,9 @@ struct MultiRun {
             for (int s = 0; s < rank(i); ++s) base = std::max(base, heads[s]);
             bd[i].off = S[i].off; bd[i].base = base;
             MG_OP(g, c, ids[i].alloc(c, cnt[i])); MG_OP(g, c, qa[i].alloc(c, cnt[i])); MG_OP(g, c, ql[i].alloc(c, cnt[i])); MG_OP(g, c, qh[i].alloc(c, cnt[i]));
+            const Pyramid<T> lp = lcp_pyramid_or_block(i);
             MG_OP(g, c, op_rebucket_refine<T>(c, rec[i].k1.p, rec[i].k2.p, rec[i].v.p, plist[i], cnt[i], n, h, &bd[i], S[i].SA, S[i].Bsa.p,
-                                              S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i]));
+                                              S[i].LCP, ids[i].p, qa[i].p, ql[i].p, qh[i].p, &nq[i], &nact[i], &nunf[i], &lp));
             return PSACX_OK;
         }));
         {
@@ -1780,7 +1832,7 @@ struct MultiRun {
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
                 OP_PROLOGUE(c);
-                SIMPLE_LAUNCH(c, (lcp_apply_kernel<T>), nq[i], S[i].LCP, qa[i].p, nq[i], S[i].off, mins[i].p, h);
+                SIMPLE_LAUNCH(c, (lcp_apply_pyr_kernel<T>), nq[i], lcp_pyramid_or_block(i), qa[i].p, nq[i], S[i].off, mins[i].p, h);
                 return PSACX_OK;
             }));
         }

@@ -2038,8 +2038,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             const T lo = p2 < a2[j] ? p2 : a2[j];
             const T hi = p2 < a2[j] ? a2[j] : p2;
             if (p2 == 0 || a2[j] == 0) {
-                if (DIST) { if (pyr.lvl[0][at] == (T)n) pyr.lvl[0][at] = (T)h; }
-                else if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);
+                if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);          // (DIST: a pyramid of level 0 only unless the caller keeps one)
             } else if (DIST) {
                 const unsigned long long slot = atomicAdd(q_count, 1ull);
                 q_at[slot] = ps[j]; q_lo[slot] = lo; q_hi[slot] = hi;
