@@ -1019,8 +1019,8 @@ struct MultiRun {
     // buckets and the text has ranks, instead of both 64-bit words of a three-word record (a tandem repeat of 2^31 characters on
     // 8 ranks: 40 key bits in 32-byte records instead of 66 in 48-byte ones).
     int refine_sort(std::vector<Rec<T>>& rec, const std::vector<const T*>& plist, const std::vector<uint64_t>& counts, unsigned bits1, unsigned bits2) {
-        if (solo_ || global_refine_sort_env_) return dist_sort(rec, counts, bits1, bits2);
-        // first / last bucket id of every rank
+        if (global_refine_sort_env_) return dist_sort(rec, counts, bits1, bits2);
+        // first / last bucket id of every rank (one rank: no bucket is shared, everything below is the local part)
         std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(3, 0));
         PSACX_TRY(par([&](int i) -> int {
             if (!rec[i].cnt) return PSACX_OK;
