@@ -159,10 +159,10 @@ def report(a, world, n, bits, dt, scat_ms, scat_bytes, scat_launches, phases, k,
         # the prefix sort in one-word records (engine.hpp: prefix_sort_1w): the passes inside the buckets
         # (radix_scatter1w_kernel<..., 8>: 8 + 8 bytes per record) and the last one (radix_scatter1w_kernel<..., 9>: one word in,
         # word 1 + suffix out); the figures below are their mean
-        kname = ("radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records, 8 + 8 bytes per record, and in "
-                 "all but the last pass one byte more: the digit the next pass sorts on, which its tile histograms read instead of the records; "
-                 "the tie stage and the rebucket kernel read the records where the last pass leaves them; the pass on the top digit computes its "
-                 "keys from the text and is timed with them)")
+        kname = ("radix_scatter1w_kernel (one 8-bit digit pass of the first round's prefix sort in one-word records, 8 + 8 bytes per record and one "
+                 "byte more: the digit the next pass sorts on, which its tile histograms read instead of the records -- from the last pass the lowest "
+                 "byte of the prefix, in which the tie stage looks for its groups instead of reading the records; the rebucket kernel reads the "
+                 "records where the last pass leaves them; the pass on the top digit computes its keys from the text and is timed with them)")
         tkey = 3
     out = {
         "metric": "MChars/s SA+LCP build; rank-pair radix-sort HBM GB/s vs peak",
