@@ -111,7 +111,30 @@ __global__ void rmq_split_kernel(const T* __restrict__ lo, const T* __restrict__
         ra[i] = (T)(pl + 1); rb[i] = (T)pr;
     }
 }
+// one half of the same split at a time (half 0: the part inside the rank of lo; 1: the part inside the rank of hi - 1), so that a caller short of
+// memory holds three arrays instead of eight -- the ranks in between are found again from lo / hi by rmq_combine_range_kernel
+template <typename T>
+__global__ void rmq_split_half_kernel(const T* __restrict__ lo, const T* __restrict__ hi, uint64_t cnt, BlkDist d, int half, T* own, T* l_out, T* h_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const uint64_t l = lo[i], r = hi[i];
+        const unsigned pl = d.rank_of(l), pr = d.rank_of(r - 1);
+        if (half == 0) { own[i] = (T)pl; l_out[i] = (T)l; h_out[i] = pl == pr ? (T)r : (T)(d.off(pl) + d.size(pl)); }
+        else { own[i] = (T)pr; h_out[i] = (T)r; l_out[i] = pl == pr ? (T)r : (T)d.off(pr); }
+    }
+}
 struct RankMins { unsigned long long v[64]; };
+template <typename T>
+__global__ void rmq_combine_range_kernel(const T* __restrict__ a1, const T* __restrict__ a2, const T* __restrict__ lo, const T* __restrict__ hi, uint64_t cnt, BlkDist d,
+                                         RankMins rm, T* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        T m = a1[i] < a2[i] ? a1[i] : a2[i];
+        const unsigned pl = d.rank_of((uint64_t)lo[i]), pr = d.rank_of((uint64_t)hi[i] - 1);
+        for (unsigned r = pl + 1; r < pr; ++r) { const T x = (T)rm.v[r]; m = x < m ? x : m; }
+        out[i] = m;
+    }
+}
 template <typename T>
 __global__ void rmq_combine_kernel(const T* __restrict__ a1, const T* __restrict__ a2, const T* __restrict__ ra,
                                    const T* __restrict__ rb, uint64_t cnt, RankMins rm, T* __restrict__ out) {

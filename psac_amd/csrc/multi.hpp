@@ -1626,19 +1626,20 @@ struct MultiRun {
         std::vector<Pyramid<T>> pyr(L);
         for (int i = 0; i < L; ++i) PSACX_TRY(block_pyramid(i, pyr[i], &bm[i]));
         PSACX_TRY(gather1(bm, mins));
-        // own1/lo1/hi1: the part inside the rank of lo; own2/lo2/hi2: the part inside the rank of hi - 1; ra/rb: whole ranks between
+        // a question is split into the part inside the rank of lo, the part inside the rank of hi - 1 (one half at a time: three arrays of
+        // sub-questions alive, not six) and the whole ranks between, whose block minima every rank knows
         std::vector<std::vector<DBuf<T>>> parts(L);
-        PSACX_TRY(par([&](int i) -> int {
-            psacx_ctx* c = ctx(i);
-            parts[i].resize(8);
-            for (int q = 0; q < 8; ++q) MG_OP(g, c, parts[i][q].alloc(c, cnt[i]));
-            OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (rmq_split_kernel<T>), cnt[i], lo[i], hi[i], cnt[i], make_dist(n, (unsigned)P), parts[i][0].p, parts[i][1].p, parts[i][2].p,
-                          parts[i][3].p, parts[i][4].p, parts[i][5].p, parts[i][6].p, parts[i][7].p);
-            return PSACX_OK;
-        }));
         std::vector<std::vector<DBuf<T>>> answers(2);
         for (int half = 0; half < 2; ++half) {
+            PSACX_TRY(par([&](int i) -> int {
+                psacx_ctx* c = ctx(i);
+                parts[i].clear(); parts[i].resize(6);
+                for (int q = 0; q < 3; ++q) MG_OP(g, c, parts[i][3 * half + q].alloc(c, cnt[i]));
+                OP_PROLOGUE(c);
+                SIMPLE_LAUNCH(c, (rmq_split_half_kernel<T>), cnt[i], lo[i], hi[i], cnt[i], make_dist(n, (unsigned)P), half, parts[i][3 * half].p, parts[i][3 * half + 1].p,
+                              parts[i][3 * half + 2].p);
+                return PSACX_OK;
+            }));
             std::vector<Rec<T>> ra(L), rb(L);
             std::vector<std::vector<uint64_t>> bounds(L), b2(L), rc, rc2;
             std::vector<std::vector<const T*>> in(L);
@@ -1685,7 +1686,7 @@ struct MultiRun {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, out[i].alloc(c, cnt[i]));
             OP_PROLOGUE(c);
-            SIMPLE_LAUNCH(c, (rmq_combine_kernel<T>), cnt[i], answers[0][i].p, answers[1][i].p, parts[i][6].p, parts[i][7].p, cnt[i], rm, out[i].p);
+            SIMPLE_LAUNCH(c, (rmq_combine_range_kernel<T>), cnt[i], answers[0][i].p, answers[1][i].p, lo[i], hi[i], cnt[i], make_dist(n, (unsigned)P), rm, out[i].p);
             return PSACX_OK;
         }));
         return PSACX_OK;
