@@ -471,7 +471,9 @@ int op_compact_counted(psacx_ctx* c, const T* ids, uint64_t cnt, uint64_t off, u
 // (out arrays null): *n_out = their number.  Phase 2: pos_out = their positions, k1_out / v_out = their word 1 and payload,
 // in order.  Tie groups never straddle a rank (the shuffle keeps equal prefixes together), so there is no neighbour id.
 template <typename T>
-int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigned lo1, T* pos_out, T* k1_out, T* v_out, uint64_t* n_out) {
+int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigned lo1, T* pos_out, T* k1_out, T* v_out, uint64_t* n_out, bool counted = false) {
+    // counted (with pos_out): the call before this one on this context was the counting call for the same records (pos_out == nullptr), and
+    // nothing has used the context's scratch since: the tiles' offsets are still there and the records are not read a third time
     OP_PROLOGUE(c);
     if (!pos_out) *n_out = 0;
     if (cnt == 0) return PSACX_OK;
@@ -479,9 +481,11 @@ int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigne
     TileScratch ts;
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-    hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, cnt,
-                       (T)0, (T)0, ts.nact, lo1);
-    hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, ts.nact, ntiles, OpSum(), (uint64_t)0, ts.totals);
+    if (!(counted && pos_out)) {
+        hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, cnt,
+                           (T)0, (T)0, ts.nact, lo1);
+        hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, ts.nact, ntiles, OpSum(), (uint64_t)0, ts.totals);
+    }
     PSACX_HIP(c, hipGetLastError());
     if (!pos_out) {
         PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));

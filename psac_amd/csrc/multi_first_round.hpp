@@ -384,7 +384,7 @@ int MultiRun<T>::first_sort_ties(std::vector<Rec<T>>& rec, const std::vector<uin
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             MG_OP(g, c, tpos[i].alloc(c, tn[i])); MG_OP(g, c, tk1[i].alloc(c, tn[i])); MG_OP(g, c, tv[i].alloc(c, tn[i]));
-            if (tn[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk)); }
+            if (tn[i]) { uint64_t chk = 0; MG_OP(g, c, op_compact_ties<T>(c, rec[i].k1.p + at[i], rec[i].v.p + at[i], end[i] - at[i], lo1, tpos[i].p, tk1[i].p, tv[i].p, &chk, /*counted=*/true)); }
             return PSACX_OK;
         }));
         {
