@@ -2,6 +2,7 @@
 #include "multi.hpp"
 #include "multi_first_round.hpp"     // members of MultiRun: the first round in two-word / one-word records
 #include "multi_queries.hpp"         // members of MultiRun: ANSV, left-branching characters, suffix-tree table, checker
+#include "multi_refine.hpp"          // members of MultiRun: the sort and the range minima of a refinement round
 
 using namespace psacx;
 
