@@ -6,7 +6,8 @@
 // tasks of at most CAP records (window t = the buckets that start in list entries [t W, (t + 1) W)), one workgroup sorts a task by
 // least-significant-digit passes that never leave LDS, and the records cross HBM once (12 bytes read, 16 written).  A bucket longer
 // than CAP - W raises the flag; the caller then tries narrower windows (long tasks amortise the fixed cost of a pass -- barriers, the scan
-// of the digit counters -- over more records: 3.4 against 7.4 ns per record), or runs the global sort on the untouched input.
+// of the digit counters -- over more records: 2^30 characters of repeated reads with mutations 64 -> 51 ms for the four rounds it takes),
+// or runs the global sort on the untouched input.
 // Records: K = bucket number << kb2 | rank (gather_keys_kernel's one-word keys), V32 = the suffix as a 32-bit entry.  The order of
 // equal keys is the order of the list, as the stable global sort leaves it.
 #pragma once
