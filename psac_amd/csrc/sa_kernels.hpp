@@ -2112,14 +2112,33 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if (excl > carry) carry = excl;
     T sa[ITEMS];
     load_run_x<T, ITEMS>(V, e0, cnt, sa, (T)0, xw);
+    // a wave whose 64 x ITEMS list entries are neighbours in SA too (a round in which nearly every suffix is unresolved: a tandem repeat, the
+    // first rounds of repeated reads) writes SA and the ids through whole rows, like the arrays in list order, instead of entry by entry
+    bool rows = false;
+    uint64_t row0 = 0;
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t wave_e0 = e0 - (uint64_t)lane_id() * ITEMS;
+        const uint64_t p_first = shfl<uint64_t>((uint64_t)ps[0], 0), p_last = shfl<uint64_t>((uint64_t)ps[ITEMS - 1], WAVE - 1);
+        rows = wave_e0 + (uint64_t)WAVE * ITEMS <= cnt && p_last - p_first == (uint64_t)WAVE * ITEMS - 1;
+        row0 = p_first - bd.off;
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
         if (id[j] == 0) id[j] = carry; else carry = id[j];
         if (e < cnt) {
-            SA[(uint64_t)ps[j] - bd.off] = sa[j];
-            Bsa[(uint64_t)ps[j] - bd.off] = id[j];
+            if (!rows) {
+                SA[(uint64_t)ps[j] - bd.off] = sa[j];
+                Bsa[(uint64_t)ps[j] - bd.off] = id[j];
+            }
             if (!DIST && ISA && !pairs_out) ISA[sa[j]] = id[j] - 1;
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (rows) {
+            const uint64_t rel = (uint64_t)lane_id() * ITEMS;          // (store_run_x addresses a thread's run by its first element: the wave's rows start at row0)
+            store_run_x<T, ITEMS>(SA + row0, rel, (uint64_t)WAVE * ITEMS, sa, xw);
+            store_run_x<T, ITEMS>(Bsa + row0, rel, (uint64_t)WAVE * ITEMS, id, xw);
         }
     }
     store_run_x<T, ITEMS>(ids_out, e0, cnt, id, xw);
