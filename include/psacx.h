@@ -80,6 +80,10 @@ typedef struct psacx_stats {
     uint64_t workspace_bytes;      /* HBM held by the ctx */
     uint64_t onew_passes;          /* bucket passes run over one-word records (the MSD-first prefix sort of the first round); 0: that sort ran
                                       in the two-array form, whose passes are counted in scatter_*[2] alone */
+    uint64_t heavy_rounds;         /* refinement rounds (or slabs of one) whose records were split into heavy and light ones (psac_amd/csrc/heavy_keys.hpp) */
+    uint64_t heavy_records;        /* ... records that carried their bucket's heavy rank and skipped the sort */
+    uint64_t light_records;        /* ... records that were sorted */
+    uint64_t level_gathers;        /* refinement rounds (or slabs) whose ranks h further came through partition levels (construct.hpp: gather_by_levels) */
 } psacx_stats;
 
 /* life cycle ------------------------------------------------------------- */

@@ -50,7 +50,8 @@ class Stats(C.Structure):
                 ("ms_rmq_build", C.c_double), ("ms_finalize", C.c_double),
                 ("ms_sort_scatter3", C.c_double), ("ms_sort_tilehist", C.c_double), ("ms_sort_scatter2", C.c_double),
                 ("scatter_launches", C.c_uint64 * 3), ("scatter_records", C.c_uint64 * 3),
-                ("scatter_bytes", C.c_uint64 * 3), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("onew_passes", C.c_uint64)]
+                ("scatter_bytes", C.c_uint64 * 3), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("onew_passes", C.c_uint64),
+                ("heavy_rounds", C.c_uint64), ("heavy_records", C.c_uint64), ("light_records", C.c_uint64), ("level_gathers", C.c_uint64)]
 
 
 class PsacxError(RuntimeError):

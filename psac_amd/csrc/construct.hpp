@@ -11,6 +11,7 @@
 #pragma once
 #include "engine.hpp"
 #include "bucket_sort.hpp"
+#include "heavy_keys.hpp"
 
 namespace psacx {
 
@@ -43,6 +44,9 @@ template <typename T> struct Work {
     uint64_t* d_chunks;                // 2 x SCAN_CHUNKS chunk totals of the long tile scans
     unsigned* d_cursors;               // fill cursors of the destination buckets (ISA inversion)
     size_t n_cursors;
+    unsigned* d_gcursors;              // the same for the rank requests of a refinement round (GatherLevels; the ISA levels of a round in slabs stay open meanwhile)
+    uint64_t* d_gwin;                  // ... and where the records of every window start in the round's sort input
+    uint64_t* d_heavy;                 // tables of the heavy / light split of a round (heavy_keys.hpp: HeavyTabs for HEAVY_MAXB buckets)
     SortScratch sc;
 };
 
@@ -54,6 +58,7 @@ template <typename T> struct Work {
 constexpr uint64_t ONEW_PAD = 20480;            // places per bucket: 160 KiB
 template <typename T> inline uint64_t onew_pad_total(uint64_t n) { return (sizeof(T) == 8 && n >= (1ull << 28)) ? (uint64_t)RADIX * ONEW_PAD : 0; }
 
+constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;      // windows of 2^14 positions, 512-way partition levels (invert_permutation, IsaLevels, GatherLevels)
 template <typename T>
 size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool diet, uint64_t cap, T* d_sa, T* d_isa, const Knobs& kn) {
     w.diet = diet;
@@ -93,6 +98,9 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.d_chunks = a.take<uint64_t>(2 * SCAN_CHUNKS);
     w.n_cursors = (size_t)(n >> INV_WINDOW_BITS) + 2 + RADIX_P;
     w.d_cursors = a.take<unsigned>(w.n_cursors);
+    w.d_gcursors = a.take<unsigned>(1024 + (size_t)(n >> ISA_NARROW_WB) + 2);
+    w.d_gwin = a.take<uint64_t>((size_t)(n >> ISA_NARROW_WB) + 2);
+    w.d_heavy = a.take<uint64_t>(HeavyTabs::words(HEAVY_MAXB));
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.desc_bytes = sort_desc_bytes(n);
@@ -236,7 +244,6 @@ inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
 // read-bound, no gain.
 // 64-bit words, at most 2^32 positions: the inversion moves 32-bit (position, rank) pairs through 512-way partition
 // levels down to windows of 2^14 positions.  Returns the number of levels (0: the form does not apply).
-constexpr int ISA_NARROW_WB = 14, ISA_NARROW_CB = 9;
 template <typename T>
 inline int isa_narrow_levels(uint64_t n, const Knobs& kn) {
     if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32)) return 0;
@@ -316,10 +323,10 @@ int invert_permutation(psacx_ctx* c, unsigned* d_cursors, const T* d_sa, const T
             PSACX_HIP(c, hipMemsetAsync(d_cursors, 0, ((size_t)(n >> shift) + 1) * sizeof(unsigned), c->stream));
             uint64_t* o = pb[lv & 1];
             if (lv == 0)
-                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, true, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
+                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 1, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, d_sa, val,
                                    (const uint64_t*)nullptr, o, n, shift, d_cursors, koff);
             else
-                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, (const T*)nullptr,
+                hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)ntiles), dim3(PB), 0, c->stream, (const T*)nullptr,
                                    (const T*)nullptr, cur, o, n, shift, d_cursors, (uint64_t)0);
             PSACX_HIP(c, hipGetLastError());
             cur = o;
@@ -367,7 +374,7 @@ template <typename T> struct IsaLevels {
         return PSACX_OK;
     }
     int add(const uint64_t* pairs, uint64_t cnt) {
-        hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+        hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
                            (const T*)nullptr, pairs, lvl_a, cnt, isa_narrow_shift(lv9, 0), lv9 == 1 ? c1() : c0(), (uint64_t)0);
         PSACX_HIP(c, hipGetLastError());
         return PSACX_OK;
@@ -376,7 +383,7 @@ template <typename T> struct IsaLevels {
         open = false;
         const uint64_t* last = lvl_a;
         if (lv9 == 2) {
-            hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, false, CB>), dim3((unsigned)((n + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+            hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)((n + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
                                (const T*)nullptr, (const uint64_t*)lvl_a, lvl_b, n, (unsigned)WB, c1(), (uint64_t)0, (const unsigned*)c0(), isa_narrow_shift(lv9, 0));
             PSACX_HIP(c, hipGetLastError());
             last = lvl_b;
@@ -386,6 +393,75 @@ template <typename T> struct IsaLevels {
         return PSACX_OK;
     }
 };
+
+// The ranks h further of a refinement round (B2, suffix_array.hpp:972-996) fetched like the ISA entries are stored: the request of list entry j --
+// (SA[pos[j]] + h | number of j's bucket << 32) -- goes through the same 512-way partition levels by text position (psac batches its requests by
+// owner, bulk_rma.hpp:20-49; this is the one-GPU form of it), the window kernel reads ISA in whole lines and the requests leave it as the records
+// of the round's sort, (number << kb2 | rank + 1) with the suffix as a 32-bit entry.  One random 8-byte fetch per record costs 27 - 30 ps on this
+// part whatever the distance between neighbouring requests (tools/ubench_gather.hip: 36 G requests/s over 32 GiB, 38 G inside 64 MiB, 58 G inside
+// 128 KiB -- the fetch is bound by the number of requests, not by HBM); the levels move 8-byte requests at the bandwidth of a copy.
+// 64-bit words, 2^23 < n <= 2^32 (two levels), a list with its buckets' numbers beside it.  lvl_a, lvl_b: two arrays of n entries; keys: cnt
+// words (may be lvl_a); v32: cnt 32-bit entries.
+template <typename T>
+int gather_by_levels(psacx_ctx* c, Work<T>& w, uint64_t n, uint64_t h, const T* plist, uint64_t cnt, const T* d_sa, const uint32_t* ord, const T* d_isa,
+                     uint64_t* lvl_a, uint64_t* lvl_b, T* keys, uint32_t* v32, unsigned kb2, const Knobs& kn, unsigned* nblocks) {
+    constexpr int PB = 512, PI = 16, WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
+    if (isa_narrow_levels<T>(n, kn) != 2) { c->hip_err = "B2 fetch by levels: text size out of range"; return PSACX_EINVAL; }
+    unsigned* const c0 = w.d_gcursors; unsigned* const c1 = w.d_gcursors + 1024;
+    const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
+    PSACX_HIP(c, hipMemsetAsync(c0, 0, (1024 + (size_t)nwin + 1) * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 2, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, d_sa, plist,
+                       (const uint64_t*)nullptr, lvl_a, cnt, isa_narrow_shift(2, 0), c0, (uint64_t)0, (const unsigned*)nullptr, 0u, ord, h, n);
+    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)((n + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+                       (const T*)nullptr, (const uint64_t*)lvl_a, lvl_b, n, (unsigned)WB, c1, (uint64_t)0, (const unsigned*)c0, isa_narrow_shift(2, 0));
+    hipLaunchKernelGGL(window_offsets_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, (const unsigned*)c1, nwin, w.d_gwin);
+    hipLaunchKernelGGL((window_gather_kernel<T, 1024, WB>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, (const uint64_t*)lvl_b, (const unsigned*)c1,
+                       (const uint64_t*)w.d_gwin, n, h, d_isa, kb2, keys, v32, w.sc.d_partials);
+    PSACX_HIP(c, hipGetLastError());
+    *nblocks = (unsigned)nwin;
+    return PSACX_OK;
+}
+
+// gather_by_levels with the heavy / light split of heavy_keys.hpp: the requests go through the same two levels; the window kernel writes the
+// light records (LK: keys, LV: suffixes as 32-bit entries, compacted in any order) and the heavy suffixes (HB, in their buckets' runs of a
+// cnt-entry array in list order).  *light = the number of light records (the stream is drained for it).
+inline HeavyTabs heavy_tabs(uint64_t* base, unsigned nb) {
+    HeavyTabs ht;
+    ht.bstart = base; base += nb + 1;
+    ht.value = base; base += nb;
+    ht.less = reinterpret_cast<unsigned long long*>(base); base += nb;
+    ht.lstart = base; base += nb + 1;
+    ht.light = reinterpret_cast<unsigned long long*>(base); base += 8;           // (the reservation counters start on a 64-byte line: d_heavy is 256-byte aligned, nb words above are whole lines only by luck -- the padding keeps the counters apart from each other, which is what matters)
+    ht.eq = reinterpret_cast<unsigned long long*>(base);
+    return ht;
+}
+template <typename T>
+int gather_heavy_by_levels(psacx_ctx* c, Work<T>& w, uint64_t n, uint64_t h, const T* plist, uint64_t cnt, const T* d_sa, const uint32_t* ord, unsigned nb,
+                           const T* d_isa, uint64_t* lvl_a, uint64_t* lvl_b, T* LK, uint32_t* LV, uint32_t* HB, unsigned kb2, const Knobs& kn, HeavyTabs* tabs,
+                           uint64_t* light, unsigned* nblocks) {
+    constexpr int PB = 512, PI = 16, WB = ISA_NARROW_WB, CB = ISA_NARROW_CB;
+    if (isa_narrow_levels<T>(n, kn) != 2 || nb == 0 || nb > HEAVY_MAXB) { c->hip_err = "heavy / light split: out of range"; return PSACX_EINVAL; }
+    const HeavyTabs ht = heavy_tabs(w.d_heavy, nb);
+    *tabs = ht;
+    unsigned* const c0 = w.d_gcursors; unsigned* const c1 = w.d_gcursors + 1024;
+    const uint64_t nwin = (n + (1ull << WB) - 1) >> WB;
+    hipLaunchKernelGGL((heavy_probe_kernel<T>), dim3((nb + 1 + 255) / 256), dim3(256), 0, c->stream, ord, cnt, (uint32_t)nb, plist, d_sa, d_isa, n, h, ht);
+    PSACX_HIP(c, hipMemsetAsync(c0, 0, (1024 + (size_t)nwin + 1) * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 2, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, d_sa, plist,
+                       (const uint64_t*)nullptr, lvl_a, cnt, isa_narrow_shift(2, 0), c0, (uint64_t)0, (const unsigned*)nullptr, 0u, ord, h, n);
+    hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)((n + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
+                       (const T*)nullptr, (const uint64_t*)lvl_a, lvl_b, n, (unsigned)WB, c1, (uint64_t)0, (const unsigned*)c0, isa_narrow_shift(2, 0));
+    hipLaunchKernelGGL((window_gather_heavy_kernel<T, 1024, WB>), dim3((unsigned)nwin), dim3(1024), (size_t)nb * 2 * sizeof(uint32_t), c->stream, (const uint64_t*)lvl_b,
+                       (const unsigned*)c1, n, h, d_isa, kb2, (uint32_t)nb, ht, LK, LV, HB, w.sc.d_partials);
+    uint64_t* const h_light = reinterpret_cast<uint64_t*>(c->pinned + 112);
+    PSACX_HIP(c, hipGetLastError());
+    PSACX_HIP(c, hipMemcpyAsync(h_light, ht.light, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    PSACX_HIP(c, hipStreamSynchronize(c->stream));
+    if (h_light[0] > cnt) { c->hip_err = "heavy / light split: more light records than records"; return PSACX_EDEVICE; }
+    *light = h_light[0];
+    *nblocks = (unsigned)nwin;
+    return PSACX_OK;
+}
 
 // Range minima of a refinement round (suffix_array.hpp:1457-1476 issues one per freshly split boundary)
 // read LCP values set in earlier rounds only, so per-group running minima can be tabulated once per
@@ -866,12 +942,79 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         const bool by_ord = dense && both && ord_arr && nb_in > 0;
         const unsigned num_bits = by_ord ? bits_for(nb_in > 1 ? nb_in - 1 : 1) : dense ? bits_for(cnt > 2 ? (cnt - 1) >> 1 : 1) : id_bits;
         T* const key2 = both ? (T*)nullptr : w.x.k2;
-        {
+        // large rounds: the ranks h further come through partition levels by text position instead of one random fetch per record
+        // (gather_by_levels); the requests then leave the levels as the sort's records, in the order of the text
+        // -- for rounds whose buckets are too long for the sort in LDS (bucket_sort.hpp), which needs a bucket's records side by side
+        const bool lds_sort_possible = sizeof(T) == 8 && both && dense && !kn.no_bucket_sort && (by_ord ? cnt / nb_in : (uint64_t)0) <= BSORT_CAP / 4;
+        const bool by_levels = by_ord && !gsa && !lds_sort_possible && isa_narrow_levels<T>(n, kn) == 2 && cnt >= (1ull << 22) &&
+                               (kn.gather == 2 || (kn.gather == 0 && cnt >= n / 8));
+        // (the payload entries of the sort's input; in the reduced layout the levels end in x.v, so the records' suffixes start in the other set)
+        T* const vin = (by_levels && w.diet) ? w.ry.v : w.x.v;
+        T* const valt = (by_levels && w.diet) ? w.x.v : w.ry.v;
+        psacx_round rs; std::memset(&rs, 0, sizeof(rs));
+        // ... and when the list has few enough buckets for their tables to live in LDS, the records are split where their keys are made: those that
+        // carry their bucket's heavy rank skip the sort (heavy_keys.hpp)
+        const bool heavy = by_levels && !kn.no_heavy && nb_in <= HEAVY_MAXB && (!w.diet || (2 * cnt + 64 <= n && cnt + 64 <= w.cap_active));
+        bool merged = false;
+        T* ids_heavy = nullptr; uint64_t* pairs_heavy = nullptr;
+        uint64_t rmq_queries = cnt;
+        if constexpr (sizeof(T) == 8) {
+            if (heavy) {
+                // arrays (normal layout: everything has n entries; reduced layout: x.k1, x.k2, x.v have n, the ry set and the lists cap_active):
+                //   levels            ry.k1 -> ry.k2                       | x.k1 -> x.v
+                //   light records     x.k1, x.v (32-bit)                   | x.k1, ry.v (32-bit)
+                //   heavy suffixes    ry.v (32-bit)                        | ry.k1, lower half (32-bit)
+                //   light sort, alt   ry.k1, x.k2                          | x.k1 behind the records, ry.k1 upper half
+                //   merged records    ry.k2, the idle list                 | the idle list, ry.k2
+                //   then ids / pairs  x.k1 / ry.v                          | ry.k1 / ry.v
+                T* const other_list = (plist == w.pos_a) ? w.pos_b : w.pos_a;
+                const uint64_t cnt_r = (cnt + 63) & ~63ull;
+                uint64_t* const la = reinterpret_cast<uint64_t*>(w.diet ? w.x.k1 : w.ry.k1);
+                uint64_t* const lb = reinterpret_cast<uint64_t*>(w.diet ? w.x.v : w.ry.k2);
+                uint32_t* const LV = reinterpret_cast<uint32_t*>(w.diet ? w.ry.v : w.x.v);
+                uint32_t* const HB = reinterpret_cast<uint32_t*>(w.diet ? w.ry.k1 : w.ry.v);
+                SortBufs<T> altL;
+                altL.k1 = w.diet ? w.x.k1 + cnt_r : w.ry.k1; altL.k2 = nullptr;
+                altL.v = w.diet ? reinterpret_cast<T*>(reinterpret_cast<uint32_t*>(w.ry.k1) + cnt_r) : w.x.k2;
+                T* const MK = w.diet ? other_list : w.ry.k2;
+                T* const MV = w.diet ? w.ry.k2 : other_list;
+                ids_heavy = w.diet ? w.ry.k1 : w.x.k1;
+                pairs_heavy = reinterpret_cast<uint64_t*>(w.ry.v);
+                HeavyTabs ht; uint64_t nlight = 0; unsigned nblk = 0;
+                {
+                    ProfScope ps(c, TC_GATHER);
+                    PSACX_TRY(gather_heavy_by_levels<T>(c, w, n, h, plist, cnt, d_sa, ord_arr, (unsigned)nb_in, d_isa, la, lb, w.x.k1, LV, HB, kb2, kn, &ht, &nlight, &nblk));
+                    if (nlight) PSACX_TRY(summary_finish(c, w.sc, nblk));
+                }
+                SortBufs<T> sl{w.x.k1, nullptr, reinterpret_cast<T*>(LV)};
+                if (nlight)
+                    PSACX_TRY(pair_sort<T>(c, w.sc, sl, altL, nlight, /*iota=*/false, kb2 + num_bits, 0, nullptr, &sl, &rs, 0, 0,
+                                           /*summary_ready=*/true, 0, -1, /*v32_in=*/true, /*keep_v32=*/true));
+                {
+                    ProfScope ps(c, TC_SORT_SCATTER);
+                    hipLaunchKernelGGL((heavy_plan_kernel<T>), dim3(((unsigned)nb_in + 1 + 255) / 256), dim3(256), 0, c->stream, (uint32_t)nb_in, ht, kb2, (const T*)sl.k1, nlight, w.sc.d_err);
+                    hipLaunchKernelGGL((heavy_merge_kernel<T, 256, 16, HEAVY_MAXB>), dim3((unsigned)((cnt + 4095) / 4096)), dim3(256), 0, c->stream, cnt, (uint32_t)nb_in, ht, kb2,
+                                       (const T*)sl.k1, reinterpret_cast<const uint32_t*>(sl.v), (const uint32_t*)HB, MK, MV);
+                    PSACX_HIP(c, hipGetLastError());
+                }
+                c->stats.heavy_rounds += 1; c->stats.heavy_records += cnt - nlight; c->stats.light_records += nlight; c->stats.level_gathers += 1;
+                sorted.k1 = MK; sorted.k2 = nullptr; sorted.v = MV;
+                rmq_queries = nlight + 2 * nb_in;
+                merged = true;
+            }
+        }
+        if (!merged) {
             ProfScope ps(c, TC_GATHER);
-            const int gg = grid_for(c, cnt, 256, 16);
+            int gg = grid_for(c, cnt, 256, 16);
             if (whole)
                 hipLaunchKernelGGL((shift_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen);
-            else
+            else if (by_levels) {
+                unsigned nb = 0;
+                PSACX_TRY(gather_by_levels<T>(c, w, n, h, plist, cnt, d_sa, ord_arr, d_isa, reinterpret_cast<uint64_t*>(w.diet ? w.x.k1 : w.ry.k1),
+                                              reinterpret_cast<uint64_t*>(w.diet ? w.x.v : w.ry.k2), w.x.k1, reinterpret_cast<uint32_t*>(vin), kb2, kn, &nb));
+                gg = (int)nb;
+                c->stats.level_gathers += 1;
+            } else
                 hipLaunchKernelGGL((gather_keys_kernel<T>), dim3(gg), dim3(256), 0, c->stream,
                                    plist, cnt, d_sa, w.bsa, d_isa, n, h, w.x.k1, key2, w.x.v, w.sc.d_partials, d_slen, kb2,
                                    by_ord ? (const uint32_t*)ord_arr : (const uint32_t*)nullptr);
@@ -879,12 +1022,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             // (only the three-kernel form of the sort reads the key summary)
             if (sort_is_three(cnt, true)) PSACX_TRY(summary_finish(c, w.sc, (unsigned)gg));
         }
-        psacx_round rs; std::memset(&rs, 0, sizeof(rs));
         // no bucket longer than a workgroup holds in LDS (asked of the device first): every bucket is sorted there and the records cross
         // memory once (bucket_sort.hpp); a text with a few huge buckets left -- a tandem repeat -- is not worth the question
         bool sorted_in_lds = false;
         if constexpr (sizeof(T) == 8) {
-            if (both && dense && !kn.no_bucket_sort && (by_ord ? cnt / nb_in : (uint64_t)0) <= BSORT_CAP / 4) {
+            if (lds_sort_possible) {
                 // (wide windows first; both questions are asked before the one synchronisation)
                 const uint64_t nt_wide = (cnt + BSORT_W_WIDE - 1) / BSORT_W_WIDE, nt_narrow = (cnt + BSORT_W_NARROW - 1) / BSORT_W_NARROW;
                 uint64_t* const st_wide = reinterpret_cast<uint64_t*>(w.sc.d_desc + 256);
@@ -908,18 +1050,18 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 if (wide || h_over[1] == 0) {
                     ProfScope ps(c, TC_SORT_SCATTER);
                     hipLaunchKernelGGL((bucket_sort_lds_kernel<BSORT_BLOCK, BSORT_ITEMS>), dim3((unsigned)ntasks), dim3(BSORT_BLOCK), 0, c->stream,
-                                       reinterpret_cast<const uint64_t*>(w.x.k1), reinterpret_cast<const uint32_t*>(w.x.v), starts, kb2,
-                                       reinterpret_cast<uint64_t*>(w.ry.k1), reinterpret_cast<uint64_t*>(w.ry.v));
+                                       reinterpret_cast<const uint64_t*>(w.x.k1), reinterpret_cast<const uint32_t*>(vin), starts, kb2,
+                                       reinterpret_cast<uint64_t*>(w.ry.k1), reinterpret_cast<uint64_t*>(valt));
                     PSACX_HIP(c, hipGetLastError());
-                    sorted.k1 = w.ry.k1; sorted.k2 = nullptr; sorted.v = w.ry.v;
+                    sorted.k1 = w.ry.k1; sorted.k2 = nullptr; sorted.v = valt;
                     rs.sort_passes = 1;
                     sorted_in_lds = true;
                 }
             }
         }
-        if (sorted_in_lds) {
+        if (sorted_in_lds || merged) {
         } else if (both) {
-            SortBufs<T> in2{w.x.k1, nullptr, w.x.v}, alt2{w.ry.k1, nullptr, w.ry.v};
+            SortBufs<T> in2{w.x.k1, nullptr, vin}, alt2{w.ry.k1, nullptr, valt};
             PSACX_TRY(pair_sort<T>(c, w.sc, in2, alt2, cnt, /*iota=*/false, kb2 + num_bits, 0, nullptr, &sorted, &rs, 0, 0,
                                    /*summary_ready=*/true, 0, -1, /*v32_in=*/true));
             sorted.k2 = nullptr;
@@ -927,13 +1069,15 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         PSACX_TRY(pair_sort<T>(c, w.sc, w.x, w.ry, cnt, /*iota=*/false, id_bits, id_bits, nullptr, &sorted, &rs, 0, 0,
                                /*summary_ready=*/true));
         if (rr) { rr->sort_passes += rs.sort_passes; rr->sort_passes_skipped += rs.sort_passes_skipped; }
-        T* ids = (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
+        T* ids = merged ? ids_heavy : (sorted.k1 == w.x.k1) ? w.ry.k1 : w.x.k1;    // the set not holding the result is free
         // large rounds of the two-word form: the ISA entries leave the rebucket kernel as pairs (in the idle second key array of the round's
         // second record set) and reach ISA through partition levels once the compaction has read the ids (x.k2 and x.k1 are idle then)
-        const bool levels_pay = kn.isa_update == 2 || (kn.isa_update == 0 && n >= (1ull << 31) && cnt >= n / 8);
+        // (... also at fewer characters when the round's ranks came through the levels: long buckets that stride through the text)
+        const bool levels_pay = kn.isa_update == 2 || (kn.isa_update == 0 && cnt >= n / 8 && (n >= (1ull << 31) || by_levels));
         uint64_t* const isa_pairs = (both && !whole && ((cnt >= (1ull << 22) && levels_pay) || isa_lv.open) && isa_narrow_levels<T>(n, kn) > 0)
-                                        ? reinterpret_cast<uint64_t*>(w.ry.k2) : (uint64_t*)nullptr;
-        if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, cnt, n, kn));
+                                        ? (merged ? pairs_heavy : reinterpret_cast<uint64_t*>(w.ry.k2)) : (uint64_t*)nullptr;
+        // (a split round asks for a range minimum at most once per light record and bucket: its heavy runs stay whole)
+        if (WITH_LCP) PSACX_TRY(prepare_range_min<T>(c, w, merged ? rmq_queries : cnt, n, kn));
         {
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
@@ -980,7 +1124,11 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         // rounds in which at least 7/8 of the suffixes are unresolved (repetitive texts) take all n in text order, as psac's
         // doubling rounds do: the random fetch of the ranks h further and the random ISA stores turn into streams
         bool whole = !no_fast && !w.diet && have_list && w.cap_active >= n && n >= (1ull << 16) &&
-                     active >= n - n / 8;
+                     active >= n - n / 8 && !kn.no_whole;
+        // ... unless the list takes the partition levels (long buckets, 64-bit words: gather_by_levels and the heavy / light split in refine):
+        // the round then sorts bucket numbers of a few bits instead of ranks of log n, and mostly not even those (heavy_keys.hpp)
+        if (whole && sizeof(T) == 8 && !gsa && ord_arr && kn.gather != 1 && isa_narrow_levels<T>(n, kn) == 2 && active >= (1ull << 22) &&
+            unf_b > 0 && active / unf_b > BSORT_CAP / 4) whole = false;
         if (whole) {
             // ... unless SA order is nearly text order (sa_locality_kernel): 2^27 equal characters take 9.2 ms per round through
             // the list and 12.0 ms as whole rounds, a period-1024 tandem repeat 18.0 against 14.7 (profiles/r03g_*)

@@ -151,6 +151,10 @@ struct Knobs {
                             // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
     bool no_digit_bytes;    // PSACX_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
     bool no_bucket_sort;    // PSACX_NO_BUCKET_SORT: the refinement rounds always take the global radix sort (A/B runs; bucket_sort.hpp)
+    int gather;             // PSACX_GATHER=fetch | levels: how a refinement round gets the ranks h further -- one random fetch per record, or requests through
+                            // partition levels (construct.hpp: gather_by_levels); default (0): levels for rounds of at least n / 8 records
+    bool no_heavy;          // PSACX_NO_HEAVY: no split of a round's records into heavy and light ones (heavy_keys.hpp; A/B runs)
+    bool no_whole;          // PSACX_NO_WHOLE: rounds in which nearly every suffix is unresolved take the list of positions too (A/B runs)
     bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                             // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
 };
@@ -170,6 +174,10 @@ inline Knobs read_knobs() {
     k.no_digit_bytes = getenv("PSACX_NO_DIGIT_BYTES") != nullptr;
     e = getenv("PSACX_ISA_UPDATE");
     k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
+    e = getenv("PSACX_GATHER");
+    k.gather = !e ? 0 : (e[0] == 'f' ? 1 : 2);
+    k.no_whole = getenv("PSACX_NO_WHOLE") != nullptr;
+    k.no_heavy = getenv("PSACX_NO_HEAVY") != nullptr;
     return k;
 }
 
@@ -683,7 +691,8 @@ template <typename T>
 int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, uint64_t n, bool iota,
               unsigned bits1, unsigned bits2, T* final_v, SortBufs<T>* res, psacx_round* rs,
               uint64_t spec = 0, uint64_t spec_n = 0, bool summary_ready = false, unsigned lo1 = 0,
-              int ready_hist_shift = -1, bool v32_in = false) {
+              int ready_hist_shift = -1, bool v32_in = false, bool keep_v32 = false) {
+    // keep_v32 (with v32_in): the payloads stay 32-bit entries after the last pass too (res->v holds n 32-bit entries)
     if (bits1 > sizeof(T) * 8) bits1 = sizeof(T) * 8;
     if (bits2 > sizeof(T) * 8) bits2 = sizeof(T) * 8;
     if (!in.k2) bits2 = 0;
@@ -771,6 +780,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     // travels as 32-bit entries between the passes and is widened by the last one (radix.hpp: VN)
     const bool narrow = three && sizeof(T) == 8 && ((iota && n <= (1ull << 32)) || v32_in);
     if (v32_in && !narrow) return PSACX_EINVAL;
+    if (keep_v32 && (!v32_in || final_v)) return PSACX_EINVAL;
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
     for (int p = 0; p < plan.n_pass; ++p) {
@@ -791,7 +801,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
         if (three) {
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift;
-            const int vn = narrow ? (last ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
+            const int vn = narrow ? ((last && !keep_v32) ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
             dispatch_pass3<T>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, spec, spec_n, have_hist, vn);
             PSACX_HIP(c, hipGetLastError());
         } else {
@@ -815,6 +825,8 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         if (iota) {
             hipLaunchKernelGGL((iota_kernel<T>), dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, dst, n, spec, spec_n);
             PSACX_HIP(c, hipGetLastError());
+        } else if (v32_in && keep_v32) {
+            dst = cur.v;               // (32-bit entries in and out: nothing to do)
         } else if (v32_in) {
             // (32-bit entries in, words out: through the other payload array when the widening would run in place)
             T* const w = (dst == cur.v) ? oth.v : dst;

@@ -1151,12 +1151,18 @@ __global__ __launch_bounds__(BLOCK) void window_scatter_kernel(const TI* __restr
 
 // The same two kernels for pairs packed into one 64-bit entry (position in the low half, rank in the high half; at most
 // 2^32 positions): one array, one staging round, runs of 64 to 128 bytes where the two-array form writes two of 32 to 64.
-// FIRST: the level reads (SA, bucket id) words and packs (position - koff, id - 1).
-template <typename TI, int BLOCK, int ITEMS, bool FIRST, int CB>
+// FIRST = 1: the level reads (SA, bucket id) words and packs (position - koff, id - 1).
+// FIRST = 2: the level makes up the rank REQUESTS of a refinement round (the B2 fetch of suffix_array.hpp:972-996 batched by address,
+// as psac batches it by owner, bulk_rma.hpp:20-49): list entry j asks for the rank of text position q = SA[pos[j]] + h and carries the
+// number of its bucket in the sort key, (q | number << 32); key_in = SA, val_in = pos, req_ord = the numbers.  A suffix with fewer than h
+// characters left (q >= n_text: rank 0, suffix_array.hpp:1010-1016) travels under q - n_text with bit 63 set: those addresses lie in [0, h),
+// the others in [h, n_text), so no two requests share one and a class of 2^k addresses never receives more than 2^k records.
+template <typename TI, int BLOCK, int ITEMS, int FIRST, int CB>
 __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __restrict__ key_in, const TI* __restrict__ val_in,
                                                                  const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n,
                                                                  unsigned shift, unsigned* __restrict__ cursors, uint64_t koff,
-                                                                 const unsigned* __restrict__ in_counts = nullptr, unsigned in_shift = 0) {
+                                                                 const unsigned* __restrict__ in_counts = nullptr, unsigned in_shift = 0,
+                                                                 const uint32_t* __restrict__ req_ord = nullptr, uint64_t req_h = 0, uint64_t n_text = 0) {
     // in_counts (levels after the first, pairs of a SUBSET of the positions: the ISA update of a refinement round): the class regions of
     // the level before are filled to in_counts[class] only (class = index >> in_shift; a tile lies inside one region)
     constexpr int NCLS = 1 << CB;
@@ -1184,7 +1190,12 @@ __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __res
     for (int i = 0; i < ITEMS; ++i) {
         const unsigned loc = tid + i * BLOCK;
         if (loc < count) {
-            if (FIRST) rec[i] = (uint64_t)(uint32_t)((uint64_t)key_in[base + loc] - koff) | ((uint64_t)(uint32_t)((uint64_t)val_in[base + loc] - 1u) << 32);
+            if (FIRST == 2) {
+                const uint64_t sa = (uint64_t)key_in[(uint64_t)val_in[base + loc]], q = sa + req_h;
+                const uint64_t num = (uint64_t)req_ord[base + loc] << 32;
+                rec[i] = q < n_text ? (q | num) : ((q - n_text) | num | (1ull << 63));
+            }
+            else if (FIRST) rec[i] = (uint64_t)(uint32_t)((uint64_t)key_in[base + loc] - koff) | ((uint64_t)(uint32_t)((uint64_t)val_in[base + loc] - 1u) << 32);
             else rec[i] = in[base + loc];
         } else rec[i] = 0;
     }
@@ -1202,7 +1213,8 @@ __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __res
         bstart[tid] = bs;
         if (tot) {
             // all keys of a tile share the bits above shift + CB (tiles never straddle a parent bucket)
-            const uint64_t first_key = FIRST ? (uint64_t)key_in[base] - koff : (uint64_t)(uint32_t)in[base];
+            // (the requests of a round enter at the top level: no parent bucket)
+            const uint64_t first_key = FIRST == 2 ? (uint64_t)0 : FIRST ? (uint64_t)key_in[base] - koff : (uint64_t)(uint32_t)in[base];
             const uint64_t g = ((first_key >> shift >> CB) << CB) | tid;
             const unsigned at = atomicAdd(&cursors[g], tot);
             gbase[tid] = (g << shift) + at - bs;
@@ -1258,6 +1270,57 @@ __global__ __launch_bounds__(BLOCK) void window_store_sparse_kernel(const uint64
     for (unsigned p = threadIdx.x; p < count; p += BLOCK) { const uint64_t x = pairs[base + p]; win[(uint32_t)x & (W - 1)] = (uint32_t)(x >> 32); }
     __syncthreads();
     for (unsigned p = threadIdx.x; p < wn; p += BLOCK) out[base + p] = (TO)win[p];
+}
+
+// The last step of the B2 fetch through partition levels (partition_packed_kernel<..., 2, ...>): window w holds counts[w] requests
+// (q | number << 32) for text positions q of its 2^WB entries of ISA.  The window of ISA comes into LDS in whole lines (ranks below 2^32:
+// texts of at most 2^32 characters) unless only a few of its entries are asked for, and every request leaves as a record of the round's
+// sort: key (number << kb2 | rank + 1) and the suffix q - h as a 32-bit entry, windows back to back (offs = exclusive scan of counts).
+// The records of a bucket are no longer neighbours -- the sort that follows orders by (number, rank) anyway -- and equal keys
+// may come out in any order: they stay one bucket, whose inner order no result depends on.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void window_offsets_kernel(const unsigned* __restrict__ counts, uint64_t nwin, uint64_t* __restrict__ offs) {
+    __shared__ uint64_t scan_tmp[BLOCK / WAVE + 1];
+    const uint64_t per = (nwin + BLOCK - 1) / BLOCK, lo = (uint64_t)threadIdx.x * per, hi = lo + per < nwin ? lo + per : nwin;
+    uint64_t mine = 0;
+    for (uint64_t w = lo; w < hi; ++w) mine += counts[w];
+    uint64_t total;
+    uint64_t run = block_scan_exclusive<BLOCK, uint64_t>(mine, OpSum(), (uint64_t)0, scan_tmp, &total);
+    for (uint64_t w = lo; w < hi; ++w) { offs[w] = run; run += counts[w]; }
+    if (threadIdx.x == 0) offs[nwin] = total;
+}
+
+template <typename T, int BLOCK, int WB>
+__global__ __launch_bounds__(BLOCK) void window_gather_kernel(const uint64_t* __restrict__ pairs, const unsigned* __restrict__ counts,
+                                                              const uint64_t* __restrict__ offs, uint64_t n, uint64_t h, const T* __restrict__ ISA,
+                                                              unsigned kb2, T* __restrict__ K1, uint32_t* __restrict__ V32,
+                                                              unsigned long long* __restrict__ summary) {
+    constexpr unsigned W = 1u << WB;
+    __shared__ uint32_t win[W];
+    const uint64_t base = (uint64_t)blockIdx.x << WB;
+    const unsigned count = counts[blockIdx.x];
+    const uint64_t remain = n - base;
+    const unsigned wn = remain < (uint64_t)W ? (unsigned)remain : W;
+    const bool staged = count * 4u >= wn;            // (the same for every thread of the workgroup)
+    if (staged) {
+        for (unsigned p = threadIdx.x; p < wn; p += BLOCK) win[p] = (uint32_t)ISA[base + p];
+        __syncthreads();
+    }
+    const uint64_t o = offs[blockIdx.x];
+    T o1 = 0, a1 = ~(T)0;
+    for (unsigned p = threadIdx.x; p < count; p += BLOCK) {
+        const uint64_t x = pairs[base + p];
+        const uint32_t q = (uint32_t)x;
+        const bool beyond = (x >> 63) != 0;
+        const uint64_t num = (x >> 32) & 0x7FFFFFFFull;
+        uint64_t b2 = 0;
+        if (!beyond) b2 = (staged ? (uint64_t)win[q & (W - 1)] : (uint64_t)ISA[q]) + 1;
+        const T kk = (T)((num << kb2) | b2);
+        K1[o + p] = kk;
+        V32[o + p] = (uint32_t)(beyond ? (uint64_t)q + n - h : (uint64_t)q - h);
+        o1 |= kk; a1 &= kk;
+    }
+    key_summary_add<T>(summary, o1, a1, (T)0, ~(T)0);
 }
 
 // ------------------------------------------------------------------ K12

@@ -26,4 +26,5 @@ if len(sys.argv) > 5 and sys.argv[5] == "check":
         err = list(mgc.check_device([d_text], [n], [d_sa], [d_isa], [d_lcp], 64))
     finally:
         mgc.close()
-print("kind", kind, "n 2^%d" % lg, "knob", os.environ.get("PSACX_NO_DIGIT_BYTES"), "ms", " ".join("%.1f" % t for t in ts), "rounds", st.n_rounds, "check", err)
+print("kind", kind, "n 2^%d" % lg, "ms", " ".join("%.1f" % t for t in ts), "rounds", st.n_rounds, "check", err)
+print("rounds (h, records, unfinished buckets, unfinished elements, sort passes):", [(r.h, r.active, r.unfinished_buckets, r.unfinished_elements, r.sort_passes) for r in st.rounds[:st.n_rounds]])
