@@ -371,13 +371,17 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
     lib = ctx._lib
     res = {}
 
-    def run(tag, kind, n, bits, steps, env=None, seed=None, period=1024, recurrence_check=False):
+    def run(tag, kind, n, bits, steps, options=None, seed=None, period=1024, recurrence_check=False):
         # recurrence_check: verified by the distributed checker with one rank (every LCP entry through its recurrence) -- the device
         # checker compares characters, sum(LCP) of them: hours on a long repeat
+        # options: psacx_configure options of this workload (when the wrappers take their options from PSACX_* variables -- the test suite's
+        # debug shim -- the variable of the same name is set as well)
+        old = {}
         try:
-            old = {}
-            for k_, v_ in (env or {}).items():
-                old[k_] = os.environ.get(k_); os.environ[k_] = v_
+            for k_, v_ in (options or {}).items():
+                if psac_amd._lib.ENV_KNOBS:
+                    old["PSACX_" + k_.upper()] = os.environ.get("PSACX_" + k_.upper()); os.environ["PSACX_" + k_.upper()] = str(v_)
+            ctx.configure(**(options or {}))
             ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID[kind], a.seed if seed is None else seed, period))
             s_ = sa64 if bits == 64 else psac_amd.SuffixArray(index_bits=32, lcp=True, ctx=ctx)
             s_.construct_device(d_text, n, d_sa, d_isa, d_lcp)
@@ -412,6 +416,7 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
         except Exception as e:              # a side measurement never breaks the bench line
             res[tag] = {"error": str(e)[:200]}
         finally:
+            ctx.configure(reset=0)
             for k_, v_ in old.items():
                 if v_ is None:
                     os.environ.pop(k_, None)
@@ -427,9 +432,9 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
     run("configs[4] twin (/256): 128 MiB period-1024 tandem repeat of DNA, uint64", "tandem", 1 << 27, 64, 2, seed=3, recurrence_check=True)
     run("repeated reads with mutations: 1024 MiB (period 65536, one substitution in 200), uint64", "mutated", 1 << 30, 64, 2, seed=7, period=1 << 16,
         recurrence_check=True)
-    # the (B1,B2,idx) records of idxsort.hpp:58-62 through every digit of both words (PSACX_ONE_STAGE=1 switches the
+    # the (B1,B2,idx) records of idxsort.hpp:58-62 through every digit of both words (psacx_configure: PSACX_OPT_ONE_STAGE switches the
     # two-stage first round off): 6w = 48 bytes per record and pass, SURVEY 8(d)'s per-unit figure
-    run("three-word scatter form: 2048 MiB random DNA, uint64, one-stage first round", "dna", 1 << 31, 64, 2, {"PSACX_ONE_STAGE": "1"})
+    run("three-word scatter form: 2048 MiB random DNA, uint64, one-stage first round", "dna", 1 << 31, 64, 2, {"one_stage": 1})
     ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), 1 << 32, 0, KIND_ID[a.alphabet], a.seed, 1024))
     return res
 

@@ -101,6 +101,38 @@ const char* psacx_last_hip_error(const psacx_ctx* ctx);
 /* release the cached HBM workspace and the host-side staging of the host-pointer path: pinned ring, widening threads (all re-made on the next call that needs them) */
 int psacx_trim(psacx_ctx* ctx);
 
+/* Options of a context.  Every stage of the construction has one or more forms; the engine picks by text size, free
+ * HBM and what it finds in the text.  An option pins the choice of one stage -- for the parity suite, which runs every form, and for A/B
+ * timings.  None changes SA / ISA / LCP.  Values: 0 = the engine decides (default), 1 = on, or as listed.  An option stays set until it
+ * is set again; psacx_configure(ctx, PSACX_OPT_RESET, 0) restores all defaults.  (The reference has no counterpart: its forms are
+ * template parameters and #defines, e.g. suffix_array.hpp:170, :470.)
+ *   FORCE_DIET        reduced-memory layout although the normal one fits
+ *   DIET_CAP          at most this many records of room for the refinement rounds of the reduced layout (0 = what fits)
+ *   ONE_STAGE         first round as one sort over both key words
+ *   TIES_RADIX        ties of the two-stage first round through compaction + radix sort
+ *   NO_ONE_WORD       the prefix sort of the first round in (word 1, suffix) passes, not one-word records
+ *   ONE_WORD_ALWAYS   no repetition probe before the one-word prefix sort
+ *   ONE_WORD_MIN      log2 of the smallest text that takes the one-word form (0 = 24)
+ *   WIDEN_LAST        the last pass of the one-word prefix sort writes two arrays
+ *   NO_DIGIT_BYTES    tile histograms of the bucket passes from the records
+ *   NO_BUCKET_SORT    refinement rounds never sort inside LDS
+ *   ISA_UPDATE        1 = one store per record, 2 = partition levels
+ *   GATHER            ranks h further of a refinement round: 1 = one fetch per record, 2 = partition levels
+ *   NO_HEAVY          no split of a round's records into heavy and light ones
+ *   NO_WHOLE          no text-order rounds                                                                                           */
+enum {
+    PSACX_OPT_RESET = 0, PSACX_OPT_FORCE_DIET, PSACX_OPT_DIET_CAP, PSACX_OPT_ONE_STAGE, PSACX_OPT_TIES_RADIX, PSACX_OPT_NO_ONE_WORD,
+    PSACX_OPT_ONE_WORD_ALWAYS, PSACX_OPT_ONE_WORD_MIN, PSACX_OPT_WIDEN_LAST, PSACX_OPT_NO_DIGIT_BYTES, PSACX_OPT_NO_BUCKET_SORT,
+    PSACX_OPT_ISA_UPDATE, PSACX_OPT_GATHER, PSACX_OPT_NO_HEAVY, PSACX_OPT_NO_WHOLE, PSACX_OPT_COUNT
+};
+int psacx_configure(psacx_ctx* ctx, int option, uint64_t value);
+/* Debug shim, the ONLY place where the library looks at the environment, and only when called: resets the options of ctx and sets those
+ * named by PSACX_<OPTION> variables (PSACX_FORCE_DIET=1, PSACX_DIET_CAP=<records>, PSACX_ISA_UPDATE=stores|levels, PSACX_GATHER=fetch|levels, ...).
+ * The Python tests call it before every construction (psac_amd.ENV_KNOBS); products call psacx_configure. */
+int psacx_configure_from_env(psacx_ctx* ctx);
+/* value of environment variable `name` as the shim sees it (NULL if unset): shared with psacx_multi_configure_from_env */
+const char* psacx_debug_env(const char* name);
+
 /* construction ------------------------------------------------------------
  * Replace suffix_array<char,index_t,LCP>::construct(begin, end, fast_resolval, k)
  * (suffix_array.hpp:469-486 -> :365-466) for one rank holding the whole text.
@@ -352,10 +384,49 @@ int psacx_multi_get_stats(const psacx_multi* mg, psacx_stats* out, uint64_t* byt
  *   PSACX_MULTI_OPT_OUTPUT_SLACK  the d_SA / d_ISA / d_LCP arrays handed to psacx_multi_construct_dev_* hold this many
  *                                 elements MORE than the block (m / 8 + 256 lets every rank use them as record arrays
  *                                 despite the sample sort's imbalance; without slack a rank falls back to allocating)
- * Environment for tests: PSACX_MULTI_DIET=1, PSACX_MULTI_SLAB=<elements>. */
+ * Forms of single stages (tests, A/B runs, traces; none changes the result; 0 = the engine decides unless listed):
+ *   PSACX_MULTI_OPT_TRACE          1 = wall time of every phase on stderr (all local streams drained at each mark)
+ *   PSACX_MULTI_OPT_WIRE_PIECE     largest message in bytes (0 = 2^28; a single 2^31-byte ncclSend arrives damaged on this stack)
+ *   PSACX_MULTI_OPT_PIECES         ranges per destination of the first round's shuffle
+ *   PSACX_MULTI_OPT_CHECK_CHUNKS   chunks of the distributed checker
+ *   PSACX_MULTI_OPT_GLOBAL_REFINE_SORT  1 = refinement rounds sort all their records across the ranks
+ *   PSACX_MULTI_OPT_ONE_STAGE      1 = first round as one sort over both key words
+ *   PSACX_MULTI_OPT_TWO_WORD       first round in two-word records: 1 = never, 2 = also below 2^21 records per rank, 3 = additionally whatever the samples say
+ *   PSACX_MULTI_OPT_ONE_WORD       first round in one-word records dealt by top digit: 1 = never, 2 = also for small blocks
+ *   PSACX_MULTI_OPT_NO_SLICES      1 = SA -> ISA without destination slices
+ *   PSACX_MULTI_OPT_SLICE_WIDE     1 = slice inversion on full words although 32-bit entries would do
+ *   PSACX_MULTI_OPT_SLICE_SHAPE    window bits | slice bits << 8 | slices per step << 16 of the slice inversion (0 = by size)
+ * psacx_multi_configure_from_env: the debug shim of psacx_configure_from_env for these options (PSACX_MULTI_DIET, PSACX_MULTI_SLAB,
+ * PSACX_MULTI_TRACE, PSACX_MULTI_WIRE_PIECE, PSACX_MULTI_PIECES, PSACX_MULTI_CHECK_CHUNKS, PSACX_MULTI_GLOBAL_REFINE_SORT, PSACX_ONE_STAGE,
+ * PSACX_MULTI_TWO_WORD, PSACX_MULTI_ONE_WORD, PSACX_MULTI_NO_SLICES, PSACX_SLICE_WIDE, PSACX_SLICE_SHAPE=wb,s1,step); options set through
+ * psacx_multi_configure before it (layout, slab, slack) are kept unless a variable names them.  It also forwards to
+ * psacx_configure_from_env for the rank contexts. */
 #define PSACX_MULTI_OPT_LAYOUT 1
 #define PSACX_MULTI_OPT_SLAB 2
 #define PSACX_MULTI_OPT_OUTPUT_SLACK 3
+#define PSACX_MULTI_OPT_TRACE 4
+#define PSACX_MULTI_OPT_WIRE_PIECE 5
+#define PSACX_MULTI_OPT_PIECES 6
+#define PSACX_MULTI_OPT_CHECK_CHUNKS 7
+#define PSACX_MULTI_OPT_GLOBAL_REFINE_SORT 8
+#define PSACX_MULTI_OPT_ONE_STAGE 9
+#define PSACX_MULTI_OPT_TWO_WORD 10
+#define PSACX_MULTI_OPT_ONE_WORD 11
+#define PSACX_MULTI_OPT_NO_SLICES 12
+#define PSACX_MULTI_OPT_SLICE_WIDE 13
+#define PSACX_MULTI_OPT_SLICE_SHAPE 14
+int psacx_multi_configure_from_env(psacx_multi* mg);
+/* Creation with explicit transport choices (psacx_multi_create / psacx_multi_create_rank = flags 0, shm_box_bytes 0):
+ *   PSACX_MULTI_FORCE_WIRE  no shortcut for data a rank sends to itself or for scalars already on this host: every ncclSend / ncclRecv /
+ *                           ncclAllGather is really issued (a single rank then drives RCCL too)
+ *   PSACX_MULTI_NO_RCCL     peer copies between distinct devices of one process instead of a communicator
+ *   PSACX_MULTI_SHM         (create_rank) one process per rank on one host, exchanges staged through POSIX shared memory: ranks may share a device;
+ *                           shm_box_bytes = size of a rank's mailbox (0 = 32 MiB) */
+#define PSACX_MULTI_FORCE_WIRE 1u
+#define PSACX_MULTI_NO_RCCL 2u
+#define PSACX_MULTI_SHM 4u
+int psacx_multi_create_ex(psacx_multi** out, int ndev, const int* dev_ids, uint32_t flags);
+int psacx_multi_create_rank_ex(psacx_multi** out, int rank, int nranks, int device, const void* id128, uint32_t flags, uint64_t shm_box_bytes);
 int psacx_multi_configure(psacx_multi* mg, int option, uint64_t value);
 /* after a construction: peak_bytes[i] = high-water mark of the device memory local rank i's engine had in use at once
  * (every array it allocated; the caller's text and result arrays are not in it; free blocks the rank keeps cached for

@@ -16,8 +16,19 @@ PSACX_NO_FAST = 2
 PSACX_PROFILE = 4
 PSACX_MAX_ROUNDS = 72
 
+# psacx_configure options (include/psacx.h); Context.configure(force_diet=1, ...) takes them by name
+OPTIONS = {"reset": 0, "force_diet": 1, "diet_cap": 2, "one_stage": 3, "ties_radix": 4, "no_one_word": 5, "one_word_always": 6, "one_word_min": 7,
+           "widen_last": 8, "no_digit_bytes": 9, "no_bucket_sort": 10, "isa_update": 11, "gather": 12, "no_heavy": 13, "no_whole": 14}
+MULTI_OPTIONS = {"layout": 1, "slab": 2, "output_slack": 3, "trace": 4, "wire_piece": 5, "pieces": 6, "check_chunks": 7, "global_refine_sort": 8,
+                 "one_stage": 9, "two_word": 10, "one_word": 11, "no_slices": 12, "slice_wide": 13, "slice_shape": 14}
+MULTI_FORCE_WIRE, MULTI_NO_RCCL, MULTI_SHM = 1, 2, 4
+# The library never reads the environment.  With ENV_KNOBS set (the test suite and the tools/ scripts do: PSACX_ENV_KNOBS=1, tests/conftest.py)
+# the Python wrappers call the debug shims psacx_configure_from_env / psacx_multi_configure_from_env before every call that runs the engine,
+# so that PSACX_* variables select the forms of single stages, and read the transport variables when a multi-GPU context is made.
+ENV_KNOBS = bool(os.environ.get("PSACX_ENV_KNOBS"))
+
 EXPORTS = [
-    "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim",
+    "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim", "psacx_configure", "psacx_configure_from_env", "psacx_debug_env",
     "psacx_construct_u32", "psacx_construct_u64", "psacx_construct_dev_u32", "psacx_construct_dev_u64",
     "psacx_construct_gsa_u32", "psacx_construct_gsa_u64", "psacx_construct_gsa_dev_u32", "psacx_construct_gsa_dev_u64",
     "psacx_construct_lc_u32", "psacx_construct_lc_u64", "psacx_construct_lc_dev_u32", "psacx_construct_lc_dev_u64",
@@ -31,7 +42,7 @@ EXPORTS = [
     "psacx_multi_construct_gsa_dev_u32", "psacx_multi_construct_gsa_dev_u64", "psacx_multi_construct_gsa_u32", "psacx_multi_construct_gsa_u64",
     "psacx_multi_suffix_tree_dev_u32", "psacx_multi_suffix_tree_dev_u64", "psacx_multi_suffix_tree_u32", "psacx_multi_suffix_tree_u64",
     "psacx_multi_left_chars_dev_u32", "psacx_multi_left_chars_dev_u64", "psacx_multi_construct_lc_u32", "psacx_multi_construct_lc_u64",
-    "psacx_multi_configure", "psacx_multi_get_memory", "psacx_multi_transport", "psacx_multi_get_wire", "psacx_multi_get_phases", "psacx_multi_last_form",
+    "psacx_multi_configure", "psacx_multi_configure_from_env", "psacx_multi_create_ex", "psacx_multi_create_rank_ex", "psacx_multi_get_memory", "psacx_multi_transport", "psacx_multi_get_wire", "psacx_multi_get_phases", "psacx_multi_last_form",
 ]
 
 
@@ -85,6 +96,10 @@ def load():
     lib.psacx_last_hip_error.argtypes = [vp]
     lib.psacx_last_hip_error.restype = C.c_char_p
     lib.psacx_trim.argtypes = [vp]
+    lib.psacx_configure.argtypes = [vp, i32, u64]
+    lib.psacx_configure_from_env.argtypes = [vp]
+    lib.psacx_debug_env.argtypes = [C.c_char_p]
+    lib.psacx_debug_env.restype = C.c_char_p
     for suf in ("u32", "u64"):
         for name in ("psacx_construct_", "psacx_construct_dev_"):
             getattr(lib, name + suf).argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
@@ -135,6 +150,9 @@ def load():
         getattr(lib, "psacx_multi_ansv_dev_" + suf).argtypes = [vp, vp, vp, i32, i32, u64, vp, vp]
     lib.psacx_multi_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.psacx_multi_configure.argtypes = [vp, i32, u64]
+    lib.psacx_multi_configure_from_env.argtypes = [vp]
+    lib.psacx_multi_create_ex.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_int), u32]
+    lib.psacx_multi_create_rank_ex.argtypes = [C.POINTER(vp), i32, i32, i32, vp, u32, u64]
     lib.psacx_multi_get_memory.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(u32)]
     # step-level ops of the distributed path (include/psacx_ops.h)
     i64, u16p = C.c_int64, C.POINTER(C.c_uint16)

@@ -521,7 +521,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                   T* d_sa, T* d_isa, T* d_lcp, const T* d_slen = nullptr) {
     const bool gsa = d_slen != nullptr;
     const bool no_fast = (flags & PSACX_NO_FAST) != 0;
-    const Knobs kn = read_knobs();
+    const Knobs kn = c->knobs;
     psacx_stats& st = c->stats;
     PSACX_TRY(ensure_pinned(c, 2 * sizeof(unsigned long long) * MAX_PASSES * RADIX + 4096));
 

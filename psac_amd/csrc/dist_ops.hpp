@@ -293,7 +293,7 @@ int op_put_perm(psacx_ctx* c, T* block, const T* gidx, uint64_t cnt, uint64_t of
     const size_t ncur = (size_t)(cnt >> INV_WINDOW_BITS) + 2 + RADIX_P;
     PSACX_TRY(ensure_slab(c, ncur * sizeof(unsigned) + 8192));
     SortBufs<T> t1{s1, s2, nullptr}, t2{s3, s4, nullptr};
-    return invert_permutation<T>(c, reinterpret_cast<unsigned*>(c->slab), gidx, vals, cnt, block, t1, t2, read_knobs(), off);
+    return invert_permutation<T>(c, reinterpret_cast<unsigned*>(c->slab), gidx, vals, cnt, block, t1, t2, c->knobs, off);
 }
 
 template <typename T>

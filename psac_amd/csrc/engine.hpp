@@ -31,6 +31,33 @@ enum TimerCat {
 
 namespace psacx { struct HostPool; }
 
+namespace psacx {
+// Switches of a construction (psacx_configure, include/psacx.h): each selects the fallback form of one stage, which the parity suite keeps
+// covered; none changes the result.  The library never reads the environment: tests and A/B runs go through psacx_configure, or through
+// the debug shim psacx_configure_from_env that maps PSACX_* variables to these options.
+struct Knobs {
+    bool force_diet = false;      // PSACX_OPT_FORCE_DIET: reduced-memory layout although the normal one fits
+    uint64_t diet_cap = 0;        // PSACX_OPT_DIET_CAP: at most this many records of room for the refinement rounds (0 = no limit)
+    bool one_stage = false;       // PSACX_OPT_ONE_STAGE: first round as one sort over both key words
+    bool ties_radix = false;      // PSACX_OPT_TIES_RADIX: stage 2 of the first round through compaction + radix sort
+    bool no_one_word = false;     // PSACX_OPT_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
+    bool one_word_always = false; // PSACX_OPT_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
+    unsigned one_word_min = 24;   // PSACX_OPT_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
+    int isa_update = 0;           // PSACX_OPT_ISA_UPDATE: 1 = stores, 2 = levels: how large refinement rounds update ISA -- one random store per record, or pairs through
+                                  // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
+                                  // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11), and for rounds of long buckets
+    bool no_digit_bytes = false;  // PSACX_OPT_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
+    bool no_bucket_sort = false;  // PSACX_OPT_NO_BUCKET_SORT: the refinement rounds always take the global radix sort (A/B runs; bucket_sort.hpp)
+    int gather = 0;               // PSACX_OPT_GATHER: 1 = fetch, 2 = levels: how a refinement round gets the ranks h further -- one random fetch per record, or requests through
+                                  // partition levels (construct.hpp: gather_by_levels); default (0): levels for rounds of at least n / 8 records in long buckets
+    bool no_heavy = false;        // PSACX_OPT_NO_HEAVY: no split of a round's records into heavy and light ones (heavy_keys.hpp; A/B runs)
+    bool no_whole = false;        // PSACX_OPT_NO_WHOLE: rounds in which nearly every suffix is unresolved take the list of positions too (A/B runs)
+    bool widen_last = false;      // PSACX_OPT_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
+                                  // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
+};
+
+} // namespace psacx
+
 struct psacx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -72,6 +99,7 @@ struct psacx_ctx {
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     int n_cu = 256;
+    psacx::Knobs knobs;              // psacx_configure
 };
 
 namespace psacx {
@@ -133,52 +161,6 @@ inline void prof_collect(psacx_ctx* c) {
     s.ms_sort_scatter2 = acc[TC_SORT_SCATTER2];
     s.ms_isa_scatter = acc[TC_ISA_SCATTER]; s.ms_gather = acc[TC_GATHER]; s.ms_compact = acc[TC_COMPACT];
     s.ms_rmq_build = acc[TC_RMQ_BUILD]; s.ms_finalize = acc[TC_FINALIZE]; s.ms_total = acc[TC_TOTAL];
-}
-
-// Test switches of a construction, read from the environment in ONE place at the start of every call (the tests flip them
-// between calls of one process, so they are not cached).  Each selects the fallback form of a stage that the parity suite keeps
-// covered; none changes the result.
-struct Knobs {
-    bool force_diet;        // PSACX_FORCE_DIET: reduced-memory layout although the normal one fits
-    uint64_t diet_cap;      // PSACX_DIET_CAP: at most this many records of room for the refinement rounds (0 = no limit)
-    bool one_stage;         // PSACX_ONE_STAGE: first round as one sort over both key words
-    bool ties_radix;        // PSACX_TIES_RADIX: stage 2 of the first round through compaction + radix sort
-    bool no_one_word;       // PSACX_NO_ONE_WORD: the prefix sort of the first round in (word 1, 32-bit suffix) passes, not one-word records
-    bool one_word_always;   // PSACX_ONE_WORD_ALWAYS: no repetition probe before the one-word prefix sort (tests of its tie paths)
-    unsigned one_word_min;  // PSACX_ONE_WORD_MIN: log2 of the smallest text that takes the one-word form (default 24; tests: 21)
-    int isa_update;         // PSACX_ISA_UPDATE=stores | levels: how large refinement rounds update ISA -- one random store per record, or pairs through
-                            // partition levels (construct.hpp: IsaLevels); default (0): levels from 2^31 characters on, where the random stores
-                            // into 16 GiB and more cost three times as much per record (2^30: 16 against 18 ps, 2^32: 32 against 11)
-    bool no_digit_bytes;    // PSACX_NO_DIGIT_BYTES: the tile histograms of the bucket passes read the records, not the digit bytes the pass before left (A/B runs)
-    bool no_bucket_sort;    // PSACX_NO_BUCKET_SORT: the refinement rounds always take the global radix sort (A/B runs; bucket_sort.hpp)
-    int gather;             // PSACX_GATHER=fetch | levels: how a refinement round gets the ranks h further -- one random fetch per record, or requests through
-                            // partition levels (construct.hpp: gather_by_levels); default (0): levels for rounds of at least n / 8 records
-    bool no_heavy;          // PSACX_NO_HEAVY: no split of a round's records into heavy and light ones (heavy_keys.hpp; A/B runs)
-    bool no_whole;          // PSACX_NO_WHOLE: rounds in which nearly every suffix is unresolved take the list of positions too (A/B runs)
-    bool widen_last;        // PSACX_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
-                            // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records
-};
-inline Knobs read_knobs() {
-    Knobs k;
-    k.force_diet = getenv("PSACX_FORCE_DIET") != nullptr;
-    const char* e = getenv("PSACX_DIET_CAP");
-    k.diet_cap = e ? strtoull(e, nullptr, 10) : 0;
-    k.one_stage = getenv("PSACX_ONE_STAGE") != nullptr;
-    k.ties_radix = getenv("PSACX_TIES_RADIX") != nullptr;
-    k.no_one_word = getenv("PSACX_NO_ONE_WORD") != nullptr;
-    k.one_word_always = getenv("PSACX_ONE_WORD_ALWAYS") != nullptr;
-    e = getenv("PSACX_ONE_WORD_MIN");
-    k.one_word_min = e ? (unsigned)std::max(16, atoi(e)) : 24u;
-    k.widen_last = getenv("PSACX_WIDEN_LAST") != nullptr;
-    k.no_bucket_sort = getenv("PSACX_NO_BUCKET_SORT") != nullptr;
-    k.no_digit_bytes = getenv("PSACX_NO_DIGIT_BYTES") != nullptr;
-    e = getenv("PSACX_ISA_UPDATE");
-    k.isa_update = !e ? 0 : (e[0] == 's' ? 1 : 2);
-    e = getenv("PSACX_GATHER");
-    k.gather = !e ? 0 : (e[0] == 'f' ? 1 : 2);
-    k.no_whole = getenv("PSACX_NO_WHOLE") != nullptr;
-    k.no_heavy = getenv("PSACX_NO_HEAVY") != nullptr;
-    return k;
 }
 
 // bump allocator over the ctx slab; a first pass with base == nullptr sizes it

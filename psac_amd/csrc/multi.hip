@@ -7,9 +7,6 @@
 using namespace psacx;
 
 namespace {
-// PSACX_MULTI_FORCE_WIRE: no shortcut for data a rank sends to itself or for scalars already on this host (psacx_multi: force_wire)
-bool force_wire_env() { return getenv("PSACX_MULTI_FORCE_WIRE") != nullptr; }
-
 int make_rank(psacx_multi* g, int i, int grank, int device) {
     MRank& R = g->R[i];
     R.grank = grank;
@@ -181,8 +178,10 @@ int suffix_tree_host(psacx_multi* g, const uint8_t* text, uint64_t n, const T* s
 
 extern "C" {
 
-int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) {
-    if (!out || ndev < 1 || ndev > 64) return PSACX_EINVAL;
+int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) { return psacx_multi_create_ex(out, ndev, dev_ids, 0u); }
+
+int psacx_multi_create_ex(psacx_multi** out, int ndev, const int* dev_ids, uint32_t flags) {
+    if (!out || ndev < 1 || ndev > 64 || (flags & ~(PSACX_MULTI_FORCE_WIRE | PSACX_MULTI_NO_RCCL))) return PSACX_EINVAL;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return PSACX_ENOGPU; }
     std::vector<int> devs(ndev);
@@ -200,10 +199,10 @@ int psacx_multi_create(psacx_multi** out, int ndev, const int* dev_ids) {
         if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
     }
     // one RCCL communicator over the devices; ranks that share a device (and a single rank) exchange by copies.
-    // A communicator that cannot be built is an error, not a silent change of transport (PSACX_MULTI_NO_RCCL=1 asks
+    // A communicator that cannot be built is an error, not a silent change of transport (the flag PSACX_MULTI_NO_RCCL asks
     // for peer copies between distinct devices explicitly).
-    g->force_wire = force_wire_env();
-    g->use_rccl = distinct && (ndev > 1 || g->force_wire) && !getenv("PSACX_MULTI_NO_RCCL");
+    g->force_wire = (flags & PSACX_MULTI_FORCE_WIRE) != 0;
+    g->use_rccl = distinct && (ndev > 1 || g->force_wire) && !(flags & PSACX_MULTI_NO_RCCL);
     if (g->use_rccl) {
         std::string err;
         std::vector<ncclComm_t> comms(ndev);
@@ -232,7 +231,11 @@ int psacx_multi_unique_id(void* id128) {
 }
 
 int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device, const void* id128) {
-    if (!out || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || device < 0) return PSACX_EINVAL;
+    return psacx_multi_create_rank_ex(out, rank, nranks, device, id128, 0u, 0);
+}
+
+int psacx_multi_create_rank_ex(psacx_multi** out, int rank, int nranks, int device, const void* id128, uint32_t flags, uint64_t shm_box_bytes) {
+    if (!out || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || device < 0 || (flags & ~(PSACX_MULTI_FORCE_WIRE | PSACX_MULTI_SHM))) return PSACX_EINVAL;
     if (nranks > 1 && !id128) return PSACX_EINVAL;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return PSACX_ENOGPU; }
@@ -242,12 +245,11 @@ int psacx_multi_create_rank(psacx_multi** out, int rank, int nranks, int device,
     g->R.resize(1);
     int rc = make_rank(g, 0, rank, device);
     if (rc != PSACX_OK) { psacx_multi_destroy(g); return rc; }
-    g->force_wire = force_wire_env();
-    const char* tr = getenv("PSACX_MULTI_TRANSPORT");
-    if (id128 && tr && std::string(tr) == "shm") {
+    g->force_wire = (flags & PSACX_MULTI_FORCE_WIRE) != 0;
+    if (id128 && (flags & PSACX_MULTI_SHM)) {
         // one process per rank on one host, exchanges staged through shared memory (shm_link.hpp): ranks may share a device
         std::string err;
-        if (!g->shm.open(rank, nranks, id128, err)) { g->err = err; psacx_multi_destroy(g); return PSACX_MULTI_EPEER; }
+        if (!g->shm.open(rank, nranks, id128, err, (size_t)shm_box_bytes)) { g->err = err; psacx_multi_destroy(g); return PSACX_MULTI_EPEER; }
         g->transport = PSACX_TR_SHM;
     } else if (id128) {
         std::string err;
@@ -326,8 +328,41 @@ int psacx_multi_configure(psacx_multi* g, int option, uint64_t value) {
     case PSACX_MULTI_OPT_LAYOUT: if (value > 2) return PSACX_EINVAL; g->opt_layout = (int)value; return PSACX_OK;
     case PSACX_MULTI_OPT_SLAB: g->opt_slab = value; return PSACX_OK;
     case PSACX_MULTI_OPT_OUTPUT_SLACK: g->out_slack = value; return PSACX_OK;
+    case PSACX_MULTI_OPT_TRACE: g->opt_trace = value != 0; return PSACX_OK;
+    case PSACX_MULTI_OPT_WIRE_PIECE: g->opt_wire_piece = value; return PSACX_OK;
+    case PSACX_MULTI_OPT_PIECES: if (value > 64) return PSACX_EINVAL; g->opt_pieces = (int)value; return PSACX_OK;
+    case PSACX_MULTI_OPT_CHECK_CHUNKS: g->opt_check_chunks = value; return PSACX_OK;
+    case PSACX_MULTI_OPT_GLOBAL_REFINE_SORT: g->opt_global_refine_sort = value != 0; return PSACX_OK;
+    case PSACX_MULTI_OPT_ONE_STAGE: g->opt_one_stage = value != 0; return PSACX_OK;
+    case PSACX_MULTI_OPT_TWO_WORD: if (value > 3) return PSACX_EINVAL; g->opt_two_word = (int)value; return PSACX_OK;
+    case PSACX_MULTI_OPT_ONE_WORD: if (value > 2) return PSACX_EINVAL; g->opt_one_word = (int)value; return PSACX_OK;
+    case PSACX_MULTI_OPT_NO_SLICES: g->opt_no_slices = value != 0; return PSACX_OK;
+    case PSACX_MULTI_OPT_SLICE_WIDE: g->opt_slice_wide = value != 0; return PSACX_OK;
+    case PSACX_MULTI_OPT_SLICE_SHAPE: g->opt_slice_wb = (unsigned)(value & 0xFF); g->opt_slice_s1 = (unsigned)((value >> 8) & 0xFF); g->opt_slice_step = value >> 16; return PSACX_OK;
     default: return PSACX_EINVAL;
     }
+}
+
+int psacx_multi_configure_from_env(psacx_multi* g) {
+    if (!g) return PSACX_EINVAL;
+    auto num = [](const char* name, uint64_t* v) { const char* e = psacx_debug_env(name); if (!e) return false; *v = strtoull(e, nullptr, 10); return true; };
+    uint64_t v = 0;
+    g->opt_trace = psacx_debug_env("PSACX_MULTI_TRACE") != nullptr;
+    g->opt_wire_piece = num("PSACX_MULTI_WIRE_PIECE", &v) ? v : 0;
+    g->opt_pieces = num("PSACX_MULTI_PIECES", &v) ? (int)std::min<uint64_t>(v, 64) : 0;
+    g->opt_check_chunks = num("PSACX_MULTI_CHECK_CHUNKS", &v) ? v : 0;
+    g->opt_global_refine_sort = psacx_debug_env("PSACX_MULTI_GLOBAL_REFINE_SORT") != nullptr;
+    g->opt_one_stage = psacx_debug_env("PSACX_ONE_STAGE") != nullptr;
+    g->opt_two_word = num("PSACX_MULTI_TWO_WORD", &v) ? (int)std::min<uint64_t>(v, 2) + 1 : 0;
+    g->opt_one_word = num("PSACX_MULTI_ONE_WORD", &v) ? (int)std::min<uint64_t>(v, 1) + 1 : 0;
+    g->opt_no_slices = psacx_debug_env("PSACX_MULTI_NO_SLICES") != nullptr;
+    g->opt_slice_wide = psacx_debug_env("PSACX_SLICE_WIDE") != nullptr;
+    g->opt_slice_wb = g->opt_slice_s1 = 0; g->opt_slice_step = 0;
+    if (const char* e = psacx_debug_env("PSACX_SLICE_SHAPE")) { unsigned a = 0, b = 0; unsigned long long st = 0; if (sscanf(e, "%u,%u,%llu", &a, &b, &st) >= 1) { g->opt_slice_wb = a; g->opt_slice_s1 = b; g->opt_slice_step = st; } }
+    if (num("PSACX_MULTI_DIET", &v) && v) g->opt_layout = 2;
+    if (num("PSACX_MULTI_SLAB", &v)) g->opt_slab = v;
+    for (auto& R : g->R) if (R.ctx) (void)psacx_configure_from_env(R.ctx);
+    return PSACX_OK;
 }
 
 int psacx_multi_get_memory(const psacx_multi* g, uint64_t* peak_bytes, int* reduced, uint32_t* slab_rounds) {

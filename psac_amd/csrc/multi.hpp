@@ -161,6 +161,11 @@ struct psacx_multi {
     int opt_layout = 0;               // 0: choose by free device memory, 1: normal, 2: reduced-memory
     uint64_t opt_slab = 0;            // unresolved suffixes per refinement slab of the reduced-memory layout (0: block / 16)
     uint64_t out_slack = 0;           // the output arrays given to construct_dev hold this many elements beyond the block
+    bool opt_trace = false;           // PSACX_MULTI_OPT_*: forms of single stages (tests, A/B runs); see include/psacx.h
+    uint64_t opt_wire_piece = 0, opt_check_chunks = 0, opt_slice_step = 0;
+    int opt_pieces = 0, opt_two_word = 0, opt_one_word = 0;
+    bool opt_global_refine_sort = false, opt_one_stage = false, opt_no_slices = false, opt_slice_wide = false;
+    unsigned opt_slice_wb = 0, opt_slice_s1 = 0;
     bool last_reduced = false;        // layout the last construction ran in
     bool last_two_word = false;       // the first round ran in two-word form (sort_first_two_word)
     bool last_one_word = false;       // the first round ran in one-word records dealt by top digit (sort_first_one_word)
@@ -359,19 +364,19 @@ struct MultiRun {
         return PSACX_OK;
     }
 
-    explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(getenv("PSACX_MULTI_TRACE") != nullptr) {
-        if (const char* e = getenv("PSACX_MULTI_WIRE_PIECE")) wire_piece_ = std::max<size_t>(256, strtoull(e, nullptr, 10));
-        if (const char* e = getenv("PSACX_MULTI_PIECES")) pieces_env_ = std::max(1, atoi(e));      // ranges per destination of the first round's shuffle (tests)
-        global_refine_sort_env_ = getenv("PSACX_MULTI_GLOBAL_REFINE_SORT") != nullptr;               // refinement rounds sort all their records across the ranks (tests, A/B runs)
-        one_stage_env_ = getenv("PSACX_ONE_STAGE") != nullptr;                                      // first round as one sort over both key words
-        if (const char* e = getenv("PSACX_MULTI_SLAB")) slab_env_ = strtoull(e, nullptr, 10);       // unresolved suffixes per refinement slab (reduced-memory layout)
-        if (const char* e = getenv("PSACX_MULTI_CHECK_CHUNKS")) check_chunks_env_ = strtoull(e, nullptr, 10);
-        // PSACX_SLICE_SHAPE=wb,s1,step (tests: the levels of the slice inversion on small inputs): window bits, slice bits, slices per step; 0 = default
-        if (const char* e = getenv("PSACX_SLICE_SHAPE")) { unsigned a = 0, b = 0; unsigned long long st = 0; if (sscanf(e, "%u,%u,%llu", &a, &b, &st) >= 1) { slice_wb_env_ = a; slice_s1_env_ = b; slice_step_env_ = st; } }
+    explicit MultiRun(psacx_multi* mg) : g(mg), P(mg->nranks), L(mg->nlocal), trace_(mg->opt_trace) {
+        // (the forms of single stages: psacx_multi_configure)
+        if (mg->opt_wire_piece) wire_piece_ = std::max<size_t>(256, (size_t)mg->opt_wire_piece);
+        pieces_env_ = std::max(0, mg->opt_pieces);                    // ranges per destination of the first round's shuffle (tests)
+        global_refine_sort_env_ = mg->opt_global_refine_sort;         // refinement rounds sort all their records across the ranks (tests, A/B runs)
+        one_stage_env_ = mg->opt_one_stage;                           // first round as one sort over both key words
+        slab_env_ = 0;
+        check_chunks_env_ = mg->opt_check_chunks;
+        slice_wb_env_ = mg->opt_slice_wb; slice_s1_env_ = mg->opt_slice_s1; slice_step_env_ = mg->opt_slice_step;      // (tests: the levels of the slice inversion on small inputs)
         solo_ = P == 1 && !mg->force_wire;
         t_last_ = t_phase_ = std::chrono::steady_clock::now();
     }
-    // PSACX_MULTI_TRACE=1: wall time of every phase on stderr (all local streams drained at each mark)
+    // PSACX_MULTI_OPT_TRACE: wall time of every phase on stderr (all local streams drained at each mark)
     bool trace_;
     std::chrono::steady_clock::time_point t_last_, t_phase_;
     // every phase leaves its host wall time in g->phases (accumulated by name: the refinement rounds repeat theirs)
@@ -1424,7 +1429,7 @@ struct MultiRun {
         return PSACX_OK;
     }
     int isa_by_slices(bool ids_in_isa = false) {
-        if (sizeof(T) == 4 || (n <= (1ull << 32) && !getenv("PSACX_SLICE_WIDE"))) return isa_by_slices_t<uint32_t>(ids_in_isa);      // (PSACX_SLICE_WIDE: tests)
+        if (sizeof(T) == 4 || (n <= (1ull << 32) && !g->opt_slice_wide)) return isa_by_slices_t<uint32_t>(ids_in_isa);      // (PSACX_SLICE_WIDE: tests)
         return isa_by_slices_t<T>(ids_in_isa);
     }
 
@@ -1692,7 +1697,6 @@ struct MultiRun {
             std::vector<std::vector<uint64_t>> mine(L, std::vector<uint64_t>(258, 0));
             // the normal layout holds up to ~14 words per character beside the outputs; a rank whose share of the free
             // device memory is smaller asks for the reduced-memory layout, and then every rank uses it
-            const char* env_diet = getenv("PSACX_MULTI_DIET");
             for (int i = 0; i < L; ++i) {
                 int same = 0;
                 for (int j = 0; j < L; ++j) same += ctx(j)->device == ctx(i)->device;
@@ -1701,7 +1705,7 @@ struct MultiRun {
                 MG_HIP(g, hipMemGetInfo(&fr, &tot));
                 const double avail = ((double)fr + (double)ctx(i)->pool_bytes * same) / same;
                 const bool tight = 14.0 * (double)S[i].m * sizeof(T) > 0.9 * avail;
-                mine[i][257] = g->opt_layout == 2 || (g->opt_layout == 0 && ((env_diet && atoi(env_diet)) || tight)) ? 1 : 0;
+                mine[i][257] = g->opt_layout == 2 || (g->opt_layout == 0 && tight) ? 1 : 0;
             }
             PSACX_TRY(par([&](int i) -> int {
                 psacx_ctx* c = ctx(i);
@@ -1907,16 +1911,14 @@ struct MultiRun {
         // (tests: repetitive texts through the tie machinery).
         const unsigned bits_w1 = c1 * lc, bits_w2 = c2 * lc;
         const unsigned lead = (bits_for(n - 1) + 3 + RADIX_BITS - 1) / RADIX_BITS * RADIX_BITS;
-        const char* env_tw = getenv("PSACX_MULTI_TWO_WORD");
-        const int tw_mode = env_tw ? atoi(env_tw) : -1;
+        const int tw_mode = g->opt_two_word - 1;          // (-1: the engine decides)
         bool two_word = !gsa && tw_mode != 0 && lead <= bits_w1 && lead + RADIX_BITS <= bits_w1 + bits_w2 && (tw_mode >= 1 || min_local >= (1ull << 21)) &&
                         !one_stage_env_;
         // One-word records dealt by the top digit of the prefix (sort_first_one_word): 64-bit words, blocks of at least 2^21 characters
         // (PSACX_MULTI_ONE_WORD: 0 = never, 1 = also for small blocks: tests)
         CodeTable tab; for (int ch = 0; ch < 256; ++ch) tab.c[ch] = codes_[ch];
         KeyShape ks; ks.lc = lc; ks.c1 = c1; ks.c2 = c2; ks.spec = 0;
-        const char* env_ow = getenv("PSACX_MULTI_ONE_WORD");
-        const int ow_mode = env_ow ? atoi(env_ow) : -1;
+        const int ow_mode = g->opt_one_word - 1;
         bool one_word = two_word && sizeof(T) == 8 && ow_mode != 0 && !tiny_blocks && (ow_mode >= 1 || min_local >= (1ull << 21));
         unsigned lo1_first = bits_w1 - lead;
         g->last_one_word = false;
@@ -1959,7 +1961,7 @@ struct MultiRun {
         PSACX_TRY(gather1(lh, heads));
         std::vector<uint64_t> nact(L), nunf(L);
         std::vector<DBuf<uint64_t>> tile_act(L);      // per-tile counts of unresolved positions out of the rebucket kernel
-        const bool slices = !getenv("PSACX_MULTI_NO_SLICES") && sizes[0] <= (1ull << 32);      // SA -> ISA by destination slices (below)
+        const bool slices = !g->opt_no_slices && sizes[0] <= (1ull << 32);      // SA -> ISA by destination slices (below)
         PSACX_TRY(par([&](int i) -> int {
             psacx_ctx* c = ctx(i);
             uint64_t base = 0;

@@ -91,6 +91,47 @@ const char* psacx_strerror(int code) {
 
 const char* psacx_last_hip_error(const psacx_ctx* c) { return c ? c->hip_err.c_str() : ""; }
 
+int psacx_configure(psacx_ctx* c, int option, uint64_t value) {
+    if (!c) return PSACX_EINVAL;
+    psacx::Knobs& k = c->knobs;
+    switch (option) {
+    case PSACX_OPT_RESET: k = psacx::Knobs(); return PSACX_OK;
+    case PSACX_OPT_FORCE_DIET: k.force_diet = value != 0; return PSACX_OK;
+    case PSACX_OPT_DIET_CAP: k.diet_cap = value; return PSACX_OK;
+    case PSACX_OPT_ONE_STAGE: k.one_stage = value != 0; return PSACX_OK;
+    case PSACX_OPT_TIES_RADIX: k.ties_radix = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_ONE_WORD: k.no_one_word = value != 0; return PSACX_OK;
+    case PSACX_OPT_ONE_WORD_ALWAYS: k.one_word_always = value != 0; return PSACX_OK;
+    case PSACX_OPT_ONE_WORD_MIN: if (value > 62) return PSACX_EINVAL; k.one_word_min = value ? (unsigned)std::max<uint64_t>(16, value) : 24u; return PSACX_OK;
+    case PSACX_OPT_WIDEN_LAST: k.widen_last = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_DIGIT_BYTES: k.no_digit_bytes = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_BUCKET_SORT: k.no_bucket_sort = value != 0; return PSACX_OK;
+    case PSACX_OPT_ISA_UPDATE: if (value > 2) return PSACX_EINVAL; k.isa_update = (int)value; return PSACX_OK;
+    case PSACX_OPT_GATHER: if (value > 2) return PSACX_EINVAL; k.gather = (int)value; return PSACX_OK;
+    case PSACX_OPT_NO_HEAVY: k.no_heavy = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_WHOLE: k.no_whole = value != 0; return PSACX_OK;
+    default: return PSACX_EINVAL;
+    }
+}
+
+const char* psacx_debug_env(const char* name) { return name ? getenv(name) : nullptr; }
+
+int psacx_configure_from_env(psacx_ctx* c) {
+    if (!c) return PSACX_EINVAL;
+    static const struct { const char* name; int option; } flags[] = {
+        {"PSACX_FORCE_DIET", PSACX_OPT_FORCE_DIET}, {"PSACX_ONE_STAGE", PSACX_OPT_ONE_STAGE}, {"PSACX_TIES_RADIX", PSACX_OPT_TIES_RADIX},
+        {"PSACX_NO_ONE_WORD", PSACX_OPT_NO_ONE_WORD}, {"PSACX_ONE_WORD_ALWAYS", PSACX_OPT_ONE_WORD_ALWAYS}, {"PSACX_WIDEN_LAST", PSACX_OPT_WIDEN_LAST},
+        {"PSACX_NO_DIGIT_BYTES", PSACX_OPT_NO_DIGIT_BYTES}, {"PSACX_NO_BUCKET_SORT", PSACX_OPT_NO_BUCKET_SORT}, {"PSACX_NO_HEAVY", PSACX_OPT_NO_HEAVY},
+        {"PSACX_NO_WHOLE", PSACX_OPT_NO_WHOLE}};
+    (void)psacx_configure(c, PSACX_OPT_RESET, 0);
+    for (const auto& f : flags) if (psacx_debug_env(f.name)) (void)psacx_configure(c, f.option, 1);
+    if (const char* e = psacx_debug_env("PSACX_DIET_CAP")) (void)psacx_configure(c, PSACX_OPT_DIET_CAP, strtoull(e, nullptr, 10));
+    if (const char* e = psacx_debug_env("PSACX_ONE_WORD_MIN")) (void)psacx_configure(c, PSACX_OPT_ONE_WORD_MIN, strtoull(e, nullptr, 10));
+    if (const char* e = psacx_debug_env("PSACX_ISA_UPDATE")) (void)psacx_configure(c, PSACX_OPT_ISA_UPDATE, e[0] == 's' ? 1 : 2);
+    if (const char* e = psacx_debug_env("PSACX_GATHER")) (void)psacx_configure(c, PSACX_OPT_GATHER, e[0] == 'f' ? 1 : 2);
+    return PSACX_OK;
+}
+
 int psacx_trim(psacx_ctx* c) {
     if (!c) return PSACX_EINVAL;
     PSACX_HIP(c, hipSetDevice(c->device));

@@ -58,12 +58,11 @@ struct ShmLink {
     // id128 must be unique per communicator (an RCCL unique id is).  A segment of the same name that a crashed run left behind, or that
     // rank 0 has not yet replaced, is recognised and dropped: a rank that is not rank 0 only stays on a segment whose name still leads to
     // the inode it mapped, waits there until all P ranks have attached, and refuses one that P ranks hold already.
-    bool open(int rank_, int nranks, const void* id128, std::string& err) {
+    bool open(int rank_, int nranks, const void* id128, std::string& err, size_t box = 0) {
         rank = rank_; P = nranks; name = name_of(id128);
         opened = false;
-        const char* e = getenv("PSACX_SHM_BOX");
         slot_bytes = (size_t)1 << 20;
-        box_bytes = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32 << 20;
+        box_bytes = box ? box : (size_t)32 << 20;          // (psacx_multi_create_rank_ex: shm_box_bytes)
         box_bytes = (box_bytes + 4095) & ~(size_t)4095;
         if (box_bytes < 4096) box_bytes = 4096;
         bytes = 4096 + (size_t)P * (slot_bytes + box_bytes);

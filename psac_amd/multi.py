@@ -23,8 +23,23 @@ def unique_id():
     return bytes(buf)
 
 
+def _env_create_flags(lib):
+    """(flags, shm_box_bytes) of a new context from the PSACX_MULTI_* transport variables -- only with _lib.ENV_KNOBS (tests, tools)."""
+    flags, box = 0, 0
+    if _lib.ENV_KNOBS:
+        env = lambda name: lib.psacx_debug_env(name.encode())
+        if env("PSACX_MULTI_FORCE_WIRE"):
+            flags |= _lib.MULTI_FORCE_WIRE
+        if env("PSACX_MULTI_NO_RCCL"):
+            flags |= _lib.MULTI_NO_RCCL
+        if (env("PSACX_MULTI_TRANSPORT") or b"") == b"shm":
+            flags |= _lib.MULTI_SHM
+        box = int(env("PSACX_SHM_BOX") or 0)
+    return flags, box
+
+
 class MultiContext(object):
-    def __init__(self, dev_ids=None, ndev=None, _handle=None):
+    def __init__(self, dev_ids=None, ndev=None, _handle=None, force_wire=False, no_rccl=False):
         self._lib = _lib.load()
         if _handle is not None:
             self.handle = _handle
@@ -33,7 +48,8 @@ class MultiContext(object):
                 dev_ids = list(range(int(ndev)))
             arr = (C.c_int * len(dev_ids))(*[int(d) for d in dev_ids])
             h = C.c_void_p()
-            rc = self._lib.psacx_multi_create(C.byref(h), len(dev_ids), arr)
+            flags = (_lib.MULTI_FORCE_WIRE if force_wire else 0) | (_lib.MULTI_NO_RCCL if no_rccl else 0) | (_env_create_flags(self._lib)[0] & ~_lib.MULTI_SHM)
+            rc = self._lib.psacx_multi_create_ex(C.byref(h), len(dev_ids), arr, flags)
             if rc != 0:
                 raise PsacxError(rc, self._lib.psacx_strerror(rc).decode())
             self.handle = h
@@ -43,11 +59,13 @@ class MultiContext(object):
         self.transport = ("copy", "rccl", "shm")[self._lib.psacx_multi_transport(self.handle)]
 
     @classmethod
-    def for_rank(cls, rank, nranks, device, uid):
+    def for_rank(cls, rank, nranks, device, uid, force_wire=False, shm=False, shm_box_bytes=0):
         lib = _lib.load()
         h = C.c_void_p()
         buf = (C.c_uint8 * 128)(*bytearray(uid)) if uid is not None else None
-        rc = lib.psacx_multi_create_rank(C.byref(h), int(rank), int(nranks), int(device), buf)
+        eflags, ebox = _env_create_flags(lib)
+        flags = (_lib.MULTI_FORCE_WIRE if force_wire else 0) | (_lib.MULTI_SHM if shm else 0) | (eflags & ~_lib.MULTI_NO_RCCL)
+        rc = lib.psacx_multi_create_rank_ex(C.byref(h), int(rank), int(nranks), int(device), buf, flags, int(shm_box_bytes or ebox))
         if rc != 0:
             raise PsacxError(rc, "psacx_multi_create_rank: %s" % lib.psacx_strerror(rc).decode())
         return cls(_handle=h)
@@ -95,11 +113,17 @@ class MultiContext(object):
 
     LAYOUT_AUTO, LAYOUT_NORMAL, LAYOUT_REDUCED = 0, 1, 2
 
-    def configure(self, layout=None, slab=None, output_slack=None):
-        """psacx_multi_configure: memory layout of the distributed construction (include/psacx.h)."""
-        for opt, val in ((1, layout), (2, slab), (3, output_slack)):
+    def configure(self, **options):
+        """psacx_multi_configure: memory layout of the distributed construction (layout, slab, output_slack) and the forms of single
+        stages (trace, wire_piece, pieces, two_word, ...; include/psacx.h)."""
+        for name, val in options.items():
             if val is not None:
-                self.check(self._lib.psacx_multi_configure(self.handle, opt, int(val)))
+                self.check(self._lib.psacx_multi_configure(self.handle, _lib.MULTI_OPTIONS[name], int(val)))
+
+    def _pre(self):
+        """Before every call that runs the engine: with _lib.ENV_KNOBS the options come from PSACX_* variables (debug shim)."""
+        if _lib.ENV_KNOBS:
+            self.check(self._lib.psacx_multi_configure_from_env(self.handle))
 
     def memory(self):
         """(peak bytes of every local rank's block cache, reduced-memory layout used?, refinement rounds run in slabs)
@@ -112,6 +136,7 @@ class MultiContext(object):
     def construct(self, text, index_bits=64, lcp=True, k=0):
         """suffix_array<char, index_t, LCP>::construct on p ranks, the whole text and results on this host
         (needs every rank in this process).  Returns (SA, ISA, LCP or None, rounds)."""
+        self._pre()
         if isinstance(text, str):
             text = text.encode("latin-1")
         t = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
@@ -129,6 +154,7 @@ class MultiContext(object):
         """suffix_array::construct_ss (suffix_array.hpp:267-363) on p ranks: the generalized suffix array of a string set
         (a list of byte strings, or one flat buffer cut at runs of `sep`), the strings back to back in the
         block-distributed text.  Returns (SA, ISA, LCP or None, rounds, string offsets)."""
+        self._pre()
         from .suffix_array import parse_stringset
         t, off = parse_stringset(strings, sep)
         n = int(t.size)
@@ -144,6 +170,7 @@ class MultiContext(object):
 
     def construct_device(self, d_text, m, d_sa, d_isa, d_lcp, index_bits, k=0):
         """Blocks resident in HBM: lists (one entry per local rank) of raw device addresses and block lengths."""
+        self._pre()
         L = self.nlocal
         vp = C.c_void_p * L
         mm = (C.c_uint64 * L)(*[int(x) for x in m])
@@ -155,6 +182,7 @@ class MultiContext(object):
     def check_device(self, d_text, m, d_sa, d_isa, d_lcp, index_bits):
         """Distributed d_check_sa (+ LCP recurrence) over blocks resident in HBM; returns the four error counters
         summed over all ranks (all zero = correct)."""
+        self._pre()
         L = self.nlocal
         vp = C.c_void_p * L
         mm = (C.c_uint64 * L)(*[int(x) for x in m])
@@ -166,6 +194,7 @@ class MultiContext(object):
     def left_chars_device(self, d_text, m, d_sa, d_lcp, d_lc, index_bits):
         """Left-branching characters Lc[i] = S[SA[i-1] + LCP[i]] of block-distributed results resident in HBM
         (suffix_array.hpp:211-212); d_lc[i] receives m[i] bytes."""
+        self._pre()
         L = self.nlocal
         vp = C.c_void_p * L
         mm = (C.c_uint64 * L)(*[int(x) for x in m])
@@ -175,6 +204,7 @@ class MultiContext(object):
     def suffix_tree_device(self, d_text, m, d_sa, d_lcp, d_nodes, index_bits):
         """construct_suffix_tree on p ranks (suffix_tree.hpp:413-499) over blocks resident in HBM: d_nodes[i] receives the
         m[i] x (sigma + 1) rows of local rank i's LCP indices (uint64 cells); d_nodes=None only returns sigma."""
+        self._pre()
         L = self.nlocal
         vp = C.c_void_p * L
         mm = (C.c_uint64 * L)(*[int(x) for x in m])
@@ -189,6 +219,7 @@ class MultiContext(object):
     def ansv_device(self, d_in, m, d_left, d_right, index_bits, left_type=0, right_type=0, nonsv=0):
         """ansv<T, left_type, right_type, global_indexing> over a block-distributed array resident in HBM (lists of raw
         device addresses, one per local rank; results are uint64 global indices)."""
+        self._pre()
         L = self.nlocal
         vp = C.c_void_p * L
         mm = (C.c_uint64 * L)(*[int(x) for x in m])

@@ -37,6 +37,16 @@ class Context(object):
         self.check(self._lib.psacx_get_stats(self.handle, C.byref(s)))
         return s
 
+    def configure(self, **options):
+        """psacx_configure: pins the form of single stages (include/psacx.h), e.g. configure(force_diet=1, diet_cap=1 << 20), configure(reset=0)."""
+        for name, value in options.items():
+            self.check(self._lib.psacx_configure(self.handle, _lib.OPTIONS[name], int(value)))
+
+    def _pre(self):
+        """Before every call that runs the engine: with _lib.ENV_KNOBS the options come from PSACX_* variables (debug shim)."""
+        if _lib.ENV_KNOBS:
+            self.check(self._lib.psacx_configure_from_env(self.handle))
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.psacx_destroy(self.handle)
@@ -170,6 +180,7 @@ class SuffixArray(object):
             args.append(_ptr(self.local_Lc))
         else:
             fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
+        self.ctx._pre()
         self.ctx.check(fn(*args))
         return self._after()
 
@@ -181,6 +192,7 @@ class SuffixArray(object):
         assert SA.size == n and B.size == n and SA.dtype == self.dtype and B.dtype == self.dtype
         assert (LCP is not None and LCP.size == n) or not self.lcp
         fn = getattr(self.ctx._lib, "psacx_construct_u%d" % self.index_bits)
+        self.ctx._pre()
         self.ctx.check(fn(self.ctx.handle, _ptr(t), n, int(k), self._flags(fast_resolval, False), _ptr(SA), _ptr(B),
                           _ptr(LCP) if self.lcp else None))
         self.n = self.local_size = n
@@ -206,6 +218,7 @@ class SuffixArray(object):
         self.local_B = np.empty(n, self.dtype)
         self.local_LCP = np.empty(n, self.dtype) if self.lcp else np.zeros(0, self.dtype)
         fn = getattr(self.ctx._lib, "psacx_construct_gsa_u%d" % self.index_bits)
+        self.ctx._pre()
         self.ctx.check(fn(self.ctx.handle, _ptr(text), n, _ptr(off), int(off.size - 1), int(k), self._flags(True, profile),
                           _ptr(self.local_SA), _ptr(self.local_B), _ptr(self.local_LCP) if self.lcp else None))
         self.string_offsets = off
@@ -220,6 +233,7 @@ class SuffixArray(object):
             args.append(C.c_void_p(d_lc))
         else:
             fn = getattr(self.ctx._lib, "psacx_construct_dev_u%d" % self.index_bits)
+        self.ctx._pre()
         self.ctx.check(fn(*args))
         self.n = self.local_size = int(n)
         return self._after()

@@ -11,7 +11,7 @@ static int run_rank(int rank, int P, const unsigned char* id) {
     ShmLink sh;
     std::string err;
     sh.timeout_s = 30;
-    if (!sh.open(rank, P, id, err)) { fprintf(stderr, "rank %d: %s\n", rank, err.c_str()); return 2; }
+    if (!sh.open(rank, P, id, err, 65536)) { fprintf(stderr, "rank %d: %s\n", rank, err.c_str()); return 2; }
     int bad = 0;
     for (int round = 0; round < 50; ++round) {
         // scalar all-gather
@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     const int P = argc > 1 ? atoi(argv[1]) : 3;
     unsigned char id[128];
     for (int i = 0; i < 128; ++i) id[i] = (unsigned char)(i * 37 + getpid());
-    setenv("PSACX_SHM_BOX", "65536", 1);
+    // (mailboxes of 64 KiB: the box size is an argument of open() since the library stopped reading the environment)
     {
         // what a crashed run with the same id leaves behind: a complete-looking segment that all its P ranks had attached to.  The ranks
         // below must not settle on it (rank 0 replaces it; a rank that mapped the old one sees the name lead elsewhere and looks again)
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 128; ++i) id2[i] = (unsigned char)(i * 11 + 3);
         ShmLink lone; std::string err;
         lone.timeout_s = 0.3;
-        if (lone.open(0, 2, id2, err)) rc = 20;            // rank 1 is missing: open()'s first barrier must time out
+        if (lone.open(0, 2, id2, err, 65536)) rc = 20;            // rank 1 is missing: open()'s first barrier must time out
         if (lone.base) { munmap(lone.base, lone.bytes); shm_unlink(lone.name.c_str()); }
     }
     printf(rc == 0 ? "ok\n" : "FAILED %d\n", rc);

@@ -810,6 +810,89 @@ def test_refinement_sort_inside_lds(ctx, monkeypatch):
     assert np.array_equal(other.local_SA, got.local_SA) and np.array_equal(other.local_LCP, got.local_LCP)
 
 
+def test_options_through_the_abi(ctx, monkeypatch):
+    # psacx_configure (include/psacx.h): the forms of single stages are options of the context; the library itself never reads the
+    # environment (the suite's PSACX_* variables go through the debug shim psacx_configure_from_env, switched off here)
+    import psac_amd
+    monkeypatch.setattr(psac_amd._lib, "ENV_KNOBS", False)
+    monkeypatch.setenv("PSACX_NO_BUCKET_SORT", "1")               # (must be ignored now)
+    text = inputs.mutated((1 << 23) + 1234, 4096, 5)          # (the text of test_refinement_sort_inside_lds)
+    in_lds = lambda sa: [r for r in sa.rounds[1:] if r[3] >= (1 << 21) and r[4] == 1]
+    try:
+        a = run(ctx, text, bits=64)
+        assert in_lds(a), a.rounds
+        ctx.configure(no_bucket_sort=1)
+        b = run(ctx, text, bits=64)
+        assert not in_lds(b) and np.array_equal(a.local_SA, b.local_SA) and np.array_equal(a.local_LCP, b.local_LCP)
+        ctx.configure(no_bucket_sort=0, force_diet=1, diet_cap=1 << 20)
+        c = run(ctx, text, bits=64)
+        assert np.array_equal(a.local_SA, c.local_SA) and np.array_equal(a.local_B, c.local_B) and np.array_equal(a.local_LCP, c.local_LCP)
+        ctx.configure(reset=0)
+        d = run(ctx, text, bits=64)
+        assert in_lds(d) and d.rounds == a.rounds
+        assert ctx._lib.psacx_configure(ctx.handle, 999, 1) == -1 and ctx._lib.psacx_configure(ctx.handle, psac_amd._lib.OPTIONS["gather"], 7) == -1
+        # ... and the shim: the same variable, asked for explicitly
+        ctx.check(ctx._lib.psacx_configure_from_env(ctx.handle))
+        e = run(ctx, text, bits=64)
+        assert not in_lds(e)
+    finally:
+        ctx.configure(reset=0)
+
+
+def _construct_dev64(ctx, text):
+    import psac_amd
+    n = int(text.size)
+    d_text = ctx.alloc(n); ctx.h2d(d_text, text)
+    d = [ctx.alloc(n * 8) for _ in range(3)]
+    sa = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+    st = sa.construct_device(d_text, n, d[0], d[1], d[2])
+    out = [np.empty(n, np.uint64) for _ in range(3)]
+    for a, p in zip(out, d):
+        ctx.d2h(a, p)
+    for p in [d_text] + d:
+        ctx.free(p)
+    return out, st, sa.rounds
+
+
+def test_long_bucket_rounds_through_levels_and_the_heavy_light_split(ctx, monkeypatch):
+    # Rounds whose buckets are too long for the sort in LDS (a tandem repeat: period-many buckets of n / period suffixes): the ranks h
+    # further come through partition levels by text position (construct.hpp: gather_by_levels, psac's bulk_rma batched by owner,
+    # bulk_rma.hpp:20-49) and, with at most 4096 buckets, the records that carry their bucket's heavy rank skip the radix sort
+    # (heavy_keys.hpp).  Every form -- one random fetch per record and a sort of all records (the older path), levels without the split,
+    # both layouts, a round in slabs -- must give the same SA / ISA / LCP and the same round log; one text also against the oracle.
+    n = (1 << 24) + 4321
+    rng = np.random.RandomState(11)
+    spotted = inputs.tandem(n, 1024, inputs.dna(1024, 3))
+    spotted[rng.randint(0, n, 40)] = 84                        # a few substitutions: buckets split early, many light records
+    texts = [inputs.tandem(n, 1024, inputs.dna(1024, 3)), inputs.tandem(n, 96, inputs.dna(96, 5)), spotted]
+    for ti, text in enumerate(texts):
+        for k_ in ("PSACX_GATHER", "PSACX_NO_HEAVY", "PSACX_FORCE_DIET", "PSACX_DIET_CAP"):
+            monkeypatch.delenv(k_, raising=False)
+        (SA, ISA, LCP), st, log = _construct_dev64(ctx, text)
+        assert st.heavy_rounds > 0 and st.level_gathers >= st.heavy_rounds and st.heavy_records > st.light_records, (st.heavy_rounds, st.level_gathers)
+        if ti == 0:
+            oSA, oLCP = O.construct_all_cores(text, bits=64)
+            assert np.array_equal(SA, oSA) and np.array_equal(LCP, oLCP)
+            assert np.array_equal(ISA[SA.astype(np.int64)], np.arange(n, dtype=np.uint64))
+        forms = [{"PSACX_GATHER": "fetch"}, {"PSACX_NO_HEAVY": "1"}, {"PSACX_FORCE_DIET": "1"},
+                 {"PSACX_FORCE_DIET": "1", "PSACX_DIET_CAP": str(6 << 20)}, {"PSACX_FORCE_DIET": "1", "PSACX_NO_HEAVY": "1"}]
+        for fi, env in enumerate(forms if ti != 1 else forms[:3]):
+            for k_ in ("PSACX_GATHER", "PSACX_NO_HEAVY", "PSACX_FORCE_DIET", "PSACX_DIET_CAP"):
+                monkeypatch.delenv(k_, raising=False)
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            (a, b, c), st2, log2 = _construct_dev64(ctx, text)
+            assert np.array_equal(a, SA) and np.array_equal(b, ISA) and np.array_equal(c, LCP), (ti, env)
+            if "PSACX_DIET_CAP" not in env:             # (the counters of a round in slabs may run ahead of the one-step log)
+                assert [r[:3] for r in log2] == [r[:3] for r in log], (ti, env)
+            if env.get("PSACX_GATHER") == "fetch":
+                assert st2.level_gathers == 0 and st2.heavy_rounds == 0
+            elif "PSACX_NO_HEAVY" in env:
+                assert st2.level_gathers > 0 and st2.heavy_rounds == 0
+            else:
+                assert st2.heavy_rounds > 0, (ti, env)
+
+
 def test_ansv_device_resident(ctx):
     # psacx_ansv_dev_*: LCP left in HBM by the construction -> ANSV without leaving the device (psac -t's
     # pair: left furthest_eq, right nearest_sm, suffix_tree.hpp:62); 2^24 characters, compared with the oracle

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """A/B of an environment switch inside one process (same memory placement): tools/ab_env.py ENVNAME [log2 n] [bits]."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import ctypes as C
 import os
 import sys

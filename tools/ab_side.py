@@ -1,6 +1,7 @@
 """Wall time of construct_device on the side workloads of bench.py (for A/B runs of a knob): python tools/ab_side.py KIND LOG2N PERIOD [REPS] [check]
 KIND: 0 random DNA, 2 tandem repeat, 3 repeated reads with mutations (psacx_synth_text_dev).  check: the result of the last construction goes
 through the recurrence checker of the multi-GPU engine on one rank (LCP by ranks, not by characters: repetitive texts)."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import sys, time, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import psac_amd

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ANSV over an LCP array resident in HBM: tools/ansv_time.py <log2 n> <bits>.  Constructs SA+LCP of random DNA,
 then times psacx_ansv_dev_* (left furthest_eq, right nearest_sm: the pair psac -t uses)."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os
 import sys
 import time

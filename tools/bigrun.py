@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Large single-GPU runs: tools/bigrun.py <n> <bits> <dna|ascii128> [steps].  Builds the text in chunks,
 constructs SA+ISA+LCP with everything resident in HBM, verifies on the device, prints timings."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import json
 import os
 import sys

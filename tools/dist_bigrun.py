@@ -6,6 +6,7 @@ on one GPU, i.e. the 64-bit payload forms of the exchanges; BIGRUN_ITERS=k times
 Prints the device memory every rank's engine allocated at its peak in words per character (beside the three result
 arrays and the text the caller owns), the total against the 288 GB of one MI355X for a block of 2^32 characters with
 64-bit words (BASELINE.json configs[4]: 32 GiB over 8 GPUs), ms per construction and the distributed checker's verdict."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import ctypes as C
 import os
 import sys

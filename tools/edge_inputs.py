@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Alphabet and size edge cases around the 2^21 threshold (two-stage first round, three-kernel passes) against the
 CPU oracle, on the GPU: tools/edge_inputs.py.  SA, ISA, LCP, k and the per-round log must all agree."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

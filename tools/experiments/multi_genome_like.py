@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/experiments/multi_genome_like.py <P> <log2 n>: the interspersed-repeats text of tools/skewrun.py on P virtual ranks (host path),
 against the one-GPU engine."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """tools/experiments/skew_one.py <log2 n>: the repeated-reads text of tools/skewrun.py, uint64, phases only (no check)."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

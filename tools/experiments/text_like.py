@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/experiments/text_like.py <log2 n>: words of a Zipf vocabulary (50000 words of 2..12 lower-case letters) joined by spaces;
 SA + ISA + LCP, uint64, phases + device check."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

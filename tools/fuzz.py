@@ -2,6 +2,7 @@
 """Randomised parity run on the GPU: tools/fuzz.py <seconds> [seed].  Random lengths (1 .. 2^23, biased to the
 thresholds), alphabets, generators, index widths, k, fast_resolval, LCP / Lc / string-set modes; every result is
 compared with the CPU oracle (SA, ISA, LCP, Lc, round log).  Stops at the first mismatch."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os
 import sys
 import time

@@ -4,6 +4,7 @@ Random rank counts (1 .. 8), lengths (a few characters per rank .. 2^21), alphab
 repeats with mutations, one symbol), index widths, both layouts and small slabs (PSACX_MULTI_SLAB picked at random so that
 refinement rounds run in several steps); SA, ISA, LCP and the per-round log are compared with the CPU oracle.  Stops at the
 first mismatch."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os
 import sys
 import time

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generalized suffix array at scale: tools/gsa_time.py <log2 total characters> <read length> <bits>.
 Random DNA reads of equal length; SA+ISA+LCP through psacx_construct_gsa_*; spot-checks order and LCP."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os
 import sys
 import time

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the C++ multi-GPU engine with P ranks sharing device 0 (virtual ranks, copy transport):
 tools/multi_time.py <P> <log2 n total> <bits> [kind].  Reports ms per construction and the exchange volume."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import ctypes as C
 import sys
 import time

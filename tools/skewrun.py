@@ -3,6 +3,7 @@
 symbol frequencies over 20 symbols), (b) a text of repeated reads with mutations (long shared prefixes), (c) random DNA with
 40 % interspersed repeats (1000 families of 300 bp, 5 % divergence),
 constructs SA+ISA+LCP on the GPU, verifies on the device, prints timings."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import json
 import os
 import sys

@@ -2,6 +2,7 @@
 """Times the stand-alone rank-pair sort (psacx_pair_sort_dev) on round-1-like keys:
 (B1,B2) = (10-mer at i, 10-mer at i+10) of random DNA, 3 bits per character.
 """
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import ctypes as C
 import os
 import sys

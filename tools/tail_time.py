@@ -2,6 +2,7 @@
 """Launch-bound refinement rounds: tools/tail_time.py [log2 n] [period] [bits].  A tandem repeat keeps every suffix
 unresolved for log2(n / period) rounds of n records each; with n = 2^20 a round is ~20 us of work.  Prints ms per
 construction and per refinement round."""
+import os as _os; _os.environ.setdefault("PSACX_ENV_KNOBS", "1")      # PSACX_* variables select the forms of single stages (psac_amd/_lib.py: ENV_KNOBS)
 import os
 import sys
 import time
