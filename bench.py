@@ -432,11 +432,56 @@ def side_workloads(a, ctx, sa64, d_text, d_sa, d_isa, d_lcp):
     run("configs[4] twin (/256): 128 MiB period-1024 tandem repeat of DNA, uint64", "tandem", 1 << 27, 64, 2, seed=3, recurrence_check=True)
     run("repeated reads with mutations: 1024 MiB (period 65536, one substitution in 200), uint64", "mutated", 1 << 30, 64, 2, seed=7, period=1 << 16,
         recurrence_check=True)
+    # configs[4]'s per-GPU block on the one-GPU engine: 2^32 characters of the period-1024 tandem repeat (28 rounds, the reduced-memory
+    # layout with its rounds in slabs; rank requests through partition levels and the heavy / light split, psac_amd/csrc/heavy_keys.hpp)
+    run("configs[4] block on one GPU: 4096 MiB period-1024 tandem repeat of DNA, uint64", "tandem", 1 << 32, 64, 1, seed=a.seed, recurrence_check=True)
     # the (B1,B2,idx) records of idxsort.hpp:58-62 through every digit of both words (psacx_configure: PSACX_OPT_ONE_STAGE switches the
     # two-stage first round off): 6w = 48 bytes per record and pass, SURVEY 8(d)'s per-unit figure
     run("three-word scatter form: 2048 MiB random DNA, uint64, one-stage first round", "dna", 1 << 31, 64, 2, {"one_stage": 1})
+    # the multi-GPU engine on ONE rank with every message through RCCL (no 8-GPU node is needed to time the rank's own work: partition,
+    # self-send of the shuffle, bucket passes, ties, rebucket, slice inversion): 2^31 characters of random DNA, uint64
+    res["multi-GPU engine, 1 rank, wire forced: 2048 MiB random DNA, uint64"] = multi_engine_leg(a, ctx, d_text, d_sa, d_isa, d_lcp)
     ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), 1 << 32, 0, KIND_ID[a.alphabet], a.seed, 1024))
     return res
+
+
+def multi_engine_leg(a, ctx, d_text, d_sa, d_isa, d_lcp, lg=31):
+    """psacx_multi_construct_dev_u64 on one rank made with PSACX_MULTI_FORCE_WIRE: the rank sends its whole shuffle to itself through
+    ncclSend / ncclRecv and gathers its scalars through ncclAllGather, so the line carries a driver-timed figure of the rank overhead
+    of the multi-GPU engine although the box has one GPU.  The result arrays of the default workload (2^32 entries) are reused: they hold
+    the block and the slack the reduced-memory layout asks for."""
+    import ctypes as C
+    import psac_amd
+    lib = ctx._lib
+    try:
+        n = 1 << lg
+        ctx.check(lib.psacx_trim(ctx.handle))
+        ctx.check(lib.psacx_synth_text_dev(ctx.handle, C.c_void_p(d_text), n, 0, KIND_ID["dna"], a.seed, 1024))
+        mg = psac_amd.MultiContext([ctx.device], force_wire=True)
+        try:
+            slack = n // 8 + 256
+            mg.configure(output_slack=slack)
+            mg.construct_device([d_text], [n], [d_sa], [d_isa], [d_lcp], 64)
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st, sent, nex, nga = mg.construct_device([d_text], [n], [d_sa], [d_isa], [d_lcp], 64)
+                times.append(time.perf_counter() - t0)
+            dt = sum(times) / len(times)
+            phases, form, wire = mg.phases(), mg.last_form(), mg.wire()
+            peak, reduced, slab_rounds = mg.memory()
+            err = mg.check_device([d_text], [n], [d_sa], [d_isa], [d_lcp], 64)
+            return {"n": n, "index_bits": 64, "ms_per_construction": round(dt * 1e3, 3), "best_ms": round(min(times) * 1e3, 3), "MChars_per_s": round(n / dt / 1e6, 1),
+                    "timing": "host wall clock over 3 constructions after one warm-up call, text and results resident in HBM",
+                    "ranks_seen_by_rccl": mg.nranks, "transport": mg.transport, "uses_rccl": mg.uses_rccl, "rounds": int(st.n_rounds),
+                    "payload_bytes_through_rccl_per_construction": int(sent), "nccl_calls_last_construction": {k: wire[k] for k in ("sends", "recvs", "allgathers")},
+                    "exchange_ms_on_second_stream": wire["exchange_ms"][0], "forms": form, "layout_reduced": bool(reduced),
+                    "engine_words_per_char_at_peak": round(peak[0] / float(n * 8), 2),
+                    "phases_ms_last_construction": dict((k.strip(), round(v, 3)) for k, v in phases), "verified": list(err) == [0, 0, 0, 0]}
+        finally:
+            mg.close()
+    except Exception as e:              # a side measurement never breaks the bench line
+        return {"error": str(e)[:300]}
 
 
 def ansv_leg(ctx, d_in, n, bits, d_l, d_r):

@@ -26,7 +26,7 @@ int main() {
     CK(hipMemset(text, 1, n));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rd = 0; rd < 2; ++rd)
-        for (uint64_t region : {n, n / 2, n / 16, n / 256}) {
+        for (uint64_t region : {n, n / 16, n / 256, n / 4096, n / 16384}) {
             for (uint64_t skew : {0ull, 20000ull, 40000ull, 65536ull + 16ull, 131072ull + 48ull, 262144ull + 272ull, 1000003ull}) {
                 if (skew && region != n && region != n / 2) continue;
                 hipLaunchKernelGGL(fronts, dim3((unsigned)(n / 4096)), dim3(512), 0, 0, out, n, region, rd, (const uint8_t*)text, skew);
