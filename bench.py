@@ -453,6 +453,25 @@ def multi_engine_leg(a, ctx, d_text, d_sa, d_isa, d_lcp, lg=31):
     import ctypes as C
     import psac_amd
     lib = ctx._lib
+    # RCCL prints a version banner on the C stdout of the process: while it may, file descriptor 1 is the process's stderr (as in
+    # main_distributed), so that the JSON line stays the only thing on the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _multi_engine_leg(a, ctx, lib, d_text, d_sa, d_isa, d_lcp, lg)
+    finally:
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _multi_engine_leg(a, ctx, lib, d_text, d_sa, d_isa, d_lcp, lg):
+    import ctypes as C
+    import psac_amd
     try:
         n = 1 << lg
         ctx.check(lib.psacx_trim(ctx.handle))
@@ -474,7 +493,7 @@ def multi_engine_leg(a, ctx, d_text, d_sa, d_isa, d_lcp, lg=31):
             return {"n": n, "index_bits": 64, "ms_per_construction": round(dt * 1e3, 3), "best_ms": round(min(times) * 1e3, 3), "MChars_per_s": round(n / dt / 1e6, 1),
                     "timing": "host wall clock over 3 constructions after one warm-up call, text and results resident in HBM",
                     "ranks_seen_by_rccl": mg.nranks, "transport": mg.transport, "uses_rccl": mg.uses_rccl, "rounds": int(st.n_rounds),
-                    "payload_bytes_through_rccl_per_construction": int(sent), "nccl_calls_last_construction": {k: wire[k] for k in ("sends", "recvs", "allgathers")},
+                    "payload_bytes_sent_to_other_ranks": int(sent), "nccl_calls_last_construction": {k: wire[k] for k in ("sends", "recvs", "allgathers")},
                     "exchange_ms_on_second_stream": wire["exchange_ms"][0], "forms": form, "layout_reduced": bool(reduced),
                     "engine_words_per_char_at_peak": round(peak[0] / float(n * 8), 2),
                     "phases_ms_last_construction": dict((k.strip(), round(v, 3)) for k, v in phases), "verified": list(err) == [0, 0, 0, 0]}

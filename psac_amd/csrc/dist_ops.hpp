@@ -473,15 +473,18 @@ int op_compact_counted(psacx_ctx* c, const T* ids, uint64_t cnt, uint64_t off, u
 template <typename T>
 int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigned lo1, T* pos_out, T* k1_out, T* v_out, uint64_t* n_out, bool counted = false) {
     // counted (with pos_out): the call before this one on this context was the counting call for the same records (pos_out == nullptr), and
-    // nothing has used the context's scratch since: the tiles' offsets are still there and the records are not read a third time
+    // nothing has used the context's scratch since: the tiles' offsets are still there and the records are not read a third time.  The
+    // counting call leaves a stamp (records, length, shift, generation of the scratch); a counted call whose stamp does not match counts again.
     OP_PROLOGUE(c);
     if (!pos_out) *n_out = 0;
     if (cnt == 0) return PSACX_OK;
     PSACX_TRY(ensure_pinned(c, 4096));
+    const bool reuse = counted && pos_out && c->tie_stamp.s1 == (const void*)s1 && c->tie_stamp.cnt == cnt && c->tie_stamp.lo1 == lo1 &&
+                       c->tie_stamp.gen == c->slab_gen;
     TileScratch ts;
     PSACX_TRY(tile_scratch(c, cnt, ts, 0, nullptr));
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
-    if (!(counted && pos_out)) {
+    if (!reuse) {
         hipLaunchKernelGGL((count_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1, cnt,
                            (T)0, (T)0, ts.nact, lo1);
         hipLaunchKernelGGL((tile_scan_kernel<1024, OpSum>), dim3(1), dim3(1024), 0, c->stream, ts.nact, ntiles, OpSum(), (uint64_t)0, ts.totals);
@@ -491,8 +494,10 @@ int op_compact_ties(psacx_ctx* c, const T* s1, const T* v, uint64_t cnt, unsigne
         PSACX_HIP(c, hipMemcpyAsync(c->pinned, ts.totals, 8, hipMemcpyDeviceToHost, c->stream));
         PSACX_HIP(c, hipStreamSynchronize(c->stream));
         *n_out = *reinterpret_cast<uint64_t*>(c->pinned);
+        c->tie_stamp.s1 = s1; c->tie_stamp.cnt = cnt; c->tie_stamp.lo1 = lo1; c->tie_stamp.gen = c->slab_gen;
         return PSACX_OK;
     }
+    c->tie_stamp.s1 = nullptr;
     hipLaunchKernelGGL((compact_active_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, true>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, s1,
                        (const T*)nullptr, cnt, pos_out, ts.nact, (uint64_t)0, (T)0, (T)0, lo1, v, k1_out, v_out);
     PSACX_HIP(c, hipGetLastError());

@@ -100,6 +100,8 @@ struct psacx_ctx {
     size_t ev_used = 0;
     int n_cu = 256;
     psacx::Knobs knobs;              // psacx_configure
+    uint64_t slab_gen = 0;           // bumped whenever an operation claims the slab as its scratch (ensure_slab)
+    struct { const void* s1 = nullptr; uint64_t cnt = 0; unsigned lo1 = 0; uint64_t gen = 0; } tie_stamp;      // dist_ops.hpp: op_compact_ties(counted)
 };
 
 namespace psacx {
@@ -178,6 +180,7 @@ struct Arena {
 inline void pool_flush(psacx_ctx* c);
 
 inline int ensure_slab(psacx_ctx* c, size_t bytes) {
+    ++c->slab_gen;
     if (c->slab_bytes >= bytes) return PSACX_OK;
     if (c->slab) { (void)hipFree(c->slab); c->slab = nullptr; c->slab_bytes = 0; }
     hipError_t e = hipMalloc((void**)&c->slab, bytes);

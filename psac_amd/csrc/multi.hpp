@@ -317,7 +317,7 @@ struct MultiRun {
         r.cnt = cnt;
         if (diet && !S[i].out_busy && cnt <= S[i].out_cap) {
             r.v.borrow(c, S[i].SA, cnt); r.k1.borrow(c, S[i].ISA, cnt);
-            if (S[i].LCP) r.k2.borrow(c, S[i].LCP, cnt); else if (want_k2) MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
+            if (S[i].LCP) { r.k2.borrow(c, S[i].LCP, cnt); invalidate_lcp_pyramid(i); } else if (want_k2) MG_OP(g, c, r.k2.alloc(c, cnt, reserve_of(i)));
             S[i].out_busy = true;
             return PSACX_OK;
         }
@@ -1486,6 +1486,8 @@ struct MultiRun {
     // 34 GB, 1700 times per construction of a tandem repeat: 8.7 of its 33 s).
     std::vector<Pyramid<T>> lcp_pyr_;
     std::vector<DBuf<T>> lcp_pyr_mem_;
+    // whoever lends the LCP block out as scratch or writes it without pyramid_set calls this: the upper levels are rebuilt when next asked for
+    void invalidate_lcp_pyramid(int i) { if (i < (int)lcp_pyr_.size()) lcp_pyr_[i] = Pyramid<T>(); }
     int block_pyramid(int i, Pyramid<T>& Pm, uint64_t* block_min) {
         psacx_ctx* c = ctx(i);
         const uint64_t m = S[i].m;

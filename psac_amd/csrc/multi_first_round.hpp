@@ -601,7 +601,7 @@ int MultiRun<T>::sort_first_one_word(std::vector<Rec<T>>& rec, const std::vector
             S[i].out_busy = true;
             other.borrow(c, S[i].ISA, room);
             vout[i].borrow(c, S[i].SA, room);
-            if (S[i].LCP && !solo_) grp[i].borrow(c, S[i].LCP, ng);
+            if (S[i].LCP && !solo_) { grp[i].borrow(c, S[i].LCP, ng); invalidate_lcp_pyramid(i); }
         } else {
             rc_alloc = other.alloc(c, room, reserve_of(i));
             if (rc_alloc == PSACX_OK) rc_alloc = vout[i].alloc(c, room, reserve_of(i));

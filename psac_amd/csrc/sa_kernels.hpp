@@ -2182,7 +2182,14 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if constexpr (sizeof(T) == 8) {
         const uint64_t wave_e0 = e0 - (uint64_t)lane_id() * ITEMS;
         const uint64_t p_first = shfl<uint64_t>((uint64_t)ps[0], 0), p_last = shfl<uint64_t>((uint64_t)ps[ITEMS - 1], WAVE - 1);
-        rows = wave_e0 + (uint64_t)WAVE * ITEMS <= cnt && p_last - p_first == (uint64_t)WAVE * ITEMS - 1;
+        // (pos ascends strictly -- every caller passes list positions in SA order --, so a span of 64 x ITEMS - 1 means consecutive positions;
+        //  the check below costs eight compares and keeps a list that breaks the rule on the entry-by-entry path instead of writing wrong rows)
+        bool consecutive = true;
+#pragma unroll
+        for (int j = 0; j + 1 < ITEMS; ++j) consecutive = consecutive && (uint64_t)ps[j + 1] == (uint64_t)ps[j] + 1;
+        const uint64_t nxt = shfl<uint64_t>((uint64_t)ps[0], (int)((lane_id() + 1) & (WAVE - 1)));
+        consecutive = consecutive && (lane_id() == WAVE - 1 || nxt == (uint64_t)ps[ITEMS - 1] + 1);
+        rows = wave_e0 + (uint64_t)WAVE * ITEMS <= cnt && p_last - p_first == (uint64_t)WAVE * ITEMS - 1 && __ballot(!consecutive) == 0;
         row0 = p_first - bd.off;
     }
 #pragma unroll

@@ -21,7 +21,8 @@ d_l, d_r = ctx.alloc(n * 8), ctx.alloc(n * 8)
 sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
 sa.construct_device(d_text, n, d_sa, d_isa, d_lcp)
 names = ("nearest_sm", "nearest_eq", "furthest_eq")
-pairs = ((0, 0),) if len(sys.argv) > 3 and sys.argv[3] == "one" else ((2, 0), (0, 0), (1, 1), (2, 2))
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+pairs = ((0, 0),) if mode == "one" else ((2, 0),) if mode == "t" else ((2, 0), (0, 0), (1, 1), (2, 2))          # one: nearest_sm pair; t: the pair psac -t uses
 for lt, rt in pairs:
     for it in range(3):
         t0 = time.perf_counter()
