@@ -47,6 +47,7 @@ template <typename T> struct Work {
     unsigned* d_gcursors;              // the same for the rank requests of a refinement round (GatherLevels; the ISA levels of a round in slabs stay open meanwhile)
     uint64_t* d_gwin;                  // ... and where the records of every window start in the round's sort input
     uint64_t* d_heavy;                 // tables of the heavy / light split of a round (heavy_keys.hpp: HeavyTabs for HEAVY_MAXB buckets)
+    ulonglong2* d_htile;               // ... and per scan tile the key and the shift of the heavy run that holds it (sa_kernels.hpp: heavy_tiles_kernel)
     SortScratch sc;
 };
 
@@ -101,6 +102,7 @@ size_t carve(Arena& a, Work<T>& w, uint64_t n, bool with_lcp, T* d_lcp, bool die
     w.d_gcursors = a.take<unsigned>(1024 + (size_t)(n >> ISA_NARROW_WB) + 2);
     w.d_gwin = a.take<uint64_t>((size_t)(n >> ISA_NARROW_WB) + 2);
     w.d_heavy = a.take<uint64_t>(HeavyTabs::words(HEAVY_MAXB));
+    w.d_htile = a.take<ulonglong2>((n + SCAN_TILE_MIN - 1) / SCAN_TILE_MIN + 1);
     w.sc.d_hist = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.d_base = a.take<unsigned long long>((size_t)MAX_PASSES * RADIX);
     w.sc.desc_bytes = sort_desc_bytes(n);
@@ -164,8 +166,13 @@ int scan_carries(psacx_ctx* c, Work<T>& w, uint64_t ntiles) {
 // per-tile carries of the prefix-max: last head of every tile, then an exclusive max-scan
 template <typename T, bool REFINE, bool GSA = false>
 int run_carries(psacx_ctx* c, Work<T>& w, const T* a1, const T* a2, const T* pos, uint64_t cnt, const T* sa,
-                KeyShape ks) {
+                KeyShape ks, const HeavyView<T>* hv = nullptr) {
+    // hv (refinement rounds): the sorted records of a split round, read through the view (heavy_keys.hpp)
     const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+    if (REFINE && !GSA && hv)
+        hipLaunchKernelGGL((last_head_kernel<T, REFINE, false, true>), dim3((unsigned)ntiles), dim3(256), 0, c->stream,
+                           (const T*)nullptr, (const T*)nullptr, pos, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>(), *hv);
+    else
     hipLaunchKernelGGL((last_head_kernel<T, REFINE, GSA>), dim3((unsigned)(REFINE ? ntiles : (ntiles + 3) / 4)), dim3(256), 0, c->stream,
                        a1, a2, pos, cnt, (unsigned)ScanCfg<T>::TILE, ntiles, w.d_carry, sa, ks, cnt, Boundary<T>());
     PSACX_HIP(c, hipGetLastError());
@@ -957,6 +964,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         const bool heavy = by_levels && !kn.no_heavy && nb_in <= HEAVY_MAXB && (!w.diet || (2 * cnt + 64 <= n && cnt + 64 <= w.cap_active));
         bool merged = false;
         T* ids_heavy = nullptr; uint64_t* pairs_heavy = nullptr;
+        HeavyView<T> hview;
         uint64_t rmq_queries = cnt;
         if constexpr (sizeof(T) == 8) {
             if (heavy) {
@@ -965,9 +973,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 //   light records     x.k1, x.v (32-bit)                   | x.k1, ry.v (32-bit)
                 //   heavy suffixes    ry.v (32-bit)                        | ry.k1, lower half (32-bit)
                 //   light sort, alt   ry.k1, x.k2                          | x.k1 behind the records, ry.k1 upper half
-                //   merged records    ry.k2, the idle list                 | the idle list, ry.k2
-                //   then ids / pairs  x.k1 / ry.v                          | ry.k1 / ry.v
-                T* const other_list = (plist == w.pos_a) ? w.pos_b : w.pos_a;
+                //   (the sorted order is read through a HeavyView by the kernels that follow: nothing is merged into arrays)
+                //   then ids / pairs  ry.k2 / x.k1 or ry.k1 (the idle one) | ry.k2 / x.v
                 const uint64_t cnt_r = (cnt + 63) & ~63ull;
                 uint64_t* const la = reinterpret_cast<uint64_t*>(w.diet ? w.x.k1 : w.ry.k1);
                 uint64_t* const lb = reinterpret_cast<uint64_t*>(w.diet ? w.x.v : w.ry.k2);
@@ -976,10 +983,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 SortBufs<T> altL;
                 altL.k1 = w.diet ? w.x.k1 + cnt_r : w.ry.k1; altL.k2 = nullptr;
                 altL.v = w.diet ? reinterpret_cast<T*>(reinterpret_cast<uint32_t*>(w.ry.k1) + cnt_r) : w.x.k2;
-                T* const MK = w.diet ? other_list : w.ry.k2;
-                T* const MV = w.diet ? w.ry.k2 : other_list;
-                ids_heavy = w.diet ? w.ry.k1 : w.x.k1;
-                pairs_heavy = reinterpret_cast<uint64_t*>(w.ry.v);
+
                 HeavyTabs ht; uint64_t nlight = 0; unsigned nblk = 0;
                 {
                     ProfScope ps(c, TC_GATHER);
@@ -993,12 +997,24 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 {
                     ProfScope ps(c, TC_SORT_SCATTER);
                     hipLaunchKernelGGL((heavy_plan_kernel<T>), dim3(((unsigned)nb_in + 1 + 255) / 256), dim3(256), 0, c->stream, (uint32_t)nb_in, ht, kb2, (const T*)sl.k1, nlight, w.sc.d_err);
-                    hipLaunchKernelGGL((heavy_merge_kernel<T, 256, 16, HEAVY_MAXB>), dim3((unsigned)((cnt + 4095) / 4096)), dim3(256), 0, c->stream, cnt, (uint32_t)nb_in, ht, kb2,
-                                       (const T*)sl.k1, reinterpret_cast<const uint32_t*>(sl.v), (const uint32_t*)HB, MK, MV);
                     PSACX_HIP(c, hipGetLastError());
                 }
+                // the round's sorted records are not written out: the kernels below read them through the view
+                hview.bstart = ht.bstart; hview.value = ht.value; hview.less = ht.less; hview.eq = ht.eq; hview.lstart = ht.lstart;
+                hview.SLK = sl.k1; hview.SLV = reinterpret_cast<const uint32_t*>(sl.v); hview.HB = HB; hview.nb = (uint32_t)nb_in; hview.kb2 = kb2;
+                // (what the rebucket kernel writes must not lie where the view reads: the sorted light records are in one array of each pair of the
+                //  light sort, the heavy suffixes in ry.v / ry.k1)
+                hview.tile_b = w.d_htile;
+                {
+                    ProfScope ps(c, TC_REBUCKET);
+                    const uint64_t nt_ = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+                    hipLaunchKernelGGL((heavy_tiles_kernel<T>), dim3((unsigned)((nt_ + 255) / 256)), dim3(256), 0, c->stream, hview, cnt, (unsigned)ScanCfg<T>::TILE, nt_, w.d_htile);
+                    PSACX_HIP(c, hipGetLastError());
+                }
+                ids_heavy = w.ry.k2;
+                pairs_heavy = reinterpret_cast<uint64_t*>(w.diet ? w.x.v : (sl.k1 == w.x.k1 ? w.ry.k1 : w.x.k1));
                 c->stats.heavy_rounds += 1; c->stats.heavy_records += cnt - nlight; c->stats.light_records += nlight; c->stats.level_gathers += 1;
-                sorted.k1 = MK; sorted.k2 = nullptr; sorted.v = MV;
+                sorted.k1 = nullptr; sorted.k2 = nullptr; sorted.v = nullptr;
                 rmq_queries = nlight + 2 * nb_in;
                 merged = true;
             }
@@ -1082,7 +1098,13 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_REBUCKET);
             const uint64_t ntiles = (cnt + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
             KeyShape split; split.lc = kb2; split.c1 = split.c2 = 0; split.spec = 0;       // (last_head_kernel: where a one-word key divides)
-            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, split)));
+            PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, split, merged ? &hview : nullptr)));
+            if (merged)
+                hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, true>), dim3((unsigned)ntiles),
+                                   dim3(ScanCfg<T>::BLOCK), 0, c->stream, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, plist, cnt, n, h,
+                                   d_sa, w.bsa, d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),
+                                   (T*)nullptr, (T*)nullptr, (T*)nullptr, (unsigned long long*)nullptr, kb2, isa_pairs, hview);
+            else
             hipLaunchKernelGGL((rebucket_refine_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false>), dim3((unsigned)ntiles),
                                dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, sorted.v, plist, cnt, n, h,
                                d_sa, w.bsa, whole ? (T*)nullptr : d_isa, w.pyr, ids, w.d_carry, w.d_nact, w.d_nunf, Boundary<T>(),

@@ -9,9 +9,10 @@
 //   * heavy: B2 equals the bucket's heavy value (the B2 of three probed members, majority) -- the suffix alone goes into the bucket's run
 //            of an array in list order (per window and bucket one reservation; the order inside the run is free: equal keys stay one bucket);
 //   * light: everything else -- a sort record as before, compacted; only these are radix-sorted, by (bucket number, B2);
-// and one merge pass writes the round's sorted records in list order: per bucket the light records below the heavy value, the heavy run,
-// the light records above it.  A 4 GiB period-1024 tandem repeat: 26 rounds x 6 digit passes over 2^32 records become 26 merge passes and the
-// sort of about one record in twenty.
+// and the round's sorted order -- per bucket the light records below the heavy value, the heavy run, the light records above it -- is read
+// where it lies by the kernels that follow (sa_kernels.hpp: HeavyView; last_head_kernel, rebucket_refine_kernel): a tile of the list inside one
+// heavy run takes its suffixes straight out of the run.  A 4 GiB period-1024 tandem repeat: 26 rounds x 6 digit passes over 2^32 records become
+// the sort of about one record in twenty.
 // Applies to 64-bit words, lists with at most HEAVY_MAXB buckets (their tables live in LDS) that take the partition levels (long buckets).
 #pragma once
 #include "sa_kernels.hpp"
@@ -160,66 +161,6 @@ __global__ void heavy_plan_kernel(uint32_t nb, HeavyTabs ht, unsigned kb2, const
     ht.lstart[b] = s;
     ht.less[b] = lower(((uint64_t)b << kb2) | ht.value[b]) - s;
     if ((e - s) + ht.eq[(size_t)b * HEAVY_PAD] != ht.bstart[b + 1] - ht.bstart[b]) atomicOr(err, 2u);
-}
-
-// The round's sorted records in list order: bucket b = [light records below its heavy value | heavy run | light records above].
-// SLK / SLV: the light records sorted by (bucket number, B2), payload as 32-bit entries.  A workgroup takes a tile of BLOCK x ITEMS list
-// entries; the buckets are long, so most tiles lie inside one bucket and most of those inside its heavy run.
-template <typename T, int BLOCK, int ITEMS, unsigned MAXB>
-__global__ __launch_bounds__(BLOCK) void heavy_merge_kernel(uint64_t cnt, uint32_t nb, HeavyTabs ht, unsigned kb2, const T* __restrict__ SLK,
-                                                            const uint32_t* __restrict__ SLV, const uint32_t* __restrict__ HB, T* __restrict__ MK,
-                                                            T* __restrict__ MV) {
-    constexpr unsigned TILE = BLOCK * ITEMS;
-    __shared__ uint64_t bs[MAXB + 1];
-    __shared__ unsigned range[2];
-    const uint64_t t0 = (uint64_t)blockIdx.x * TILE, t1 = t0 + TILE < cnt ? t0 + TILE : cnt;
-    if (threadIdx.x < 2) {
-        const uint64_t r = threadIdx.x ? t1 - 1 : t0;
-        unsigned lo = 0, hi = nb;                  // last bucket that starts at or before r
-        while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (ht.bstart[m] <= r) lo = m; else hi = m; }
-        range[threadIdx.x] = lo;
-    }
-    __syncthreads();
-    const unsigned b_lo = range[0], b_hi = range[1];
-    for (unsigned b = b_lo + threadIdx.x; b <= b_hi + 1; b += BLOCK) bs[b - b_lo] = ht.bstart[b];
-    __syncthreads();
-    if (b_lo == b_hi) {
-        // the whole tile inside one bucket: its four numbers once, the heavy suffixes of the tile asked for before the first is stored
-        const unsigned b = b_lo;
-        const uint64_t s0 = bs[0], less = ht.less[b], eq = ht.eq[(size_t)b * HEAVY_PAD], ls = ht.lstart[b];
-        const T hkey = (T)(((uint64_t)b << kb2) | ht.value[b]);
-        T key[ITEMS], val[ITEMS];
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint64_t r = t0 + threadIdx.x + (uint64_t)i * BLOCK;
-            key[i] = hkey; val[i] = 0;
-            if (r < t1) {
-                const uint64_t o = r - s0;
-                if (o >= less && o < less + eq) val[i] = (T)HB[s0 + (o - less)];
-                else { const uint64_t s = ls + (o < less ? o : o - eq); key[i] = SLK[s]; val[i] = (T)SLV[s]; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint64_t r = t0 + threadIdx.x + (uint64_t)i * BLOCK;
-            if (r < t1) { MK[r] = key[i]; MV[r] = val[i]; }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint64_t r = t0 + threadIdx.x + (uint64_t)i * BLOCK;
-        if (r >= t1) break;
-        unsigned lo = 0, hi = b_hi - b_lo + 1;
-        while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (bs[m] <= r) lo = m; else hi = m; }
-        const unsigned b = b_lo + lo;
-        const uint64_t o = r - bs[lo];
-        const uint64_t less = ht.less[b], eq = ht.eq[(size_t)b * HEAVY_PAD];
-        T key, val;
-        if (o >= less && o < less + eq) { key = (T)(((uint64_t)b << kb2) | ht.value[b]); val = (T)HB[bs[lo] + (o - less)]; }
-        else { const uint64_t s = ht.lstart[b] + (o < less ? o : o - eq); key = SLK[s]; val = (T)SLV[s]; }
-        MK[r] = key; MV[r] = val;
-    }
 }
 
 } // namespace psacx

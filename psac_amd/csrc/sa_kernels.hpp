@@ -498,6 +498,83 @@ template <typename T> struct Boundary {
     T next1, next2, next3;   // first record of the nearest non-empty higher rank
 };
 
+// ------------------------------------------------------------------ the sorted records of a split round, read where they lie
+// A refinement round whose records were split into heavy and light ones (heavy_keys.hpp) has its sorted order in three pieces: the light
+// records sorted by (bucket number, rank h further) (SLK / SLV, suffixes as 32-bit entries), the heavy suffixes in their buckets' runs of an
+// array in list order (HB), and per bucket where it starts in the list, its heavy rank, how many light records lie below it, the length of
+// its heavy run and where its light records start.  Sorted record r of bucket b (o = r - bstart[b]) is light record lstart[b] + o for
+// o < less[b], heavy suffix HB[r - less[b]] under the key (b << kb2 | value[b]) for less[b] <= o < less[b] + eq[b], light record
+// lstart[b] + o - eq[b] behind that.  last_head_kernel and rebucket_refine_kernel read the records through this view instead of through two
+// arrays a merge pass would have to write and they would have to read back (2^30 records: 7 + 5 ms of a round of 63).
+template <typename T> struct HeavyView {
+    const uint64_t* bstart = nullptr; const uint64_t* value = nullptr; const unsigned long long* less = nullptr;
+    const unsigned long long* eq = nullptr; const uint64_t* lstart = nullptr;
+    const T* SLK = nullptr; const uint32_t* SLV = nullptr; const uint32_t* HB = nullptr;
+    uint32_t nb = 0; unsigned kb2 = 0;
+    const ulonglong2* tile_b = nullptr;        // per scan tile whose records, the one before and the one after lie inside ONE heavy run: (their key, less of the bucket);
+                                               // else (0, ~0) (heavy_tiles_kernel)
+};
+template <typename T>
+__device__ __forceinline__ unsigned heavy_bucket_of(const HeavyView<T>& hv, uint64_t r) {
+    unsigned lo = 0, hi = hv.nb;               // last bucket that starts at or before r
+    while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (hv.bstart[m] <= r) lo = m; else hi = m; }
+    return lo;
+}
+template <typename T>
+__device__ __forceinline__ void heavy_record(const HeavyView<T>& hv, uint64_t r, T& key, T& val) {
+    const unsigned b = heavy_bucket_of(hv, r);
+    const uint64_t o = r - hv.bstart[b], less = hv.less[b], eq = hv.eq[b];
+    if (o >= less && o < less + eq) { key = (T)(((uint64_t)b << hv.kb2) | hv.value[b]); val = (T)hv.HB[r - less]; }
+    else { const uint64_t s = hv.lstart[b] + (o < less ? o : o - eq); key = hv.SLK[s]; val = (T)hv.SLV[s]; }
+}
+// ITEMS consecutive records from r0 on (keys and suffixes; zeros from n on): the bucket is looked up once and followed from there
+template <typename T, int ITEMS>
+__device__ __forceinline__ void heavy_run(const HeavyView<T>& hv, uint64_t r0, uint64_t n, T (&key)[ITEMS], T (&val)[ITEMS]) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { key[j] = 0; val[j] = 0; }
+    if (r0 >= n) return;
+    unsigned b = heavy_bucket_of<T>(hv, r0);
+    uint64_t s0 = hv.bstart[b], s1 = hv.bstart[b + 1], less = hv.less[b], eq = hv.eq[b], ls = hv.lstart[b];
+    T hk = (T)(((uint64_t)b << hv.kb2) | hv.value[b]);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint64_t r = r0 + j;
+        if (r >= n) break;
+        if (r >= s1) {          // (buckets have at least two records)
+            ++b;
+            s0 = s1; s1 = hv.bstart[b + 1]; less = hv.less[b]; eq = hv.eq[b]; ls = hv.lstart[b];
+            hk = (T)(((uint64_t)b << hv.kb2) | hv.value[b]);
+        }
+        const uint64_t o = r - s0;
+        if (o >= less && o < less + eq) { key[j] = hk; val[j] = (T)hv.HB[r - less]; }
+        else { const uint64_t s = ls + (o < less ? o : o - eq); key[j] = hv.SLK[s]; val[j] = (T)hv.SLV[s]; }
+    }
+}
+// do the records r0 .. r1 (both included) lie inside ONE heavy run?  Then they share *key and record r is the suffix HB[r - *less].
+template <typename T>
+__device__ __forceinline__ bool heavy_pure(const HeavyView<T>& hv, uint64_t r0, uint64_t r1, T* key, uint64_t* less) {
+    const unsigned b = heavy_bucket_of(hv, r0);
+    const uint64_t a = hv.bstart[b] + hv.less[b];
+    if (r0 < a || r1 >= a + hv.eq[b]) return false;
+    *key = (T)(((uint64_t)b << hv.kb2) | hv.value[b]); *less = hv.less[b];
+    return true;
+}
+
+// tile_b[t] for the scan tiles of `tile` records each (a tile on its own would find its bucket by a chain of twelve dependent loads while
+// the rest of its workgroup waits: 3 ms of a 13 ms rebucket pass over 2^30 records; here the chains of all tiles run side by side)
+template <typename T>
+__global__ void heavy_tiles_kernel(HeavyView<T> hv, uint64_t cnt, unsigned tile, uint64_t ntiles, ulonglong2* __restrict__ tile_b) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t t0 = t * tile, t1 = t0 + tile < cnt ? t0 + tile : cnt - 1;
+    ulonglong2 out; out.x = 0; out.y = ~0ull;
+    if (t0 > 0) {
+        T key; uint64_t less;
+        if (heavy_pure<T>(hv, t0 - 1, t1, &key, &less)) { out.x = (unsigned long long)key; out.y = less; }
+    }
+    tile_b[t] = out;
+}
+
 // ------------------------------------------------------------------ tile carries for the prefix-max
 // Bucket ids are a prefix maximum over "head" positions (bucketing.hpp:21-53).  It is
 // evaluated in three launches without any inter-workgroup waiting:
@@ -508,11 +585,12 @@ template <typename T> struct Boundary {
 // REFINE = false: heads of the first round, the 2k-character windows differ (packed pair
 //                 differs, or one of the two suffixes is shorter than 2k).
 // REFINE = true : heads inside old buckets, (K1,K2) differs or K2 == 0; id = pos + 1.
-template <typename T, bool REFINE, bool GSA = false>
+// HEAVY (REFINE, one-word keys): the records come through a HeavyView; a tile inside one heavy run has no head.
+template <typename T, bool REFINE, bool GSA = false, bool HEAVY = false>
 __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1, const T* __restrict__ A2,
                                  const T* __restrict__ pos, uint64_t cnt, unsigned tile_size,
                                  uint64_t ntiles, uint64_t* __restrict__ agg, const T* __restrict__ SA,
-                                 KeyShape ks, uint64_t n_global, Boundary<T> bd) {
+                                 KeyShape ks, uint64_t n_global, Boundary<T> bd, HeavyView<T> hv = HeavyView<T>()) {
     // Refinement rounds: one workgroup of four waves per tile, every wave searching its quarter of the tile backwards.  In
     // ordinary text each finds a head in its first window; in a text with long runs of equal records (tandem repeats) the
     // whole tile is walked, and one wave per tile was 96 dependent steps = 34 us of a 230 us refinement round on 2^20
@@ -531,8 +609,14 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
     const uint64_t lo = t_lo + (uint64_t)sub * quarter < t_hi ? t_lo + (uint64_t)sub * quarter : t_hi;
     const uint64_t hi = lo + quarter < t_hi ? lo + quarter : t_hi;
     uint64_t found = 0;
+    bool quarter_pure = false;          // (HEAVY: this wave's records and the one before them lie in one heavy run: no head among them)
+    if constexpr (HEAVY) {
+        T k_; uint64_t l_;
+        quarter_pure = tile < ntiles && hv.tile_b[tile].y != ~0ull;
+        if (!quarter_pure) quarter_pure = hi > lo && lo > 0 && heavy_pure<T>(hv, lo - 1, hi - 1, &k_, &l_);
+    }
     // walk backwards in windows of 64 records [w0, w0 + 64)
-    for (uint64_t wend = hi; wend > lo; ) {
+    for (uint64_t wend = hi; wend > lo && !quarter_pure; ) {
         const uint64_t w0 = wend >= lo + WAVE ? wend - WAVE : lo;
         const uint64_t e = w0 + lane;
         bool head = false;
@@ -541,8 +625,14 @@ __global__ __launch_bounds__(256) void last_head_kernel(const T* __restrict__ A1
             else {
                 // (A2 == nullptr: 64-bit words holding both keys of a refinement record, K1 << kb2 | K2, kb2 = ks.lc bits for K2)
                 const uint64_t m2 = (~0ull) >> (64 - (REFINE ? ks.lc : 32u));
-                const T x1 = A1[e], x2 = A2 ? A2[e] : (T)((uint64_t)x1 & m2);
-                const T y1 = e ? A1[e - 1] : bd.prev1, y2 = A2 ? (e ? A2[e - 1] : bd.prev2) : (T)((uint64_t)y1 & m2);
+                T x1, y1;
+                if constexpr (HEAVY) {
+                    T v_;
+                    heavy_record<T>(hv, e, x1, v_);
+                    if (e) heavy_record<T>(hv, e - 1, y1, v_); else y1 = bd.prev1;
+                } else { x1 = A1[e]; y1 = e ? A1[e - 1] : bd.prev1; }
+                const T x2 = A2 ? A2[e] : (T)((uint64_t)x1 & m2);
+                const T y2 = A2 ? (e ? A2[e - 1] : bd.prev2) : (T)((uint64_t)y1 & m2);
                 head = (x1 != y1) || (x2 != y2) || (REFINE && x2 == 0);
                 if (!REFINE && !head) {
                     // equal packed windows: still a boundary if either suffix is shorter than 2k
@@ -2027,14 +2117,16 @@ __device__ __forceinline__ void pyramid_set(const Pyramid<T>& P, uint64_t p, T v
 // DIST: this rank holds only a block of SA / Bsa / LCP (positions bd.off ...).  ISA is not
 // written (the ids go to their owners afterwards), range minima are not evaluated here: every
 // new boundary that needs one is appended to q_at / q_lo / q_hi (q_count = running length).
-template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool DIST>
+// HEAVY (one GPU, one-word keys): the sorted records come through a HeavyView (K1, K2, V unused).
+template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool DIST, bool HEAVY = false>
 __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     const T* __restrict__ K1, const T* __restrict__ K2, const T* __restrict__ V,
     const T* __restrict__ pos, uint64_t cnt, uint64_t n, uint64_t h, T* __restrict__ SA,
     T* __restrict__ Bsa, T* __restrict__ ISA, Pyramid<T> pyr, T* __restrict__ ids_out,
     const uint64_t* __restrict__ carry_in, uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf,
     Boundary<T> bd, T* __restrict__ q_at, T* __restrict__ q_lo, T* __restrict__ q_hi,
-    unsigned long long* __restrict__ q_count, unsigned kb2 = 32, uint64_t* __restrict__ pairs_out = nullptr) {
+    unsigned long long* __restrict__ q_count, unsigned kb2 = 32, uint64_t* __restrict__ pairs_out = nullptr,
+    HeavyView<T> hv = HeavyView<T>()) {
     // pairs_out (one GPU, at most 2^32 characters): the ISA entries of the round leave as (suffix | new id - 1 << 32) pairs in list order
     // instead of one random store each; the caller takes them to their places through partition levels (construct.hpp: isa_update_by_levels)
     constexpr int TILE = BLOCK * ITEMS;
@@ -2045,11 +2137,26 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
 
     // K2 == nullptr: both keys of a record in one 64-bit word (K1 << kb2 | K2; texts of at most 2^32 characters, one GPU); only
     // equality of K1 matters here (a bucket's number), K2 is the rank of the suffix h further
-    const bool both = K2 == nullptr;
+    const bool both = HEAVY || K2 == nullptr;
     const uint64_t m2 = (~0ull) >> (64 - kb2);
     __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
+    // HEAVY: most tiles of a split round lie inside one heavy run -- one key for all their records (and the two beside them), the suffixes
+    // straight out of the run; the other tiles take their records one by one through the view
+    bool hv_pure = false;
+    T hv_key = 0;
+    uint64_t hv_less = 0;
+    T sa_h[HEAVY ? ITEMS : 1];          // (HEAVY, a tile that is not one heavy run: the suffixes come with the keys)
+    if constexpr (HEAVY) {
+        const ulonglong2 tb = hv.tile_b[tile];        // (the same for the whole workgroup: one scalar load)
+        hv_pure = tb.y != ~0ull;
+        hv_key = (T)tb.x; hv_less = tb.y;
+        if (hv_pure) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) a1[j] = e0 + j < cnt ? hv_key : (T)0;
+        } else heavy_run<T, ITEMS>(hv, e0, cnt, a1, sa_h);
+    } else
     load_run_x<T, ITEMS>(K1, e0, cnt, a1, (T)0, xw);
     if (!both) load_run_x<T, ITEMS>(K2, e0, cnt, a2, (T)0, xw);
     else {
@@ -2063,14 +2170,17 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) {
-        p1 = K1[e0 - 1];
+        if constexpr (HEAVY) { if (hv_pure) p1 = hv_key; else { T v_; heavy_record<T>(hv, e0 - 1, p1, v_); } }
+        else p1 = K1[e0 - 1];
         if (both) { p2 = (T)((uint64_t)p1 & m2); p1 = (T)((uint64_t)p1 >> kb2); } else p2 = K2[e0 - 1];
     }
     else if (e0 == 0 && bd.has_prev) { p1 = bd.prev1; p2 = bd.prev2; }
     bool next_head = true;
     if (e0 + ITEMS <= cnt && (e0 + ITEMS < cnt || bd.has_next)) {
         const bool in = e0 + ITEMS < cnt;
-        T q1 = in ? K1[e0 + ITEMS] : bd.next1, q2 = in ? (both ? (T)0 : K2[e0 + ITEMS]) : bd.next2;
+        T q1 = bd.next1;
+        if (in) { if constexpr (HEAVY) { if (hv_pure) q1 = hv_key; else { T v_; heavy_record<T>(hv, e0 + ITEMS, q1, v_); } } else q1 = K1[e0 + ITEMS]; }
+        T q2 = in ? (both ? (T)0 : K2[e0 + ITEMS]) : bd.next2;
         if (in && both) { q2 = (T)((uint64_t)q1 & m2); q1 = (T)((uint64_t)q1 >> kb2); }
         next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
     }
@@ -2174,6 +2284,26 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if ((T)bd.base > carry) carry = (T)bd.base;
     if (excl > carry) carry = excl;
     T sa[ITEMS];
+    if constexpr (HEAVY) {
+        if (hv_pure) {
+            // the wave's 64 x ITEMS suffixes lie side by side in the heavy run: whole rows of 256 bytes, handed to their threads through LDS like load_run_x does
+            const unsigned lane = lane_id();
+            const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
+            const uint32_t* __restrict__ q = hv.HB + (wb - hv_less) + lane;
+            uint32_t row[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) row[i] = (wb + (uint64_t)i * WAVE + lane < cnt) ? q[i * WAVE] : 0u;
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) { const unsigned s_ = (unsigned)i * WAVE + lane; xw[s_ + (s_ >> 3)] = (T)row[i]; }
+            xrun_order();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) { const unsigned s_ = lane * ITEMS + j; sa[j] = xw[s_ + (s_ >> 3)]; }
+            xrun_order();
+        } else {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sa[j] = sa_h[HEAVY ? j : 0];
+        }
+    } else
     load_run_x<T, ITEMS>(V, e0, cnt, sa, (T)0, xw);
     // a wave whose 64 x ITEMS list entries are neighbours in SA too (a round in which nearly every suffix is unresolved: a tandem repeat, the
     // first rounds of repeated reads) writes SA and the ids through whole rows, like the arrays in list order, instead of entry by entry
