@@ -119,11 +119,12 @@ int psacx_trim(psacx_ctx* ctx);
  *   ISA_UPDATE        1 = one store per record, 2 = partition levels
  *   GATHER            ranks h further of a refinement round: 1 = one fetch per record, 2 = partition levels
  *   NO_HEAVY          no split of a round's records into heavy and light ones
- *   NO_WHOLE          no text-order rounds                                                                                           */
+ *   NO_WHOLE          no text-order rounds
+ *   NO_LAZY_RANKS     the heavy runs of a split round always take the rank of their head and store it                                */
 enum {
     PSACX_OPT_RESET = 0, PSACX_OPT_FORCE_DIET, PSACX_OPT_DIET_CAP, PSACX_OPT_ONE_STAGE, PSACX_OPT_TIES_RADIX, PSACX_OPT_NO_ONE_WORD,
     PSACX_OPT_ONE_WORD_ALWAYS, PSACX_OPT_ONE_WORD_MIN, PSACX_OPT_WIDEN_LAST, PSACX_OPT_NO_DIGIT_BYTES, PSACX_OPT_NO_BUCKET_SORT,
-    PSACX_OPT_ISA_UPDATE, PSACX_OPT_GATHER, PSACX_OPT_NO_HEAVY, PSACX_OPT_NO_WHOLE, PSACX_OPT_COUNT
+    PSACX_OPT_ISA_UPDATE, PSACX_OPT_GATHER, PSACX_OPT_NO_HEAVY, PSACX_OPT_NO_WHOLE, PSACX_OPT_NO_LAZY_RANKS, PSACX_OPT_COUNT
 };
 int psacx_configure(psacx_ctx* ctx, int option, uint64_t value);
 /* Debug shim, the ONLY place where the library looks at the environment, and only when called: resets the options of ctx and sets those

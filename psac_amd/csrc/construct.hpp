@@ -380,9 +380,12 @@ template <typename T> struct IsaLevels {
         PSACX_HIP(c, hipMemsetAsync(cursors, 0, (1024 + (size_t)(n >> WB) + 1) * sizeof(unsigned), c->stream));
         return PSACX_OK;
     }
-    int add(const uint64_t* pairs, uint64_t cnt) {
+    // skip (split rounds, heavy_keys.hpp): per scan tile of the list whether it lies inside a heavy run that keeps its rank -- tiles of such entries are left out
+    int add(const uint64_t* pairs, uint64_t cnt, const ulonglong2* skip = nullptr) {
+        static_assert((PB * PI) % ScanCfg<T>::TILE == 0 || sizeof(T) != 8, "a tile of pairs covers whole scan tiles");
         hipLaunchKernelGGL((partition_packed_kernel<T, PB, PI, 0, CB>), dim3((unsigned)((cnt + PB * PI - 1) / (PB * PI))), dim3(PB), 0, c->stream, (const T*)nullptr,
-                           (const T*)nullptr, pairs, lvl_a, cnt, isa_narrow_shift(lv9, 0), lv9 == 1 ? c1() : c0(), (uint64_t)0);
+                           (const T*)nullptr, pairs, lvl_a, cnt, isa_narrow_shift(lv9, 0), lv9 == 1 ? c1() : c0(), (uint64_t)0, (const unsigned*)nullptr, 0u,
+                           (const uint32_t*)nullptr, (uint64_t)0, (uint64_t)0, skip, skip ? (unsigned)((PB * PI) / ScanCfg<T>::TILE) : 0u);
         PSACX_HIP(c, hipGetLastError());
         return PSACX_OK;
     }
@@ -438,6 +441,7 @@ inline HeavyTabs heavy_tabs(uint64_t* base, unsigned nb) {
     ht.value = base; base += nb;
     ht.less = reinterpret_cast<unsigned long long*>(base); base += nb;
     ht.lstart = base; base += nb + 1;
+    ht.rank = base; base += nb;
     ht.light = reinterpret_cast<unsigned long long*>(base); base += 8;           // (the reservation counters start on a 64-byte line: d_heavy is 256-byte aligned, nb words above are whole lines only by luck -- the padding keeps the counters apart from each other, which is what matters)
     ht.eq = reinterpret_cast<unsigned long long*>(base);
     return ht;
@@ -996,12 +1000,14 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                                            /*summary_ready=*/true, 0, -1, /*v32_in=*/true, /*keep_v32=*/true));
                 {
                     ProfScope ps(c, TC_SORT_SCATTER);
-                    hipLaunchKernelGGL((heavy_plan_kernel<T>), dim3(((unsigned)nb_in + 1 + 255) / 256), dim3(256), 0, c->stream, (uint32_t)nb_in, ht, kb2, (const T*)sl.k1, nlight, w.sc.d_err);
+                    hipLaunchKernelGGL((heavy_plan_kernel<T>), dim3(((unsigned)nb_in + 1 + 255) / 256), dim3(256), 0, c->stream, (uint32_t)nb_in, ht, kb2, (const T*)sl.k1, nlight, w.sc.d_err,
+                                       plist, kn.no_lazy_ranks ? 0 : 1);
                     PSACX_HIP(c, hipGetLastError());
                 }
                 // the round's sorted records are not written out: the kernels below read them through the view
                 hview.bstart = ht.bstart; hview.value = ht.value; hview.less = ht.less; hview.eq = ht.eq; hview.lstart = ht.lstart;
                 hview.SLK = sl.k1; hview.SLV = reinterpret_cast<const uint32_t*>(sl.v); hview.HB = HB; hview.nb = (uint32_t)nb_in; hview.kb2 = kb2;
+                hview.rank = ht.rank;
                 // (what the rebucket kernel writes must not lie where the view reads: the sorted light records are in one array of each pair of the
                 //  light sort, the heavy suffixes in ry.v / ry.k1)
                 hview.tile_b = w.d_htile;
@@ -1117,7 +1123,7 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             ProfScope ps(c, TC_ISA_SCATTER);
             const bool mine = !isa_lv.open;          // (a round in slabs opens the levels itself and closes them after its last slab)
             if (mine) PSACX_TRY(isa_lv.begin(c, w.d_cursors, n, reinterpret_cast<uint64_t*>(w.x.k2), kn));
-            PSACX_TRY(isa_lv.add(isa_pairs, cnt));
+            PSACX_TRY(isa_lv.add(isa_pairs, cnt, merged ? (const ulonglong2*)w.d_htile : (const ulonglong2*)nullptr));
             if (mine) PSACX_TRY(isa_lv.finish(d_isa, reinterpret_cast<uint64_t*>(w.x.k1)));
         }
         if (whole) {

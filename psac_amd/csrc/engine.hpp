@@ -51,6 +51,7 @@ struct Knobs {
     int gather = 0;               // PSACX_OPT_GATHER: 1 = fetch, 2 = levels: how a refinement round gets the ranks h further -- one random fetch per record, or requests through
                                   // partition levels (construct.hpp: gather_by_levels); default (0): levels for rounds of at least n / 8 records in long buckets
     bool no_heavy = false;        // PSACX_OPT_NO_HEAVY: no split of a round's records into heavy and light ones (heavy_keys.hpp; A/B runs)
+    bool no_lazy_ranks = false;   // PSACX_OPT_NO_LAZY_RANKS: every heavy run of a split round takes the rank of its head and stores it (heavy_keys.hpp; A/B runs)
     bool no_whole = false;        // PSACX_OPT_NO_WHOLE: rounds in which nearly every suffix is unresolved take the list of positions too (A/B runs)
     bool widen_last = false;      // PSACX_OPT_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
                                   // tie stage's radix path and the multi-GPU engine read) although the kernels after the sort could read one-word records

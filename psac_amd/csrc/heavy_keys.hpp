@@ -13,6 +13,12 @@
 // where it lies by the kernels that follow (sa_kernels.hpp: HeavyView; last_head_kernel, rebucket_refine_kernel): a tile of the list inside one
 // heavy run takes its suffixes straight out of the run.  A 4 GiB period-1024 tandem repeat: 26 rounds x 6 digit passes over 2^32 records become
 // the sort of about one record in twenty.
+// ISA.  The rank of an unresolved suffix only has to (a) be the same for all members of its bucket and (b) order the buckets -- ANY position
+// inside the bucket's range of SA will do (psac writes the head's, bucketing.hpp:21-53; the final rank of a resolved suffix is its one position
+// either way, and a range minimum over LCP between a position inside bucket A and one inside bucket B is the minimum between their heads: the
+// entries inside unresolved buckets are still unset).  So a heavy run whose members carry a rank that still lies inside the run after the
+// round keeps it -- no ISA store for any of them -- and a run that has to move takes the rank of its MIDDLE, which survives the most shrinking
+// (a tandem repeat's runs lose h members at their front per round: a handful of stores per run and construction instead of one per round).
 // Applies to 64-bit words, lists with at most HEAVY_MAXB buckets (their tables live in LDS) that take the partition levels (long buckets).
 #pragma once
 #include "sa_kernels.hpp"
@@ -30,8 +36,11 @@ struct HeavyTabs {
     unsigned long long* less;  // [nb] light records below the heavy value
     unsigned long long* light; // [1] light records
     uint64_t* lstart;          // [nb + 1] where a bucket's light records start in the sorted light list
-    static size_t words(unsigned nb) { return (size_t)(nb + 1) * 2 + (size_t)nb * (HEAVY_PAD + 2) + 8; }
+    uint64_t* rank;            // [nb] probe: the rank the bucket's members carry in ISA now; plan: the rank its heavy run carries after the round, bit 63
+                               //      set when that is the rank it carries already (HEAVY_KEEP: no ISA entry of the run needs a store)
+    static size_t words(unsigned nb) { return (size_t)(nb + 1) * 2 + (size_t)nb * (HEAVY_PAD + 3) + 8; }
 };
+constexpr uint64_t HEAVY_KEEP = 1ull << 63;
 
 // first list entry whose bucket number is >= b (ord ascends along the list)
 __device__ __forceinline__ uint64_t heavy_lower_bound(const uint32_t* __restrict__ ord, uint64_t cnt, uint32_t b) {
@@ -62,6 +71,7 @@ __global__ void heavy_probe_kernel(const uint32_t* __restrict__ ord, uint64_t cn
     if (x == 0 || (v[0] == v[2] && v[0] != 0)) x = v[0] ? v[0] : v[2];
     ht.value[b] = x;                               // (0 only if the bucket is malformed; such a bucket then has no heavy records at all)
     ht.eq[(size_t)b * HEAVY_PAD] = 0; ht.less[b] = 0;
+    ht.rank[b] = (uint64_t)ISA[(uint64_t)SA[(uint64_t)pos[lo]]];          // the rank every member of the bucket carries now
 }
 
 // The window kernel of gather_by_levels with the split: window w holds counts[w] requests (q | bucket number << 32), bit 63 = fewer than h
@@ -151,8 +161,11 @@ __global__ __launch_bounds__(BLOCK) void window_gather_heavy_kernel(const uint64
 
 // After the sort of the light records: one thread per bucket finds where its light records lie in the sorted list (SLK ascending by
 // (bucket number, B2)) and how many of them come before the heavy value; err is raised when a bucket's records do not add up.
+// ... and whether the bucket's heavy run keeps the rank its members carry (pos = the list: the bucket's first SA position is pos[bstart[b]], all its
+// members are in the list, so it occupies the SA positions from there on)
 template <typename T>
-__global__ void heavy_plan_kernel(uint32_t nb, HeavyTabs ht, unsigned kb2, const T* __restrict__ SLK, uint64_t nlight, unsigned* __restrict__ err) {
+__global__ void heavy_plan_kernel(uint32_t nb, HeavyTabs ht, unsigned kb2, const T* __restrict__ SLK, uint64_t nlight, unsigned* __restrict__ err,
+                                  const T* __restrict__ pos, int lazy) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     auto lower = [&](uint64_t key) { uint64_t lo = 0, hi = nlight; while (lo < hi) { const uint64_t m = lo + ((hi - lo) >> 1); if ((uint64_t)SLK[m] < key) lo = m + 1; else hi = m; } return lo; };
@@ -160,7 +173,10 @@ __global__ void heavy_plan_kernel(uint32_t nb, HeavyTabs ht, unsigned kb2, const
     const uint64_t s = lower((uint64_t)b << kb2), e = b + 1 == nb ? nlight : lower((uint64_t)(b + 1) << kb2);
     ht.lstart[b] = s;
     ht.less[b] = lower(((uint64_t)b << kb2) | ht.value[b]) - s;
-    if ((e - s) + ht.eq[(size_t)b * HEAVY_PAD] != ht.bstart[b + 1] - ht.bstart[b]) atomicOr(err, 2u);
+    const uint64_t eq = ht.eq[(size_t)b * HEAVY_PAD], less = ht.less[b];
+    if ((e - s) + eq != ht.bstart[b + 1] - ht.bstart[b]) atomicOr(err, 2u);
+    const uint64_t first = (uint64_t)pos[ht.bstart[b]] + less, now = ht.rank[b];          // the run takes the SA positions first .. first + eq - 1
+    ht.rank[b] = (lazy && eq && now >= first && now < first + eq) ? (now | HEAVY_KEEP) : first + (lazy ? eq / 2 : 0);
 }
 
 } // namespace psacx

@@ -110,6 +110,7 @@ int psacx_configure(psacx_ctx* c, int option, uint64_t value) {
     case PSACX_OPT_GATHER: if (value > 2) return PSACX_EINVAL; k.gather = (int)value; return PSACX_OK;
     case PSACX_OPT_NO_HEAVY: k.no_heavy = value != 0; return PSACX_OK;
     case PSACX_OPT_NO_WHOLE: k.no_whole = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_LAZY_RANKS: k.no_lazy_ranks = value != 0; return PSACX_OK;
     default: return PSACX_EINVAL;
     }
 }
@@ -122,7 +123,7 @@ int psacx_configure_from_env(psacx_ctx* c) {
         {"PSACX_FORCE_DIET", PSACX_OPT_FORCE_DIET}, {"PSACX_ONE_STAGE", PSACX_OPT_ONE_STAGE}, {"PSACX_TIES_RADIX", PSACX_OPT_TIES_RADIX},
         {"PSACX_NO_ONE_WORD", PSACX_OPT_NO_ONE_WORD}, {"PSACX_ONE_WORD_ALWAYS", PSACX_OPT_ONE_WORD_ALWAYS}, {"PSACX_WIDEN_LAST", PSACX_OPT_WIDEN_LAST},
         {"PSACX_NO_DIGIT_BYTES", PSACX_OPT_NO_DIGIT_BYTES}, {"PSACX_NO_BUCKET_SORT", PSACX_OPT_NO_BUCKET_SORT}, {"PSACX_NO_HEAVY", PSACX_OPT_NO_HEAVY},
-        {"PSACX_NO_WHOLE", PSACX_OPT_NO_WHOLE}};
+        {"PSACX_NO_WHOLE", PSACX_OPT_NO_WHOLE}, {"PSACX_NO_LAZY_RANKS", PSACX_OPT_NO_LAZY_RANKS}};
     (void)psacx_configure(c, PSACX_OPT_RESET, 0);
     for (const auto& f : flags) if (psacx_debug_env(f.name)) (void)psacx_configure(c, f.option, 1);
     if (const char* e = psacx_debug_env("PSACX_DIET_CAP")) (void)psacx_configure(c, PSACX_OPT_DIET_CAP, strtoull(e, nullptr, 10));

@@ -511,9 +511,11 @@ template <typename T> struct HeavyView {
     const unsigned long long* eq = nullptr; const uint64_t* lstart = nullptr;
     const T* SLK = nullptr; const uint32_t* SLV = nullptr; const uint32_t* HB = nullptr;
     uint32_t nb = 0; unsigned kb2 = 0;
-    const ulonglong2* tile_b = nullptr;        // per scan tile whose records, the one before and the one after lie inside ONE heavy run: (their key, less of the bucket);
-                                               // else (0, ~0) (heavy_tiles_kernel)
+    const uint64_t* rank = nullptr;            // per bucket: the rank (0-based) the members of its heavy run carry in ISA after the round; bit 63: they carry it already
+    const ulonglong2* tile_b = nullptr;        // per scan tile whose records, the one before and the one after lie inside ONE heavy run: (their key, less of the bucket
+                                               // | bit 62 when the run keeps its rank); else (0, ~0) (heavy_tiles_kernel)
 };
+constexpr uint64_t HEAVY_VIEW_KEEP = 1ull << 62, HEAVY_RANK_KEEP = 1ull << 63;
 template <typename T>
 __device__ __forceinline__ unsigned heavy_bucket_of(const HeavyView<T>& hv, uint64_t r) {
     unsigned lo = 0, hi = hv.nb;               // last bucket that starts at or before r
@@ -528,14 +530,17 @@ __device__ __forceinline__ void heavy_record(const HeavyView<T>& hv, uint64_t r,
     else { const uint64_t s = hv.lstart[b] + (o < less ? o : o - eq); key = hv.SLK[s]; val = (T)hv.SLV[s]; }
 }
 // ITEMS consecutive records from r0 on (keys and suffixes; zeros from n on): the bucket is looked up once and followed from there
+// hrank[j]: the ISA rank of record j if it is a heavy one (bit j of *hmask), as the plan of the round has it
 template <typename T, int ITEMS>
-__device__ __forceinline__ void heavy_run(const HeavyView<T>& hv, uint64_t r0, uint64_t n, T (&key)[ITEMS], T (&val)[ITEMS]) {
+__device__ __forceinline__ void heavy_run(const HeavyView<T>& hv, uint64_t r0, uint64_t n, T (&key)[ITEMS], T (&val)[ITEMS], uint32_t (&hrank)[ITEMS], unsigned* hmask) {
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { key[j] = 0; val[j] = 0; }
+    for (int j = 0; j < ITEMS; ++j) { key[j] = 0; val[j] = 0; hrank[j] = 0; }
+    *hmask = 0;
     if (r0 >= n) return;
     unsigned b = heavy_bucket_of<T>(hv, r0);
     uint64_t s0 = hv.bstart[b], s1 = hv.bstart[b + 1], less = hv.less[b], eq = hv.eq[b], ls = hv.lstart[b];
     T hk = (T)(((uint64_t)b << hv.kb2) | hv.value[b]);
+    uint32_t hr = (uint32_t)hv.rank[b];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t r = r0 + j;
@@ -544,9 +549,10 @@ __device__ __forceinline__ void heavy_run(const HeavyView<T>& hv, uint64_t r0, u
             ++b;
             s0 = s1; s1 = hv.bstart[b + 1]; less = hv.less[b]; eq = hv.eq[b]; ls = hv.lstart[b];
             hk = (T)(((uint64_t)b << hv.kb2) | hv.value[b]);
+            hr = (uint32_t)hv.rank[b];
         }
         const uint64_t o = r - s0;
-        if (o >= less && o < less + eq) { key[j] = hk; val[j] = (T)hv.HB[r - less]; }
+        if (o >= less && o < less + eq) { key[j] = hk; val[j] = (T)hv.HB[r - less]; hrank[j] = hr; *hmask |= 1u << j; }
         else { const uint64_t s = ls + (o < less ? o : o - eq); key[j] = hv.SLK[s]; val[j] = (T)hv.SLV[s]; }
     }
 }
@@ -570,7 +576,8 @@ __global__ void heavy_tiles_kernel(HeavyView<T> hv, uint64_t cnt, unsigned tile,
     ulonglong2 out; out.x = 0; out.y = ~0ull;
     if (t0 > 0) {
         T key; uint64_t less;
-        if (heavy_pure<T>(hv, t0 - 1, t1, &key, &less)) { out.x = (unsigned long long)key; out.y = less; }
+        if (heavy_pure<T>(hv, t0 - 1, t1, &key, &less))
+            { out.x = (unsigned long long)key; out.y = less | ((hv.rank[(uint64_t)key >> hv.kb2] & HEAVY_RANK_KEEP) ? HEAVY_VIEW_KEEP : 0ull); }
     }
     tile_b[t] = out;
 }
@@ -1252,7 +1259,10 @@ __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __res
                                                                  const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n,
                                                                  unsigned shift, unsigned* __restrict__ cursors, uint64_t koff,
                                                                  const unsigned* __restrict__ in_counts = nullptr, unsigned in_shift = 0,
-                                                                 const uint32_t* __restrict__ req_ord = nullptr, uint64_t req_h = 0, uint64_t n_text = 0) {
+                                                                 const uint32_t* __restrict__ req_ord = nullptr, uint64_t req_h = 0, uint64_t n_text = 0,
+                                                                 const ulonglong2* __restrict__ skip_tiles = nullptr, unsigned skip_per_tile = 0) {
+    // skip_tiles (the ISA entries of a split round, heavy_keys.hpp): this tile covers skip_per_tile scan tiles of the list; when all of them
+    // lie inside heavy runs that keep their ranks (HeavyView::tile_b) there is nothing in it to store
     // in_counts (levels after the first, pairs of a SUBSET of the positions: the ISA update of a refinement round): the class regions of
     // the level before are filled to in_counts[class] only (class = index >> in_shift; a tile lies inside one region)
     constexpr int NCLS = 1 << CB;
@@ -1272,6 +1282,16 @@ __global__ __launch_bounds__(BLOCK) void partition_packed_kernel(const TI* __res
         remain = filled - into < remain ? filled - into : remain;
     }
     const unsigned count = remain < (uint64_t)TILE ? (unsigned)remain : (unsigned)TILE;
+    if (skip_tiles) {
+        bool all = true;
+        for (unsigned q = 0; q < skip_per_tile; ++q) {
+            const uint64_t st = (uint64_t)blockIdx.x * skip_per_tile + q;
+            if (st * (TILE / skip_per_tile) >= n) break;
+            const ulonglong2 tb = skip_tiles[st];
+            all = all && tb.y != ~0ull && (tb.y & HEAVY_VIEW_KEEP) != 0;
+        }
+        if (all) return;                             // (the same for every thread of the workgroup)
+    }
     for (int i = tid; i < NCLS; i += BLOCK) cnt[i] = 0;
     __syncthreads();
     uint64_t rec[ITEMS];
@@ -2148,14 +2168,25 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     T hv_key = 0;
     uint64_t hv_less = 0;
     T sa_h[HEAVY ? ITEMS : 1];          // (HEAVY, a tile that is not one heavy run: the suffixes come with the keys)
+    uint32_t hrank[HEAVY ? ITEMS : 1];  // (... and the ranks the heavy ones among them carry in ISA after the round)
+    unsigned hmask = 0;
+    bool hv_keep = false;               // (HEAVY, a tile inside one heavy run that keeps its rank, beside another such tile: nothing to store into ISA)
+    uint32_t hv_rank = 0;
     if constexpr (HEAVY) {
         const ulonglong2 tb = hv.tile_b[tile];        // (the same for the whole workgroup: one scalar load)
         hv_pure = tb.y != ~0ull;
-        hv_key = (T)tb.x; hv_less = tb.y;
+        hv_key = (T)tb.x; hv_less = tb.y & (HEAVY_VIEW_KEEP - 1);
+        hv_keep = hv_pure && (tb.y & HEAVY_VIEW_KEEP) != 0;
+        if (hv_pure) hv_rank = (uint32_t)hv.rank[(uint64_t)hv_key >> hv.kb2];
+        if (hv_keep) {
+            // the levels take the ISA entries in tiles of two scan tiles (IsaLevels::add) and leave a tile out only when both keep their ranks
+            const uint64_t mate = (uint64_t)tile ^ 1u;
+            if (mate * TILE < cnt) { const ulonglong2 tm = hv.tile_b[mate]; hv_keep = tm.y != ~0ull && (tm.y & HEAVY_VIEW_KEEP) != 0; }
+        }
         if (hv_pure) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) a1[j] = e0 + j < cnt ? hv_key : (T)0;
-        } else heavy_run<T, ITEMS>(hv, e0, cnt, a1, sa_h);
+        } else heavy_run<T, ITEMS>(hv, e0, cnt, a1, sa_h, hrank, &hmask);
     } else
     load_run_x<T, ITEMS>(K1, e0, cnt, a1, (T)0, xw);
     if (!both) load_run_x<T, ITEMS>(K2, e0, cnt, a2, (T)0, xw);
@@ -2343,9 +2374,14 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     store_run_x<T, ITEMS>(ids_out, e0, cnt, id, xw);
     if constexpr (!DIST && sizeof(T) == 8) {
-        if (pairs_out) {
+        if (pairs_out && !(HEAVY && hv_keep)) {          // (a tile of a run that keeps its rank: the levels skip its entries, heavy_keys.hpp)
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sa[j] = (T)((uint64_t)(uint32_t)sa[j] | ((uint64_t)(uint32_t)(id[j] - 1) << 32));
+            for (int j = 0; j < ITEMS; ++j) {
+                uint32_t rk = (uint32_t)(id[j] - 1);
+                // (split rounds: a heavy record takes the rank of its run -- the one it carries already, or that of the run's middle)
+                if constexpr (HEAVY) { if (hv_pure) rk = hv_rank; else if (hmask & (1u << j)) rk = hrank[HEAVY ? j : 0]; }
+                sa[j] = (T)((uint64_t)(uint32_t)sa[j] | ((uint64_t)rk << 32));
+            }
             store_run_x<T, ITEMS>(reinterpret_cast<T*>(pairs_out), e0, cnt, sa, xw);
         }
     }

@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.RandomState(seed)
 ctx = psac_amd.Context(0)
-KNOBS = ("PSACX_GATHER", "PSACX_NO_HEAVY", "PSACX_FORCE_DIET", "PSACX_DIET_CAP", "PSACX_NO_WHOLE", "PSACX_ISA_UPDATE")
+KNOBS = ("PSACX_GATHER", "PSACX_NO_HEAVY", "PSACX_FORCE_DIET", "PSACX_DIET_CAP", "PSACX_NO_WHOLE", "PSACX_ISA_UPDATE", "PSACX_NO_LAZY_RANKS")
 
 
 def construct(text, env):
@@ -65,6 +65,8 @@ while time.time() < t_end:
         env["PSACX_NO_HEAVY"] = "1"
     if rng.rand() < 0.2:
         env["PSACX_ISA_UPDATE"] = "stores"
+    if rng.rand() < 0.15:
+        env["PSACX_NO_LAZY_RANKS"] = "1"
     try:
         (SA, ISA, LCP), st, log = construct(text, env)
     except psac_amd.PsacxError as e:
