@@ -512,6 +512,7 @@ template <typename T> struct HeavyView {
     const T* SLK = nullptr; const uint32_t* SLV = nullptr; const uint32_t* HB = nullptr;
     uint32_t nb = 0; unsigned kb2 = 0;
     const uint64_t* rank = nullptr;            // per bucket: the rank (0-based) the members of its heavy run carry in ISA after the round; bit 63: they carry it already
+    int pure_elsewhere = 0;                    // rebucket_refine_kernel leaves the tiles inside one heavy run to rebucket_pure_kernel
     const ulonglong2* tile_b = nullptr;        // per scan tile whose records, the one before and the one after lie inside ONE heavy run: (their key, less of the bucket
                                                // | bit 62 when the run keeps its rank); else (0, ~0) (heavy_tiles_kernel)
 };
@@ -2178,6 +2179,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
         hv_key = (T)tb.x; hv_less = tb.y & (HEAVY_VIEW_KEEP - 1);
         hv_keep = hv_pure && (tb.y & HEAVY_VIEW_KEEP) != 0;
         if (hv_pure) hv_rank = (uint32_t)hv.rank[(uint64_t)hv_key >> hv.kb2];
+        if (hv_pure && hv.pure_elsewhere) return;          // (rebucket_pure_kernel takes the tiles inside one heavy run)
         if (hv_keep) {
             // the levels take the ISA entries in tiles of two scan tiles (IsaLevels::add) and leave a tile out only when both keep their ranks
             const uint64_t mate = (uint64_t)tile ^ 1u;
@@ -2385,6 +2387,48 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             store_run_x<T, ITEMS>(reinterpret_cast<T*>(pairs_out), e0, cnt, sa, xw);
         }
     }
+}
+
+// rebucket_refine_kernel for the tiles of a split round that lie inside ONE heavy run (with the record before and the one after: HeavyView::tile_b) -- in a
+// tandem repeat nearly all of them.  Such a tile has no bucket head, no new LCP entry and one id, the carry; what is left is moving its suffixes from the run
+// to SA and writing the id three times: no ranking, no queue, a fifth of the registers of the general kernel (which runs one workgroup per CU at 190).
+// Element e of every array is handled by one thread, rows of 64 x 8 bytes per wave.
+template <typename T, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void rebucket_pure_kernel(HeavyView<T> hv, const T* __restrict__ pos, uint64_t cnt, T* __restrict__ SA, T* __restrict__ Bsa,
+                                                              T* __restrict__ ISA, T* __restrict__ ids_out, const uint64_t* __restrict__ carry_in,
+                                                              uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t* __restrict__ pairs_out) {
+    constexpr int TILE = BLOCK * ITEMS;
+    const uint64_t tile = blockIdx.x;
+    const ulonglong2 tb = hv.tile_b[tile];
+    if (tb.y == ~0ull) return;
+    const uint64_t base = tile * TILE, less = tb.y & (HEAVY_VIEW_KEEP - 1);
+    const unsigned count = cnt - base < (uint64_t)TILE ? (unsigned)(cnt - base) : (unsigned)TILE;
+    const T id = (T)carry_in[tile];
+    const uint32_t rank = (uint32_t)hv.rank[tb.x >> hv.kb2];
+    bool keep = (tb.y & HEAVY_VIEW_KEEP) != 0;
+    if (keep) {          // (the levels leave out the entries of two scan tiles that both keep their ranks, IsaLevels::add)
+        const uint64_t mate = tile ^ 1u;
+        if (mate * TILE < cnt) { const ulonglong2 tm = hv.tile_b[mate]; keep = tm.y != ~0ull && (tm.y & HEAVY_VIEW_KEEP) != 0; }
+    }
+    T p[ITEMS]; uint32_t s[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = threadIdx.x + (unsigned)i * BLOCK;
+        p[i] = 0; s[i] = 0;
+        if (loc < count) { p[i] = pos[base + loc]; s[i] = hv.HB[base + loc - less]; }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const unsigned loc = threadIdx.x + (unsigned)i * BLOCK;
+        if (loc < count) {
+            SA[(uint64_t)p[i]] = (T)s[i];
+            Bsa[(uint64_t)p[i]] = id;
+            ids_out[base + loc] = id;
+            if (pairs_out) { if (!keep) pairs_out[base + loc] = (uint64_t)s[i] | ((uint64_t)rank << 32); }
+            else if (ISA) ISA[s[i]] = id - 1;
+        }
+    }
+    if (threadIdx.x == 0) { n_active[tile] = count; n_unf[tile] = 0; }
 }
 
 // ------------------------------------------------------------------ K14
