@@ -61,11 +61,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 #     profiles/r5j_bench_{fetch,write}_4gib_u64.txt: (2 x 17325130 + 40009069) KiB = 76451152896 bytes (1.063 x the algorithmic 16.75 bytes per record and pass)
 # ... round 5, final code (every bucket pass writes a byte: three the next digit, the last the byte the tie stage reads),
 #     profiles/r5n_bench_{fetch,write}_4gib_u64.txt: (2 x 17325395 + 41356537) KiB = 77831502848 bytes (1.066 x the algorithmic 17 bytes per record and pass)
+# ... round 6 (same kernels; the run of the final code), profiles/r6_bench_{fetch,write}_4gib_u64.txt: (2 x 17325391 + 41437855) KiB = 77914764288 bytes (1.067 x)
 # Every entry names the committed profile it was read from (roofline.traffic_profile).
 TRAFFIC = {(1, 1 << 28, 32): (6553287372, "profiles/r01_pmc_fetch_size.txt + r01_pmc_write_size.txt"),
            (2, 1 << 28, 32): (4184907503, "profiles/r01d_pmc_fetch_size.txt + r01d_pmc_write_size.txt"),
            (2, 1 << 32, 64): (117173345280, "profiles/r04s_pmc_fetch_size_4gib_u64.txt + r04s_pmc_write_size_4gib_u64.txt"),
-           (3, 1 << 32, 64): (77831502848, "profiles/r5n_bench_fetch_4gib_u64.txt + r5n_bench_write_4gib_u64.txt")}
+           (3, 1 << 32, 64): (77914764288, "profiles/r6_bench_fetch_4gib_u64.txt + r6_bench_write_4gib_u64.txt")}
 
 
 def parse():
