@@ -27,6 +27,8 @@ namespace psacx {
 
 constexpr unsigned AW_PEND = 0xFFFFu;       // the answer lies beyond the edge of the tile
 constexpr unsigned AW_DONE = 0xFFFEu;       // written by the search beyond the edge: the store pass leaves it alone
+constexpr unsigned AW_SLOT0 = 0xFF00u;      // furthest_eq: AW_SLOT0 + s = the answer lies beyond the edge and has been looked up already: entry s of slot0 / slot1
+constexpr unsigned AW_NSLOT = 64;           // (a tile with more such elements -- one falling run -- leaves the others at AW_PEND: they ask one by one)
 
 template <typename T> struct AnsvWaveShared {
     static constexpr int RUN = 16, TILE = 64 * RUN;
@@ -34,6 +36,8 @@ template <typename T> struct AnsvWaveShared {
     __attribute__((aligned(16))) uint16_t ans[TILE];          // tile position of every element's answer (nearest types; nearest <= for furthest_eq)
     __attribute__((aligned(16))) uint16_t q[TILE];            // queue of open elements; afterwards the far ends of the chains (furthest_eq)
     AnsvMemo<T> memo[2];                                      // answers beyond the edge, left / right side
+    unsigned long long slot0[AW_NSLOT];                       // furthest_eq, per element without a <= element in the tile: its answer beyond the edge,
+    unsigned long long slot1[AW_NSLOT];                       // ... and the far end of the run of its value beyond the edge (ANSV_NOCONT: the run ends with it)
 };
 
 // rightmost (LEFT) / leftmost index of the 16 values that qualifies (-1: none)
@@ -98,6 +102,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     // ---- 1. the run in registers and in LDS, all pairs
     T mn;
     unsigned total;
+    unsigned nslots = 0;                          // (furthest_eq) elements whose answers beyond the edge have been looked up, wave-uniform
     {
         T a[16];
         answ_fetch<T>(in, n, t, a);
@@ -152,6 +157,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     //      qualifies (descent over window minima of the 64 run minima) and the search inside it.
     {
         unsigned total2 = 0;
+        nslots = 0;
 #pragma unroll 1
         for (unsigned i0 = 0; i0 < total; i0 += 64) {
             const unsigned i = i0 + lane;
@@ -190,10 +196,29 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
                 const int j = answ_in_run<T, LEFT>(b, x, strict);
                 if (found) { pos = tr * RUN + (unsigned)(j < 0 ? 0 : j); if (pos >= n_rel) pos = AW_PEND; }
             }
+            const bool pend = valid && pos == AW_PEND;
             if (!FUR) {
-                const bool pend = valid && pos == AW_PEND;
                 ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, type, 0u, memo, nonsv, out, tile_base + e, SKIP);
                 if (pend) pos = AW_DONE;
+            } else {
+                // furthest_eq: both answers beyond the edge are looked up here, once per distinct value of a queue step, and kept per
+                // element: step 4 then reads them lane by lane (a walk per group of 64 elements there cost a third of the pass)
+                uint64_t m = __ballot(pend);
+                if (m) {
+                    const unsigned slot = nslots + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    nslots += (unsigned)__builtin_popcountll(m);
+                    const bool fits = pend && slot < AW_NSLOT;
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        const T vq = shfl<T>(x, src);
+                        const uint64_t r0 = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, 2, 0u, memo, SKIP);
+                        const uint64_t r1 = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, 2, 1u, memo, SKIP);
+                        const bool mine = pend && x == vq;
+                        if (mine && fits) { sh.slot0[slot] = r0 == NSV_NONE ? nonsv : r0; sh.slot1[slot] = r1; }
+                        m &= ~__ballot(mine);
+                    }
+                    if (fits) pos = AW_SLOT0 + slot;
+                }
             }
             if (valid) sh.ans[e] = (uint16_t)pos;
         }
@@ -216,9 +241,9 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
 #pragma unroll
             for (unsigned k = 0; k < 8; ++k) { ne[k] = sh.ans[(h * 8 + k) * 64 + lane]; xe[k] = sh.v[(h * 8 + k) * 64 + lane]; }
 #pragma unroll
-            for (unsigned k = 0; k < 8; ++k) xn[k] = sh.v[ne[k] != AW_PEND ? ne[k] : 0u];
+            for (unsigned k = 0; k < 8; ++k) xn[k] = sh.v[ne[k] < AW_SLOT0 ? ne[k] : 0u];
 #pragma unroll
-            for (unsigned k = 0; k < 8; ++k) sh.q[(h * 8 + k) * 64 + lane] = (uint16_t)((ne[k] != AW_PEND && xn[k] == xe[k]) ? ne[k] : (h * 8 + k) * 64 + lane);
+            for (unsigned k = 0; k < 8; ++k) sh.q[(h * 8 + k) * 64 + lane] = (uint16_t)((ne[k] < AW_SLOT0 && xn[k] == xe[k]) ? ne[k] : (h * 8 + k) * 64 + lane);
         }
         xrun_order();
         for (;;) {
@@ -237,26 +262,39 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
             if (!__ballot(changed)) break;
         }
         // the answer of e: the far end of the chain of its nearest <= element; a chain whose far end inside the tile has ITS nearest <=
-        // element beyond the edge may go on there (asked per value); an element without a <= element in the tile asks for everything
+        // element beyond the edge may go on there; an element without a <= element in the tile has its whole answer there (both looked
+        // up by the queue loop: slot0 / slot1)
+        const bool overflow = nslots > AW_NSLOT;
 #pragma unroll 1
         for (unsigned h = 0; h < 4; ++h) {            // four elements at a time
-            unsigned ne[4], r[4], ar[4]; T x[4], u[4];
+            unsigned ne[4], r[4], ar[4];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) { ne[k] = sh.ans[(h * 4 + k) * 64 + lane]; x[k] = sh.v[(h * 4 + k) * 64 + lane]; }
+            for (unsigned k = 0; k < 4; ++k) ne[k] = sh.ans[(h * 4 + k) * 64 + lane];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) r[k] = ne[k] != AW_PEND ? sh.q[ne[k]] : 0u;
+            for (unsigned k = 0; k < 4; ++k) r[k] = ne[k] < AW_SLOT0 ? sh.q[ne[k]] : 0u;
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) { ar[k] = sh.ans[r[k]]; u[k] = sh.v[r[k]]; }
+            for (unsigned k = 0; k < 4; ++k) ar[k] = sh.ans[r[k]];
 #pragma unroll
             for (unsigned k = 0; k < 4; ++k) {
                 const unsigned e = (h * 4 + k) * 64 + lane;
                 const uint64_t g = tile_base + e;
                 const bool in_range = e < n_rel;
-                const bool pend = in_range && ne[k] == AW_PEND;
-                const bool cont = in_range && ne[k] != AW_PEND && ar[k] == AW_PEND;
-                if (in_range && !pend) out[g] = tile_base + r[k];
-                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x[k], 2, 0u, memo, nonsv, out, g, SKIP);
-                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, u[k], 2, 1u, memo, nonsv, out, g, SKIP);
+                const bool beyond = ne[k] >= AW_SLOT0;                       // no <= element in the tile
+                const unsigned code = beyond ? ne[k] : ar[k];               // (the element itself / the far end of its chain)
+                const bool looked_up = code >= AW_SLOT0 && code < AW_SLOT0 + AW_NSLOT;
+                uint64_t res = tile_base + r[k];
+                if (looked_up) {
+                    const uint64_t far = beyond ? sh.slot0[code - AW_SLOT0] : sh.slot1[code - AW_SLOT0];
+                    if (beyond || far != ANSV_NOCONT) res = far;
+                }
+                if (in_range && (!beyond || looked_up)) out[g] = res;
+                if (overflow) {
+                    const bool pend = in_range && ne[k] == AW_PEND;
+                    const bool cont = in_range && !beyond && ar[k] == AW_PEND;
+                    const T x = sh.v[e], u = sh.v[r[k]];
+                    ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, 2, 0u, memo, nonsv, out, g, SKIP);
+                    ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, u, 2, 1u, memo, nonsv, out, g, SKIP);
+                }
             }
         }
     }
@@ -292,7 +330,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
             if (kind == 1 && u < x) { if (lane == 0) { memo.res[idx] = ANSV_NOCONT; memo.first[idx] = gp; } continue; }
             // the chain of value u from j: its far end inside the tile, and whether it may go on beyond the tile
             const unsigned r = sh.q[j];
-            const bool at_edge = sh.ans[r] == AW_PEND;
+            const bool at_edge = sh.ans[r] >= AW_SLOT0;
             uint64_t res = tile_base + r;
             bool keep = true;
             if (at_edge) {

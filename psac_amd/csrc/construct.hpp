@@ -1106,7 +1106,6 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
             KeyShape split; split.lc = kb2; split.c1 = split.c2 = 0; split.spec = 0;       // (last_head_kernel: where a one-word key divides)
             PSACX_TRY((run_carries<T, true>(c, w, sorted.k1, sorted.k2, plist, cnt, nullptr, split, merged ? &hview : nullptr)));
             if (merged) {
-                hview.pure_elsewhere = 1;
                 if constexpr (sizeof(T) == 8)
                     hipLaunchKernelGGL((rebucket_pure_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS>), dim3((unsigned)ntiles), dim3(ScanCfg<T>::BLOCK), 0, c->stream, hview, plist, cnt,
                                        d_sa, w.bsa, d_isa, ids, (const uint64_t*)w.d_carry, w.d_nact, w.d_nunf, isa_pairs);

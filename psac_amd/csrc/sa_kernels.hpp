@@ -512,7 +512,6 @@ template <typename T> struct HeavyView {
     const T* SLK = nullptr; const uint32_t* SLV = nullptr; const uint32_t* HB = nullptr;
     uint32_t nb = 0; unsigned kb2 = 0;
     const uint64_t* rank = nullptr;            // per bucket: the rank (0-based) the members of its heavy run carry in ISA after the round; bit 63: they carry it already
-    int pure_elsewhere = 0;                    // rebucket_refine_kernel leaves the tiles inside one heavy run to rebucket_pure_kernel
     const ulonglong2* tile_b = nullptr;        // per scan tile whose records, the one before and the one after lie inside ONE heavy run: (their key, less of the bucket
                                                // | bit 62 when the run keeps its rank); else (0, ~0) (heavy_tiles_kernel)
 };
@@ -2163,32 +2162,14 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     __shared__ T xp[sizeof(T) == 8 ? (BLOCK / WAVE) * XRUN_WORDS<ITEMS>::N : 1];          // runs through whole rows of a wave (dev_common.hpp: load_run_x)
     T* const xw = xp + (threadIdx.x / WAVE) * XRUN_WORDS<ITEMS>::N;
     T a1[ITEMS], a2[ITEMS], ps[ITEMS];
-    // HEAVY: most tiles of a split round lie inside one heavy run -- one key for all their records (and the two beside them), the suffixes
-    // straight out of the run; the other tiles take their records one by one through the view
-    bool hv_pure = false;
-    T hv_key = 0;
-    uint64_t hv_less = 0;
-    T sa_h[HEAVY ? ITEMS : 1];          // (HEAVY, a tile that is not one heavy run: the suffixes come with the keys)
+    // HEAVY: most tiles of a split round lie inside one heavy run and belong to rebucket_pure_kernel; the tiles here take their records
+    // one by one through the view
+    T sa_h[HEAVY ? ITEMS : 1];          // (HEAVY: the suffixes come with the keys)
     uint32_t hrank[HEAVY ? ITEMS : 1];  // (... and the ranks the heavy ones among them carry in ISA after the round)
     unsigned hmask = 0;
-    bool hv_keep = false;               // (HEAVY, a tile inside one heavy run that keeps its rank, beside another such tile: nothing to store into ISA)
-    uint32_t hv_rank = 0;
     if constexpr (HEAVY) {
-        const ulonglong2 tb = hv.tile_b[tile];        // (the same for the whole workgroup: one scalar load)
-        hv_pure = tb.y != ~0ull;
-        hv_key = (T)tb.x; hv_less = tb.y & (HEAVY_VIEW_KEEP - 1);
-        hv_keep = hv_pure && (tb.y & HEAVY_VIEW_KEEP) != 0;
-        if (hv_pure) hv_rank = (uint32_t)hv.rank[(uint64_t)hv_key >> hv.kb2];
-        if (hv_pure && hv.pure_elsewhere) return;          // (rebucket_pure_kernel takes the tiles inside one heavy run)
-        if (hv_keep) {
-            // the levels take the ISA entries in tiles of two scan tiles (IsaLevels::add) and leave a tile out only when both keep their ranks
-            const uint64_t mate = (uint64_t)tile ^ 1u;
-            if (mate * TILE < cnt) { const ulonglong2 tm = hv.tile_b[mate]; hv_keep = tm.y != ~0ull && (tm.y & HEAVY_VIEW_KEEP) != 0; }
-        }
-        if (hv_pure) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) a1[j] = e0 + j < cnt ? hv_key : (T)0;
-        } else heavy_run<T, ITEMS>(hv, e0, cnt, a1, sa_h, hrank, &hmask);
+        if (hv.tile_b[tile].y != ~0ull) return;        // (the same for the whole workgroup: one scalar load)
+        heavy_run<T, ITEMS>(hv, e0, cnt, a1, sa_h, hrank, &hmask);
     } else
     load_run_x<T, ITEMS>(K1, e0, cnt, a1, (T)0, xw);
     if (!both) load_run_x<T, ITEMS>(K2, e0, cnt, a2, (T)0, xw);
@@ -2203,7 +2184,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     T p1 = 0, p2 = 0;
     if (e0 > 0 && e0 - 1 < cnt) {
-        if constexpr (HEAVY) { if (hv_pure) p1 = hv_key; else { T v_; heavy_record<T>(hv, e0 - 1, p1, v_); } }
+        if constexpr (HEAVY) { T v_; heavy_record<T>(hv, e0 - 1, p1, v_); }
         else p1 = K1[e0 - 1];
         if (both) { p2 = (T)((uint64_t)p1 & m2); p1 = (T)((uint64_t)p1 >> kb2); } else p2 = K2[e0 - 1];
     }
@@ -2212,7 +2193,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if (e0 + ITEMS <= cnt && (e0 + ITEMS < cnt || bd.has_next)) {
         const bool in = e0 + ITEMS < cnt;
         T q1 = bd.next1;
-        if (in) { if constexpr (HEAVY) { if (hv_pure) q1 = hv_key; else { T v_; heavy_record<T>(hv, e0 + ITEMS, q1, v_); } } else q1 = K1[e0 + ITEMS]; }
+        if (in) { if constexpr (HEAVY) { T v_; heavy_record<T>(hv, e0 + ITEMS, q1, v_); } else q1 = K1[e0 + ITEMS]; }
         T q2 = in ? (both ? (T)0 : K2[e0 + ITEMS]) : bd.next2;
         if (in && both) { q2 = (T)((uint64_t)q1 & m2); q1 = (T)((uint64_t)q1 >> kb2); }
         next_head = (q1 != a1[ITEMS - 1]) || (q2 != a2[ITEMS - 1]) || q2 == 0;
@@ -2318,24 +2299,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     if (excl > carry) carry = excl;
     T sa[ITEMS];
     if constexpr (HEAVY) {
-        if (hv_pure) {
-            // the wave's 64 x ITEMS suffixes lie side by side in the heavy run: whole rows of 256 bytes, handed to their threads through LDS like load_run_x does
-            const unsigned lane = lane_id();
-            const uint64_t wb = e0 - (uint64_t)lane * ITEMS;
-            const uint32_t* __restrict__ q = hv.HB + (wb - hv_less) + lane;
-            uint32_t row[ITEMS];
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) row[i] = (wb + (uint64_t)i * WAVE + lane < cnt) ? q[i * WAVE] : 0u;
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { const unsigned s_ = (unsigned)i * WAVE + lane; xw[s_ + (s_ >> 3)] = (T)row[i]; }
-            xrun_order();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { const unsigned s_ = lane * ITEMS + j; sa[j] = xw[s_ + (s_ >> 3)]; }
-            xrun_order();
-        } else {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sa[j] = sa_h[HEAVY ? j : 0];
-        }
+        for (int j = 0; j < ITEMS; ++j) sa[j] = sa_h[HEAVY ? j : 0];
     } else
     load_run_x<T, ITEMS>(V, e0, cnt, sa, (T)0, xw);
     // a wave whose 64 x ITEMS list entries are neighbours in SA too (a round in which nearly every suffix is unresolved: a tandem repeat, the
@@ -2376,12 +2341,12 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     }
     store_run_x<T, ITEMS>(ids_out, e0, cnt, id, xw);
     if constexpr (!DIST && sizeof(T) == 8) {
-        if (pairs_out && !(HEAVY && hv_keep)) {          // (a tile of a run that keeps its rank: the levels skip its entries, heavy_keys.hpp)
+        if (pairs_out) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 uint32_t rk = (uint32_t)(id[j] - 1);
                 // (split rounds: a heavy record takes the rank of its run -- the one it carries already, or that of the run's middle)
-                if constexpr (HEAVY) { if (hv_pure) rk = hv_rank; else if (hmask & (1u << j)) rk = hrank[HEAVY ? j : 0]; }
+                if constexpr (HEAVY) { if (hmask & (1u << j)) rk = hrank[HEAVY ? j : 0]; }
                 sa[j] = (T)((uint64_t)(uint32_t)sa[j] | ((uint64_t)rk << 32));
             }
             store_run_x<T, ITEMS>(reinterpret_cast<T*>(pairs_out), e0, cnt, sa, xw);
