@@ -580,24 +580,20 @@ void ansv_seq(const T* in, uint64_t n, int left, uint64_t nonsv, uint64_t* out) 
 template <typename T>
 void ansv_typed(const T* in, uint64_t n, int left, int type, uint64_t nonsv, uint64_t* out) {
     if (type == 0) { ansv_seq<T>(in, n, left, nonsv, out); return; }
-    // stack of indices whose values are non-decreasing towards the top
+    // stack of indices whose values are non-decreasing towards the top; run[k] = the lowest stack position that holds the same value
+    // as position k with only equal values between (the walk "on through equal values" of furthest_eq, remembered instead of repeated:
+    // an array whose minimum recurs without anything smaller between keeps every occurrence on the stack, and walking down through
+    // them for every element is quadratic -- the many-tile ANSV tests of round 6 use such arrays)
     std::vector<uint64_t> st;
+    std::vector<uint64_t> run;
     for (uint64_t t = 0; t < n; ++t) {
         uint64_t i = left ? t : n - 1 - t;
         // pop strictly larger elements
-        while (!st.empty() && in[st.back()] > in[i]) st.pop_back();
+        while (!st.empty() && in[st.back()] > in[i]) { st.pop_back(); run.pop_back(); }
         // st.back() (if any) has value <= in[i]
-        if (type == 1) {
-            out[i] = st.empty() ? nonsv : st.back();
-        } else {
-            if (st.empty()) out[i] = nonsv;
-            else {
-                size_t p = st.size();
-                T v = in[st[p - 1]];
-                while (p > 1 && in[st[p - 2]] == v) --p;
-                out[i] = st[p - 1];
-            }
-        }
+        if (type == 1) out[i] = st.empty() ? nonsv : st.back();
+        else out[i] = st.empty() ? nonsv : st[run.back()];
+        run.push_back(!st.empty() && in[st.back()] == in[i] ? run.back() : (uint64_t)st.size());
         st.push_back(i);
     }
 }

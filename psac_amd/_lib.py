@@ -26,6 +26,8 @@ MULTI_FORCE_WIRE, MULTI_NO_RCCL, MULTI_SHM = 1, 2, 4
 # the Python wrappers call the debug shims psacx_configure_from_env / psacx_multi_configure_from_env before every call that runs the engine,
 # so that PSACX_* variables select the forms of single stages, and read the transport variables when a multi-GPU context is made.
 ENV_KNOBS = bool(os.environ.get("PSACX_ENV_KNOBS"))
+if ENV_KNOBS and os.environ.get("PSACX_LIB"):          # (tools/experiments: a variant build of the library, e.g. with parts of a kernel left out to time them)
+    LIB_PATH = os.environ["PSACX_LIB"]
 
 EXPORTS = [
     "psacx_create", "psacx_destroy", "psacx_strerror", "psacx_last_hip_error", "psacx_trim", "psacx_configure", "psacx_configure_from_env", "psacx_debug_env",

@@ -10,14 +10,16 @@
 
 namespace psacx {
 
-constexpr unsigned ANSV_MEMO = 16;
+#ifndef AW_MEMO_ENTRIES
+#define AW_MEMO_ENTRIES 16
+#endif
+constexpr unsigned ANSV_MEMO = AW_MEMO_ENTRIES;
 constexpr uint64_t ANSV_NOCONT = ~0ull - 1;      // a run of equal values does not continue beyond the tile edge
 
 
 template <typename T> struct AnsvMemo {
     T val[ANSV_MEMO];
     unsigned long long res[ANSV_MEMO];      // the answer
-    unsigned long long first[ANSV_MEMO];    // the nearest qualifying element the answer was derived from (NSV_NONE: none)
     unsigned kind[ANSV_MEMO];
     unsigned ready[ANSV_MEMO];
     unsigned cnt;
@@ -89,39 +91,67 @@ __device__ __forceinline__ bool ansv_memo_find(AnsvMemo<T>& m, T v, unsigned kin
     *res = m.res[__builtin_ctzll(b)];
     return true;
 }
+// (whole wave) a new entry: at the end of the table, else in the place of a dropped one, else in the place of the LARGEST value held if v is
+// smaller -- the values asked for beyond a tile edge are prefix minima, and it is the small ones that are asked for again tile after tile.
+// (Round 5 dropped what came after the table had filled: on an LCP array with more than 16 distinct values at tile edges the later ones
+// walked the pyramid every time: 0.1 of 2.7 ms.)
 template <typename T>
-__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind, uint64_t res, uint64_t first) {
-    if (lane_id() == 0) {
-        const unsigned idx = atomicAdd(&m.cnt, 1u);
-        if (idx < ANSV_MEMO) {
-            m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res; m.first[idx] = first;
-            __hip_atomic_store(&m.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind, uint64_t res) {
+    const unsigned lane = lane_id();
+    const unsigned c = __hip_atomic_load(&m.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned idx = c;
+    if (c >= ANSV_MEMO) {
+        const bool in = lane < ANSV_MEMO;
+        const bool dead = in && __hip_atomic_load(&m.ready[in ? lane : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+        const T key = in ? m.val[lane] : (T)0;
+        const uint64_t d = __ballot(dead);
+        if (d) idx = (unsigned)__builtin_ctzll(d);
+        else {
+            const T mx = shfl<T>(wave_scan_inclusive<T>(key, OpMax()), 63);
+            if (!(v < mx)) return;
+            idx = (unsigned)__builtin_ctzll(__ballot(in && key == mx));
         }
+    }
+    if (lane == 0) {
+        m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res;
+        __hip_atomic_store(&m.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (c < ANSV_MEMO) __hip_atomic_store(&m.cnt, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-// A workgroup walks its tiles in ascending order and carries the shared answers from tile to tile (wave 0, between
-// two tiles, while the LDS arrays of the finished tile are still in place).
-// Right side: an answer stays true while the element it was derived from lies beyond the right edge of the next tile.
+// furthest_eq keeps ONE entry per value v: res = the answer beyond the edge for an element of value v that has no <= element in its tile (the
+// far end of the chain that starts at the nearest <= element there; NSV_NONE: nothing there), kind = 1 when that nearest element has
+// the value v itself -- a run of v's inside the tile then goes on to the same far end, otherwise it ends inside the tile.  (Two entries per
+// value, one per question, halved the values the table holds and walked the pyramid twice per value: 0.5 of 4.3 ms of the psac -t pair.)
 template <typename T>
-__device__ __forceinline__ void ansv_carry_right(AnsvMemo<T>& m, uint64_t next_end) {
+__device__ __forceinline__ bool ansv_memo_find_value(AnsvMemo<T>& m, T v, uint64_t* res, unsigned* kind) {
     const unsigned lane = lane_id();
-    const unsigned c = m.cnt < ANSV_MEMO ? m.cnt : ANSV_MEMO;
-    if (lane < c && m.ready[lane] && !(m.first[lane] == NSV_NONE || m.first[lane] >= next_end)) m.ready[lane] = 0;
+    unsigned c = __hip_atomic_load(&m.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (c > ANSV_MEMO) c = ANSV_MEMO;
+    bool hit = false;
+    if (lane < c && __hip_atomic_load(&m.ready[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) hit = m.val[lane] == v;
+    const uint64_t b = __ballot(hit);
+    if (!b) return false;
+    *res = m.res[__builtin_ctzll(b)];
+    *kind = m.kind[__builtin_ctzll(b)];
+    return true;
 }
-// makes room when the table is nearly full of dropped entries (one lane; rare)
-template <typename T>
-__device__ __forceinline__ void ansv_memo_compact(AnsvMemo<T>& m) {
-    if (m.cnt < ANSV_MEMO - 4) return;
-    const unsigned c = m.cnt < ANSV_MEMO ? m.cnt : ANSV_MEMO;
-    unsigned o = 0;
-    for (unsigned i = 0; i < c; ++i) {
-        if (!m.ready[i]) continue;
-        if (o != i) { m.val[o] = m.val[i]; m.kind[o] = m.kind[i]; m.res[o] = m.res[i]; m.first[o] = m.first[i]; m.ready[o] = 1; }
-        ++o;
+template <typename T, bool LEFT>
+__device__ __forceinline__ uint64_t ansv_global_fur(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end, T v,
+                                                    AnsvMemo<T>& memo, int skip, bool* run_goes_on) {
+    uint64_t r; unsigned k;
+    if (ansv_memo_find_value<T>(memo, v, &r, &k)) { *run_goes_on = k != 0; return r; }
+    const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
+    const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
+    uint64_t j = NSV_NONE;
+    r = NSV_NONE; k = 0;
+    if (!edge) {
+        j = nsv_search_wave<T, LEFT>(P, start, v, false, skip);
+        if (j != NSV_NONE) { r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2); k = P.lvl[0][j] == v ? 1u : 0u; }
     }
-    for (unsigned i = o; i < ANSV_MEMO; ++i) m.ready[i] = 0;
-    m.cnt = o;
+    ansv_memo_add<T>(memo, v, k, r);
+    *run_goes_on = k != 0;
+    return r;
 }
 
 // Answer of a search that leaves the tile (whole wave, wave-uniform arguments).  kind 0: the typed nearest
@@ -132,21 +162,16 @@ template <typename T, bool LEFT>
 __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
                                                 T v, int type, unsigned kind, AnsvMemo<T>& memo, int skip) {
     uint64_t r;
-    if (ansv_memo_find<T>(memo, v, kind, &r)) return r;
+    if (type == 2) {
+        bool goes_on;
+        r = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, v, memo, skip, &goes_on);
+        return kind == 0 ? r : goes_on ? r : ANSV_NOCONT;
+    }
+    if (ansv_memo_find<T>(memo, v, 0u, &r)) return r;
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
-    uint64_t j = NSV_NONE;
-    r = kind == 0 ? NSV_NONE : ANSV_NOCONT;
-    if (!edge) {
-        j = nsv_search_wave<T, LEFT>(P, start, v, kind == 0 && type == 0, skip);
-        if (kind == 0) {
-            r = j;
-            if (type == 2 && j != NSV_NONE) r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
-        } else if (j != NSV_NONE && P.lvl[0][j] == v) {
-            r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2);
-        }
-    }
-    ansv_memo_add<T>(memo, v, kind, r, j);
+    r = edge ? NSV_NONE : nsv_search_wave<T, LEFT>(P, start, v, type == 0, skip);
+    ansv_memo_add<T>(memo, v, 0u, r);
     return r;
 }
 

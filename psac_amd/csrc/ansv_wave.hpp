@@ -23,12 +23,22 @@
 #pragma once
 #include "ansv_tile.hpp"
 
+#ifndef AW_FINAL_W
+#define AW_FINAL_W 4
+#endif
+#ifndef AW_ABLATE
+#define AW_ABLATE 0          // (tools/experiments/ansv_ablate.sh: parts of the furthest_eq pass left out, to time them; results are wrong then)
+#endif
+
 namespace psacx {
 
 constexpr unsigned AW_PEND = 0xFFFFu;       // the answer lies beyond the edge of the tile
 constexpr unsigned AW_DONE = 0xFFFEu;       // written by the search beyond the edge: the store pass leaves it alone
 constexpr unsigned AW_SLOT0 = 0xFF00u;      // furthest_eq: AW_SLOT0 + s = the answer lies beyond the edge and has been looked up already: entry s of slot0 / slot1
-constexpr unsigned AW_NSLOT = 64;           // (a tile with more such elements -- one falling run -- leaves the others at AW_PEND: they ask one by one)
+// slots per tile and side (a tile with more such elements -- one falling run -- leaves the others at AW_PEND: they ask one by one).  64-bit
+// values: 16, which keeps a workgroup at 53312 bytes of LDS -- three of them on a CU; with 512 bytes more the occupancy query still says
+// three, two are resident, and the grid sized for three runs in two rounds (1.57 against 1.24 ms at 2^26)
+template <typename T> struct AwSlots { static constexpr unsigned N = sizeof(T) == 4 ? 32 : 16; };
 
 template <typename T> struct AnsvWaveShared {
     static constexpr int RUN = 16, TILE = 64 * RUN;
@@ -36,9 +46,15 @@ template <typename T> struct AnsvWaveShared {
     __attribute__((aligned(16))) uint16_t ans[TILE];          // tile position of every element's answer (nearest types; nearest <= for furthest_eq)
     __attribute__((aligned(16))) uint16_t q[TILE];            // queue of open elements; afterwards the far ends of the chains (furthest_eq)
     AnsvMemo<T> memo[2];                                      // answers beyond the edge, left / right side
-    unsigned long long slot0[AW_NSLOT];                       // furthest_eq, per element without a <= element in the tile: its answer beyond the edge,
-    unsigned long long slot1[AW_NSLOT];                       // ... and the far end of the run of its value beyond the edge (ANSV_NOCONT: the run ends with it)
+    unsigned long long slot0[AwSlots<T>::N];                       // furthest_eq, per element without a <= element in the tile: its answer beyond the edge,
+    unsigned long long slot1[AwSlots<T>::N];                       // ... and the far end of the run of its value beyond the edge (ANSV_NOCONT: the run ends with it)
+#ifdef AW_PAD_BYTES
+    char pad[AW_PAD_BYTES];                                   // (tools/experiments: fewer workgroups per CU)
+#endif
 };
+
+// (four waves a workgroup: four workgroups of 32-bit values, three of 64-bit values on the 160 KB of a CU)
+static_assert(sizeof(AnsvWaveShared<uint32_t>) * 4 <= 40960 && sizeof(AnsvWaveShared<uint64_t>) * 4 <= 53312, "LDS of the ANSV kernel: a workgroup fewer per CU");
 
 // rightmost (LEFT) / leftmost index of the 16 values that qualifies (-1: none)
 template <typename T, bool LEFT>
@@ -207,14 +223,14 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
                 if (m) {
                     const unsigned slot = nslots + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     nslots += (unsigned)__builtin_popcountll(m);
-                    const bool fits = pend && slot < AW_NSLOT;
+                    const bool fits = pend && slot < AwSlots<T>::N;
                     while (m) {
                         const int src = __builtin_ctzll(m);
                         const T vq = shfl<T>(x, src);
-                        const uint64_t r0 = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, 2, 0u, memo, SKIP);
-                        const uint64_t r1 = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, 2, 1u, memo, SKIP);
+                        bool goes_on;
+                        const uint64_t r0 = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, vq, memo, SKIP, &goes_on);
                         const bool mine = pend && x == vq;
-                        if (mine && fits) { sh.slot0[slot] = r0 == NSV_NONE ? nonsv : r0; sh.slot1[slot] = r1; }
+                        if (mine && fits) { sh.slot0[slot] = r0 == NSV_NONE ? nonsv : r0; sh.slot1[slot] = goes_on ? r0 : ANSV_NOCONT; }
                         m &= ~__ballot(mine);
                     }
                     if (fits) pos = AW_SLOT0 + slot;
@@ -236,7 +252,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     } else {
         // ---- 4. furthest_eq: links to the nearest <= element where it is EQUAL, pointer doubling to the far end of every chain
 #pragma unroll
-        for (unsigned h = 0; h < 2; ++h) {            // eight elements at a time: their loads travel together
+        for (unsigned h = 0; h < ((AW_ABLATE & 2) ? 0 : 2); ++h) {            // eight elements at a time: their loads travel together
             unsigned ne[8]; T xe[8], xn[8];
 #pragma unroll
             for (unsigned k = 0; k < 8; ++k) { ne[k] = sh.ans[(h * 8 + k) * 64 + lane]; xe[k] = sh.v[(h * 8 + k) * 64 + lane]; }
@@ -246,7 +262,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
             for (unsigned k = 0; k < 8; ++k) sh.q[(h * 8 + k) * 64 + lane] = (uint16_t)((ne[k] < AW_SLOT0 && xn[k] == xe[k]) ? ne[k] : (h * 8 + k) * 64 + lane);
         }
         xrun_order();
-        for (;;) {
+        for (; !(AW_ABLATE & 1);) {
             bool changed = false;
 #pragma unroll
             for (unsigned h = 0; h < 2; ++h) {            // eight elements at a time: their loads travel together
@@ -264,24 +280,24 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
         // the answer of e: the far end of the chain of its nearest <= element; a chain whose far end inside the tile has ITS nearest <=
         // element beyond the edge may go on there; an element without a <= element in the tile has its whole answer there (both looked
         // up by the queue loop: slot0 / slot1)
-        const bool overflow = nslots > AW_NSLOT;
+        const bool overflow = nslots > AwSlots<T>::N;
 #pragma unroll 1
-        for (unsigned h = 0; h < 4; ++h) {            // four elements at a time
-            unsigned ne[4], r[4], ar[4];
+        for (unsigned h = 0; h < ((AW_ABLATE & 4) ? 0 : 16 / AW_FINAL_W); ++h) {            // AW_FINAL_W elements at a time
+            unsigned ne[AW_FINAL_W], r[AW_FINAL_W], ar[AW_FINAL_W];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) ne[k] = sh.ans[(h * 4 + k) * 64 + lane];
+            for (unsigned k = 0; k < AW_FINAL_W; ++k) ne[k] = sh.ans[(h * AW_FINAL_W + k) * 64 + lane];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) r[k] = ne[k] < AW_SLOT0 ? sh.q[ne[k]] : 0u;
+            for (unsigned k = 0; k < AW_FINAL_W; ++k) r[k] = ne[k] < AW_SLOT0 ? sh.q[ne[k]] : 0u;
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) ar[k] = sh.ans[r[k]];
+            for (unsigned k = 0; k < AW_FINAL_W; ++k) ar[k] = sh.ans[r[k]];
 #pragma unroll
-            for (unsigned k = 0; k < 4; ++k) {
-                const unsigned e = (h * 4 + k) * 64 + lane;
+            for (unsigned k = 0; k < AW_FINAL_W; ++k) {
+                const unsigned e = (h * AW_FINAL_W + k) * 64 + lane;
                 const uint64_t g = tile_base + e;
                 const bool in_range = e < n_rel;
                 const bool beyond = ne[k] >= AW_SLOT0;                       // no <= element in the tile
                 const unsigned code = beyond ? ne[k] : ar[k];               // (the element itself / the far end of its chain)
-                const bool looked_up = code >= AW_SLOT0 && code < AW_SLOT0 + AW_NSLOT;
+                const bool looked_up = code >= AW_SLOT0 && code < AW_SLOT0 + AwSlots<T>::N;
                 uint64_t res = tile_base + r[k];
                 if (looked_up) {
                     const uint64_t far = beyond ? sh.slot0[code - AW_SLOT0] : sh.slot1[code - AW_SLOT0];
@@ -301,46 +317,66 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     // ---- 6. the answers beyond the edge, for the next tile on this side.  An entry stays true unless this tile holds a qualifying element:
     //      that element, the nearest one to the next tile, is then the new nearest answer.  furthest_eq: from that element j the chain
     //      runs to its far end r inside the tile (sh.q, step 4); when r's own nearest <= element lies beyond this tile's edge the chain may
-    //      go on there, which the table may know (value u = in[j], kind 1).  Entries of kind 0 first: they read the OLD entries of kind 1.
-    {
+    //      go on there, which the table may know (value u = in[j], kind 1): the entries as the previous tile left them.
+    if (!(FUR && (AW_ABLATE & 8))) {
         const unsigned c = memo.cnt < ANSV_MEMO ? memo.cnt : ANSV_MEMO;
-        // (the entries in registers, one per lane: the loop below asks lanes, not LDS)
+        // (the entries in registers, one per lane)
         const T mval = lane < c ? memo.val[lane] : (T)0;
         const unsigned mkind = lane < c ? memo.kind[lane] : 0u;
         const bool mlive = lane < c && memo.ready[lane] != 0;
-#pragma unroll 1
-        for (int round = 0; round < (FUR ? 2 : 1); ++round) {
-        uint64_t todo = __ballot(mlive && (!FUR || mkind == (unsigned)round));
-        while (todo) {
-            const unsigned idx = (unsigned)__builtin_ctzll(todo);
-            todo &= todo - 1;
-            const unsigned kind = (unsigned)__builtin_amdgcn_readlane((int)mkind, (int)idx);
-            const T x = answ_readlane<T>(mval, idx);
-            const uint64_t bal = __ballot(strict ? mn < x : mn <= x);
-            if (!bal) continue;
-            const unsigned rr = LEFT ? 63u - (unsigned)__builtin_clzll(bal) : (unsigned)__builtin_ctzll(bal);
-            const T y = sh.v[rr * RUN + (lane & 15u)];
-            const uint64_t in_b = __ballot(lane < 16 && (strict ? y < x : y <= x));
-            const unsigned pl = LEFT ? 63u - (unsigned)__builtin_clzll(in_b) : (unsigned)__builtin_ctzll(in_b);
-            const unsigned j = rr * RUN + pl;
-            const uint64_t gp = tile_base + j;
-            const T u = answ_readlane<T>(y, pl);
-            if (j >= n_rel) { if (lane == 0) memo.ready[idx] = 0; continue; }           // (padding past the end of the array)
-            if (!FUR) { if (lane == 0) { memo.res[idx] = gp; memo.first[idx] = gp; } continue; }
-            if (kind == 1 && u < x) { if (lane == 0) { memo.res[idx] = ANSV_NOCONT; memo.first[idx] = gp; } continue; }
-            // the chain of value u from j: its far end inside the tile, and whether it may go on beyond the tile
-            const unsigned r = sh.q[j];
-            const bool at_edge = sh.ans[r] >= AW_SLOT0;
-            uint64_t res = tile_base + r;
-            bool keep = true;
-            if (at_edge) {
-                if (kind == 1) { const uint64_t old = memo.res[idx]; if (old != ANSV_NOCONT) res = old; }      // (u == x: the entry itself tells)
-                else { uint64_t far; if (ansv_memo_find<T>(memo, u, 1u, &far)) { if (far != ANSV_NOCONT) res = far; } else keep = false; }
+        {
+            // an entry per lane, all at once (round 5 took an entry at a time: a sixth of a furthest_eq pass, 7 % of a nearest one); every
+            // entry reads the table as the previous tile left it
+            if (__ballot(mlive)) {
+                const uint64_t myres = lane < c ? memo.res[lane] : 0ull;
+                T W[6];
+                if (LEFT) ansv_tables_left<T>(mn, W); else ansv_tables_right<T>(mn, W);
+                // the run nearest to the next tile whose minimum qualifies: the run at that edge itself, or the nearest one before it
+                const T edge_mn = answ_readlane<T>(mn, LEFT ? 63u : 0u);
+                unsigned rr = ansv_descend<T, LEFT>(W, LEFT ? 63u : 0u, mval, strict);
+                if (strict ? edge_mn < mval : edge_mn <= mval) rr = LEFT ? 63u : 0u;
+                T b[16];
+                answ_load_run<T>(sh.v + (mlive && rr < 64 ? rr : 0u) * RUN, b);
+                const int jj = answ_in_run<T, LEFT>(b, mval, strict);
+                const bool any = mlive && rr < 64 && jj >= 0;
+                const unsigned j = any ? rr * RUN + (unsigned)jj : 0u;
+                const uint64_t gp = tile_base + j;
+                if (!FUR) {
+                    if (any) { if (j >= n_rel) memo.ready[lane] = 0; else memo.res[lane] = gp; }
+                } else {
+                    const T u = sh.v[j];
+                    const unsigned r = sh.q[j];                 // the far end inside the tile of the chain of value u from j (step 4)
+                    const bool at_edge = sh.ans[r] >= AW_SLOT0; // ... whose own nearest <= element lies beyond this tile: the chain may go on there
+                    // what the table knew about the value u (u < x; u == x: the entry itself)
+                    bool known = false, far_on = false; uint64_t far = 0;
+                    if (__ballot(any && at_edge && u < mval)) {
+                        uint64_t live = __ballot(mlive);
+                        while (live) {
+                            const unsigned i = (unsigned)__builtin_ctzll(live);
+                            live &= live - 1;
+                            const T vi = answ_readlane<T>(mval, i);
+                            const uint64_t ri = answ_readlane<uint64_t>(myres, i);
+                            const unsigned ki = (unsigned)__builtin_amdgcn_readlane((int)mkind, (int)i);
+                            if (!known && vi == u) { known = true; far = ri; far_on = ki != 0; }
+                        }
+                    }
+                    if (any) {
+                        if (j >= n_rel) memo.ready[lane] = 0;                                   // (padding past the end of the array)
+                        else {
+                            // the chain of value u from j ends at r inside the tile, or goes on beyond it where the table says so
+                            uint64_t res = tile_base + r;
+                            bool keep = true;
+                            if (at_edge) {
+                                if (u == mval) { if (mkind != 0) res = myres; }
+                                else if (known) { if (far_on) res = far; }
+                                else keep = false;
+                            }
+                            if (keep) { memo.res[lane] = res; memo.kind[lane] = u == mval ? 1u : 0u; } else memo.ready[lane] = 0;
+                        }
+                    }
+                }
             }
-            if (lane == 0) { if (keep) { memo.res[idx] = res; memo.first[idx] = gp; } else memo.ready[idx] = 0; }
         }
-        }
-        if (lane == 0) ansv_memo_compact<T>(memo);
     }
     xrun_order();
 }
@@ -373,8 +409,8 @@ void launch_ansv_wave(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int
     const uint64_t ntiles = (n + TILE - 1) / TILE;
 #define PSACX_ANSW(LF, RF)                                                                                                       \
     do {                                                                                                                         \
-        int occ = 0;                                                                                                             \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_wave_kernel<T, LF, RF, WAVES>, 64 * WAVES, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; } \
+        static int occ = 0;          /* (asked once per form: the kernel and its LDS are fixed) */                             \
+        if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_wave_kernel<T, LF, RF, WAVES>, 64 * WAVES, 0) != hipSuccess || occ < 1)) { (void)hipGetLastError(); occ = 1; } \
         const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + WAVES - 1) / WAVES, (uint64_t)c->n_cu * occ);               \
         hipLaunchKernelGGL((ansv_wave_kernel<T, LF, RF, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles); \
     } while (0)

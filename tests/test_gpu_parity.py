@@ -946,3 +946,38 @@ def test_scaled_down_twins_of_the_baseline_configs(ctx):
     assert np.array_equal(isa[sa.astype(np.int64)], np.arange(text.size, dtype=np.uint64))
     if O.have_divsufsort():
         assert np.array_equal(sa, O.divsufsort(text, 64))
+
+@pytest.mark.gpu
+def test_ansv_answers_carried_from_tile_to_tile(ctx):
+    # 2^25 elements: every wave of the kernel works through eight tiles per side and carries the answers that lie beyond a tile edge
+    # from one to the next (psac_amd/csrc/ansv_wave.hpp step 6; arrays of a few ten thousand elements give a wave one tile).  Shapes
+    # that stress the carried table: rare deep minima (answers many tiles away), falling runs longer than a tile (every element asks
+    # beyond it: more than the kernel keeps per tile), plateaus across tiles (furthest_eq chains that go on beyond the edge), a level
+    # per tile (more distinct values at the edges than the table holds).  ansv.hpp:48-65, tie rules ansv_common.hpp:20-22.
+    import psac_amd
+    rng = np.random.RandomState(31)
+    n = (1 << 25) + 777
+    NO = (1 << 64) - 1
+    band = (10 + rng.geometric(0.35, size=n)).astype(np.uint32)
+    deep = np.flatnonzero(rng.rand(n) < 1e-4); band[deep] = rng.randint(0, 10, size=deep.size)
+    teeth = (1500 - np.arange(n, dtype=np.uint64) % 1500).astype(np.uint32)
+    cuts = np.flatnonzero(rng.rand(n) < 1.0 / 3000)
+    plateaus = rng.randint(0, 5, size=cuts.size + 1).astype(np.uint64)[np.searchsorted(cuts, np.arange(n), side="right")]
+    levels = ((np.arange(n, dtype=np.uint64) // 1024 * 2654435761 % 40) * 3 + rng.randint(0, 4, size=n).astype(np.uint64)).astype(np.uint32)
+    cases = [(band, ((2, 0), (0, 1))), (teeth, ((2, 0), (1, 2))), (plateaus, ((2, 2), (1, 0))), (levels, ((2, 0), (0, 2)))]
+    for v, pairs in cases:
+        bits = v.dtype.itemsize * 8
+        d_in, d_l, d_r = ctx.alloc(n * v.dtype.itemsize), ctx.alloc(n * 8), ctx.alloc(n * 8)
+        ctx.h2d(d_in, v)
+        want = {}
+        for lt, rt in pairs:
+            psac_amd.ansv_device(ctx, d_in, n, d_l, d_r, bits, lt, rt, NO)
+            L = np.empty(n, np.uint64); R = np.empty(n, np.uint64)
+            ctx.d2h(L, d_l); ctx.d2h(R, d_r)
+            for side, t, got in ((True, lt, L), (False, rt, R)):
+                if (side, t) not in want:
+                    want[(side, t)] = O.ansv(v, side, t, NO)
+                assert np.array_equal(got, want[(side, t)]), (bits, lt, rt, side)
+        for p_ in (d_in, d_l, d_r):
+            ctx.free(p_)
+
