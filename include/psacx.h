@@ -84,6 +84,9 @@ typedef struct psacx_stats {
     uint64_t heavy_records;        /* ... records that carried their bucket's heavy rank and skipped the sort */
     uint64_t light_records;        /* ... records that were sorted */
     uint64_t level_gathers;        /* refinement rounds (or slabs) whose ranks h further came through partition levels (construct.hpp: gather_by_levels) */
+    /* host-pointer calls (psacx_construct_u32 / _u64), host wall clock, milliseconds: [0] text to the device, [1] the construction,
+       [2] SA, [3] ISA, [4] LCP (+ Lc) into the caller's arrays -- what is left of each after the overlap with the step before --, [5] the call */
+    double ms_host[6];
 } psacx_stats;
 
 /* life cycle ------------------------------------------------------------- */
@@ -120,11 +123,13 @@ int psacx_trim(psacx_ctx* ctx);
  *   GATHER            ranks h further of a refinement round: 1 = one fetch per record, 2 = partition levels
  *   NO_HEAVY          no split of a round's records into heavy and light ones
  *   NO_WHOLE          no text-order rounds
- *   NO_LAZY_RANKS     the heavy runs of a split round always take the rank of their head and store it                                */
+ *   NO_LAZY_RANKS     the heavy runs of a split round always take the rank of their head and store it
+ *   NO_EARLY_OUT      host-pointer calls: SA and LCP leave the device only when the construction has returned (default: from the moment the
+ *                     first round has written them, under the SA -> ISA inversion; copied again if refinement rounds follow)             */
 enum {
     PSACX_OPT_RESET = 0, PSACX_OPT_FORCE_DIET, PSACX_OPT_DIET_CAP, PSACX_OPT_ONE_STAGE, PSACX_OPT_TIES_RADIX, PSACX_OPT_NO_ONE_WORD,
     PSACX_OPT_ONE_WORD_ALWAYS, PSACX_OPT_ONE_WORD_MIN, PSACX_OPT_WIDEN_LAST, PSACX_OPT_NO_DIGIT_BYTES, PSACX_OPT_NO_BUCKET_SORT,
-    PSACX_OPT_ISA_UPDATE, PSACX_OPT_GATHER, PSACX_OPT_NO_HEAVY, PSACX_OPT_NO_WHOLE, PSACX_OPT_NO_LAZY_RANKS, PSACX_OPT_COUNT
+    PSACX_OPT_ISA_UPDATE, PSACX_OPT_GATHER, PSACX_OPT_NO_HEAVY, PSACX_OPT_NO_WHOLE, PSACX_OPT_NO_LAZY_RANKS, PSACX_OPT_NO_EARLY_OUT, PSACX_OPT_COUNT
 };
 int psacx_configure(psacx_ctx* ctx, int option, uint64_t value);
 /* Debug shim, the ONLY place where the library looks at the environment, and only when called: resets the options of ctx and sets those

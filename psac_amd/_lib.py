@@ -18,7 +18,7 @@ PSACX_MAX_ROUNDS = 72
 
 # psacx_configure options (include/psacx.h); Context.configure(force_diet=1, ...) takes them by name
 OPTIONS = {"reset": 0, "force_diet": 1, "diet_cap": 2, "one_stage": 3, "ties_radix": 4, "no_one_word": 5, "one_word_always": 6, "one_word_min": 7,
-           "widen_last": 8, "no_digit_bytes": 9, "no_bucket_sort": 10, "isa_update": 11, "gather": 12, "no_heavy": 13, "no_whole": 14, "no_lazy_ranks": 15}
+           "widen_last": 8, "no_digit_bytes": 9, "no_bucket_sort": 10, "isa_update": 11, "gather": 12, "no_heavy": 13, "no_whole": 14, "no_lazy_ranks": 15, "no_early_out": 16}
 MULTI_OPTIONS = {"layout": 1, "slab": 2, "output_slack": 3, "trace": 4, "wire_piece": 5, "pieces": 6, "check_chunks": 7, "global_refine_sort": 8,
                  "one_stage": 9, "two_word": 10, "one_word": 11, "no_slices": 12, "slice_wide": 13, "slice_shape": 14}
 MULTI_FORCE_WIRE, MULTI_NO_RCCL, MULTI_SHM = 1, 2, 4
@@ -64,7 +64,8 @@ class Stats(C.Structure):
                 ("ms_sort_scatter3", C.c_double), ("ms_sort_tilehist", C.c_double), ("ms_sort_scatter2", C.c_double),
                 ("scatter_launches", C.c_uint64 * 3), ("scatter_records", C.c_uint64 * 3),
                 ("scatter_bytes", C.c_uint64 * 3), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("onew_passes", C.c_uint64),
-                ("heavy_rounds", C.c_uint64), ("heavy_records", C.c_uint64), ("light_records", C.c_uint64), ("level_gathers", C.c_uint64)]
+                ("heavy_rounds", C.c_uint64), ("heavy_records", C.c_uint64), ("light_records", C.c_uint64), ("level_gathers", C.c_uint64),
+                ("ms_host", C.c_double * 6)]
 
 
 class PsacxError(RuntimeError):

@@ -9,6 +9,8 @@
 // unresolved suffixes.  The final SA / ISA / LCP are identical to the
 // reference's because they are uniquely determined by the text.
 #pragma once
+#include <chrono>
+#include <thread>
 #include "engine.hpp"
 #include "bucket_sort.hpp"
 #include "heavy_keys.hpp"
@@ -251,6 +253,18 @@ inline bool isa_radix_levels(uint64_t n, const Knobs& kn) {
 // read-bound, no gain.
 // 64-bit words, at most 2^32 positions: the inversion moves 32-bit (position, rank) pairs through 512-way partition
 // levels down to windows of 2^14 positions.  Returns the number of levels (0: the form does not apply).
+// buckets left unresolved, summed over the tiles of the first round's rebucket kernel (one workgroup)
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void sum_counts_kernel(const uint64_t* __restrict__ per_tile, uint64_t ntiles, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[16];
+    unsigned long long s = 0;
+    for (uint64_t i = threadIdx.x; i < ntiles; i += 1024) s += per_tile[i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += part[i]; *out = t; }
+}
+
 template <typename T>
 inline int isa_narrow_levels(uint64_t n, const Knobs& kn) {
     if (sizeof(T) != 8 || n < (1ull << 22) || n > (1ull << 32)) return 0;
@@ -896,6 +910,13 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
         }
         PSACX_HIP(c, hipGetLastError());
     }
+    // (a host-pointer call starts SA and LCP on their way out from here: they are final unless refinement rounds follow)
+    if (c->first_round_hook && !gsa && c->early_word) {
+        const uint64_t ntiles = (n + ScanCfg<T>::TILE - 1) / ScanCfg<T>::TILE;
+        hipLaunchKernelGGL(sum_counts_kernel<0>, dim3(1), dim3(1024), 0, c->stream, (const uint64_t*)w.d_nunf, ntiles, c->early_word);
+        PSACX_HIP(c, hipGetLastError());
+        void (*hook)(void*) = c->first_round_hook; c->first_round_hook = nullptr; hook(c->first_round_hook_arg);
+    }
     // ---- SA -> ISA (bulk_permute.hpp:14-73)
     {
         ProfScope ps(c, TC_ISA_SCATTER);
@@ -1360,6 +1381,36 @@ int construct_gsa_host(psacx_ctx* c, const uint8_t* text, uint64_t n, const uint
 
 // host-pointer form: stage over PCIe, run, copy back.  The device copies live in the ctx between calls
 // (suffix_array<>::construct may be called repeatedly on one object, test/test_psac.cpp:148-170).
+// SA and LCP on their way to the caller's arrays while the first round's SA -> ISA inversion still runs (random text: the two arrays are
+// final when rebucket_first_kernel has written them, 37 of the 173 ms of a 2^32 construction before it ends).  The hook runs on the
+// constructing thread right after that kernel has been enqueued; a second host thread then drives the staged copies, their narrowing
+// kernels on a stream of their own behind an event.  Speculative: if refinement rounds follow, the arrays change and are copied again.
+template <typename T>
+struct EarlyOut {
+    psacx_ctx* c; T* sa; const T* d_sa; T* lcp; const T* d_lcp; uint64_t n;
+    std::thread th; int rc; bool started;
+};
+template <typename T>
+void early_out_hook(void* p) {
+    EarlyOut<T>* eo = static_cast<EarlyOut<T>*>(p);
+    psacx_ctx* c = eo->c;
+    if (hipEventRecord(c->early_ev, c->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    eo->started = true;
+    eo->th = std::thread([eo]() {
+        psacx_ctx* c = eo->c;
+        // nothing leaves unless the first round has resolved every bucket (one word, counted behind the rebucket kernel on its own stream)
+        unsigned long long* const h_left = reinterpret_cast<unsigned long long*>(c->stage[0]);
+        *h_left = 1;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(c->early_stream, c->early_ev, 0) != hipSuccess ||
+            hipMemcpyAsync(h_left, c->early_word, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->early_stream) != hipSuccess ||
+            hipStreamSynchronize(c->early_stream) != hipSuccess) { (void)hipGetLastError(); eo->rc = PSACX_EHIP; return; }
+        if (*h_left != 0) { eo->rc = PSACX_EINVAL; return; }          // (refinement rounds follow: the arrays leave when they are through)
+        int rc = staged_d2h_entries<T>(c, eo->sa, eo->d_sa, eo->n, eo->n - 1, c->early_stream);
+        if (rc == PSACX_OK && eo->lcp) rc = staged_d2h_entries<T>(c, eo->lcp, eo->d_lcp, eo->n, ~0ull, c->early_stream);
+        eo->rc = rc;
+    });
+}
+
 template <typename T>
 int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, uint32_t flags, T* sa, T* isa, T* lcp,
                    uint8_t* lc = nullptr) {
@@ -1379,13 +1430,36 @@ int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, ui
     { Arena dry(nullptr); layout(dry); PSACX_TRY(ensure_io(c, dry.off + 4096)); }
     Arena ar(c->io);
     layout(ar);
+    typedef std::chrono::steady_clock clk;
+    const clk::time_point t0 = clk::now();
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    double ms[6];
     PSACX_TRY(staged_h2d(c, d_text, text, n));
+    ms[0] = ms_since(t0);
+    clk::time_point t1 = clk::now();
+    // arrays of at least eight staging chunks leave early (smaller ones are on the wire for a few milliseconds)
+    EarlyOut<T> eo{c, sa, d_sa, d_lcp ? lcp : (T*)nullptr, d_lcp, n, std::thread(), PSACX_OK, false};
+    if (!c->knobs.no_early_out && n * sizeof(T) >= 8 * STAGE_CHUNK && ensure_stage(c) == PSACX_OK) {
+        if (!c->early_stream && hipStreamCreateWithFlags(&c->early_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->early_stream = nullptr; }
+        if (!c->early_ev && hipEventCreateWithFlags(&c->early_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->early_ev = nullptr; }
+        if (!c->early_word && hipMalloc((void**)&c->early_word, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); c->early_word = nullptr; }
+        if (c->early_stream && c->early_ev && c->early_word) { c->first_round_hook = early_out_hook<T>; c->first_round_hook_arg = &eo; }
+    }
     int rc = construct_dispatch<T>(c, d_text, n, k, flags, d_sa, d_isa, d_lcp, d_lc);
+    c->first_round_hook = nullptr;
+    ms[1] = ms_since(t1); t1 = clk::now();
+    if (eo.started) eo.th.join();          // (the staging buffers are its until it is through)
     if (rc != PSACX_OK) return rc;
-    PSACX_TRY(staged_d2h_entries<T>(c, sa, d_sa, n, n - 1));
+    // what left early stands if the first round was the only one
+    const bool early = eo.started && eo.rc == PSACX_OK && c->stats.n_rounds == 1;
+    if (!early) PSACX_TRY(staged_d2h_entries<T>(c, sa, d_sa, n, n - 1));
+    ms[2] = ms_since(t1); t1 = clk::now();
     PSACX_TRY(staged_d2h_entries<T>(c, isa, d_isa, n, n - 1));
-    if (d_lcp) PSACX_TRY(staged_d2h_entries<T>(c, lcp, d_lcp, n, ~0ull));
+    ms[3] = ms_since(t1); t1 = clk::now();
+    if (d_lcp && !early) PSACX_TRY(staged_d2h_entries<T>(c, lcp, d_lcp, n, ~0ull));
     if (d_lc) PSACX_TRY(staged_d2h(c, lc, d_lc, n));
+    ms[4] = ms_since(t1); ms[5] = ms_since(t0);
+    for (int i = 0; i < 6; ++i) c->stats.ms_host[i] = ms[i];
     return PSACX_OK;
 }
 

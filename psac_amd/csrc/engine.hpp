@@ -51,6 +51,7 @@ struct Knobs {
     int gather = 0;               // PSACX_OPT_GATHER: 1 = fetch, 2 = levels: how a refinement round gets the ranks h further -- one random fetch per record, or requests through
                                   // partition levels (construct.hpp: gather_by_levels); default (0): levels for rounds of at least n / 8 records in long buckets
     bool no_heavy = false;        // PSACX_OPT_NO_HEAVY: no split of a round's records into heavy and light ones (heavy_keys.hpp; A/B runs)
+    bool no_early_out = false;    // PSACX_OPT_NO_EARLY_OUT: host-pointer calls copy SA / LCP out only after the construction (construct.hpp: construct_host)
     bool no_lazy_ranks = false;   // PSACX_OPT_NO_LAZY_RANKS: every heavy run of a split round takes the rank of its head and stores it (heavy_keys.hpp; A/B runs)
     bool no_whole = false;        // PSACX_OPT_NO_WHOLE: rounds in which nearly every suffix is unresolved take the list of positions too (A/B runs)
     bool widen_last = false;      // PSACX_OPT_WIDEN_LAST: the last pass of the one-word prefix sort writes word 1 and the suffixes as two arrays (the form the
@@ -81,6 +82,13 @@ struct psacx_ctx {
     hipEvent_t stage_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t copy_stream[2] = {nullptr, nullptr};     // the device -> host copies of the narrowed chunks alternate between two streams (two DMA engines)
     hipEvent_t narrow_ev[STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    // host-pointer calls: called by the construction once its first round has written SA and LCP (final unless refinement rounds follow);
+    // construct_host starts their way out from there, on early_stream, under the SA -> ISA inversion
+    void (*first_round_hook)(void*) = nullptr;
+    void* first_round_hook_arg = nullptr;
+    hipStream_t early_stream = nullptr;
+    hipEvent_t early_ev = nullptr;
+    unsigned long long* early_word = nullptr;       // device: buckets the first round left unresolved (0: SA and LCP are final)
     psacx::HostPool* hpool = nullptr;
     // Freed device blocks of the multi-GPU path, kept for reuse (size -> pointer).  Every use of such a block is
     // ordered on this ctx's stream (its second stream joins it through events), so a block handed out again is
@@ -294,8 +302,9 @@ inline void pool_memcpy(HostPool* hp, char* dst, const char* src, size_t bytes) 
     });
 }
 
-inline int staged_d2h(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) {
+inline int staged_d2h(psacx_ctx* c, void* dst_, const void* src_, size_t bytes, hipStream_t on = nullptr) {
     PSACX_TRY(ensure_stage(c));
+    const hipStream_t S = on ? on : c->stream;
     constexpr int NS = psacx_ctx::STAGE_SLOTS;
     char* dst = static_cast<char*>(dst_); const char* src = static_cast<const char*>(src_);
     size_t issued = 0, drained = 0; int qi = 0, qd = 0, inflight = 0;
@@ -303,8 +312,8 @@ inline int staged_d2h(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) 
     while (drained < bytes) {
         while (issued < bytes && inflight < NS) {
             const size_t m = std::min(STAGE_CHUNK, bytes - issued);
-            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], src + issued, m, hipMemcpyDeviceToHost, c->stream));
-            PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], c->stream));
+            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], src + issued, m, hipMemcpyDeviceToHost, S));
+            PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], S));
             len[qi] = m; issued += m; qi = (qi + 1) % NS; ++inflight;
         }
         PSACX_HIP(c, hipEventSynchronize(c->stage_ev[qd]));
@@ -331,23 +340,25 @@ __global__ void max_entry_kernel(const T* __restrict__ in, uint64_t cnt, unsigne
 // `count` entries of T from device memory into the caller's array, travelling as the narrowest of 1 / 2 / 4-byte entries that hold
 // max_value (UINT64_MAX: found here with one pass over the array; wide values travel as they are)
 template <typename T>
-int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint64_t max_value) {
+int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint64_t max_value, hipStream_t on = nullptr) {
+    // on: the stream of the narrowing kernels (default: the ctx's own)
     if (count == 0) return PSACX_OK;
     PSACX_TRY(ensure_stage(c));
+    const hipStream_t S = on ? on : c->stream;
     constexpr int NS = psacx_ctx::STAGE_SLOTS;
-    if (count * sizeof(T) < 4 * STAGE_CHUNK) return staged_d2h(c, dst, src, count * sizeof(T));
-    if (!c->dstage && hipMalloc((void**)&c->dstage, NS * STAGE_CHUNK) != hipSuccess) { (void)hipGetLastError(); c->dstage = nullptr; return staged_d2h(c, dst, src, count * sizeof(T)); }
+    if (count * sizeof(T) < 4 * STAGE_CHUNK) return staged_d2h(c, dst, src, count * sizeof(T), S);
+    if (!c->dstage && hipMalloc((void**)&c->dstage, NS * STAGE_CHUNK) != hipSuccess) { (void)hipGetLastError(); c->dstage = nullptr; return staged_d2h(c, dst, src, count * sizeof(T), S); }
     if (max_value == ~0ull) {
         unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->dstage);
-        PSACX_HIP(c, hipMemsetAsync(d_max, 0, 8, c->stream));
-        hipLaunchKernelGGL((max_entry_kernel<T>), dim3(grid_for(c, count, 256, 8)), dim3(256), 0, c->stream, src, count, d_max);
+        PSACX_HIP(c, hipMemsetAsync(d_max, 0, 8, S));
+        hipLaunchKernelGGL((max_entry_kernel<T>), dim3(grid_for(c, count, 256, 8)), dim3(256), 0, S, src, count, d_max);
         PSACX_HIP(c, hipGetLastError());
-        PSACX_HIP(c, hipMemcpyAsync(c->stage[0], d_max, 8, hipMemcpyDeviceToHost, c->stream));
-        PSACX_HIP(c, hipStreamSynchronize(c->stream));
+        PSACX_HIP(c, hipMemcpyAsync(c->stage[0], d_max, 8, hipMemcpyDeviceToHost, S));
+        PSACX_HIP(c, hipStreamSynchronize(S));
         max_value = *reinterpret_cast<unsigned long long*>(c->stage[0]);
     }
     const size_t e = max_value < (1ull << 8) ? 1 : max_value < (1ull << 16) ? 2 : max_value < (1ull << 32) ? 4 : 8;
-    if (e >= sizeof(T)) return staged_d2h(c, dst, src, count * sizeof(T));
+    if (e >= sizeof(T)) return staged_d2h(c, dst, src, count * sizeof(T), S);
     const uint64_t per = STAGE_CHUNK / e;
     uint64_t issued = 0, drained = 0; int qi = 0, qd = 0, inflight = 0;
     uint64_t len[NS] = {0, 0, 0, 0};
@@ -357,14 +368,14 @@ int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint6
             const uint64_t m = std::min(per, count - issued);
             char* const bounce = c->dstage + (size_t)qi * STAGE_CHUNK;
             const int grid = grid_for(c, m, 256, 8);
-            if (e == 1) hipLaunchKernelGGL((narrow_entries_kernel<T, uint8_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint8_t*>(bounce));
-            else if (e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint16_t*>(bounce));
-            else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, c->stream, src + issued, m, reinterpret_cast<uint32_t*>(bounce));
+            if (e == 1) hipLaunchKernelGGL((narrow_entries_kernel<T, uint8_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint8_t*>(bounce));
+            else if (e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint16_t*>(bounce));
+            else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint32_t*>(bounce));
             PSACX_HIP(c, hipGetLastError());
-            hipStream_t cs = c->stream;
+            hipStream_t cs = S;
             if (c->copy_stream[qi & 1] && c->narrow_ev[qi]) {
                 cs = c->copy_stream[qi & 1];
-                PSACX_HIP(c, hipEventRecord(c->narrow_ev[qi], c->stream));
+                PSACX_HIP(c, hipEventRecord(c->narrow_ev[qi], S));
                 PSACX_HIP(c, hipStreamWaitEvent(cs, c->narrow_ev[qi], 0));
             }
             PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * e, hipMemcpyDeviceToHost, cs));

@@ -70,6 +70,9 @@ void psacx_destroy(psacx_ctx* c) {
     if (c->dstage) (void)hipFree(c->dstage);
     for (int i = 0; i < 2; ++i) if (c->copy_stream[i]) (void)hipStreamDestroy(c->copy_stream[i]);
     for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) if (c->narrow_ev[i]) (void)hipEventDestroy(c->narrow_ev[i]);
+    if (c->early_ev) (void)hipEventDestroy(c->early_ev);
+    if (c->early_stream) (void)hipStreamDestroy(c->early_stream);
+    if (c->early_word) (void)hipFree(c->early_word);
     delete c->hpool;
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -111,6 +114,7 @@ int psacx_configure(psacx_ctx* c, int option, uint64_t value) {
     case PSACX_OPT_NO_HEAVY: k.no_heavy = value != 0; return PSACX_OK;
     case PSACX_OPT_NO_WHOLE: k.no_whole = value != 0; return PSACX_OK;
     case PSACX_OPT_NO_LAZY_RANKS: k.no_lazy_ranks = value != 0; return PSACX_OK;
+    case PSACX_OPT_NO_EARLY_OUT: k.no_early_out = value != 0; return PSACX_OK;
     default: return PSACX_EINVAL;
     }
 }
@@ -123,7 +127,8 @@ int psacx_configure_from_env(psacx_ctx* c) {
         {"PSACX_FORCE_DIET", PSACX_OPT_FORCE_DIET}, {"PSACX_ONE_STAGE", PSACX_OPT_ONE_STAGE}, {"PSACX_TIES_RADIX", PSACX_OPT_TIES_RADIX},
         {"PSACX_NO_ONE_WORD", PSACX_OPT_NO_ONE_WORD}, {"PSACX_ONE_WORD_ALWAYS", PSACX_OPT_ONE_WORD_ALWAYS}, {"PSACX_WIDEN_LAST", PSACX_OPT_WIDEN_LAST},
         {"PSACX_NO_DIGIT_BYTES", PSACX_OPT_NO_DIGIT_BYTES}, {"PSACX_NO_BUCKET_SORT", PSACX_OPT_NO_BUCKET_SORT}, {"PSACX_NO_HEAVY", PSACX_OPT_NO_HEAVY},
-        {"PSACX_NO_WHOLE", PSACX_OPT_NO_WHOLE}, {"PSACX_NO_LAZY_RANKS", PSACX_OPT_NO_LAZY_RANKS}};
+        {"PSACX_NO_WHOLE", PSACX_OPT_NO_WHOLE}, {"PSACX_NO_LAZY_RANKS", PSACX_OPT_NO_LAZY_RANKS},
+        {"PSACX_NO_EARLY_OUT", PSACX_OPT_NO_EARLY_OUT}};
     (void)psacx_configure(c, PSACX_OPT_RESET, 0);
     for (const auto& f : flags) if (psacx_debug_env(f.name)) (void)psacx_configure(c, f.option, 1);
     if (const char* e = psacx_debug_env("PSACX_DIET_CAP")) (void)psacx_configure(c, PSACX_OPT_DIET_CAP, strtoull(e, nullptr, 10));

@@ -155,16 +155,17 @@ def test_host_pointer_path_narrow_transfers(ctx):
     # as they are: random DNA (LCP < 256), one repeat of 300 characters (LCP < 65536), one of 100000 characters (4-byte entries), and
     # 2^30 characters.
     import psac_amd
-    def both(text):
+    def both(text, bits=64):
         n = text.size
-        hs = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+        w = bits // 8
+        hs = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
         hs.construct(text)
         d_text = ctx.alloc(n); ctx.h2d(d_text, text)
-        d = [ctx.alloc(n * 8) for _ in range(3)]
+        d = [ctx.alloc(n * w) for _ in range(3)]
         try:
-            ds = psac_amd.SuffixArray(index_bits=64, lcp=True, ctx=ctx)
+            ds = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
             ds.construct_device(d_text, n, d[0], d[1], d[2])
-            tmp = np.empty(n, np.uint64)
+            tmp = np.empty(n, np.uint64 if bits == 64 else np.uint32)
             for arr, p in ((hs.local_SA, d[0]), (hs.local_B, d[1]), (hs.local_LCP, d[2])):
                 ctx.d2h(tmp, p)
                 assert np.array_equal(arr, tmp)
@@ -172,10 +173,19 @@ def test_host_pointer_path_narrow_transfers(ctx):
             for p in [d_text] + d:
                 ctx.free(p)
         return hs
+    # (round 6: when the first round leaves no bucket unresolved, SA and LCP start on their way out under its SA -> ISA inversion,
+    #  construct.hpp: EarlyOut -- the random texts below at 64 bits; with repeats, or a few equal 2k-mers at 32 bits, they wait)
     n = (1 << 27) + 12345
     t = inputs.dna(n, 21)
     hs = both(t)
     assert int(hs.local_LCP.max()) < 256
+    os.environ["PSACX_NO_EARLY_OUT"] = "1"          # (the test suite's debug shim: psac_amd/_lib.py ENV_KNOBS)
+    try:
+        both(t)
+    finally:
+        del os.environ["PSACX_NO_EARLY_OUT"]
+    both(t, bits=32)
+    both(inputs.ascii128(n, 3), bits=32)
     t2 = t.copy(); t2[90000000:90000300] = t2[1000:1300]
     hs = both(t2)
     assert 300 <= int(hs.local_LCP.max()) < 65536
