@@ -85,8 +85,10 @@ typedef struct psacx_stats {
     uint64_t light_records;        /* ... records that were sorted */
     uint64_t level_gathers;        /* refinement rounds (or slabs) whose ranks h further came through partition levels (construct.hpp: gather_by_levels) */
     /* host-pointer calls (psacx_construct_u32 / _u64), host wall clock, milliseconds: [0] text to the device, [1] the construction,
-       [2] SA, [3] ISA, [4] LCP (+ Lc) into the caller's arrays -- what is left of each after the overlap with the step before --, [5] the call */
-    double ms_host[6];
+       [2] what was left of SA and LCP on their early way out when the construction returned (below), [3] ISA (and SA, LCP if they did not
+       leave early) into the caller's arrays, [4] Lc, [5] the call; SA and LCP leaving early (from the end of the first round):
+       [6] when that began, [7] = [8] when both were through, since the call began */
+    double ms_host[9];
 } psacx_stats;
 
 /* life cycle ------------------------------------------------------------- */

@@ -65,7 +65,7 @@ class Stats(C.Structure):
                 ("scatter_launches", C.c_uint64 * 3), ("scatter_records", C.c_uint64 * 3),
                 ("scatter_bytes", C.c_uint64 * 3), ("hist_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("onew_passes", C.c_uint64),
                 ("heavy_rounds", C.c_uint64), ("heavy_records", C.c_uint64), ("light_records", C.c_uint64), ("level_gathers", C.c_uint64),
-                ("ms_host", C.c_double * 6)]
+                ("ms_host", C.c_double * 9)]
 
 
 class PsacxError(RuntimeError):

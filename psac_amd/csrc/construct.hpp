@@ -1389,6 +1389,7 @@ template <typename T>
 struct EarlyOut {
     psacx_ctx* c; T* sa; const T* d_sa; T* lcp; const T* d_lcp; uint64_t n;
     std::thread th; int rc; bool started;
+    std::chrono::steady_clock::time_point t0; double ms[3];
 };
 template <typename T>
 void early_out_hook(void* p) {
@@ -1405,8 +1406,11 @@ void early_out_hook(void* p) {
             hipMemcpyAsync(h_left, c->early_word, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->early_stream) != hipSuccess ||
             hipStreamSynchronize(c->early_stream) != hipSuccess) { (void)hipGetLastError(); eo->rc = PSACX_EHIP; return; }
         if (*h_left != 0) { eo->rc = PSACX_EINVAL; return; }          // (refinement rounds follow: the arrays leave when they are through)
-        int rc = staged_d2h_entries<T>(c, eo->sa, eo->d_sa, eo->n, eo->n - 1, c->early_stream);
-        if (rc == PSACX_OK && eo->lcp) rc = staged_d2h_entries<T>(c, eo->lcp, eo->d_lcp, eo->n, ~0ull, c->early_stream);
+        auto since = [eo]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - eo->t0).count(); };
+        eo->ms[0] = since();
+        D2hJob<T> jobs[2] = {{eo->sa, eo->d_sa, eo->n, eo->n - 1, 0, 0, 0, 0}, {eo->lcp, eo->d_lcp, eo->n, ~0ull, 0, 0, 0, 0}};
+        const int rc = staged_d2h_jobs<T>(c, jobs, eo->lcp ? 2 : 1, c->early_stream);          // (SA and LCP chunk by chunk: engine.hpp)
+        eo->ms[1] = eo->ms[2] = since();
         eo->rc = rc;
     });
 }
@@ -1433,12 +1437,12 @@ int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, ui
     typedef std::chrono::steady_clock clk;
     const clk::time_point t0 = clk::now();
     auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
-    double ms[6];
+    double ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PSACX_TRY(staged_h2d(c, d_text, text, n));
     ms[0] = ms_since(t0);
     clk::time_point t1 = clk::now();
     // arrays of at least eight staging chunks leave early (smaller ones are on the wire for a few milliseconds)
-    EarlyOut<T> eo{c, sa, d_sa, d_lcp ? lcp : (T*)nullptr, d_lcp, n, std::thread(), PSACX_OK, false};
+    EarlyOut<T> eo{c, sa, d_sa, d_lcp ? lcp : (T*)nullptr, d_lcp, n, std::thread(), PSACX_OK, false, t0, {0, 0, 0}};
     if (!c->knobs.no_early_out && n * sizeof(T) >= 8 * STAGE_CHUNK && ensure_stage(c) == PSACX_OK) {
         if (!c->early_stream && hipStreamCreateWithFlags(&c->early_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->early_stream = nullptr; }
         if (!c->early_ev && hipEventCreateWithFlags(&c->early_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->early_ev = nullptr; }
@@ -1452,14 +1456,20 @@ int construct_host(psacx_ctx* c, const uint8_t* text, uint64_t n, uint32_t k, ui
     if (rc != PSACX_OK) return rc;
     // what left early stands if the first round was the only one
     const bool early = eo.started && eo.rc == PSACX_OK && c->stats.n_rounds == 1;
-    if (!early) PSACX_TRY(staged_d2h_entries<T>(c, sa, d_sa, n, n - 1));
-    ms[2] = ms_since(t1); t1 = clk::now();
-    PSACX_TRY(staged_d2h_entries<T>(c, isa, d_isa, n, n - 1));
+    ms[2] = ms_since(t1); t1 = clk::now();          // (what was left of SA and LCP on their early way out)
+    {
+        // ISA, and SA and LCP unless they are out already, chunk by chunk through one ring (engine.hpp: staged_d2h_jobs)
+        D2hJob<T> jobs[3]; int nj = 0;
+        jobs[nj++] = D2hJob<T>{isa, d_isa, n, n - 1, 0, 0, 0, 0};
+        if (!early) jobs[nj++] = D2hJob<T>{sa, d_sa, n, n - 1, 0, 0, 0, 0};
+        if (!early && d_lcp) jobs[nj++] = D2hJob<T>{lcp, d_lcp, n, ~0ull, 0, 0, 0, 0};
+        PSACX_TRY(staged_d2h_jobs<T>(c, jobs, nj));
+    }
     ms[3] = ms_since(t1); t1 = clk::now();
-    if (d_lcp && !early) PSACX_TRY(staged_d2h_entries<T>(c, lcp, d_lcp, n, ~0ull));
     if (d_lc) PSACX_TRY(staged_d2h(c, lc, d_lc, n));
     ms[4] = ms_since(t1); ms[5] = ms_since(t0);
-    for (int i = 0; i < 6; ++i) c->stats.ms_host[i] = ms[i];
+    if (early) { ms[6] = eo.ms[0]; ms[7] = eo.ms[1]; ms[8] = eo.ms[2]; }
+    for (int i = 0; i < 9; ++i) c->stats.ms_host[i] = ms[i];
     return PSACX_OK;
 }
 

@@ -14,6 +14,10 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sched.h>
+#include <pthread.h>
+#include <cctype>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/psacx.h"
@@ -237,10 +241,12 @@ struct HostPool {
     uint64_t gen = 0;
     int pending = 0, n = 0;
     bool stop = false;
-    explicit HostPool(int threads) : n(threads) {
+    std::vector<cpu_set_t> homes;          // where the threads run: thread i on the CPUs of homes[i % homes.size()] (empty: anywhere)
+    explicit HostPool(int threads, const std::vector<cpu_set_t>& where = std::vector<cpu_set_t>()) : n(threads), homes(where) {
         for (int i = 0; i < n; ++i) th.emplace_back([this, i]() { work(i); });
     }
     void work(int i) {
+        if (!homes.empty()) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &homes[(size_t)i % homes.size()]);
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(int, int)>* f;
@@ -268,6 +274,50 @@ struct HostPool {
     }
 };
 
+// The CPUs of ONE NUMA node of the host -- the device's own by sysfs, else the one this thread runs on --, cut down to what the process may
+// use (nothing if fewer than four are left: a process confined elsewhere keeps its threads where they are).  The threads that widen the
+// staged chunks into the caller's arrays stay there: the pages of arrays the library is the first to write then lie on that node, and
+// every later call writes them from there.  Left to float over both sockets of the GPU box, the same call took 0.96 s in one process and
+// 1.12 s in the next (profiles/r6_host_path_early_out.txt) -- the copy engines deliver 56 GB/s into pinned memory on either node
+// (tools/ubench_numa.hip); it was the widening that crossed the socket link.  (Threads spread over both nodes, each always on its own
+// part of a chunk: 0.96 - 1.04 s; all on one: 0.955 - 0.967 in five processes.)
+inline std::vector<cpu_set_t> host_home_cpus(int device) {
+    std::vector<cpu_set_t> home;
+    cpu_set_t allowed; CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return home;
+    int node = -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) == hipSuccess) {
+        for (char* p = bdf; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+        if (FILE* f = std::fopen(path.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+    } else (void)hipGetLastError();
+    const int cpu_now = sched_getcpu();
+    for (int nd = 0; nd < 64; ++nd) {
+        const std::string path = "/sys/devices/system/node/node" + std::to_string(nd) + "/cpulist";
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) break;
+        cpu_set_t set; CPU_ZERO(&set);
+        bool here = false;
+        int a = 0, b = 0;
+        for (;;) {
+            if (std::fscanf(f, "%d", &a) != 1) break;
+            b = a;
+            int ch = std::fgetc(f);
+            if (ch == '-') { if (std::fscanf(f, "%d", &b) != 1) break; ch = std::fgetc(f); }
+            for (int x = a; x <= b && x < CPU_SETSIZE; ++x) { CPU_SET(x, &set); if (x == cpu_now) here = true; }
+            if (ch != ',') break;
+        }
+        std::fclose(f);
+        if (node >= 0 ? nd != node : !here) continue;
+        cpu_set_t mine; CPU_ZERO(&mine);
+        CPU_AND(&mine, &set, &allowed);
+        if (CPU_COUNT(&mine) >= 4) home.push_back(mine);
+        break;
+    }
+    return home;
+}
+
 inline int ensure_stage(psacx_ctx* c) {
     if (c->stage[0] && c->hpool) return PSACX_OK;
     for (int i = 0; i < psacx_ctx::STAGE_SLOTS; ++i) {
@@ -288,7 +338,7 @@ inline int ensure_stage(psacx_ctx* c) {
         // (tools/ubench_pcie.hip on the GPU box: 8 - 16 threads with streaming stores widen at 280 - 300 GB/s, 48 threads at 98 -- more
         //  threads than memory channels lose; the DMA engine delivers 51 - 57 GB/s)
         const unsigned hw = std::thread::hardware_concurrency();
-        c->hpool = new HostPool((int)std::max(1u, std::min(16u, hw ? hw : 8u)));
+        c->hpool = new HostPool((int)std::max(1u, std::min(16u, hw ? hw : 8u)), host_home_cpus(c->device));
     }
     return PSACX_OK;
 }
@@ -337,40 +387,68 @@ __global__ void max_entry_kernel(const T* __restrict__ in, uint64_t cnt, unsigne
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (unsigned long long)m);
 }
 
-// `count` entries of T from device memory into the caller's array, travelling as the narrowest of 1 / 2 / 4-byte entries that hold
-// max_value (UINT64_MAX: found here with one pass over the array; wide values travel as they are)
+// `count` entries of T per job from device memory into the caller's arrays, travelling as the narrowest of 1 / 2 / 4-byte entries that hold
+// max_value (UINT64_MAX: found here with one pass over the array; wide values travel as they are).  Several arrays share the ring of
+// staging buffers chunk by chunk, the one with the largest part still to go next: the 1-byte LCP entries of a random text widen to 8 on
+// the host -- 512 MiB of stores per 64 MiB chunk off the wire, more than one socket's memory takes in the 1.15 ms the chunk is on the
+// wire -- while SA entries widen from 4 to 8; mixed, the stores keep up with the wire (SA then LCP: 305 + 130 ms; together: 21.5 GB at
+// the wire's 56 GB/s).
 template <typename T>
-int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint64_t max_value, hipStream_t on = nullptr) {
+struct D2hJob { T* dst; const T* src; uint64_t count; uint64_t max_value; size_t e; uint64_t per, issued, drained; };
+
+template <typename T>
+int staged_d2h_jobs(psacx_ctx* c, D2hJob<T>* jobs, int nj, hipStream_t on = nullptr) {
     // on: the stream of the narrowing kernels (default: the ctx's own)
-    if (count == 0) return PSACX_OK;
     PSACX_TRY(ensure_stage(c));
     const hipStream_t S = on ? on : c->stream;
     constexpr int NS = psacx_ctx::STAGE_SLOTS;
-    if (count * sizeof(T) < 4 * STAGE_CHUNK) return staged_d2h(c, dst, src, count * sizeof(T), S);
-    if (!c->dstage && hipMalloc((void**)&c->dstage, NS * STAGE_CHUNK) != hipSuccess) { (void)hipGetLastError(); c->dstage = nullptr; return staged_d2h(c, dst, src, count * sizeof(T), S); }
-    if (max_value == ~0ull) {
-        unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->dstage);
-        PSACX_HIP(c, hipMemsetAsync(d_max, 0, 8, S));
-        hipLaunchKernelGGL((max_entry_kernel<T>), dim3(grid_for(c, count, 256, 8)), dim3(256), 0, S, src, count, d_max);
-        PSACX_HIP(c, hipGetLastError());
-        PSACX_HIP(c, hipMemcpyAsync(c->stage[0], d_max, 8, hipMemcpyDeviceToHost, S));
-        PSACX_HIP(c, hipStreamSynchronize(S));
-        max_value = *reinterpret_cast<unsigned long long*>(c->stage[0]);
+    if (!c->dstage && hipMalloc((void**)&c->dstage, NS * STAGE_CHUNK) != hipSuccess) { (void)hipGetLastError(); c->dstage = nullptr; }
+    // widths; what is small, or as wide as it is already, goes as it is
+    bool pipeline = false;
+    for (int j = 0; j < nj; ++j) {
+        D2hJob<T>& J = jobs[j];
+        J.e = sizeof(T); J.issued = J.drained = 0; J.per = 0;
+        if (J.count == 0 || !c->dstage || J.count * sizeof(T) < 4 * STAGE_CHUNK) continue;
+        if (J.max_value == ~0ull) {
+            unsigned long long* d_max = reinterpret_cast<unsigned long long*>(c->dstage);
+            PSACX_HIP(c, hipMemsetAsync(d_max, 0, 8, S));
+            hipLaunchKernelGGL((max_entry_kernel<T>), dim3(grid_for(c, J.count, 256, 8)), dim3(256), 0, S, J.src, J.count, d_max);
+            PSACX_HIP(c, hipGetLastError());
+            PSACX_HIP(c, hipMemcpyAsync(c->stage[0], d_max, 8, hipMemcpyDeviceToHost, S));
+            PSACX_HIP(c, hipStreamSynchronize(S));
+            J.max_value = *reinterpret_cast<unsigned long long*>(c->stage[0]);
+        }
+        J.e = J.max_value < (1ull << 8) ? 1 : J.max_value < (1ull << 16) ? 2 : J.max_value < (1ull << 32) ? 4 : 8;
+        if (J.e >= sizeof(T)) { J.e = sizeof(T); continue; }
+        J.per = STAGE_CHUNK / J.e;
+        pipeline = true;
     }
-    const size_t e = max_value < (1ull << 8) ? 1 : max_value < (1ull << 16) ? 2 : max_value < (1ull << 32) ? 4 : 8;
-    if (e >= sizeof(T)) return staged_d2h(c, dst, src, count * sizeof(T), S);
-    const uint64_t per = STAGE_CHUNK / e;
-    uint64_t issued = 0, drained = 0; int qi = 0, qd = 0, inflight = 0;
-    uint64_t len[NS] = {0, 0, 0, 0};
+    for (int j = 0; j < nj; ++j)
+        if (jobs[j].count && !jobs[j].per) PSACX_TRY(staged_d2h(c, jobs[j].dst, jobs[j].src, jobs[j].count * sizeof(T), S));
+    if (!pipeline) return PSACX_OK;
+    int qi = 0, qd = 0, inflight = 0;
+    uint64_t len[NS] = {0, 0, 0, 0}, at[NS] = {0, 0, 0, 0}; int of[NS] = {0, 0, 0, 0};
     HostPool* hp = c->hpool;
-    while (drained < count) {
-        while (issued < count && inflight < NS) {
-            const uint64_t m = std::min(per, count - issued);
+    auto next_job = [&]() -> int {          // the array with the largest part still to be issued
+        int best = -1; double most = 0.0;
+        for (int j = 0; j < nj; ++j) {
+            const D2hJob<T>& J = jobs[j];
+            if (!J.per || J.issued >= J.count) continue;
+            const double part = (double)(J.count - J.issued) / (double)J.count;
+            if (part > most) { most = part; best = j; }
+        }
+        return best;
+    };
+    for (;;) {
+        int j;
+        while (inflight < NS && (j = next_job()) >= 0) {
+            D2hJob<T>& J = jobs[j];
+            const uint64_t m = std::min(J.per, J.count - J.issued);
             char* const bounce = c->dstage + (size_t)qi * STAGE_CHUNK;
             const int grid = grid_for(c, m, 256, 8);
-            if (e == 1) hipLaunchKernelGGL((narrow_entries_kernel<T, uint8_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint8_t*>(bounce));
-            else if (e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint16_t*>(bounce));
-            else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, S, src + issued, m, reinterpret_cast<uint32_t*>(bounce));
+            if (J.e == 1) hipLaunchKernelGGL((narrow_entries_kernel<T, uint8_t>), dim3(grid), dim3(256), 0, S, J.src + J.issued, m, reinterpret_cast<uint8_t*>(bounce));
+            else if (J.e == 2) hipLaunchKernelGGL((narrow_entries_kernel<T, uint16_t>), dim3(grid), dim3(256), 0, S, J.src + J.issued, m, reinterpret_cast<uint16_t*>(bounce));
+            else hipLaunchKernelGGL((narrow_entries_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, S, J.src + J.issued, m, reinterpret_cast<uint32_t*>(bounce));
             PSACX_HIP(c, hipGetLastError());
             hipStream_t cs = S;
             if (c->copy_stream[qi & 1] && c->narrow_ev[qi]) {
@@ -378,14 +456,17 @@ int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint6
                 PSACX_HIP(c, hipEventRecord(c->narrow_ev[qi], S));
                 PSACX_HIP(c, hipStreamWaitEvent(cs, c->narrow_ev[qi], 0));
             }
-            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * e, hipMemcpyDeviceToHost, cs));
+            PSACX_HIP(c, hipMemcpyAsync(c->stage[qi], bounce, (size_t)m * J.e, hipMemcpyDeviceToHost, cs));
             PSACX_HIP(c, hipEventRecord(c->stage_ev[qi], cs));
-            len[qi] = m; issued += m; qi = (qi + 1) % NS; ++inflight;
+            len[qi] = m; at[qi] = J.issued; of[qi] = j; J.issued += m; qi = (qi + 1) % NS; ++inflight;
         }
+        if (!inflight) break;
         PSACX_HIP(c, hipEventSynchronize(c->stage_ev[qd]));
         {
+            D2hJob<T>& J = jobs[of[qd]];
             const uint64_t m = len[qd];
-            T* const out = dst + drained;
+            const size_t e = J.e;
+            T* const out = J.dst + at[qd];
             const char* const in = c->stage[qd];
             hp->run([=](int t, int nt) {
                 const uint64_t a = m * (uint64_t)t / nt, b = m * (uint64_t)(t + 1) / nt;
@@ -395,10 +476,18 @@ int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint6
                 else if (e == 2) { const uint16_t* p = reinterpret_cast<const uint16_t*>(in); for (uint64_t i = a; i < b; ++i) __builtin_nontemporal_store((T)p[i], out + i); }
                 else { const uint32_t* p = reinterpret_cast<const uint32_t*>(in); for (uint64_t i = a; i < b; ++i) __builtin_nontemporal_store((T)p[i], out + i); }
             });
+            J.drained += m;
         }
-        drained += len[qd]; len[qd] = 0; qd = (qd + 1) % NS; --inflight;
+        len[qd] = 0; qd = (qd + 1) % NS; --inflight;
     }
     return PSACX_OK;
+}
+
+template <typename T>
+int staged_d2h_entries(psacx_ctx* c, T* dst, const T* src, uint64_t count, uint64_t max_value, hipStream_t on = nullptr) {
+    if (count == 0) return PSACX_OK;
+    D2hJob<T> job{dst, src, count, max_value, 0, 0, 0, 0};
+    return staged_d2h_jobs<T>(c, &job, 1, on);
 }
 
 inline int staged_h2d(psacx_ctx* c, void* dst_, const void* src_, size_t bytes) {

@@ -127,10 +127,10 @@ int run_host(psacx_multi* g, const uint8_t* text, uint64_t n, uint32_t k, uint32
         psacx_ctx* cx = g->R[r].ctx;
         MG_HIP(g, hipSetDevice(cx->device));
         if (!m[r]) continue;
-        // (narrowed on the device, widened on the host: engine.hpp: staged_d2h_entries)
-        MG_OP(g, cx, staged_d2h_entries<T>(cx, sa + off[r], dsa[r].p, m[r], n - 1));
-        MG_OP(g, cx, staged_d2h_entries<T>(cx, isa + off[r], disa[r].p, m[r], n - 1));
-        if (want_lcp) MG_OP(g, cx, staged_d2h_entries<T>(cx, lcp + off[r], dlcp[r].p, m[r], ~0ull));
+        // (narrowed on the device, widened on the host, the three arrays chunk by chunk through one ring: engine.hpp: staged_d2h_jobs)
+        D2hJob<T> jobs[3] = {{sa + off[r], dsa[r].p, m[r], n - 1, 0, 0, 0, 0}, {isa + off[r], disa[r].p, m[r], n - 1, 0, 0, 0, 0},
+                             {want_lcp ? lcp + off[r] : (T*)nullptr, want_lcp ? dlcp[r].p : (const T*)nullptr, m[r], ~0ull, 0, 0, 0, 0}};
+        MG_OP(g, cx, staged_d2h_jobs<T>(cx, jobs, want_lcp ? 3 : 2));
     }
     return PSACX_OK;
 }

@@ -23,11 +23,12 @@ text = np.empty(n, np.uint8)
 ctx.d2h(text, d_text); ctx.free(d_text)
 sa = psac_amd.SuffixArray(index_bits=bits, lcp=True, ctx=ctx)
 sa.construct(text)
-names = ("text up", "construction", "SA down", "ISA down", "LCP down", "call")
+names = ("text up", "construction", "rest of SA + LCP (early)", "ISA (+ SA, LCP) down", "Lc down", "call")
 for it in range(calls):
     t0 = time.perf_counter()
     sa.local_SA, sa.local_B, sa.local_LCP = sa.construct_into(text, sa.local_SA, sa.local_B, sa.local_LCP)
     dt = time.perf_counter() - t0
     ms = list(ctx.stats().ms_host)
     print("2^%d random DNA, uint%d, host pointers: %.1f ms = %.2f GChars/s;  " % (logn, bits, dt * 1e3, n / dt / 1e9)
-          + ", ".join("%s %.1f" % (names[i], ms[i]) for i in range(6)), flush=True)
+          + ", ".join("%s %.1f" % (names[i], ms[i]) for i in range(6))
+          + ("; early: began %.1f, SA + LCP through %.1f" % (ms[6], ms[8]) if ms[6] > 0 else ""), flush=True)
