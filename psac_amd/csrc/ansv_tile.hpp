@@ -10,6 +10,9 @@
 
 namespace psacx {
 
+#ifndef AW_ABLATE
+#define AW_ABLATE 0          // (tools/experiments/ansv_ablate.sh: parts left out to time them; bit 16: no pyramid walks, the answers beyond a tile edge are wrong then)
+#endif
 #ifndef AW_MEMO_ENTRIES
 #define AW_MEMO_ENTRIES 16
 #endif
@@ -145,7 +148,7 @@ __device__ __forceinline__ uint64_t ansv_global_fur(const Pyramid<T>& P, uint64_
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
     uint64_t j = NSV_NONE;
     r = NSV_NONE; k = 0;
-    if (!edge) {
+    if (!edge && !(AW_ABLATE & 16)) {
         j = nsv_search_wave<T, LEFT>(P, start, v, false, skip);
         if (j != NSV_NONE) { r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2); k = P.lvl[0][j] == v ? 1u : 0u; }
     }
@@ -170,7 +173,7 @@ __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n,
     if (ansv_memo_find<T>(memo, v, 0u, &r)) return r;
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
-    r = edge ? NSV_NONE : nsv_search_wave<T, LEFT>(P, start, v, type == 0, skip);
+    r = (edge || (AW_ABLATE & 16)) ? NSV_NONE : nsv_search_wave<T, LEFT>(P, start, v, type == 0, skip);
     ansv_memo_add<T>(memo, v, 0u, r);
     return r;
 }

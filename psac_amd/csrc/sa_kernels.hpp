@@ -11,6 +11,12 @@
 //   pyramid_level_kernel    rmq.hpp:87-179 / par_rmq.hpp:199-332 (range-minimum structure)
 //   isa_finalize_kernel     suffix_array.hpp:460-464   ISA -= 1
 #pragma once
+#ifndef RB_WAVES_ATTR
+#define RB_WAVES_ATTR          // (tools/experiments: __attribute__((amdgpu_waves_per_eu(6, 6))) -- three workgroups of rebucket_first_kernel per CU)
+#endif
+#ifndef RB_ABLATE
+#define RB_ABLATE 0          // (tools/experiments/rb_ablate.sh: output streams of rebucket_first_kernel left out to time them: 1 LCP, 2 SA, 4 the fused partition level, 8 its stores; results are wrong then)
+#endif
 #include <type_traits>
 #include "dev_common.hpp"
 
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void tile_scan2_kernel(uint64_t* __restrict_
 // ONEW (one GPU, 64-bit words): S1 holds the one-word records of the prefix sort (OneWordView), S1t word 1 of the suffixes that tie on the
 // leading bits (S2 their word 2), SA is not read: the suffixes come out of the records and leave through sa_out.
 template <typename T, int BLOCK, int ITEMS, bool WITH_LCP, bool GSA = false, int PCB = 0, bool PPK = false, bool ONEW = false>
-__global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
+__global__ __launch_bounds__(BLOCK) RB_WAVES_ATTR void rebucket_first_kernel(
     const T* __restrict__ S1, const T* __restrict__ S2, const T* __restrict__ SA, uint64_t n, KeyShape ks,
     T* __restrict__ Bsa, T* __restrict__ LCP, const uint64_t* __restrict__ carry_in,
     uint64_t* __restrict__ n_active, uint64_t* __restrict__ n_unf, uint64_t ng, Boundary<T> bd,
@@ -1024,8 +1030,8 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         if (id[j] == 0) id[j] = carry; else carry = id[j];
     }
     if (!(lazy_ids && tact == 0)) store_run_x<T, ITEMS>(Bsa, e0, n, id, xw);
-    if (WITH_LCP) store_run_x<T, ITEMS>(LCP, e0, n, lc, xw);
-    if (sa_out) store_run_x<T, ITEMS>(sa_out, e0, n, sa, xw);
+    if (WITH_LCP && !(RB_ABLATE & 1)) store_run_x<T, ITEMS>(LCP, e0, n, lc, xw);
+    if (sa_out && !(RB_ABLATE & 2)) store_run_x<T, ITEMS>(sa_out, e0, n, sa, xw);
     if (sa_hist) {
         __shared__ unsigned dh[4 * RADIX];
         for (int i = threadIdx.x; i < 4 * RADIX; i += BLOCK) dh[i] = 0;
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
         for (int d = 1; d < 64 / ITEMS; d <<= 1) { const T o = shfl_xor<T>(m, d); m = o < m ? o : m; }
         if ((threadIdx.x & (64 / ITEMS - 1)) == 0 && e0 < n) pyr1[e0 >> 6] = m;
     }
-    if constexpr (PCB > 0) {
+    if constexpr (PCB > 0 && !(RB_ABLATE & 4)) {
         constexpr int NCLS = 1 << PCB;
         static_assert(BLOCK >= NCLS, "one thread per class");
         typedef typename std::conditional<PPK, uint64_t, uint32_t>::type ST;
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_first_kernel(
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const unsigned p = tid + j * BLOCK;
-                if (p < count) {
+                if (p < count && !(RB_ABLATE & 8)) {
                     const uint64_t x = stage[p];
                     out[pbase[((uint32_t)x >> part_shift) & (NCLS - 1)] + p] = x;
                 }

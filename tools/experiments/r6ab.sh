@@ -2,8 +2,8 @@
 # variants of the ANSV kernel side by side (tools/experiments/ansv_ablate.sh builds them)
 cd $GRAFT_REPO_ROOT; export PSACX_ENV_KNOBS=1
 O=gpurun_out/r6ab; mkdir -p $O; rm -f $O/ablate.txt
-for f in psac_amd/lib/libpsacx.so tools/experiments/ablate/*.so; do
-  for a in "26 64 t" "26 64 one" "28 32 t" "28 32 one" "27 64 t"; do
+for f in tools/experiments/ablate/*.so; do
+  for a in "28 32 t" "28 32 one" "26 64 t"; do
   PSACX_LIB=$PWD/$f timeout 100 python tools/ansv_time.py $a 2>&1 | grep ANSV | sed "s/^/$(basename $f .so): /" >> $O/ablate.txt
   done
 done
