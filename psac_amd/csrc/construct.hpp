@@ -21,6 +21,9 @@ namespace psacx {
 // workgroups (two per CU at their register count: rebucket_first_kernel 60.8 -> 51.1 ms at 2^32), 32-bit words
 // 768-thread ones (the tile of their radix scatter passes; 512 and 1024 measured the same or slower).
 constexpr int SCAN_ITEMS = 8;
+#ifndef RB1W_BLOCK
+#define RB1W_BLOCK 512      // threads of rebucket_first_kernel on one-word records (the tile stays 4096 records)
+#endif
 template <typename T> struct ScanCfg {
     static constexpr int BLOCK = sizeof(T) == 8 ? 512 : 768;
     static constexpr int TILE = BLOCK * SCAN_ITEMS;
@@ -887,8 +890,8 @@ int construct_dev(psacx_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t k_re
                 PSACX_TRY(scan_carries<T>(c, w, ntiles));
                 PSACX_HIP(c, hipMemsetAsync(w.d_cursors, 0, ((size_t)1 << ISA_NARROW_CB) * sizeof(unsigned) + sizeof(unsigned), c->stream));
                 lazy_ids = n >= (1ull << 22);
-                hipLaunchKernelGGL((rebucket_first_kernel<T, ScanCfg<T>::BLOCK, SCAN_ITEMS, WITH_LCP, false, ISA_NARROW_CB, true, true>), dim3((unsigned)ntiles),
-                                   dim3(ScanCfg<T>::BLOCK), 0, c->stream, sorted.k1, sorted.k2, (const T*)nullptr, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact, w.d_nunf, n,
+                hipLaunchKernelGGL((rebucket_first_kernel<T, RB1W_BLOCK, ScanCfg<T>::TILE / RB1W_BLOCK, WITH_LCP, false, ISA_NARROW_CB, true, true>), dim3((unsigned)ntiles),
+                                   dim3(RB1W_BLOCK), 0, c->stream, sorted.k1, sorted.k2, (const T*)nullptr, n, ks, w.bsa, d_lcp, w.d_carry, w.d_nact, w.d_nunf, n,
                                    Boundary<T>(), pyr1, (unsigned*)nullptr, 0, reinterpret_cast<uint32_t*>(w.x.v), (uint32_t*)nullptr,
                                    isa_narrow_shift(isa_narrow_levels<T>(n, kn), 0), w.d_cursors, d_sa, lazy_ids ? 1 : 0, onew_view, (const T*)onew_w1);
             }
