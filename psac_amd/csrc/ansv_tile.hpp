@@ -81,17 +81,34 @@ __device__ __forceinline__ unsigned ansv_descend(const T (&W)[6], unsigned start
     return pos < 63 ? pos + 1 : 64u;
 }
 
+template <typename T> __device__ __forceinline__ T answ_readlane(T v, unsigned src);      // src: wave-uniform
+template <> __device__ __forceinline__ uint32_t answ_readlane<uint32_t>(uint32_t v, unsigned src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+template <> __device__ __forceinline__ uint64_t answ_readlane<uint64_t>(uint64_t v, unsigned src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// The table of one side in registers for the length of a pass: lane i holds entry i.  Every question a pass asks of the table is then a
+// compare and a ballot; through LDS (count, flags, values, kinds, then the answer: five dependent reads per distinct value, a handful of
+// values per tile and side) the questions were a fifth of the kernel (left out: nearest pair 2.64 -> 2.10 ms per call, of which the walks
+// are 0.07 and bringing the table up to date 0.2).  New entries go to both copies; the pass's last step writes the table back.
+template <typename T> struct MemoRegs { T val; unsigned long long res; unsigned kind; bool live; unsigned cnt; };
 template <typename T>
-__device__ __forceinline__ bool ansv_memo_find(AnsvMemo<T>& m, T v, unsigned kind, uint64_t* res) {
+__device__ __forceinline__ MemoRegs<T> ansv_memo_load(const AnsvMemo<T>& m) {
+    MemoRegs<T> r;
     const unsigned lane = lane_id();
-    unsigned c = __hip_atomic_load(&m.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned c = m.cnt;
     if (c > ANSV_MEMO) c = ANSV_MEMO;
-    bool hit = false;
-    if (lane < c && __hip_atomic_load(&m.ready[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP))
-        hit = m.val[lane] == v && m.kind[lane] == kind;
-    const uint64_t b = __ballot(hit);
+    const bool in = lane < c;
+    r.cnt = c;
+    r.val = in ? m.val[lane] : (T)0; r.res = in ? m.res[lane] : 0ull; r.kind = in ? m.kind[lane] : 0u; r.live = in && m.ready[lane] != 0;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ bool ansv_memo_find(const MemoRegs<T>& r, T v, unsigned kind, uint64_t* res) {
+    const uint64_t b = __ballot(r.live && r.val == v && r.kind == kind);
     if (!b) return false;
-    *res = m.res[__builtin_ctzll(b)];
+    *res = answ_readlane<uint64_t>((uint64_t)r.res, (unsigned)__builtin_ctzll(b));
     return true;
 }
 // (whole wave) a new entry: at the end of the table, else in the place of a dropped one, else in the place of the LARGEST value held if v is
@@ -99,26 +116,26 @@ __device__ __forceinline__ bool ansv_memo_find(AnsvMemo<T>& m, T v, unsigned kin
 // (Round 5 dropped what came after the table had filled: on an LCP array with more than 16 distinct values at tile edges the later ones
 // walked the pyramid every time: 0.1 of 2.7 ms.)
 template <typename T>
-__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind, uint64_t res) {
+__device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, MemoRegs<T>& r, T v, unsigned kind, uint64_t res) {
     const unsigned lane = lane_id();
-    const unsigned c = __hip_atomic_load(&m.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    unsigned idx = c;
-    if (c >= ANSV_MEMO) {
+    unsigned idx = r.cnt;
+    if (r.cnt >= ANSV_MEMO) {
         const bool in = lane < ANSV_MEMO;
-        const bool dead = in && __hip_atomic_load(&m.ready[in ? lane : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
-        const T key = in ? m.val[lane] : (T)0;
-        const uint64_t d = __ballot(dead);
+        const uint64_t d = __ballot(in && !r.live);
         if (d) idx = (unsigned)__builtin_ctzll(d);
         else {
+            const T key = in ? r.val : (T)0;
             const T mx = shfl<T>(wave_scan_inclusive<T>(key, OpMax()), 63);
             if (!(v < mx)) return;
             idx = (unsigned)__builtin_ctzll(__ballot(in && key == mx));
         }
+    } else {
+        r.cnt++;
+        if (lane == 0) m.cnt = r.cnt;
     }
-    if (lane == 0) {
-        m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res;
-        __hip_atomic_store(&m.ready[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (c < ANSV_MEMO) __hip_atomic_store(&m.cnt, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == idx) {
+        r.val = v; r.res = res; r.kind = kind; r.live = true;
+        m.val[idx] = v; m.kind[idx] = kind; m.res[idx] = res; m.ready[idx] = 1u;
     }
 }
 
@@ -127,23 +144,19 @@ __device__ __forceinline__ void ansv_memo_add(AnsvMemo<T>& m, T v, unsigned kind
 // the value v itself -- a run of v's inside the tile then goes on to the same far end, otherwise it ends inside the tile.  (Two entries per
 // value, one per question, halved the values the table holds and walked the pyramid twice per value: 0.5 of 4.3 ms of the psac -t pair.)
 template <typename T>
-__device__ __forceinline__ bool ansv_memo_find_value(AnsvMemo<T>& m, T v, uint64_t* res, unsigned* kind) {
-    const unsigned lane = lane_id();
-    unsigned c = __hip_atomic_load(&m.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (c > ANSV_MEMO) c = ANSV_MEMO;
-    bool hit = false;
-    if (lane < c && __hip_atomic_load(&m.ready[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) hit = m.val[lane] == v;
-    const uint64_t b = __ballot(hit);
+__device__ __forceinline__ bool ansv_memo_find_value(const MemoRegs<T>& r, T v, uint64_t* res, unsigned* kind) {
+    const uint64_t b = __ballot(r.live && r.val == v);
     if (!b) return false;
-    *res = m.res[__builtin_ctzll(b)];
-    *kind = m.kind[__builtin_ctzll(b)];
+    const unsigned i = (unsigned)__builtin_ctzll(b);
+    *res = answ_readlane<uint64_t>((uint64_t)r.res, i);
+    *kind = (unsigned)__builtin_amdgcn_readlane((int)r.kind, (int)i);
     return true;
 }
 template <typename T, bool LEFT>
 __device__ __forceinline__ uint64_t ansv_global_fur(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end, T v,
-                                                    AnsvMemo<T>& memo, int skip, bool* run_goes_on) {
+                                                    AnsvMemo<T>& memo, MemoRegs<T>& mr, int skip, bool* run_goes_on) {
     uint64_t r; unsigned k;
-    if (ansv_memo_find_value<T>(memo, v, &r, &k)) { *run_goes_on = k != 0; return r; }
+    if (ansv_memo_find_value<T>(mr, v, &r, &k)) { *run_goes_on = k != 0; return r; }
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
     uint64_t j = NSV_NONE;
@@ -152,7 +165,7 @@ __device__ __forceinline__ uint64_t ansv_global_fur(const Pyramid<T>& P, uint64_
         j = nsv_search_wave<T, LEFT>(P, start, v, false, skip);
         if (j != NSV_NONE) { r = nsv_typed_wave<T, LEFT>(P, n, start, v, 2); k = P.lvl[0][j] == v ? 1u : 0u; }
     }
-    ansv_memo_add<T>(memo, v, k, r);
+    ansv_memo_add<T>(memo, mr, v, k, r);
     *run_goes_on = k != 0;
     return r;
 }
@@ -163,18 +176,18 @@ __device__ __forceinline__ uint64_t ansv_global_fur(const Pyramid<T>& P, uint64_
 // skip: levels of the pyramid on which the walk from the tile edge can find nothing (1 for a tile whose edges are multiples of 64)
 template <typename T, bool LEFT>
 __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
-                                                T v, int type, unsigned kind, AnsvMemo<T>& memo, int skip) {
+                                                T v, int type, unsigned kind, AnsvMemo<T>& memo, MemoRegs<T>& mr, int skip) {
     uint64_t r;
     if (type == 2) {
         bool goes_on;
-        r = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, v, memo, skip, &goes_on);
+        r = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, v, memo, mr, skip, &goes_on);
         return kind == 0 ? r : goes_on ? r : ANSV_NOCONT;
     }
-    if (ansv_memo_find<T>(memo, v, 0u, &r)) return r;
+    if (ansv_memo_find<T>(mr, v, 0u, &r)) return r;
     const bool edge = LEFT ? tile_base == 0 : tile_end >= n;            // nothing beyond the edge
     const uint64_t start = LEFT ? tile_base : tile_end - 1;             // searches look strictly beyond `start`
     r = (edge || (AW_ABLATE & 16)) ? NSV_NONE : nsv_search_wave<T, LEFT>(P, start, v, type == 0, skip);
-    ansv_memo_add<T>(memo, v, 0u, r);
+    ansv_memo_add<T>(memo, mr, v, 0u, r);
     return r;
 }
 
@@ -182,13 +195,13 @@ __device__ __forceinline__ uint64_t ansv_global(const Pyramid<T>& P, uint64_t n,
 // distinct value (whole wave).  kind 0: out = answer (nonsv if none); kind 1: out = far end of the run if it continues.
 template <typename T, bool LEFT>
 __device__ __forceinline__ void ansv_resolve_pending(const Pyramid<T>& P, uint64_t n, uint64_t tile_base, uint64_t tile_end,
-                                                     bool pend, T myq, int type, unsigned kind, AnsvMemo<T>& memo, uint64_t nonsv,
+                                                     bool pend, T myq, int type, unsigned kind, AnsvMemo<T>& memo, MemoRegs<T>& mr, uint64_t nonsv,
                                                      uint64_t* __restrict__ out, uint64_t g, int skip) {
     uint64_t m = __ballot(pend);
     while (m) {
-        const int src = __builtin_ctzll(m);
-        const T vq = shfl<T>(myq, src);
-        const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, kind, memo, skip);
+        const unsigned src = (unsigned)__builtin_ctzll(m);
+        const T vq = answ_readlane<T>(myq, src);
+        const uint64_t r = ansv_global<T, LEFT>(P, n, tile_base, tile_end, vq, type, kind, memo, mr, skip);
         const bool mine = pend && myq == vq;
         if (mine) {
             if (kind == 0) out[g] = r == NSV_NONE ? nonsv : r;

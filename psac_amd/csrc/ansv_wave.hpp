@@ -27,7 +27,9 @@
 #define AW_FINAL_W 4
 #endif
 #ifndef AW_ABLATE
-#define AW_ABLATE 0          // (tools/experiments/ansv_ablate.sh: parts of the furthest_eq pass left out, to time them; results are wrong then)
+#define AW_ABLATE 0          // (tools/experiments/ansv_ablate.sh: parts of a pass left out, to time them; results are wrong then.  furthest_eq: 1 pointer
+                             //  doubling, 2 links, 4 the answers out, 8 the carried table; 16 no pyramid walks (ansv_tile.hpp); nearest types: 32 the answers out;
+                             //  64 the second queue loop, 128 both queue loops, 256 the carried table)
 #endif
 
 namespace psacx {
@@ -82,12 +84,6 @@ __device__ __forceinline__ void answ_load_run(const T* __restrict__ p, T (&a)[16
 }
 
 // type: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq (FUR)
-template <typename T> __device__ __forceinline__ T answ_readlane(T v, unsigned src);      // src: wave-uniform
-template <> __device__ __forceinline__ uint32_t answ_readlane<uint32_t>(uint32_t v, unsigned src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
-template <> __device__ __forceinline__ uint64_t answ_readlane<uint64_t>(uint64_t v, unsigned src) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);
-    return ((uint64_t)hi << 32) | lo;
-}
 
 // the run of this lane in tile t (padding past the end of the array: all ones)
 template <typename T>
@@ -102,15 +98,20 @@ __device__ __forceinline__ void answ_fetch(const T* __restrict__ in, uint64_t n,
 
 // (asking for the next pass's run as soon as the registers of this one are free was measured: 16 registers held through the pass, a few
 //  spills, nearest_sm pair 2.69 against 2.60 ms -- the pass is bound by its instruction count, not by the load at its head)
-template <typename T, bool LEFT, bool FUR>
-__device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyramid<T>& P, uint64_t n, uint64_t t, int type, uint64_t nonsv,
+// TYPE: 0 nearest_sm, 1 nearest_eq, 2 furthest_eq -- a template parameter since round 6: the compare of every pair is one instruction
+// instead of two compares and a select, and a kernel holds the code of its two passes only (45 - 90 KB of code per kernel before, against
+// 64 KB of instruction cache shared by two CUs)
+template <typename T, bool LEFT, int TYPE>
+__device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyramid<T>& P, uint64_t n, uint64_t t, uint64_t nonsv,
                                                uint64_t* __restrict__ out) {
     typedef AnsvWaveShared<T> SH;
     constexpr unsigned TILE = SH::TILE, RUN = SH::RUN;
     constexpr int SKIP = 1;                       // the tile edges are multiples of 64: nothing beyond them on level 0 of the pyramid
     const T* __restrict__ in = P.lvl[0];
     const unsigned lane = lane_id();
-    const bool strict = !FUR && type == 0;
+    constexpr bool FUR = TYPE == 2;
+    constexpr int type = TYPE;
+    constexpr bool strict = TYPE == 0;
     AnsvMemo<T>& memo = sh.memo[LEFT ? 0 : 1];
     const uint64_t tile_base = t * TILE;
     const uint64_t tile_end = tile_base + TILE < n ? tile_base + TILE : n;
@@ -119,6 +120,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     T mn;
     unsigned total;
     unsigned nslots = 0;                          // (furthest_eq) elements whose answers beyond the edge have been looked up, wave-uniform
+    MemoRegs<T> mr;
     {
         T a[16];
         answ_fetch<T>(in, n, t, a);
@@ -174,8 +176,9 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     {
         unsigned total2 = 0;
         nslots = 0;
+        mr = ansv_memo_load<T>(memo);          // (the table in registers from here to the end of the pass: ansv_tile.hpp)
 #pragma unroll 1
-        for (unsigned i0 = 0; i0 < total; i0 += 64) {
+        for (unsigned i0 = 0; i0 < ((AW_ABLATE & 128) ? 0u : total); i0 += 64) {
             const unsigned i = i0 + lane;
             const bool valid = i < total;
             const unsigned e = valid ? sh.q[i] : 0u;
@@ -196,14 +199,15 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
         }
         xrun_order();
         T W[6];
-        if (LEFT) ansv_tables_left<T>(mn, W); else ansv_tables_right<T>(mn, W);
+        if (!(AW_ABLATE & 512)) { if (LEFT) ansv_tables_left<T>(mn, W); else ansv_tables_right<T>(mn, W); }
 #pragma unroll 1
-        for (unsigned i0 = 0; i0 < total2; i0 += 64) {
+        for (unsigned i0 = 0; i0 < ((AW_ABLATE & (64 | 128)) ? 0u : total2); i0 += 64) {
             const unsigned i = i0 + lane;
             const bool valid = i < total2;
             const unsigned e = valid ? sh.q[i] : 0u;
             const T x = sh.v[e];
-            const unsigned tr = ansv_descend<T, LEFT>(W, e >> 4, x, strict);
+            const unsigned tr = (AW_ABLATE & 512) ? (LEFT ? ((e >> 4) >= 2 ? (e >> 4) - 2 : 64u) : ((e >> 4) + 2 < 64 ? (e >> 4) + 2 : 64u))      // (512: no descent, a made-up run)
+                                                  : ansv_descend<T, LEFT>(W, e >> 4, x, strict);
             const bool found = valid && tr < 64;
             unsigned pos = AW_PEND;
             if (__ballot(found)) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
             }
             const bool pend = valid && pos == AW_PEND;
             if (!FUR) {
-                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, type, 0u, memo, nonsv, out, tile_base + e, SKIP);
+                if (!(AW_ABLATE & 1024)) ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, type, 0u, memo, mr, nonsv, out, tile_base + e, SKIP);
                 if (pend) pos = AW_DONE;
             } else {
                 // furthest_eq: both answers beyond the edge are looked up here, once per distinct value of a queue step, and kept per
@@ -228,7 +232,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
                         const int src = __builtin_ctzll(m);
                         const T vq = shfl<T>(x, src);
                         bool goes_on;
-                        const uint64_t r0 = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, vq, memo, SKIP, &goes_on);
+                        const uint64_t r0 = ansv_global_fur<T, LEFT>(P, n, tile_base, tile_end, vq, memo, mr, SKIP, &goes_on);
                         const bool mine = pend && x == vq;
                         if (mine && fits) { sh.slot0[slot] = r0 == NSV_NONE ? nonsv : r0; sh.slot1[slot] = goes_on ? r0 : ANSV_NOCONT; }
                         m &= ~__ballot(mine);
@@ -240,7 +244,8 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
         }
     }
     xrun_order();
-    if (!FUR) {
+    if (!FUR && (AW_ABLATE & 32)) {
+    } else if (!FUR) {
         // ---- 5. the answers out, lane = element
         uint64_t* __restrict__ o = out + tile_base + lane;
 #pragma unroll 4
@@ -304,13 +309,26 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
                     if (beyond || far != ANSV_NOCONT) res = far;
                 }
                 if (in_range && (!beyond || looked_up)) out[g] = res;
-                if (overflow) {
-                    const bool pend = in_range && ne[k] == AW_PEND;
-                    const bool cont = in_range && !beyond && ar[k] == AW_PEND;
-                    const T x = sh.v[e], u = sh.v[r[k]];
-                    ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, 2, 0u, memo, nonsv, out, g, SKIP);
-                    ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, u, 2, 1u, memo, nonsv, out, g, SKIP);
-                }
+            }
+        }
+        if (overflow) {
+            // more elements without a <= element in the tile than slots (one falling run): those without a slot ask one by one, and so do
+            // the chains that end at one of them.  (Its own loop, not unrolled: the walks it holds were inlined eight times into the
+            // loop above -- 30 of the pass's 44 KB of code.)
+#pragma unroll 1
+            for (unsigned k = 0; k < RUN; ++k) {
+                const unsigned e = k * 64 + lane;
+                const uint64_t g = tile_base + e;
+                const bool in_range = e < n_rel;
+                const unsigned ne = sh.ans[e];
+                const bool beyond = ne >= AW_SLOT0;
+                const unsigned r = beyond ? 0u : sh.q[ne];
+                const unsigned ar = sh.ans[r];
+                const bool pend = in_range && ne == AW_PEND;
+                const bool cont = in_range && !beyond && ar == AW_PEND;
+                const T x = sh.v[e], u = sh.v[r];
+                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, pend, x, 2, 0u, memo, mr, nonsv, out, g, SKIP);
+                ansv_resolve_pending<T, LEFT>(P, n, tile_base, tile_end, cont, u, 2, 1u, memo, mr, nonsv, out, g, SKIP);
             }
         }
     }
@@ -318,23 +336,28 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     //      that element, the nearest one to the next tile, is then the new nearest answer.  furthest_eq: from that element j the chain
     //      runs to its far end r inside the tile (sh.q, step 4); when r's own nearest <= element lies beyond this tile's edge the chain may
     //      go on there, which the table may know (value u = in[j], kind 1): the entries as the previous tile left them.
-    if (!(FUR && (AW_ABLATE & 8))) {
-        const unsigned c = memo.cnt < ANSV_MEMO ? memo.cnt : ANSV_MEMO;
-        // (the entries in registers, one per lane)
-        const T mval = lane < c ? memo.val[lane] : (T)0;
-        const unsigned mkind = lane < c ? memo.kind[lane] : 0u;
-        const bool mlive = lane < c && memo.ready[lane] != 0;
+    if (!((FUR && (AW_ABLATE & 8)) || (AW_ABLATE & 256))) {
+        // (the entries in registers, one per lane, since the queue loops: mr)
+        const T mval = mr.val;
+        const unsigned mkind = mr.kind;
+        const bool mlive = mr.live;
         {
             // an entry per lane, all at once (round 5 took an entry at a time: a sixth of a furthest_eq pass, 7 % of a nearest one); every
             // entry reads the table as the previous tile left it
             if (__ballot(mlive)) {
-                const uint64_t myres = lane < c ? memo.res[lane] : 0ull;
-                T W[6];
-                if (LEFT) ansv_tables_left<T>(mn, W); else ansv_tables_right<T>(mn, W);
-                // the run nearest to the next tile whose minimum qualifies: the run at that edge itself, or the nearest one before it
-                const T edge_mn = answ_readlane<T>(mn, LEFT ? 63u : 0u);
-                unsigned rr = ansv_descend<T, LEFT>(W, LEFT ? 63u : 0u, mval, strict);
-                if (strict ? edge_mn < mval : edge_mn <= mval) rr = LEFT ? 63u : 0u;
+                const uint64_t myres = mr.res;
+                // the run nearest to the next tile whose minimum qualifies, entry by entry: a compare and a ballot over the run minima the
+                // lanes hold (no table of window minima, no descent: twelve dependent lane moves)
+                unsigned rr = 64u;
+                uint64_t todo = __ballot(mlive);
+                while (todo) {
+                    const unsigned i = (unsigned)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const T x = answ_readlane<T>(mval, i);
+                    const uint64_t bal = __ballot(strict ? mn < x : mn <= x);
+                    const unsigned ri = bal ? (LEFT ? 63u - (unsigned)__builtin_clzll(bal) : (unsigned)__builtin_ctzll(bal)) : 64u;
+                    if (lane == i) rr = ri;
+                }
                 T b[16];
                 answ_load_run<T>(sh.v + (mlive && rr < 64 ? rr : 0u) * RUN, b);
                 const int jj = answ_in_run<T, LEFT>(b, mval, strict);
@@ -381,7 +404,7 @@ __device__ __forceinline__ void ansv_wave_pass(AnsvWaveShared<T>& sh, const Pyra
     xrun_order();
 }
 
-template <typename T, bool LF, bool RF, int WAVES>
+template <typename T, int LT, int RT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, sizeof(T) == 4 ? 4 : 3) void ansv_wave_kernel(Pyramid<T> P, uint64_t n, int left_type, int right_type, uint64_t nonsv,
                                                                uint64_t* __restrict__ left, uint64_t* __restrict__ right, uint64_t ntiles) {
     // left / right may be null: that side is not computed (the distributed search asks for one side at a time)
@@ -397,8 +420,8 @@ __global__ __launch_bounds__(64 * WAVES, sizeof(T) == 4 ? 4 : 3) void ansv_wave_
     if (lane < 2 * ANSV_MEMO) sh.memo[lane / ANSV_MEMO].ready[lane % ANSV_MEMO] = 0;
     xrun_order();
     for (uint64_t k = 0; t_lo + k < t_hi; ++k) {
-        if (left) ansv_wave_pass<T, true, LF>(sh, P, n, t_lo + k, LF ? 2 : left_type, nonsv, left);
-        if (right) ansv_wave_pass<T, false, RF>(sh, P, n, t_hi - 1 - k, RF ? 2 : right_type, nonsv, right);
+        if (left) ansv_wave_pass<T, true, LT>(sh, P, n, t_lo + k, nonsv, left);
+        if (right) ansv_wave_pass<T, false, RT>(sh, P, n, t_hi - 1 - k, nonsv, right);
     }
 }
 
@@ -407,17 +430,18 @@ void launch_ansv_wave(psacx_ctx* c, const Pyramid<T>& P, uint64_t n, int lt, int
     constexpr int WAVES = 4;
     constexpr uint64_t TILE = AnsvWaveShared<T>::TILE;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
-#define PSACX_ANSW(LF, RF)                                                                                                       \
+#define PSACX_ANSW(LT, RT)                                                                                                       \
     do {                                                                                                                         \
         static int occ = 0;          /* (asked once per form: the kernel and its LDS are fixed) */                             \
-        if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_wave_kernel<T, LF, RF, WAVES>, 64 * WAVES, 0) != hipSuccess || occ < 1)) { (void)hipGetLastError(); occ = 1; } \
+        if (occ < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ansv_wave_kernel<T, LT, RT, WAVES>, 64 * WAVES, 0) != hipSuccess || occ < 1)) { (void)hipGetLastError(); occ = 1; } \
         const unsigned grid = (unsigned)std::min<uint64_t>((ntiles + WAVES - 1) / WAVES, (uint64_t)c->n_cu * occ);               \
-        hipLaunchKernelGGL((ansv_wave_kernel<T, LF, RF, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles); \
+        hipLaunchKernelGGL((ansv_wave_kernel<T, LT, RT, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, P, n, lt, rt, nonsv, d_l, d_r, ntiles); \
     } while (0)
-    if (lt == 2 && rt == 2) PSACX_ANSW(true, true);
-    else if (lt == 2) PSACX_ANSW(true, false);
-    else if (rt == 2) PSACX_ANSW(false, true);
-    else PSACX_ANSW(false, false);
+    switch (lt * 3 + rt) {
+    case 0: PSACX_ANSW(0, 0); break; case 1: PSACX_ANSW(0, 1); break; case 2: PSACX_ANSW(0, 2); break;
+    case 3: PSACX_ANSW(1, 0); break; case 4: PSACX_ANSW(1, 1); break; case 5: PSACX_ANSW(1, 2); break;
+    case 6: PSACX_ANSW(2, 0); break; case 7: PSACX_ANSW(2, 1); break; default: PSACX_ANSW(2, 2); break;
+    }
 #undef PSACX_ANSW
 }
 
