@@ -2216,7 +2216,7 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
     __shared__ uint32_t rq_buf[(WITH_LCP && !DIST) ? (BLOCK / WAVE) * RQ_CAP * 3 : 1];
     const bool rq_queue = WITH_LCP && !DIST && n <= (1ull << 32);
     const T p2_first = p2;
-    unsigned rq = 0;
+    unsigned rq = 0, rz = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t e = e0 + j;
@@ -2230,49 +2230,68 @@ __global__ __launch_bounds__(BLOCK) void rebucket_refine_kernel(
             const uint64_t at = (uint64_t)ps[j] - bd.off;
             const T lo = p2 < a2[j] ? p2 : a2[j];
             const T hi = p2 < a2[j] ? a2[j] : p2;
-            if (p2 == 0 || a2[j] == 0) {
+            if (!DIST) {
+                // (one GPU: every such boundary goes through the wave's queue below, also the ones beside a suffix that ends within h
+                //  characters -- rank 0: LCP = h unless the entry is set already -- so that the walk over the pyramid and the store into
+                //  it exist ONCE in the kernel: inlined per record they made 57 of its 68 KB of code)
+                rq |= 1u << j;
+                if (p2 == 0 || a2[j] == 0) rz |= 1u << j;
+            } else if (p2 == 0 || a2[j] == 0) {
                 if (pyr.lvl[0][at] == (T)n) pyramid_set<T>(pyr, at, (T)h);          // (DIST: a pyramid of level 0 only unless the caller keeps one)
-            } else if (DIST) {
+            } else {
                 const unsigned long long slot = atomicAdd(q_count, 1ull);
                 q_at[slot] = ps[j]; q_lo[slot] = lo; q_hi[slot] = hi;
-            } else if (rq_queue) {
-                rq |= 1u << j;
-            } else {
-                const T m = pyramid_min<T>(pyr, (uint64_t)lo, (uint64_t)hi);
-                pyramid_set<T>(pyr, at, (T)(h + m));
             }
         }
         p1 = a1[j]; p2 = a2[j];
         if (id[j] > run) run = id[j];
     }
     if constexpr (WITH_LCP && !DIST) {
-        if (rq_queue && __ballot(rq != 0)) {
+        if (__ballot(rq != 0)) {
+            // entries: place in LCP, then the two ranks - 1 as 32-bit words (texts of at most 2^32 characters); longer texts (no one-GPU
+            // text is) keep their ranks as they are, in a queue of 64-bit words that takes a lane's records one at a time
             uint32_t* const qb = rq_buf + (threadIdx.x / WAVE) * (RQ_CAP * 3);
             const unsigned lane = lane_id();
-#pragma unroll
-            for (int part = 0; part < ITEMS / RQ_PER; ++part) {
+            static_assert(ITEMS == 2 * RQ_PER, "the queue takes a lane's records in two parts");
+            const int nparts = rq_queue ? 2 : ITEMS;
+#pragma unroll 1
+            for (int part = 0; part < nparts; ++part) {
                 unsigned qn = 0;
 #pragma unroll
                 for (int jj = 0; jj < RQ_PER; ++jj) {
-                    const int j = part * RQ_PER + jj;
+                    if (!rq_queue && jj) break;
+                    // (a lane's record of this part, picked by selects: no register array is indexed by a loop variable)
+                    const int j = rq_queue ? part * RQ_PER + jj : part;
                     const bool has = (rq >> j) & 1u;
                     const uint64_t mo = __ballot(has);
                     if (has) {
-                        const T pv = j ? a2[j ? j - 1 : 0] : p2_first;
-                        const T lo = pv < a2[j] ? pv : a2[j], hi = pv < a2[j] ? a2[j] : pv;
+                        T cur = a2[0], pv = p2_first, pos_ = ps[0];
+#pragma unroll
+                        for (int t = 1; t < ITEMS; ++t) if (t == j) { cur = a2[t]; pv = a2[t - 1]; pos_ = ps[t]; }
+                        const T lo = pv < cur ? pv : cur, hi = pv < cur ? cur : pv;
+                        const bool zero = (rz >> j) & 1u;
                         const unsigned slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mo, 0u));
-                        qb[slot * 3 + 0] = (uint32_t)((uint64_t)ps[j] - bd.off);
-                        qb[slot * 3 + 1] = (uint32_t)((uint64_t)lo - 1);
-                        qb[slot * 3 + 2] = (uint32_t)((uint64_t)hi - 1);
+                        const uint64_t at = (uint64_t)pos_ - bd.off;
+                        if (rq_queue) {
+                            qb[slot * 3 + 0] = (uint32_t)at;
+                            qb[slot * 3 + 1] = zero ? 0xFFFFFFFFu : (uint32_t)((uint64_t)lo - 1);          // (lo - 1 <= n - 2: never all ones)
+                            qb[slot * 3 + 2] = (uint32_t)((uint64_t)hi - 1);
+                        } else {
+                            uint64_t* const qw = reinterpret_cast<uint64_t*>(qb);          // (64 entries of three words: half the queue's room)
+                            qw[slot * 3 + 0] = at; qw[slot * 3 + 1] = zero ? ~0ull : (uint64_t)lo; qw[slot * 3 + 2] = (uint64_t)hi;
+                        }
                     }
                     qn += (unsigned)__builtin_popcountll(mo);
                 }
                 xrun_order();
                 for (unsigned i = lane; i < qn; i += WAVE) {
-                    const uint64_t at = qb[i * 3 + 0];
-                    const uint64_t lo = (uint64_t)qb[i * 3 + 1] + 1, hi = (uint64_t)qb[i * 3 + 2] + 1;
-                    const T m = pyramid_min<T>(pyr, lo, hi);
-                    pyramid_set<T>(pyr, at, (T)(h + m));
+                    uint64_t at, lo, hi; bool zero;
+                    if (rq_queue) { at = qb[i * 3 + 0]; zero = qb[i * 3 + 1] == 0xFFFFFFFFu; lo = (uint64_t)qb[i * 3 + 1] + 1; hi = (uint64_t)qb[i * 3 + 2] + 1; }
+                    else { const uint64_t* const qw = reinterpret_cast<const uint64_t*>(qb); at = qw[i * 3 + 0]; zero = qw[i * 3 + 1] == ~0ull; lo = qw[i * 3 + 1]; hi = qw[i * 3 + 2]; }
+                    // a boundary beside a suffix that ends within h characters: LCP = h unless set already; else h + the minimum between the ranks
+                    const bool go = zero ? pyr.lvl[0][at] == (T)n : true;
+                    const T m = zero ? (T)0 : pyramid_min<T>(pyr, lo, hi);
+                    if (go) pyramid_set<T>(pyr, at, (T)(h + m));
                 }
                 xrun_order();
             }
