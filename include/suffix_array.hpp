@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <fstream>
+#include <limits>
 #include <iostream>
 #include <iterator>
 #include <stdexcept>
@@ -234,7 +235,7 @@ private:
         if (n == 0) throw std::runtime_error("psacx: empty input");
         std::vector<uint8_t> bytes(n);
         std::vector<char_t> chars;
-        densify(begin, end, bytes, chars);
+        const unsigned w = densify(begin, end, bytes, chars);
         if (given) {
             const std::vector<char_t>& have = given->unique_chars();
             for (std::size_t i = 0; i < chars.size(); ++i)
@@ -250,7 +251,30 @@ private:
         std::vector<uint8_t> lc;
         if (_CONSTRUCT_LC) lc.assign(n, 0);
         int rc;
-        if (multi_) {
+        if (w > 1) {
+            // more than 256 distinct symbols: the engine builds the arrays of the text of w bytes per symbol, reduce_wide keeps the
+            // suffixes that start on a symbol boundary
+            if ((uint64_t)n * w > (uint64_t)std::numeric_limits<index_t>::max())
+                throw std::runtime_error("psacx: the text of this many distinct symbols needs a wider index type");
+            if (multi_ && !fast_resolval) throw std::runtime_error("psacx: fast_resolval = false needs a single-rank communicator");
+            struct length_guard {                       // run() and run_multi() read the length from the object
+                std::size_t& n; std::size_t n0;
+                length_guard(std::size_t& n_, std::size_t bytes_) : n(n_), n0(n_) { n = bytes_; }
+                ~length_guard() { n = n0; }
+            };
+            std::vector<index_t> sa((std::size_t)n * w), isa((std::size_t)n * w), lcp;
+            if (_CONSTRUCT_LCP) lcp.assign((std::size_t)n * w, 0);
+            {
+                length_guard g(n, (std::size_t)n * w);
+                rc = multi_ ? run_multi(bytes.data(), k * w, flags, sa.data(), isa.data(), _CONSTRUCT_LCP ? lcp.data() : nullptr, nullptr)
+                            : run(bytes.data(), k * w, flags, sa.data(), isa.data(), _CONSTRUCT_LCP ? lcp.data() : nullptr, nullptr);
+            }
+            if (multi_) {
+                if (rc != PSACX_OK) throw std::runtime_error(std::string("psacx: ") + (rc > -7 ? psacx_strerror(rc) : "RCCL failure") + " [" +
+                                                             psacx_multi_last_error(multi_) + "]");
+            } else psacx::check(ctx_, rc);
+            reduce_wide(w, sa, lcp);
+        } else if (multi_) {
             // p ranks, one GPU each: blocks of n / p characters (mxx::blk_dist), results gathered in rank order
             if (!fast_resolval) throw std::runtime_error("psacx: fast_resolval = false needs a single-rank communicator");
             rc = run_multi(bytes.data(), k, flags, local_SA.data(), local_B.data(), _CONSTRUCT_LCP ? local_LCP.data() : nullptr,
@@ -266,9 +290,12 @@ private:
         if (_CONSTRUCT_LC) {
             // positions past the end carry '\0' (alphabet.hpp:168); they are exactly those with SA[i-1] + LCP[i] == n
             local_Lc.assign(n, (char_t)0);
+            std::vector<char_t> sym;
+            if (w > 1) sym.assign(begin, end);          // (wide symbols: the character itself, read from the caller's text)
             for (std::size_t i = 1; i < n; ++i) {
-                if ((std::size_t)local_SA[i - 1] + (std::size_t)local_LCP[i] >= n) continue;
-                local_Lc[i] = sizeof(char_t) == 1 ? (char_t)lc[i] : chars[lc[i]];
+                const std::size_t at = (std::size_t)local_SA[i - 1] + (std::size_t)local_LCP[i];
+                if (at >= n) continue;
+                local_Lc[i] = w > 1 ? sym[at] : sizeof(char_t) == 1 ? (char_t)lc[i] : chars[lc[i]];
             }
         }
         psacx_stats st;
@@ -402,10 +429,13 @@ private:
         return run(t, k, flags, reinterpret_cast<W*>(sa), reinterpret_cast<W*>(isa), reinterpret_cast<W*>(lcp), lc);
     }
 
-    // bytes pass through; wider symbols (int alphabets, test/test_psac.cpp:277-304) are ranked
-    // to bytes, which keeps their order, as long as at most 256 distinct symbols occur
+    // bytes pass through; wider symbols (int alphabets, test/test_psac.cpp:277-304) are ranked among the distinct symbols that occur,
+    // which keeps their order.  At most 256 of them: one byte per symbol.  More (the reference's alphabet<int> is unbounded,
+    // alphabet.hpp:205-236): the rank as w = 2, 3 or 4 bytes, most significant first -- fixed-width big-endian codes compare as the
+    // symbols do, so the suffixes of the byte text that start on a symbol boundary stand in the order of the symbol text's suffixes
+    // (reduce_wide below).  Returns w.
     template <typename Iterator>
-    void densify(Iterator begin, Iterator end, std::vector<uint8_t>& bytes, std::vector<char_t>& chars) {
+    unsigned densify(Iterator begin, Iterator end, std::vector<uint8_t>& bytes, std::vector<char_t>& chars) {
         typedef typename std::make_unsigned<char_t>::type uchar_t;
         chars.clear();
         if (sizeof(char_t) == 1) {
@@ -413,26 +443,39 @@ private:
             std::size_t i = 0;
             for (Iterator it = begin; it != end; ++it, ++i) { const uint8_t b = (uint8_t)(uchar_t)*it; bytes[i] = b; used[b] = true; }
             for (int ch = 0; ch < 256; ++ch) if (used[ch]) chars.push_back((char_t)(uchar_t)ch);
-            return;
+            return 1;
         }
         std::vector<uchar_t> u; u.reserve(n);
         for (Iterator it = begin; it != end; ++it) u.push_back((uchar_t)*it);
-        std::vector<uchar_t> uniq;                      // distinct symbols, ascending by unsigned value
-        {
-            std::vector<uchar_t> seen;
-            for (std::size_t i = 0; i < n; ++i) {
-                // symbols are few: a sorted vector probed by binary search
-                typename std::vector<uchar_t>::iterator at = std::lower_bound(seen.begin(), seen.end(), u[i]);
-                if (at == seen.end() || *at != u[i]) {
-                    seen.insert(at, u[i]);
-                    if (seen.size() > 256) throw std::runtime_error("psacx: more than 256 distinct symbols");
-                }
-            }
-            uniq.swap(seen);
-        }
+        std::vector<uchar_t> uniq(u);                   // distinct symbols, ascending by unsigned value
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
         for (std::size_t i = 0; i < uniq.size(); ++i) chars.push_back((char_t)uniq[i]);
-        for (std::size_t i = 0; i < n; ++i)
-            bytes[i] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), u[i]) - uniq.begin());
+        unsigned w = 1;
+        while (w < 4 && (uniq.size() - 1) >> (8 * w)) ++w;
+        if ((uint64_t)(uniq.size() - 1) >> 32) throw std::runtime_error("psacx: more than 2^32 distinct symbols");
+        bytes.resize(n * w);
+        for (std::size_t i = 0; i < n; ++i) {
+            const uint64_t r = (uint64_t)(std::lower_bound(uniq.begin(), uniq.end(), u[i]) - uniq.begin());
+            for (unsigned b = 0; b < w; ++b) bytes[i * w + b] = (uint8_t)(r >> (8 * (w - 1 - b)));
+        }
+        return w;
+    }
+    // Results over the byte text of w bytes per symbol -> results over the symbols.  The suffixes that start on a symbol boundary, in
+    // the order they have in SA', are SA; the rank among them is ISA; the common prefix of two neighbours among them is the minimum of
+    // LCP' over the entries between them, in whole symbols.
+    void reduce_wide(unsigned w, const std::vector<index_t>& sa, const std::vector<index_t>& lcp) {
+        std::size_t r = 0;
+        uint64_t run = ~(uint64_t)0;                    // minimum of LCP' since the last kept entry
+        for (std::size_t j = 0; j < sa.size(); ++j) {
+            if (!lcp.empty() && j && (uint64_t)lcp[j] < run) run = (uint64_t)lcp[j];
+            if ((uint64_t)sa[j] % w) continue;
+            const std::size_t i = (std::size_t)((uint64_t)sa[j] / w);
+            local_SA[r] = (index_t)i; local_B[i] = (index_t)r;
+            if (!lcp.empty()) local_LCP[r] = r ? (index_t)(run / w) : (index_t)0;
+            run = ~(uint64_t)0;
+            ++r;
+        }
     }
     template <typename V> static void dump(const std::string& fn, const std::vector<V>& v) {
         std::ofstream f(fn.c_str(), std::ios::binary | std::ios::trunc);

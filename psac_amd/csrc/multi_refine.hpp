@@ -97,11 +97,18 @@ int MultiRun<T>::refine_sort(std::vector<Rec<T>>& rec, const std::vector<const T
             MG_HIP(g, hipGetLastError());
             MG_HIP(g, hipStreamSynchronize(c->stream));          // (the second record set goes back to the cache when this scope ends)
         } else if (len >= 2) {
+            // (32-bit words, or keys too wide for one word: three arrays of the middle section's length only -- the records of the shared
+            //  buckets at both ends are refilled from sh[] below -- and the sorted section copied back where the passes left it there)
             Rec<T> alt;
-            PSACX_TRY(take3(i, alt, cn));
+            PSACX_TRY(take3(i, alt, len));
             int32_t where = 0;
-            MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p + lo, rec[i].k2.p + lo, rec[i].v.p + lo, alt.k1.p + lo, alt.k2.p + lo, alt.v.p + lo, len, bits1, bits2, &where));
-            if (where) swap3(rec[i], alt);
+            MG_OP(g, c, op_pair_sort<T>(c, rec[i].k1.p + lo, rec[i].k2.p + lo, rec[i].v.p + lo, alt.k1.p, alt.k2.p, alt.v.p, len, bits1, bits2, &where));
+            if (where) {
+                MG_HIP(g, hipMemcpyAsync(rec[i].k1.p + lo, alt.k1.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                MG_HIP(g, hipMemcpyAsync(rec[i].k2.p + lo, alt.k2.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                MG_HIP(g, hipMemcpyAsync(rec[i].v.p + lo, alt.v.p, len * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+                MG_HIP(g, hipStreamSynchronize(c->stream));
+            }
             drop3(i, alt);
         }
         if (any && ns[i]) {

@@ -96,6 +96,53 @@ int main(int argc, char** argv) {
         CHECK(si.local_Lc == ilc);
     }
     {
+        // more than 256 distinct symbols (the reference's alphabet<int> is unbounded, alphabet.hpp:205-236): the text goes to the
+        // engine as two (three) bytes per symbol.  Expected arrays: comparison sort of the suffixes, common prefixes counted directly.
+        for (int variant = 0; variant < 3; ++variant) {
+            const std::size_t m = variant == 2 ? 3000 : 20000;
+            const unsigned distinct = variant == 0 ? 1000u : variant == 1 ? 300u : 70000u;
+            std::vector<int> v(m);
+            uint64_t x = 88172645463325252ull + variant;
+            for (std::size_t i = 0; i < m; ++i) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                // (repeats, so that common prefixes of several symbols occur; negative values sort above the positive ones: unsigned order)
+                v[i] = (i >= 500 && (x >> 60) < 3) ? v[i - 500] : (int)((x >> 20) % distinct) * (variant == 1 ? -7919 : 7919) - 5;
+            }
+            if (variant == 2) for (std::size_t i = 0; i < m; ++i) v[i] = (int)(i * 23u % distinct);          // all 70000 > 2^16 values cannot occur in 3000: force them
+            if (variant == 2) { v.resize(70000 + 3000); for (std::size_t i = 3000; i < v.size(); ++i) v[i] = (int)(i - 3000); }
+            const std::size_t nn = v.size();
+            std::vector<uint32_t> esa(nn), eisa(nn), elcp(nn, 0);
+            for (std::size_t i = 0; i < nn; ++i) esa[i] = (uint32_t)i;
+            std::sort(esa.begin(), esa.end(), [&](uint32_t a, uint32_t b) {
+                return std::lexicographical_compare(v.begin() + a, v.end(), v.begin() + b, v.end(),
+                                                    [](int c, int d) { return (unsigned)c < (unsigned)d; });
+            });
+            for (std::size_t r = 0; r < nn; ++r) eisa[esa[r]] = (uint32_t)r;
+            for (std::size_t r = 1; r < nn; ++r) {
+                std::size_t a = esa[r - 1], b = esa[r], l = 0;
+                while (a + l < nn && b + l < nn && v[a + l] == v[b + l]) ++l;
+                elcp[r] = (uint32_t)l;
+            }
+            suffix_array<int, uint32_t, true, true> sw((psacx::comm(0)));
+            sw.verbose = false;
+            sw.construct(v.begin(), v.end());
+            CHECK(sw.n == nn && sw.local_SA.size() == nn);
+            CHECK(sw.alpha.sigma() > 256);
+            CHECK(sw.local_SA == esa);
+            CHECK(sw.local_B == eisa);
+            CHECK(sw.local_LCP == elcp);
+            for (std::size_t r = 1; r < nn; ++r) {
+                const std::size_t at = (std::size_t)esa[r - 1] + elcp[r];
+                CHECK(sw.local_Lc[r] == (at < nn ? v[at] : 0));
+            }
+            suffix_array<int, uint64_t, false> s64((psacx::comm(0)));
+            s64.verbose = false;
+            s64.construct(v.begin(), v.end(), true, 2);
+            CHECK(s64.local_LCP.empty());
+            for (std::size_t r = 0; r < nn; ++r) CHECK(s64.local_SA[r] == esa[r] && s64.local_B[r] == eisa[r]);
+        }
+    }
+    {
         // generalized suffix array (test/test_gsa.cpp:73-105, SimpleTiny)
         std::vector<std::string> strs = {"abab", "baba"};
         std::string flat = flatten_strings(strs);
