@@ -577,6 +577,8 @@ struct SortScratch {
     unsigned long long* d_summary; // OR/AND of the keys (see key_summary_add), 4 words
     unsigned long long* h_summary; // pinned, 4 words
     unsigned long long* d_partials;// per-workgroup key summaries of the producer kernel
+    uint8_t* d_dig = nullptr;      // digit bytes between the three-kernel passes of a sort of 64-bit words with 32-bit payloads (dispatch_pass3), or null
+    uint64_t dig_cap = 0;          // ... records it has room for
 };
 
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
@@ -626,7 +628,10 @@ inline void dispatch_scatter(psacx_ctx* c, const T* kd_in, const T* ko_in, const
 template <typename T>
 inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T* v_in, T* kd_out, T* ko_out, T* v_out,
                            uint64_t n, int shift, const unsigned long long* base, char* scratch, uint64_t spec, uint64_t spec_n,
-                           bool have_hist = false, int vn = 0) {
+                           bool have_hist = false, int vn = 0, const uint8_t* dig_in = nullptr, uint8_t* dig_out = nullptr, int dig_shift = 0, int dig_ko = 0) {
+    // dig_in: the digit of this pass of the record at every place, one byte each, left by the pass before -- the tile histograms read it instead of
+    // the records (8 bytes per record less); dig_out (vn == 1 only): this pass leaves the byte of the NEXT pass (bits dig_shift .. + 7 of the digit
+    // word, or of the other key word when dig_ko) beside its records.  One array serves both: the histograms are done when the scatter starts.
     constexpr int BLOCK = ScatterCfg<T>::BLOCK, ITEMS = ScatterCfg<T>::ITEMS, TILE = BLOCK * ITEMS;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const unsigned slab_tiles = slab_tiles_for(ntiles);
@@ -635,7 +640,11 @@ inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
     unsigned long long* slab_tot = reinterpret_cast<unsigned long long*>(scratch + 256 + ((ntiles * RADIX * sizeof(unsigned) + 255) & ~(size_t)255));
     {
         ProfScope ps(c, TC_SORT_TILEHIST);
-        if (!have_hist)        // (the producer of the keys may have left this pass's tile histograms in place)
+        if (have_hist) {       // (the producer of the keys may have left this pass's tile histograms in place)
+        } else if (dig_in)
+            hipLaunchKernelGGL((radix_tile_hist_bytes_flat_kernel<BLOCK, TILE>), dim3((unsigned)((ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0, c->stream,
+                               dig_in, n, ntiles, tile_hist);
+        else
             hipLaunchKernelGGL((radix_tile_hist_kernel<T, BLOCK, ITEMS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, n,
                                shift, tile_hist);
         hipLaunchKernelGGL(radix_slab_scan_kernel<0>, dim3((unsigned)nslabs), dim3(RADIX), 0, c->stream, tile_hist, ntiles, slab_tot, slab_tiles);
@@ -648,6 +657,12 @@ inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
     if constexpr (sizeof(T) == 8) {
         // 32-bit payload arrays: registers capped for six waves per SIMD = three workgroups per CU: the narrow forms need 82, the cap
         // costs them a few spilled registers and gains a third tile in flight (the pass is bound by the latency chain of a tile)
+        if (vn == 1 && !ko_in && dig_out) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 6, true, 1, sizeof(T), true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, ko_in, v_in, kd_out,
+                               ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n, counter, chunk, (const T*)nullptr, slab_tiles,
+                               (uint64_t)0, 0u, dig_out, dig_shift, 0);
+            return;
+        }
         if (vn == 1 && !ko_in) {
             hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 6, true, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in, ko_in, v_in, kd_out,
                                ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n, counter, chunk, (const T*)nullptr, slab_tiles);
@@ -662,6 +677,12 @@ inline void dispatch_pass3(psacx_ctx* c, const T* kd_in, const T* ko_in, const T
     if constexpr (sizeof(T) == 8) {
         // three-word records whose payload stays below 2^32 (the suffixes of a text of at most 2^32 characters): 32-bit payload entries
         // between the passes here too -- 40 instead of 48 bytes per record and pass (the one-stage first round of repetitive texts)
+        if (ko_in && vn == 1 && dig_out) {
+            hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1, false, 1, sizeof(T), true>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
+                               ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
+                               counter, chunk, (const T*)nullptr, slab_tiles, (uint64_t)0, 0u, dig_out, dig_shift, dig_ko);
+            return;
+        }
         if (ko_in && vn == 1) {
             hipLaunchKernelGGL((radix_scatter3_kernel<T, BLOCK, ITEMS, false, 1, false, 1>), dim3((unsigned)ntiles), dim3(BLOCK), 0, c->stream, kd_in,
                                ko_in, v_in, kd_out, ko_out, v_out, n, shift, base, tile_hist, slab_tot, (unsigned long long*)nullptr, spec, spec_n,
@@ -869,6 +890,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
     if (keep_v32 && (!v32_in || final_v)) return PSACX_EINVAL;
     SortBufs<T> cur = in, oth = alt;
     int done = 0;
+    bool dig_ready = false;          // the pass before left this pass's digit bytes in sc.d_dig
     for (int p = 0; p < plan.n_pass; ++p) {
         if (skip[p]) continue;
         const bool first = (done == 0);
@@ -885,10 +907,19 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         char* const desc = dev_scan ? sc.d_desc + (size_t)(done - 1) * desc_stride : sc.d_desc;
         if (!dev_scan) PSACX_HIP(c, hipMemsetAsync(sc.d_desc, 0, three ? 256 : dbytes, c->stream));
         const unsigned long long* base = sc.d_base + (size_t)p * RADIX;
+        bool dig_next = false;
         if (three) {
             const bool have_hist = first && plan.word[p] == 0 && plan.shift[p] == ready_hist_shift;
             const int vn = narrow ? ((last && !keep_v32) ? ((first && !v32_in) ? 0 : 2) : 1) : 0;
-            dispatch_pass3<T>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, spec, spec_n, have_hist, vn);
+            // the digit of the next executed pass travels as a byte beside the records this pass writes (not out of a pass that writes padded
+            // or widened output, and only when the caller gave the array)
+            int q = p + 1;
+            while (q < plan.n_pass && skip[q]) ++q;
+            dig_next = sizeof(T) == 8 && vn == 1 && !last && q < plan.n_pass && sc.d_dig && n <= sc.dig_cap;
+            dispatch_pass3<T>(c, kd_in, ko_in, v_in, kd_out, ko_out, v_out, n, plan.shift[p], base, sc.d_desc, spec, spec_n, have_hist, vn,
+                              dig_ready ? sc.d_dig : (const uint8_t*)nullptr, dig_next ? sc.d_dig : (uint8_t*)nullptr, dig_next ? plan.shift[q] : 0,
+                              dig_next && plan.word[q] != plan.word[p] ? 1 : 0);
+            dig_ready = dig_next;
             PSACX_HIP(c, hipGetLastError());
         } else {
             ProfScope ps(c, TC_SORT_SCATTER);
@@ -900,7 +931,7 @@ int pair_sort(psacx_ctx* c, SortScratch& sc, SortBufs<T> in, SortBufs<T> alt, ui
         c->stats.scatter_launches[form] += 1;
         c->stats.scatter_records[form] += n;
         // words read + written per record; a pass that makes up its payload (iota) reads one word less
-        if (narrow) c->stats.scatter_bytes[form] += ((in.k2 ? 4ull : 2ull) * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull)) * n;
+        if (narrow) c->stats.scatter_bytes[form] += ((in.k2 ? 4ull : 2ull) * sizeof(T) + (v_in ? ((first && !v32_in) ? sizeof(T) : 4ull) : 0ull) + (last ? sizeof(T) : 4ull) + (dig_next ? 1ull : 0ull)) * n;
         else c->stats.scatter_bytes[form] += ((in.k2 ? 6ull : 4ull) - (v_in ? 0ull : 1ull)) * sizeof(T) * n;
         std::swap(cur, oth);
         cur.v = v_out;

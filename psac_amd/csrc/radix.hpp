@@ -165,7 +165,9 @@ template <typename T, int TILE, int NW> struct ScatterShared {
 // prefix sort then moves 12 instead of 16 bytes per record and pass.
 // CLSB (EXT only): bytes per entry of the class array dsrc (sizeof(T), or 1 for a byte array).
 // voff: added to the payload a pass makes up itself (v_in == nullptr): the records of a rank's block, or of a piece of it.
-template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int VN = 0, int CLSB = sizeof(T)>
+// DNEXT3 (records of several words, three-kernel form): as dnext below for the passes of radix_scatter3_kernel -- the byte comes from the digit word
+// (dnext_ko = 0) or from the other key word (dnext_ko = 1: the next pass sorts on a digit of that word)
+template <typename T, typename D, int BLOCK, int ITEMS, bool FULL, bool LB, bool EXT = false, bool NOKO = false, int VN = 0, int CLSB = sizeof(T), bool DNEXT3 = false>
 __device__ __forceinline__ void radix_scatter_tile(
     ScatterShared<T, BLOCK * ITEMS, BLOCK / WAVE>& sh, const unsigned tile, const unsigned count,
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
@@ -174,7 +176,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     unsigned long long* __restrict__ dbg, const uint64_t spec, const uint64_t spec_n,
     const unsigned* __restrict__ tile_excl, const unsigned long long* __restrict__ slab_excl,
     const T* __restrict__ dsrc = nullptr, const unsigned slab_tiles = SLAB_TILES, const uint64_t voff = 0, const unsigned pack = 0,
-    const T (*kd_made)[ITEMS] = nullptr, uint8_t* __restrict__ dnext = nullptr, const int dnext_shift = 0, const uint64_t out_pad = 0) {
+    const T (*kd_made)[ITEMS] = nullptr, uint8_t* __restrict__ dnext = nullptr, const int dnext_shift = 0, const uint64_t out_pad = 0,
+    const int dnext_ko = 0) {
     // out_pad: the records of digit d land d * out_pad places further (the pass on the top digit: 256 output fronts that lie a multiple of
     // 2^27 bytes apart alias in the memory channels -- 14.1 against 7.2 ms for the stores alone at 2^32 records, tools/ubench_fronts.hip)
     // dnext (one-word records out): byte `at` receives bits dnext_shift .. + 7 of the record written to place `at` -- the digit the NEXT pass
@@ -377,6 +380,7 @@ __device__ __forceinline__ void radix_scatter_tile(
             } else {
                 kd_out[at] = x;
                 if (ONEW_OUT && dnext) dnext[at] = (uint8_t)((uint64_t)x >> dnext_shift);
+                if (DNEXT3 && !dnext_ko) dnext[at] = (uint8_t)((uint64_t)x >> dnext_shift);
             }
         }
     }
@@ -391,7 +395,11 @@ __device__ __forceinline__ void radix_scatter_tile(
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const unsigned p = tid + j * BLOCK;
-            if (FULL || p < count) ko_out[(T)(goff[sdig[p]] + (T)p)] = stage[p];
+            if (FULL || p < count) {
+                const T at = (T)(goff[sdig[p]] + (T)p);
+                ko_out[at] = stage[p];
+                if (DNEXT3 && dnext_ko) dnext[at] = (uint8_t)((uint64_t)stage[p] >> dnext_shift);
+            }
         }
         __syncthreads();
     }
@@ -590,14 +598,15 @@ __global__ __launch_bounds__(RADIX) void radix_top_scan_kernel(unsigned long lon
     digit_base[d] = start;
 }
 
-template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int VN = 0, int CLSB = sizeof(T)>
+template <typename T, int BLOCK, int ITEMS, bool EXT = false, int MINW = 1, bool NOKO = false, int VN = 0, int CLSB = sizeof(T), bool DNEXT3 = false>
 __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const T* __restrict__ kd_in, const T* __restrict__ ko_in, const T* __restrict__ v_in,
     T* __restrict__ kd_out, T* __restrict__ ko_out, T* __restrict__ v_out, uint64_t n, int shift,
     const unsigned long long* __restrict__ digit_base, const unsigned* __restrict__ tile_excl,
     const unsigned long long* __restrict__ slab_excl, unsigned long long* __restrict__ dbg, uint64_t spec,
     uint64_t spec_n, unsigned* __restrict__ tile_counter, unsigned chunk, const T* __restrict__ dsrc = nullptr,
-    unsigned slab_tiles = SLAB_TILES, uint64_t voff = 0, unsigned pack = 0) {
+    unsigned slab_tiles = SLAB_TILES, uint64_t voff = 0, unsigned pack = 0, uint8_t* __restrict__ dnext = nullptr, int dnext_shift = 0, int dnext_ko = 0) {
+    // dnext (DNEXT3): one byte per record, at the record's place in the output: the digit the next pass sorts on (radix_tile_hist_bytes_flat_kernel)
     // (a persistent variant, one workgroup looping over tiles with its next ticket prefetched, was
     // measured: the loop raised the register count from 118 to 173 and lost 20 %)
     constexpr int TILE = BLOCK * ITEMS;
@@ -613,13 +622,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void radix_scatter3_kernel(
     const unsigned tile = sh.s_tile;
     const uint64_t remain = n - (uint64_t)tile * TILE;
     if (remain >= (uint64_t)TILE)
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, VN, CLSB>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, true, false, EXT, NOKO, VN, CLSB, DNEXT3>(sh, tile, (unsigned)TILE, kd_in, ko_in, v_in, kd_out,
                                                                         ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
+                                                                        spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack,
+                                                                        nullptr, dnext, dnext_shift, 0, dnext_ko);
     else
-        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, VN, CLSB>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
+        radix_scatter_tile<T, unsigned, BLOCK, ITEMS, false, false, EXT, NOKO, VN, CLSB, DNEXT3>(sh, tile, (unsigned)remain, kd_in, ko_in, v_in, kd_out,
                                                                          ko_out, v_out, shift, digit_base, nullptr, nullptr, dbg,
-                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack);
+                                                                         spec, spec_n, tile_excl, slab_excl, dsrc, slab_tiles, voff, pack,
+                                                                         nullptr, dnext, dnext_shift, 0, dnext_ko);
 }
 
 // ---------------------------------------------------------------------------
@@ -749,6 +760,41 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_kernel(const uint
     if (lane == 0 && a0 != g0) piece(a0 + 16ull * 4 * WAVE);
     xrun_order();
     unsigned* row = tile_hist + (uint64_t)vt * RADIX;
+#pragma unroll
+    for (int i = 0; i < RADIX / WAVE; ++i) row[i * WAVE + lane] = my[i * WAVE + lane];
+}
+
+// ... and for the flat arrays of the three-kernel passes (engine.hpp: dispatch_pass3): tile t is the TILE bytes from t * TILE on, a wave per tile,
+// the array 16-byte aligned and readable up to the next multiple of 16 beyond n.  The keys of a refinement round come in long runs of one digit
+// when they are nearly sorted already (64 same-address LDS atomics serialise): a wave that agrees on a byte adds once.
+template <int BLOCK, int TILE>
+__global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_flat_kernel(const uint8_t* __restrict__ dig, uint64_t n, uint64_t ntiles, unsigned* __restrict__ tile_hist) {
+    constexpr int NW = BLOCK / WAVE;
+    static_assert(TILE % (16 * WAVE) == 0, "whole 16-byte pieces per lane");
+    __shared__ unsigned lh[NW][RADIX];
+    const unsigned wave = threadIdx.x / WAVE, lane = lane_id();
+    const uint64_t t = (uint64_t)blockIdx.x * NW + wave;
+    if (t >= ntiles) return;
+    unsigned* const my = lh[wave];
+#pragma unroll
+    for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
+    xrun_order();
+    const uint64_t g0 = t * TILE, g1 = n - g0 < (uint64_t)TILE ? n : g0 + TILE;
+    uint4 q[TILE / (16 * WAVE)];
+#pragma unroll
+    for (int i = 0; i < TILE / (16 * WAVE); ++i) {
+        const uint64_t e0 = g0 + 16ull * (uint64_t)(i * WAVE + lane);
+        q[i] = e0 < g1 ? *reinterpret_cast<const uint4*>(dig + e0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TILE / (16 * WAVE); ++i) {
+        const uint64_t e0 = g0 + 16ull * (uint64_t)(i * WAVE + lane);
+        const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wave_hist_add(my, (w[k >> 2] >> (8 * (k & 3))) & 255u, e0 + k < g1);
+    }
+    xrun_order();
+    unsigned* row = tile_hist + t * RADIX;
 #pragma unroll
     for (int i = 0; i < RADIX / WAVE; ++i) row[i * WAVE + lane] = my[i * WAVE + lane];
 }
