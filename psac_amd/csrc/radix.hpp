@@ -766,7 +766,7 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_kernel(const uint
 
 // ... and for the flat arrays of the three-kernel passes (engine.hpp: dispatch_pass3): tile t is the TILE bytes from t * TILE on, a wave per tile,
 // the array 16-byte aligned and readable up to the next multiple of 16 beyond n.  The keys of a refinement round come in long runs of one digit
-// when they are nearly sorted already (64 same-address LDS atomics serialise): a wave that agrees on a byte adds once.
+// when they are nearly sorted already (64 same-address LDS atomics serialise): a wave whose 1024 bytes of a step agree adds once.
 template <int BLOCK, int TILE>
 __global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_flat_kernel(const uint8_t* __restrict__ dig, uint64_t n, uint64_t ntiles, unsigned* __restrict__ tile_hist) {
     constexpr int NW = BLOCK / WAVE;
@@ -790,8 +790,31 @@ __global__ __launch_bounds__(BLOCK) void radix_tile_hist_bytes_flat_kernel(const
     for (int i = 0; i < TILE / (16 * WAVE); ++i) {
         const uint64_t e0 = g0 + 16ull * (uint64_t)(i * WAVE + lane);
         const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+        // Keys that are nearly sorted already, or drawn from few distinct values (repeated reads), come in runs of one digit: 64 same-address
+        // LDS adds serialise.  A lane whose 16 bytes agree is `pure`; neighbouring pure lanes of one value form a segment and its first lane adds
+        // once for all of them; the other lanes add once per run of equal bytes.  (Measured on 2^30 bytes of the first sort of repeated reads
+        // with mutations: a plain add per byte 3.3 ms, two ballots and an add per byte -- wave_hist_add -- 2.2, the histogram over the records 1.45.)
+        const bool pure = e0 + 16 <= g1 && w[0] == w[1] && w[1] == w[2] && w[2] == w[3] && ((w[0] >> 8) | (w[0] << 24)) == w[0];
+        const unsigned v = w[0] & 255u;
+        const uint64_t P = __ballot(pure);
+        const unsigned vprev = shfl<unsigned>(v, (int)((lane + WAVE - 1) & (WAVE - 1)));
+        const bool head = pure && (lane == 0 || !((P >> ((lane - 1) & (WAVE - 1))) & 1ull) || vprev != v);
+        const uint64_t H = __ballot(head);
+        if (head) {
+            const uint64_t stop = ((H | ~P) >> lane) >> 1;          // the lanes behind this one that end its segment
+            const unsigned len = stop ? (unsigned)__builtin_ctzll(stop) + 1u : (unsigned)WAVE - lane;
+            atomicAdd(&my[v], 16u * len);
+        }
+        if (!pure && e0 < g1) {
+            unsigned prev = v, cnt = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wave_hist_add(my, (w[k >> 2] >> (8 * (k & 3))) & 255u, e0 + k < g1);
+            for (int k = 0; k < 16; ++k) {
+                const unsigned b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+                if (b != prev) { if (cnt) atomicAdd(&my[prev], cnt); prev = b; cnt = 0; }
+                cnt += e0 + k < g1 ? 1u : 0u;
+            }
+            if (cnt) atomicAdd(&my[prev], cnt);
+        }
     }
     xrun_order();
     unsigned* row = tile_hist + t * RADIX;
