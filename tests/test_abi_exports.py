@@ -61,6 +61,24 @@ def test_strerror_and_no_gpu_behaviour():
         assert lib.psacx_create(C.byref(h), 0, None) == -6      # PSACX_ENOGPU: fails loudly, no CPU fallback
 
 
+def test_cpp_mirror_compiles_as_cxx11_and_fails_loudly_without_a_gpu(tmp_path):
+    # include/suffix_array.hpp (the class contract, suffix_array.hpp:170-228) with every instantiation tests/cpp/test_header.cpp makes --
+    # char / int symbols, 32- and 64-bit indices, more than 256 distinct symbols -- builds warning-free as C++11 against the library;
+    # without a GPU the program ends with the library's error, not with results from somewhere else
+    import subprocess
+    exe = str(tmp_path / "test_header")
+    lib = os.path.join(ROOT, "psac_amd", "lib")
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_header.cpp"),
+           "-L" + lib, "-lpsacx", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+        assert r.returncode != 0 and "cpp header tests passed" not in r.stdout
+        assert "psacx" in (r.stdout + r.stderr)
+
+
 def test_product_does_not_touch_the_oracle():
     bad = []
     for dp, _, fs in os.walk(os.path.join(ROOT, "psac_amd")):
