@@ -810,6 +810,34 @@ def test_refinement_sort_inside_lds(ctx, monkeypatch):
     assert np.array_equal(other.local_SA, got.local_SA) and np.array_equal(other.local_LCP, got.local_LCP)
 
 
+def test_digit_bytes_between_the_three_kernel_sort_passes(ctx, monkeypatch):
+    # engine.hpp: dispatch_pass3 -- the sorts of 64-bit words with 32-bit payloads (the one-stage first sort of a repetitive text over both key
+    # words, the text-order rounds, the list rounds when the LDS sort is switched off) leave the next pass's digit as a byte beside the records
+    # and take their tile histograms from it (radix_tile_hist_bytes_flat_kernel: runs of one digit, the keys of repeated reads, add once per
+    # segment of lanes).  With and without the bytes: the oracle's arrays, the same log of rounds and passes.
+    import psac_amd
+    monkeypatch.setattr(psac_amd._lib, "ENV_KNOBS", False)
+    texts = [inputs.mutated((1 << 23) + 1234, 4096, 5), inputs.tandem((1 << 22) + 77, 1024, inputs.dna(1024, 3)),
+             np.concatenate([inputs.dna(1 << 21, 9), inputs.mutated(1 << 22, 512, 6), inputs.dna(3001, 10)])]
+    def same(x, ref):
+        return np.array_equal(x.local_SA, ref["SA"]) and np.array_equal(x.local_B, ref["ISA"]) and np.array_equal(x.local_LCP, ref["LCP"])
+    try:
+        for text in texts:
+            ctx.configure(reset=0)
+            a, ref = same_as_oracle(ctx, text, bits=64)
+            assert [(h, x, e) for (h, x, e, *_r) in a.rounds] == [(h, x, e) for h, x, e, _ in ref["trace"]]
+            ctx.configure(no_bucket_sort=1)
+            b = run(ctx, text, bits=64)
+            ctx.configure(no_bucket_sort=1, no_digit_bytes=1)
+            c = run(ctx, text, bits=64)
+            assert same(b, ref) and same(c, ref) and b.rounds == c.rounds
+            ctx.configure(reset=0); ctx.configure(no_digit_bytes=1)
+            d = run(ctx, text, bits=64)
+            assert same(d, ref) and d.rounds == a.rounds
+    finally:
+        ctx.configure(reset=0)
+
+
 def test_options_through_the_abi(ctx, monkeypatch):
     # psacx_configure (include/psacx.h): the forms of single stages are options of the context; the library itself never reads the
     # environment (the suite's PSACX_* variables go through the debug shim psacx_configure_from_env, switched off here)
