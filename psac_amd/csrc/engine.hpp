@@ -578,7 +578,7 @@ struct SortScratch {
     unsigned long long* h_summary; // pinned, 4 words
     unsigned long long* d_partials;// per-workgroup key summaries of the producer kernel
     uint8_t* d_dig = nullptr;      // digit bytes between the three-kernel passes of a sort of 64-bit words with 32-bit payloads (dispatch_pass3), or null
-    uint64_t dig_cap = 0;          // ... records it has room for
+    uint64_t dig_cap = 0;          // ... records it has room for (the array 16-byte aligned and readable up to the next multiple of 16 beyond them: the histograms read 16-byte pieces)
 };
 
 constexpr int SORT_TILE_MIN = 2048;   // smallest tile of any scatter configuration
